@@ -1,0 +1,88 @@
+// ORACLE support (test infrastructure, CPU only) -- not part of the shipped engine.
+// extern "C" entry points around the reference's own, unmodified, self-contained FEC classes.
+// This file is the only thing of ours in oracle/_ref/libdvbs2ref.so: the reference sources are compiled
+// where they lie under /root/reference (see oracle/Makefile, target `ref`); nothing is copied.
+// It exists so tests can (a) pin the restatement in oracle/*.cpp and (b) generate tests/golden/*.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "dvbs2/codings/bbframe_ldpc.h"
+#include "dvbs2/codings/bbframe_bch.h"
+#include "dvbs2/codings/bbframe_descramble.h"
+#include "dvbs2/codings/s2_deinterleaver.h"
+
+using namespace dsp::dvbs2;
+
+static dvbs2_code_rate_t to_rate(int r) {
+    // our rate index 0..10 = 1/4 1/3 2/5 1/2 3/5 2/3 3/4 4/5 5/6 8/9 9/10; the reference enum has C7_8 at 9
+    static const dvbs2_code_rate_t map[11] = {C1_4, C1_3, C2_5, C1_2, C3_5, C2_3, C3_4, C4_5, C5_6, C8_9, C9_10};
+    return map[r];
+}
+static dvbs2_framesize_t to_fs(int s) { return s ? FECFRAME_SHORT : FECFRAME_NORMAL; }
+
+extern "C" {
+
+// BBFrameLDPC::decode exactly as the plugin calls it (one frame, lane 0).  bbframe_ldpc.cpp:123-139
+int ref_ldpc_decode(int rate, int shortframe, int8_t* frame, int max_trials) {
+    BBFrameLDPC ldpc(to_fs(shortframe), to_rate(rate));
+    return ldpc.decode(frame, max_trials);
+}
+
+// Decode `nframes` frames one after the other with one decoder object (amortises table set-up).
+void ref_ldpc_decode_many(int rate, int shortframe, int8_t* frames, int nframes, int max_trials, int* trials_out) {
+    BBFrameLDPC ldpc(to_fs(shortframe), to_rate(rate));
+    int n = shortframe ? 16200 : 64800;
+    for (int f = 0; f < nframes; ++f) trials_out[f] = ldpc.decode(frames + (size_t)f * n, max_trials);
+}
+
+// The library used the way its SIMD type was designed for (bbframe_ldpc.h:21-22): 16 frames, one per
+// int8 lane, one decoder call.  Used only as the "library-intended" CPU baseline.
+// frames: 16 x N, frame-major.  Returns the decoder's raw `trials` value (remaining, or -1).
+int ref_ldpc_decode_simd16(int rate, int shortframe, int8_t* frames, int max_trials, int reps) {
+    BBFrameLDPC holder(to_fs(shortframe), to_rate(rate));
+    LDPCDecoder<simd_type, algorithm_type> dec;
+    dec.init(holder.get_instance());
+    int n = shortframe ? 16200 : 64800;
+    int k = holder.dataSize();
+    const int W = simd_type::SIZE;
+    std::vector<simd_type> buf(n);
+    int last = 0;
+    for (int rep = 0; rep < reps; ++rep) {
+        for (int i = 0; i < n; ++i)
+            for (int l = 0; l < W; ++l) reinterpret_cast<int8_t*>(&buf[i])[l] = frames[(size_t)l * n + i];
+        last = dec(buf.data(), buf.data() + k, max_trials, W);
+    }
+    for (int i = 0; i < n; ++i)
+        for (int l = 0; l < W; ++l) frames[(size_t)l * n + i] = reinterpret_cast<int8_t*>(&buf[i])[l];
+    return last;
+}
+
+int ref_simd_width(void) { return simd_type::SIZE; }
+
+int ref_bch_decode(int rate, int shortframe, uint8_t* frame) {
+    BBFrameBCH bch(to_fs(shortframe), to_rate(rate));
+    return bch.decode(frame);
+}
+
+void ref_bch_decode_many(int rate, int shortframe, uint8_t* frames, int nframes, int nbch_bytes, int* corr_out) {
+    BBFrameBCH bch(to_fs(shortframe), to_rate(rate));
+    int nb = nbch_bytes;
+    for (int f = 0; f < nframes; ++f) corr_out[f] = bch.decode(frames + (size_t)f * nb);
+}
+
+void ref_bch_encode(int rate, int shortframe, uint8_t* frame) {
+    BBFrameBCH bch(to_fs(shortframe), to_rate(rate));
+    bch.encode(frame);
+}
+
+void ref_bb_descramble(int rate, int shortframe, uint8_t* frame) {
+    BBFrameDescrambler d(to_fs(shortframe), to_rate(rate));
+    d.work(frame);
+}
+
+void ref_deinterleave(int constel, int rate, int shortframe, int8_t* in, int8_t* out) {
+    S2Deinterleaver d((dvbs2_constellation_t)constel, to_fs(shortframe), to_rate(rate));
+    d.deinterleave(in, out);
+}
+
+}  // extern "C"
