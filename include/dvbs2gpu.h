@@ -1,0 +1,98 @@
+/*
+ * dvbs2gpu -- C ABI of the MI355X (gfx950) DVB-S / DVB-S2 demodulation + FEC engine.
+ *
+ * This is the drop-in boundary for the hot path of cropinghigh/sdrpp-dvbs-demodulator: the SDR++ plugin
+ * shell (src/main.cpp) stays host C++; the bodies of
+ *     int DVBS2Demod::process(int count, const complex_t* in, uint8_t* out)   src/demod/dvbs2/module_dvbs2_demod.cpp:216
+ *     int DVBSDemod::process(int count, const complex_t* in, uint8_t* out)    src/demod/dvbs/module_dvbs_demod.cpp:78
+ * and every stage they call are replaced by the entry points below.  Plain C types only, no exceptions
+ * cross this boundary (the reference throws std::runtime_error for a bad MODCOD, modcod_to_cfg.cpp:11,135;
+ * here that is DVBS2GPU_ERR_MODCOD).
+ *
+ * Pointer convention: arguments named d_* are DEVICE pointers (hipMalloc / torch CUDA tensors); h_* are
+ * host pointers.  `stream` is a hipStream_t passed as void* (NULL = default stream).  Batch entry points
+ * enqueue work on the stream and return without synchronising unless stated otherwise.
+ *
+ * Every function returns 0 (or a non-negative count) on success and a negative DVBS2GPU_ERR_* code on error.
+ */
+#ifndef DVBS2GPU_H
+#define DVBS2GPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVBS2GPU_OK 0
+#define DVBS2GPU_ERR_ARG (-1)      /* null pointer / bad size */
+#define DVBS2GPU_ERR_MODCOD (-2)   /* MODCOD <= 0, >= 29, or short-frame 9/10 (does not exist) */
+#define DVBS2GPU_ERR_HIP (-3)      /* a HIP call failed; dvbs2gpu_last_error() has the text */
+#define DVBS2GPU_ERR_NODEVICE (-4) /* no gfx950 device visible: the engine has no CPU fallback */
+#define DVBS2GPU_ERR_CAPACITY (-5) /* output buffer too small */
+
+/* code rate index used throughout: 0=1/4 1=1/3 2=2/5 3=1/2 4=3/5 5=2/3 6=3/4 7=4/5 8=5/6 9=8/9 10=9/10 */
+
+typedef struct dvbs2gpu_ctx dvbs2gpu_ctx;   /* one per device / host thread; owns tables + workspaces */
+
+const char* dvbs2gpu_version(void);
+const char* dvbs2gpu_last_error(void);
+
+/* Create a context on HIP device `device`.  Fails with DVBS2GPU_ERR_NODEVICE when no GPU is present. */
+int dvbs2gpu_create(int device, dvbs2gpu_ctx** out);
+void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx);
+
+/* Static parameter queries (no GPU needed).  Mirrors get_dvbs2_cfg (modcod_to_cfg.cpp:5-140),
+ * BBFrameBCH::BBFrameBCH (bbframe_bch.cpp:39-161) and the PLFRAME size of dvbs2_pl_sync.cpp:14-31. */
+typedef struct dvbs2gpu_modcod_info {
+    int32_t constellation;   /* 0 QPSK, 1 8PSK, 2 16APSK, 3 32APSK */
+    int32_t bits_per_symbol;
+    int32_t rate;            /* code rate index */
+    int32_t slots;           /* 90-symbol payload slots */
+    int32_t pilot_blocks;
+    int32_t plframe_symbols; /* 90 + 90*slots + 36*pilot_blocks */
+    int32_t ldpc_n, ldpc_k;  /* codeword / information bits (ldpc_k = nbch) */
+    int32_t kbch;            /* BBFRAME bits; output is kbch/8 bytes per frame (DVBS2Demod::getKBCH) */
+    int32_t bch_t;
+    int32_t ldpc_edges;      /* Tanner-graph edges (LINKS_TOTAL) */
+    float g1, g2;
+} dvbs2gpu_modcod_info;
+int dvbs2gpu_modcod_info_get(int modcod, int shortframes, int pilots, dvbs2gpu_modcod_info* out);
+int dvbs2gpu_fec_info_get(int rate, int shortframes, dvbs2gpu_modcod_info* out);
+
+/* ------------------------------------------------------------------ FEC stages (DVB-S2)
+ *
+ * dvbs2gpu_ldpc_decode_batch  replaces  BBFrameLDPC::decode  (bbframe_ldpc.cpp:123-139), one call per
+ * frame in the reference, here `nframes` frames per launch.
+ *   d_llr     [nframes][N] int8, bit 1 <-> negative (module_dvbs2_demod.cpp:360)
+ *   d_hard    [nframes][K/8] hard decisions of the K information bits, MSB first (the repack loop of
+ *             module_dvbs2_demod.cpp:357-360), may be NULL
+ *   d_post    [nframes][N] int8 posteriors in the reference's layout, may be NULL
+ *   d_trials  [nframes] int32: iterations used, or -1 if not converged after max_trials
+ *   force != 0: benchmark mode, no early exit, exactly max_trials iterations; trials = max_trials or -1.
+ */
+int dvbs2gpu_ldpc_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, const int8_t* d_llr, int nframes,
+                               int max_trials, int force, uint8_t* d_hard, int8_t* d_post, int32_t* d_trials, void* stream);
+
+/* replaces BBFrameBCH::decode (bbframe_bch.cpp:380-405).  d_frames [nframes][K/8] corrected in place;
+ * d_corrections [nframes] int32: #bits corrected, 0 clean, -1 uncorrectable (frame left untouched). */
+int dvbs2gpu_bch_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, uint8_t* d_frames, int nframes,
+                              int32_t* d_corrections, void* stream);
+
+/* replaces BBFrameDescrambler::work + the copy of module_dvbs2_demod.cpp:364-366.
+ * d_frames [nframes][K/8] -> d_out [nframes][kbch/8] */
+int dvbs2gpu_bb_descramble_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, const uint8_t* d_frames, int nframes,
+                                 uint8_t* d_out, void* stream);
+
+/* LDPC -> repack -> BCH -> descramble for a batch (module_dvbs2_demod.cpp:349-366, with every frame
+ * LDPC-decoded -- the reference only decodes SIMD lane 0).
+ * d_bbframes [nframes][kbch/8]; d_trials, d_corrections [nframes] (either may be NULL). */
+int dvbs2gpu_fec_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, const int8_t* d_llr, int nframes,
+                              int max_trials, int force, uint8_t* d_bbframes, int32_t* d_trials, int32_t* d_corrections,
+                              void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

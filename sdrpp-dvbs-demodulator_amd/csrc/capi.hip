@@ -1,0 +1,310 @@
+// C ABI of the engine (include/dvbs2gpu.h): context, table upload, workspace management, stage launches.
+// Host-side only logic here; kernels live in *_kernel.hip.  No CPU fallback: without a HIP device
+// dvbs2gpu_create fails with DVBS2GPU_ERR_NODEVICE.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/dvbs2gpu.h"
+#include "s2_params.h"
+#include "ldpc_plan.h"
+#include "kernels.h"
+
+using namespace s2;
+
+static thread_local std::string g_err;
+static int fail_hip(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return DVBS2GPU_ERR_HIP;
+}
+#define HIP_TRY(x)                                        \
+    do {                                                  \
+        hipError_t _e = (x);                              \
+        if (_e != hipSuccess) return fail_hip(_e, #x);    \
+    } while (0)
+
+struct Workspace {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t n) {
+        if (n <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) return fail_hip(e, "hipMalloc(workspace)");
+        bytes = n;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct dvbs2gpu_ctx {
+    int device = 0;
+    int num_cus = 256;
+    std::mutex mtx;
+    std::map<int, LdpcDeviceCode> ldpc;       // by code_index
+    std::map<int, BchDeviceCode> bch;         // by m*100 + t  (GF(2^16) t=12/10/8 share tables of t=12)
+    uint8_t* d_prbs = nullptr;                // BB scrambler sequence, 8100 bytes
+    Workspace ws_msg, ws_hard, ws_syn, ws_misc;
+};
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+static int upload(const std::vector<T>& v, T** dptr) {
+    *dptr = nullptr;
+    size_t n = v.size() * sizeof(T);
+    if (!n) n = sizeof(T);
+    HIP_TRY(hipMalloc((void**)dptr, n));
+    if (!v.empty()) HIP_TRY(hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
+    std::lock_guard<std::mutex> l(ctx->mtx);
+    auto it = ctx->ldpc.find(code_index);
+    if (it == ctx->ldpc.end()) {
+        LdpcPlan P = build_ldpc_plan(code_index);
+        LdpcDeviceCode D;
+        D.code_index = code_index;
+        D.N = P.N; D.K = P.K; D.R = P.R; D.q = P.q; D.max_deg = P.max_deg; D.rec_dwords = P.rec_dwords; D.edges = P.edges;
+        int rc;
+        if ((rc = upload(P.layers, &D.d_layers))) return rc;
+        if ((rc = upload(P.ents, &D.d_ents))) return rc;
+        if ((rc = upload(P.rows, &D.d_rows))) return rc;
+        D.blocks_per_cu = ldpc_blocks_per_cu(P.max_deg, P.N);
+        it = ctx->ldpc.emplace(code_index, D).first;
+    }
+    *out = &it->second;
+    return 0;
+}
+
+// GF(2^m) tables exactly as the reference builds them (galois_field.hh:152-163) + Artin-Schreier map
+// (reed_solomon_error_correction.hh:67-96) + this engine's byte-Horner syndrome tables.
+static int get_bch(dvbs2gpu_ctx* ctx, int m, int t, BchDeviceCode** out) {
+    std::lock_guard<std::mutex> l(ctx->mtx);
+    int key = m * 100 + t;
+    auto it = ctx->bch.find(key);
+    if (it == ctx->bch.end()) {
+        const int Q = 1 << m, N = Q - 1;
+        const uint32_t poly = (m == 16) ? 0x1002Du : 0x402Bu;
+        std::vector<uint16_t> LOG(Q), EXP(Q), IMAP(Q, 0);
+        EXP[N] = 0; LOG[0] = (uint16_t)N;
+        uint32_t a = 1;
+        for (int i = 0; i < N; ++i) {
+            EXP[i] = (uint16_t)a; LOG[a] = (uint16_t)i;
+            a = (a & (uint32_t)(Q >> 1)) ? ((a << 1) ^ poly) : (a << 1);
+            a &= (uint32_t)(Q - 1);
+        }
+        auto vmul = [&](uint32_t x, uint32_t y) -> uint16_t {
+            if (!x || !y) return 0;
+            int e = LOG[x] + LOG[y];
+            if (e >= N) e -= N;
+            return EXP[e];
+        };
+        for (int i = 2; i < N; i += 2) {
+            uint16_t x = (uint16_t)i;
+            uint16_t xxx = (uint16_t)(vmul(x, x) ^ x);
+            if (xxx == (uint16_t)N) continue;
+            IMAP[xxx] = x;
+        }
+        // syndrome tables for the odd roots alpha^(2r+1), r < t
+        std::vector<uint16_t> tab((size_t)t * 768, 0);
+        for (int r = 0; r < t; ++r) {
+            int i = 2 * r + 1;
+            uint16_t* T = &tab[(size_t)r * 768];
+            for (int byte = 0; byte < 256; ++byte) {
+                uint16_t v = 0;
+                for (int b = 0; b < 8; ++b)
+                    if ((byte >> (7 - b)) & 1) v ^= EXP[(int)(((long)i * (7 - b)) % N)];
+                T[byte] = v;
+            }
+            uint16_t c = EXP[(int)(((long)i * 8) % N)];  // alpha^(8i)
+            for (int x = 0; x < 256; ++x) {
+                T[256 + x] = vmul((uint32_t)x, c);
+                uint32_t hi = (uint32_t)x << 8;
+                T[512 + x] = (hi < (uint32_t)Q) ? vmul(hi, c) : 0;
+            }
+        }
+        BchDeviceCode D;
+        D.m = m; D.t = t; D.N = N; D.K_full = N - m * t;
+        int rc;
+        if ((rc = upload(LOG, &D.d_log))) return rc;
+        if ((rc = upload(EXP, &D.d_exp))) return rc;
+        if ((rc = upload(IMAP, &D.d_imap))) return rc;
+        if ((rc = upload(tab, &D.d_syn_tab))) return rc;
+        it = ctx->bch.emplace(key, D).first;
+    }
+    *out = &it->second;
+    return 0;
+}
+
+static int get_prbs(dvbs2gpu_ctx* ctx) {
+    std::lock_guard<std::mutex> l(ctx->mtx);
+    if (ctx->d_prbs) return 0;
+    // PRBS 1 + x^14 + x^15, seed 0x4A80 as the reference loads it (bbframe_descramble.cpp:122-136)
+    std::vector<uint8_t> seq(64800 / 8, 0);
+    int sr = 0x4A80;
+    for (int i = 0; i < 64800; i++) {
+        int b = ((sr) ^ (sr >> 1)) & 1;
+        seq[i / 8] |= (uint8_t)(b << (7 - (i % 8)));
+        sr >>= 1;
+        if (b) sr |= 0x4000;
+    }
+    return upload(seq, &ctx->d_prbs);
+}
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* dvbs2gpu_version(void) { return "dvbs2gpu 0.1 (gfx950)"; }
+const char* dvbs2gpu_last_error(void) { return g_err.c_str(); }
+
+int dvbs2gpu_create(int device, dvbs2gpu_ctx** out) {
+    if (!out) return DVBS2GPU_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_err = "no HIP device visible (this engine has no CPU fallback)";
+        return DVBS2GPU_ERR_NODEVICE;
+    }
+    if (device < 0 || device >= n) { g_err = "bad device index"; return DVBS2GPU_ERR_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    dvbs2gpu_ctx* c = new dvbs2gpu_ctx();
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = c;
+    return DVBS2GPU_OK;
+}
+
+void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : ctx->ldpc) {
+        (void)hipFree(kv.second.d_layers); (void)hipFree(kv.second.d_ents); (void)hipFree(kv.second.d_rows);
+    }
+    for (auto& kv : ctx->bch) {
+        (void)hipFree(kv.second.d_log); (void)hipFree(kv.second.d_exp); (void)hipFree(kv.second.d_imap); (void)hipFree(kv.second.d_syn_tab);
+    }
+    if (ctx->d_prbs) (void)hipFree(ctx->d_prbs);
+    ctx->ws_msg.release(); ctx->ws_hard.release(); ctx->ws_syn.release(); ctx->ws_misc.release();
+    delete ctx;
+}
+
+static void fill_info(const ModcodParams& p, dvbs2gpu_modcod_info* o) {
+    o->constellation = p.constel; o->bits_per_symbol = p.bits; o->rate = p.rate; o->slots = p.slots;
+    o->pilot_blocks = p.pilot_blocks; o->plframe_symbols = p.plframe; o->ldpc_n = p.fec.N; o->ldpc_k = p.fec.K;
+    o->kbch = p.fec.kbch; o->bch_t = p.fec.bch_t; o->ldpc_edges = QC_CODES[p.fec.code_index].edges;
+    o->g1 = p.g1; o->g2 = p.g2;
+}
+
+int dvbs2gpu_modcod_info_get(int modcod, int shortframes, int pilots, dvbs2gpu_modcod_info* out) {
+    if (!out) return DVBS2GPU_ERR_ARG;
+    ModcodParams p;
+    if (!modcod_params(modcod, shortframes, pilots, &p)) { g_err = "unsupported MODCOD"; return DVBS2GPU_ERR_MODCOD; }
+    fill_info(p, out);
+    return DVBS2GPU_OK;
+}
+
+int dvbs2gpu_fec_info_get(int rate, int shortframes, dvbs2gpu_modcod_info* out) {
+    if (!out) return DVBS2GPU_ERR_ARG;
+    FecParams f;
+    if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
+    memset(out, 0, sizeof(*out));
+    out->constellation = -1; out->rate = rate; out->ldpc_n = f.N; out->ldpc_k = f.K; out->kbch = f.kbch; out->bch_t = f.bch_t;
+    out->ldpc_edges = QC_CODES[f.code_index].edges;
+    return DVBS2GPU_OK;
+}
+
+static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, int nframes, int max_trials, int force,
+                    uint8_t* d_hard, int hard_stride, int8_t* d_post, int32_t* d_trials, hipStream_t st) {
+    LdpcDeviceCode* C;
+    int rc = get_ldpc(ctx, f.code_index, &C);
+    if (rc) return rc;
+    int grid = ctx->num_cus * C->blocks_per_cu;
+    if (grid > nframes) grid = nframes;
+    size_t need = (size_t)grid * C->R * C->rec_dwords * sizeof(uint32_t);
+    if ((rc = ctx->ws_msg.ensure(need))) return rc;
+    if (!d_trials) {
+        if ((rc = ctx->ws_misc.ensure((size_t)nframes * 2 * sizeof(int32_t)))) return rc;
+        d_trials = (int32_t*)ctx->ws_misc.p;
+    }
+    if (!d_hard) {
+        if ((rc = ctx->ws_hard.ensure((size_t)nframes * (f.K / 8)))) return rc;
+        d_hard = (uint8_t*)ctx->ws_hard.p; hard_stride = f.K / 8;
+    }
+    HIP_TRY(ldpc_decode_launch(*C, d_llr, nframes, max_trials, force, d_hard, hard_stride, d_post, d_trials,
+                               (uint32_t*)ctx->ws_msg.p, grid, st));
+    return 0;
+}
+
+int dvbs2gpu_ldpc_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, const int8_t* d_llr, int nframes, int max_trials,
+                               int force, uint8_t* d_hard, int8_t* d_post, int32_t* d_trials, void* stream) {
+    if (!ctx || !d_llr || nframes < 0 || max_trials < 0) return DVBS2GPU_ERR_ARG;
+    FecParams f;
+    if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
+    if (nframes == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return ldpc_run(ctx, f, d_llr, nframes, max_trials, force, d_hard, f.K / 8, d_post, d_trials, (hipStream_t)stream);
+}
+
+static int bch_run(dvbs2gpu_ctx* ctx, const FecParams& f, uint8_t* d_frames, int nframes, int32_t* d_corr, hipStream_t st) {
+    BchDeviceCode* B;
+    // GF(2^16): t = 8 and 10 use the first 2t syndromes of the same field; tables depend on (m, t) only via t rows
+    int rc = get_bch(ctx, f.bch_m, f.bch_t, &B);
+    if (rc) return rc;
+    if ((rc = ctx->ws_syn.ensure((size_t)nframes * 32 * sizeof(uint16_t)))) return rc;
+    uint16_t* syn = (uint16_t*)ctx->ws_syn.p;
+    HIP_TRY(bch_syndromes_launch(*B, d_frames, f.K / 8, f.K, nframes, syn, st));
+    HIP_TRY(bch_correct_launch(*B, d_frames, f.K / 8, f.K, f.kbch, nframes, syn, d_corr, st));
+    return 0;
+}
+
+int dvbs2gpu_bch_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, uint8_t* d_frames, int nframes, int32_t* d_corrections,
+                              void* stream) {
+    if (!ctx || !d_frames || nframes < 0) return DVBS2GPU_ERR_ARG;
+    FecParams f;
+    if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
+    if (nframes == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return bch_run(ctx, f, d_frames, nframes, d_corrections, (hipStream_t)stream);
+}
+
+int dvbs2gpu_bb_descramble_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, const uint8_t* d_frames, int nframes, uint8_t* d_out,
+                                 void* stream) {
+    if (!ctx || !d_frames || !d_out || nframes < 0) return DVBS2GPU_ERR_ARG;
+    FecParams f;
+    if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
+    if (nframes == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = get_prbs(ctx);
+    if (rc) return rc;
+    HIP_TRY(bb_descramble_launch(d_frames, f.K / 8, ctx->d_prbs, f.kbch / 8, nframes, d_out, (hipStream_t)stream));
+    return 0;
+}
+
+int dvbs2gpu_fec_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, const int8_t* d_llr, int nframes, int max_trials,
+                              int force, uint8_t* d_bbframes, int32_t* d_trials, int32_t* d_corrections, void* stream) {
+    if (!ctx || !d_llr || !d_bbframes || nframes < 0 || max_trials < 0) return DVBS2GPU_ERR_ARG;
+    FecParams f;
+    if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
+    if (nframes == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = ctx->ws_hard.ensure((size_t)nframes * (f.K / 8)))) return rc;
+    uint8_t* hard = (uint8_t*)ctx->ws_hard.p;
+    if ((rc = ldpc_run(ctx, f, d_llr, nframes, max_trials, force, hard, f.K / 8, nullptr, d_trials, st))) return rc;
+    if ((rc = bch_run(ctx, f, hard, nframes, d_corrections, st))) return rc;
+    if ((rc = get_prbs(ctx))) return rc;
+    HIP_TRY(bb_descramble_launch(hard, f.K / 8, ctx->d_prbs, f.kbch / 8, nframes, d_bbframes, st));
+    return 0;
+}
+
+}  // extern "C"
