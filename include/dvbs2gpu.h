@@ -75,6 +75,11 @@ int dvbs2gpu_fec_info_get(int rate, int shortframes, dvbs2gpu_modcod_info* out);
 int dvbs2gpu_ldpc_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, const int8_t* d_llr, int nframes,
                                int max_trials, int force, uint8_t* d_hard, int8_t* d_post, int32_t* d_trials, void* stream);
 
+/* Introspection of the decoder plan of one code (for DESIGN.md / bench reporting):
+ * out8 = {layers q, max row degree, message record dwords, sum of layer depths, resident workgroups per CU,
+ *         CUs, Tanner edges, layers with intra-layer shared bits}. */
+int dvbs2gpu_ldpc_plan_info(dvbs2gpu_ctx* ctx, int rate, int shortframes, int32_t* out8);
+
 /* replaces BBFrameBCH::decode (bbframe_bch.cpp:380-405).  d_frames [nframes][K/8] corrected in place;
  * d_corrections [nframes] int32: #bits corrected, 0 clean, -1 uncorrectable (frame left untouched). */
 int dvbs2gpu_bch_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, uint8_t* d_frames, int nframes,

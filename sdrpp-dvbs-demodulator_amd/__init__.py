@@ -41,6 +41,7 @@ PROTOTYPES = {
     'dvbs2gpu_destroy': (None, [_vp]),
     'dvbs2gpu_modcod_info_get': (_i, [_i, _i, _i, C.POINTER(ModcodInfo)]),
     'dvbs2gpu_fec_info_get': (_i, [_i, _i, C.POINTER(ModcodInfo)]),
+    'dvbs2gpu_ldpc_plan_info': (_i, [_vp, _i, _i, C.POINTER(C.c_int32)]),
     'dvbs2gpu_ldpc_decode_batch': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'dvbs2gpu_bch_decode_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
     'dvbs2gpu_bb_descramble_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
@@ -118,6 +119,12 @@ class Engine:
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def ldpc_plan_info(self, rate, shortframes=False):
+        out = (C.c_int32 * 8)()
+        self._check(self.lib.dvbs2gpu_ldpc_plan_info(self.h, int(rate), int(bool(shortframes)), out))
+        keys = ['layers', 'max_deg', 'rec_dwords', 'sum_depth', 'blocks_per_cu', 'cus', 'edges', 'conflict_layers']
+        return dict(zip(keys, list(out)))
 
     # ---- FEC stages --------------------------------------------------------------------------------
     def ldpc_decode(self, llr, rate, shortframes=False, max_trials=25, force=False, want_post=False):

@@ -14,6 +14,7 @@
 #include "kernels.h"
 
 using namespace s2;
+namespace s2 { extern unsigned long long* g_ldpc_prof; }
 
 static thread_local std::string g_err;
 static int fail_hip(hipError_t e, const char* what) {
@@ -69,12 +70,12 @@ static int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
         LdpcPlan P = build_ldpc_plan(code_index);
         LdpcDeviceCode D;
         D.code_index = code_index;
-        D.N = P.N; D.K = P.K; D.R = P.R; D.q = P.q; D.max_deg = P.max_deg; D.rec_dwords = P.rec_dwords; D.edges = P.edges;
+        D.N = P.N; D.K = P.K; D.R = P.R; D.q = P.q; D.max_deg = P.max_deg; D.irregular = (P.min_deg != P.max_deg); D.rec_dwords = P.rec_dwords; D.edges = P.edges;
         int rc;
         if ((rc = upload(P.layers, &D.d_layers))) return rc;
         if ((rc = upload(P.ents, &D.d_ents))) return rc;
         if ((rc = upload(P.rows, &D.d_rows))) return rc;
-        D.blocks_per_cu = ldpc_blocks_per_cu(P.max_deg, P.N);
+        D.blocks_per_cu = ldpc_blocks_per_cu(P.max_deg, D.irregular, P.N);
         it = ctx->ldpc.emplace(code_index, D).first;
     }
     *out = &it->second;
@@ -197,6 +198,9 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
     delete ctx;
 }
 
+// development aid: phase-cycle buffer (96 x u64, device memory) used by -DLDPC_PROF builds; not part of the public ABI
+void dvbs2gpu_debug_set_prof(void* d_buf) { s2::g_ldpc_prof = (unsigned long long*)d_buf; }
+
 static void fill_info(const ModcodParams& p, dvbs2gpu_modcod_info* o) {
     o->constellation = p.constel; o->bits_per_symbol = p.bits; o->rate = p.rate; o->slots = p.slots;
     o->pilot_blocks = p.pilot_blocks; o->plframe_symbols = p.plframe; o->ldpc_n = p.fec.N; o->ldpc_k = p.fec.K;
@@ -244,12 +248,27 @@ static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, 
     return 0;
 }
 
+int dvbs2gpu_ldpc_plan_info(dvbs2gpu_ctx* ctx, int rate, int shortframes, int32_t* out8) {
+    if (!ctx || !out8) return DVBS2GPU_ERR_ARG;
+    FecParams f;
+    if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    LdpcDeviceCode* C;
+    int rc = get_ldpc(ctx, f.code_index, &C);
+    if (rc) return rc;
+    LdpcPlan P = build_ldpc_plan(f.code_index);
+    out8[0] = C->q; out8[1] = C->max_deg; out8[2] = C->rec_dwords; out8[3] = P.sum_depth;
+    out8[4] = C->blocks_per_cu; out8[5] = ctx->num_cus; out8[6] = C->edges; out8[7] = P.conflict_layers;
+    return 0;
+}
+
 int dvbs2gpu_ldpc_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, const int8_t* d_llr, int nframes, int max_trials,
                                int force, uint8_t* d_hard, int8_t* d_post, int32_t* d_trials, void* stream) {
-    if (!ctx || !d_llr || nframes < 0 || max_trials < 0) return DVBS2GPU_ERR_ARG;
+    if (!ctx || nframes < 0 || max_trials < 0) return DVBS2GPU_ERR_ARG;
     FecParams f;
     if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
     if (nframes == 0) return 0;
+    if (!d_llr) return DVBS2GPU_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     return ldpc_run(ctx, f, d_llr, nframes, max_trials, force, d_hard, f.K / 8, d_post, d_trials, (hipStream_t)stream);
 }
@@ -268,20 +287,22 @@ static int bch_run(dvbs2gpu_ctx* ctx, const FecParams& f, uint8_t* d_frames, int
 
 int dvbs2gpu_bch_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, uint8_t* d_frames, int nframes, int32_t* d_corrections,
                               void* stream) {
-    if (!ctx || !d_frames || nframes < 0) return DVBS2GPU_ERR_ARG;
+    if (!ctx || nframes < 0) return DVBS2GPU_ERR_ARG;
     FecParams f;
     if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
     if (nframes == 0) return 0;
+    if (!d_frames) return DVBS2GPU_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     return bch_run(ctx, f, d_frames, nframes, d_corrections, (hipStream_t)stream);
 }
 
 int dvbs2gpu_bb_descramble_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, const uint8_t* d_frames, int nframes, uint8_t* d_out,
                                  void* stream) {
-    if (!ctx || !d_frames || !d_out || nframes < 0) return DVBS2GPU_ERR_ARG;
+    if (!ctx || nframes < 0) return DVBS2GPU_ERR_ARG;
     FecParams f;
     if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
     if (nframes == 0) return 0;
+    if (!d_frames || !d_out) return DVBS2GPU_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = get_prbs(ctx);
     if (rc) return rc;
@@ -291,10 +312,11 @@ int dvbs2gpu_bb_descramble_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, c
 
 int dvbs2gpu_fec_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, const int8_t* d_llr, int nframes, int max_trials,
                               int force, uint8_t* d_bbframes, int32_t* d_trials, int32_t* d_corrections, void* stream) {
-    if (!ctx || !d_llr || !d_bbframes || nframes < 0 || max_trials < 0) return DVBS2GPU_ERR_ARG;
+    if (!ctx || nframes < 0 || max_trials < 0) return DVBS2GPU_ERR_ARG;
     FecParams f;
     if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
     if (nframes == 0) return 0;
+    if (!d_llr || !d_bbframes) return DVBS2GPU_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     int rc;

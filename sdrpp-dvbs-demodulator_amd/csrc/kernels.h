@@ -6,20 +6,18 @@
 namespace s2 {
 
 struct LdpcLayerDesc;
-struct LdpcLinkEnt;
-struct LdpcRowInfo;
 
 // Device-resident plan of one LDPC code (built from ldpc_plan.h by the context, cached per code).
 struct LdpcDeviceCode {
     int code_index = -1;
-    int N = 0, K = 0, R = 0, q = 0, max_deg = 0, rec_dwords = 0, edges = 0;
+    int N = 0, K = 0, R = 0, q = 0, max_deg = 0, irregular = 0, rec_dwords = 0, edges = 0;
     LdpcLayerDesc* d_layers = nullptr;
-    LdpcLinkEnt* d_ents = nullptr;
-    LdpcRowInfo* d_rows = nullptr;
+    uint32_t* d_ents = nullptr;
+    uint32_t* d_rows = nullptr;
     int blocks_per_cu = 1;
 };
 
-int ldpc_blocks_per_cu(int max_deg, int N);
+int ldpc_blocks_per_cu(int max_deg, int irregular, int N);
 hipError_t ldpc_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nframes, int max_trials, int force,
                               uint8_t* hard, int hard_stride, int8_t* post, int32_t* trials, uint32_t* msg_ws, int grid,
                               hipStream_t stream);

@@ -25,10 +25,9 @@
 
 namespace s2 {
 
+// Code tables are separate `const T* __restrict__` kernel parameters (not struct members) so that hipcc can
+// prove them invariant and fetch the wave-uniform layer/link descriptors with scalar loads (s_load_*).
 struct LdpcKernelArgs {
-    const LdpcLayerDesc* layers;
-    const LdpcLinkEnt* ents;
-    const LdpcRowInfo* rows;
     const int8_t* llr;     // [nframes][N]
     uint8_t* hard;         // [nframes][hard_stride] packed hard decisions of bits [0,K), MSB first
     int8_t* post;          // optional [nframes][N] posteriors (reference layout), may be null
@@ -37,7 +36,16 @@ struct LdpcKernelArgs {
     int nframes, N, K, R, q;
     int max_trials, force;
     int hard_stride;
+    unsigned long long* prof;   // development aid (-DLDPC_PROF builds only): per-wave phase cycle sums of workgroup 0
 };
+
+#ifdef LDPC_PROF
+#define PROF_T(var) unsigned long long var = clock64()
+#define PROF_ADD(slot, t0, t1) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) A.prof[(threadIdx.x >> 6) * 16 + (slot)] += (t1) - (t0); } while (0)
+#else
+#define PROF_T(var) do { } while (0)
+#define PROF_ADD(slot, t0, t1) do { } while (0)
+#endif
 
 __device__ __forceinline__ int med3i(int a, int lo, int hi) { return min(max(a, lo), hi); }  // folds to v_med3_i32 for lo <= hi
 __device__ __forceinline__ int clamp8(int v) { return med3i(v, -128, 127); }
@@ -46,6 +54,14 @@ __device__ __forceinline__ int clamp8(int v) { return med3i(v, -128, 127); }
 __device__ __forceinline__ int mag_of(int in) {
     int a = in < 0 ? -in : in;
     return med3i(a - 1, 0, 126);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() would also drain vmcnt, i.e. wait
+// for the in-flight message-record prefetch and store of every layer (cdna guide, "Pipelining across barriers").
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 template <int REC>
@@ -88,116 +104,114 @@ __device__ __forceinline__ int new_msg(int in, int mg, int min0, int min1, int s
     return med3i(v, -32, 31);
 }
 
-// One sweep step for one layer.  CONF = layer has intra-layer shared bits.
-template <int MAXDEG, int REC, bool CONF>
-__device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const LdpcKernelArgs& A, const LdpcLayerDesc L, int layer,
-                                             int j, bool active, const uint32_t (&rec_in)[REC], uint32_t* __restrict__ rec_out_ptr) {
+// byte address of link `ent` for row j: 360*r + (j + sp) mod 360
+__device__ __forceinline__ int link_addr(uint32_t ent, int j) {
+    int t = j + (int)(ent & 0xffffu);
+    t = (int)min((uint32_t)t, (uint32_t)(t - 360));
+    return t + 360 * (int)(ent >> 16);
+}
+
+#define ROW_ACCUM(v, m)                     \
+    do {                                    \
+        min1 = min(min1, max(min0, (m)));   \
+        min0 = min(min0, (m));              \
+        sx ^= (v);                          \
+    } while (0)
+
+// One sweep step for one layer.  CONF = layer has intra-layer shared bits (links 0..nc-1), IRREG = the
+// code has layers of different degree (short tables C1, C4, C7, C8, C9).
+template <int MAXDEG, int REC, bool CONF, bool IRREG>
+__device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const LdpcKernelArgs& A, const uint32_t* __restrict__ ents,
+                                             const LdpcLayerDesc L, uint32_t rowword, int layer, int j, bool active,
+                                             const uint32_t (&rec_in)[REC], uint32_t* __restrict__ rec_out_ptr) {
     constexpr int NL = MAXDEG + 2;
+    constexpr int MAXC = MAXDEG < LDPC_MAX_CONFLICT_LINKS ? MAXDEG : LDPC_MAX_CONFLICT_LINKS;
     int in[NL], mg[NL];
     int addr[MAXDEG];
-    const int deg = L.deg;
-    const LdpcLinkEnt* __restrict__ ents = A.ents + L.ent_off;
-    uint32_t late = 0, early = 0, level = 1;
-    if constexpr (CONF) {
-        if (active) {
-            LdpcRowInfo ri = A.rows[L.row_off + j];
-            late = ri.late; early = ri.early; level = ri.level;
-        }
-    }
+    const int deg = IRREG ? (int)L.deg : MAXDEG;
+    const int nc = CONF ? (int)(L.depth_nc >> 16) : 0;
+    const uint32_t level = rowword & 0xffu, late = (rowword >> 8) & 0xfffu, early = rowword >> 20;
     int min0 = 255, min1 = 255, sx = 0;
     const int own = A.K + 360 * layer + j;
     const bool has_prev = (layer | j) != 0;
     const int prev = layer ? own - 360 : A.K + 360 * (A.q - 1) + j - 1;
+    PROF_T(t_a);
     if (active) {
 #pragma unroll
         for (int k = 0; k < MAXDEG; ++k) {
-            if (k < deg) {
-                LdpcLinkEnt e = ents[k];
-                int t = j + (int)e.sb;
-                if (t >= (int)e.thr) t -= 360;
-                addr[k] = t;
-                int x = post[t];
+            if (!IRREG || k < deg) {
+                addr[k] = link_addr(ents[k], j);
+                int x = post[addr[k]];
                 int v = clamp8(x - rec_byte<REC>(rec_in, k));
                 int m = mag_of(v);
                 if constexpr (CONF) {
-                    if ((late >> k) & 1) { v = 0; m = 255; }  // joins the totals at its level
+                    if (k < MAXC && ((late >> k) & 1)) { v = 0; m = 255; }  // joins the totals at its level
                 }
                 in[k] = v; mg[k] = m;
-                min1 = min(min1, max(min0, m));
-                min0 = min(min0, m);
-                sx ^= v;
+                ROW_ACCUM(v, m);
             } else {
                 in[k] = 0; mg[k] = 255; addr[k] = 0;
             }
         }
         {
-            int x = post[own];
-            int v = clamp8(x - rec_byte<REC>(rec_in, MAXDEG));
+            int v = clamp8((int)post[own] - rec_byte<REC>(rec_in, MAXDEG));
             int m = mag_of(v);
             in[MAXDEG] = v; mg[MAXDEG] = m;
-            min1 = min(min1, max(min0, m));
-            min0 = min(min0, m);
-            sx ^= v;
+            ROW_ACCUM(v, m);
         }
         if (has_prev) {
-            int x = post[prev];
-            int v = clamp8(x - rec_byte<REC>(rec_in, MAXDEG + 1));
+            int v = clamp8((int)post[prev] - rec_byte<REC>(rec_in, MAXDEG + 1));
             int m = mag_of(v);
             in[MAXDEG + 1] = v; mg[MAXDEG + 1] = m;
-            min1 = min(min1, max(min0, m));
-            min0 = min(min0, m);
-            sx ^= v;
+            ROW_ACCUM(v, m);
         } else {
             in[MAXDEG + 1] = 0; mg[MAXDEG + 1] = 255;
         }
     }
+    PROF_T(t_b);
+    PROF_ADD(CONF ? 4 : 0, t_a, t_b);
     if constexpr (CONF) {
-        // level 1 rows have complete totals already: publish the links a later row waits for
-        const int depth = L.depth;
+        // rows of level 1 have complete totals: they publish the links a later row waits for right away
+        const int depth = (int)(L.depth_nc & 0xffffu);
         for (int lvl = 1; lvl <= depth; ++lvl) {
-            if (lvl > 1) __syncthreads();
+            if (lvl > 1) lds_barrier();
             if (active && level == (uint32_t)lvl) {
                 if (lvl > 1) {
 #pragma unroll
-                    for (int k = 0; k < MAXDEG; ++k) {
-                        if ((L.cmask >> k) & 1) {
-                            if ((late >> k) & 1) {
-                                int x = post[addr[k]];
-                                int v = clamp8(x - rec_byte<REC>(rec_in, k));
-                                int m = mag_of(v);
-                                in[k] = v; mg[k] = m;
-                                min1 = min(min1, max(min0, m));
-                                min0 = min(min0, m);
-                                sx ^= v;
-                            }
+                    for (int k = 0; k < MAXC; ++k) {
+                        if (k < nc && ((late >> k) & 1)) {
+                            int v = clamp8((int)post[addr[k]] - rec_byte<REC>(rec_in, k));
+                            int m = mag_of(v);
+                            in[k] = v; mg[k] = m;
+                            ROW_ACCUM(v, m);
                         }
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < MAXDEG; ++k) {
-                    if ((L.cmask >> k) & 1) {
-                        if ((early >> k) & 1) {
-                            int nm = new_msg(in[k], mg[k], min0, min1, sx);
-                            post[addr[k]] = (int8_t)clamp8(in[k] + nm);
-                        }
+                for (int k = 0; k < MAXC; ++k) {
+                    if (k < nc && ((early >> k) & 1)) {
+                        int nm = new_msg(in[k], mg[k], min0, min1, sx);
+                        post[addr[k]] = (int8_t)clamp8(in[k] + nm);
                     }
                 }
             }
         }
     }
+    PROF_T(t_c);
+    PROF_ADD(CONF ? 5 : 1, t_b, t_c);
     if (active) {
         uint32_t rec_out[REC];
 #pragma unroll
         for (int w = 0; w < REC; ++w) rec_out[w] = 0;
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
-            bool present = (k < MAXDEG) ? (k < deg) : (k == MAXDEG ? true : has_prev);
+            bool present = (k < MAXDEG) ? (!IRREG || k < deg) : (k == MAXDEG ? true : has_prev);
             if (present) {
                 int nm = new_msg(in[k], mg[k], min0, min1, sx);
                 rec_out[k >> 2] |= ((uint32_t)nm & 0xffu) << ((k & 3) * 8);
                 bool wr = true;
                 if constexpr (CONF) {
-                    if (k < MAXDEG) wr = !((early >> k) & 1);
+                    if (k < MAXC) wr = !((early >> k) & 1);
                 }
                 if (wr) {
                     int a = (k < MAXDEG) ? addr[k] : (k == MAXDEG ? own : prev);
@@ -207,15 +221,19 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
         }
         rec_store<REC>(rec_out, rec_out_ptr);
     }
+    PROF_T(t_d);
+    PROF_ADD(CONF ? 6 : 2, t_c, t_d);
 }
 
 // LDPCDecoder::bad (layered_decoder.hh:28-45) for the rows owned by lane j; true if any is unsatisfied.
-template <int MAXDEG>
-__device__ __forceinline__ bool rows_bad(const int8_t* __restrict__ post, const LdpcKernelArgs& A, int j) {
+template <int MAXDEG, bool IRREG>
+__device__ __forceinline__ bool rows_bad(const int8_t* __restrict__ post, const LdpcKernelArgs& A, const LdpcLayerDesc* __restrict__ layers,
+                                         const uint32_t* __restrict__ ents_all, int j) {
     int badacc = 0;
     for (int layer = 0; layer < A.q; ++layer) {
-        const LdpcLayerDesc L = A.layers[layer];
-        const LdpcLinkEnt* __restrict__ ents = A.ents + L.ent_off;
+        const LdpcLayerDesc L = layers[layer];
+        const uint32_t* __restrict__ ents = ents_all + L.ent_off;
+        const int deg = IRREG ? (int)L.deg : MAXDEG;
         const int own = A.K + 360 * layer + j;
         int x = post[own];
         int sx = x;
@@ -227,11 +245,8 @@ __device__ __forceinline__ bool rows_bad(const int8_t* __restrict__ post, const 
         }
 #pragma unroll
         for (int k = 0; k < MAXDEG; ++k) {
-            if (k < (int)L.deg) {
-                LdpcLinkEnt e = ents[k];
-                int t = j + (int)e.sb;
-                if (t >= (int)e.thr) t -= 360;
-                x = post[t];
+            if (!IRREG || k < deg) {
+                x = post[link_addr(ents[k], j)];
                 sx ^= x; zero |= (x == 0);
             }
         }
@@ -240,9 +255,11 @@ __device__ __forceinline__ bool rows_bad(const int8_t* __restrict__ post, const 
     return badacc != 0;
 }
 
-template <int MAXDEG, int REC>
-__global__ __launch_bounds__(384) void ldpc_decode_kernel(LdpcKernelArgs A) {
+template <int MAXDEG, int REC, bool IRREG>
+__global__ __launch_bounds__(384) void ldpc_decode_kernel(const LdpcLayerDesc* __restrict__ layers, const uint32_t* __restrict__ ents,
+                                                          const uint32_t* __restrict__ rows, LdpcKernelArgs A) {
     extern __shared__ __attribute__((aligned(16))) int8_t post[];
+    __shared__ int s_flag[8];
     const int j = threadIdx.x;
     const bool active = j < 360;
     const int N = A.N, K = A.K, R = A.R, q = A.q;
@@ -257,33 +274,52 @@ __global__ __launch_bounds__(384) void ldpc_decode_kernel(LdpcKernelArgs A) {
             int jj = c / q, i = c - jj * q;
             post[K + 360 * i + jj] = src[K + c];
         }
-        __syncthreads();
+        lds_barrier();
 
         int it = 0, ret = 0;
         while (true) {
             if (!A.force || it == A.max_trials) {
-                bool bad = active ? rows_bad<MAXDEG>(post, A, j) : false;
-                int any = __syncthreads_or(bad ? 1 : 0);
+                bool bad = active ? rows_bad<MAXDEG, IRREG>(post, A, layers, ents, j) : false;
+                // workgroup OR of `bad`
+                unsigned long long b = __ballot(bad);
+                if ((j & 63) == 0) s_flag[j >> 6] = (b != 0);
+                lds_barrier();
+                int any = s_flag[0] | s_flag[1] | s_flag[2] | s_flag[3] | s_flag[4] | s_flag[5];
+                lds_barrier();
                 if (A.force) { ret = any ? -1 : A.max_trials; break; }
                 if (!any) { ret = it; break; }
                 if (it == A.max_trials) { ret = -1; break; }
             }
-            // ---- one layered sweep (LDPCDecoder::update)
+            // ---- one layered sweep (LDPCDecoder::update), descriptors / records / row words prefetched one layer ahead
+            const bool first = (it == 0);
             uint32_t rec_next[REC];
 #pragma unroll
             for (int w = 0; w < REC; ++w) rec_next[w] = 0;
-            const bool first = (it == 0);
             if (!first && active) rec_load<REC>(rec_next, msg + (size_t)j * REC);
+            LdpcLayerDesc Lnext = layers[0];
+            uint32_t rw_next = 1;
+            if ((Lnext.depth_nc & 0xffffu) > 1 && active) rw_next = rows[Lnext.row_off + j];
             for (int layer = 0; layer < q; ++layer) {
+                PROF_T(t_g);
                 uint32_t rec[REC];
 #pragma unroll
                 for (int w = 0; w < REC; ++w) rec[w] = rec_next[w];
+                const LdpcLayerDesc L = Lnext;
+                const uint32_t rw = rw_next;
                 uint32_t* rp = msg + ((size_t)layer * 360 + j) * REC;
-                if (!first && active && layer + 1 < q) rec_load<REC>(rec_next, rp + 360 * REC);
-                const LdpcLayerDesc L = A.layers[layer];
-                if (L.depth == 1) layer_update<MAXDEG, REC, false>(post, A, L, layer, j, active, rec, rp);
-                else layer_update<MAXDEG, REC, true>(post, A, L, layer, j, active, rec, rp);
-                __syncthreads();
+                if (layer + 1 < q) {
+                    Lnext = layers[layer + 1];
+                    if (!first && active) rec_load<REC>(rec_next, rp + 360 * REC);
+                    if ((Lnext.depth_nc & 0xffffu) > 1 && active) rw_next = rows[Lnext.row_off + j];
+                }
+                PROF_T(t_h);
+                PROF_ADD(7, t_g, t_h);
+                if ((L.depth_nc & 0xffffu) == 1) layer_update<MAXDEG, REC, false, IRREG>(post, A, ents + L.ent_off, L, 1u, layer, j, active, rec, rp);
+                else layer_update<MAXDEG, REC, true, IRREG>(post, A, ents + L.ent_off, L, rw, layer, j, active, rec, rp);
+                PROF_T(t_e);
+                lds_barrier();
+                PROF_T(t_f);
+                PROF_ADD(3, t_e, t_f);
             }
             ++it;
         }
@@ -314,63 +350,74 @@ __global__ __launch_bounds__(384) void ldpc_decode_kernel(LdpcKernelArgs A) {
                 dst[K + c] = post[K + 360 * i + jj];
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
-template <int MAXDEG, int REC>
-static hipError_t launch_ldpc(const LdpcKernelArgs& A, int grid, hipStream_t stream) {
+template <int MAXDEG, int REC, bool IRREG>
+static hipError_t launch_ldpc(const LdpcDeviceCode& C, const LdpcKernelArgs& A, int grid, hipStream_t stream) {
     size_t lds = (size_t)((A.N + 15) / 16) * 16;
-    auto kern = ldpc_decode_kernel<MAXDEG, REC>;
+    auto kern = ldpc_decode_kernel<MAXDEG, REC, IRREG>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(384), lds, stream, A);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(384), lds, stream, C.d_layers, C.d_ents, C.d_rows, A);
     return hipGetLastError();
 }
 
-template <int MAXDEG, int REC>
+template <int MAXDEG, int REC, bool IRREG>
 static int occupancy_ldpc(int N) {
     int nb = 0;
     size_t lds = (size_t)((N + 15) / 16) * 16;
-    auto kern = ldpc_decode_kernel<MAXDEG, REC>;
+    auto kern = ldpc_decode_kernel<MAXDEG, REC, IRREG>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 384, lds) != hipSuccess) nb = 1;
     return nb < 1 ? 1 : nb;
 }
 
+// (max_deg, irregular) pairs that occur in DVB-S2: regular B1..B11, C2, C3, C5, C6, C10; irregular C1 C4 C7 C8 C9
 #define LDPC_DISPATCH(FN, ...)                                                             \
-    switch (max_deg) {                                                                     \
-        case 2: return FN<2, 1>(__VA_ARGS__);                                              \
-        case 3: return FN<3, 2>(__VA_ARGS__);                                              \
-        case 4: return FN<4, 2>(__VA_ARGS__);                                              \
-        case 5: return FN<5, 2>(__VA_ARGS__);                                              \
-        case 8: return FN<8, 4>(__VA_ARGS__);                                              \
-        case 9: return FN<9, 4>(__VA_ARGS__);                                              \
-        case 11: return FN<11, 4>(__VA_ARGS__);                                            \
-        case 12: return FN<12, 4>(__VA_ARGS__);                                            \
-        case 16: return FN<16, 8>(__VA_ARGS__);                                            \
-        case 17: return FN<17, 8>(__VA_ARGS__);                                            \
-        case 20: return FN<20, 8>(__VA_ARGS__);                                            \
-        case 25: return FN<25, 8>(__VA_ARGS__);                                            \
-        case 28: return FN<28, 8>(__VA_ARGS__);                                            \
-        default: break;                                                                    \
+    if (!irregular) {                                                                      \
+        switch (max_deg) {                                                                 \
+            case 2: return FN<2, 1, false>(__VA_ARGS__);                                   \
+            case 3: return FN<3, 2, false>(__VA_ARGS__);                                   \
+            case 4: return FN<4, 2, false>(__VA_ARGS__);                                   \
+            case 5: return FN<5, 2, false>(__VA_ARGS__);                                   \
+            case 8: return FN<8, 4, false>(__VA_ARGS__);                                   \
+            case 9: return FN<9, 4, false>(__VA_ARGS__);                                   \
+            case 12: return FN<12, 4, false>(__VA_ARGS__);                                 \
+            case 16: return FN<16, 8, false>(__VA_ARGS__);                                 \
+            case 20: return FN<20, 8, false>(__VA_ARGS__);                                 \
+            case 25: return FN<25, 8, false>(__VA_ARGS__);                                 \
+            case 28: return FN<28, 8, false>(__VA_ARGS__);                                 \
+            default: break;                                                                \
+        }                                                                                  \
+    } else {                                                                               \
+        switch (max_deg) {                                                                 \
+            case 2: return FN<2, 1, true>(__VA_ARGS__);                                    \
+            case 5: return FN<5, 2, true>(__VA_ARGS__);                                    \
+            case 11: return FN<11, 4, true>(__VA_ARGS__);                                  \
+            case 17: return FN<17, 8, true>(__VA_ARGS__);                                  \
+            default: break;                                                                \
+        }                                                                                  \
     }
 
-int ldpc_blocks_per_cu(int max_deg, int N) {
+int ldpc_blocks_per_cu(int max_deg, int irregular, int N) {
     LDPC_DISPATCH(occupancy_ldpc, N)
     return 1;
 }
+
+unsigned long long* g_ldpc_prof = nullptr;   // set by tools/ldpc_prof.py through dvbs2gpu_debug_set_prof (PROF builds)
 
 hipError_t ldpc_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nframes, int max_trials, int force,
                               uint8_t* hard, int hard_stride, int8_t* post, int32_t* trials, uint32_t* msg_ws, int grid,
                               hipStream_t stream) {
     LdpcKernelArgs A;
-    A.layers = C.d_layers; A.ents = C.d_ents; A.rows = C.d_rows;
     A.llr = llr; A.hard = hard; A.post = post; A.trials = trials; A.msg_ws = msg_ws;
     A.nframes = nframes; A.N = C.N; A.K = C.K; A.R = C.R; A.q = C.q;
     A.max_trials = max_trials; A.force = force; A.hard_stride = hard_stride;
-    const int max_deg = C.max_deg;
-    LDPC_DISPATCH(launch_ldpc, A, grid, stream)
+    A.prof = g_ldpc_prof;
+    const int max_deg = C.max_deg, irregular = C.irregular;
+    LDPC_DISPATCH(launch_ldpc, C, A, grid, stream)
     return hipErrorInvalidValue;
 }
 

@@ -2,14 +2,16 @@
 //
 // The reference decoder (xdsopl-ldpc-pabr/layered_decoder.hh:46-74) sweeps the parity-check rows strictly
 // in the order layer i = 0..q-1, row j = 0..359.  Rows of one layer are NOT always independent: when a
-// table row has two (or three) addresses with the same residue mod q, the rows j and j+d of that layer
-// share an information bit, and the later row must see the earlier row's write (SURVEY section 7 hard
-// part 1).  To stay bit-exact while running the 360 rows of a layer on 360 lanes, the plan marks for
-// every (layer, row, link):
+// table row has two (or more) addresses with the same residue mod q, rows j and j+d of that layer share
+// an information bit, and the later row must see the earlier row's write (SURVEY section 7 hard part 1).
+// To stay bit-exact while running the 360 rows of a layer on 360 lanes, the plan marks for every
+// (layer, row, shared link):
 //   late  : an earlier row of this layer also touches the bit  -> read only after that row has written
 //   early : a later row of this layer also touches the bit     -> write before that row reads
 // and assigns each row a level = 1 + max(level of the rows it waits for).  Rows of equal level are
-// independent; levels are separated by a workgroup barrier (see ldpc_kernel.hip).
+// independent; levels are separated by a workgroup barrier (ldpc_kernel.hip).  Inside a layer the links
+// are reordered so that shared ("conflict") links come first: the per-level work only walks those.
+// Link order inside a row does not influence the result (min/xor are order-free, algorithms.hh:233-256).
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -19,31 +21,28 @@
 
 namespace s2 {
 
-struct LdpcLayerDesc {   // 16 bytes, wave-uniform, fetched with scalar loads
+struct LdpcLayerDesc {   // 16 bytes = one s_load_dwordx4 (all fields 32-bit: sub-dword fields would force vector loads)
     uint32_t ent_off;    // index of the layer's first link entry
-    uint16_t deg;        // information-bit links per row in this layer
-    uint16_t depth;      // 1 = conflict-free, else number of levels
-    uint32_t row_off;    // index (in rows) of the layer's RowInfo block, conflict layers only
-    uint32_t cmask;      // bit k set: link k is shared between rows of this layer
+    uint32_t deg;        // information-bit links per row in this layer
+    uint32_t depth_nc;   // bits 0..15 depth (1 = conflict-free, else number of levels), bits 16..31 nc = number of
+                         // conflict links (they are links 0..nc-1)
+    uint32_t row_off;    // index of the layer's first per-row word (conflict layers only)
 };
-struct LdpcLinkEnt {     // 8 bytes, wave-uniform
-    uint32_t sb;         // 360*r + (360 - s) % 360 : lane j reads byte sb + j, minus 360 if >= thr
-    uint32_t thr;        // 360*r + 360
-};
-struct LdpcRowInfo {     // 12 bytes per (conflict layer, row)
-    uint32_t late;       // bit k: link k must be read after an earlier row's write
-    uint32_t early;      // bit k: link k must be written before a later row's read
-    uint32_t level;      // 1..depth
-};
+// link entry: bits 0..15 = sp = (360 - s) % 360, bits 16..31 = r.
+//   lane j reads byte 360*r + ((j + sp) mod 360) of the posterior array.
+// per-row word (conflict layers): bits 0..7 level, 8..19 late mask, 20..31 early mask (over links 0..nc-1)
+
+constexpr int LDPC_MAX_CONFLICT_LINKS = 12;
 
 struct LdpcPlan {
     int code_index = -1;
-    int N = 0, K = 0, R = 0, q = 0, max_deg = 0, edges = 0;
+    int N = 0, K = 0, R = 0, q = 0, max_deg = 0, min_deg = 0, edges = 0;
     int rec_dwords = 0;  // message record size per row, dwords (power of two >= ceil((max_deg+2)/4))
     int sum_depth = 0;   // sum of layer depths (q when no layer has conflicts)
+    int conflict_layers = 0;
     std::vector<LdpcLayerDesc> layers;
-    std::vector<LdpcLinkEnt> ents;
-    std::vector<LdpcRowInfo> rows;
+    std::vector<uint32_t> ents;
+    std::vector<uint32_t> rows;
 };
 
 inline LdpcPlan build_ldpc_plan(int code_index) {
@@ -51,62 +50,65 @@ inline LdpcPlan build_ldpc_plan(int code_index) {
     LdpcPlan P;
     P.code_index = code_index;
     P.N = d.N; P.K = d.K; P.R = d.N - d.K; P.q = d.q; P.max_deg = d.max_deg; P.edges = d.edges;
+    P.min_deg = d.max_deg;
     int rd = (d.max_deg + 2 + 3) / 4, pw = 1;
     while (pw < rd) pw <<= 1;
     P.rec_dwords = pw;
     for (int i = 0; i < d.q; ++i) {
         LdpcLayerDesc L;
         L.ent_off = (uint32_t)P.ents.size();
-        L.deg = (uint16_t)(d.off[i + 1] - d.off[i]);
-        L.depth = 1; L.row_off = 0; L.cmask = 0;
+        L.deg = (uint32_t)(d.off[i + 1] - d.off[i]);
+        L.row_off = 0;
+        uint32_t l_depth = 1, l_nc = 0;
+        P.min_deg = std::min(P.min_deg, (int)L.deg);
         std::vector<int> rr, ss;
         for (int e = d.off[i]; e < d.off[i + 1]; ++e) {
-            int r = d.ent[e] >> 16, s = d.ent[e] & 0xffff;
-            rr.push_back(r); ss.push_back(s);
-            LdpcLinkEnt E;
-            E.sb = (uint32_t)(360 * r + (360 - s) % 360);
-            E.thr = (uint32_t)(360 * r + 360);
-            P.ents.push_back(E);
+            rr.push_back((int)(d.ent[e] >> 16));
+            ss.push_back((int)(d.ent[e] & 0xffff));
         }
-        // links sharing a table row r touch the same 360 bits
-        std::map<int, std::vector<int>> byr;
-        for (int k = 0; k < (int)rr.size(); ++k) byr[rr[k]].push_back(k);
-        bool conflict = false;
-        for (auto& kv : byr)
-            if (kv.second.size() > 1) {
-                conflict = true;
-                for (int k : kv.second) L.cmask |= 1u << k;
-            }
-        if (conflict) {
-            std::vector<LdpcRowInfo> ri(360);
-            for (auto& x : ri) { x.late = 0; x.early = 0; x.level = 1; }
-            // preds[j] = rows that must finish their shared-link write before row j reads
+        // links sharing a table row r touch the same 360 bits -> conflict links, moved to the front
+        std::map<int, int> cnt;
+        for (int r : rr) cnt[r]++;
+        std::vector<int> order;
+        for (int k = 0; k < (int)rr.size(); ++k)
+            if (cnt[rr[k]] > 1) order.push_back(k);
+        l_nc = (uint32_t)order.size();
+        for (int k = 0; k < (int)rr.size(); ++k)
+            if (cnt[rr[k]] == 1) order.push_back(k);
+        std::vector<int> r2, s2v;
+        for (int k : order) { r2.push_back(rr[k]); s2v.push_back(ss[k]); }
+        rr = r2; ss = s2v;
+        for (int k = 0; k < (int)rr.size(); ++k) P.ents.push_back((uint32_t)((360 - ss[k]) % 360) | ((uint32_t)rr[k] << 16));
+        if (l_nc > 0) {
+            std::vector<uint32_t> late(360, 0), early(360, 0), level(360, 1);
             std::vector<std::vector<int>> preds(360);
-            for (auto& kv : byr) {
-                if (kv.second.size() < 2) continue;
+            std::map<int, std::vector<int>> byr;
+            for (int k = 0; k < (int)l_nc; ++k) byr[rr[k]].push_back(k);
+            for (auto& kv : byr)
                 for (int m = 0; m < 360; ++m) {
-                    // touchers of bit 360*r+m: (row, link), sequential order = ascending row
+                    // touchers of bit 360*r+m as (row, link); sequential order = ascending row
                     std::vector<std::pair<int, int>> t;
                     for (int k : kv.second) t.push_back({(ss[k] + m) % 360, k});
                     std::sort(t.begin(), t.end());
                     for (size_t a = 0; a < t.size(); ++a) {
-                        if (a > 0) { ri[t[a].first].late |= 1u << t[a].second; preds[t[a].first].push_back(t[a - 1].first); }
-                        if (a + 1 < t.size()) ri[t[a].first].early |= 1u << t[a].second;
+                        if (a > 0) { late[t[a].first] |= 1u << t[a].second; preds[t[a].first].push_back(t[a - 1].first); }
+                        if (a + 1 < t.size()) early[t[a].first] |= 1u << t[a].second;
                     }
                 }
-            }
-            int depth = 1;
-            for (int j = 0; j < 360; ++j) {  // preds always have a smaller row index
+            uint32_t depth = 1;
+            for (int j = 0; j < 360; ++j) {  // predecessors always have a smaller row index
                 uint32_t lv = 1;
-                for (int p : preds[j]) lv = std::max(lv, ri[p].level + 1);
-                ri[j].level = lv;
-                depth = std::max(depth, (int)lv);
+                for (int p : preds[j]) lv = std::max(lv, level[p] + 1);
+                level[j] = lv;
+                depth = std::max(depth, lv);
             }
-            L.depth = (uint16_t)depth;
+            l_depth = depth;
             L.row_off = (uint32_t)P.rows.size();
-            P.rows.insert(P.rows.end(), ri.begin(), ri.end());
+            for (int j = 0; j < 360; ++j) P.rows.push_back(level[j] | (late[j] << 8) | (early[j] << 20));
+            P.conflict_layers++;
         }
-        P.sum_depth += L.depth;
+        L.depth_nc = l_depth | (l_nc << 16);
+        P.sum_depth += (int)l_depth;
         P.layers.push_back(L);
     }
     return P;

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Development aid: per-phase cycle breakdown of the LDPC kernel (needs `make -C .../csrc prof`)."""
+import sys, os, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import __graft_entry__ as g
+pkg = g.load_package()
+pkg.LIB_PATH = os.path.join(ROOT, 'sdrpp-dvbs-demodulator_amd', 'libdvbs2gpu_prof.so')
+eng = pkg.Engine(0)
+rate, short = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (6, 0)
+iters = int(os.environ.get('ITERS', '20'))
+fi = pkg.fec_info(rate, short); pi = eng.ldpc_plan_info(rate, short)
+F = pi['cus'] * pi['blocks_per_cu']
+llr = torch.randint(-30, 31, (F, fi['ldpc_n']), dtype=torch.int8, device='cuda')
+buf = torch.zeros(96, dtype=torch.int64, device='cuda')
+eng.lib.dvbs2gpu_debug_set_prof.argtypes = [C.c_void_p]
+eng.lib.dvbs2gpu_debug_set_prof(C.c_void_p(buf.data_ptr()))
+eng.ldpc_decode(llr, rate, bool(short), max_trials=iters, force=True)
+torch.cuda.synchronize()
+b = buf.cpu().numpy().reshape(6, 16)
+names = ['free:S1', 'free:(none)', 'free:S3', 'barrier', 'conf:S1', 'conf:levels', 'conf:S3', 'prefetch/top']
+print(pi)
+for w in range(6):
+    print('wave', w, ' '.join('%s=%.0f' % (names[i], b[w, i] / iters) for i in range(8)), 'total/iter=%.0f cycles' % (b[w, :8].sum() / iters))
