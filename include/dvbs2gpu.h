@@ -97,6 +97,76 @@ int dvbs2gpu_fec_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, cons
                               int max_trials, int force, uint8_t* d_bbframes, int32_t* d_trials, int32_t* d_corrections,
                               void* stream);
 
+/* ------------------------------------------------------------------ soft demap + bit de-interleave
+ * replaces S2BBToSoft::process (dvbs2_bb_to_soft.cpp:7-33): constellation_t::demod_soft_lut per payload
+ * symbol (constellation.cpp:293-322) followed by S2Deinterleaver::deinterleave (s2_deinterleaver.cpp:72-136).
+ *   d_frames  [nframes][plframe_symbols] complex64 PLL output (header in [0,90), payload after it, pilot
+ *             blocks at their standard positions when pilots != 0)
+ *   d_llr     [nframes][N] int8 */
+int dvbs2gpu_demap_batch(dvbs2gpu_ctx* ctx, int modcod, int shortframes, int pilots, const float* d_frames, int nframes,
+                         int8_t* d_llr, void* stream);
+
+/* ------------------------------------------------------------------ full DVB-S2 demodulator (one stream)
+ *
+ * Mirror of dsp::dvbs2::DVBS2Demod (module_dvbs2_demod.h:51-160).  A handle is one transponder stream:
+ * it owns the loop state that the reference keeps in its member blocks (AGC gain, NCO phase/frequency,
+ * Gardner delay line + PCL, RRC delay line, /2 decimator phase, PL-sync buffer and state machine, PLL and
+ * PLHDR loops).  Not re-entrant per handle (the reference guards process() with ctrlMtx the same way).
+ *
+ * cfg mirrors the arguments of DVBS2Demod::init (module_dvbs2_demod.cpp:7-30) in the same units. */
+typedef struct dvbs2gpu_demod_cfg {
+    double symbolrate, samplerate;       /* only their ratio matters (RRC taps); the plugin uses samplerate = 2*symbolrate */
+    float agc_rate, rrc_alpha;
+    int32_t rrc_taps;
+    float loop_bw, fll_bw;
+    float clock_omega_gain, clock_mu_gain, omega_rel_limit;
+    int32_t modcod, shortframes, pilots;
+    float sof_threshold;                 /* stored, unused -- as in the reference (dvbs2_pl_sync.cpp:140-142) */
+    int32_t max_ldpc_trials;
+    int32_t force_ldpc_iters;            /* 0 = normal early exit; n > 0 = benchmark mode, exactly n iterations */
+} dvbs2gpu_demod_cfg;
+
+typedef struct dvbs2gpu_demod dvbs2gpu_demod;
+
+/* Defaults of the plugin shell (main.cpp:64-73,134-140). */
+void dvbs2gpu_demod_default_cfg(int modcod, int shortframes, int pilots, dvbs2gpu_demod_cfg* out);
+
+/* max_samples: largest `count` a single process call may pass (SDR++ STREAM_BUFFER_SIZE = 1000000). */
+int dvbs2gpu_demod_create(dvbs2gpu_ctx* ctx, const dvbs2gpu_demod_cfg* cfg, int max_samples, dvbs2gpu_demod** out);
+void dvbs2gpu_demod_destroy(dvbs2gpu_demod* d);
+int dvbs2gpu_demod_reset(dvbs2gpu_demod* d);                                            /* DVBS2Demod::reset */
+int dvbs2gpu_demod_set_params(dvbs2gpu_demod* d, int modcod, int shortframes, int pilots, float sof_threshold,
+                              int max_ldpc_trials);                                      /* DVBS2Demod::setDemodParams */
+int dvbs2gpu_demod_get_kbch(dvbs2gpu_demod* d);                                          /* DVBS2Demod::getKBCH */
+
+/* int DVBS2Demod::process(int count, const complex_t* in, uint8_t* out): h_iq = count interleaved (re,im)
+ * float pairs at 2 samples/symbol, h_out receives the descrambled BBFRAMEs completed by this call
+ * (kbch/8 bytes each, input order).  Returns bytes written (0 is legal) or a negative error.  Synchronous. */
+int dvbs2gpu_demod_process(dvbs2gpu_demod* d, int count, const float* h_iq, uint8_t* h_out, int out_cap);
+
+/* Same for `n` independent streams in one go (frames of all streams share the FEC launches).  d_iq[i] are
+ * DEVICE pointers (inputs already resident in HBM), counts[i] samples each; d_out[i] DEVICE buffers of
+ * out_cap bytes; out_bytes[i] (host) receives the byte count of stream i.  Synchronous. */
+int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const float* const* d_iq, const int* counts,
+                                 uint8_t* const* d_out, int out_cap, int* out_bytes);
+
+/* Stats of the frames completed by the last process call of this handle (the public fields the GUI polls,
+ * module_dvbs2_demod.h:82-87, one record per frame). */
+typedef struct dvbs2gpu_frame_stats {
+    float pl_sync_best_match;
+    int32_t detected_modcod, detected_shortframes, detected_pilots;
+    float coarse_freq_err;
+    int32_t ldpc_trials, bch_corrections;
+} dvbs2gpu_frame_stats;
+int dvbs2gpu_demod_get_stats(dvbs2gpu_demod* d, dvbs2gpu_frame_stats* h_out, int cap);
+float dvbs2gpu_demod_get_nco_freq(dvbs2gpu_demod* d);
+
+/* Debug taps of the last process call (device->host copies; for parity tests and the constellation
+ * display callback d_handler, module_dvbs2_demod.cpp:337).  which: 0 = 1-sps symbols entering PL sync,
+ * 1 = aligned raw PLFRAMEs, 2 = PLL output, (complex64, count in complex samples); 3 = LLRs (int8).
+ * Returns the element count; copies at most cap elements when h_dst != NULL. */
+int dvbs2gpu_demod_get_tap(dvbs2gpu_demod* d, int which, void* h_dst, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -102,3 +102,89 @@ int orc_fec_decode_frame(int rate, int shortframe, int8_t* llr, int max_trials, 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------- S2 chain (s2chain.cpp)
+#include "s2chain.h"
+
+extern "C" {
+
+void orc_default_cfg(int modcod, int shortframes, int pilots, DemodCfg* out) { *out = default_cfg(modcod, shortframes, pilots); }
+
+void* orc_s2rx_create(const DemodCfg* cfg) {
+    try { return new S2Rx(*cfg); } catch (...) { return nullptr; }
+}
+void orc_s2rx_destroy(void* h) { delete (S2Rx*)h; }
+void orc_s2rx_reset(void* h) { ((S2Rx*)h)->reset(); }
+int orc_s2rx_process(void* h, int count, const float* iq, uint8_t* out, int out_cap) {
+    return ((S2Rx*)h)->process(count, (const cf*)iq, out, out_cap);
+}
+// debug taps of the last process() call: which = 0 symbols, 1 aligned frames, 2 PLL output (complex float);
+// 3 = LLRs (int8); 4 = stats (FrameStats).  Returns the element count; copies when dst != null.
+int orc_s2rx_tap(void* h, int which, void* dst) {
+    S2Rx* r = (S2Rx*)h;
+    switch (which) {
+        case 0: if (dst) memcpy(dst, r->dbg_symbols.data(), r->dbg_symbols.size() * sizeof(cf)); return (int)r->dbg_symbols.size();
+        case 1: if (dst) memcpy(dst, r->dbg_frames.data(), r->dbg_frames.size() * sizeof(cf)); return (int)r->dbg_frames.size();
+        case 2: if (dst) memcpy(dst, r->dbg_pll.data(), r->dbg_pll.size() * sizeof(cf)); return (int)r->dbg_pll.size();
+        case 3: if (dst) memcpy(dst, r->dbg_llr.data(), r->dbg_llr.size()); return (int)r->dbg_llr.size();
+        case 4: if (dst) memcpy(dst, r->dbg_stats.data(), r->dbg_stats.size() * sizeof(FrameStats)); return (int)r->dbg_stats.size();
+    }
+    return -1;
+}
+float orc_s2rx_nco_freq(void* h) { return ((S2Rx*)h)->nco_freq(); }
+
+// stage-level entry points on a receiver object (state carried inside it)
+void orc_s2rx_agc(void* h, int n, const float* in, float* out) { ((S2Rx*)h)->agc(n, (const cf*)in, (cf*)out); }
+void orc_s2rx_nco(void* h, int n, const float* in, float* out) { ((S2Rx*)h)->nco(n, (const cf*)in, (cf*)out); }
+int orc_s2rx_gardner(void* h, int n, const float* in, float* out) { return ((S2Rx*)h)->gardner(n, (const cf*)in, (cf*)out); }
+void orc_s2rx_rrc(void* h, int n, const float* in, float* out) { ((S2Rx*)h)->rrc_filter(n, (const cf*)in, (cf*)out); }
+float orc_s2rx_fed(void* h, const float* frame) { return ((S2Rx*)h)->coarse_fed((const cf*)frame); }
+void orc_s2rx_pll(void* h, const float* frame, float* out) { ((S2Rx*)h)->pll((const cf*)frame, (cf*)out); }
+void orc_s2rx_plhdr(void* h, const float* frame, float* out, int* det3) { ((S2Rx*)h)->plhdr((const cf*)frame, (cf*)out, det3, det3 + 1, det3 + 2); }
+void orc_s2rx_to_soft(void* h, const float* pllout, int8_t* llr) { ((S2Rx*)h)->to_soft((const cf*)pllout, llr); }
+
+// transmitter: returns number of complex samples; call with iq == null to get the size
+int orc_s2_transmit(const TxCfg* t, float* iq, int iq_cap, uint8_t* bbframes, float* symbols, int sym_cap) {
+    std::vector<uint8_t> bb;
+    std::vector<cf> syms;
+    std::vector<cf> v = s2_transmit(*t, &bb, &syms);
+    if (iq && (int)v.size() <= iq_cap) memcpy(iq, v.data(), v.size() * sizeof(cf));
+    if (bbframes) memcpy(bbframes, bb.data(), bb.size());
+    if (symbols && (int)syms.size() <= sym_cap) memcpy(symbols, syms.data(), syms.size() * sizeof(cf));
+    return (int)v.size();
+}
+
+// tables for fixtures / GPU table parity
+int orc_constellation_lut(int constel, float g1, float g2, int8_t* bits_out, float* err_out) {
+    Constellation C(constel, g1, g2);
+    if (C.bits == 5) return 0;
+    if (bits_out) memcpy(bits_out, C.lut_bits.data(), C.lut_bits.size());
+    if (err_out) memcpy(err_out, C.lut_err.data(), C.lut_err.size() * sizeof(float));
+    return C.bits;
+}
+void orc_constellation_soft_calc(int constel, float g1, float g2, int n, const float* samples, int8_t* bits_out, float* err_out) {
+    Constellation C(constel, g1, g2);
+    for (int i = 0; i < n; ++i) C.soft_calc(cf{samples[2 * i], samples[2 * i + 1]}, bits_out + (size_t)i * C.bits, err_out + i);
+}
+void orc_constellation_points(int constel, float g1, float g2, float* pts_out) {
+    Constellation C(constel, g1, g2);
+    for (int i = 0; i < C.states; ++i) { cf p = C.mod(i); pts_out[2 * i] = p.re; pts_out[2 * i + 1] = p.im; }
+}
+void orc_s2_deinterleave(int constel, int rate, int shortframe, const int8_t* in, int8_t* out) { s2_deinterleave(constel, rate, shortframe, in, out); }
+void orc_pl_tables(float* sof52, float* plsc_128x64x2, uint64_t* codes128, uint8_t* rn131072) {
+    const PlTables& T = pl_tables();
+    if (sof52) memcpy(sof52, T.sof, sizeof(T.sof));
+    if (plsc_128x64x2) memcpy(plsc_128x64x2, T.plsc_sym, sizeof(T.plsc_sym));
+    if (codes128) memcpy(codes128, T.plsc_code, sizeof(T.plsc_code));
+    if (rn131072) memcpy(rn131072, T.Rn.data(), 131072);
+}
+void orc_rrc_taps(int count, double beta, double symrate, double samprate, float* out) {
+    std::vector<float> t = rrc_taps(count, beta, symrate, samprate);
+    memcpy(out, t.data(), t.size() * sizeof(float));
+}
+void orc_gardner_bank(float* out1024) {
+    std::vector<float> b = gardner_bank(128, 8);
+    memcpy(out1024, b.data(), b.size() * sizeof(float));
+}
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+// ORACLE (test infrastructure, CPU only) -- not part of the shipped engine.
+// DVB-S2 physical-layer receive chain (float DSP + PL framing) and a synthetic transmitter.
+//
+// PARITY UNPINNED for every float stage that rests on SDR++ core / VOLK (FastAGC, FIR, tap generators,
+// PhaseControlLoop, phasor, the VOLK dot products): those libraries are not in /root/reference and the
+// reference has no tests, so these restate the call-site semantics of the plugin plus the textbook
+// definitions listed in SURVEY.md Appendix C.  What IS pinned here against the reference's own code:
+// the S2 deinterleaver (compiled reference, oracle/_ref) and everything integer downstream (LDPC/BCH/BB).
+#pragma once
+#include <cstdint>
+#include <vector>
+#include <cmath>
+#include "oracle.h"
+
+namespace orc {
+
+struct cf { float re, im; };
+static inline cf cmul(cf a, cf b) { return cf{a.re * b.re - a.im * b.im, a.im * b.re + a.re * b.im}; }
+static inline cf cconj(cf a) { return cf{a.re, -a.im}; }
+static inline cf cadd(cf a, cf b) { return cf{a.re + b.re, a.im + b.im}; }
+static inline cf csub(cf a, cf b) { return cf{a.re - b.re, a.im - b.im}; }
+static inline cf cscale(cf a, float s) { return cf{a.re * s, a.im * s}; }
+static inline float camp(cf a) { return sqrtf(a.re * a.re + a.im * a.im); }
+static inline float cphase(cf a) { return atan2f(a.im, a.re); }
+static inline cf phasor(float x) { return cf{cosf(x), sinf(x)}; }
+
+// SDR++ loop::PhaseControlLoop<float, CLAMP_PHASE> as used by the plugin
+struct Pcl {
+    float alpha = 0, beta = 0, phase = 0, freq = 0, minPhase = 0, maxPhase = 0, minFreq = 0, maxFreq = 0;
+    bool clampPhase = true;
+    void init(float a, float b, float ph, float minP, float maxP, float fr, float minF, float maxF, bool clamp) {
+        alpha = a; beta = b; phase = ph; minPhase = minP; maxPhase = maxP; freq = fr; minFreq = minF; maxFreq = maxF; clampPhase = clamp;
+    }
+    void advance(float err) {
+        freq += beta * err;
+        if (freq > maxFreq) freq = maxFreq; else if (freq < minFreq) freq = minFreq;
+        phase += freq + alpha * err;
+        if (clampPhase) {
+            float delta = maxPhase - minPhase;
+            while (phase > maxPhase) phase -= delta;
+            while (phase < minPhase) phase += delta;
+        }
+    }
+};
+void critically_damped(float bw, float* alpha, float* beta);
+
+// ---- constants / tables
+struct PlTables {
+    cf sof[26];                 // s2_defs.h:15-30
+    uint64_t plsc_code[128];    // s2_defs.h:32-80
+    cf plsc_sym[128][64];
+    std::vector<uint8_t> Rn;    // 131072 entries, s2_scrambling.cpp:9-28
+    PlTables();
+};
+const PlTables& pl_tables();
+
+// ---- soft demapper (constellation.cpp:19-322)
+struct Constellation {
+    int type;                   // s2::Constel
+    int bits, states;
+    float amp, sca, prescale;
+    std::vector<cf> pts;
+    std::vector<int8_t> lut_bits;   // [256][256][bits], x-major like the reference's lut[x][y]
+    std::vector<float> lut_err;     // [256][256]
+    Constellation(int type, float g1, float g2);
+    cf mod(int sym) const;
+    void soft_calc(cf s, int8_t* bits_out, float* phase_err) const;
+    void soft_lut(cf s, int8_t* bits_out, float* phase_err) const;
+    static int lut_index(float v);
+};
+
+void s2_deinterleave(int constel, int rate, int shortframe, const int8_t* in, int8_t* out);
+
+// ---- stage functions
+std::vector<float> rrc_taps(int count, double beta, double symbolrate, double samplerate);
+std::vector<float> gardner_bank(int phases, int taps_per_phase);   // [phase][tap]
+
+struct DemodCfg {           // same fields / meaning as dvbs2gpu_demod_cfg in include/dvbs2gpu.h
+    double symbolrate, samplerate;
+    float agc_rate, rrc_alpha;
+    int rrc_taps;
+    float loop_bw, fll_bw, clock_omega_gain, clock_mu_gain, omega_rel_limit;
+    int modcod, shortframes, pilots;
+    float sof_threshold;
+    int max_ldpc_trials, force_ldpc_iters;
+};
+DemodCfg default_cfg(int modcod, int shortframes, int pilots);
+
+struct FrameStats { float best_match; int detect_modcod, detect_short, detect_pilots; float fed_err; int ldpc_trials, bch_corr; };
+
+// Mirror of DVBS2Demod (module_dvbs2_demod.cpp) with every frame LDPC-decoded and BBFRAMEs
+// emitted in the call that completes them.
+class S2Rx {
+public:
+    explicit S2Rx(const DemodCfg& cfg);
+    int process(int count, const cf* in, uint8_t* out, int out_cap);
+    void reset();
+    // stage taps for tests (filled by the last process() call)
+    std::vector<cf> dbg_symbols;        // 1-sps symbols entering PL sync
+    std::vector<cf> dbg_frames;         // aligned raw PL frames
+    std::vector<cf> dbg_pll;            // PLL output per frame (header un-rotated + descrambled payload)
+    std::vector<int8_t> dbg_llr;        // deinterleaved LLRs per frame
+    std::vector<FrameStats> dbg_stats;
+    float nco_freq() const { return nco_freq_; }
+    s2::ModcodParams mp;
+
+private:
+    DemodCfg cfg;
+    // front end state
+    float agc_gain;
+    float nco_phase, nco_freq_;
+    std::vector<float> rrc; std::vector<cf> rrc_hist;
+    std::vector<float> bank; std::vector<cf> g_hist; int g_offset; int g_spsctr; Pcl g_pcl;
+    bool cr_samp;
+    // PL sync state (dvbs2_pl_sync.cpp)
+    std::vector<cf> in_buffer, corr_buffer; int in_ptr, in_lim, in_state, best_pos; float last_bm = 0;
+    // PLL / PLHDR
+    Pcl pll_pcl, hdr_pcl;
+    Constellation constel;
+    int pls_code;
+    std::vector<cf> work1, work2;
+    const LdpcCode* ldpc; const BchCode* bch;
+
+    int plsync_internal(std::vector<cf>& out, float* best_match);
+public:
+    // individual stages, exposed for stage-level parity tests
+    void agc(int n, const cf* in, cf* out);
+    void nco(int n, const cf* in, cf* out);
+    int gardner(int n, const cf* in, cf* out);
+    void rrc_filter(int n, const cf* in, cf* out);
+    float coarse_fed(const cf* frame) const;
+    void pll(const cf* frame, cf* out);
+    void plhdr(const cf* frame, cf* out, int* modcod, int* sh, int* pil);
+    void to_soft(const cf* pllout, int8_t* llr) const;
+};
+
+// ---- synthetic transmitter (SURVEY 8d "Synthetic inputs")
+struct TxCfg {
+    int modcod, shortframes, pilots;
+    int nframes;
+    uint64_t seed;
+    double esn0_db;          // AWGN; >= 100 -> noiseless
+    double cfo;              // carrier offset, rad/sample (2 sps)
+    double timing;           // fractional timing offset, samples
+    double phase0;           // initial carrier phase
+    int lead_symbols;        // random QPSK symbols before the first frame (sync acquisition run-in)
+};
+// returns 2-sps IQ; bbframes_out gets nframes x kbch/8 bytes (what the receiver must output)
+std::vector<cf> s2_transmit(const TxCfg& t, std::vector<uint8_t>* bbframes_out, std::vector<cf>* symbols_out = nullptr);
+
+}  // namespace orc

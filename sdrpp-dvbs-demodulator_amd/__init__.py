@@ -31,6 +31,20 @@ class ModcodInfo(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class DemodCfg(C.Structure):
+    """dvbs2gpu_demod_cfg"""
+    _fields_ = [('symbolrate', C.c_double), ('samplerate', C.c_double), ('agc_rate', C.c_float), ('rrc_alpha', C.c_float),
+                ('rrc_taps', C.c_int32), ('loop_bw', C.c_float), ('fll_bw', C.c_float), ('clock_omega_gain', C.c_float),
+                ('clock_mu_gain', C.c_float), ('omega_rel_limit', C.c_float), ('modcod', C.c_int32), ('shortframes', C.c_int32),
+                ('pilots', C.c_int32), ('sof_threshold', C.c_float), ('max_ldpc_trials', C.c_int32), ('force_ldpc_iters', C.c_int32)]
+
+
+class FrameStats(C.Structure):
+    """dvbs2gpu_frame_stats"""
+    _fields_ = [('pl_sync_best_match', C.c_float), ('detected_modcod', C.c_int32), ('detected_shortframes', C.c_int32),
+                ('detected_pilots', C.c_int32), ('coarse_freq_err', C.c_float), ('ldpc_trials', C.c_int32), ('bch_corrections', C.c_int32)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/dvbs2gpu.h
 _vp = C.c_void_p
 _i = C.c_int
@@ -46,6 +60,18 @@ PROTOTYPES = {
     'dvbs2gpu_bch_decode_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
     'dvbs2gpu_bb_descramble_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
     'dvbs2gpu_fec_decode_batch': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'dvbs2gpu_demap_batch': (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
+    'dvbs2gpu_demod_default_cfg': (None, [_i, _i, _i, C.POINTER(DemodCfg)]),
+    'dvbs2gpu_demod_create': (_i, [_vp, C.POINTER(DemodCfg), _i, C.POINTER(_vp)]),
+    'dvbs2gpu_demod_destroy': (None, [_vp]),
+    'dvbs2gpu_demod_reset': (_i, [_vp]),
+    'dvbs2gpu_demod_set_params': (_i, [_vp, _i, _i, _i, C.c_float, _i]),
+    'dvbs2gpu_demod_get_kbch': (_i, [_vp]),
+    'dvbs2gpu_demod_process': (_i, [_vp, _i, _vp, _vp, _i]),
+    'dvbs2gpu_demod_process_batch': (_i, [C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), _i, C.POINTER(_i)]),
+    'dvbs2gpu_demod_get_stats': (_i, [_vp, C.POINTER(FrameStats), _i]),
+    'dvbs2gpu_demod_get_nco_freq': (C.c_float, [_vp]),
+    'dvbs2gpu_demod_get_tap': (_i, [_vp, _i, _vp, _i]),
 }
 
 _lib = None
@@ -174,3 +200,94 @@ class Engine:
         self._check(self.lib.dvbs2gpu_fec_decode_batch(self.h, int(rate), int(bool(shortframes)), _ptr(llr), F, int(max_trials),
                                                        int(bool(force)), _ptr(out), _ptr(trials), _ptr(corr), self._stream()))
         return out, trials, corr
+
+    def demap(self, frames, modcod, shortframes=False, pilots=False):
+        """frames complex64 [F, plframe] (PLL output) -> LLR int8 [F, N]"""
+        t = self.torch
+        mi = modcod_info(modcod, shortframes, pilots)
+        assert frames.dtype == t.complex64 and frames.is_cuda and frames.is_contiguous() and frames.shape[1] == mi['plframe_symbols']
+        llr = t.empty((frames.shape[0], mi['ldpc_n']), dtype=t.int8, device=frames.device)
+        self._check(self.lib.dvbs2gpu_demap_batch(self.h, int(modcod), int(bool(shortframes)), int(bool(pilots)), _ptr(frames),
+                                                  frames.shape[0], _ptr(llr), self._stream()))
+        return llr
+
+    def default_cfg(self, modcod, shortframes=False, pilots=False, **kw):
+        c = DemodCfg()
+        self.lib.dvbs2gpu_demod_default_cfg(int(modcod), int(bool(shortframes)), int(bool(pilots)), C.byref(c))
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+
+    def demod(self, cfg, max_samples=1000000):
+        return Demod(self, cfg, max_samples)
+
+    def process_batch(self, demods, iq_tensors, out_tensors):
+        """One call for many streams: iq_tensors[i] complex64 CUDA 1-D, out_tensors[i] uint8 CUDA buffers.
+        Returns the list of byte counts."""
+        n = len(demods)
+        hs = (C.c_void_p * n)(*[d.h for d in demods])
+        iq = (C.c_void_p * n)(*[t.data_ptr() for t in iq_tensors])
+        cnt = (C.c_int * n)(*[int(t.numel()) for t in iq_tensors])
+        out = (C.c_void_p * n)(*[t.data_ptr() for t in out_tensors])
+        nb = (C.c_int * n)()
+        cap = min(int(t.numel()) for t in out_tensors)
+        self._check(self.lib.dvbs2gpu_demod_process_batch(hs, n, iq, cnt, out, cap, nb))
+        return list(nb)
+
+
+class Demod:
+    """One DVB-S2 transponder stream: mirror of DVBS2Demod (init/process/reset/setDemodParams/getKBCH)."""
+
+    def __init__(self, engine, cfg, max_samples=1000000):
+        self.eng = engine
+        self.lib = engine.lib
+        self.cfg = cfg
+        self.info = modcod_info(cfg.modcod, cfg.shortframes, cfg.pilots)
+        h = C.c_void_p()
+        engine._check(self.lib.dvbs2gpu_demod_create(engine.h, C.byref(cfg), int(max_samples), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.dvbs2gpu_demod_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self.eng._check(self.lib.dvbs2gpu_demod_reset(self.h))
+
+    def get_kbch(self):
+        return self.lib.dvbs2gpu_demod_get_kbch(self.h)
+
+    def process(self, iq):
+        """iq: numpy complex64 1-D (host, 2 sps) -> numpy uint8 [frames, kbch/8]"""
+        import numpy as np
+        iq = np.ascontiguousarray(iq, np.complex64)
+        kb = self.info['kbch'] // 8
+        cap = (iq.size // (2 * self.info['plframe_symbols']) + 4) * kb
+        out = np.zeros(cap, np.uint8)
+        n = self.lib.dvbs2gpu_demod_process(self.h, int(iq.size), C.c_void_p(iq.ctypes.data), C.c_void_p(out.ctypes.data), cap)
+        self.eng._check(n)
+        return out[:n].reshape(-1, kb)
+
+    def stats(self):
+        n = self.lib.dvbs2gpu_demod_get_stats(self.h, None, 0)
+        arr = (FrameStats * max(n, 1))()
+        self.lib.dvbs2gpu_demod_get_stats(self.h, arr, n)
+        return [arr[i] for i in range(n)]
+
+    def nco_freq(self):
+        return float(self.lib.dvbs2gpu_demod_get_nco_freq(self.h))
+
+    def tap(self, which):
+        import numpy as np
+        n = self.eng._check(self.lib.dvbs2gpu_demod_get_tap(self.h, which, None, 0))
+        a = np.zeros(n, np.int8 if which == 3 else np.complex64)
+        if n:
+            self.eng._check(self.lib.dvbs2gpu_demod_get_tap(self.h, which, C.c_void_p(a.ctypes.data), n))
+        return a

@@ -1,69 +1,24 @@
 // C ABI of the engine (include/dvbs2gpu.h): context, table upload, workspace management, stage launches.
 // Host-side only logic here; kernels live in *_kernel.hip.  No CPU fallback: without a HIP device
 // dvbs2gpu_create fails with DVBS2GPU_ERR_NODEVICE.
-#include <hip/hip_runtime.h>
-#include <cstdio>
-#include <cstring>
-#include <map>
-#include <mutex>
-#include <string>
-#include <vector>
-#include "../../include/dvbs2gpu.h"
-#include "s2_params.h"
-#include "ldpc_plan.h"
-#include "kernels.h"
+#include "ctx.h"
 
 using namespace s2;
 namespace s2 { extern unsigned long long* g_ldpc_prof; }
 
+namespace s2 {
 static thread_local std::string g_err;
-static int fail_hip(hipError_t e, const char* what) {
+std::string& last_error() { return g_err; }
+int fail_hip(hipError_t e, const char* what) {
     g_err = std::string(what) + ": " + hipGetErrorString(e);
     return DVBS2GPU_ERR_HIP;
 }
-#define HIP_TRY(x)                                        \
-    do {                                                  \
-        hipError_t _e = (x);                              \
-        if (_e != hipSuccess) return fail_hip(_e, #x);    \
-    } while (0)
-
-struct Workspace {
-    void* p = nullptr;
-    size_t bytes = 0;
-    int ensure(size_t n) {
-        if (n <= bytes) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr; bytes = 0;
-        hipError_t e = hipMalloc(&p, n);
-        if (e != hipSuccess) return fail_hip(e, "hipMalloc(workspace)");
-        bytes = n;
-        return 0;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
-};
-
-struct dvbs2gpu_ctx {
-    int device = 0;
-    int num_cus = 256;
-    std::mutex mtx;
-    std::map<int, LdpcDeviceCode> ldpc;       // by code_index
-    std::map<int, BchDeviceCode> bch;         // by m*100 + t  (GF(2^16) t=12/10/8 share tables of t=12)
-    uint8_t* d_prbs = nullptr;                // BB scrambler sequence, 8100 bytes
-    Workspace ws_msg, ws_hard, ws_syn, ws_misc;
-};
+}  // namespace s2
+#define g_err s2::last_error()
 
 // ---------------------------------------------------------------------------------------------------
-template <typename T>
-static int upload(const std::vector<T>& v, T** dptr) {
-    *dptr = nullptr;
-    size_t n = v.size() * sizeof(T);
-    if (!n) n = sizeof(T);
-    HIP_TRY(hipMalloc((void**)dptr, n));
-    if (!v.empty()) HIP_TRY(hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-    return 0;
-}
-
-static int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
+namespace s2 {
+int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
     std::lock_guard<std::mutex> l(ctx->mtx);
     auto it = ctx->ldpc.find(code_index);
     if (it == ctx->ldpc.end()) {
@@ -84,7 +39,7 @@ static int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
 
 // GF(2^m) tables exactly as the reference builds them (galois_field.hh:152-163) + Artin-Schreier map
 // (reed_solomon_error_correction.hh:67-96) + this engine's byte-Horner syndrome tables.
-static int get_bch(dvbs2gpu_ctx* ctx, int m, int t, BchDeviceCode** out) {
+int get_bch(dvbs2gpu_ctx* ctx, int m, int t, BchDeviceCode** out) {
     std::lock_guard<std::mutex> l(ctx->mtx);
     int key = m * 100 + t;
     auto it = ctx->bch.find(key);
@@ -142,7 +97,7 @@ static int get_bch(dvbs2gpu_ctx* ctx, int m, int t, BchDeviceCode** out) {
     return 0;
 }
 
-static int get_prbs(dvbs2gpu_ctx* ctx) {
+int get_prbs(dvbs2gpu_ctx* ctx) {
     std::lock_guard<std::mutex> l(ctx->mtx);
     if (ctx->d_prbs) return 0;
     // PRBS 1 + x^14 + x^15, seed 0x4A80 as the reference loads it (bbframe_descramble.cpp:122-136)
@@ -156,6 +111,63 @@ static int get_prbs(dvbs2gpu_ctx* ctx) {
     }
     return upload(seq, &ctx->d_prbs);
 }
+}  // namespace s2
+
+namespace s2 {
+static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, int nframes, int max_trials, int force,
+                    uint8_t* d_hard, int hard_stride, int8_t* d_post, int32_t* d_trials, hipStream_t st);
+static int bch_run(dvbs2gpu_ctx* ctx, const FecParams& f, uint8_t* d_frames, int nframes, int32_t* d_corr, hipStream_t st);
+
+int fec_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, int nframes, int max_trials, int force, uint8_t* d_bbframes,
+            int32_t* d_trials, int32_t* d_corr, hipStream_t st) {
+    int rc;
+    if ((rc = ctx->ws_hard.ensure((size_t)nframes * (f.K / 8)))) return rc;
+    uint8_t* hard = (uint8_t*)ctx->ws_hard.p;
+    if ((rc = ldpc_run(ctx, f, d_llr, nframes, max_trials, force, hard, f.K / 8, nullptr, d_trials, st))) return rc;
+    if ((rc = bch_run(ctx, f, hard, nframes, d_corr, st))) return rc;
+    if ((rc = get_prbs(ctx))) return rc;
+    HIP_TRY(bb_descramble_launch(hard, f.K / 8, ctx->d_prbs, f.kbch / 8, nframes, d_bbframes, st));
+    return 0;
+}
+}  // namespace s2
+
+namespace s2 {
+static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, int nframes, int max_trials, int force,
+                    uint8_t* d_hard, int hard_stride, int8_t* d_post, int32_t* d_trials, hipStream_t st) {
+    LdpcDeviceCode* C;
+    int rc = get_ldpc(ctx, f.code_index, &C);
+    if (rc) return rc;
+    int grid = ctx->num_cus * C->blocks_per_cu;
+    if (grid > nframes) grid = nframes;
+    size_t need = (size_t)grid * C->R * C->rec_dwords * sizeof(uint32_t);
+    if ((rc = ctx->ws_msg.ensure(need))) return rc;
+    if (!d_trials) {
+        if ((rc = ctx->ws_misc.ensure((size_t)nframes * 2 * sizeof(int32_t)))) return rc;
+        d_trials = (int32_t*)ctx->ws_misc.p;
+    }
+    if (!d_hard) {
+        if ((rc = ctx->ws_hard.ensure((size_t)nframes * (f.K / 8)))) return rc;
+        d_hard = (uint8_t*)ctx->ws_hard.p; hard_stride = f.K / 8;
+    }
+    HIP_TRY(ldpc_decode_launch(*C, d_llr, nframes, max_trials, force, d_hard, hard_stride, d_post, d_trials,
+                               (uint32_t*)ctx->ws_msg.p, grid, st));
+    return 0;
+}
+}  // namespace s2
+
+namespace s2 {
+static int bch_run(dvbs2gpu_ctx* ctx, const FecParams& f, uint8_t* d_frames, int nframes, int32_t* d_corr, hipStream_t st) {
+    BchDeviceCode* B;
+    // GF(2^16): t = 8 and 10 use the first 2t syndromes of the same field; tables depend on (m, t) only via t rows
+    int rc = get_bch(ctx, f.bch_m, f.bch_t, &B);
+    if (rc) return rc;
+    if ((rc = ctx->ws_syn.ensure((size_t)nframes * 32 * sizeof(uint16_t)))) return rc;
+    uint16_t* syn = (uint16_t*)ctx->ws_syn.p;
+    HIP_TRY(bch_syndromes_launch(*B, d_frames, f.K / 8, f.K, nframes, syn, st));
+    HIP_TRY(bch_correct_launch(*B, d_frames, f.K / 8, f.K, f.kbch, nframes, syn, d_corr, st));
+    return 0;
+}
+}  // namespace s2
 
 // ---------------------------------------------------------------------------------------------------
 extern "C" {
@@ -226,27 +238,6 @@ int dvbs2gpu_fec_info_get(int rate, int shortframes, dvbs2gpu_modcod_info* out) 
     return DVBS2GPU_OK;
 }
 
-static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, int nframes, int max_trials, int force,
-                    uint8_t* d_hard, int hard_stride, int8_t* d_post, int32_t* d_trials, hipStream_t st) {
-    LdpcDeviceCode* C;
-    int rc = get_ldpc(ctx, f.code_index, &C);
-    if (rc) return rc;
-    int grid = ctx->num_cus * C->blocks_per_cu;
-    if (grid > nframes) grid = nframes;
-    size_t need = (size_t)grid * C->R * C->rec_dwords * sizeof(uint32_t);
-    if ((rc = ctx->ws_msg.ensure(need))) return rc;
-    if (!d_trials) {
-        if ((rc = ctx->ws_misc.ensure((size_t)nframes * 2 * sizeof(int32_t)))) return rc;
-        d_trials = (int32_t*)ctx->ws_misc.p;
-    }
-    if (!d_hard) {
-        if ((rc = ctx->ws_hard.ensure((size_t)nframes * (f.K / 8)))) return rc;
-        d_hard = (uint8_t*)ctx->ws_hard.p; hard_stride = f.K / 8;
-    }
-    HIP_TRY(ldpc_decode_launch(*C, d_llr, nframes, max_trials, force, d_hard, hard_stride, d_post, d_trials,
-                               (uint32_t*)ctx->ws_msg.p, grid, st));
-    return 0;
-}
 
 int dvbs2gpu_ldpc_plan_info(dvbs2gpu_ctx* ctx, int rate, int shortframes, int32_t* out8) {
     if (!ctx || !out8) return DVBS2GPU_ERR_ARG;
@@ -273,17 +264,6 @@ int dvbs2gpu_ldpc_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, con
     return ldpc_run(ctx, f, d_llr, nframes, max_trials, force, d_hard, f.K / 8, d_post, d_trials, (hipStream_t)stream);
 }
 
-static int bch_run(dvbs2gpu_ctx* ctx, const FecParams& f, uint8_t* d_frames, int nframes, int32_t* d_corr, hipStream_t st) {
-    BchDeviceCode* B;
-    // GF(2^16): t = 8 and 10 use the first 2t syndromes of the same field; tables depend on (m, t) only via t rows
-    int rc = get_bch(ctx, f.bch_m, f.bch_t, &B);
-    if (rc) return rc;
-    if ((rc = ctx->ws_syn.ensure((size_t)nframes * 32 * sizeof(uint16_t)))) return rc;
-    uint16_t* syn = (uint16_t*)ctx->ws_syn.p;
-    HIP_TRY(bch_syndromes_launch(*B, d_frames, f.K / 8, f.K, nframes, syn, st));
-    HIP_TRY(bch_correct_launch(*B, d_frames, f.K / 8, f.K, f.kbch, nframes, syn, d_corr, st));
-    return 0;
-}
 
 int dvbs2gpu_bch_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, uint8_t* d_frames, int nframes, int32_t* d_corrections,
                               void* stream) {
@@ -318,15 +298,7 @@ int dvbs2gpu_fec_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, cons
     if (nframes == 0) return 0;
     if (!d_llr || !d_bbframes) return DVBS2GPU_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t st = (hipStream_t)stream;
-    int rc;
-    if ((rc = ctx->ws_hard.ensure((size_t)nframes * (f.K / 8)))) return rc;
-    uint8_t* hard = (uint8_t*)ctx->ws_hard.p;
-    if ((rc = ldpc_run(ctx, f, d_llr, nframes, max_trials, force, hard, f.K / 8, nullptr, d_trials, st))) return rc;
-    if ((rc = bch_run(ctx, f, hard, nframes, d_corrections, st))) return rc;
-    if ((rc = get_prbs(ctx))) return rc;
-    HIP_TRY(bb_descramble_launch(hard, f.K / 8, ctx->d_prbs, f.kbch / 8, nframes, d_bbframes, st));
-    return 0;
+    return fec_run(ctx, f, d_llr, nframes, max_trials, force, d_bbframes, d_trials, d_corrections, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,83 @@
+// Engine context internals shared by capi.hip (FEC entry points) and s2_demod.hip (demodulator handles).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/dvbs2gpu.h"
+#include "s2_params.h"
+#include "ldpc_plan.h"
+#include "kernels.h"
+#include "s2_rx.h"
+
+namespace s2 {
+
+std::string& last_error();
+int fail_hip(hipError_t e, const char* what);
+#define HIP_TRY(x)                                            \
+    do {                                                      \
+        hipError_t _e = (x);                                  \
+        if (_e != hipSuccess) return s2::fail_hip(_e, #x);    \
+    } while (0)
+
+struct Workspace {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t n) {
+        if (n <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        size_t want = n + n / 4;   // grow with slack so alternating sizes do not thrash
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return fail_hip(e, "hipMalloc(workspace)");
+        bytes = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+template <typename T>
+inline int upload(const std::vector<T>& v, T** dptr) {
+    *dptr = nullptr;
+    size_t n = v.size() * sizeof(T);
+    if (!n) n = sizeof(T);
+    HIP_TRY(hipMalloc((void**)dptr, n));
+    if (!v.empty()) HIP_TRY(hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+struct ConstelTables {          // device tables of one constellation (type, gamma1, gamma2)
+    S2ConstelDev dev;
+    int8_t* d_bits = nullptr;
+    float* d_err = nullptr;
+};
+
+}  // namespace s2
+
+struct dvbs2gpu_ctx {
+    int device = 0;
+    int num_cus = 256;
+    std::mutex mtx;
+    std::map<int, s2::LdpcDeviceCode> ldpc;   // by code_index
+    std::map<int, s2::BchDeviceCode> bch;     // by m*100 + t
+    uint8_t* d_prbs = nullptr;                // BB scrambler sequence, 8100 bytes
+    s2::Workspace ws_msg, ws_hard, ws_syn, ws_misc;
+    // receive-chain tables (s2_demod.hip)
+    float* d_gardner_bank = nullptr;
+    s2::S2PlTablesDev pl{};
+    std::map<int, s2::ConstelTables> constel; // by modcod (gammas depend on it)
+    std::map<int, float*> rrc;                // by ntaps*1000 + round(alpha*100) (Ts = 2)
+    s2::Workspace ws_rx[8];
+};
+
+namespace s2 {
+int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out);
+int get_bch(dvbs2gpu_ctx* ctx, int m, int t, BchDeviceCode** out);
+int get_prbs(dvbs2gpu_ctx* ctx);
+// LLR -> BBFRAME for nframes frames of one code; all pointers device
+int fec_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, int nframes, int max_trials, int force, uint8_t* d_bbframes,
+            int32_t* d_trials, int32_t* d_corr, hipStream_t st);
+}  // namespace s2

@@ -1,0 +1,652 @@
+// Host side of the DVB-S2 demodulator handles: the mirror of dsp::dvbs2::DVBS2Demod
+// (reference src/demod/dvbs2/module_dvbs2_demod.{h,cpp}) on top of the kernels in s2_rx_kernels.hip and
+// the FEC launches of capi.hip.  One handle = one transponder stream; a batch call runs the same stage of
+// all streams in one launch and pools their frames for the FEC kernels.
+//
+// Call anatomy (process / process_batch), all on one HIP stream:
+//   1 front end (AGC+NCO+Gardner, lane per stream)            s2_frontend_kernel
+//   2 RRC on the kept samples + /2, append to the symbol FIFO  s2_rrc_decim_kernel        -> D2H symbol counts
+//   3 PL sync: correlate every complete window of every stream s2_plsync_kernel           -> D2H best_pos
+//     host replays S2PLSyncBlock's two-state realign logic (dvbs2_pl_sync.cpp:102-165) on the results;
+//     only when a window is misaligned are the following windows of that stream re-correlated
+//   4 per-frame loops (FED -> NCO feedback, PLL, PLHDR)        s2_frame_loops_kernel
+//   5 soft demap + de-interleave                               s2_demap_kernel
+//   6 LDPC / BCH / descramble over the pooled frames           ldpc_decode_kernel, bch_*, bb_descramble
+//   7 D2H (or D2D for the batch entry point) of BBFRAMEs + stats; FIFO remainder moved to the spare buffer
+#include "ctx.h"
+#include <cmath>
+#include <algorithm>
+#include <memory>
+
+using namespace s2;
+
+namespace {
+
+// ------------------------------------------------------------------------------- host-side table builders
+// (own restatement of the SDR++ tap generators and the reference's constellation / PL constants; the CPU
+//  oracle builds the same tables independently in oracle/s2chain.cpp)
+std::vector<float> make_rrc_taps(int count, double beta, double Ts) {
+    const double PI = 3.14159265358979323846, SQ2 = 1.41421356237309504880;
+    double limit = Ts / (4.0 * beta), half = (double)count / 2.0;
+    std::vector<float> taps(count);
+    for (int i = 0; i < count; i++) {
+        double t = (double)i - half + 0.5, v;
+        if (t == 0.0) v = (1.0 + beta * (4.0 / PI - 1.0)) / Ts;
+        else if (t == limit || t == -limit)
+            v = ((1.0 + 2.0 / PI) * sin(PI / (4.0 * beta)) + (1.0 - 2.0 / PI) * cos(PI / (4.0 * beta))) * beta / (Ts * SQ2);
+        else
+            v = ((sin((1.0 - beta) * PI * t / Ts) + cos((1.0 + beta) * PI * t / Ts) * 4.0 * beta * t / Ts) /
+                 ((1.0 - (4.0 * beta * t / Ts) * (4.0 * beta * t / Ts)) * PI * t / Ts)) / Ts;
+        taps[i] = (float)v;
+    }
+    return taps;
+}
+
+std::vector<float> make_gardner_bank() {   // gardner.cpp:154-159: 128 phases x 8 taps, Nuttall-windowed sinc
+    const double PI = 3.14159265358979323846;
+    const int phases = GARDNER_PHASES, tpp = GARDNER_TAPS, count = phases * tpp;
+    double omega = 2.0 * PI * (0.5 / (double)phases), half = (double)count / 2.0, corr = (double)phases * omega / PI;
+    const double coefs[4] = {0.355768, 0.487396, 0.144232, 0.012604};
+    std::vector<float> bank((size_t)count, 0.f);
+    for (int i = 0; i < count; ++i) {
+        double t = (double)i - half + 0.5, x = t * omega;
+        double sinc = (x == 0.0) ? 1.0 : sin(x) / x;
+        double n = t - half, win = 0.0, sign = 1.0;
+        for (int c = 0; c < 4; ++c) { win += sign * coefs[c] * cos((double)c * 2.0 * PI * n / (double)count); sign = -sign; }
+        bank[(size_t)((phases - 1) - (i % phases)) * tpp + i / phases] = (float)(sinc * win * corr);
+    }
+    return bank;
+}
+
+struct HostConstel {
+    int constel, bits, states;
+    float amp = 1.0f, sca = 50.0f, prescale = 1.0f;
+    cf32 pts[32];
+    static cf32 polar(float r, int n, float i) {
+        float a = i * 2 * M_PI / n;
+        return cf32{r * cosf(a), r * sinf(a)};
+    }
+    static cf32 scale(cf32 a, float s) { return cf32{a.re * s, a.im * s}; }
+    HostConstel(int type, float g1, float g2) : constel(type) {   // constellation.cpp:19-150
+        const double SQ2 = 1.41421356237309504880;
+        if (type == C_QPSK) {
+            states = 4; bits = 2; amp = 3;
+            pts[0] = cf32{(float)-SQ2, (float)-SQ2}; pts[1] = cf32{(float)SQ2, (float)-SQ2};
+            pts[2] = cf32{(float)-SQ2, (float)SQ2}; pts[3] = cf32{(float)SQ2, (float)SQ2};
+        } else if (type == C_8PSK) {
+            states = 8; bits = 3;
+            float r = 0.70710678118654752440;
+            const cf32 p[8] = {{0.0f, -1.0f}, {-r, r}, {r, -r}, {0.0f, 1.0f}, {-r, -r}, {-1.0f, 0.0f}, {1.0f, 0.0f}, {r, r}};
+            for (int i = 0; i < 8; ++i) pts[i] = p[i];
+        } else if (type == C_16APSK) {
+            states = 16; bits = 4; amp = 100; sca = 1; prescale = 0.53;
+            float gamma1 = g1 ? g1 : 2.57f;
+            float r1 = sqrtf(4 / (1 + 3 * gamma1 * gamma1));
+            float r2 = gamma1 * r1;
+            r1 *= 0.5; r2 *= 0.5;
+            const float inner[4] = {2.5f, 1.5f, 3.5f, 0.5f};
+            const float outer[12] = {8.5f, 3.5f, 9.5f, 2.5f, 6.5f, 5.5f, 11.5f, 0.5f, 7.5f, 4.5f, 10.5f, 1.5f};
+            for (int i = 0; i < 4; ++i) pts[i] = scale(polar(r1, 4, inner[i]), amp);
+            for (int i = 0; i < 12; ++i) pts[4 + i] = scale(polar(r2, 12, outer[i]), amp);
+        } else {
+            states = 32; bits = 5; amp = 100; sca = 1; prescale = 0.54;
+            float gamma1 = g1 ? g1 : 2.53f, gamma2 = g2 ? g2 : 4.30f;
+            float r1 = sqrtf(8 / (1 + 3 * gamma1 * gamma1 + 4 * gamma2 * gamma2));
+            float r2 = gamma1 * r1, r3 = gamma2 * r1;
+            r1 *= 0.5; r2 *= 0.5; r3 *= 0.5;
+            struct P { int ring, n; float i; };
+            const P tab[32] = {{3, 16, 10}, {3, 16, 8}, {3, 16, 5}, {3, 16, 7}, {3, 16, 13}, {3, 16, 15}, {3, 16, 2}, {3, 16, 0},
+                               {1, 4, 2.5f}, {2, 12, 6.5f}, {1, 4, 1.5f}, {2, 12, 5.5f}, {1, 4, 3.5f}, {2, 12, 11.5f}, {1, 4, 0.5f}, {2, 12, 0.5f},
+                               {3, 16, 11}, {3, 16, 9}, {3, 16, 4}, {3, 16, 6}, {3, 16, 12}, {3, 16, 14}, {3, 16, 3}, {3, 16, 1},
+                               {2, 12, 8.5f}, {2, 12, 7.5f}, {2, 12, 3.5f}, {2, 12, 4.5f}, {2, 12, 9.5f}, {2, 12, 10.5f}, {2, 12, 2.5f}, {2, 12, 1.5f}};
+            for (int i = 0; i < 32; ++i) {
+                float r = tab[i].ring == 1 ? r1 : (tab[i].ring == 2 ? r2 : r3);
+                pts[i] = scale(polar(r, tab[i].n, tab[i].i), amp);
+            }
+        }
+    }
+    static int8_t clampv(float x) {   // constellation.cpp:263-270
+        while (x < -127 || x > 127) {
+            x *= 0.5;
+            if (!std::isfinite(x)) return (int8_t)x;
+        }
+        return (int8_t)x;
+    }
+    void soft_calc(cf32 sample, int8_t* bits_out, float* phase_err) const {   // constellation.cpp:205-261
+        float tmp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (amp != 1) sample = scale(sample, amp);
+        if (prescale != 1) sample = scale(sample, prescale);
+        float min_dist = std::numeric_limits<float>::max();
+        cf32 closest{0, 0};
+        for (int i = 0; i < states; i++) {
+            float dre = sample.re - pts[i].re, dim = sample.im - pts[i].im;
+            float dist = sqrtf(dre * dre + dim * dim);
+            if (dist < min_dist) { min_dist = dist; closest = pts[i]; }
+            float d = expf(-dist / 1.0f);
+            for (int j = 0; j < bits; j++) {
+                if (((i >> j) & 1) == 0) tmp[2 * j + 0] += d;
+                else tmp[2 * j + 1] += d;
+            }
+        }
+        for (int i = 0; i < bits; i++) bits_out[bits - 1 - i] = clampv((logf(tmp[2 * i + 1]) - logf(tmp[2 * i + 0])) * sca);
+        // sample * conj(closest)
+        float pre = sample.re * closest.re - sample.im * (-closest.im), pim = sample.im * closest.re + sample.re * (-closest.im);
+        *phase_err = atan2f(pim, pre);
+    }
+};
+
+int get_rx_tables(dvbs2gpu_ctx* ctx) {
+    std::lock_guard<std::mutex> l(ctx->mtx);
+    if (ctx->d_gardner_bank) return 0;
+    int rc;
+    if ((rc = upload(make_gardner_bank(), &ctx->d_gardner_bank))) return rc;
+    // SOF / PLSC / Gold sequence (s2_defs.h:15-80, s2_scrambling.cpp:9-28)
+    std::vector<cf32> sof(26), plsc(128 * 64);
+    std::vector<uint64_t> codes(128);
+    const uint32_t VALUE = 0x18d2e82;
+    for (int s = 0; s < 26; ++s) {
+        int bit = (VALUE >> (25 - s)) & 1, angle = bit * 2 + (s & 1);
+        sof[s].re = cosf(M_PI / 4 + 2 * M_PI * angle / 4);
+        sof[s].im = sinf(M_PI / 4 + 2 * M_PI * angle / 4);
+    }
+    const uint32_t G[6] = {0x55555555, 0x33333333, 0x0f0f0f0f, 0x00ff00ff, 0x0000ffff, 0xffffffff};
+    const uint64_t SCR = 0x719d83c953422dfaull;
+    for (int index = 0; index < 128; ++index) {
+        uint32_t y = 0;
+        for (int row = 0; row < 6; ++row)
+            if ((index >> (6 - row)) & 1) y ^= G[row];
+        uint64_t code = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            int yi = (y >> bit) & 1;
+            code = (code << 2) | ((uint64_t)yi << 1) | (uint64_t)((index & 1) ? (yi ^ 1) : yi);
+        }
+        code ^= SCR;
+        codes[index] = code;
+        for (int i = 0; i < 64; ++i) {
+            int yi = (code >> (63 - i)) & 1, nyi = yi ^ (i & 1);
+            plsc[index * 64 + i].re = (1 - 2 * nyi) / sqrtf(2);
+            plsc[index * 64 + i].im = (1 - 2 * yi) / sqrtf(2);
+        }
+    }
+    std::vector<uint8_t> rn(131072, 0);
+    auto lfsr_x = [](uint32_t X) { int bit = ((X >> 7) ^ X) & 1; return ((uint32_t)(bit << 18) | X) >> 1; };
+    auto lfsr_y = [](uint32_t Y) { int bit = ((Y >> 10) ^ (Y >> 7) ^ (Y >> 5) ^ Y) & 1; return ((uint32_t)(bit << 18) | Y) >> 1; };
+    uint32_t stx = 0x00001, sty = 0x3ffff;
+    for (int i = 0; i < 131072; ++i) { rn[i] = (uint8_t)((stx ^ sty) & 1); stx = lfsr_x(stx); sty = lfsr_y(sty); }
+    for (int i = 0; i < 131072; ++i) { rn[i] |= (uint8_t)(((stx ^ sty) & 1) << 1); stx = lfsr_x(stx); sty = lfsr_y(sty); }
+    cf32 *d_sof, *d_plsc; uint64_t* d_codes; uint8_t* d_rn;
+    if ((rc = upload(sof, &d_sof))) return rc;
+    if ((rc = upload(plsc, &d_plsc))) return rc;
+    if ((rc = upload(codes, &d_codes))) return rc;
+    if ((rc = upload(rn, &d_rn))) return rc;
+    ctx->pl.sof = d_sof; ctx->pl.plsc = d_plsc; ctx->pl.plsc_code = d_codes; ctx->pl.rn = d_rn;
+    return 0;
+}
+
+int get_constel(dvbs2gpu_ctx* ctx, const ModcodParams& mp, ConstelTables** out) {
+    std::lock_guard<std::mutex> l(ctx->mtx);
+    int key = mp.constel >= C_16APSK ? 100 + mp.modcod : mp.constel;   // PSK tables do not depend on the MODCOD
+    auto it = ctx->constel.find(key);
+    if (it == ctx->constel.end()) {
+        HostConstel H(mp.constel, mp.g1, mp.g2);
+        ConstelTables T;
+        T.dev.constel = H.constel; T.dev.bits = H.bits; T.dev.states = H.states;
+        T.dev.amp = H.amp; T.dev.sca = H.sca; T.dev.prescale = H.prescale;
+        for (int i = 0; i < 32; ++i) T.dev.pts[i] = i < H.states ? H.pts[i] : cf32{0, 0};
+        T.dev.lut_bits = nullptr; T.dev.lut_err = nullptr;
+        if (H.bits != 5) {   // make_lut(256), constellation.cpp:272-291 -- built with the host libm, uploaded
+            std::vector<int8_t> lb((size_t)65536 * H.bits);
+            std::vector<float> le(65536);
+            for (int x = 0; x < 256; ++x)
+                for (int y = 0; y < 256; ++y) {
+                    float xv = (float(x - 128) / float(256)) * 1.5f, yv = (float(y - 128) / float(256)) * 1.5f;
+                    H.soft_calc(cf32{xv, yv}, &lb[((size_t)x * 256 + y) * H.bits], &le[(size_t)x * 256 + y]);
+                }
+            int rc;
+            if ((rc = upload(lb, &T.d_bits))) return rc;
+            if ((rc = upload(le, &T.d_err))) return rc;
+            T.dev.lut_bits = T.d_bits; T.dev.lut_err = T.d_err;
+        }
+        it = ctx->constel.emplace(key, T).first;
+    }
+    *out = &it->second;
+    return 0;
+}
+
+int get_rrc(dvbs2gpu_ctx* ctx, int ntaps, float alpha, double Ts, float** out) {
+    std::lock_guard<std::mutex> l(ctx->mtx);
+    int key = ntaps * 100000 + (int)lround(alpha * 1000) * 10 + (int)lround(Ts);
+    auto it = ctx->rrc.find(key);
+    if (it == ctx->rrc.end()) {
+        float* d;
+        int rc = upload(make_rrc_taps(ntaps, alpha, Ts), &d);
+        if (rc) return rc;
+        it = ctx->rrc.emplace(key, d).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
+void critically_damped(float bw, float* alpha, float* beta) {   // SDR++ PhaseControlLoop::criticallyDamped
+    double damping = 0.70710678118654752440;
+    double den = 1.0 + 2.0 * damping * bw + (double)bw * bw;
+    *alpha = (float)((4.0 * damping * bw) / den);
+    *beta = (float)((4.0 * (double)bw * bw) / den);
+}
+
+inline size_t fe_capacity(int n) { return (size_t)2 * n + n / 16 + 256; }
+
+}  // namespace
+
+struct dvbs2gpu_demod {
+    dvbs2gpu_ctx* ctx = nullptr;
+    dvbs2gpu_demod_cfg cfg{};
+    ModcodParams mp{};
+    S2LoopCoefs co{};
+    int pls_code = 0;
+    int max_samples = 0;
+    // device
+    S2StreamState* d_state = nullptr;
+    cf32* d_in = nullptr;        // staging for the host-pointer entry point
+    cf32* d_fe = nullptr;        // timing-recovery output + scratch
+    cf32* d_fifo[2] = {nullptr, nullptr};
+    uint8_t* d_out = nullptr;    // staging for the host-pointer entry point
+    int fifo_cap = 0, fifo_cur = 0, fifo_fill = 0;
+    // PL-sync state machine (dvbs2_pl_sync.cpp): 0 = next window starts at fifo[0]; pending_pos > 0 = state 1
+    int pending_pos = 0;
+    float last_best_match = 0.f;
+    // results of the last call
+    std::vector<S2FrameStats> stats;
+    std::vector<const cf32*> frame_ptrs;     // aligned frames of the last call (device pointers into the old FIFO buffer)
+    int tap_sym_off = 0, tap_sym_cnt = 0, tap_fifo = 0;
+    const cf32* tap_pll = nullptr;           // into ctx workspace, valid until the next call on this context
+    const int8_t* tap_llr = nullptr;
+    float nco_freq_host = 0.f;
+};
+
+namespace {
+
+int demod_configure(dvbs2gpu_demod* d) {
+    const dvbs2gpu_demod_cfg& c = d->cfg;
+    if (!modcod_params(c.modcod, c.shortframes, c.pilots, &d->mp)) { last_error() = "unsupported MODCOD"; return DVBS2GPU_ERR_MODCOD; }
+    if (c.rrc_taps < 1 || c.rrc_taps > RRC_MAX_TAPS) { last_error() = "rrc_taps out of range"; return DVBS2GPU_ERR_ARG; }
+    S2LoopCoefs& co = d->co;
+    co.agc_rate = c.agc_rate;
+    co.g_alpha = c.clock_mu_gain; co.g_beta = c.clock_omega_gain;
+    co.g_min_freq = (float)(1.0 * (1.0 - c.omega_rel_limit)); co.g_max_freq = (float)(1.0 * (1.0 + c.omega_rel_limit));
+    critically_damped(c.loop_bw, &co.pll_alpha, &co.pll_beta);
+    co.pll_min_freq = -0.01f * (float)M_PI; co.pll_max_freq = 0.01f * (float)M_PI;
+    critically_damped(c.loop_bw * 0.03f, &co.hdr_alpha, &co.hdr_beta);
+    co.hdr_min_freq = -1.0f * (float)M_PI; co.hdr_max_freq = 1.0f * (float)M_PI;
+    co.fll_bw = c.fll_bw;
+    co.rrc_taps = c.rrc_taps;
+    d->pls_code = c.modcod << 2 | (c.shortframes ? 2 : 0) | (c.pilots ? 1 : 0);
+    return 0;
+}
+
+int demod_reset_state(dvbs2gpu_demod* d) {
+    S2StreamState st;
+    memset(&st, 0, sizeof(st));
+    st.agc_gain = 1.0f;
+    st.g_freq = 1.0f;
+    HIP_TRY(hipMemcpy(d->d_state, &st, sizeof(st), hipMemcpyHostToDevice));
+    d->fifo_fill = 0; d->pending_pos = 0; d->last_best_match = 0.f; d->nco_freq_host = 0.f;
+    return 0;
+}
+
+// Runs one group of streams that share (modcod, shortframes, pilots) and loop coefficients.
+int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts,
+                  uint8_t* const* d_out, int out_cap, int* out_bytes, hipStream_t st) {
+    dvbs2gpu_demod* d0 = dm[0];
+    const ModcodParams& mp = d0->mp;
+    const int raw = mp.plframe, kb = mp.fec.kbch / 8, N = mp.fec.N;
+    int rc;
+    if ((rc = get_rx_tables(ctx))) return rc;
+    ConstelTables* CT;
+    if ((rc = get_constel(ctx, mp, &CT))) return rc;
+    float* d_taps;
+    if ((rc = get_rrc(ctx, d0->cfg.rrc_taps, d0->cfg.rrc_alpha, d0->cfg.samplerate / d0->cfg.symbolrate, &d_taps))) return rc;
+
+    // ---- 1,2: front end + RRC
+    std::vector<S2StreamWork> work(n);
+    int max_count = 0;
+    for (int i = 0; i < n; ++i) {
+        dvbs2gpu_demod* d = dm[i];
+        if (counts[i] < 0 || counts[i] > d->max_samples) { last_error() = "count exceeds max_samples"; return DVBS2GPU_ERR_ARG; }
+        work[i].in = d_iq[i]; work[i].count = counts[i]; work[i].fe_out = d->d_fe;
+        work[i].fifo = d->d_fifo[d->fifo_cur]; work[i].fifo_fill = d->fifo_fill; work[i].st = d->d_state;
+        max_count = std::max(max_count, counts[i]);
+        d->stats.clear(); d->frame_ptrs.clear();
+    }
+    Workspace& ws_work = ctx->ws_rx[0];
+    if ((rc = ws_work.ensure(sizeof(S2StreamWork) * n + sizeof(int) * (n + 1)))) return rc;
+    S2StreamWork* d_work = (S2StreamWork*)ws_work.p;
+    HIP_TRY(hipMemcpyAsync(d_work, work.data(), sizeof(S2StreamWork) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(s2_frontend_launch(d_work, n, d0->co, ctx->d_gardner_bank, st));
+    HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st));
+    // symbol counts back (n_sym sits in each stream's state struct)
+    std::vector<int> nsym(n);
+    for (int i = 0; i < n; ++i)
+        HIP_TRY(hipMemcpyAsync(&nsym[i], &dm[i]->d_state->n_sym, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+
+    // ---- 3: PL sync.  cur[i] = FIFO index where stream i's next window starts.
+    std::vector<int> cur(n, 0), avail(n);
+    std::vector<std::vector<int>> frame_start(n);
+    std::vector<std::vector<float>> frame_bm(n);
+    std::vector<char> active(n, 1);
+    for (int i = 0; i < n; ++i) {
+        dvbs2gpu_demod* d = dm[i];
+        d->tap_sym_off = d->fifo_fill; d->tap_sym_cnt = nsym[i]; d->tap_fifo = d->fifo_cur;
+        d->fifo_fill += nsym[i];
+        avail[i] = d->fifo_fill;
+        if (d->fifo_fill > d->fifo_cap) { last_error() = "symbol FIFO overflow"; return DVBS2GPU_ERR_CAPACITY; }
+        // state 1 carried over from the previous call: the realigned frame starts at pending_pos
+        if (d->pending_pos > 0) {
+            if (avail[i] >= raw + d->pending_pos) {
+                frame_start[i].push_back(d->pending_pos); frame_bm[i].push_back(d->last_best_match);
+                cur[i] = raw + d->pending_pos;
+                d->pending_pos = 0;
+            } else {
+                active[i] = 0;
+            }
+        }
+    }
+    Workspace& ws_win = ctx->ws_rx[1];
+    while (true) {
+        // speculate: every complete window from cur[i] on is aligned
+        std::vector<const cf32*> wins;
+        std::vector<int> win_stream;
+        for (int i = 0; i < n; ++i) {
+            if (!active[i]) continue;
+            const cf32* base = dm[i]->d_fifo[dm[i]->fifo_cur];
+            for (int p = cur[i]; p + raw <= avail[i]; p += raw) { wins.push_back(base + p); win_stream.push_back(i); }
+        }
+        if (wins.empty()) break;
+        const int nw = (int)wins.size();
+        if ((rc = ws_win.ensure(nw * (sizeof(cf32*) + sizeof(int) + sizeof(float))))) return rc;
+        const cf32** d_win = (const cf32**)ws_win.p;
+        int* d_pos = (int*)(d_win + nw);
+        float* d_bm = (float*)(d_pos + nw);
+        HIP_TRY(hipMemcpyAsync(d_win, wins.data(), nw * sizeof(cf32*), hipMemcpyHostToDevice, st));
+        HIP_TRY(s2_plsync_launch(d_win, nw, raw, d_pos, d_bm, st));
+        std::vector<int> pos(nw);
+        std::vector<float> bm(nw);
+        HIP_TRY(hipMemcpyAsync(pos.data(), d_pos, nw * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(bm.data(), d_bm, nw * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::vector<char> again(n, 0);
+        for (int w = 0; w < nw; ++w) {
+            int i = win_stream[w];
+            if (!active[i] || again[i]) continue;   // windows after a realign are stale
+            dvbs2gpu_demod* d = dm[i];
+            d->last_best_match = bm[w];
+            if (pos[w] == 0) {
+                frame_start[i].push_back(cur[i]); frame_bm[i].push_back(bm[w]);
+                cur[i] += raw;
+            } else {
+                // state 0 -> 1: this window is dropped, the next frame is window[pos:] + pos more symbols
+                if (avail[i] >= cur[i] + raw + pos[w]) {
+                    frame_start[i].push_back(cur[i] + pos[w]); frame_bm[i].push_back(bm[w]);
+                    cur[i] += raw + pos[w];
+                    again[i] = 1;
+                } else {
+                    // not enough symbols yet: keep the window at the FIFO head and wait (state 1)
+                    d->pending_pos = pos[w];
+                    active[i] = 0;
+                }
+            }
+        }
+        bool any = false;
+        for (int i = 0; i < n; ++i) {
+            if (!again[i]) active[i] = 0;   // all its windows consumed
+            else any = true;
+        }
+        if (!any) break;
+    }
+
+    // ---- 4..6 on the pooled frames
+    std::vector<S2FrameRef> frames;
+    std::vector<int> first(n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+        first[i] = (int)frames.size();
+        const cf32* base = dm[i]->d_fifo[dm[i]->fifo_cur];
+        for (int s : frame_start[i]) { frames.push_back(S2FrameRef{base + s, i, 0}); dm[i]->frame_ptrs.push_back(base + s); }
+    }
+    first[n] = (int)frames.size();
+    const int nf = (int)frames.size();
+    std::vector<S2FrameStats> hstats(nf);
+    std::vector<int32_t> trials(nf), corr(nf);
+    uint8_t* d_bb = nullptr;
+    if (nf > 0) {
+        Workspace& ws_fr = ctx->ws_rx[2];
+        if ((rc = ws_fr.ensure(sizeof(S2FrameRef) * nf + sizeof(S2FrameStats) * nf + sizeof(int32_t) * 2 * nf + 64))) return rc;
+        S2FrameRef* d_frames = (S2FrameRef*)ws_fr.p;
+        S2FrameStats* d_stats = (S2FrameStats*)(d_frames + nf);
+        int32_t* d_trials = (int32_t*)(d_stats + nf);
+        int32_t* d_corr = d_trials + nf;
+        int* d_first = (int*)((char*)ws_work.p + sizeof(S2StreamWork) * n);
+        Workspace &ws_pll = ctx->ws_rx[3], &ws_llr = ctx->ws_rx[4], &ws_bb = ctx->ws_rx[5];
+        if ((rc = ws_pll.ensure((size_t)nf * raw * sizeof(cf32)))) return rc;
+        if ((rc = ws_llr.ensure((size_t)nf * N))) return rc;
+        if ((rc = ws_bb.ensure((size_t)nf * kb))) return rc;
+        cf32* d_pll = (cf32*)ws_pll.p;
+        int8_t* d_llr = (int8_t*)ws_llr.p;
+        d_bb = (uint8_t*)ws_bb.p;
+        HIP_TRY(hipMemcpyAsync(d_frames, frames.data(), sizeof(S2FrameRef) * nf, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_first, first.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, st));
+        HIP_TRY(s2_frame_loops_launch(d_work, n, d_frames, d_first, d0->co, ctx->pl, CT->dev, d0->pls_code, mp.slots, mp.pilots,
+                                      mp.pilot_blocks, raw, d_pll, d_stats, st));
+        HIP_TRY(s2_demap_launch(CT->dev, mp.rate, mp.shortframe, mp.slots, mp.pilots, raw, d_pll, nf, d_llr, N, st));
+        const int force = d0->cfg.force_ldpc_iters > 0;
+        const int mt = force ? d0->cfg.force_ldpc_iters : d0->cfg.max_ldpc_trials;
+        // keep a copy of the demapper output for the tap before LDPC consumes it? LDPC does not modify d_llr.
+        if ((rc = fec_run(ctx, mp.fec, d_llr, nf, mt, force, d_bb, d_trials, d_corr, st))) return rc;
+        HIP_TRY(hipMemcpyAsync(hstats.data(), d_stats, sizeof(S2FrameStats) * nf, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(trials.data(), d_trials, sizeof(int32_t) * nf, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(corr.data(), d_corr, sizeof(int32_t) * nf, hipMemcpyDeviceToHost, st));
+        for (int i = 0; i < n; ++i) {
+            int cnt = first[i + 1] - first[i];
+            dm[i]->tap_pll = d_pll + (size_t)first[i] * raw;
+            dm[i]->tap_llr = d_llr + (size_t)first[i] * N;
+            int bytes = cnt * kb;
+            if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
+            if (bytes) HIP_TRY(hipMemcpyAsync(d_out[i], d_bb + (size_t)first[i] * kb, bytes, hipMemcpyDeviceToDevice, st));
+            out_bytes[i] = bytes;
+        }
+    } else {
+        for (int i = 0; i < n; ++i) { out_bytes[i] = 0; dm[i]->tap_pll = nullptr; dm[i]->tap_llr = nullptr; }
+    }
+    // ---- 7: FIFO remainder to the spare buffer, NCO frequency for the getter
+    for (int i = 0; i < n; ++i) {
+        dvbs2gpu_demod* d = dm[i];
+        int rem = d->fifo_fill - cur[i];
+        if (cur[i] > 0) {
+            if (rem > 0)
+                HIP_TRY(hipMemcpyAsync(d->d_fifo[d->fifo_cur ^ 1], d->d_fifo[d->fifo_cur] + cur[i], (size_t)rem * sizeof(cf32),
+                                       hipMemcpyDeviceToDevice, st));
+            d->fifo_cur ^= 1;
+            d->fifo_fill = rem;
+        }
+        HIP_TRY(hipMemcpyAsync(&d->nco_freq_host, &d->d_state->nco_freq, sizeof(float), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < n; ++i) {
+        for (int f = first[i]; f < first[i + 1]; ++f) {
+            S2FrameStats s = hstats[f];
+            s.best_match = frame_bm[i][f - first[i]];
+            s.ldpc_trials = trials[f]; s.bch_corr = corr[f];
+            dm[i]->stats.push_back(s);
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void dvbs2gpu_demod_default_cfg(int modcod, int shortframes, int pilots, dvbs2gpu_demod_cfg* c) {   // main.cpp:64-73,134-140
+    c->symbolrate = 27.5e6; c->samplerate = 55e6;
+    c->agc_rate = 0.0001f; c->rrc_alpha = 0.35f; c->rrc_taps = 65; c->loop_bw = 0.00628f; c->fll_bw = 0.006f;
+    float bw = 0.00628f, damp = 0.707f;
+    float den = (1.0f + 2.0 * damp * bw + bw * bw);
+    c->clock_mu_gain = (4.0f * damp * bw) / den;
+    c->clock_omega_gain = (4.0f * bw * bw) / den;
+    c->omega_rel_limit = 0.02f;
+    c->modcod = modcod; c->shortframes = shortframes; c->pilots = pilots;
+    c->sof_threshold = 0.6f; c->max_ldpc_trials = 16; c->force_ldpc_iters = 0;
+}
+
+int dvbs2gpu_demod_create(dvbs2gpu_ctx* ctx, const dvbs2gpu_demod_cfg* cfg, int max_samples, dvbs2gpu_demod** out) {
+    if (!ctx || !cfg || !out || max_samples < 16) return DVBS2GPU_ERR_ARG;
+    *out = nullptr;
+    std::unique_ptr<dvbs2gpu_demod> d(new dvbs2gpu_demod());
+    d->ctx = ctx; d->cfg = *cfg; d->max_samples = max_samples;
+    int rc = demod_configure(d.get());
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMalloc((void**)&d->d_state, sizeof(S2StreamState)));
+    HIP_TRY(hipMalloc((void**)&d->d_in, (size_t)max_samples * sizeof(cf32)));
+    HIP_TRY(hipMalloc((void**)&d->d_fe, fe_capacity(max_samples) * sizeof(cf32)));
+    // FIFO: leftover (< 2 PLFRAMEs, the largest one) + the symbols of one call
+    d->fifo_cap = max_samples / 2 + max_samples / 32 + 2 * 33282 + 1024;
+    for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void**)&d->d_fifo[k], (size_t)d->fifo_cap * sizeof(cf32)));
+    int max_frames = d->fifo_cap / 3330 + 2;
+    HIP_TRY(hipMalloc((void**)&d->d_out, (size_t)max_frames * 8100));
+    if ((rc = demod_reset_state(d.get()))) return rc;
+    *out = d.release();
+    return DVBS2GPU_OK;
+}
+
+void dvbs2gpu_demod_destroy(dvbs2gpu_demod* d) {
+    if (!d) return;
+    (void)hipSetDevice(d->ctx->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(d->d_state); (void)hipFree(d->d_in); (void)hipFree(d->d_fe);
+    (void)hipFree(d->d_fifo[0]); (void)hipFree(d->d_fifo[1]); (void)hipFree(d->d_out);
+    delete d;
+}
+
+int dvbs2gpu_demod_reset(dvbs2gpu_demod* d) {
+    if (!d) return DVBS2GPU_ERR_ARG;
+    HIP_TRY(hipSetDevice(d->ctx->device));
+    return demod_reset_state(d);
+}
+
+int dvbs2gpu_demod_set_params(dvbs2gpu_demod* d, int modcod, int shortframes, int pilots, float sof_threshold, int max_ldpc_trials) {
+    if (!d) return DVBS2GPU_ERR_ARG;
+    dvbs2gpu_demod_cfg saved = d->cfg;
+    d->cfg.modcod = modcod; d->cfg.shortframes = shortframes; d->cfg.pilots = pilots;
+    d->cfg.sof_threshold = sof_threshold; d->cfg.max_ldpc_trials = max_ldpc_trials;
+    int rc = demod_configure(d);
+    if (rc) { d->cfg = saved; (void)demod_configure(d); return rc; }
+    // setDemodParams restarts the PL sync buffer (dvbs2_pl_sync.cpp:51-79); loops keep running
+    d->fifo_fill = 0; d->pending_pos = 0;
+    return 0;
+}
+
+int dvbs2gpu_demod_get_kbch(dvbs2gpu_demod* d) { return d ? d->mp.fec.kbch : DVBS2GPU_ERR_ARG; }
+
+int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const float* const* d_iq, const int* counts,
+                                 uint8_t* const* d_out, int out_cap, int* out_bytes) {
+    if (!demods || n <= 0 || !d_iq || !counts || !d_out || !out_bytes) return DVBS2GPU_ERR_ARG;
+    dvbs2gpu_ctx* ctx = demods[0]->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    // group streams that share a configuration (order inside a group = caller's order)
+    std::vector<char> done(n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (done[i]) continue;
+        std::vector<int> idx;
+        for (int k = i; k < n; ++k) {
+            if (done[k] || demods[k]->ctx != ctx) continue;
+            const dvbs2gpu_demod_cfg &a = demods[i]->cfg, &b = demods[k]->cfg;
+            if (memcmp(&a, &b, sizeof(a)) == 0) { idx.push_back(k); done[k] = 1; }
+        }
+        std::vector<dvbs2gpu_demod*> g;
+        std::vector<const cf32*> gi;
+        std::vector<int> gc, gb(idx.size());
+        std::vector<uint8_t*> go;
+        for (int k : idx) { g.push_back(demods[k]); gi.push_back((const cf32*)d_iq[k]); gc.push_back(counts[k]); go.push_back(d_out[k]); }
+        int rc = process_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), nullptr);
+        if (rc) return rc;
+        for (size_t k = 0; k < idx.size(); ++k) out_bytes[idx[k]] = gb[k];
+    }
+    return 0;
+}
+
+int dvbs2gpu_demod_process(dvbs2gpu_demod* d, int count, const float* h_iq, uint8_t* h_out, int out_cap) {
+    if (!d || count < 0 || (count > 0 && !h_iq) || !h_out) return DVBS2GPU_ERR_ARG;
+    if (count > d->max_samples) { last_error() = "count exceeds max_samples"; return DVBS2GPU_ERR_ARG; }
+    HIP_TRY(hipSetDevice(d->ctx->device));
+    if (count) HIP_TRY(hipMemcpy(d->d_in, h_iq, (size_t)count * sizeof(cf32), hipMemcpyHostToDevice));
+    const cf32* in = d->d_in;
+    uint8_t* dout = d->d_out;
+    int bytes = 0;
+    int cap = (d->fifo_cap / d->mp.plframe + 2) * (d->mp.fec.kbch / 8);
+    dvbs2gpu_demod* dd = d;
+    int rc = process_group(d->ctx, &dd, 1, &in, &count, &dout, cap, &bytes, nullptr);
+    if (rc) return rc;
+    if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
+    if (bytes) HIP_TRY(hipMemcpy(h_out, d->d_out, bytes, hipMemcpyDeviceToHost));
+    return bytes;
+}
+
+int dvbs2gpu_demod_get_stats(dvbs2gpu_demod* d, dvbs2gpu_frame_stats* h_out, int cap) {
+    if (!d) return DVBS2GPU_ERR_ARG;
+    int n = (int)d->stats.size();
+    static_assert(sizeof(dvbs2gpu_frame_stats) == sizeof(S2FrameStats), "stats layout");
+    if (h_out) memcpy(h_out, d->stats.data(), sizeof(S2FrameStats) * std::min(n, cap));
+    return n;
+}
+
+float dvbs2gpu_demod_get_nco_freq(dvbs2gpu_demod* d) { return d ? d->nco_freq_host : 0.f; }
+
+int dvbs2gpu_demod_get_tap(dvbs2gpu_demod* d, int which, void* h_dst, int cap) {
+    if (!d) return DVBS2GPU_ERR_ARG;
+    HIP_TRY(hipSetDevice(d->ctx->device));
+    const int raw = d->mp.plframe, N = d->mp.fec.N, nf = (int)d->frame_ptrs.size();
+    switch (which) {
+        case 0: {
+            int n = d->tap_sym_cnt;
+            if (h_dst && n) HIP_TRY(hipMemcpy(h_dst, d->d_fifo[d->tap_fifo] + d->tap_sym_off, sizeof(cf32) * std::min(n, cap), hipMemcpyDeviceToHost));
+            return n;
+        }
+        case 1: {
+            int n = nf * raw;
+            if (h_dst)
+                for (int f = 0; f < nf && (f + 1) * raw <= cap; ++f)
+                    HIP_TRY(hipMemcpy((cf32*)h_dst + (size_t)f * raw, d->frame_ptrs[f], sizeof(cf32) * raw, hipMemcpyDeviceToHost));
+            return n;
+        }
+        case 2: {
+            int n = nf * raw;
+            if (h_dst && n && d->tap_pll) HIP_TRY(hipMemcpy(h_dst, d->tap_pll, sizeof(cf32) * std::min(n, cap), hipMemcpyDeviceToHost));
+            return n;
+        }
+        case 3: {
+            int n = nf * N;
+            if (h_dst && n && d->tap_llr) HIP_TRY(hipMemcpy(h_dst, d->tap_llr, (size_t)std::min(n, cap), hipMemcpyDeviceToHost));
+            return n;
+        }
+    }
+    return DVBS2GPU_ERR_ARG;
+}
+
+int dvbs2gpu_demap_batch(dvbs2gpu_ctx* ctx, int modcod, int shortframes, int pilots, const float* d_frames, int nframes,
+                         int8_t* d_llr, void* stream) {
+    if (!ctx || nframes < 0) return DVBS2GPU_ERR_ARG;
+    ModcodParams mp;
+    if (!modcod_params(modcod, shortframes, pilots, &mp)) { last_error() = "unsupported MODCOD"; return DVBS2GPU_ERR_MODCOD; }
+    if (nframes == 0) return 0;
+    if (!d_frames || !d_llr) return DVBS2GPU_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    ConstelTables* CT;
+    int rc = get_constel(ctx, mp, &CT);
+    if (rc) return rc;
+    HIP_TRY(s2_demap_launch(CT->dev, mp.rate, mp.shortframe, mp.slots, mp.pilots, mp.plframe, (const cf32*)d_frames, nframes, d_llr,
+                            mp.fec.N, (hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"

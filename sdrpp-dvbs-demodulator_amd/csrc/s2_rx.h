@@ -1,0 +1,92 @@
+// Device-side data structures + launch prototypes of the DVB-S2 receive chain (front end, PL sync,
+// PLL/PLHDR/FED frame loops, soft demapper).  Kernels: s2_rx_kernels.hip; host orchestration: s2_demod.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace s2 {
+
+struct cf32 { float re, im; };
+
+constexpr int RRC_MAX_TAPS = 129;
+constexpr int GARDNER_PHASES = 128;
+constexpr int GARDNER_TAPS = 8;
+
+// Loop state of one stream, device resident.  Field-for-field the state the reference keeps in
+// FastAGC / FreqShift / Gardner (+PCL) / FIR / cr_samp / S2PLLBlock::pcl / S2PLHDRDemod::pcl.
+struct S2StreamState {
+    float agc_gain;
+    float nco_phase, nco_freq;
+    float g_phase, g_freq;
+    int g_offset, g_spsctr;
+    cf32 g_hist[GARDNER_TAPS - 1];
+    int cr_samp;
+    cf32 rrc_hist[RRC_MAX_TAPS - 1];
+    float pll_phase, pll_freq;
+    float hdr_phase, hdr_freq;
+    int n_fe_out;     // outputs of the timing-recovery stage in the last call
+    int n_sym;        // symbols appended to the PL-sync FIFO in the last call
+};
+
+// loop coefficients shared by all streams of one configuration
+struct S2LoopCoefs {
+    float agc_rate;
+    float g_alpha, g_beta, g_min_freq, g_max_freq;    // Gardner PCL: alpha = mu gain, beta = omega gain
+    float pll_alpha, pll_beta, pll_min_freq, pll_max_freq;
+    float hdr_alpha, hdr_beta, hdr_min_freq, hdr_max_freq;
+    float fll_bw;
+    int rrc_taps;
+};
+
+// per-call work description of one stream (array in device memory, one entry per stream of the batch)
+struct S2StreamWork {
+    const cf32* in;          // 2-sps input of this call
+    int count;
+    cf32* fe_out;            // timing-recovery output (capacity count + 8)
+    cf32* fifo;              // PL-sync symbol FIFO
+    int fifo_fill;           // symbols already in the FIFO before this call
+    S2StreamState* st;
+};
+
+// one aligned PLFRAME found by PL sync
+struct S2FrameRef {
+    const cf32* sym;         // plframe symbols
+    int stream;              // index into the batch
+    int pad;
+};
+
+struct S2FrameStats {        // == dvbs2gpu_frame_stats
+    float best_match;
+    int detected_modcod, detected_short, detected_pilots;
+    float fed_err;
+    int ldpc_trials, bch_corr;
+};
+
+// tables of one (constellation, gamma) pair
+struct S2ConstelDev {
+    int constel, bits, states;
+    float amp, sca, prescale;
+    const int8_t* lut_bits;    // [256][256][bits]   (null for 32APSK)
+    const float* lut_err;      // [256][256]
+    cf32 pts[32];
+};
+
+struct S2PlTablesDev {
+    const cf32* sof;           // [26]
+    const cf32* plsc;          // [128][64]
+    const uint64_t* plsc_code; // [128]
+    const uint8_t* rn;         // [131072]
+};
+
+hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCoefs coefs, const float* d_bank, hipStream_t st);
+hipError_t s2_rrc_decim_launch(const S2StreamWork* d_work, int nstreams, int max_count, const float* d_taps, int ntaps, hipStream_t st);
+// windows: d_win[w] = pointer to raw symbols of candidate window w; outputs best_pos / best_match per window
+hipError_t s2_plsync_launch(const cf32* const* d_win, int nwin, int raw, int* d_best_pos, float* d_best_match, hipStream_t st);
+// per-stream frame loops: frames of stream s are d_frames[first[s] .. first[s+1])
+hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const S2FrameRef* d_frames, const int* d_first,
+                                 S2LoopCoefs coefs, S2PlTablesDev tabs, S2ConstelDev con, int pls_code, int slots, int pilots,
+                                 int pilot_blocks, int plframe, cf32* d_pllout, S2FrameStats* d_stats, hipStream_t st);
+hipError_t s2_demap_launch(S2ConstelDev con, int rate, int shortframe, int slots, int pilots, int plframe, const cf32* d_pllout,
+                           int nframes, int8_t* d_llr, int N, hipStream_t st);
+
+}  // namespace s2

@@ -111,3 +111,136 @@ def bits_to_llr(bits, snr_db, rng, scale=None, mod='bpsk'):
         scale = 8.0
     l = np.clip(np.rint(y * scale * 2 / (sigma * sigma) / 8.0), -127, 127)
     return l.astype(np.int8)
+
+
+# ------------------------------------------------------------------------------- DVB-S2 chain (oracle/s2chain.cpp)
+class DemodCfg(C.Structure):
+    """Same layout as dvbs2gpu_demod_cfg (include/dvbs2gpu.h) and orc::DemodCfg."""
+    _fields_ = [('symbolrate', C.c_double), ('samplerate', C.c_double), ('agc_rate', C.c_float), ('rrc_alpha', C.c_float),
+                ('rrc_taps', C.c_int), ('loop_bw', C.c_float), ('fll_bw', C.c_float), ('clock_omega_gain', C.c_float),
+                ('clock_mu_gain', C.c_float), ('omega_rel_limit', C.c_float), ('modcod', C.c_int), ('shortframes', C.c_int),
+                ('pilots', C.c_int), ('sof_threshold', C.c_float), ('max_ldpc_trials', C.c_int), ('force_ldpc_iters', C.c_int)]
+
+
+class TxCfg(C.Structure):
+    _fields_ = [('modcod', C.c_int), ('shortframes', C.c_int), ('pilots', C.c_int), ('nframes', C.c_int), ('seed', C.c_uint64),
+                ('esn0_db', C.c_double), ('cfo', C.c_double), ('timing', C.c_double), ('phase0', C.c_double), ('lead_symbols', C.c_int)]
+
+
+class FrameStats(C.Structure):
+    _fields_ = [('best_match', C.c_float), ('detect_modcod', C.c_int), ('detect_short', C.c_int), ('detect_pilots', C.c_int),
+                ('fed_err', C.c_float), ('ldpc_trials', C.c_int), ('bch_corr', C.c_int)]
+
+
+def _bind_chain():
+    L = lib()
+    if getattr(L, '_chain_bound', False):
+        return L
+    L.orc_default_cfg.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(DemodCfg)]
+    L.orc_default_cfg.restype = None
+    L.orc_s2rx_create.argtypes = [C.POINTER(DemodCfg)]
+    L.orc_s2rx_create.restype = C.c_void_p
+    L.orc_s2rx_destroy.argtypes = [C.c_void_p]
+    L.orc_s2rx_destroy.restype = None
+    L.orc_s2rx_reset.argtypes = [C.c_void_p]
+    L.orc_s2rx_process.argtypes = [C.c_void_p, C.c_int, _f32p, _u8p, C.c_int]
+    L.orc_s2rx_tap.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_s2rx_nco_freq.argtypes = [C.c_void_p]
+    L.orc_s2rx_nco_freq.restype = C.c_float
+    for name in ('orc_s2rx_agc', 'orc_s2rx_nco', 'orc_s2rx_rrc'):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_int, _f32p, _f32p]
+        getattr(L, name).restype = None
+    L.orc_s2rx_gardner.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p]
+    L.orc_s2rx_fed.argtypes = [C.c_void_p, _f32p]
+    L.orc_s2rx_fed.restype = C.c_float
+    L.orc_s2rx_pll.argtypes = [C.c_void_p, _f32p, _f32p]
+    L.orc_s2rx_pll.restype = None
+    L.orc_s2rx_plhdr.argtypes = [C.c_void_p, _f32p, _f32p, _i32p]
+    L.orc_s2rx_plhdr.restype = None
+    L.orc_s2rx_to_soft.argtypes = [C.c_void_p, _f32p, _i8p]
+    L.orc_s2rx_to_soft.restype = None
+    L.orc_s2_transmit.argtypes = [C.POINTER(TxCfg), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_constellation_lut.argtypes = [C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_constellation_soft_calc.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, _f32p, _i8p, _f32p]
+    L.orc_constellation_soft_calc.restype = None
+    L.orc_constellation_points.argtypes = [C.c_int, C.c_float, C.c_float, _f32p]
+    L.orc_constellation_points.restype = None
+    L.orc_s2_deinterleave.argtypes = [C.c_int, C.c_int, C.c_int, _i8p, _i8p]
+    L.orc_s2_deinterleave.restype = None
+    L.orc_pl_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_pl_tables.restype = None
+    L.orc_rrc_taps.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, _f32p]
+    L.orc_rrc_taps.restype = None
+    L.orc_gardner_bank.argtypes = [_f32p]
+    L.orc_gardner_bank.restype = None
+    L._chain_bound = True
+    return L
+
+
+def default_cfg(modcod, short=0, pilots=0, **kw):
+    L = _bind_chain()
+    c = DemodCfg()
+    L.orc_default_cfg(modcod, short, pilots, C.byref(c))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def modcod_params(modcod, short=0, pilots=0):
+    out = np.zeros(8, np.int32)
+    g = np.zeros(2, np.float32)
+    if lib().orc_modcod_params(modcod, short, pilots, out, g) != 0:
+        return None
+    keys = ['constel', 'bits', 'rate', 'slots', 'pilot_blocks', 'plframe', 'N', 'kbch']
+    d = dict(zip(keys, [int(x) for x in out]))
+    d['g1'], d['g2'] = float(g[0]), float(g[1])
+    return d
+
+
+def transmit(modcod, short=0, pilots=0, nframes=2, seed=1, esn0_db=200.0, cfo=0.0, timing=0.0, phase0=0.0, lead_symbols=0):
+    """-> (iq complex64 [n], bbframes uint8 [nframes, kbch/8], symbols complex64)"""
+    L = _bind_chain()
+    t = TxCfg(modcod, short, pilots, nframes, seed, esn0_db, cfo, timing, phase0, lead_symbols)
+    mp = modcod_params(modcod, short, pilots)
+    nsym = lead_symbols + nframes * mp['plframe']
+    iq = np.zeros(2 * nsym, np.complex64)
+    bb = np.zeros((nframes, mp['kbch'] // 8), np.uint8)
+    syms = np.zeros(nsym, np.complex64)
+    n = L.orc_s2_transmit(C.byref(t), iq.ctypes.data, iq.size, bb.ctypes.data, syms.ctypes.data, syms.size)
+    assert n == iq.size, (n, iq.size)
+    return iq, bb, syms
+
+
+class OracleRx:
+    def __init__(self, cfg):
+        self.L = _bind_chain()
+        self.cfg = cfg
+        self.h = self.L.orc_s2rx_create(C.byref(cfg))
+        assert self.h
+        self.mp = modcod_params(cfg.modcod, cfg.shortframes, cfg.pilots)
+
+    def __del__(self):
+        if getattr(self, 'h', None):
+            self.L.orc_s2rx_destroy(self.h)
+            self.h = None
+
+    def process(self, iq):
+        iq = np.ascontiguousarray(iq, np.complex64)
+        cap = (iq.size // (2 * self.mp['plframe']) + 3) * (self.mp['kbch'] // 8)
+        out = np.zeros(cap, np.uint8)
+        n = self.L.orc_s2rx_process(self.h, iq.size, iq.view(np.float32), out, cap)
+        return out[:n].reshape(-1, self.mp['kbch'] // 8)
+
+    def tap(self, which):
+        n = self.L.orc_s2rx_tap(self.h, which, None)
+        if which in (0, 1, 2):
+            a = np.zeros(n, np.complex64)
+        elif which == 3:
+            a = np.zeros(n, np.int8)
+        else:
+            a = (FrameStats * n)()
+            self.L.orc_s2rx_tap(self.h, which, C.cast(a, C.c_void_p))
+            return list(a)
+        if n:
+            self.L.orc_s2rx_tap(self.h, which, a.ctypes.data)
+        return a
