@@ -80,6 +80,12 @@ int dvbs2gpu_ldpc_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, con
  *         CUs, Tanner edges, layers with intra-layer shared bits}. */
 int dvbs2gpu_ldpc_plan_info(dvbs2gpu_ctx* ctx, int rate, int shortframes, int32_t* out8);
 
+/* Host-only dump of the decoder plan (no GPU needed; used by the CPU test-suite to check the intra-layer
+ * ordering against the reference's sequential row order).  Call with NULL arrays to get the counts:
+ * counts3 = {layers, link entries, per-row words}.  layers4: 4 uint32 per layer {first entry, degree,
+ * depth | nc<<16, first row word}; ents: sp | r<<16; rows: level | late<<8 | early<<20 (ldpc_plan.h). */
+int dvbs2gpu_ldpc_plan_dump(int rate, int shortframes, uint32_t* layers4, uint32_t* ents, uint32_t* rows, int32_t* counts3);
+
 /* replaces BBFrameBCH::decode (bbframe_bch.cpp:380-405).  d_frames [nframes][K/8] corrected in place;
  * d_corrections [nframes] int32: #bits corrected, 0 clean, -1 uncorrectable (frame left untouched). */
 int dvbs2gpu_bch_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, uint8_t* d_frames, int nframes,

@@ -50,6 +50,19 @@ int orc_ldpc_edges(int rate, int shortframe) {
     return QC_CODES[f.code_index].edges;
 }
 
+// the reference-order parity-check structure: for layer-major row rho = 360*i + j the ascending list of
+// information bits (layered_decoder.hh:99-119).  out: R x CNL uint16, cnt: R counts.  Returns CNL.
+int orc_ldpc_rows(int rate, int shortframe, uint16_t* out, uint8_t* cnt) {
+    s2::FecParams f;
+    if (!s2::fec_params(rate, shortframe, &f)) return -2;
+    const LdpcCode& C = ldpc_code(f.code_index);
+    if (out) memcpy(out, C.pos.data(), C.pos.size() * sizeof(uint16_t));
+    if (cnt)
+        for (int i = 0; i < C.q; ++i)
+            for (int j = 0; j < 360; ++j) cnt[360 * i + j] = C.cnc[i];
+    return C.CNL;
+}
+
 int orc_ldpc_decode(int rate, int shortframe, int8_t* frame, int max_trials, int force) {
     s2::FecParams f;
     if (!s2::fec_params(rate, shortframe, &f)) return -2;

@@ -239,6 +239,18 @@ int dvbs2gpu_fec_info_get(int rate, int shortframes, dvbs2gpu_modcod_info* out) 
 }
 
 
+int dvbs2gpu_ldpc_plan_dump(int rate, int shortframes, uint32_t* layers4, uint32_t* ents, uint32_t* rows, int32_t* counts3) {
+    FecParams f;
+    if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
+    if (!counts3) return DVBS2GPU_ERR_ARG;
+    LdpcPlan P = build_ldpc_plan(f.code_index);
+    counts3[0] = (int32_t)P.layers.size(); counts3[1] = (int32_t)P.ents.size(); counts3[2] = (int32_t)P.rows.size();
+    if (layers4) memcpy(layers4, P.layers.data(), P.layers.size() * sizeof(LdpcLayerDesc));
+    if (ents) memcpy(ents, P.ents.data(), P.ents.size() * sizeof(uint32_t));
+    if (rows) memcpy(rows, P.rows.data(), P.rows.size() * sizeof(uint32_t));
+    return 0;
+}
+
 int dvbs2gpu_ldpc_plan_info(dvbs2gpu_ctx* ctx, int rate, int shortframes, int32_t* out8) {
     if (!ctx || !out8) return DVBS2GPU_ERR_ARG;
     FecParams f;

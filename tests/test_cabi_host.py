@@ -1,0 +1,122 @@
+"""CPU-side checks of the shipped library: every symbol of include/dvbs2gpu.h is exported, the static
+queries work without a GPU, the engine refuses to run without one (no CPU fallback), and the LDPC plan's
+intra-layer ordering is consistent with the reference's sequential row order."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, 'include', 'dvbs2gpu.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(dvbs2gpu_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.load_library()
+    names = header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), n
+    # and the ctypes prototype table covers the header
+    assert set(names) <= set(pkg.PROTOTYPES)
+
+
+def test_static_queries_without_gpu(pkg):
+    mi = pkg.modcod_info(14, False, False)
+    assert (mi['plframe_symbols'], mi['ldpc_n'], mi['ldpc_k'], mi['kbch'], mi['ldpc_edges'], mi['bch_t']) == (21690, 64800, 48600, 48408, 226799, 12)
+    assert pkg.modcod_info(4)['plframe_symbols'] == 32490
+    assert pkg.modcod_info(27, True, True)['plframe_symbols'] == 3402       # 36 slots + 2 pilot blocks
+    for bad in (0, -1, 29, 100):
+        with pytest.raises(pkg.Dvbs2GpuError) as e:
+            pkg.modcod_info(bad)
+        assert e.value.code == -2                                              # reference throws here (modcod_to_cfg.cpp:11,135)
+    with pytest.raises(pkg.Dvbs2GpuError):
+        pkg.modcod_info(11, True)                                              # short 9/10 has no table
+    for modcod in range(1, 29):
+        for short in (0, 1):
+            o = orc.modcod_params(modcod, short, 1)
+            if o is None:
+                continue
+            g = pkg.modcod_info(modcod, bool(short), True)
+            assert (g['constellation'], g['bits_per_symbol'], g['rate'], g['slots'], g['pilot_blocks'], g['plframe_symbols'], g['ldpc_n'], g['kbch']) == \
+                   (o['constel'], o['bits'], o['rate'], o['slots'], o['pilot_blocks'], o['plframe'], o['N'], o['kbch'])
+
+
+def test_no_cpu_fallback(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    h = C.c_void_p()
+    rc = pkg.load_library().dvbs2gpu_create(0, C.byref(h))
+    assert rc == -4 and not h.value
+    with pytest.raises(pkg.Dvbs2GpuError):
+        pkg.Engine(0)
+
+
+@pytest.mark.parametrize('rate,short', orc.ALL_CODES)
+def test_ldpc_plan_matches_reference_row_order(pkg, rate, short):
+    lib = pkg.load_library()
+    cnt = (C.c_int32 * 3)()
+    assert lib.dvbs2gpu_ldpc_plan_dump(rate, short, None, None, None, cnt) == 0
+    nl, ne, nr = list(cnt)
+    layers = np.zeros((nl, 4), np.uint32); ents = np.zeros(ne, np.uint32); rows = np.zeros(max(nr, 1), np.uint32)
+    assert lib.dvbs2gpu_ldpc_plan_dump(rate, short, layers.ctypes.data, ents.ctypes.data, rows.ctypes.data, cnt) == 0
+    p = orc.fec_params(rate, short)
+    R = p['N'] - p['K']
+    q = R // 360
+    assert nl == q
+    pos = np.zeros((R, 64), np.uint16)
+    cn = np.zeros(R, np.uint8)
+    lib_o = orc.lib()
+    lib_o.orc_ldpc_rows.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    cnl = lib_o.orc_ldpc_rows(rate, short, None, None)
+    pos = np.zeros((R, cnl), np.uint16)
+    lib_o.orc_ldpc_rows(rate, short, pos.ctypes.data, cn.ctypes.data)
+    j = np.arange(360)
+    for i in range(q):
+        off, deg, dn, row_off = (int(x) for x in layers[i])
+        depth, nc = dn & 0xffff, dn >> 16
+        e = ents[off:off + deg]
+        sp, r = (e & 0xffff).astype(np.int64), (e >> 16).astype(np.int64)
+        bits = 360 * r[None, :] + (j[:, None] + sp[None, :]) % 360             # [row j][link k]
+        # 1. same set of information bits per row as the reference's expansion
+        want = pos[360 * i:360 * i + 360, :cn[360 * i]].astype(np.int64)
+        assert deg == cn[360 * i]
+        assert np.array_equal(np.sort(bits, axis=1), np.sort(want, axis=1))
+        # 2. ordering: any two rows of the layer that share a bit are ordered by level, flags agree
+        owner = {}
+        conflict_links = set()
+        late = np.zeros((360, deg), bool); early = np.zeros((360, deg), bool)
+        for jj in range(360):
+            for k in range(deg):
+                owner.setdefault(int(bits[jj, k]), []).append((jj, k))
+        for b, lst in owner.items():
+            if len(lst) > 1:
+                lst.sort()
+                for a in range(len(lst)):
+                    conflict_links.add(lst[a][1])
+                    if a > 0:
+                        late[lst[a]] = True
+                    if a + 1 < len(lst):
+                        early[lst[a]] = True
+        if not conflict_links:
+            assert depth == 1 and nc == 0
+            continue
+        assert conflict_links == set(range(nc)) and nc <= 12
+        rw = rows[row_off:row_off + 360]
+        lvl = (rw & 0xff).astype(np.int64)
+        for k in range(nc):
+            assert np.array_equal(((rw >> (8 + k)) & 1).astype(bool), late[:, k])
+            assert np.array_equal(((rw >> (20 + k)) & 1).astype(bool), early[:, k])
+        assert lvl.max() == depth and lvl.min() == 1
+        for b, lst in owner.items():
+            for a in range(1, len(lst)):
+                assert lvl[lst[a][0]] > lvl[lst[a - 1][0]]        # the later row waits for the earlier one
