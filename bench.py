@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Msymbols/s of the DVB-S2 hot path on MI355X.
+"""Headline benchmark: Msymbols/s of the DVB-S2 demod + FEC hot path on MI355X.
 
 Workload (BASELINE.json configs[2], the one the metric is quoted on): DVB-S2 8PSK 3/4 normal FECFRAME
-(MODCOD 14, PLFRAME 21 690 symbols, LDPC table B7, BCH t=12), LDPC forced to exactly 50 layered
-iterations per frame (no early exit), synthetic frames resident in HBM when the timed region starts.
-One step = one pass of the hot path over one batch of `--frames` PLFRAMEs per GPU.
+(MODCOD 14, PLFRAME 21 690 symbols, LDPC table B7, BCH t=12), pilots off, LDPC forced to exactly 50 layered
+iterations per frame (no early exit).  `--streams` independent transponder streams per GPU, each a
+continuous synthetic 27.5 Msym/s-class signal (2 samples/symbol complex64 IQ, RRC 0.35, timing offset
+0.3 sample, AWGN Es/N0 14 dB) of `--frames` PLFRAMEs per step, resident in HBM when the timed region
+starts.  One step = one dvbs2gpu_demod_process_batch call = the whole hot path
+  IQ -> AGC -> NCO -> Gardner -> RRC -> /2 -> PL sync -> FED/PLL/PLHDR -> soft demap + de-interleave
+     -> LDPC (50 it) -> BCH -> BB descramble -> BBFRAMEs
+over every stream; the streams keep their loop state from step to step (the IQ block is periodic, so the
+signal is seamless).  value = PLFRAME symbols consumed per second, all GPUs.
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel:
-the LDPC decoder, HIP-event timed in here) and `cpu_baseline` (reference FEC compiled from
-/root/reference into oracle/_ref when that build travelled, else the oracle port; rank 0, N=1 only).
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the LDPC decoder, HIP-event timed in
+here on the stream it is launched on) and `cpu_baseline` (rank 0, N=1 only: the reference's own FEC code
+compiled into oracle/_ref when that build travelled, else the oracle port, plus the oracle front end).
 """
 import argparse
 import json
@@ -28,105 +34,111 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 MODCOD = 14          # 8PSK 3/4
 RATE, SHORT = 6, 0
 ITERS = 50
+ESN0_DB = 14.0
 HBM_PEAK_GBS = 8000.0
+DISTINCT = 4         # distinct periodic IQ blocks; stream s replays block s % DISTINCT
 
 
-def make_batch(nframes, seed):
-    """Synthetic receive-side input for the stages that exist: int8 LLRs of valid codewords in AWGN
-    (Es/N0 about threshold + 1 dB), built by the repo's own transmitter (oracle encoder, test/bench
-    infrastructure).  A few distinct frames are tiled to the batch size."""
+def make_blocks(frames, seed):
+    """periodic IQ blocks built by the repo's own transmitter (oracle/s2chain.cpp, bench/test infrastructure)"""
     import orc
-    rng = np.random.default_rng(seed)
-    p = orc.fec_params(RATE, SHORT)
-    distinct = 16
-    llr = np.zeros((distinct, p['N']), np.int8)
-    bbs = np.zeros((distinct, p['kbch'] // 8), np.uint8)
-    for f in range(distinct):
-        bb, bits = orc.encode_frame(RATE, SHORT, 0xD5B2 + seed * 1000 + f)
-        llr[f] = orc.bits_to_llr(bits, 5.7, rng)
-        bbs[f] = bb
-    reps = (nframes + distinct - 1) // distinct
-    return p, np.tile(llr, (reps, 1))[:nframes], np.tile(bbs, (reps, 1))[:nframes]
+    blocks, sent = [], []
+    for b in range(DISTINCT):
+        iq, bb, _ = orc.transmit(MODCOD, 0, 0, nframes=frames, seed=0xD5B2 + 16 * seed + b, esn0_db=ESN0_DB, cfo=0.0, timing=0.3,
+                                 phase0=0.1, lead_symbols=0, circular=1)
+        blocks.append(iq)
+        sent.append({bytes(x) for x in bb})
+    return blocks, sent
 
 
-def cpu_baseline(budget_s=12.0):
-    """Reference (or oracle-port) FEC timed on this box's host cores: LDPC 50 iterations on noise-only
-    LLRs (never converges => exactly 50 sweeps, same work as the forced GPU run) + BCH + descramble."""
+def cpu_baseline(frames_block, budget_s=10.0):
+    """CPU path on this box's host cores.  FEC: the reference's own code (oracle/_ref: LDPC with 16 frames in the
+    16 int8 SSE4.1 lanes of one call, 50 iterations on noise LLRs = never converges = same work as the forced GPU
+    run, + BCH + descrambler) when it travelled, else the oracle's scalar port.  Front end: the oracle restatement
+    (the reference's float blocks need SDR++/VOLK, not buildable here).  Both legs run on all cores; the
+    per-symbol times add."""
     import orc
     p = orc.fec_params(RATE, SHORT)
     sym_per_frame = 21690
     ncores = os.cpu_count() or 1
     R = orc.ref()
     rng = np.random.default_rng(1)
-    results = {}
-    if R is not None:
-        kind = 'reference'
-        noise = rng.integers(-40, 41, size=(16, p['N'])).astype(np.int8)
+
+    def run_threads(fn):
         counts = [0] * ncores
-        stop = time.time() + budget_s
+        stop = time.time() + budget_s / 2
 
         def worker(i):
-            buf = noise.copy()
-            fr = np.zeros(p['K'] // 8, np.uint8)
             while time.time() < stop:
-                b = buf.copy()
-                R.ref_ldpc_decode_simd16(RATE, SHORT, b, ITERS, 1)       # 16 frames, one per SSE4.1 int8 lane
-                for f in range(16):
-                    orc.lib().orc_hard_pack(b[f], p['K'], fr)
-                    R.ref_bch_decode(RATE, SHORT, fr)
-                    R.ref_bb_descramble(RATE, SHORT, fr)
-                counts[i] += 16
+                counts[i] += fn(i)
         t0 = time.time()
         th = [threading.Thread(target=worker, args=(i,)) for i in range(ncores)]
         [t.start() for t in th]
         [t.join() for t in th]
-        dt = time.time() - t0
-        frames = sum(counts)
-        value = frames * sym_per_frame / dt / 1e6
+        return sum(counts), time.time() - t0
+
+    # ---- FEC leg
+    if R is not None:
+        kind = 'reference'
+        noise = rng.integers(-40, 41, size=(16, p['N'])).astype(np.int8)
+
+        def fec(i):
+            b = noise.copy()
+            fr = np.zeros(p['K'] // 8, np.uint8)
+            R.ref_ldpc_decode_simd16(RATE, SHORT, b, ITERS, 1)
+            for f in range(16):
+                orc.lib().orc_hard_pack(b[f], p['K'], fr)
+                R.ref_bch_decode(RATE, SHORT, fr)
+                R.ref_bb_descramble(RATE, SHORT, fr)
+            return 16
+    else:
+        kind = 'port'
+        noise = rng.integers(-40, 41, size=(p['N'],)).astype(np.int8)
+
+        def fec(i):
+            bb = np.zeros(p['kbch'] // 8, np.uint8)
+            c = np.zeros(1, np.int32)
+            x = noise.copy()
+            orc.lib().orc_fec_decode_frame(RATE, SHORT, x, ITERS, 1, bb, c)
+            return 1
+    nfec, tfec = run_threads(fec)
+    fec_frames_per_s = nfec / tfec
+    # ---- front-end leg (oracle; FEC skipped with force_ldpc_iters = -1)
+    blk = frames_block[0]
+    rxs = [orc.OracleRx(orc.default_cfg(MODCOD, 0, 0, force_ldpc_iters=-1)) for _ in range(ncores)]
+
+    def fe(i):
+        rxs[i].process(blk)
+        return blk.size // 2
+    nsym, tfe = run_threads(fe)
+    fe_sym_per_s = nsym / tfe
+    t_per_sym = 1.0 / fe_sym_per_s + 1.0 / (fec_frames_per_s * sym_per_frame)
+    out = dict(value=round(1e-6 / t_per_sym, 4), unit='Msymbols/s', cores=ncores, kind=kind,
+               sample='%d threads: FEC leg %d frames in %.1f s (%s LDPC 50 it + BCH + descramble = %.3f Msym/s), front-end leg '
+                      '%d symbols in %.1f s (oracle AGC..demap = %.3f Msym/s); per-symbol times added'
+                      % (ncores, nfec, tfec, 'reference 16-lane SSE4.1' if kind == 'reference' else 'oracle scalar',
+                         fec_frames_per_s * sym_per_frame / 1e6, nsym, tfe, fe_sym_per_s / 1e6),
+               fec_only_msym_s=round(fec_frames_per_s * sym_per_frame / 1e6, 4), frontend_only_msym_s=round(fe_sym_per_s / 1e6, 4))
+    if R is not None:
         # as-wired variant: one frame per decode call, single thread (bbframe_ldpc.cpp:123-139)
         b = noise[0].copy()
         t1 = time.time()
         n1 = 0
-        while time.time() - t1 < 2.0:
+        while time.time() - t1 < 1.5:
             x = b.copy()
             R.ref_ldpc_decode(RATE, SHORT, x, ITERS)
             n1 += 1
-        aswired = n1 * sym_per_frame / (time.time() - t1) / 1e6
-        sample = ('%d frames: reference LDPC (16 frames/call in the 16 int8 SSE4.1 lanes, 50 iterations, noise LLRs) '
-                  '+ reference BCH + descrambler, %d threads, %.1f s' % (frames, ncores, dt))
-        results = dict(value=round(value, 4), unit='Msymbols/s', cores=ncores, kind=kind, sample=sample,
-                       as_wired_1thread_msym_s=round(aswired, 4))
-    else:
-        kind = 'port'
-        noise = rng.integers(-40, 41, size=(p['N'],)).astype(np.int8)
-        counts = [0] * ncores
-        stop = time.time() + budget_s
-
-        def worker(i):
-            bb = np.zeros(p['kbch'] // 8, np.uint8)
-            c = np.zeros(1, np.int32)
-            while time.time() < stop:
-                x = noise.copy()
-                orc.lib().orc_fec_decode_frame(RATE, SHORT, x, ITERS, 1, bb, c)
-                counts[i] += 1
-        t0 = time.time()
-        th = [threading.Thread(target=worker, args=(i,)) for i in range(ncores)]
-        [t.start() for t in th]
-        [t.join() for t in th]
-        dt = time.time() - t0
-        frames = sum(counts)
-        value = frames * sym_per_frame / dt / 1e6
-        sample = '%d frames: oracle scalar port LDPC 50 iterations + BCH + descrambler, %d threads, %.1f s' % (frames, ncores, dt)
-        results = dict(value=round(value, 4), unit='Msymbols/s', cores=ncores, kind=kind, sample=sample)
-    return results
+        out['fec_as_wired_1thread_msym_s'] = round(n1 * sym_per_frame / (time.time() - t1) / 1e6, 4)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--frames', type=int, default=4096, help='PLFRAMEs per GPU per step')
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--streams', type=int, default=256, help='transponder streams per GPU')
+    ap.add_argument('--frames', type=int, default=8, help='PLFRAMEs per stream per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -144,21 +156,25 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     else:
-        torch.cuda.set_device(0)
         local_rank = 0
+        torch.cuda.set_device(0)
     dev = torch.device('cuda', local_rank)
     eng = pkg.Engine(local_rank)
 
     info = pkg.modcod_info(MODCOD, False, False)
-    p, llr_h, bbs_h = make_batch(args.frames, seed=rank)
-    F = args.frames
-    llr = torch.from_numpy(llr_h).to(dev)
-    out = torch.empty((F, p['kbch'] // 8), dtype=torch.uint8, device=dev)
-    trials = torch.empty((F,), dtype=torch.int32, device=dev)
-    corr = torch.empty((F,), dtype=torch.int32, device=dev)
+    sym = info['plframe_symbols']
+    kb = info['kbch'] // 8
+    S, F = args.streams, args.frames
+    blocks, sent = make_blocks(F, seed=rank)
+    d_blocks = [torch.from_numpy(b).to(dev) for b in blocks]
+    nsamp = blocks[0].size
+    cfg = eng.default_cfg(MODCOD, False, False, force_ldpc_iters=ITERS)
+    demods = [eng.demod(cfg, max_samples=nsamp) for _ in range(S)]
+    tin = [d_blocks[s % DISTINCT] for s in range(S)]
+    tout = [torch.zeros((F + 2) * kb, dtype=torch.uint8, device=dev) for _ in range(S)]
 
     def step():
-        eng.fec_decode(llr, RATE, False, max_trials=ITERS, force=True, out=out, trials=trials, corr=corr)
+        return eng.process_batch(demods, tin, tout)
 
     def barrier():
         torch.cuda.synchronize()
@@ -170,8 +186,9 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
+    nb = None
     for _ in range(args.steps):
-        step()
+        nb = step()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -179,48 +196,64 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # parity of the timed output: bit-exact BBFRAMEs (what the transmitter sent)
-    ok = bool(np.array_equal(out.cpu().numpy(), bbs_h))
+    # parity of the timed output: every stream delivered F frames per step, each bit-exact one of the BBFRAMEs sent
+    frames_ok = all(n == F * kb for n in nb)
+    exact = frames_ok
+    if frames_ok:
+        for s in range(0, S, max(1, S // 16)):
+            got = tout[s][:nb[s]].cpu().numpy().reshape(-1, kb)
+            exact = exact and all(bytes(x) in sent[s % DISTINCT] for x in got)
 
-    # dominant kernel (LDPC) timed alone with HIP events on the launch stream
+    # dominant kernel (LDPC) alone, HIP events on its launch stream, same batch size as inside a step
+    nfr = S * F
+    llr = torch.randint(-40, 41, (nfr, info['ldpc_n']), dtype=torch.int8, device=dev)
+    hard = torch.empty((nfr, info['ldpc_k'] // 8), dtype=torch.uint8, device=dev)
+    tri = torch.empty((nfr,), dtype=torch.int32, device=dev)
+
+    def ldpc_only():
+        eng.lib.dvbs2gpu_ldpc_decode_batch(eng.h, RATE, 0, llr.data_ptr(), nfr, ITERS, 1, hard.data_ptr(), None, tri.data_ptr(), eng._stream())
+    ldpc_only()
+    torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
-    nk = max(3, min(args.steps, 10))
-    hard = torch.empty((F, p['K'] // 8), dtype=torch.uint8, device=dev)
-    eng.lib.dvbs2gpu_ldpc_decode_batch(eng.h, RATE, 0, llr.data_ptr(), F, ITERS, 1, hard.data_ptr(), None, trials.data_ptr(), eng._stream())
-    torch.cuda.synchronize()
+    nk = 3
     e0.record()
     for _ in range(nk):
-        eng.lib.dvbs2gpu_ldpc_decode_batch(eng.h, RATE, 0, llr.data_ptr(), F, ITERS, 1, hard.data_ptr(), None, trials.data_ptr(), eng._stream())
+        ldpc_only()
     e1.record()
     torch.cuda.synchronize()
     k_ms = e0.elapsed_time(e1) / nk
     bytes_per_frame = ITERS * 4 * info['ldpc_edges'] + info['ldpc_n'] + info['kbch'] // 8
-    achieved = bytes_per_frame * F / (k_ms * 1e-3) / 1e9
+    achieved = bytes_per_frame * nfr / (k_ms * 1e-3) / 1e9
+    plan = eng.ldpc_plan_info(RATE, False)
 
     if rank == 0:
-        sym = info['plframe_symbols']
-        value = world * F * args.steps * sym / dt / 1e6
+        value = world * S * F * args.steps * sym / dt / 1e6
         line = {
             'metric': 'Msymbols/s demod+FEC, DVB-S2 8PSK 3/4 normal-frame @50 LDPC iters',
             'value': round(value, 3), 'unit': 'Msymbols/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'int8', 'data': 'synthetic',
-            'config': {'workload': 'DVB-S2 8PSK 3/4 normal FECFRAME (MODCOD 14), pilots off, 27.5 Msym/s-class stream, '
-                                   '50 forced LDPC iterations',
-                       'stages': 'LLR(int8) -> LDPC -> BCH -> BB-descramble -> BBFRAME (front-end stages not yet in the timed path)',
-                       'frames_per_gpu_per_step': F, 'symbols_per_frame': sym, 'parallelism': 'frames sharded over GPUs, no collective',
-                       'output_bit_exact': ok},
-            'roofline': {'bound': 'hbm', 'kernel': 'ldpc_decode_kernel<12,4>', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+            'dtype': 'int8 (FEC) / f32 (demod)', 'data': 'synthetic',
+            'config': {'workload': 'DVB-S2 8PSK 3/4 normal FECFRAME (MODCOD 14), pilots off, 27.5 Msym/s-class streams at 2 sps, '
+                                   'Es/N0 14 dB, 50 forced LDPC iterations, IQ in -> BBFRAMEs out',
+                       'streams_per_gpu': S, 'frames_per_stream_per_step': F, 'symbols_per_frame': sym,
+                       'parallelism': 'independent transponder streams sharded over GPUs, no data-path collective',
+                       'all_frames_delivered': frames_ok, 'output_bit_exact': exact},
+            'roofline': {'bound': 'hbm', 'kernel': 'ldpc_decode_kernel<12,4,false>', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
-                         'kernel_ms': round(k_ms, 4), 'algorithmic_bytes_per_frame': bytes_per_frame},
+                         'kernel_ms': round(k_ms, 4), 'frames_per_launch': nfr, 'algorithmic_bytes_per_frame': bytes_per_frame,
+                         'ldpc_share_of_step': round(k_ms / (dt / args.steps * 1e3), 3),
+                         'note': 'posteriors stay in LDS, messages in L2/Infinity Cache: real HBM traffic is far below the algorithmic bytes',
+                         'plan': plan},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline()
+            line['cpu_baseline'] = cpu_baseline(blocks)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    for d in demods:
+        d.close()
     eng.close()
 
 

@@ -584,6 +584,7 @@ int S2Rx::process(int count, const cf* in, uint8_t* out, int out_cap) {
             dbg_frames.insert(dbg_frames.end(), frame.begin(), frame.end());
             dbg_pll.insert(dbg_pll.end(), pllout.begin(), pllout.end());
             dbg_llr.insert(dbg_llr.end(), llr.begin(), llr.end());
+            if (cfg.force_ldpc_iters < 0) { dbg_stats.push_back(st); continue; }   // front-end timing only (bench cpu_baseline)
             int mt = cfg.force_ldpc_iters ? cfg.force_ldpc_iters : cfg.max_ldpc_trials;
             st.ldpc_trials = ldpc_decode(*ldpc, llr.data(), mt, cfg.force_ldpc_iters ? 1 : 0);
             std::vector<uint8_t> fr(mp.fec.K / 8);
@@ -686,7 +687,8 @@ std::vector<cf> s2_transmit(const TxCfg& t, std::vector<uint8_t>* bbframes_out, 
         double re = 0, im = 0;
         for (int k = -span; k <= span; ++k) {
             int si = m - k;
-            if (si < 0 || si >= ns) continue;
+            if (t.circular) si = ((si % ns) + ns) % ns;
+            else if (si < 0 || si >= ns) continue;
             // contribution of symbol si at time (n - frac)/2: h((n - frac)/2 - si) = h(((n&1) - frac)/2 + k) -> index -k
             double hv = h[-k + span];
             re += hv * syms[si].re; im += hv * syms[si].im;

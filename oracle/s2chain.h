@@ -144,6 +144,7 @@ struct TxCfg {
     double timing;           // fractional timing offset, samples
     double phase0;           // initial carrier phase
     int lead_symbols;        // random QPSK symbols before the first frame (sync acquisition run-in)
+    int circular;            // != 0: pulse shaping wraps around, so the block can be repeated as a seamless stream
 };
 // returns 2-sps IQ; bbframes_out gets nframes x kbch/8 bytes (what the receiver must output)
 std::vector<cf> s2_transmit(const TxCfg& t, std::vector<uint8_t>* bbframes_out, std::vector<cf>* symbols_out = nullptr);

@@ -56,76 +56,130 @@ __device__ __forceinline__ cf32 dot8(const cf32* x, const float* t) {
 }
 
 // ------------------------------------------------------------------------------------------------ front end
-// one lane = one stream.  fe_out holds [Gardner output: up to n + n/16 + 64][scratch: 7 history + n NCO samples];
-// the host allocates 2n + n/16 + 256 complex values (fe_capacity in s2_demod.hip).
+// sin/cos for |x| <= a few pi: 3-term Cody-Waite reduction by pi/4 and the classic single-precision minimax
+// polynomials (~1 ULP).  Used instead of the device libm on the serial per-sample paths (~35 instructions
+// for both values, no slow-path branches).  sincos(0) = (0, 1) exactly.
+__device__ __forceinline__ cf32 phasor_fast(float x) {
+    float ax = fabsf(x);
+    int j = (int)(ax * 1.27323954473516f);
+    j = (j + 1) & ~1;
+    float y = (float)j;
+    float r = ((ax - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    float z = r * r;
+    float ps = r + r * z * ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f);
+    float pc = (1.0f - 0.5f * z) + z * z * ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f);
+    int q = (j >> 1) & 3;
+    float sn = (q & 1) ? pc : ps, cs = (q & 1) ? ps : pc;
+    if (q == 1 || q == 2) cs = -cs;
+    if (q >= 2) sn = -sn;
+    if (x < 0.f) sn = -sn;
+    return cf32{cs, sn};
+}
+
+// ONE WAVE PER STREAM.  The recurrences (AGC gain, NCO phase, Gardner PCL) are serial in time, so the wave runs
+// them as uniform code; the lanes are used for what is parallel: coalesced tile loads/stores, the NCO rotation
+// (4 samples per lane per tile) and the three 8-tap interpolator dot products (one (arm, re/im) pair per lane,
+// taps accumulated in the reference's order).  Many streams = many waves: the GPU is filled by the batch.
+constexpr int FE_TILE = 256;
+
 __global__ __launch_bounds__(64) void s2_frontend_kernel(const S2StreamWork* __restrict__ work, int nstreams, S2LoopCoefs co,
                                                          const float* __restrict__ bank_g) {
-    __shared__ float bank[GARDNER_PHASES * GARDNER_TAPS];
-    for (int i = threadIdx.x; i < GARDNER_PHASES * GARDNER_TAPS; i += 64) bank[i] = bank_g[i];
-    __syncthreads();
-    const int s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= nstreams) return;
-    const S2StreamWork w = work[s];
+    __shared__ __attribute__((aligned(16))) float bank[GARDNER_PHASES * GARDNER_TAPS];
+    __shared__ cf32 raw[FE_TILE];            // input tile, then AGC output in place
+    __shared__ float ph[FE_TILE];            // NCO phase per sample
+    __shared__ float xre[FE_TILE + 8], xim[FE_TILE + 8];   // NCO output: [7 history][tile]
+    __shared__ cf32 ostage[FE_TILE + FE_TILE / 16 + 16];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < GARDNER_PHASES * GARDNER_TAPS; i += 64) bank[i] = bank_g[i];
+    const S2StreamWork w = work[blockIdx.x];
     S2StreamState* st = w.st;
     const int n = w.count;
-    cf32* __restrict__ scratch = w.fe_out + (n + n / 16 + 64);   // [7 history + n]
-    // ---- AGC + NCO
     float gain = st->agc_gain, nph = st->nco_phase;
     const float nfr = st->nco_freq;
-    for (int i = 0; i < GARDNER_TAPS - 1; ++i) scratch[i] = st->g_hist[i];
-    for (int i = 0; i < n; ++i) {
-        cf32 x = w.in[i];
-        cf32 y = cscale(x, gain);
-        float a = camp(y);
-        gain += (1.0f - a) * co.agc_rate;
-        if (gain > 10e6f) gain = 10e6f;
-        cf32 z = cmul(y, phasor(-nph));
-        nph += nfr;
-        while ((double)nph > 6.283185307179586) nph = (float)((double)nph - 6.283185307179586);
-        while ((double)nph < -6.283185307179586) nph = (float)((double)nph + 6.283185307179586);
-        scratch[GARDNER_TAPS - 1 + i] = z;
-    }
-    st->agc_gain = gain; st->nco_phase = nph;
-    // ---- Gardner timing recovery (omega = 1 sample per output, TED on every 2nd output)
+    if (lane < GARDNER_TAPS - 1) { xre[lane] = st->g_hist[lane].re; xim[lane] = st->g_hist[lane].im; }
     PclDev pcl{co.g_alpha, co.g_beta, st->g_phase, st->g_freq, co.g_min_freq, co.g_max_freq};
     int offset = st->g_offset, spsctr = st->g_spsctr, outCount = 0;
-    cf32* __restrict__ out = w.fe_out;
-    while (offset < n) {
-        int phase = (int)floorf(pcl.phase * 128.0f);
-        phase = phase < 0 ? 0 : (phase > 127 ? 127 : phase);
-        cf32 x[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = scratch[offset + k];
-        cf32 outVal = dot8(x, &bank[phase * 8]);
-        out[outCount++] = outVal;
-        float error;
-        if (spsctr == 0) {
-            cf32 dfdt;
-            if (phase == 0) {
-                dfdt = csub(dot8(x, &bank[(phase + 1) * 8]), outVal);
-            } else if (phase == 127) {
-                dfdt = csub(outVal, dot8(x, &bank[(phase - 1) * 8]));
-            } else {
-                cf32 a = dot8(x, &bank[(phase + 1) * 8]), b = dot8(x, &bank[(phase - 1) * 8]);
-                dfdt = cscale(csub(a, b), 0.5f);
-            }
-            error = -(((outVal.re > 0 ? 1.0f : -1.0f) * dfdt.re) + ((outVal.im > 0 ? 1.0f : -1.0f) * dfdt.im));
-        } else {
-            error = 0.f;
+    __syncthreads();
+    for (int base = 0; base < n; base += FE_TILE) {
+        const int m = min(FE_TILE, n - base);
+        // ---- coalesced tile load
+        for (int i = lane; i < m; i += 64) raw[i] = w.in[base + i];
+        __syncthreads();
+        // ---- AGC (serial gain recurrence) + NCO phase recurrence; every lane runs the same scalar chain
+        for (int i = 0; i < m; ++i) {
+            cf32 x = raw[i];
+            cf32 y = cscale(x, gain);
+            float a = camp(y);
+            gain += (1.0f - a) * co.agc_rate;
+            if (gain > 10e6f) gain = 10e6f;
+            if (lane == 0) { raw[i] = y; ph[i] = nph; }
+            nph += nfr;
+            while ((double)nph > 6.283185307179586) nph = (float)((double)nph - 6.283185307179586);
+            while ((double)nph < -6.283185307179586) nph = (float)((double)nph + 6.283185307179586);
         }
-        spsctr++;
-        if (spsctr >= 2) spsctr = 0;
-        if (error > 1.0f) error = 1.0f;
-        if (error < -1.0f) error = -1.0f;
-        pcl.advance(error);
-        float delta = floorf(pcl.phase);
-        offset = (int)((float)offset + delta);
-        pcl.phase -= delta;
+        __syncthreads();
+        // ---- NCO rotation, parallel over the tile
+        for (int i = lane; i < m; i += 64) {
+            cf32 z = cmul(raw[i], phasor_fast(-ph[i]));
+            xre[GARDNER_TAPS - 1 + i] = z.re; xim[GARDNER_TAPS - 1 + i] = z.im;
+        }
+        __syncthreads();
+        // ---- Gardner: outputs whose 8-sample window starts inside this tile
+        const int arm_sel = (lane >> 1) % 3;          // lanes 0..5: arm-1, arm, arm+1  x  (re, im)
+        const float* __restrict__ xc = (lane & 1) ? xim : xre;
+        int nout = 0;
+        while (offset < base + m) {
+            int phase = (int)floorf(pcl.phase * 128.0f);
+            phase = phase < 0 ? 0 : (phase > 127 ? 127 : phase);
+            int arm = phase + arm_sel - 1;
+            arm = arm < 0 ? 0 : (arm > 127 ? 127 : arm);
+            const float* __restrict__ t = &bank[arm * 8];
+            const float* __restrict__ xw = xc + (offset - base);
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += xw[k] * t[k];
+            // lanes: 0/1 = arm-1 (re,im), 2/3 = arm, 4/5 = arm+1
+            const float m_re = __shfl(acc, 0), m_im = __shfl(acc, 1);
+            const float o_re = __shfl(acc, 2), o_im = __shfl(acc, 3);
+            const float p_re = __shfl(acc, 4), p_im = __shfl(acc, 5);
+            if (lane == 0) ostage[nout] = cf32{o_re, o_im};
+            ++nout;
+            float error;
+            if (spsctr == 0) {
+                float d_re, d_im;
+                if (phase == 0) { d_re = p_re - o_re; d_im = p_im - o_im; }
+                else if (phase == 127) { d_re = o_re - m_re; d_im = o_im - m_im; }
+                else { d_re = (p_re - m_re) * 0.5f; d_im = (p_im - m_im) * 0.5f; }
+                error = -(((o_re > 0 ? 1.0f : -1.0f) * d_re) + ((o_im > 0 ? 1.0f : -1.0f) * d_im));
+            } else {
+                error = 0.f;
+            }
+            spsctr++;
+            if (spsctr >= 2) spsctr = 0;
+            if (error > 1.0f) error = 1.0f;
+            if (error < -1.0f) error = -1.0f;
+            pcl.advance(error);
+            float delta = floorf(pcl.phase);
+            offset = (int)((float)offset + delta);
+            pcl.phase -= delta;
+        }
+        __syncthreads();
+        // ---- coalesced store of this tile's outputs, slide the 7-sample history
+        for (int i = lane; i < nout; i += 64) w.fe_out[outCount + i] = ostage[i];
+        outCount += nout;
+        float hr = 0.f, hi = 0.f;
+        if (lane < GARDNER_TAPS - 1) { hr = xre[m + lane]; hi = xim[m + lane]; }
+        __syncthreads();
+        if (lane < GARDNER_TAPS - 1) { xre[lane] = hr; xim[lane] = hi; }
+        __syncthreads();
     }
     offset -= n;
-    for (int i = 0; i < GARDNER_TAPS - 1; ++i) st->g_hist[i] = scratch[n + i];
-    st->g_phase = pcl.phase; st->g_freq = pcl.freq; st->g_offset = offset; st->g_spsctr = spsctr;
-    st->n_fe_out = outCount;
+    if (lane < GARDNER_TAPS - 1) st->g_hist[lane] = cf32{xre[lane], xim[lane]};
+    if (lane == 0) {
+        st->agc_gain = gain; st->nco_phase = nph;
+        st->g_phase = pcl.phase; st->g_freq = pcl.freq; st->g_offset = offset; st->g_spsctr = spsctr;
+        st->n_fe_out = outCount;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ RRC + /2
@@ -280,13 +334,21 @@ __device__ void soft_calc_dev(const S2ConstelDev& C, cf32 sample, int8_t* bits_o
     if (phase_err) *phase_err = cphase(cmul(sample, cconj(closest)));
 }
 
+// ONE WAVE PER STREAM (see the front end): the PLL / PLHDR phase recurrences are serial per symbol and run as
+// uniform code; lanes do the coalesced symbol loads/stores, the FED terms and the PLSC codeword search.
 __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* __restrict__ work, int nstreams,
                                                             const S2FrameRef* __restrict__ frames, const int* __restrict__ first,
                                                             S2LoopCoefs co, S2PlTablesDev T, S2ConstelDev C, int pls_code, int slots,
                                                             int pilots, int pilot_blocks, int plframe, cf32* __restrict__ pllout,
                                                             S2FrameStats* __restrict__ stats) {
-    const int s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= nstreams) return;
+    __shared__ cf32 tile[64];
+    __shared__ cf32 otile[64];
+    __shared__ uint8_t rnt[64];
+    __shared__ float fedt[128];
+    __shared__ cf32 hdr_sym[90];
+    __shared__ int red_d[64], red_c[64];
+    const int s = blockIdx.x;
+    const int lane = threadIdx.x;
     S2StreamState* st = work[s].st;
     PclDev pll{co.pll_alpha, co.pll_beta, st->pll_phase, st->pll_freq, co.pll_min_freq, co.pll_max_freq};
     PclDev hdr{co.hdr_alpha, co.hdr_beta, st->hdr_phase, st->hdr_freq, co.hdr_min_freq, co.hdr_max_freq};
@@ -296,24 +358,27 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
     for (int f = first[s]; f < first[s + 1]; ++f) {
         const cf32* __restrict__ fr = frames[f].sym;
         cf32* __restrict__ out = pllout + (size_t)f * plframe;
-        // ---- coarse frequency error detector (dvbs2_fed.h) and NCO feedback (module_dvbs2_demod.cpp:319-331)
-        float err = 0.f, symcnt = 90 - 2;
-        for (int i = 0; i < 88; ++i) {
-            // term order of the reference: i = 0..23 SOF, 24, 25 (SOF/PLSC boundary), 26..87 PLSC
+        // ---- coarse frequency error detector (dvbs2_fed.h): terms in parallel, summed in the reference's order
+        for (int i = lane; i < 88; i += 64) {
             cf32 r2 = (i + 2) < 26 ? T.sof[i + 2] : plsc[i + 2 - 26];
             cf32 r0 = i < 26 ? T.sof[i] : plsc[i - 26];
-            err += cmul(cmul(cmul(fr[i + 2], cconj(r2)), cconj(fr[i])), r0).im;
+            fedt[i] = cmul(cmul(cmul(fr[i + 2], cconj(r2)), cconj(fr[i])), r0).im;
         }
+        if (lane < 90 - 64) hdr_sym[64 + lane] = fr[64 + lane];
+        hdr_sym[lane] = fr[lane];
+        __syncthreads();
+        float err = 0.f, symcnt = 90 - 2;
+        for (int i = 0; i < 88; ++i) err += fedt[i];
         if (pilots) {
             const cf32 p{0.707f, 0.707f};
             for (int b = 0; b < pilot_blocks; ++b) {
                 int start = pilot_start(b);
-                cf32 d1{0.f, 0.f}, d2{0.f, 0.f};
-                for (int i = 0; i < 36; ++i) {
-                    cf32 descr = pl_descramble(fr[start + i], T.rn[start - 90 + i]);
-                    if (i >= 2) err += cmul(cmul(cmul(descr, cconj(p)), cconj(d2)), p).im;
-                    d2 = d1; d1 = descr;
-                }
+                __syncthreads();
+                if (lane < 36) tile[lane] = pl_descramble(fr[start + lane], T.rn[start - 90 + lane]);
+                __syncthreads();
+                if (lane >= 2 && lane < 36) fedt[lane] = cmul(cmul(cmul(tile[lane], cconj(p)), cconj(tile[lane - 2])), p).im;
+                __syncthreads();
+                for (int i = 2; i < 36; ++i) err += fedt[i];
                 symcnt += 36 - 2;
             }
         }
@@ -322,38 +387,54 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
         else nco_freq = nco_freq + est * co.fll_bw;
         if (nco_freq > 0.3f * PI_F) nco_freq = 0.3f * PI_F;
         if (nco_freq < -0.3f * PI_F) nco_freq = -0.3f * PI_F;
-        // ---- PLL (dvbs2_pll.cpp:34-86)
+        // ---- PLL (dvbs2_pll.cpp:34-86), 64-symbol tiles
         int next_pilot = (pilots && pilot_blocks > 0) ? pilot_start(0) : -1, pb = 0;
-        for (int i = 0; i < plframe; ++i) {
-            cf32 tmp_val = cmul(fr[i], phasor(-pll.phase));
-            float error = 0.f;
-            if (i >= 90) {
-                cf32 descr = pl_descramble(tmp_val, T.rn[i - 90]);
-                bool is_pilot = next_pilot >= 0 && i >= next_pilot && i < next_pilot + 36;
-                if (!is_pilot) {
-                    if (C.bits != 5) error = C.lut_err[lut_index(tmp_val.re) * 256 + lut_index(tmp_val.im)];
-                    else soft_calc_dev(C, tmp_val, nullptr, &error);
-                } else {
-                    error = cphase(cmul(descr, cf32{0.707f, -0.707f}));
-                    if (i == next_pilot + 35) { ++pb; next_pilot = pb < pilot_blocks ? pilot_start(pb) : -1; }
-                }
-                out[i] = descr;
-            } else {
-                if (i < 26) error = cphase(cmul(tmp_val, cconj(T.sof[i])));
-                else error = cphase(cmul(tmp_val, cconj(plsc[i - 26])));
-                // header symbols are overwritten by the PLHDR demod below (module_dvbs2_demod.cpp:332-333)
+        for (int base = 0; base < plframe; base += 64) {
+            const int m = min(64, plframe - base);
+            __syncthreads();
+            if (lane < m) {
+                tile[lane] = fr[base + lane];
+                int gi = base + lane;
+                rnt[lane] = gi >= 90 ? T.rn[gi - 90] : 0;
             }
-            pll.advance(error);
-            pll.wrap_pi();
+            __syncthreads();
+            for (int k = 0; k < m; ++k) {
+                const int i = base + k;
+                cf32 tmp_val = cmul(tile[k], phasor_fast(-pll.phase));
+                float error = 0.f;
+                cf32 o;
+                if (i >= 90) {
+                    cf32 descr = pl_descramble(tmp_val, rnt[k]);
+                    bool is_pilot = next_pilot >= 0 && i >= next_pilot && i < next_pilot + 36;
+                    if (!is_pilot) {
+                        if (C.bits != 5) error = C.lut_err[lut_index(tmp_val.re) * 256 + lut_index(tmp_val.im)];
+                        else soft_calc_dev(C, tmp_val, nullptr, &error);
+                    } else {
+                        error = cphase(cmul(descr, cf32{0.707f, -0.707f}));
+                        if (i == next_pilot + 35) { ++pb; next_pilot = pb < pilot_blocks ? pilot_start(pb) : -1; }
+                    }
+                    o = descr;
+                } else {
+                    if (i < 26) error = cphase(cmul(tmp_val, cconj(T.sof[i])));
+                    else error = cphase(cmul(tmp_val, cconj(plsc[i - 26])));
+                    o = cf32{0.f, 0.f};   // header symbols come from the PLHDR demod below
+                }
+                if (lane == 0) otile[k] = o;
+                pll.advance(error);
+                pll.wrap_pi();
+            }
+            __syncthreads();
+            if (lane < m && base + lane >= 90) out[base + lane] = otile[lane];
         }
-        // ---- PL header demod (dvbs2_plhdr_demod.cpp:33-67): own loop over the 90 header symbols, PLSC decode
+        // ---- PL header demod (dvbs2_plhdr_demod.cpp:33-67)
         unsigned long long plheader = 0;
         const cf32 rot{(float)0.70710678118654757, (float)-0.70710678118654746};   // (cos(-pi/4), sin(-pi/4)) in double, cast
+        __syncthreads();
         for (int i = 0; i < 90; ++i) {
-            cf32 tmp_val = cmul(fr[i], phasor(-hdr.phase));
+            cf32 tmp_val = cmul(hdr_sym[i], phasor_fast(-hdr.phase));
             float error = ((tmp_val.re > 0 ? 1.0f : -1.0f) * tmp_val.im) - ((tmp_val.im > 0 ? 1.0f : -1.0f) * tmp_val.re);
             cf32 o = (i & 1) ? cf32{-tmp_val.re, tmp_val.im} : cf32{tmp_val.im, tmp_val.re};
-            out[i] = o;
+            if (lane == 0) out[i] = o;
             if (i >= 26) {
                 bool value = cmul(o, rot).re > 0;
                 plheader = plheader << 1 | (unsigned long long)(!value);
@@ -364,20 +445,33 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
         hdr.phase += hdr.freq * (plframe - 91);
         hdr.advance(0.f);
         hdr.wrap_pi();
-        int best = 0, diffs = 64;
-        for (int c = 0; c < 128; ++c) {
+        // codeword search: lowest index among the minima (the reference scans with strict '<')
+        int bd = 65, bc = 0;
+        for (int c = lane; c < 128; c += 64) {
             int dd = __popcll((T.plsc_code[c] ^ plheader) & ((1ull << 60) - 1));
-            if (dd < diffs) { best = c; diffs = dd; }
+            if (dd < bd) { bd = dd; bc = c; }
         }
-        S2FrameStats stt;
-        stt.best_match = 0.f; stt.ldpc_trials = 0; stt.bch_corr = 0;   // filled in by the host
-        stt.detected_modcod = (best >> 2) & 31; stt.detected_short = (best & 2) >> 1; stt.detected_pilots = best & 1;
-        stt.fed_err = est;
-        stats[f] = stt;
+        red_d[lane] = bd; red_c[lane] = bc;
+        __syncthreads();
+        if (lane == 0) {
+            int best = 0, diffs = 64;
+            for (int l = 0; l < 64; ++l) {   // lane l holds codewords l and l+64: merge in index order
+                int d0 = red_d[l], c0 = red_c[l];
+                if (d0 < diffs || (d0 == diffs && c0 < best && d0 < 64)) { diffs = d0; best = c0; }
+            }
+            S2FrameStats stt;
+            stt.best_match = 0.f; stt.ldpc_trials = 0; stt.bch_corr = 0;   // filled in by the host
+            stt.detected_modcod = (best >> 2) & 31; stt.detected_short = (best & 2) >> 1; stt.detected_pilots = best & 1;
+            stt.fed_err = est;
+            stats[f] = stt;
+        }
+        __syncthreads();
     }
-    st->pll_phase = pll.phase; st->pll_freq = pll.freq;
-    st->hdr_phase = hdr.phase; st->hdr_freq = hdr.freq;
-    st->nco_freq = nco_freq;
+    if (lane == 0) {
+        st->pll_phase = pll.phase; st->pll_freq = pll.freq;
+        st->hdr_phase = hdr.phase; st->hdr_freq = hdr.freq;
+        st->nco_freq = nco_freq;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ demapper
@@ -415,7 +509,7 @@ __global__ __launch_bounds__(256) void s2_demap_kernel(S2ConstelDev C, int rate,
 
 // ------------------------------------------------------------------------------------------------ launchers
 hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCoefs coefs, const float* d_bank, hipStream_t st) {
-    hipLaunchKernelGGL(s2_frontend_kernel, dim3((nstreams + 63) / 64), dim3(64), 0, st, d_work, nstreams, coefs, d_bank);
+    hipLaunchKernelGGL(s2_frontend_kernel, dim3(nstreams), dim3(64), 0, st, d_work, nstreams, coefs, d_bank);
     return hipGetLastError();
 }
 hipError_t s2_rrc_decim_launch(const S2StreamWork* d_work, int nstreams, int max_count, const float* d_taps, int ntaps, hipStream_t st) {
@@ -433,7 +527,7 @@ hipError_t s2_plsync_launch(const cf32* const* d_win, int nwin, int raw, int* d_
 hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const S2FrameRef* d_frames, const int* d_first,
                                  S2LoopCoefs coefs, S2PlTablesDev tabs, S2ConstelDev con, int pls_code, int slots, int pilots,
                                  int pilot_blocks, int plframe, cf32* d_pllout, S2FrameStats* d_stats, hipStream_t st) {
-    hipLaunchKernelGGL(s2_frame_loops_kernel, dim3((nstreams + 63) / 64), dim3(64), 0, st, d_work, nstreams, d_frames, d_first, coefs,
+    hipLaunchKernelGGL(s2_frame_loops_kernel, dim3(nstreams), dim3(64), 0, st, d_work, nstreams, d_frames, d_first, coefs,
                        tabs, con, pls_code, slots, pilots, pilot_blocks, plframe, d_pllout, d_stats);
     return hipGetLastError();
 }

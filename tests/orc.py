@@ -124,7 +124,8 @@ class DemodCfg(C.Structure):
 
 class TxCfg(C.Structure):
     _fields_ = [('modcod', C.c_int), ('shortframes', C.c_int), ('pilots', C.c_int), ('nframes', C.c_int), ('seed', C.c_uint64),
-                ('esn0_db', C.c_double), ('cfo', C.c_double), ('timing', C.c_double), ('phase0', C.c_double), ('lead_symbols', C.c_int)]
+                ('esn0_db', C.c_double), ('cfo', C.c_double), ('timing', C.c_double), ('phase0', C.c_double), ('lead_symbols', C.c_int),
+                ('circular', C.c_int)]
 
 
 class FrameStats(C.Structure):
@@ -197,10 +198,10 @@ def modcod_params(modcod, short=0, pilots=0):
     return d
 
 
-def transmit(modcod, short=0, pilots=0, nframes=2, seed=1, esn0_db=200.0, cfo=0.0, timing=0.0, phase0=0.0, lead_symbols=0):
+def transmit(modcod, short=0, pilots=0, nframes=2, seed=1, esn0_db=200.0, cfo=0.0, timing=0.0, phase0=0.0, lead_symbols=0, circular=0):
     """-> (iq complex64 [n], bbframes uint8 [nframes, kbch/8], symbols complex64)"""
     L = _bind_chain()
-    t = TxCfg(modcod, short, pilots, nframes, seed, esn0_db, cfo, timing, phase0, lead_symbols)
+    t = TxCfg(modcod, short, pilots, nframes, seed, esn0_db, cfo, timing, phase0, lead_symbols, circular)
     mp = modcod_params(modcod, short, pilots)
     nsym = lead_symbols + nframes * mp['plframe']
     iq = np.zeros(2 * nsym, np.complex64)
