@@ -315,19 +315,23 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         if (counts[i] < 0 || counts[i] > d->max_samples) { last_error() = "count exceeds max_samples"; return DVBS2GPU_ERR_ARG; }
         work[i].in = d_iq[i]; work[i].count = counts[i]; work[i].fe_out = d->d_fe;
         work[i].fifo = d->d_fifo[d->fifo_cur]; work[i].fifo_fill = d->fifo_fill; work[i].st = d->d_state;
+        work[i].fifo_next = d->d_fifo[d->fifo_cur ^ 1]; work[i].out = d_out[i];
         max_count = std::max(max_count, counts[i]);
         d->stats.clear(); d->frame_ptrs.clear();
     }
     Workspace& ws_work = ctx->ws_rx[0];
-    if ((rc = ws_work.ensure(sizeof(S2StreamWork) * n + sizeof(int) * (n + 1)))) return rc;
+    if ((rc = ws_work.ensure(sizeof(S2StreamWork) * n + sizeof(int) * (n + 1) + sizeof(int) * 4 * n + 64))) return rc;
     S2StreamWork* d_work = (S2StreamWork*)ws_work.p;
+    int* d_nsym = (int*)((char*)ws_work.p + sizeof(S2StreamWork) * n + sizeof(int) * (n + 1));   // [n]
+    float* d_nco = (float*)(d_nsym + n);                                                          // [n]
+    int* d_curfill = (int*)(d_nco + n);                                                           // [2n]
     HIP_TRY(hipMemcpyAsync(d_work, work.data(), sizeof(S2StreamWork) * n, hipMemcpyHostToDevice, st));
     HIP_TRY(s2_frontend_launch(d_work, n, d0->co, ctx->d_gardner_bank, st));
     HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st));
     // symbol counts back (n_sym sits in each stream's state struct)
     std::vector<int> nsym(n);
-    for (int i = 0; i < n; ++i)
-        HIP_TRY(hipMemcpyAsync(&nsym[i], &dm[i]->d_state->n_sym, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(s2_collect_launch(d_work, n, d_nsym, d_nco, st));
+    HIP_TRY(hipMemcpyAsync(nsym.data(), d_nsym, sizeof(int) * n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
 
     // ---- 3: PL sync.  cur[i] = FIFO index where stream i's next window starts.
@@ -451,26 +455,26 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             dm[i]->tap_llr = d_llr + (size_t)first[i] * N;
             int bytes = cnt * kb;
             if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
-            if (bytes) HIP_TRY(hipMemcpyAsync(d_out[i], d_bb + (size_t)first[i] * kb, bytes, hipMemcpyDeviceToDevice, st));
             out_bytes[i] = bytes;
         }
+        HIP_TRY(s2_scatter_out_launch(d_work, d_frames, d_first, nf, kb, d_bb, st));
     } else {
         for (int i = 0; i < n; ++i) { out_bytes[i] = 0; dm[i]->tap_pll = nullptr; dm[i]->tap_llr = nullptr; }
     }
     // ---- 7: FIFO remainder to the spare buffer, NCO frequency for the getter
+    std::vector<int> curfill(2 * n);
+    for (int i = 0; i < n; ++i) { curfill[2 * i] = cur[i]; curfill[2 * i + 1] = dm[i]->fifo_fill; }
+    HIP_TRY(hipMemcpyAsync(d_curfill, curfill.data(), sizeof(int) * 2 * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(s2_fifo_compact_launch(d_work, n, d_curfill, st));
+    std::vector<float> nco(n);
+    HIP_TRY(s2_collect_launch(d_work, n, d_nsym, d_nco, st));
+    HIP_TRY(hipMemcpyAsync(nco.data(), d_nco, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     for (int i = 0; i < n; ++i) {
         dvbs2gpu_demod* d = dm[i];
-        int rem = d->fifo_fill - cur[i];
-        if (cur[i] > 0) {
-            if (rem > 0)
-                HIP_TRY(hipMemcpyAsync(d->d_fifo[d->fifo_cur ^ 1], d->d_fifo[d->fifo_cur] + cur[i], (size_t)rem * sizeof(cf32),
-                                       hipMemcpyDeviceToDevice, st));
-            d->fifo_cur ^= 1;
-            d->fifo_fill = rem;
-        }
-        HIP_TRY(hipMemcpyAsync(&d->nco_freq_host, &d->d_state->nco_freq, sizeof(float), hipMemcpyDeviceToHost, st));
+        if (cur[i] > 0) { d->fifo_fill -= cur[i]; d->fifo_cur ^= 1; }
+        d->nco_freq_host = nco[i];
     }
-    HIP_TRY(hipStreamSynchronize(st));
     for (int i = 0; i < n; ++i) {
         for (int f = first[i]; f < first[i + 1]; ++f) {
             S2FrameStats s = hstats[f];

@@ -46,6 +46,8 @@ struct S2StreamWork {
     cf32* fifo;              // PL-sync symbol FIFO
     int fifo_fill;           // symbols already in the FIFO before this call
     S2StreamState* st;
+    cf32* fifo_next;         // spare FIFO buffer (receives the unconsumed tail at the end of the call)
+    uint8_t* out;            // BBFRAME output of this stream
 };
 
 // one aligned PLFRAME found by PL sync
@@ -86,6 +88,11 @@ hipError_t s2_plsync_launch(const cf32* const* d_win, int nwin, int raw, int* d_
 hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const S2FrameRef* d_frames, const int* d_first,
                                  S2LoopCoefs coefs, S2PlTablesDev tabs, S2ConstelDev con, int pls_code, int slots, int pilots,
                                  int pilot_blocks, int plframe, cf32* d_pllout, S2FrameStats* d_stats, hipStream_t st);
+// batched tails of a call: per-stream symbol counts / NCO frequency in contiguous arrays, BBFRAME scatter, FIFO compaction
+hipError_t s2_collect_launch(const S2StreamWork* d_work, int nstreams, int* d_nsym, float* d_nco, hipStream_t st);
+hipError_t s2_scatter_out_launch(const S2StreamWork* d_work, const S2FrameRef* d_frames, const int* d_first, int nframes, int kb,
+                                 const uint8_t* d_bb, hipStream_t st);
+hipError_t s2_fifo_compact_launch(const S2StreamWork* d_work, int nstreams, const int* d_cur_fill /*[2*nstreams]: cur, fill*/, hipStream_t st);
 hipError_t s2_demap_launch(S2ConstelDev con, int rate, int shortframe, int slots, int pilots, int plframe, const cf32* d_pllout,
                            int nframes, int8_t* d_llr, int N, hipStream_t st);
 

@@ -85,7 +85,8 @@ constexpr int FE_TILE = 256;
 __global__ __launch_bounds__(64) void s2_frontend_kernel(const S2StreamWork* __restrict__ work, int nstreams, S2LoopCoefs co,
                                                          const float* __restrict__ bank_g) {
     __shared__ __attribute__((aligned(16))) float bank[GARDNER_PHASES * GARDNER_TAPS];
-    __shared__ cf32 raw[FE_TILE];            // input tile, then AGC output in place
+    __shared__ cf32 raw[FE_TILE];            // input tile
+    __shared__ cf32 ys[FE_TILE];             // AGC output (separate array: lets the tile reads run ahead of the serial chain)
     __shared__ float ph[FE_TILE];            // NCO phase per sample
     __shared__ float xre[FE_TILE + 8], xim[FE_TILE + 8];   // NCO output: [7 history][tile]
     __shared__ cf32 ostage[FE_TILE + FE_TILE / 16 + 16];
@@ -106,21 +107,41 @@ __global__ __launch_bounds__(64) void s2_frontend_kernel(const S2StreamWork* __r
         for (int i = lane; i < m; i += 64) raw[i] = w.in[base + i];
         __syncthreads();
         // ---- AGC (serial gain recurrence) + NCO phase recurrence; every lane runs the same scalar chain
-        for (int i = 0; i < m; ++i) {
-            cf32 x = raw[i];
-            cf32 y = cscale(x, gain);
-            float a = camp(y);
-            gain += (1.0f - a) * co.agc_rate;
-            if (gain > 10e6f) gain = 10e6f;
-            if (lane == 0) { raw[i] = y; ph[i] = nph; }
-            nph += nfr;
-            while ((double)nph > 6.283185307179586) nph = (float)((double)nph - 6.283185307179586);
-            while ((double)nph < -6.283185307179586) nph = (float)((double)nph + 6.283185307179586);
+        {
+            const cf32* __restrict__ rp = raw;
+            cf32* __restrict__ yp = ys;
+            float* __restrict__ pp = ph;
+            int i = 0;
+            for (; i + 4 <= m; i += 4) {
+                cf32 x0 = rp[i], x1 = rp[i + 1], x2 = rp[i + 2], x3 = rp[i + 3];
+                cf32 xs4[4] = {x0, x1, x2, x3};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    cf32 y = cscale(xs4[u], gain);
+                    float a = camp(y);
+                    gain += (1.0f - a) * co.agc_rate;
+                    if (gain > 10e6f) gain = 10e6f;
+                    if (lane == 0) { yp[i + u] = y; pp[i + u] = nph; }
+                    nph += nfr;
+                    while ((double)nph > 6.283185307179586) nph = (float)((double)nph - 6.283185307179586);
+                    while ((double)nph < -6.283185307179586) nph = (float)((double)nph + 6.283185307179586);
+                }
+            }
+            for (; i < m; ++i) {
+                cf32 y = cscale(rp[i], gain);
+                float a = camp(y);
+                gain += (1.0f - a) * co.agc_rate;
+                if (gain > 10e6f) gain = 10e6f;
+                if (lane == 0) { yp[i] = y; pp[i] = nph; }
+                nph += nfr;
+                while ((double)nph > 6.283185307179586) nph = (float)((double)nph - 6.283185307179586);
+                while ((double)nph < -6.283185307179586) nph = (float)((double)nph + 6.283185307179586);
+            }
         }
         __syncthreads();
         // ---- NCO rotation, parallel over the tile
         for (int i = lane; i < m; i += 64) {
-            cf32 z = cmul(raw[i], phasor_fast(-ph[i]));
+            cf32 z = cmul(ys[i], phasor_fast(-ph[i]));
             xre[GARDNER_TAPS - 1 + i] = z.re; xim[GARDNER_TAPS - 1 + i] = z.im;
         }
         __syncthreads();
@@ -507,7 +528,42 @@ __global__ __launch_bounds__(256) void s2_demap_kernel(S2ConstelDev C, int rate,
     }
 }
 
+// ------------------------------------------------------------------------------------------------ call tails
+__global__ void s2_collect_kernel(const S2StreamWork* __restrict__ work, int nstreams, int* __restrict__ nsym, float* __restrict__ nco) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < nstreams) { nsym[s] = work[s].st->n_sym; nco[s] = work[s].st->nco_freq; }
+}
+__global__ __launch_bounds__(256) void s2_scatter_out_kernel(const S2StreamWork* __restrict__ work, const S2FrameRef* __restrict__ frames,
+                                                             const int* __restrict__ first, int kb, const uint8_t* __restrict__ bb) {
+    const int f = blockIdx.x;
+    const int s = frames[f].stream;
+    uint8_t* __restrict__ dst = work[s].out + (size_t)(f - first[s]) * kb;
+    const uint8_t* __restrict__ src = bb + (size_t)f * kb;
+    for (int i = threadIdx.x; i < kb; i += 256) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void s2_fifo_compact_kernel(const S2StreamWork* __restrict__ work, const int* __restrict__ cur_fill) {
+    const int s = blockIdx.y;
+    const int cur = cur_fill[2 * s], fill = cur_fill[2 * s + 1];
+    if (cur <= 0) return;
+    const cf32* __restrict__ src = work[s].fifo + cur;
+    cf32* __restrict__ dst = work[s].fifo_next;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < fill - cur; i += gridDim.x * 256) dst[i] = src[i];
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
+hipError_t s2_collect_launch(const S2StreamWork* d_work, int nstreams, int* d_nsym, float* d_nco, hipStream_t st) {
+    hipLaunchKernelGGL(s2_collect_kernel, dim3((nstreams + 255) / 256), dim3(256), 0, st, d_work, nstreams, d_nsym, d_nco);
+    return hipGetLastError();
+}
+hipError_t s2_scatter_out_launch(const S2StreamWork* d_work, const S2FrameRef* d_frames, const int* d_first, int nframes, int kb,
+                                 const uint8_t* d_bb, hipStream_t st) {
+    hipLaunchKernelGGL(s2_scatter_out_kernel, dim3(nframes), dim3(256), 0, st, d_work, d_frames, d_first, kb, d_bb);
+    return hipGetLastError();
+}
+hipError_t s2_fifo_compact_launch(const S2StreamWork* d_work, int nstreams, const int* d_cur_fill, hipStream_t st) {
+    hipLaunchKernelGGL(s2_fifo_compact_kernel, dim3(16, nstreams), dim3(256), 0, st, d_work, d_cur_fill);
+    return hipGetLastError();
+}
 hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCoefs coefs, const float* d_bank, hipStream_t st) {
     hipLaunchKernelGGL(s2_frontend_kernel, dim3(nstreams), dim3(64), 0, st, d_work, nstreams, coefs, d_bank);
     return hipGetLastError();
