@@ -137,9 +137,10 @@ static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, 
     LdpcDeviceCode* C;
     int rc = get_ldpc(ctx, f.code_index, &C);
     if (rc) return rc;
+    // workgroups hold LDPC_FPB = 2 frame slots (ldpc_kernel.hip)
     int grid = ctx->num_cus * C->blocks_per_cu;
-    if (grid > nframes) grid = nframes;
-    size_t need = (size_t)grid * C->R * C->rec_dwords * sizeof(uint32_t);
+    if (grid > (nframes + 1) / 2) grid = (nframes + 1) / 2;
+    size_t need = (size_t)grid * 2 * C->R * C->rec_dwords * sizeof(uint32_t);
     if ((rc = ctx->ws_msg.ensure(need))) return rc;
     if (!d_trials) {
         if ((rc = ctx->ws_misc.ensure((size_t)nframes * 2 * sizeof(int32_t)))) return rc;

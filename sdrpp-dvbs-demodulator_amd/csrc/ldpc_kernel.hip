@@ -41,7 +41,7 @@ struct LdpcKernelArgs {
 
 #ifdef LDPC_PROF
 #define PROF_T(var) unsigned long long var = clock64()
-#define PROF_ADD(slot, t0, t1) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) A.prof[(threadIdx.x >> 6) * 16 + (slot)] += (t1) - (t0); } while (0)
+#define PROF_ADD(slot, t0, t1) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) A.prof[((threadIdx.x >> 6) % 6) * 16 + (slot)] += (t1) - (t0); } while (0)
 #else
 #define PROF_T(var) do { } while (0)
 #define PROF_ADD(slot, t0, t1) do { } while (0)
@@ -123,12 +123,13 @@ __device__ __forceinline__ int link_addr(uint32_t ent, int j) {
 template <int MAXDEG, int REC, bool CONF, bool IRREG>
 __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const LdpcKernelArgs& A, const uint32_t* __restrict__ ents,
                                              const LdpcLayerDesc L, uint32_t rowword, int layer, int j, bool active,
-                                             const uint32_t (&rec_in)[REC], uint32_t* __restrict__ rec_out_ptr) {
+                                             const uint32_t (&rec_in)[REC], uint32_t* __restrict__ rec_out_ptr,
+                                             uint32_t* __restrict__ cw, uint8_t* __restrict__ cres) {
     constexpr int NL = MAXDEG + 2;
     constexpr int MAXC = MAXDEG < LDPC_MAX_CONFLICT_LINKS ? MAXDEG : LDPC_MAX_CONFLICT_LINKS;
     int in[NL], mg[NL];
     int addr[MAXDEG];
-    const int deg = IRREG ? (int)L.deg : MAXDEG;
+    const int deg = IRREG ? (int)(L.deg & 0xffffu) : MAXDEG;
     const int nc = CONF ? (int)(L.depth_nc >> 16) : 0;
     const uint32_t level = rowword & 0xffu, late = (rowword >> 8) & 0xfffu, early = rowword >> 20;
     int min0 = 255, min1 = 255, sx = 0;
@@ -171,15 +172,89 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
     PROF_T(t_b);
     PROF_ADD(CONF ? 4 : 0, t_a, t_b);
     if constexpr (CONF) {
+        const int chain_d = (int)(L.deg >> 16);
+        if (chain_d > 0) {
+            // ---- chain walk (single shared pair, links 0 = E, 1 = L; see ldpc_plan.h).  Level-1 rows (j < d) publish
+            // their early links; every row whose L link is late leaves {exclusive min over its other links, in_E,
+            // old L message, sign} in cw[]; lanes c < d of wave 0 then walk rows c+d, c+2d, ...: the posterior written
+            // by one row's E link is the next row's L input and stays in a register.  new_msg() of a link equals
+            // sign * (minimum magnitude over the row's OTHER links) -- that is what (mag==min0 ? min1 : min0) selects.
+            if (active) {
+                if (level == 1u) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        if ((early >> k) & 1) {
+                            int nm = new_msg(in[k], mg[k], min0, min1, sx);
+                            post[addr[k]] = (int8_t)clamp8(in[k] + nm);
+                        }
+                    }
+                }
+                if ((late >> 1) & 1) {
+                    const int qE = (late & 1u) ? 255 : ((mg[0] == min0) ? min1 : min0);
+                    const int sgn = ((sx ^ in[0]) >> 31) & 1;
+                    cw[j] = (uint32_t)(qE & 0xff) | ((uint32_t)(in[0] & 0xff) << 8) |
+                            ((uint32_t)(rec_byte<REC>(rec_in, 1) & 0xff) << 16) | ((uint32_t)sgn << 24) | ((uint32_t)(early & 1u) << 25);
+                }
+            }
+            lds_barrier();
+            if (j < chain_d && active) {
+#ifdef LDPC_CHAIN_PRIO
+                __builtin_amdgcn_s_setprio(3);           // the chain is the workgroup's critical path: win issue arbitration
+#endif
+                const uint32_t eL = ents[1];
+                int row = j + chain_d;
+                int x = post[link_addr(eL, row)];        // written by the level-1 row j (its E link)
+                uint32_t w = cw[row];
+                while (row < 360) {
+                    const int nrow = row + chain_d;
+                    const uint32_t wn = cw[nrow < 360 ? nrow : row];   // prefetch the next row's word
+                    cres[row] = (uint8_t)x;
+                    const int qE = (int)(w & 0xffu);
+                    const int vE = (int)__builtin_amdgcn_sbfe((int)w, 8, 8);
+                    const int mL0 = (int)__builtin_amdgcn_sbfe((int)w, 16, 8);
+                    const int sgnbit = (int)((w >> 24) & 1u);
+                    const int vL = clamp8(x - mL0);
+                    const int mag = min(qE, mag_of(vL));
+                    const int neg = -(sgnbit ^ ((vL >> 31) & 1));
+                    const int nm = med3i((mag ^ neg) - neg, -32, 31);
+                    x = clamp8(vE + nm);                  // posterior after this row's E-link write (only meaningful if E is early)
+                    row = nrow;
+                    w = wn;
+                }
+#ifdef LDPC_CHAIN_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+            }
+            lds_barrier();
+            if (active) {
+                if ((late >> 1) & 1) {
+                    int v = clamp8((int)(int8_t)cres[j] - rec_byte<REC>(rec_in, 1));
+                    int m = mag_of(v);
+                    in[1] = v; mg[1] = m;
+                    ROW_ACCUM(v, m);
+                }
+                if (late & 1u) {
+                    int v = clamp8((int)post[addr[0]] - rec_byte<REC>(rec_in, 0));
+                    int m = mag_of(v);
+                    in[0] = v; mg[0] = m;
+                    ROW_ACCUM(v, m);
+                }
+            }
+        } else {
         // rows of level 1 have complete totals: they publish the links a later row waits for right away
         const int depth = (int)(L.depth_nc & 0xffffu);
         for (int lvl = 1; lvl <= depth; ++lvl) {
             if (lvl > 1) lds_barrier();
             if (active && level == (uint32_t)lvl) {
+                // keep the per-link mask tests inside the loop: hoisted, they would pin 2 SGPRs per (link, mask) pair
+                uint32_t late_l = late, early_l = early;
+#ifndef LDPC_NO_LICM_BLOCK
+                asm volatile("" : "+v"(late_l), "+v"(early_l));
+#endif
                 if (lvl > 1) {
 #pragma unroll
                     for (int k = 0; k < MAXC; ++k) {
-                        if (k < nc && ((late >> k) & 1)) {
+                        if (k < nc && ((late_l >> k) & 1)) {
                             int v = clamp8((int)post[addr[k]] - rec_byte<REC>(rec_in, k));
                             int m = mag_of(v);
                             in[k] = v; mg[k] = m;
@@ -189,12 +264,13 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                 }
 #pragma unroll
                 for (int k = 0; k < MAXC; ++k) {
-                    if (k < nc && ((early >> k) & 1)) {
+                    if (k < nc && ((early_l >> k) & 1)) {
                         int nm = new_msg(in[k], mg[k], min0, min1, sx);
                         post[addr[k]] = (int8_t)clamp8(in[k] + nm);
                     }
                 }
             }
+        }
         }
     }
     PROF_T(t_c);
@@ -233,7 +309,7 @@ __device__ __forceinline__ bool rows_bad(const int8_t* __restrict__ post, const 
     for (int layer = 0; layer < A.q; ++layer) {
         const LdpcLayerDesc L = layers[layer];
         const uint32_t* __restrict__ ents = ents_all + L.ent_off;
-        const int deg = IRREG ? (int)L.deg : MAXDEG;
+        const int deg = IRREG ? (int)(L.deg & 0xffffu) : MAXDEG;
         const int own = A.K + 360 * layer + j;
         int x = post[own];
         int sx = x;
@@ -255,42 +331,68 @@ __device__ __forceinline__ bool rows_bad(const int8_t* __restrict__ post, const 
     return badacc != 0;
 }
 
-template <int MAXDEG, int REC, bool IRREG>
-__global__ __launch_bounds__(384) void ldpc_decode_kernel(const LdpcLayerDesc* __restrict__ layers, const uint32_t* __restrict__ ents,
-                                                          const uint32_t* __restrict__ rows, LdpcKernelArgs A) {
-    extern __shared__ __attribute__((aligned(16))) int8_t post[];
-    __shared__ int s_flag[8];
-    const int j = threadIdx.x;
-    const bool active = j < 360;
-    const int N = A.N, K = A.K, R = A.R, q = A.q;
-    uint32_t* __restrict__ msg = A.msg_ws + (size_t)blockIdx.x * (size_t)R * REC;
+// TWO FRAMES PER WORKGROUP, in lockstep: 768 threads = 12 waves; threads [0,384) decode frame slot 0, [384,768)
+// slot 1 (lane j < 360 of a slot owns row j of every layer).  Both slots walk the same layer sequence, so the
+// workgroup barriers are shared (half the barrier cost per frame), the serial chain / level phases of the two
+// frames overlap, and one 12-wave workgroup per CU always gets 3 waves on each SIMD (two independent 6-wave
+// workgroups only co-reside when the dispatcher happens to start them on complementary SIMDs).
+constexpr int LDPC_FPB = 2;          // frame slots per workgroup
+constexpr int LDPC_TPS = 384;        // threads per slot
 
-    for (int f = blockIdx.x; f < A.nframes; f += gridDim.x) {
-        const int8_t* __restrict__ src = A.llr + (size_t)f * N;
-        // information-bit LLRs: straight copy (K is a multiple of 8)
-        for (int i = j; i < K / 8; i += 384) reinterpret_cast<uint2*>(post)[i] = reinterpret_cast<const uint2*>(src)[i];
-        // parity LLRs: pty[360*i + jj] = llr[K + q*jj + i]   (layered_decoder.hh:124-126)
-        for (int c = j; c < R; c += 384) {
-            int jj = c / q, i = c - jj * q;
-            post[K + 360 * i + jj] = src[K + c];
+template <int MAXDEG, int REC, bool IRREG>
+__global__ __launch_bounds__(LDPC_FPB * LDPC_TPS, 3) void ldpc_decode_kernel(const LdpcLayerDesc* __restrict__ layers, const uint32_t* __restrict__ ents,
+                                                                               const uint32_t* __restrict__ rows, LdpcKernelArgs A) {
+    extern __shared__ __attribute__((aligned(16))) int8_t post_all[];
+    __shared__ int s_flag[LDPC_FPB][8];
+    __shared__ int s_done[LDPC_FPB];
+    __shared__ uint32_t s_cw[LDPC_FPB][360];      // chain-walk hand-off words (conflict layers with a single shared pair)
+    __shared__ uint8_t s_cres[LDPC_FPB][384];
+    const int fs = threadIdx.x / LDPC_TPS;
+    const int j = threadIdx.x - fs * LDPC_TPS;
+    const int N = A.N, K = A.K, R = A.R, q = A.q;
+    const int npad = (N + 15) & ~15;
+    int8_t* __restrict__ post = post_all + (size_t)fs * npad;
+    uint32_t* __restrict__ msg = A.msg_ws + ((size_t)blockIdx.x * LDPC_FPB + fs) * (size_t)R * REC;
+    uint32_t* __restrict__ cw = s_cw[fs];
+    uint8_t* __restrict__ cres = s_cres[fs];
+
+    for (int f0 = blockIdx.x * LDPC_FPB; f0 < A.nframes; f0 += gridDim.x * LDPC_FPB) {
+        const int f = f0 + fs;
+        const bool valid = f < A.nframes;
+        const bool lane_ok = (j < 360) && valid;
+        if (valid) {
+            const int8_t* __restrict__ src = A.llr + (size_t)f * N;
+            // information-bit LLRs: straight copy (K is a multiple of 8)
+            for (int i = j; i < K / 8; i += LDPC_TPS) reinterpret_cast<uint2*>(post)[i] = reinterpret_cast<const uint2*>(src)[i];
+            // parity LLRs: pty[360*i + jj] = llr[K + q*jj + i]   (layered_decoder.hh:124-126)
+            for (int c = j; c < R; c += LDPC_TPS) {
+                int jj = c / q, i = c - jj * q;
+                post[K + 360 * i + jj] = src[K + c];
+            }
         }
         lds_barrier();
 
         int it = 0, ret = 0;
+        bool done = !valid;
         while (true) {
-            if (!A.force || it == A.max_trials) {
-                bool bad = active ? rows_bad<MAXDEG, IRREG>(post, A, layers, ents, j) : false;
-                // workgroup OR of `bad`
+            const bool check = !done && (!A.force || it == A.max_trials);
+            if (check) {
+                bool bad = lane_ok ? rows_bad<MAXDEG, IRREG>(post, A, layers, ents, j) : false;
                 unsigned long long b = __ballot(bad);
-                if ((j & 63) == 0) s_flag[j >> 6] = (b != 0);
-                lds_barrier();
-                int any = s_flag[0] | s_flag[1] | s_flag[2] | s_flag[3] | s_flag[4] | s_flag[5];
-                lds_barrier();
-                if (A.force) { ret = any ? -1 : A.max_trials; break; }
-                if (!any) { ret = it; break; }
-                if (it == A.max_trials) { ret = -1; break; }
+                if ((j & 63) == 0) s_flag[fs][j >> 6] = (b != 0);
             }
+            lds_barrier();
+            if (check) {
+                int any = s_flag[fs][0] | s_flag[fs][1] | s_flag[fs][2] | s_flag[fs][3] | s_flag[fs][4] | s_flag[fs][5];
+                if (A.force) { ret = any ? -1 : A.max_trials; done = true; }
+                else if (!any) { ret = it; done = true; }
+                else if (it == A.max_trials) { ret = -1; done = true; }
+            }
+            if (j == 0) s_done[fs] = done;
+            lds_barrier();
+            if (s_done[0] && s_done[1]) break;
             // ---- one layered sweep (LDPCDecoder::update), descriptors / records / row words prefetched one layer ahead
+            const bool active = lane_ok && !done;
             const bool first = (it == 0);
             uint32_t rec_next[REC];
 #pragma unroll
@@ -314,20 +416,20 @@ __global__ __launch_bounds__(384) void ldpc_decode_kernel(const LdpcLayerDesc* _
                 }
                 PROF_T(t_h);
                 PROF_ADD(7, t_g, t_h);
-                if ((L.depth_nc & 0xffffu) == 1) layer_update<MAXDEG, REC, false, IRREG>(post, A, ents + L.ent_off, L, 1u, layer, j, active, rec, rp);
-                else layer_update<MAXDEG, REC, true, IRREG>(post, A, ents + L.ent_off, L, rw, layer, j, active, rec, rp);
+                if ((L.depth_nc & 0xffffu) == 1) layer_update<MAXDEG, REC, false, IRREG>(post, A, ents + L.ent_off, L, 1u, layer, j, active, rec, rp, cw, cres);
+                else layer_update<MAXDEG, REC, true, IRREG>(post, A, ents + L.ent_off, L, rw, layer, j, active, rec, rp, cw, cres);
                 PROF_T(t_e);
                 lds_barrier();
                 PROF_T(t_f);
                 PROF_ADD(3, t_e, t_f);
             }
-            ++it;
+            if (!done) ++it;
         }
 
         // ---- outputs
-        if (j == 0) A.trials[f] = ret;
-        // hard decisions of [0,K): 64 bits per wave step via ballot, MSB-first bytes (module_dvbs2_demod.cpp:357-360)
-        {
+        if (valid) {
+            if (j == 0) A.trials[f] = ret;
+            // hard decisions of [0,K): 64 bits per wave step via ballot, MSB-first bytes (module_dvbs2_demod.cpp:357-360)
             uint8_t* __restrict__ hd = A.hard + (size_t)f * A.hard_stride;
             const int lane = j & 63, wave = j >> 6;
             for (int base = wave * 64; base < K; base += 6 * 64) {
@@ -341,13 +443,13 @@ __global__ __launch_bounds__(384) void ldpc_decode_kernel(const LdpcLayerDesc* _
                     else for (int n = 0; n < nbytes; ++n) hd[base / 8 + n] = (uint8_t)(b >> (8 * n));
                 }
             }
-        }
-        if (A.post) {
-            int8_t* __restrict__ dst = A.post + (size_t)f * N;
-            for (int i = j; i < K / 8; i += 384) reinterpret_cast<uint2*>(dst)[i] = reinterpret_cast<const uint2*>(post)[i];
-            for (int c = j; c < R; c += 384) {
-                int jj = c / q, i = c - jj * q;
-                dst[K + c] = post[K + 360 * i + jj];
+            if (A.post) {
+                int8_t* __restrict__ dst = A.post + (size_t)f * N;
+                for (int i = j; i < K / 8; i += LDPC_TPS) reinterpret_cast<uint2*>(dst)[i] = reinterpret_cast<const uint2*>(post)[i];
+                for (int c = j; c < R; c += LDPC_TPS) {
+                    int jj = c / q, i = c - jj * q;
+                    dst[K + c] = post[K + 360 * i + jj];
+                }
             }
         }
         lds_barrier();
@@ -356,21 +458,21 @@ __global__ __launch_bounds__(384) void ldpc_decode_kernel(const LdpcLayerDesc* _
 
 template <int MAXDEG, int REC, bool IRREG>
 static hipError_t launch_ldpc(const LdpcDeviceCode& C, const LdpcKernelArgs& A, int grid, hipStream_t stream) {
-    size_t lds = (size_t)((A.N + 15) / 16) * 16;
+    size_t lds = (size_t)((A.N + 15) / 16) * 16 * LDPC_FPB;
     auto kern = ldpc_decode_kernel<MAXDEG, REC, IRREG>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(384), lds, stream, C.d_layers, C.d_ents, C.d_rows, A);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(LDPC_FPB * LDPC_TPS), lds, stream, C.d_layers, C.d_ents, C.d_rows, A);
     return hipGetLastError();
 }
 
 template <int MAXDEG, int REC, bool IRREG>
 static int occupancy_ldpc(int N) {
     int nb = 0;
-    size_t lds = (size_t)((N + 15) / 16) * 16;
+    size_t lds = (size_t)((N + 15) / 16) * 16 * LDPC_FPB;
     auto kern = ldpc_decode_kernel<MAXDEG, REC, IRREG>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 384, lds) != hipSuccess) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, LDPC_FPB * LDPC_TPS, lds) != hipSuccess) nb = 1;
     return nb < 1 ? 1 : nb;
 }
 

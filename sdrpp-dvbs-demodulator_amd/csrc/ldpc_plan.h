@@ -23,7 +23,10 @@ namespace s2 {
 
 struct LdpcLayerDesc {   // 16 bytes = one s_load_dwordx4 (all fields 32-bit: sub-dword fields would force vector loads)
     uint32_t ent_off;    // index of the layer's first link entry
-    uint32_t deg;        // information-bit links per row in this layer
+    uint32_t deg;        // bits 0..15: information-bit links per row in this layer; bits 16..31: chain step d (0 = none):
+                         // d != 0 marks a layer whose only shared links are one pair (links 0 = "E", 1 = "L") with row j's
+                         // E-bit == row (j+d)'s L-bit: its dependency chains j, j+d, j+2d.. are walked by d lanes with the
+                         // shared posterior forwarded in a register (ldpc_kernel.hip, chain walk)
     uint32_t depth_nc;   // bits 0..15 depth (1 = conflict-free, else number of levels), bits 16..31 nc = number of
                          // conflict links (they are links 0..nc-1)
     uint32_t row_off;    // index of the layer's first per-row word (conflict layers only)
@@ -33,6 +36,9 @@ struct LdpcLayerDesc {   // 16 bytes = one s_load_dwordx4 (all fields 32-bit: su
 // per-row word (conflict layers): bits 0..7 level, 8..19 late mask, 20..31 early mask (over links 0..nc-1)
 
 constexpr int LDPC_MAX_CONFLICT_LINKS = 12;
+#ifndef LDPC_CHAIN_MAX_D
+#define LDPC_CHAIN_MAX_D 180  // chain walk for every single shared pair (step d = 1..180, d lanes); 0 disables it
+#endif
 
 struct LdpcPlan {
     int code_index = -1;
@@ -60,7 +66,7 @@ inline LdpcPlan build_ldpc_plan(int code_index) {
         L.deg = (uint32_t)(d.off[i + 1] - d.off[i]);
         L.row_off = 0;
         uint32_t l_depth = 1, l_nc = 0;
-        P.min_deg = std::min(P.min_deg, (int)L.deg);
+        P.min_deg = std::min(P.min_deg, (int)(L.deg & 0xffff));
         std::vector<int> rr, ss;
         for (int e = d.off[i]; e < d.off[i + 1]; ++e) {
             rr.push_back((int)(d.ent[e] >> 16));
@@ -78,6 +84,17 @@ inline LdpcPlan build_ldpc_plan(int code_index) {
         std::vector<int> r2, s2v;
         for (int k : order) { r2.push_back(rr[k]); s2v.push_back(ss[k]); }
         rr = r2; ss = s2v;
+        uint32_t chain_d = 0;
+        if (l_nc == 2 && rr[0] == rr[1]) {
+            // row j's link-A bit (j + spA) equals row j' link-B bit (j' + spB)  <=>  j' = j + (spA - spB) mod 360
+            int spA = (360 - ss[0]) % 360, spB = (360 - ss[1]) % 360;
+            int DA = ((spA - spB) % 360 + 360) % 360;
+            int d = std::min(DA, 360 - DA);
+            if (d >= 1 && d <= LDPC_CHAIN_MAX_D) {
+                chain_d = (uint32_t)d;
+                if (DA != d) { std::swap(rr[0], rr[1]); std::swap(ss[0], ss[1]); }   // link 0 = E (partner j + d), link 1 = L (partner j - d)
+            }
+        }
         for (int k = 0; k < (int)rr.size(); ++k) P.ents.push_back((uint32_t)((360 - ss[k]) % 360) | ((uint32_t)rr[k] << 16));
         if (l_nc > 0) {
             std::vector<uint32_t> late(360, 0), early(360, 0), level(360, 1);
@@ -107,6 +124,7 @@ inline LdpcPlan build_ldpc_plan(int code_index) {
             for (int j = 0; j < 360; ++j) P.rows.push_back(level[j] | (late[j] << 8) | (early[j] << 20));
             P.conflict_layers++;
         }
+        L.deg |= chain_d << 16;
         L.depth_nc = l_depth | (l_nc << 16);
         P.sum_depth += (int)l_depth;
         P.layers.push_back(L);

@@ -83,6 +83,7 @@ def test_ldpc_plan_matches_reference_row_order(pkg, rate, short):
     j = np.arange(360)
     for i in range(q):
         off, deg, dn, row_off = (int(x) for x in layers[i])
+        chain_d, deg = deg >> 16, deg & 0xffff
         depth, nc = dn & 0xffff, dn >> 16
         e = ents[off:off + deg]
         sp, r = (e & 0xffff).astype(np.int64), (e >> 16).astype(np.int64)
