@@ -137,8 +137,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--streams', type=int, default=1024, help='transponder streams per GPU')
-    ap.add_argument('--frames', type=int, default=4, help='PLFRAMEs per stream per step')
+    ap.add_argument('--streams', type=int, default=4096, help='transponder streams per GPU')
+    ap.add_argument('--frames', type=int, default=1, help='PLFRAMEs per stream per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 

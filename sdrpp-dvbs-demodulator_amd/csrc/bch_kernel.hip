@@ -84,8 +84,11 @@ __global__ __launch_bounds__(256) void bch_syndromes_kernel(BchDeviceCode C, con
         __syncthreads();
         if (tid == 0) {
             for (int i = 0; i < 32; ++i) sfin[i] = 0;
-            for (int r = 0; r < t; ++r) sfin[2 * r] = (uint16_t)(red[0][r] ^ red[1][r] ^ red[2][r] ^ red[3][r]);  // S_(2r+1)
-            for (int k = 1; k <= t; ++k) sfin[2 * k - 1] = G.vmul(sfin[k - 1], sfin[k - 1]);                      // S_2k = S_k^2
+            int nz = 0;
+            for (int r = 0; r < t; ++r) { sfin[2 * r] = (uint16_t)(red[0][r] ^ red[1][r] ^ red[2][r] ^ red[3][r]); nz |= sfin[2 * r]; }  // S_(2r+1)
+            if (nz)   // clean frame: the even syndromes are squares of zeros
+                for (int k = 1; k <= t; ++k) sfin[2 * k - 1] = G.vmul(sfin[k - 1], sfin[k - 1]);                  // S_2k = S_k^2
+            sfin[31] = nz ? 1 : 0;                                                                                 // "needs correction" flag
         }
         __syncthreads();
         if (tid < 32) syn_out[(size_t)f * 32 + tid] = sfin[tid];
@@ -107,6 +110,11 @@ __global__ __launch_bounds__(64) void bch_correct_kernel(BchDeviceCode C, uint8_
     for (int f = blockIdx.x; f < nframes; f += gridDim.x) {
         const uint16_t* __restrict__ syn = syn_in + (size_t)f * 32;
         // state: 0 = clean, 1 = need Chien, 2 = locations ready, -1 = failed
+        // fast path: the syndrome kernel left a flag; a clean frame costs one load
+        if (syn[31] == 0) {
+            if (lane == 0 && corrections) corrections[f] = 0;
+            continue;
+        }
         if (lane == 0) {
             int nonzero = 0;
             for (int i = 0; i < NR; ++i) nonzero += !!syn[i];
@@ -270,7 +278,7 @@ hipError_t bch_syndromes_launch(const BchDeviceCode& C, const uint8_t* frames, i
 }
 hipError_t bch_correct_launch(const BchDeviceCode& C, uint8_t* frames, int frame_stride, int nbch, int kbch, int nframes,
                               const uint16_t* syn, int32_t* corrections, hipStream_t stream) {
-    int grid = nframes < 8192 ? nframes : 8192;
+    int grid = nframes < 2048 ? nframes : 2048;
     hipLaunchKernelGGL(bch_correct_kernel, dim3(grid), dim3(64), 0, stream, C, frames, frame_stride, nbch, kbch, nframes, syn, corrections);
     return hipGetLastError();
 }

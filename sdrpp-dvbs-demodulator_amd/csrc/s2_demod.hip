@@ -511,13 +511,10 @@ int dvbs2gpu_demod_create(dvbs2gpu_ctx* ctx, const dvbs2gpu_demod_cfg* cfg, int 
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMalloc((void**)&d->d_state, sizeof(S2StreamState)));
-    HIP_TRY(hipMalloc((void**)&d->d_in, (size_t)max_samples * sizeof(cf32)));
     HIP_TRY(hipMalloc((void**)&d->d_fe, fe_capacity(max_samples) * sizeof(cf32)));
     // FIFO: leftover (< 2 PLFRAMEs, the largest one) + the symbols of one call
     d->fifo_cap = max_samples / 2 + max_samples / 32 + 2 * 33282 + 1024;
     for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void**)&d->d_fifo[k], (size_t)d->fifo_cap * sizeof(cf32)));
-    int max_frames = d->fifo_cap / 3330 + 2;
-    HIP_TRY(hipMalloc((void**)&d->d_out, (size_t)max_frames * 8100));
     if ((rc = demod_reset_state(d.get()))) return rc;
     *out = d.release();
     return DVBS2GPU_OK;
@@ -527,8 +524,8 @@ void dvbs2gpu_demod_destroy(dvbs2gpu_demod* d) {
     if (!d) return;
     (void)hipSetDevice(d->ctx->device);
     (void)hipDeviceSynchronize();
-    (void)hipFree(d->d_state); (void)hipFree(d->d_in); (void)hipFree(d->d_fe);
-    (void)hipFree(d->d_fifo[0]); (void)hipFree(d->d_fifo[1]); (void)hipFree(d->d_out);
+    (void)hipFree(d->d_state); if (d->d_in) (void)hipFree(d->d_in); (void)hipFree(d->d_fe);
+    (void)hipFree(d->d_fifo[0]); (void)hipFree(d->d_fifo[1]); if (d->d_out) (void)hipFree(d->d_out);
     delete d;
 }
 
@@ -583,6 +580,11 @@ int dvbs2gpu_demod_process(dvbs2gpu_demod* d, int count, const float* h_iq, uint
     if (!d || count < 0 || (count > 0 && !h_iq) || !h_out) return DVBS2GPU_ERR_ARG;
     if (count > d->max_samples) { last_error() = "count exceeds max_samples"; return DVBS2GPU_ERR_ARG; }
     HIP_TRY(hipSetDevice(d->ctx->device));
+    if (!d->d_in) {   // staging buffers of the host-pointer entry point, allocated on first use
+        HIP_TRY(hipMalloc((void**)&d->d_in, (size_t)d->max_samples * sizeof(cf32)));
+        int max_frames = d->fifo_cap / 3330 + 2;
+        HIP_TRY(hipMalloc((void**)&d->d_out, (size_t)max_frames * 8100));
+    }
     if (count) HIP_TRY(hipMemcpy(d->d_in, h_iq, (size_t)count * sizeof(cf32), hipMemcpyHostToDevice));
     const cf32* in = d->d_in;
     uint8_t* dout = d->d_out;

@@ -11,7 +11,7 @@ eng = pkg.Engine(0)
 rate, short = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (6, 0)
 iters = int(os.environ.get('ITERS', '20'))
 fi = pkg.fec_info(rate, short); pi = eng.ldpc_plan_info(rate, short)
-F = pi['cus'] * pi['blocks_per_cu']
+F = pi['cus'] * pi['blocks_per_cu'] * 2
 llr = torch.randint(-30, 31, (F, fi['ldpc_n']), dtype=torch.int8, device='cuda')
 buf = torch.zeros(96, dtype=torch.int64, device='cuda')
 eng.lib.dvbs2gpu_debug_set_prof.argtypes = [C.c_void_p]
