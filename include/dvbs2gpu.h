@@ -173,6 +173,54 @@ float dvbs2gpu_demod_get_nco_freq(dvbs2gpu_demod* d);
  * Returns the element count; copies at most cap elements when h_dst != NULL. */
 int dvbs2gpu_demod_get_tap(dvbs2gpu_demod* d, int which, void* h_dst, int cap);
 
+/* ================================================================== DVB-S inner code (rows a18-a20)
+ * All buffers are DEVICE pointers; calls are asynchronous on `stream`.  Handles keep per-stream state in HBM. */
+
+/* replaces the conversion of DVBSymToSoftBlock::process (dvbs/dvbs_syms_to_soft.cpp:7-13,28-31):
+ * d_soft[2i] = int8(clamp(re*100)), d_soft[2i+1] = int8(clamp(im*100)), truncation toward zero, clamp +-127.
+ * The 8192-byte blocking of :33-39 is the caller's (blocks are contiguous in d_soft). */
+int dvbs2gpu_dvbs_slice(dvbs2gpu_ctx* ctx, const float* d_iq, int nsymbols, int8_t* d_soft, void* stream);
+
+/* replaces viterbi::CCDecoder (dvbs/viterbi/cc_decoder.cpp): `nstreams` independent K=7 r=1/2 (polys 79,109) block
+ * decoders of `frame_size` bits with the reference's chaining (first block from all-31 metrics, every later block
+ * biased to the start state returned by the previous chain-back).  work_batch runs CCDecoder::work (:304-314) on
+ * `nblocks` consecutive blocks of every stream: block b of stream s is read at d_soft + s*stream_stride +
+ * b*block_stride, 2*(frame_size+6) unsigned soft bytes (128 = erasure); d_bits [nstreams][nblocks][frame_size], one
+ * bit per byte. */
+typedef struct dvbs2gpu_ccdec dvbs2gpu_ccdec;
+int dvbs2gpu_ccdec_create(dvbs2gpu_ctx* ctx, int nstreams, int frame_size, dvbs2gpu_ccdec** out);
+void dvbs2gpu_ccdec_destroy(dvbs2gpu_ccdec* h);
+int dvbs2gpu_ccdec_work_batch(dvbs2gpu_ccdec* h, const uint8_t* d_soft, int64_t stream_stride, int block_stride, int nblocks,
+                              uint8_t* d_bits, void* stream);
+
+/* replaces viterbi::Viterbi_DVBS (dvbs/viterbi_all.cpp:10-276) as created by DVBSDemod::init
+ * (module_dvbs_demod.cpp:23: threshold 0.15, max_outsync 20, 8192-soft blocks, phases {0, 90}): one self-locking
+ * punctured decoder per stream.  work_batch = DVBSVitBlock::process (dvbs_vit.cpp:6-12) for every stream: `nblocks`
+ * consecutive Viterbi_DVBS::work calls.
+ *   d_soft  [nstreams][nblocks][8192] int8 (not modified; the reference rotates it in place)
+ *   d_bits  [nstreams][nblocks][8192] decoded bits, one per byte; the first d_nbits[s][b] of a block are that call's
+ *           output (rate 5/6: bits [6799, nbits) are never written by the reference's decoder either -- stale bytes)
+ *   d_nbits [nstreams][nblocks] return values of work (0 while IDLE)
+ *   d_stats [nstreams][nblocks] or NULL: ber(), getState(), rate(), locked phase and shift after each call */
+typedef struct dvbs2gpu_viterbi dvbs2gpu_viterbi;
+typedef struct dvbs2gpu_viterbi_stats {
+    float ber;
+    int32_t state, rate, phase, shift;   /* state 0 IDLE / 1 SYNCED; rate 0..4 = 1/2,2/3,3/4,5/6,7/8 */
+} dvbs2gpu_viterbi_stats;
+int dvbs2gpu_viterbi_create(dvbs2gpu_ctx* ctx, int nstreams, float ber_threshold, int max_outsync, dvbs2gpu_viterbi** out);
+int dvbs2gpu_viterbi_reset(dvbs2gpu_viterbi* h);
+void dvbs2gpu_viterbi_destroy(dvbs2gpu_viterbi* h);
+int dvbs2gpu_viterbi_work_batch(dvbs2gpu_viterbi* h, const int8_t* d_soft, int nblocks, uint8_t* d_bits, int32_t* d_nbits,
+                                dvbs2gpu_viterbi_stats* d_stats, void* stream);
+
+/* replaces DVBSInterleaving (dvbs/dvbs_interleaving.h:27-70): Forney de-interleaver I=12, M=17, one per stream.
+ * d_in / d_out [nstreams][nbytes] (distinct buffers), nbytes a multiple of 12 (the reference handles 8*204 per call;
+ * any number of such groups may be passed at once -- the FIFO state carries over exactly). */
+typedef struct dvbs2gpu_forney dvbs2gpu_forney;
+int dvbs2gpu_forney_create(dvbs2gpu_ctx* ctx, int nstreams, dvbs2gpu_forney** out);
+void dvbs2gpu_forney_destroy(dvbs2gpu_forney* h);
+int dvbs2gpu_forney_deinterleave_batch(dvbs2gpu_forney* h, const uint8_t* d_in, int nbytes, uint8_t* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

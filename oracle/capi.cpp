@@ -201,3 +201,38 @@ void orc_gardner_bank(float* out1024) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------- DVB-S (dvbs.cpp)
+#include "dvbs.h"
+extern "C" {
+void* orc_dvbs_slicer_create() { return new DvbsSlicer(); }
+void orc_dvbs_slicer_destroy(void* h) { delete (DvbsSlicer*)h; }
+int orc_dvbs_slicer_process(void* h, int count, const float* iq, int8_t* out) { return ((DvbsSlicer*)h)->process(count, iq, out); }
+void orc_rotate_soft(int8_t* soft, int size, int phase, int iqswap) { rotate_soft(soft, size, phase, iqswap != 0); }
+void orc_signed_to_unsigned(const int8_t* in, uint8_t* out, int n) { signed_soft_to_unsigned(in, out, n); }
+int orc_depuncture_34(const uint8_t* in, uint8_t* out, int size, int shift) { return depuncture_34(in, out, size, shift != 0); }
+int orc_depuncture_78(const uint8_t* in, uint8_t* out, int size, int shift) { return depuncture_78(in, out, size, shift); }
+void* orc_depunc_create(int period) { return new DepuncCont(period); }
+void orc_depunc_destroy(void* h) { delete (DepuncCont*)h; }
+int orc_depunc_static(void* h, const uint8_t* in, uint8_t* out, int size, int shift) { return ((DepuncCont*)h)->depunc_static(in, out, size, shift); }
+void orc_depunc_set_shift(void* h, int shift) { ((DepuncCont*)h)->set_shift(shift); }
+int orc_depunc_cont(void* h, const uint8_t* in, uint8_t* out, int size) { return ((DepuncCont*)h)->depunc_cont(in, out, size); }
+void* orc_ccdec_create(int frame_size) { return new CcDecoder(frame_size); }
+void orc_ccdec_destroy(void* h) { delete (CcDecoder*)h; }
+// in must hold 2*(frame_size+6) bytes; returns the chained start state for the next block
+int orc_ccdec_work(void* h, const uint8_t* in, uint8_t* out) { ((CcDecoder*)h)->work(in, out); return ((CcDecoder*)h)->start_state_chaining; }
+void* orc_ccenc_create(int frame_size) { return new CcEncoder(frame_size); }
+void orc_ccenc_destroy(void* h) { delete (CcEncoder*)h; }
+void orc_ccenc_work(void* h, const uint8_t* in, uint8_t* out) { ((CcEncoder*)h)->work(in, out); }
+void* orc_vitdvbs_create(float thr, int max_outsync, int bufsize) { return new ViterbiDvbs(thr, max_outsync, bufsize); }
+void orc_vitdvbs_destroy(void* h) { delete (ViterbiDvbs*)h; }
+int orc_vitdvbs_work(void* h, int8_t* input, int size, uint8_t* output, float* ber_state4) {
+    ViterbiDvbs* v = (ViterbiDvbs*)h;
+    int n = v->work(input, size, output);
+    if (ber_state4) { ber_state4[0] = v->ber; ber_state4[1] = (float)v->state; ber_state4[2] = (float)v->rate; ber_state4[3] = (float)(v->d_phase * 16 + v->d_shift); }
+    return n;
+}
+void* orc_forney_create() { return new ForneyDeint(); }
+void orc_forney_destroy(void* h) { delete (ForneyDeint*)h; }
+void orc_forney_deinterleave(void* h, const uint8_t* in, uint8_t* out) { ((ForneyDeint*)h)->deinterleave(in, out); }
+}  // extern "C"

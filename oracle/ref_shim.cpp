@@ -86,3 +86,22 @@ void ref_deinterleave(int constel, int rate, int shortframe, int8_t* in, int8_t*
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------- DVB-S pieces that compile as is
+#include "dvbs/depunc.h"
+#include "dvbs/dvbs_interleaving.h"
+#include "common/codings/rotation.h"
+
+extern "C" {
+void* ref_depunc23_create() { return new viterbi::Depunc23(); }
+void* ref_depunc56_create() { return new viterbi::Depunc56(); }
+int ref_depunc23_static(void* h, uint8_t* in, uint8_t* out, int size, int shift) { return ((viterbi::Depunc23*)h)->depunc_static(in, out, size, shift); }
+int ref_depunc56_static(void* h, uint8_t* in, uint8_t* out, int size, int shift) { return ((viterbi::Depunc56*)h)->depunc_static(in, out, size, shift); }
+void ref_depunc23_set_shift(void* h, int s) { ((viterbi::Depunc23*)h)->set_shift(s); }
+void ref_depunc56_set_shift(void* h, int s) { ((viterbi::Depunc56*)h)->set_shift(s); }
+int ref_depunc23_cont(void* h, uint8_t* in, uint8_t* out, int size) { return ((viterbi::Depunc23*)h)->depunc_cont(in, out, size); }
+int ref_depunc56_cont(void* h, uint8_t* in, uint8_t* out, int size) { return ((viterbi::Depunc56*)h)->depunc_cont(in, out, size); }
+void* ref_forney_create() { return new dsp::dvbs::DVBSInterleaving(); }
+void ref_forney_deinterleave(void* h, uint8_t* in, uint8_t* out) { ((dsp::dvbs::DVBSInterleaving*)h)->deinterleave(in, out); }
+void ref_rotate_soft(int8_t* soft, int size, int phase, int iqswap) { rotate_soft(soft, size, (phase_t)phase, iqswap != 0); }
+}

@@ -13,6 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdvbs2gpu.so')
 
+ERR_ARG, ERR_MODCOD, ERR_HIP, ERR_NODEVICE, ERR_CAPACITY = -1, -2, -3, -4, -5
 ERR_NAMES = {-1: 'ERR_ARG', -2: 'ERR_MODCOD', -3: 'ERR_HIP', -4: 'ERR_NODEVICE', -5: 'ERR_CAPACITY'}
 
 
@@ -73,6 +74,18 @@ PROTOTYPES = {
     'dvbs2gpu_demod_get_stats': (_i, [_vp, C.POINTER(FrameStats), _i]),
     'dvbs2gpu_demod_get_nco_freq': (C.c_float, [_vp]),
     'dvbs2gpu_demod_get_tap': (_i, [_vp, _i, _vp, _i]),
+    # DVB-S inner code
+    'dvbs2gpu_dvbs_slice': (_i, [_vp, _vp, _i, _vp, _vp]),
+    'dvbs2gpu_ccdec_create': (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    'dvbs2gpu_ccdec_destroy': (None, [_vp]),
+    'dvbs2gpu_ccdec_work_batch': (_i, [_vp, _vp, C.c_int64, _i, _i, _vp, _vp]),
+    'dvbs2gpu_viterbi_create': (_i, [_vp, _i, C.c_float, _i, C.POINTER(_vp)]),
+    'dvbs2gpu_viterbi_reset': (_i, [_vp]),
+    'dvbs2gpu_viterbi_destroy': (None, [_vp]),
+    'dvbs2gpu_viterbi_work_batch': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    'dvbs2gpu_forney_create': (_i, [_vp, _i, C.POINTER(_vp)]),
+    'dvbs2gpu_forney_destroy': (None, [_vp]),
+    'dvbs2gpu_forney_deinterleave_batch': (_i, [_vp, _vp, _i, _vp, _vp]),
 }
 
 _lib = None
@@ -292,3 +305,96 @@ class Demod:
         if n:
             self.eng._check(self.lib.dvbs2gpu_demod_get_tap(self.h, which, C.c_void_p(a.ctypes.data), n))
         return a
+
+
+class _Handle:
+    _destroy = None
+
+    def close(self):
+        if getattr(self, 'h', None):
+            getattr(self.lib, self._destroy)(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CcDecoderBatch(_Handle):
+    """`nstreams` chained CCDecoder objects (dvbs/viterbi/cc_decoder.cpp) of `frame_size` bits."""
+    _destroy = 'dvbs2gpu_ccdec_destroy'
+
+    def __init__(self, engine, nstreams, frame_size):
+        self.eng, self.lib, self.nstreams, self.frame_size = engine, engine.lib, nstreams, frame_size
+        h = C.c_void_p()
+        engine._check(self.lib.dvbs2gpu_ccdec_create(engine.h, nstreams, frame_size, C.byref(h)))
+        self.h = h
+
+    def work(self, soft, nblocks, block_stride):
+        """soft uint8 CUDA [nstreams, L]; block b of a stream starts at b*block_stride.  -> bits uint8 [nstreams, nblocks, frame]"""
+        t = self.eng.torch
+        assert soft.dtype == t.uint8 and soft.is_cuda and soft.is_contiguous() and soft.shape[0] == self.nstreams
+        assert (nblocks - 1) * block_stride + 2 * (self.frame_size + 6) <= soft.shape[1]
+        bits = t.empty((self.nstreams, nblocks, self.frame_size), dtype=t.uint8, device=soft.device)
+        self.eng._check(self.lib.dvbs2gpu_ccdec_work_batch(self.h, _ptr(soft), soft.shape[1], block_stride, nblocks, _ptr(bits), self.eng._stream()))
+        return bits
+
+
+class ViterbiStats(C.Structure):
+    _fields_ = [('ber', C.c_float), ('state', C.c_int32), ('rate', C.c_int32), ('phase', C.c_int32), ('shift', C.c_int32)]
+
+
+class ViterbiBatch(_Handle):
+    """`nstreams` Viterbi_DVBS objects (dvbs/viterbi_all.cpp) as DVBSDemod::init creates them."""
+    _destroy = 'dvbs2gpu_viterbi_destroy'
+
+    def __init__(self, engine, nstreams, ber_threshold=0.15, max_outsync=20):
+        self.eng, self.lib, self.nstreams = engine, engine.lib, nstreams
+        h = C.c_void_p()
+        engine._check(self.lib.dvbs2gpu_viterbi_create(engine.h, nstreams, ber_threshold, max_outsync, C.byref(h)))
+        self.h = h
+
+    def reset(self):
+        self.eng._check(self.lib.dvbs2gpu_viterbi_reset(self.h))
+
+    def work(self, soft):
+        """soft int8 CUDA [nstreams, nblocks, 8192] -> (bits uint8 [nstreams, nblocks, 8192], nbits int32 [nstreams, nblocks],
+        stats int32 [nstreams, nblocks, 5] (ber as float bits, state, rate, phase, shift))"""
+        t = self.eng.torch
+        assert soft.dtype == t.int8 and soft.is_cuda and soft.is_contiguous() and soft.shape[0] == self.nstreams and soft.shape[2] == 8192
+        nb = soft.shape[1]
+        bits = t.zeros((self.nstreams, nb, 8192), dtype=t.uint8, device=soft.device)
+        nbits = t.zeros((self.nstreams, nb), dtype=t.int32, device=soft.device)
+        stats = t.zeros((self.nstreams, nb, 5), dtype=t.int32, device=soft.device)
+        self.eng._check(self.lib.dvbs2gpu_viterbi_work_batch(self.h, _ptr(soft), nb, _ptr(bits), _ptr(nbits), _ptr(stats), self.eng._stream()))
+        return bits, nbits, stats
+
+
+class ForneyBatch(_Handle):
+    """`nstreams` DVBSInterleaving de-interleavers (dvbs/dvbs_interleaving.h)."""
+    _destroy = 'dvbs2gpu_forney_destroy'
+
+    def __init__(self, engine, nstreams):
+        self.eng, self.lib, self.nstreams = engine, engine.lib, nstreams
+        h = C.c_void_p()
+        engine._check(self.lib.dvbs2gpu_forney_create(engine.h, nstreams, C.byref(h)))
+        self.h = h
+
+    def deinterleave(self, data):
+        """data uint8 CUDA [nstreams, nbytes] -> same shape"""
+        t = self.eng.torch
+        assert data.dtype == t.uint8 and data.is_cuda and data.is_contiguous() and data.shape[0] == self.nstreams
+        out = t.empty_like(data)
+        self.eng._check(self.lib.dvbs2gpu_forney_deinterleave_batch(self.h, _ptr(data), data.shape[1], _ptr(out), self.eng._stream()))
+        return out
+
+
+def dvbs_slice(engine, iq):
+    """iq complex64 CUDA 1-D -> int8 [2n] soft bits (DVBSymToSoftBlock conversion)"""
+    t = engine.torch
+    assert iq.dtype == t.complex64 and iq.is_cuda and iq.is_contiguous()
+    out = t.empty(2 * iq.numel(), dtype=t.int8, device=iq.device)
+    engine._check(engine.lib.dvbs2gpu_dvbs_slice(engine.h, _ptr(iq), iq.numel(), _ptr(out), engine._stream()))
+    return out

@@ -39,4 +39,37 @@ hipError_t bch_correct_launch(const BchDeviceCode& C, uint8_t* frames, int frame
 hipError_t bb_descramble_launch(const uint8_t* frames, int frame_stride, const uint8_t* prbs, int out_bytes, int nframes,
                                 uint8_t* out, hipStream_t stream);
 
+// ------------------------------------------------------------------ DVB-S inner code (dvbs_kernels.hip)
+// One Viterbi_DVBS object (viterbi_all.h:33-160) per stream; decoders 0-4 = BER-test decoders (rates 1/2,2/3,3/4,5/6,7/8),
+// 5-9 = main decoders; dep[0] = Depunc23, dep[1] = Depunc56.
+struct DvbsVitState {
+    int state, rate, phase, shift, invalid;
+    float ber;
+    int dec_ss[10], dec_biased[10];
+    int enc_state[5];
+    int dep_first[2], dep_shift[2], dep_extra[2], dep_buf[2];
+};
+struct DvbsVitStats {   // == dvbs2gpu_viterbi_stats
+    float ber;
+    int state, rate, phase, shift;
+};
+// per-stream workspace layout (bytes): ber_soft[2048] ++ ber_depunc[8192+64] | ber_enc[8192] | ber_dec[2048] | soft[8192+64] |
+// depunc[4*8192] | decision words [(7168+6) rounded up]
+constexpr int DVBS_VIT_WS_BER_ENC = 2048 + 8192 + 64;
+constexpr int DVBS_VIT_WS_BER_DEC = DVBS_VIT_WS_BER_ENC + 8192;
+constexpr int DVBS_VIT_WS_SOFT = DVBS_VIT_WS_BER_DEC + 2048;
+constexpr int DVBS_VIT_WS_DEPUNC = DVBS_VIT_WS_SOFT + 8192 + 64;
+constexpr int DVBS_VIT_WS_DEC = DVBS_VIT_WS_DEPUNC + 4 * 8192;
+constexpr int DVBS_VIT_WS_BYTES = DVBS_VIT_WS_DEC + 7232 * 8;
+constexpr int DVBS_FORNEY_HIST = 204 * 11;
+static_assert(DVBS_VIT_WS_DEC % 8 == 0 && DVBS_VIT_WS_BYTES % 8 == 0, "decision words must stay 8-byte aligned");
+
+hipError_t dvbs_slice_launch(const float* d_iq, int n, int8_t* d_out, hipStream_t st);
+hipError_t dvbs_cc_decode_launch(const uint8_t* d_in, long stream_stride, int block_stride, int nstreams, int nblocks, int frame_size,
+                                 uint8_t* d_out, long out_stream_stride, unsigned long long* d_dec_ws, int* d_state, hipStream_t st);
+hipError_t dvbs_viterbi_launch(const int8_t* d_soft, int nstreams, int nblocks, uint8_t* d_bits, int* d_nbits, DvbsVitStats* d_stats,
+                               DvbsVitState* d_states, uint8_t* d_ws, float thr, int max_outsync, hipStream_t st);
+hipError_t dvbs_deinterleave_launch(const uint8_t* d_in, long stream_stride, int nstreams, int nbytes, uint8_t* d_out, uint8_t* d_hist,
+                                    hipStream_t st);
+
 }  // namespace s2

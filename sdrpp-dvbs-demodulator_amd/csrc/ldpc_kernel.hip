@@ -198,9 +198,6 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
             }
             lds_barrier();
             if (j < chain_d && active) {
-#ifdef LDPC_CHAIN_PRIO
-                __builtin_amdgcn_s_setprio(3);           // the chain is the workgroup's critical path: win issue arbitration
-#endif
                 const uint32_t eL = ents[1];
                 int row = j + chain_d;
                 int x = post[link_addr(eL, row)];        // written by the level-1 row j (its E link)
@@ -221,9 +218,6 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                     row = nrow;
                     w = wn;
                 }
-#ifdef LDPC_CHAIN_PRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
             }
             lds_barrier();
             if (active) {
@@ -246,11 +240,8 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
         for (int lvl = 1; lvl <= depth; ++lvl) {
             if (lvl > 1) lds_barrier();
             if (active && level == (uint32_t)lvl) {
-                // keep the per-link mask tests inside the loop: hoisted, they would pin 2 SGPRs per (link, mask) pair
-                uint32_t late_l = late, early_l = early;
-#ifndef LDPC_NO_LICM_BLOCK
-                asm volatile("" : "+v"(late_l), "+v"(early_l));
-#endif
+                // (blocking LICM of the per-link mask tests with an empty asm was measured slower on MI355X: r01 A/B variant "e")
+                const uint32_t late_l = late, early_l = early;
                 if (lvl > 1) {
 #pragma unroll
                     for (int k = 0; k < MAXC; ++k) {
