@@ -5,6 +5,8 @@
 // It exists so tests can (a) pin the restatement in oracle/*.cpp and (b) generate tests/golden/*.
 #include <cstdint>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 #include "dvbs2/codings/bbframe_ldpc.h"
 #include "dvbs2/codings/bbframe_bch.h"
@@ -19,6 +21,21 @@ static dvbs2_code_rate_t to_rate(int r) {
     return map[r];
 }
 static dvbs2_framesize_t to_fs(int s) { return s ? FECFRAME_SHORT : FECFRAME_NORMAL; }
+
+// The reference's GF(2^m) LOG/EXP tables are static pointers that every BBFrameBCH constructor re-allocates and every destructor
+// frees (bch/galois_field.hh:128, bbframe_bch.cpp:183-185,375-377): objects of different threads would pull the tables from under
+// each other.  The plugin only ever has one; for the multi-threaded CPU baseline keep one object per (thread, code), construct
+// under a lock and never destroy it.
+static BBFrameBCH& bch_for(int rate, int shortframe) {
+    static std::mutex mtx;
+    thread_local std::map<int, BBFrameBCH*> cache;
+    BBFrameBCH*& p = cache[rate * 2 + shortframe];
+    if (!p) {
+        std::lock_guard<std::mutex> lk(mtx);
+        p = new BBFrameBCH(to_fs(shortframe), to_rate(rate));
+    }
+    return *p;
+}
 
 extern "C" {
 
@@ -59,20 +76,16 @@ int ref_ldpc_decode_simd16(int rate, int shortframe, int8_t* frames, int max_tri
 
 int ref_simd_width(void) { return simd_type::SIZE; }
 
-int ref_bch_decode(int rate, int shortframe, uint8_t* frame) {
-    BBFrameBCH bch(to_fs(shortframe), to_rate(rate));
-    return bch.decode(frame);
-}
+int ref_bch_decode(int rate, int shortframe, uint8_t* frame) { return bch_for(rate, shortframe).decode(frame); }
 
 void ref_bch_decode_many(int rate, int shortframe, uint8_t* frames, int nframes, int nbch_bytes, int* corr_out) {
-    BBFrameBCH bch(to_fs(shortframe), to_rate(rate));
+    BBFrameBCH& bch = bch_for(rate, shortframe);
     int nb = nbch_bytes;
     for (int f = 0; f < nframes; ++f) corr_out[f] = bch.decode(frames + (size_t)f * nb);
 }
 
 void ref_bch_encode(int rate, int shortframe, uint8_t* frame) {
-    BBFrameBCH bch(to_fs(shortframe), to_rate(rate));
-    bch.encode(frame);
+    bch_for(rate, shortframe).encode(frame);
 }
 
 void ref_bb_descramble(int rate, int shortframe, uint8_t* frame) {
