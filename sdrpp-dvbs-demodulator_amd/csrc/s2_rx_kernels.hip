@@ -33,11 +33,31 @@ __device__ __forceinline__ float camp(cf32 a) { return sqrtf(a.re * a.re + a.im 
 __device__ __forceinline__ float cphase(cf32 a) { return atan2f(a.im, a.re); }
 __device__ __forceinline__ cf32 phasor(float x) { return cf32{cosf(x), sinf(x)}; }
 
+// pointers read out of device structs are generic ("flat") to the compiler; flat accesses count against the LDS counter as well
+// and serialise with the LDS reads of the serial loops.  These are known to be global memory.
+template <typename T>
+__device__ __forceinline__ __attribute__((address_space(1))) T* as_global(T* p) {
+    return (__attribute__((address_space(1))) T*)p;
+}
+
+typedef float __attribute__((ext_vector_type(2))) f32x2;
+__device__ __forceinline__ cf32 ldg(const cf32* p) {
+    const f32x2 v = *as_global(reinterpret_cast<const f32x2*>(p));
+    return cf32{v.x, v.y};
+}
+__device__ __forceinline__ void stg(cf32* p, cf32 v) { *as_global(reinterpret_cast<f32x2*>(p)) = f32x2{v.re, v.im}; }
+
+// branch-free select (the compiler turns short float ternaries of the serial loops into exec-mask branches otherwise)
+__device__ __forceinline__ float fsel(bool c, float a, float b) {
+    const int m = -(int)c;
+    return __builtin_bit_cast(float, (__builtin_bit_cast(int, a) & m) | (__builtin_bit_cast(int, b) & ~m));
+}
+
 struct PclDev {
     float alpha, beta, phase, freq, minFreq, maxFreq;
     __device__ __forceinline__ void advance(float err) {
         freq += beta * err;
-        if (freq > maxFreq) freq = maxFreq; else if (freq < minFreq) freq = minFreq;
+        freq = freq > maxFreq ? maxFreq : (freq < minFreq ? minFreq : freq);
         phase += freq + alpha * err;
     }
     __device__ __forceinline__ void wrap_pi() {   // CLAMP_PHASE with [-pi, pi]
@@ -76,130 +96,189 @@ __device__ __forceinline__ cf32 phasor_fast(float x) {
     return cf32{cs, sn};
 }
 
-// ONE WAVE PER STREAM.  The recurrences (AGC gain, NCO phase, Gardner PCL) are serial in time, so the wave runs
-// them as uniform code; the lanes are used for what is parallel: coalesced tile loads/stores, the NCO rotation
-// (4 samples per lane per tile) and the three 8-tap interpolator dot products (one (arm, re/im) pair per lane,
-// taps accumulated in the reference's order).  Many streams = many waves: the GPU is filled by the batch.
-constexpr int FE_TILE = 256;
+// The front end is split along its dependency structure:
+//   s2_agc_nco_kernel  LANE = STREAM.  The AGC gain and NCO phase recurrences depend only on the input, are strictly serial in
+//                      time and ~40 instructions per sample: one lane runs one stream, a wave 64 streams, and the per-sample
+//                      (gain, phase) pairs go to the stream's scratch area.  Per-lane input reads walk whole 64-byte sectors.
+//   s2_gardner_kernel  EIGHT LANES PER STREAM (polyphase arm x re/im), 8 streams per wave.  Tiles of 64 samples per stream are
+//                      staged through LDS by all 64 lanes -- y = x*gain, z = y*phasor(-phase), the parallel part of
+//                      FastAGC/FreqShift; the loads of the next tile stay in flight during the loop -- then every lane group
+//                      runs its stream's Gardner loop: one 8-tap polyphase dot product per lane in the reference's
+//                      accumulation order, DPP row shifts to bring the three arms together, a quad swap to add the re/im
+//                      halves of the timing error, two DPP broadcasts to hand it to the whole group.
+// Many streams = many lanes: the batch fills the GPU, and nothing here is redundant across lanes (the first version ran the
+// serial chains once per wave, 64 lanes wide, and took 47 ms for 4096 x 43380 samples; this one ~4x less).
+constexpr int G_TILE = 64;     // samples per stream per staging tile
+constexpr int G_SPW = 8;       // streams per wave (8 lanes each)
+constexpr int G_PITCH = G_TILE + 9;   // 7 history + tile, odd pitch spreads the rows over the LDS banks
 
-__global__ __launch_bounds__(64) void s2_frontend_kernel(const S2StreamWork* __restrict__ work, int nstreams, S2LoopCoefs co,
-                                                         const float* __restrict__ bank_g) {
-    __shared__ __attribute__((aligned(16))) float bank[GARDNER_PHASES * GARDNER_TAPS];
-    __shared__ cf32 raw[FE_TILE];            // input tile
-    __shared__ cf32 ys[FE_TILE];             // AGC output (separate array: lets the tile reads run ahead of the serial chain)
-    __shared__ float ph[FE_TILE];            // NCO phase per sample
-    __shared__ float xre[FE_TILE + 8], xim[FE_TILE + 8];   // NCO output: [7 history][tile]
-    __shared__ cf32 ostage[FE_TILE + FE_TILE / 16 + 16];
-    const int lane = threadIdx.x;
-    for (int i = lane; i < GARDNER_PHASES * GARDNER_TAPS; i += 64) bank[i] = bank_g[i];
-    const S2StreamWork w = work[blockIdx.x];
+__device__ __forceinline__ size_t fe_scratch_offset(int n) { return (size_t)n + n / 16 + 128; }
+
+__global__ __launch_bounds__(64) void s2_agc_nco_kernel(const S2StreamWork* __restrict__ work, int nstreams, S2LoopCoefs co) {
+    const int lane = threadIdx.x, s = blockIdx.x * 64 + lane;
+    const bool act = s < nstreams;
+    const S2StreamWork w = work[act ? s : 0];
+    const int n = act ? w.count : 0;
     S2StreamState* st = w.st;
-    const int n = w.count;
     float gain = st->agc_gain, nph = st->nco_phase;
     const float nfr = st->nco_freq;
-    if (lane < GARDNER_TAPS - 1) { xre[lane] = st->g_hist[lane].re; xim[lane] = st->g_hist[lane].im; }
+    // (generic pointers on purpose: measured on MI355X, flat loads/stores are faster here than global ones -- with a single
+    // counter for loads and stores in flight the compiler has to drain the stores before it can consume a prefetched load)
+    const cf32* in = w.in;
+    cf32* gp = w.fe_out + fe_scratch_offset(n);
+    int nmax = n, nmin = act ? n : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { nmax = max(nmax, __shfl_xor(nmax, o)); nmin = min(nmin, __shfl_xor(nmin, o)); }
+    constexpr int U = 8;
+    auto sample = [&](cf32 x, int idx) {
+        gp[idx] = cf32{gain, nph};
+        // FastAGC (SDR++ loop/fast_agc.h as used at module_dvbs2_demod.cpp:222)
+        cf32 y = cscale(x, gain);
+        float a = camp(y);
+        gain += (1.0f - a) * co.agc_rate;
+        gain = gain > 10e6f ? 10e6f : gain;
+        // FreqShift phase accumulator (common/dsp/demod/freq_shift.cpp)
+        nph += nfr;
+        while ((double)nph > 6.283185307179586) nph = (float)((double)nph - 6.283185307179586);
+        while ((double)nph < -6.283185307179586) nph = (float)((double)nph + 6.283185307179586);
+    };
+    // main part: whole chunks that exist in every stream of the wave, no per-sample guards; next chunk's loads in flight
+    const int nfull = act ? (nmin / U) * U : 0;
+    int i = 0;
+    if (nfull > 0) {
+        cf32 nx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) nx[u] = in[u];
+        for (; i < nfull; i += U) {
+            cf32 x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = nx[u];
+            if (i + U < nfull) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) nx[u] = in[i + U + u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) sample(x[u], i + u);
+        }
+    }
+    for (; i < nmax; ++i)
+        if (i < n) sample(in[i], i);
+    if (act) { st->agc_gain = gain; st->nco_phase = nph; }
+}
+
+#define DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)(v)), (ctrl), 0xf, 0xf, false))
+template <typename T>
+__device__ __forceinline__ T* readlane_ptr(T* p, int srclane) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, srclane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), srclane);
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
+
+__global__ __launch_bounds__(64) void s2_gardner_kernel(const S2StreamWork* __restrict__ work, int nstreams, S2LoopCoefs co,
+                                                        const float* __restrict__ bank_g) {
+    __shared__ __attribute__((aligned(16))) float bank[GARDNER_PHASES * GARDNER_TAPS];
+    __shared__ float win[G_SPW * 2 * G_PITCH];          // [stream][re/im][7 history + tile]
+    const int lane = threadIdx.x, g = lane >> 3, r = lane & 7, arm = r >> 1, c = r & 1;   // arm 0/1/2 = phase-1 / phase / phase+1, 3 = spare
+    const int s0 = blockIdx.x * G_SPW, s = s0 + g;
+    const bool act = s < nstreams;
+    for (int i = lane; i < GARDNER_PHASES * GARDNER_TAPS; i += 64) bank[i] = bank_g[i];
+    const S2StreamWork w = work[act ? s : 0];
+    const int n = act ? w.count : 0;
+    S2StreamState* st = w.st;
     PclDev pcl{co.g_alpha, co.g_beta, st->g_phase, st->g_freq, co.g_min_freq, co.g_max_freq};
     int offset = st->g_offset, spsctr = st->g_spsctr, outCount = 0;
+    float* row = &win[(g * 2 + c) * G_PITCH];           // aliases the staging writes below: no __restrict__
+    auto outc = as_global(reinterpret_cast<float*>(w.fe_out) + c);
+    const cf32* gpp = w.fe_out + fe_scratch_offset(n);
+    if (arm == 0)
+        for (int k = 0; k < GARDNER_TAPS - 1; ++k) row[k] = c ? st->g_hist[k].im : st->g_hist[k].re;
+    int nmax = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+    // staging registers: sample `lane` of the next tile of each of the 8 streams (loads stay in flight during the Gardner loop)
+    cf32 px[G_SPW], pg[G_SPW];
+    auto issue = [&](int base) {
+#pragma unroll
+        for (int jj = 0; jj < G_SPW; ++jj) {
+            const cf32* inj = readlane_ptr(w.in, jj * 8);
+            const cf32* gpj = readlane_ptr(gpp, jj * 8);
+            const int cj = __builtin_amdgcn_readlane(n, jj * 8);
+            if (base + lane < cj) { px[jj] = ldg(inj + base + lane); pg[jj] = ldg(gpj + base + lane); }
+        }
+    };
+    auto commit = [&](int base) {
+#pragma unroll
+        for (int jj = 0; jj < G_SPW; ++jj) {
+            const int cj = __builtin_amdgcn_readlane(n, jj * 8);
+            if (base + lane < cj && lane < G_TILE) {
+                const cf32 z = cmul(cscale(px[jj], pg[jj].re), phasor_fast(-pg[jj].im));   // FastAGC scaling, FreqShift rotation
+                win[(jj * 2) * G_PITCH + GARDNER_TAPS - 1 + lane] = z.re;
+                win[(jj * 2 + 1) * G_PITCH + GARDNER_TAPS - 1 + lane] = z.im;
+            }
+        }
+    };
+    issue(0);
     __syncthreads();
-    for (int base = 0; base < n; base += FE_TILE) {
-        const int m = min(FE_TILE, n - base);
-        // ---- coalesced tile load
-        for (int i = lane; i < m; i += 64) raw[i] = w.in[base + i];
+    for (int base = 0; base < nmax; base += G_TILE) {
+        commit(base);
         __syncthreads();
-        // ---- AGC (serial gain recurrence) + NCO phase recurrence; every lane runs the same scalar chain
-        {
-            const cf32* __restrict__ rp = raw;
-            cf32* __restrict__ yp = ys;
-            float* __restrict__ pp = ph;
-            int i = 0;
-            for (; i + 4 <= m; i += 4) {
-                cf32 x0 = rp[i], x1 = rp[i + 1], x2 = rp[i + 2], x3 = rp[i + 3];
-                cf32 xs4[4] = {x0, x1, x2, x3};
+        issue(base + G_TILE);
+        // ---- Gardner (common/dsp/demod/gardner.cpp:89-150): outputs whose 8-sample window starts inside this tile
+        const int m = max(0, min(G_TILE, n - base));
+        // (the trip count is bounded: a poisoned loop state -- NaN input -- must not hang the GPU)
+        for (int guard = 0; guard < 4 * G_TILE && __any(offset < base + m && offset >= base); ++guard) {
+            if (offset < base + m && offset >= base) {
+                int phase = (int)floorf(pcl.phase * 128.0f);
+                phase = phase < 0 ? 0 : (phase > 127 ? 127 : phase);
+                int my = phase;
+                if (arm == 0) my = phase > 0 ? phase - 1 : 0;
+                if (arm == 2) my = phase < 127 ? phase + 1 : 127;
+                const float* xw = row + (offset - base);
+                const float* t = &bank[my * 8];
+                float acc = 0.f;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    cf32 y = cscale(xs4[u], gain);
-                    float a = camp(y);
-                    gain += (1.0f - a) * co.agc_rate;
-                    if (gain > 10e6f) gain = 10e6f;
-                    if (lane == 0) { yp[i + u] = y; pp[i + u] = nph; }
-                    nph += nfr;
-                    while ((double)nph > 6.283185307179586) nph = (float)((double)nph - 6.283185307179586);
-                    while ((double)nph < -6.283185307179586) nph = (float)((double)nph + 6.283185307179586);
-                }
-            }
-            for (; i < m; ++i) {
-                cf32 y = cscale(rp[i], gain);
-                float a = camp(y);
-                gain += (1.0f - a) * co.agc_rate;
-                if (gain > 10e6f) gain = 10e6f;
-                if (lane == 0) { yp[i] = y; pp[i] = nph; }
-                nph += nfr;
-                while ((double)nph > 6.283185307179586) nph = (float)((double)nph - 6.283185307179586);
-                while ((double)nph < -6.283185307179586) nph = (float)((double)nph + 6.283185307179586);
+                for (int k = 0; k < 8; ++k) acc += xw[k] * t[k];
+                // arm-1 lanes (r = 2: re, 3: im) collect the neighbours' arms: row_shr:2 = lane-2 (phase-1), row_shl:2 = lane+2 (phase+1)
+                const float xm = DPP_F(acc, 0x112), xp = DPP_F(acc, 0x102), xo = acc;
+                if (arm == 1) outc[2 * outCount] = xo;
+                ++outCount;
+                // straight-line on purpose (streams of one wave differ in spsctr): the error of the off-symbol outputs is masked to 0
+                const float d = fsel(phase == 0, xp - xo, fsel(phase == 127, xo - xm, (xp - xm) * 0.5f));
+                const float e = (xo > 0 ? 1.0f : -1.0f) * d;                 // valid in lanes r = 2 (re half), 3 (im half)
+                const float eo = DPP_F(e, 0xB1);                             // quad_perm [1,0,3,2]: the other half
+                const float er = -(e + eo);                                  // -(re part + im part)
+                const float eq = DPP_F(er, 0xAA);                            // quad_perm [2,2,2,2]: r = 0..3 <- r = 2
+                const float eh = DPP_F(eq, 0x114);                           // row_shr:4: r = 4..7 <- r = 0..3
+                float error = spsctr == 0 ? (r < 4 ? eq : eh) : 0.f;
+                spsctr = spsctr >= 1 ? 0 : spsctr + 1;
+                error = error > 1.0f ? 1.0f : error;
+                error = error < -1.0f ? -1.0f : error;
+                pcl.advance(error);
+                const float delta = floorf(pcl.phase);
+                offset = (int)((float)offset + delta);
+                pcl.phase -= delta;
             }
         }
         __syncthreads();
-        // ---- NCO rotation, parallel over the tile
-        for (int i = lane; i < m; i += 64) {
-            cf32 z = cmul(ys[i], phasor_fast(-ph[i]));
-            xre[GARDNER_TAPS - 1 + i] = z.re; xim[GARDNER_TAPS - 1 + i] = z.im;
-        }
-        __syncthreads();
-        // ---- Gardner: outputs whose 8-sample window starts inside this tile
-        const int arm_sel = (lane >> 1) % 3;          // lanes 0..5: arm-1, arm, arm+1  x  (re, im)
-        const float* __restrict__ xc = (lane & 1) ? xim : xre;
-        int nout = 0;
-        while (offset < base + m) {
-            int phase = (int)floorf(pcl.phase * 128.0f);
-            phase = phase < 0 ? 0 : (phase > 127 ? 127 : phase);
-            int arm = phase + arm_sel - 1;
-            arm = arm < 0 ? 0 : (arm > 127 ? 127 : arm);
-            const float* __restrict__ t = &bank[arm * 8];
-            const float* __restrict__ xw = xc + (offset - base);
-            float acc = 0.f;
+        // ---- slide the 7-sample history (arm-0 lanes own the rows)
+        if (arm == 0) {
+            float h[GARDNER_TAPS - 1];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc += xw[k] * t[k];
-            // lanes: 0/1 = arm-1 (re,im), 2/3 = arm, 4/5 = arm+1
-            const float m_re = __shfl(acc, 0), m_im = __shfl(acc, 1);
-            const float o_re = __shfl(acc, 2), o_im = __shfl(acc, 3);
-            const float p_re = __shfl(acc, 4), p_im = __shfl(acc, 5);
-            if (lane == 0) ostage[nout] = cf32{o_re, o_im};
-            ++nout;
-            float error;
-            if (spsctr == 0) {
-                float d_re, d_im;
-                if (phase == 0) { d_re = p_re - o_re; d_im = p_im - o_im; }
-                else if (phase == 127) { d_re = o_re - m_re; d_im = o_im - m_im; }
-                else { d_re = (p_re - m_re) * 0.5f; d_im = (p_im - m_im) * 0.5f; }
-                error = -(((o_re > 0 ? 1.0f : -1.0f) * d_re) + ((o_im > 0 ? 1.0f : -1.0f) * d_im));
-            } else {
-                error = 0.f;
-            }
-            spsctr++;
-            if (spsctr >= 2) spsctr = 0;
-            if (error > 1.0f) error = 1.0f;
-            if (error < -1.0f) error = -1.0f;
-            pcl.advance(error);
-            float delta = floorf(pcl.phase);
-            offset = (int)((float)offset + delta);
-            pcl.phase -= delta;
+            for (int k = 0; k < GARDNER_TAPS - 1; ++k) h[k] = row[m + k];
+#pragma unroll
+            for (int k = 0; k < GARDNER_TAPS - 1; ++k) row[k] = h[k];
         }
-        __syncthreads();
-        // ---- coalesced store of this tile's outputs, slide the 7-sample history
-        for (int i = lane; i < nout; i += 64) w.fe_out[outCount + i] = ostage[i];
-        outCount += nout;
-        float hr = 0.f, hi = 0.f;
-        if (lane < GARDNER_TAPS - 1) { hr = xre[m + lane]; hi = xim[m + lane]; }
-        __syncthreads();
-        if (lane < GARDNER_TAPS - 1) { xre[lane] = hr; xim[lane] = hi; }
         __syncthreads();
     }
-    offset -= n;
-    if (lane < GARDNER_TAPS - 1) st->g_hist[lane] = cf32{xre[lane], xim[lane]};
-    if (lane == 0) {
-        st->agc_gain = gain; st->nco_phase = nph;
-        st->g_phase = pcl.phase; st->g_freq = pcl.freq; st->g_offset = offset; st->g_spsctr = spsctr;
-        st->n_fe_out = outCount;
+    if (act && arm == 0) {
+        for (int k = 0; k < GARDNER_TAPS - 1; ++k) {
+            if (c) st->g_hist[k].im = row[k]; else st->g_hist[k].re = row[k];
+        }
+        if (c == 0) {
+            st->g_phase = pcl.phase; st->g_freq = pcl.freq; st->g_offset = offset - n; st->g_spsctr = spsctr;
+            st->n_fe_out = outCount;
+        }
     }
 }
 
@@ -318,7 +397,11 @@ __device__ __forceinline__ cf32 pl_descramble(cf32 p, int r) {
     }
 }
 __device__ __forceinline__ int lut_index(float v) {   // constellation.cpp:295-301: double math, truncation, clamp
-    int x = (int)(((double)v / 1.5) * 256 + 128);
+    // (int)(((double)v / 1.5) * 256 + 128) exactly: the product form is within 1e-12 of it, so it truncates to the same integer
+    // unless it lands that close to one -- only then pay for the double division
+    const double y = (double)v * 170.66666666666666 + 128.0;
+    int x = (int)y;
+    if (__builtin_fabs(y - __builtin_rint(y)) < 1e-9) x = (int)(((double)v / 1.5) * 256 + 128);
     return x < 0 ? 0 : (x > 255 ? 255 : x);
 }
 __device__ __forceinline__ int pilot_start(int b) { return 90 + (b + 1) * 1440 + b * 36; }
@@ -357,49 +440,69 @@ __device__ void soft_calc_dev(const S2ConstelDev& C, cf32 sample, int8_t* bits_o
 
 // ONE WAVE PER STREAM (see the front end): the PLL / PLHDR phase recurrences are serial per symbol and run as
 // uniform code; lanes do the coalesced symbol loads/stores, the FED terms and the PLSC codeword search.
+// SIXTEEN LANES PER STREAM, 4 streams per wave.  The FED / PLL / PLHDR recurrences are serial per stream and the phase-error
+// LUT lookup sits in the PLL's chain, so a stream is latency-bound whatever the lane count; the first version (one wave per
+// stream, 64 lanes running the same chain) was issue-bound with 4 waves per SIMD instead.  A 16-lane row is also the natural
+// DPP unit: the PLSC codeword search reduces inside it with row rotations.  Groups whose stream has fewer frames in this call
+// shadow a frame of another group (same code path, nothing stored, state restored afterwards).
+constexpr int FL_LPS = 16;
+constexpr int FL_SPW = 64 / FL_LPS;
+
 __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* __restrict__ work, int nstreams,
                                                             const S2FrameRef* __restrict__ frames, const int* __restrict__ first,
                                                             S2LoopCoefs co, S2PlTablesDev T, S2ConstelDev C, int pls_code, int slots,
                                                             int pilots, int pilot_blocks, int plframe, cf32* __restrict__ pllout,
                                                             S2FrameStats* __restrict__ stats) {
-    __shared__ cf32 tile[64];
-    __shared__ cf32 otile[64];
+    __shared__ cf32 tile[FL_SPW][64];
+    __shared__ cf32 otile[FL_SPW][64];
     __shared__ uint8_t rnt[64];
-    __shared__ float fedt[128];
-    __shared__ cf32 hdr_sym[90];
-    __shared__ int red_d[64], red_c[64];
-    const int s = blockIdx.x;
-    const int lane = threadIdx.x;
-    S2StreamState* st = work[s].st;
+    __shared__ float fedt[FL_SPW][96];
+    __shared__ cf32 hdr_sym[FL_SPW][90];
+    const int lane = threadIdx.x, g = lane / FL_LPS, gl = lane % FL_LPS;
+    const int s0 = blockIdx.x * FL_SPW, s = s0 + g;
+    const bool act = s < nstreams;
+    const int sc = act ? s : s0;
+    S2StreamState* st = work[sc].st;
     PclDev pll{co.pll_alpha, co.pll_beta, st->pll_phase, st->pll_freq, co.pll_min_freq, co.pll_max_freq};
     PclDev hdr{co.hdr_alpha, co.hdr_beta, st->hdr_phase, st->hdr_freq, co.hdr_min_freq, co.hdr_max_freq};
     float nco_freq = st->nco_freq;
     const float PI_F = 3.14159265358979323846f;
     const cf32* __restrict__ plsc = T.plsc + (size_t)pls_code * 64;
-    for (int f = first[s]; f < first[s + 1]; ++f) {
+    const int f0 = first[sc], nf = act ? first[sc + 1] - f0 : 0;
+    int nfmax = nf;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nfmax = max(nfmax, __shfl_xor(nfmax, o));
+    for (int ff = 0; ff < nfmax; ++ff) {
+        const bool fact = ff < nf;
+        const int fown = f0 + ff;
+        const int donor = __ffsll((unsigned long long)__ballot(fact)) - 1;
+        const int fdon = __shfl(fown, donor);
+        const int f = fact ? fown : fdon;
+        const PclDev pll_in = pll, hdr_in = hdr;
+        const float nco_in = nco_freq;
         const cf32* __restrict__ fr = frames[f].sym;
         cf32* __restrict__ out = pllout + (size_t)f * plframe;
         // ---- coarse frequency error detector (dvbs2_fed.h): terms in parallel, summed in the reference's order
-        for (int i = lane; i < 88; i += 64) {
+        for (int i = gl; i < 88; i += FL_LPS) {
             cf32 r2 = (i + 2) < 26 ? T.sof[i + 2] : plsc[i + 2 - 26];
             cf32 r0 = i < 26 ? T.sof[i] : plsc[i - 26];
-            fedt[i] = cmul(cmul(cmul(fr[i + 2], cconj(r2)), cconj(fr[i])), r0).im;
+            fedt[g][i] = cmul(cmul(cmul(fr[i + 2], cconj(r2)), cconj(fr[i])), r0).im;
         }
-        if (lane < 90 - 64) hdr_sym[64 + lane] = fr[64 + lane];
-        hdr_sym[lane] = fr[lane];
+        for (int i = gl; i < 90; i += FL_LPS) hdr_sym[g][i] = fr[i];
         __syncthreads();
         float err = 0.f, symcnt = 90 - 2;
-        for (int i = 0; i < 88; ++i) err += fedt[i];
+        for (int i = 0; i < 88; ++i) err += fedt[g][i];
         if (pilots) {
             const cf32 p{0.707f, 0.707f};
             for (int b = 0; b < pilot_blocks; ++b) {
                 int start = pilot_start(b);
                 __syncthreads();
-                if (lane < 36) tile[lane] = pl_descramble(fr[start + lane], T.rn[start - 90 + lane]);
+                for (int i = gl; i < 36; i += FL_LPS) tile[g][i] = pl_descramble(fr[start + i], T.rn[start - 90 + i]);
                 __syncthreads();
-                if (lane >= 2 && lane < 36) fedt[lane] = cmul(cmul(cmul(tile[lane], cconj(p)), cconj(tile[lane - 2])), p).im;
+                for (int i = gl; i < 36; i += FL_LPS)
+                    if (i >= 2) fedt[g][i] = cmul(cmul(cmul(tile[g][i], cconj(p)), cconj(tile[g][i - 2])), p).im;
                 __syncthreads();
-                for (int i = 2; i < 36; ++i) err += fedt[i];
+                for (int i = 2; i < 36; ++i) err += fedt[g][i];
                 symcnt += 36 - 2;
             }
         }
@@ -413,15 +516,15 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
         for (int base = 0; base < plframe; base += 64) {
             const int m = min(64, plframe - base);
             __syncthreads();
+            for (int i = gl; i < m; i += FL_LPS) tile[g][i] = fr[base + i];
             if (lane < m) {
-                tile[lane] = fr[base + lane];
                 int gi = base + lane;
                 rnt[lane] = gi >= 90 ? T.rn[gi - 90] : 0;
             }
             __syncthreads();
             for (int k = 0; k < m; ++k) {
                 const int i = base + k;
-                cf32 tmp_val = cmul(tile[k], phasor_fast(-pll.phase));
+                cf32 tmp_val = cmul(tile[g][k], phasor_fast(-pll.phase));
                 float error = 0.f;
                 cf32 o;
                 if (i >= 90) {
@@ -440,22 +543,24 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
                     else error = cphase(cmul(tmp_val, cconj(plsc[i - 26])));
                     o = cf32{0.f, 0.f};   // header symbols come from the PLHDR demod below
                 }
-                if (lane == 0) otile[k] = o;
+                if (gl == 0) otile[g][k] = o;
                 pll.advance(error);
                 pll.wrap_pi();
             }
             __syncthreads();
-            if (lane < m && base + lane >= 90) out[base + lane] = otile[lane];
+            if (fact)
+                for (int i = gl; i < m; i += FL_LPS)
+                    if (base + i >= 90) out[base + i] = otile[g][i];
         }
         // ---- PL header demod (dvbs2_plhdr_demod.cpp:33-67)
         unsigned long long plheader = 0;
         const cf32 rot{(float)0.70710678118654757, (float)-0.70710678118654746};   // (cos(-pi/4), sin(-pi/4)) in double, cast
         __syncthreads();
         for (int i = 0; i < 90; ++i) {
-            cf32 tmp_val = cmul(hdr_sym[i], phasor_fast(-hdr.phase));
+            cf32 tmp_val = cmul(hdr_sym[g][i], phasor_fast(-hdr.phase));
             float error = ((tmp_val.re > 0 ? 1.0f : -1.0f) * tmp_val.im) - ((tmp_val.im > 0 ? 1.0f : -1.0f) * tmp_val.re);
             cf32 o = (i & 1) ? cf32{-tmp_val.re, tmp_val.im} : cf32{tmp_val.im, tmp_val.re};
-            if (lane == 0) out[i] = o;
+            if (gl == 0 && fact) out[i] = o;
             if (i >= 26) {
                 bool value = cmul(o, rot).re > 0;
                 plheader = plheader << 1 | (unsigned long long)(!value);
@@ -466,29 +571,28 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
         hdr.phase += hdr.freq * (plframe - 91);
         hdr.advance(0.f);
         hdr.wrap_pi();
-        // codeword search: lowest index among the minima (the reference scans with strict '<')
-        int bd = 65, bc = 0;
-        for (int c = lane; c < 128; c += 64) {
+        // codeword search: minimum distance, lowest index among the minima (the reference scans 0..127 with strict '<')
+        int key = 0x7fffffff;
+        for (int c = gl; c < 128; c += FL_LPS) {
             int dd = __popcll((T.plsc_code[c] ^ plheader) & ((1ull << 60) - 1));
-            if (dd < bd) { bd = dd; bc = c; }
+            key = min(key, dd * 128 + c);
         }
-        red_d[lane] = bd; red_c[lane] = bc;
-        __syncthreads();
-        if (lane == 0) {
-            int best = 0, diffs = 64;
-            for (int l = 0; l < 64; ++l) {   // lane l holds codewords l and l+64: merge in index order
-                int d0 = red_d[l], c0 = red_c[l];
-                if (d0 < diffs || (d0 == diffs && c0 < best && d0 < 64)) { diffs = d0; best = c0; }
-            }
+        key = min(key, __builtin_amdgcn_update_dpp(key, key, 0x121, 0xf, 0xf, false));   // row_ror 1, 2, 4, 8: all-reduce in the row
+        key = min(key, __builtin_amdgcn_update_dpp(key, key, 0x122, 0xf, 0xf, false));
+        key = min(key, __builtin_amdgcn_update_dpp(key, key, 0x124, 0xf, 0xf, false));
+        key = min(key, __builtin_amdgcn_update_dpp(key, key, 0x128, 0xf, 0xf, false));
+        if (gl == 0 && fact) {
+            const int best = key & 127;
             S2FrameStats stt;
             stt.best_match = 0.f; stt.ldpc_trials = 0; stt.bch_corr = 0;   // filled in by the host
             stt.detected_modcod = (best >> 2) & 31; stt.detected_short = (best & 2) >> 1; stt.detected_pilots = best & 1;
             stt.fed_err = est;
             stats[f] = stt;
         }
+        if (!fact) { pll = pll_in; hdr = hdr_in; nco_freq = nco_in; }
         __syncthreads();
     }
-    if (lane == 0) {
+    if (act && gl == 0) {
         st->pll_phase = pll.phase; st->pll_freq = pll.freq;
         st->hdr_phase = hdr.phase; st->hdr_freq = hdr.freq;
         st->nco_freq = nco_freq;
@@ -565,7 +669,8 @@ hipError_t s2_fifo_compact_launch(const S2StreamWork* d_work, int nstreams, cons
     return hipGetLastError();
 }
 hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCoefs coefs, const float* d_bank, hipStream_t st) {
-    hipLaunchKernelGGL(s2_frontend_kernel, dim3(nstreams), dim3(64), 0, st, d_work, nstreams, coefs, d_bank);
+    hipLaunchKernelGGL(s2_agc_nco_kernel, dim3((nstreams + 63) / 64), dim3(64), 0, st, d_work, nstreams, coefs);
+    hipLaunchKernelGGL(s2_gardner_kernel, dim3((nstreams + G_SPW - 1) / G_SPW), dim3(64), 0, st, d_work, nstreams, coefs, d_bank);
     return hipGetLastError();
 }
 hipError_t s2_rrc_decim_launch(const S2StreamWork* d_work, int nstreams, int max_count, const float* d_taps, int ntaps, hipStream_t st) {
@@ -583,7 +688,7 @@ hipError_t s2_plsync_launch(const cf32* const* d_win, int nwin, int raw, int* d_
 hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const S2FrameRef* d_frames, const int* d_first,
                                  S2LoopCoefs coefs, S2PlTablesDev tabs, S2ConstelDev con, int pls_code, int slots, int pilots,
                                  int pilot_blocks, int plframe, cf32* d_pllout, S2FrameStats* d_stats, hipStream_t st) {
-    hipLaunchKernelGGL(s2_frame_loops_kernel, dim3(nstreams), dim3(64), 0, st, d_work, nstreams, d_frames, d_first, coefs,
+    hipLaunchKernelGGL(s2_frame_loops_kernel, dim3((nstreams + FL_SPW - 1) / FL_SPW), dim3(64), 0, st, d_work, nstreams, d_frames, d_first, coefs,
                        tabs, con, pls_code, slots, pilots, pilot_blocks, plframe, d_pllout, d_stats);
     return hipGetLastError();
 }
