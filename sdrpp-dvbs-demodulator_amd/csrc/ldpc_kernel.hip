@@ -118,16 +118,38 @@ __device__ __forceinline__ int link_addr(uint32_t ent, int j) {
         sx ^= (v);                          \
     } while (0)
 
+// ---- packed int16 helpers: two links per VALU instruction (v_pk_*_i16), the int8 saturation rules emulated in 16 bits
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 splat2(int v) { return s16x2{(short)v, (short)v}; }
+__device__ __forceinline__ s16x2 pmin2(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s16x2 pmax2(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ s16x2 pclamp2(s16x2 v, int lo, int hi) { return pmin2(pmax2(v, splat2(lo)), splat2(hi)); }
+__device__ __forceinline__ uint32_t bits2(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ s16x2 from_bits2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+// message bytes k, k+1 (k even) of a record, sign-extended into the two halves: one v_perm + one packed shift
+template <int REC>
+__device__ __forceinline__ s16x2 rec_pair(const uint32_t (&rec)[REC], int k) {
+    const uint32_t w = rec[k >> 2];
+    const uint32_t t = (k & 2) ? __builtin_amdgcn_perm(0u, w, 0x030c020cu) : __builtin_amdgcn_perm(0u, w, 0x010c000cu);
+    return from_bits2(t) >> 8;
+}
+
 // One sweep step for one layer.  CONF = layer has intra-layer shared bits (links 0..nc-1), IRREG = the
 // code has layers of different degree (short tables C1, C4, C7, C8, C9).
-template <int MAXDEG, int REC, bool CONF, bool IRREG>
+// Links are processed in PAIRS held in packed int16 registers: pair p = links 2p, 2p+1 of the row, where links
+// [0, MAXDEG) are the table links, MAXDEG the row's own parity bit and MAXDEG+1 the previous parity bit.
+template <int MAXDEG, int REC, int KIND, bool IRREG>
 __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const LdpcKernelArgs& A, const uint32_t* __restrict__ ents,
                                              const LdpcLayerDesc L, uint32_t rowword, int layer, int j, bool active,
                                              const uint32_t (&rec_in)[REC], uint32_t* __restrict__ rec_out_ptr,
                                              uint32_t* __restrict__ cw, uint8_t* __restrict__ cres) {
     constexpr int NL = MAXDEG + 2;
-    constexpr int MAXC = MAXDEG < LDPC_MAX_CONFLICT_LINKS ? MAXDEG : LDPC_MAX_CONFLICT_LINKS;
-    int in[NL], mg[NL];
+    constexpr int NP = (NL + 1) / 2;
+    // KIND 0: no shared bits in the layer; 1: one shared pair resolved by the chain walk (links 0, 1 only); 2: general levels
+    constexpr bool CONF = KIND != 0;
+    constexpr int MAXC_ALL = MAXDEG < LDPC_MAX_CONFLICT_LINKS ? MAXDEG : LDPC_MAX_CONFLICT_LINKS;
+    constexpr int MAXC = KIND == 1 ? (MAXDEG < 2 ? MAXDEG : 2) : MAXC_ALL;
+    s16x2 V[NP], G[NP];        // extrinsic inputs and their offset magnitudes
     int addr[MAXDEG];
     const int deg = IRREG ? (int)(L.deg & 0xffffu) : MAXDEG;
     const int nc = CONF ? (int)(L.depth_nc >> 16) : 0;
@@ -136,44 +158,59 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
     const int own = A.K + 360 * layer + j;
     const bool has_prev = (layer | j) != 0;
     const int prev = layer ? own - 360 : A.K + 360 * (A.q - 1) + j - 1;
+#define LINK_IN(k) ((int)V[(k) >> 1][(k) & 1])
+#define LINK_MG(k) ((int)G[(k) >> 1][(k) & 1])
+#define LINK_SET(k, v, m) do { V[(k) >> 1][(k) & 1] = (short)(v); G[(k) >> 1][(k) & 1] = (short)(m); } while (0)
     PROF_T(t_a);
     if (active) {
+        s16x2 MIN0 = splat2(255), MIN1 = splat2(255);
+        uint32_t SX = 0;
 #pragma unroll
-        for (int k = 0; k < MAXDEG; ++k) {
-            if (!IRREG || k < deg) {
-                addr[k] = link_addr(ents[k], j);
-                int x = post[addr[k]];
-                int v = clamp8(x - rec_byte<REC>(rec_in, k));
-                int m = mag_of(v);
-                if constexpr (CONF) {
-                    if (k < MAXC && ((late >> k) & 1)) { v = 0; m = 255; }  // joins the totals at its level
+        for (int p = 0; p < NP; ++p) {
+            int x[2] = {0, 0};
+            bool absent[2] = {false, false};     // uniform (table) absence; the missing previous parity bit of row 0 is per lane
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = 2 * p + h;
+                if (k < MAXDEG) {
+                    if (!IRREG || k < deg) { addr[k] = link_addr(ents[k], j); x[h] = post[addr[k]]; }
+                    else { addr[k] = 0; absent[h] = true; }
+                } else if (k == MAXDEG) {
+                    x[h] = post[own];
+                } else if (k == MAXDEG + 1) {
+                    x[h] = has_prev ? (int)post[prev] : 0;
+                } else {
+                    absent[h] = true;
                 }
-                in[k] = v; mg[k] = m;
-                ROW_ACCUM(v, m);
-            } else {
-                in[k] = 0; mg[k] = 255; addr[k] = 0;
             }
+            const s16x2 X = s16x2{(short)x[0], (short)x[1]};
+            s16x2 v = pclamp2(X - rec_pair<REC>(rec_in, 2 * p), -128, 127);
+            s16x2 g = pclamp2(pmax2(v, splat2(0) - v) - splat2(1), 0, 126);          // mag_of
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = 2 * p + h;
+                if (absent[h]) { v[h] = 0; g[h] = 255; }
+                if (k == MAXDEG + 1 && !has_prev) { v[h] = 0; g[h] = 255; }
+                if constexpr (CONF) {
+                    if (k < MAXC && k < nc && ((late >> k) & 1)) { v[h] = 0; g[h] = 255; }   // joins the totals at its level
+                }
+            }
+            V[p] = v; G[p] = g;
+            MIN1 = pmin2(MIN1, pmax2(MIN0, g));
+            MIN0 = pmin2(MIN0, g);
+            SX ^= bits2(v);
         }
-        {
-            int v = clamp8((int)post[own] - rec_byte<REC>(rec_in, MAXDEG));
-            int m = mag_of(v);
-            in[MAXDEG] = v; mg[MAXDEG] = m;
-            ROW_ACCUM(v, m);
-        }
-        if (has_prev) {
-            int v = clamp8((int)post[prev] - rec_byte<REC>(rec_in, MAXDEG + 1));
-            int m = mag_of(v);
-            in[MAXDEG + 1] = v; mg[MAXDEG + 1] = m;
-            ROW_ACCUM(v, m);
-        } else {
-            in[MAXDEG + 1] = 0; mg[MAXDEG + 1] = 255;
-        }
+        // merge the even-link and odd-link halves
+        const int a0 = MIN0[0], b0 = MIN0[1], a1 = MIN1[0], b1 = MIN1[1];
+        min0 = min(a0, b0);
+        min1 = min(max(a0, b0), min(a1, b1));
+        sx = (int)(short)(SX ^ (SX >> 16));
     }
     PROF_T(t_b);
     PROF_ADD(CONF ? 4 : 0, t_a, t_b);
     if constexpr (CONF) {
         const int chain_d = (int)(L.deg >> 16);
-        if (chain_d > 0) {
+        if constexpr (KIND == 1) {
             // ---- chain walk (single shared pair, links 0 = E, 1 = L; see ldpc_plan.h).  Level-1 rows (j < d) publish
             // their early links; every row whose L link is late leaves {exclusive min over its other links, in_E,
             // old L message, sign} in cw[]; lanes c < d of wave 0 then walk rows c+d, c+2d, ...: the posterior written
@@ -184,15 +221,15 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         if ((early >> k) & 1) {
-                            int nm = new_msg(in[k], mg[k], min0, min1, sx);
-                            post[addr[k]] = (int8_t)clamp8(in[k] + nm);
+                            int nm = new_msg(LINK_IN(k), LINK_MG(k), min0, min1, sx);
+                            post[addr[k]] = (int8_t)clamp8(LINK_IN(k) + nm);
                         }
                     }
                 }
                 if ((late >> 1) & 1) {
-                    const int qE = (late & 1u) ? 255 : ((mg[0] == min0) ? min1 : min0);
-                    const int sgn = ((sx ^ in[0]) >> 31) & 1;
-                    cw[j] = (uint32_t)(qE & 0xff) | ((uint32_t)(in[0] & 0xff) << 8) |
+                    const int qE = (late & 1u) ? 255 : ((LINK_MG(0) == min0) ? min1 : min0);
+                    const int sgn = ((sx ^ LINK_IN(0)) >> 31) & 1;
+                    cw[j] = (uint32_t)(qE & 0xff) | ((uint32_t)(LINK_IN(0) & 0xff) << 8) |
                             ((uint32_t)(rec_byte<REC>(rec_in, 1) & 0xff) << 16) | ((uint32_t)sgn << 24) | ((uint32_t)(early & 1u) << 25);
                 }
             }
@@ -224,17 +261,18 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                 if ((late >> 1) & 1) {
                     int v = clamp8((int)(int8_t)cres[j] - rec_byte<REC>(rec_in, 1));
                     int m = mag_of(v);
-                    in[1] = v; mg[1] = m;
+                    LINK_SET(1, v, m);
                     ROW_ACCUM(v, m);
                 }
                 if (late & 1u) {
                     int v = clamp8((int)post[addr[0]] - rec_byte<REC>(rec_in, 0));
                     int m = mag_of(v);
-                    in[0] = v; mg[0] = m;
+                    LINK_SET(0, v, m);
                     ROW_ACCUM(v, m);
                 }
             }
         } else {
+        (void)chain_d;
         // rows of level 1 have complete totals: they publish the links a later row waits for right away
         const int depth = (int)(L.depth_nc & 0xffffu);
         for (int lvl = 1; lvl <= depth; ++lvl) {
@@ -248,7 +286,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                         if (k < nc && ((late_l >> k) & 1)) {
                             int v = clamp8((int)post[addr[k]] - rec_byte<REC>(rec_in, k));
                             int m = mag_of(v);
-                            in[k] = v; mg[k] = m;
+                            LINK_SET(k, v, m);
                             ROW_ACCUM(v, m);
                         }
                     }
@@ -256,8 +294,8 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
 #pragma unroll
                 for (int k = 0; k < MAXC; ++k) {
                     if (k < nc && ((early_l >> k) & 1)) {
-                        int nm = new_msg(in[k], mg[k], min0, min1, sx);
-                        post[addr[k]] = (int8_t)clamp8(in[k] + nm);
+                        int nm = new_msg(LINK_IN(k), LINK_MG(k), min0, min1, sx);
+                        post[addr[k]] = (int8_t)clamp8(LINK_IN(k) + nm);
                     }
                 }
             }
@@ -267,27 +305,46 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
     PROF_T(t_c);
     PROF_ADD(CONF ? 5 : 1, t_b, t_c);
     if (active) {
-        uint32_t rec_out[REC];
+        const s16x2 MIN0B = splat2(min0), MIN1B = splat2(min1), NDB = splat2(min0 - min1);
+        const uint32_t SXB = ((uint32_t)sx & 0xffffu) * 0x10001u;
+        s16x2 NM[NP + 1];
+        NM[NP] = splat2(0);
 #pragma unroll
-        for (int w = 0; w < REC; ++w) rec_out[w] = 0;
+        for (int p = 0; p < NP; ++p) {
+            // new_msg for both links: other = (mag == min0) ? min1 : min0  ==  min1 + (mag != min0) * (min0 - min1)
+            const s16x2 ne = pmin2(G[p] - MIN0B, splat2(1));
+            const s16x2 other = ne * NDB + MIN1B;
+            const s16x2 neg = from_bits2(SXB ^ bits2(V[p])) >> 15;                   // 0 or -1
+            s16x2 nm = pclamp2(from_bits2(bits2(other) ^ bits2(neg)) - neg, -32, 31);
+            const s16x2 pn = pclamp2(V[p] + nm, -128, 127);
 #pragma unroll
-        for (int k = 0; k < NL; ++k) {
-            bool present = (k < MAXDEG) ? (!IRREG || k < deg) : (k == MAXDEG ? true : has_prev);
-            if (present) {
-                int nm = new_msg(in[k], mg[k], min0, min1, sx);
-                rec_out[k >> 2] |= ((uint32_t)nm & 0xffu) << ((k & 3) * 8);
-                bool wr = true;
+            for (int h = 0; h < 2; ++h) {
+                const int k = 2 * p + h;
+                bool present_u = (k < MAXDEG) ? (!IRREG || k < deg) : (k <= MAXDEG + 1);   // uniform part
+                if (!present_u) { nm[h] = 0; continue; }
+                if (k == MAXDEG + 1 && !has_prev) nm[h] = 0;
+                bool wr = (k == MAXDEG + 1) ? has_prev : true;
                 if constexpr (CONF) {
-                    if (k < MAXC) wr = !((early >> k) & 1);
+                    if (k < MAXC && k < nc) wr = !((early >> k) & 1);
                 }
                 if (wr) {
-                    int a = (k < MAXDEG) ? addr[k] : (k == MAXDEG ? own : prev);
-                    post[a] = (int8_t)clamp8(in[k] + nm);
+                    const int a = (k < MAXDEG) ? addr[k] : (k == MAXDEG ? own : prev);
+                    post[a] = (int8_t)pn[h];
                 }
             }
+            NM[p] = nm;
+        }
+        uint32_t rec_out[REC];
+#pragma unroll
+        for (int w = 0; w < REC; ++w) {
+            if (2 * w < NP) rec_out[w] = __builtin_amdgcn_perm(bits2(NM[2 * w + 1 <= NP ? 2 * w + 1 : NP]), bits2(NM[2 * w]), 0x06040200u);
+            else rec_out[w] = 0;
         }
         rec_store<REC>(rec_out, rec_out_ptr);
     }
+#undef LINK_IN
+#undef LINK_MG
+#undef LINK_SET
     PROF_T(t_d);
     PROF_ADD(CONF ? 6 : 2, t_c, t_d);
 }
@@ -407,8 +464,9 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS, 3) void ldpc_decode_kernel(con
                 }
                 PROF_T(t_h);
                 PROF_ADD(7, t_g, t_h);
-                if ((L.depth_nc & 0xffffu) == 1) layer_update<MAXDEG, REC, false, IRREG>(post, A, ents + L.ent_off, L, 1u, layer, j, active, rec, rp, cw, cres);
-                else layer_update<MAXDEG, REC, true, IRREG>(post, A, ents + L.ent_off, L, rw, layer, j, active, rec, rp, cw, cres);
+                if ((L.depth_nc & 0xffffu) == 1) layer_update<MAXDEG, REC, 0, IRREG>(post, A, ents + L.ent_off, L, 1u, layer, j, active, rec, rp, cw, cres);
+                else if ((L.deg >> 16) > 0) layer_update<MAXDEG, REC, 1, IRREG>(post, A, ents + L.ent_off, L, rw, layer, j, active, rec, rp, cw, cres);
+                else layer_update<MAXDEG, REC, 2, IRREG>(post, A, ents + L.ent_off, L, rw, layer, j, active, rec, rp, cw, cres);
                 PROF_T(t_e);
                 lds_barrier();
                 PROF_T(t_f);
