@@ -25,7 +25,7 @@ int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
         LdpcPlan P = build_ldpc_plan(code_index);
         LdpcDeviceCode D;
         D.code_index = code_index;
-        D.N = P.N; D.K = P.K; D.R = P.R; D.q = P.q; D.max_deg = P.max_deg; D.irregular = (P.min_deg != P.max_deg); D.rec_dwords = P.rec_dwords; D.edges = P.edges;
+        D.N = P.N; D.K = P.K; D.R = P.R; D.q = P.q; D.max_deg = P.max_deg; D.irregular = (P.min_deg != P.max_deg); D.rec_dwords = P.rec_dwords; D.edges = P.edges; D.pent_base = P.pent_base;
         int rc;
         if ((rc = upload(P.layers, &D.d_layers))) return rc;
         if ((rc = upload(P.ents, &D.d_ents))) return rc;

@@ -34,6 +34,7 @@ struct LdpcKernelArgs {
     int32_t* trials;       // [nframes]
     uint32_t* msg_ws;      // [gridDim.x][R][REC]
     int nframes, N, K, R, q;
+    int pent_base;         // offset of the pair-format link table inside ents[] (ldpc_plan.h)
     int max_trials, force;
     int hard_stride;
     unsigned long long* prof;   // development aid (-DLDPC_PROF builds only): per-wave phase cycle sums of workgroup 0
@@ -134,13 +135,26 @@ __device__ __forceinline__ s16x2 rec_pair(const uint32_t (&rec)[REC], int k) {
     return from_bits2(t) >> 8;
 }
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) int8_t lds_i8;
+__device__ __forceinline__ uint32_t lds_offset(const int8_t* p) { return (uint32_t)(uintptr_t)(const lds_i8*)p; }
+#define LDS_I8(a) (*(lds_i8*)(uintptr_t)(a))
+// Two posterior bytes, sign-extended into the low / high half of a register by the LDS unit (ds_read_i8_d16 / _d16_hi).
+// MI355X runs with SRAM ECC, where a d16 load ZEROES the other half instead of preserving it, so the two halves land in
+// two registers and one v_or joins them (still 1 VALU op per pair instead of 2 sign extensions + a byte permute).
+// Issue only; lds_pairs_wait() below orders the results.
+__device__ __forceinline__ void lds_read_pair_i8(uint32_t a_lo, uint32_t a_hi, uint32_t& r_lo, uint32_t& r_hi) {
+    asm volatile("ds_read_i8_d16 %0, %2\n\tds_read_i8_d16_hi %1, %3" : "=&v"(r_lo), "=&v"(r_hi) : "v"(a_lo), "v"(a_hi) : "memory");
+}
+__device__ __forceinline__ void lds_pairs_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // One sweep step for one layer.  CONF = layer has intra-layer shared bits (links 0..nc-1), IRREG = the
 // code has layers of different degree (short tables C1, C4, C7, C8, C9).
 // Links are processed in PAIRS held in packed int16 registers: pair p = links 2p, 2p+1 of the row, where links
 // [0, MAXDEG) are the table links, MAXDEG the row's own parity bit and MAXDEG+1 the previous parity bit.
 template <int MAXDEG, int REC, int KIND, bool IRREG>
 __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const LdpcKernelArgs& A, const uint32_t* __restrict__ ents,
-                                             const LdpcLayerDesc L, uint32_t rowword, int layer, int j, bool active,
+                                             const uint32_t* __restrict__ pents, const LdpcLayerDesc L, uint32_t rowword, int layer, int j, bool active,
                                              const uint32_t (&rec_in)[REC], uint32_t* __restrict__ rec_out_ptr,
                                              uint32_t* __restrict__ cw, uint8_t* __restrict__ cres) {
     constexpr int NL = MAXDEG + 2;
@@ -150,7 +164,8 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
     constexpr int MAXC_ALL = MAXDEG < LDPC_MAX_CONFLICT_LINKS ? MAXDEG : LDPC_MAX_CONFLICT_LINKS;
     constexpr int MAXC = KIND == 1 ? (MAXDEG < 2 ? MAXDEG : 2) : MAXC_ALL;
     s16x2 V[NP], G[NP];        // extrinsic inputs and their offset magnitudes
-    int addr[MAXDEG];
+    uint32_t addr[MAXDEG];     // LDS byte addresses of the table links' posteriors
+    const uint32_t lbase = lds_offset(post);
     const int deg = IRREG ? (int)(L.deg & 0xffffu) : MAXDEG;
     const int nc = CONF ? (int)(L.depth_nc >> 16) : 0;
     const uint32_t level = rowword & 0xffu, late = (rowword >> 8) & 0xfffu, early = rowword >> 20;
@@ -165,25 +180,47 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
     if (active) {
         s16x2 MIN0 = splat2(255), MIN1 = splat2(255);
         uint32_t SX = 0;
+        uint32_t XR[NP], XH[NP];
+        const uint32_t JJ = (uint32_t)j * 0x10001u;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            int x[2] = {0, 0};
             bool absent[2] = {false, false};     // uniform (table) absence; the missing previous parity bit of row 0 is per lane
+            uint32_t la[2] = {lbase, lbase};
+            if (2 * p < MAXDEG) {
+                // both table links of the pair at once: (j + sp) mod 360 + 360*r in packed uint16 (pair table, ldpc_plan.h)
+                u16x2 T = __builtin_bit_cast(u16x2, JJ) + __builtin_bit_cast(u16x2, pents[2 * p]);
+                T = __builtin_elementwise_min(T, (u16x2)(T - (u16x2){360, 360}));
+                const uint32_t AD = __builtin_bit_cast(uint32_t, (u16x2)(T + __builtin_bit_cast(u16x2, pents[2 * p + 1])));
+                la[0] = lbase + (AD & 0xffffu);
+                la[1] = lbase + (AD >> 16);
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int k = 2 * p + h;
                 if (k < MAXDEG) {
-                    if (!IRREG || k < deg) { addr[k] = link_addr(ents[k], j); x[h] = post[addr[k]]; }
-                    else { addr[k] = 0; absent[h] = true; }
+                    addr[k] = la[h];
+                    if (IRREG && k >= deg) absent[h] = true;
                 } else if (k == MAXDEG) {
-                    x[h] = post[own];
+                    la[h] = lbase + (uint32_t)own;
                 } else if (k == MAXDEG + 1) {
-                    x[h] = has_prev ? (int)post[prev] : 0;
+                    la[h] = lbase + (uint32_t)(has_prev ? prev : own);   // (row 0 of layer 0 has no previous parity bit: masked below)
                 } else {
                     absent[h] = true;
                 }
             }
-            const s16x2 X = s16x2{(short)x[0], (short)x[1]};
+            lds_read_pair_i8(la[0], la[1], XR[p], XH[p]);
+        }
+        lds_pairs_wait();
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            asm volatile("" : "+v"(XR[p]), "+v"(XH[p]));
+            const s16x2 X = from_bits2(XR[p] | XH[p]);
+            bool absent[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = 2 * p + h;
+                absent[h] = (k < MAXDEG) ? (IRREG && k >= deg) : (k > MAXDEG + 1);
+            }
             s16x2 v = pclamp2(X - rec_pair<REC>(rec_in, 2 * p), -128, 127);
             s16x2 g = pclamp2(pmax2(v, splat2(0) - v) - splat2(1), 0, 126);          // mag_of
 #pragma unroll
@@ -222,7 +259,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                     for (int k = 0; k < 2; ++k) {
                         if ((early >> k) & 1) {
                             int nm = new_msg(LINK_IN(k), LINK_MG(k), min0, min1, sx);
-                            post[addr[k]] = (int8_t)clamp8(LINK_IN(k) + nm);
+                            LDS_I8(addr[k]) = (int8_t)clamp8(LINK_IN(k) + nm);
                         }
                     }
                 }
@@ -265,7 +302,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                     ROW_ACCUM(v, m);
                 }
                 if (late & 1u) {
-                    int v = clamp8((int)post[addr[0]] - rec_byte<REC>(rec_in, 0));
+                    int v = clamp8((int)LDS_I8(addr[0]) - rec_byte<REC>(rec_in, 0));
                     int m = mag_of(v);
                     LINK_SET(0, v, m);
                     ROW_ACCUM(v, m);
@@ -284,7 +321,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
 #pragma unroll
                     for (int k = 0; k < MAXC; ++k) {
                         if (k < nc && ((late_l >> k) & 1)) {
-                            int v = clamp8((int)post[addr[k]] - rec_byte<REC>(rec_in, k));
+                            int v = clamp8((int)LDS_I8(addr[k]) - rec_byte<REC>(rec_in, k));
                             int m = mag_of(v);
                             LINK_SET(k, v, m);
                             ROW_ACCUM(v, m);
@@ -295,7 +332,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                 for (int k = 0; k < MAXC; ++k) {
                     if (k < nc && ((early_l >> k) & 1)) {
                         int nm = new_msg(LINK_IN(k), LINK_MG(k), min0, min1, sx);
-                        post[addr[k]] = (int8_t)clamp8(LINK_IN(k) + nm);
+                        LDS_I8(addr[k]) = (int8_t)clamp8(LINK_IN(k) + nm);
                     }
                 }
             }
@@ -328,8 +365,8 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                     if (k < MAXC && k < nc) wr = !((early >> k) & 1);
                 }
                 if (wr) {
-                    const int a = (k < MAXDEG) ? addr[k] : (k == MAXDEG ? own : prev);
-                    post[a] = (int8_t)pn[h];
+                    const uint32_t a = (k < MAXDEG) ? addr[k] : lbase + (uint32_t)(k == MAXDEG ? own : prev);
+                    LDS_I8(a) = (int8_t)pn[h];
                 }
             }
             NM[p] = nm;
@@ -464,9 +501,10 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS, 3) void ldpc_decode_kernel(con
                 }
                 PROF_T(t_h);
                 PROF_ADD(7, t_g, t_h);
-                if ((L.depth_nc & 0xffffu) == 1) layer_update<MAXDEG, REC, 0, IRREG>(post, A, ents + L.ent_off, L, 1u, layer, j, active, rec, rp, cw, cres);
-                else if ((L.deg >> 16) > 0) layer_update<MAXDEG, REC, 1, IRREG>(post, A, ents + L.ent_off, L, rw, layer, j, active, rec, rp, cw, cres);
-                else layer_update<MAXDEG, REC, 2, IRREG>(post, A, ents + L.ent_off, L, rw, layer, j, active, rec, rp, cw, cres);
+                const uint32_t* __restrict__ pe = ents + A.pent_base + layer * (2 * ((MAXDEG + 1) / 2));
+                if ((L.depth_nc & 0xffffu) == 1) layer_update<MAXDEG, REC, 0, IRREG>(post, A, ents + L.ent_off, pe, L, 1u, layer, j, active, rec, rp, cw, cres);
+                else if ((L.deg >> 16) > 0) layer_update<MAXDEG, REC, 1, IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, rec, rp, cw, cres);
+                else layer_update<MAXDEG, REC, 2, IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, rec, rp, cw, cres);
                 PROF_T(t_e);
                 lds_barrier();
                 PROF_T(t_f);
@@ -564,7 +602,7 @@ hipError_t ldpc_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nf
                               hipStream_t stream) {
     LdpcKernelArgs A;
     A.llr = llr; A.hard = hard; A.post = post; A.trials = trials; A.msg_ws = msg_ws;
-    A.nframes = nframes; A.N = C.N; A.K = C.K; A.R = C.R; A.q = C.q;
+    A.nframes = nframes; A.N = C.N; A.K = C.K; A.R = C.R; A.q = C.q; A.pent_base = C.pent_base;
     A.max_trials = max_trials; A.force = force; A.hard_stride = hard_stride;
     A.prof = g_ldpc_prof;
     const int max_deg = C.max_deg, irregular = C.irregular;

@@ -47,7 +47,8 @@ struct LdpcPlan {
     int sum_depth = 0;   // sum of layer depths (q when no layer has conflicts)
     int conflict_layers = 0;
     std::vector<LdpcLayerDesc> layers;
-    std::vector<uint32_t> ents;
+    std::vector<uint32_t> ents;   // per layer `deg` words sp | r<<16, then (from pent_base on) the pair-format table
+    int pent_base = 0;            // pair table: per layer (max_deg+1)/2 pairs x 2 words {spA | spB<<16, 360*rA | 360*rB<<16}
     std::vector<uint32_t> rows;
 };
 
@@ -128,6 +129,26 @@ inline LdpcPlan build_ldpc_plan(int code_index) {
         L.depth_nc = l_depth | (l_nc << 16);
         P.sum_depth += (int)l_depth;
         P.layers.push_back(L);
+    }
+    // pair-format copy of the link table for the packed-uint16 address arithmetic of the kernel (absent links: zeros)
+    P.pent_base = (int)P.ents.size();
+    const int npt = (P.max_deg + 1) / 2;
+    for (int i = 0; i < d.q; ++i) {
+        const LdpcLayerDesc& L = P.layers[i];
+        const int deg = (int)(L.deg & 0xffffu);
+        for (int p = 0; p < npt; ++p) {
+            uint32_t w0 = 0, w1 = 0;
+            for (int h = 0; h < 2; ++h) {
+                const int k = 2 * p + h;
+                if (k < deg) {
+                    const uint32_t e = P.ents[L.ent_off + k];
+                    w0 |= (e & 0xffffu) << (16 * h);
+                    w1 |= ((e >> 16) * 360u) << (16 * h);
+                }
+            }
+            P.ents.push_back(w0);
+            P.ents.push_back(w1);
+        }
     }
     return P;
 }
