@@ -143,3 +143,53 @@ def test_viterbi_dvbs_noise_never_locks_and_watchdog_unlocks():
     _, nbits, stats = v.work(rng.integers(-60, 61, (5, 8192)).astype(np.int8))
     # invalid counts 1, 2, 3 (> max_outsync = 2 -> IDLE after the third bad block), then stays idle
     assert list(stats[:, 1]) == [1, 1, 0, 0, 0] and list(nbits) == [6144, 6144, 6144, 0, 0]
+
+
+# ---------------------------------------------------------------- committed golden vectors (generated from the reference)
+def _golden():
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'dvbs_golden.json')) as f:
+        return json.load(f)
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_depunc_golden_vectors():
+    o = od.L()
+    for case in _golden()['depunc']:
+        rng = np.random.default_rng(case['seed'])
+        h = VP(o.orc_depunc_create(case['period']))
+        x = rng.integers(0, 256, 2048, dtype=np.uint8)
+        out = np.full(8192 + 64, 7, np.uint8)
+        n = o.orc_depunc_static(h, P(x), P(out), 2048, case['shift'])
+        assert n == case['static_n'] and _sha(out[:n]) == case['static_sha']
+        o.orc_depunc_set_shift(h, case['shift'])
+        for c in case['cont']:
+            x = rng.integers(0, 256, c['size'], dtype=np.uint8)
+            out = np.full(4 * c['size'] + 64, 9, np.uint8)
+            n = o.orc_depunc_cont(h, P(x), P(out), c['size'])
+            assert n == c['n'] and _sha(out[:n + 1]) == c['sha']
+        o.orc_depunc_destroy(h)
+
+
+def test_forney_and_rotation_golden_vectors():
+    o = od.L()
+    g = _golden()
+    rng = np.random.default_rng(g['forney']['seed'])
+    h = VP(o.orc_forney_create())
+    outs = []
+    for _ in range(g['forney']['calls']):
+        x = rng.integers(0, 256, 1632, dtype=np.uint8)
+        e = np.zeros(1632, np.uint8)
+        o.orc_forney_deinterleave(h, P(x), P(e))
+        outs.append(e)
+    assert _sha(np.concatenate(outs)) == g['forney']['sha'] and outs[0][-16:].tolist() == g['forney']['first_call_tail_16']
+    o.orc_forney_destroy(h)
+    for c in g['rotate']:
+        rng = np.random.default_rng(c['seed'])
+        x = rng.integers(-128, 128, 512, dtype=np.int8)
+        o.orc_rotate_soft(P(x), 512, c['phase'], c['iqswap'])
+        assert _sha(x) == c['sha']
