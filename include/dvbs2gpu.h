@@ -221,6 +221,40 @@ int dvbs2gpu_forney_create(dvbs2gpu_ctx* ctx, int nstreams, dvbs2gpu_forney** ou
 void dvbs2gpu_forney_destroy(dvbs2gpu_forney* h);
 int dvbs2gpu_forney_deinterleave_batch(dvbs2gpu_forney* h, const uint8_t* d_in, int nbytes, uint8_t* d_out, void* stream);
 
+/* ------------------------------------------------------------------ DVB-S receiver bank (rows a17-a19)
+ * Mirror of dsp::dvbs::DVBSDemod (module_dvbs_demod.h:14-60, module_dvbs_demod.cpp:9-117) from the input samples up to and
+ * including vit.process: demod::QPSK_ALT (FastAGC, band-edge FLL, RRC, COMPLEX_FD timing recovery, Costas<4>;
+ * common/dsp/demod/qpsk_alt.cpp:136-144), DVBSymToSoftBlock and Viterbi_DVBS, for `nstreams` independent streams.
+ * The output of a call is what DVBSVitBlock::process hands to the TS deframer: decoded bits, one per byte (0 bytes while
+ * the decoder is not locked).  cfg mirrors the arguments of DVBSDemod::init (module_dvbs_demod.cpp:9) in the same units. */
+typedef struct dvbs2gpu_dvbs_cfg {
+    double symbolrate, samplerate;       /* the plugin uses samplerate = 2*symbolrate (main.cpp:139) */
+    float agc_rate, rrc_alpha;
+    int32_t rrc_taps;                    /* 65 (RRC_TAP_COUNT); other lengths are rejected */
+    float loop_bw, fll_bw;               /* Costas and FLL loop bandwidths */
+    float clock_omega_gain, clock_mu_gain, omega_rel_limit;
+    float viterbi_ber_threshold;         /* 0.15 */
+    int32_t viterbi_max_outsync;         /* 20   (module_dvbs_demod.cpp:23) */
+} dvbs2gpu_dvbs_cfg;
+typedef struct dvbs2gpu_dvbs_demod dvbs2gpu_dvbs_demod;
+void dvbs2gpu_dvbs_demod_default_cfg(dvbs2gpu_dvbs_cfg* cfg);                 /* main.cpp:64-73,134-139 */
+int dvbs2gpu_dvbs_demod_create(dvbs2gpu_ctx* ctx, const dvbs2gpu_dvbs_cfg* cfg, int nstreams, int max_samples, dvbs2gpu_dvbs_demod** out);
+int dvbs2gpu_dvbs_demod_reset(dvbs2gpu_dvbs_demod* d);                        /* DVBSDemod::reset + a fresh Viterbi_DVBS */
+void dvbs2gpu_dvbs_demod_destroy(dvbs2gpu_dvbs_demod* d);
+/* DVBSDemod::process (module_dvbs_demod.cpp:78-81) for a bank with nstreams == 1: host buffers, returns the number of decoded
+ * bits written to h_bits (one per byte) or a negative error.  Synchronous. */
+int dvbs2gpu_dvbs_demod_process(dvbs2gpu_dvbs_demod* d, int count, const float* h_iq, uint8_t* h_bits, int cap);
+/* All streams of the bank in one go: d_iq[i] DEVICE pointers to counts[i] complex samples, d_bits[i] DEVICE buffers of cap
+ * bytes; out_counts[i] (host) = bits written for stream i.  Synchronous. */
+int dvbs2gpu_dvbs_demod_process_batch(dvbs2gpu_dvbs_demod* d, const float* const* d_iq, const int* counts, uint8_t* const* d_bits,
+                                      int cap, int* out_counts);
+/* stats_viterbi_ber / _lock / _rate of every stream (module_dvbs_demod.cpp:100-114); h_out [nstreams] */
+int dvbs2gpu_dvbs_demod_get_stats(dvbs2gpu_dvbs_demod* d, dvbs2gpu_viterbi_stats* h_out);
+/* which 0: symbols of the last call after the Costas loop (complex64; the constellation callback, module_dvbs_demod.cpp:35);
+ * which 1: 8 floats of loop state (AGC gain, FLL phase/freq, timing phase/freq/offset, Costas phase/freq).  Returns the
+ * element count; copies at most cap elements when h_dst != NULL. */
+int dvbs2gpu_dvbs_demod_get_tap(dvbs2gpu_dvbs_demod* d, int stream, int which, void* h_dst, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -236,3 +236,33 @@ void* orc_forney_create() { return new ForneyDeint(); }
 void orc_forney_destroy(void* h) { delete (ForneyDeint*)h; }
 void orc_forney_deinterleave(void* h, const uint8_t* in, uint8_t* out) { ((ForneyDeint*)h)->deinterleave(in, out); }
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------- DVB-S front end (dvbs_fe.cpp)
+#include "dvbs_fe.h"
+extern "C" {
+void orc_qpskalt_default_cfg(QpskAltCfg* c) { *c = qpsk_alt_default_cfg(); }
+void* orc_qpskalt_create(const QpskAltCfg* c) { return new QpskAlt(*c); }
+void orc_qpskalt_destroy(void* h) { delete (QpskAlt*)h; }
+int orc_qpskalt_process(void* h, int n, const float* iq, float* out) { return ((QpskAlt*)h)->process(n, (const cf*)iq, (cf*)out); }
+// stage taps for parity tests: which 0 agc, 1 fll, 2 rrc (n -> n), 3 complex_fd (n -> m), 4 costas (n -> n)
+int orc_qpskalt_stage(void* h, int which, int n, const float* in, float* out) {
+    QpskAlt* q = (QpskAlt*)h;
+    switch (which) {
+        case 0: q->agc(n, (const cf*)in, (cf*)out); return n;
+        case 1: q->fll(n, (const cf*)in, (cf*)out); return n;
+        case 2: q->rrc_filter(n, (const cf*)in, (cf*)out); return n;
+        case 3: return q->complex_fd(n, (const cf*)in, (cf*)out);
+        default: q->costas(n, (const cf*)in, (cf*)out); return n;
+    }
+}
+void orc_qpskalt_state(void* h, float* s8) {
+    QpskAlt* q = (QpskAlt*)h;
+    s8[0] = q->agc_gain; s8[1] = q->fll_pcl.phase; s8[2] = q->fll_pcl.freq; s8[3] = q->fd_pcl.phase; s8[4] = q->fd_pcl.freq;
+    s8[5] = (float)q->fd_offset; s8[6] = q->costas_pcl.phase; s8[7] = q->costas_pcl.freq;
+}
+// bits: 2*nsym bytes (0/1); out: 2*nsym complex samples (interleaved floats)
+void orc_dvbs_modulate(const uint8_t* bits, int nsym, double esn0_db, double cfo, double timing, double phase0, uint64_t seed, float* out) {
+    std::vector<cf> v = dvbs_modulate(bits, nsym, esn0_db, cfo, timing, phase0, seed, 65, 0.35);
+    memcpy(out, v.data(), v.size() * sizeof(cf));
+}
+}  // extern "C"

@@ -86,6 +86,14 @@ PROTOTYPES = {
     'dvbs2gpu_forney_create': (_i, [_vp, _i, C.POINTER(_vp)]),
     'dvbs2gpu_forney_destroy': (None, [_vp]),
     'dvbs2gpu_forney_deinterleave_batch': (_i, [_vp, _vp, _i, _vp, _vp]),
+    'dvbs2gpu_dvbs_demod_default_cfg': (None, [_vp]),
+    'dvbs2gpu_dvbs_demod_create': (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    'dvbs2gpu_dvbs_demod_reset': (_i, [_vp]),
+    'dvbs2gpu_dvbs_demod_destroy': (None, [_vp]),
+    'dvbs2gpu_dvbs_demod_process': (_i, [_vp, _i, _vp, _vp, _i]),
+    'dvbs2gpu_dvbs_demod_process_batch': (_i, [_vp, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), _i, C.POINTER(_i)]),
+    'dvbs2gpu_dvbs_demod_get_stats': (_i, [_vp, _vp]),
+    'dvbs2gpu_dvbs_demod_get_tap': (_i, [_vp, _i, _i, _vp, _i]),
 }
 
 _lib = None
@@ -398,3 +406,65 @@ def dvbs_slice(engine, iq):
     out = t.empty(2 * iq.numel(), dtype=t.int8, device=iq.device)
     engine._check(engine.lib.dvbs2gpu_dvbs_slice(engine.h, _ptr(iq), iq.numel(), _ptr(out), engine._stream()))
     return out
+
+
+class DvbsCfg(C.Structure):
+    _fields_ = [('symbolrate', C.c_double), ('samplerate', C.c_double), ('agc_rate', C.c_float), ('rrc_alpha', C.c_float),
+                ('rrc_taps', C.c_int32), ('loop_bw', C.c_float), ('fll_bw', C.c_float), ('clock_omega_gain', C.c_float),
+                ('clock_mu_gain', C.c_float), ('omega_rel_limit', C.c_float), ('viterbi_ber_threshold', C.c_float),
+                ('viterbi_max_outsync', C.c_int32)]
+
+
+class DvbsDemodBank(_Handle):
+    """`nstreams` DVB-S receivers: mirror of DVBSDemod from the input samples to the Viterbi output (module_dvbs_demod.cpp:78-81)."""
+    _destroy = 'dvbs2gpu_dvbs_demod_destroy'
+
+    def __init__(self, engine, nstreams=1, max_samples=1 << 20, **kw):
+        self.eng, self.lib, self.nstreams, self.max_samples = engine, engine.lib, nstreams, max_samples
+        self.cfg = DvbsCfg()
+        self.lib.dvbs2gpu_dvbs_demod_default_cfg(C.byref(self.cfg))
+        for k, v in kw.items():
+            setattr(self.cfg, k, v)
+        h = C.c_void_p()
+        engine._check(self.lib.dvbs2gpu_dvbs_demod_create(engine.h, C.byref(self.cfg), nstreams, max_samples, C.byref(h)))
+        self.h = h
+
+    def reset(self):
+        self.eng._check(self.lib.dvbs2gpu_dvbs_demod_reset(self.h))
+
+    def process(self, iq):
+        """single-stream bank: numpy complex64 (host) -> numpy uint8 decoded bits"""
+        import numpy as np
+        iq = np.ascontiguousarray(iq, np.complex64)
+        out = np.zeros(iq.size + 4 * 8192, np.uint8)
+        n = self.eng._check(self.lib.dvbs2gpu_dvbs_demod_process(self.h, int(iq.size), C.c_void_p(iq.ctypes.data), C.c_void_p(out.ctypes.data), out.size))
+        return out[:n]
+
+    def process_batch(self, iq_tensors, out_tensors):
+        n = self.nstreams
+        iq = (C.c_void_p * n)(*[t.data_ptr() for t in iq_tensors])
+        cnt = (C.c_int * n)(*[int(t.numel()) for t in iq_tensors])
+        out = (C.c_void_p * n)(*[t.data_ptr() for t in out_tensors])
+        nb = (C.c_int * n)()
+        cap = min(int(t.numel()) for t in out_tensors)
+        self.eng._check(self.lib.dvbs2gpu_dvbs_demod_process_batch(self.h, iq, cnt, out, cap, nb))
+        return list(nb)
+
+    def stats(self):
+        arr = (ViterbiStats * self.nstreams)()
+        self.eng._check(self.lib.dvbs2gpu_dvbs_demod_get_stats(self.h, arr))
+        return [arr[i] for i in range(self.nstreams)]
+
+    def symbols(self, stream=0):
+        import numpy as np
+        n = self.eng._check(self.lib.dvbs2gpu_dvbs_demod_get_tap(self.h, stream, 0, None, 0))
+        a = np.zeros(n, np.complex64)
+        if n:
+            self.eng._check(self.lib.dvbs2gpu_dvbs_demod_get_tap(self.h, stream, 0, C.c_void_p(a.ctypes.data), n))
+        return a
+
+    def loop_state(self, stream=0):
+        import numpy as np
+        a = np.zeros(8, np.float32)
+        self.eng._check(self.lib.dvbs2gpu_dvbs_demod_get_tap(self.h, stream, 1, C.c_void_p(a.ctypes.data), 8))
+        return a

@@ -71,6 +71,10 @@ struct dvbs2gpu_ctx {
     std::map<int, s2::ConstelTables> constel; // by modcod (gammas depend on it)
     std::map<int, float*> rrc;                // by ntaps*1000 + round(alpha*100) (Ts = 2)
     s2::Workspace ws_rx[8];
+    // DVB-S front end (dvbs_demod.hip)
+    float* d_fd_bank = nullptr;               // COMPLEX_FD interpolator bank, 256 x 256
+    std::map<int, s2::cf32*> bandedge;        // FLL band-edge taps [2][ntaps] by ntaps*100000 + round(alpha*1000)*10 + sps
+    s2::Workspace ws_dvbs[4];
 };
 
 namespace s2 {
@@ -78,6 +82,10 @@ int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out);
 int get_bch(dvbs2gpu_ctx* ctx, int m, int t, BchDeviceCode** out);
 int get_prbs(dvbs2gpu_ctx* ctx);
 // LLR -> BBFRAME for nframes frames of one code; all pointers device
+std::vector<float> make_polyphase_bank(int phases, int taps_per_phase);
+std::vector<float> make_rrc_taps(int count, double beta, double Ts);
+int get_rrc(dvbs2gpu_ctx* ctx, int ntaps, float alpha, double Ts, float** out);
+void critically_damped(float bw, float* alpha, float* beta);
 int fec_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, int nframes, int max_trials, int force, uint8_t* d_bbframes,
             int32_t* d_trials, int32_t* d_corr, hipStream_t st);
 }  // namespace s2

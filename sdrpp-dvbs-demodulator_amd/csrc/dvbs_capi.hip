@@ -98,8 +98,8 @@ int dvbs2gpu_viterbi_work_batch(dvbs2gpu_viterbi* h, const int8_t* d_soft, int n
     if (!d_soft || !d_bits || !d_nbits) return DVBS2GPU_ERR_ARG;
     static_assert(sizeof(dvbs2gpu_viterbi_stats) == sizeof(DvbsVitStats), "stats POD mismatch");
     HIP_TRY(hipSetDevice(h->ctx->device));
-    HIP_TRY(dvbs_viterbi_launch(d_soft, h->nstreams, nblocks, d_bits, d_nbits, (DvbsVitStats*)d_stats, h->d_states, h->d_ws, h->thr,
-                                h->max_outsync, (hipStream_t)stream));
+    HIP_TRY(dvbs_viterbi_launch(d_soft, nullptr, nullptr, h->nstreams, nblocks, d_bits, d_nbits, (DvbsVitStats*)d_stats, h->d_states, h->d_ws,
+                                h->thr, h->max_outsync, (hipStream_t)stream));
     return 0;
 }
 

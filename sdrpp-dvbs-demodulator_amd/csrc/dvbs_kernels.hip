@@ -208,7 +208,10 @@ __device__ float reencode_ber(const uint8_t* bits, int frame, int& enc_state, ui
     return (errors / total) * ratio;
 }
 
-__global__ __launch_bounds__(64) void dvbs_viterbi_kernel(const int8_t* in_all, int nblocks, uint8_t* out_all, int* out_n, DvbsVitStats* stats,
+// in_ptrs / nblk (both optional): per-stream input base and block count (the demodulator's soft FIFOs); otherwise stream s reads
+// in_all + s*nblocks*8192 and runs `nblocks` blocks.  Outputs are always laid out [stream][nblocks][...].
+__global__ __launch_bounds__(64) void dvbs_viterbi_kernel(const int8_t* in_all, const int8_t* const* in_ptrs, const int* nblk, int nblocks,
+                                                          uint8_t* out_all, int* out_n, DvbsVitStats* stats,
                                                           DvbsVitState* states, uint8_t* ws, float thr, int max_outsync) {
     const int lane = threadIdx.x, s = blockIdx.x;
     DvbsVitState* sp = states + s;
@@ -227,8 +230,10 @@ __global__ __launch_bounds__(64) void dvbs_viterbi_kernel(const int8_t* in_all, 
     for (int i = 0; i < 5; ++i) enc[i] = sp->enc_state[i];
     for (int i = 0; i < 2; ++i) { dfirst[i] = sp->dep_first[i]; dshift[i] = sp->dep_shift[i]; dextra[i] = sp->dep_extra[i]; dbuf[i] = sp->dep_buf[i]; }
     const int TEST = 2048, BUF = 8192;
-    for (int blk = 0; blk < nblocks; ++blk) {
-        const int8_t* in = in_all + ((size_t)s * nblocks + blk) * BUF;
+    const int8_t* in_base = in_ptrs ? in_ptrs[s] : in_all + (size_t)s * nblocks * BUF;
+    const int my_blocks = nblk ? min(nblk[s], nblocks) : nblocks;
+    for (int blk = 0; blk < my_blocks; ++blk) {
+        const int8_t* in = in_base + (size_t)blk * BUF;
         uint8_t* out = out_all + ((size_t)s * nblocks + blk) * BUF;
         if (state == 0) {                                     // ST_IDLE: viterbi_all.cpp:76-204
             ber = 10;
@@ -365,6 +370,28 @@ __global__ __launch_bounds__(256) void dvbs_deinterleave_hist_kernel(const uint8
     for (int i = threadIdx.x; i < DVBS_FORNEY_HIST; i += 256) h[i] = tmp[i];
 }
 
+// DVBSVitBlock::process output layout (dvbs_vit.cpp:6-12): the first nbits[b] bytes of every block, concatenated per stream
+__global__ __launch_bounds__(256) void dvbs_pack_bits_kernel(const uint8_t* __restrict__ bits, const int* __restrict__ nbits, const int* __restrict__ nblk,
+                                                             int nblocks, uint8_t* const* __restrict__ out_ptrs, int cap, int* __restrict__ out_count) {
+    const int s = blockIdx.x;
+    uint8_t* __restrict__ dst = out_ptrs[s];
+    const int mb = min(nblk[s], nblocks);
+    int off = 0;
+    for (int b = 0; b < mb; ++b) {
+        const int nb = nbits[(size_t)s * nblocks + b];
+        if (off + nb > cap) break;
+        const uint8_t* __restrict__ src = bits + ((size_t)s * nblocks + b) * 8192;
+        for (int i = threadIdx.x; i < nb; i += 256) dst[off + i] = src[i];
+        off += nb;
+    }
+    if (threadIdx.x == 0) out_count[s] = off;
+}
+hipError_t dvbs_pack_bits_launch(const uint8_t* d_bits, const int* d_nbits, const int* d_nblk, int nstreams, int nblocks, uint8_t* const* d_out_ptrs,
+                                 int cap, int* d_out_count, hipStream_t st) {
+    hipLaunchKernelGGL(dvbs_pack_bits_kernel, dim3(nstreams), dim3(256), 0, st, d_bits, d_nbits, d_nblk, nblocks, d_out_ptrs, cap, d_out_count);
+    return hipGetLastError();
+}
+
 hipError_t dvbs_slice_launch(const float* d_iq, int n, int8_t* d_out, hipStream_t st) {
     int grid = (2 * n + 255) / 256;
     if (grid > 4096) grid = 4096;
@@ -378,10 +405,11 @@ hipError_t dvbs_cc_decode_launch(const uint8_t* d_in, long stream_stride, int bl
                        out_stream_stride, d_dec_ws, d_state);
     return hipGetLastError();
 }
-hipError_t dvbs_viterbi_launch(const int8_t* d_soft, int nstreams, int nblocks, uint8_t* d_bits, int* d_nbits, DvbsVitStats* d_stats,
-                               DvbsVitState* d_states, uint8_t* d_ws, float thr, int max_outsync, hipStream_t st) {
-    hipLaunchKernelGGL(dvbs_viterbi_kernel, dim3(nstreams), dim3(64), 0, st, d_soft, nblocks, d_bits, d_nbits, d_stats, d_states, d_ws, thr,
-                       max_outsync);
+hipError_t dvbs_viterbi_launch(const int8_t* d_soft, const int8_t* const* d_soft_ptrs, const int* d_nblk, int nstreams, int nblocks,
+                               uint8_t* d_bits, int* d_nbits, DvbsVitStats* d_stats, DvbsVitState* d_states, uint8_t* d_ws, float thr,
+                               int max_outsync, hipStream_t st) {
+    hipLaunchKernelGGL(dvbs_viterbi_kernel, dim3(nstreams), dim3(64), 0, st, d_soft, d_soft_ptrs, d_nblk, nblocks, d_bits, d_nbits, d_stats,
+                       d_states, d_ws, thr, max_outsync);
     return hipGetLastError();
 }
 hipError_t dvbs_deinterleave_launch(const uint8_t* d_in, long stream_stride, int nstreams, int nbytes, uint8_t* d_out, uint8_t* d_hist,

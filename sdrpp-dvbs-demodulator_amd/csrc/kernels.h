@@ -67,8 +67,11 @@ static_assert(DVBS_VIT_WS_DEC % 8 == 0 && DVBS_VIT_WS_BYTES % 8 == 0, "decision 
 hipError_t dvbs_slice_launch(const float* d_iq, int n, int8_t* d_out, hipStream_t st);
 hipError_t dvbs_cc_decode_launch(const uint8_t* d_in, long stream_stride, int block_stride, int nstreams, int nblocks, int frame_size,
                                  uint8_t* d_out, long out_stream_stride, unsigned long long* d_dec_ws, int* d_state, hipStream_t st);
-hipError_t dvbs_viterbi_launch(const int8_t* d_soft, int nstreams, int nblocks, uint8_t* d_bits, int* d_nbits, DvbsVitStats* d_stats,
-                               DvbsVitState* d_states, uint8_t* d_ws, float thr, int max_outsync, hipStream_t st);
+hipError_t dvbs_viterbi_launch(const int8_t* d_soft, const int8_t* const* d_soft_ptrs, const int* d_nblk, int nstreams, int nblocks,
+                               uint8_t* d_bits, int* d_nbits, DvbsVitStats* d_stats, DvbsVitState* d_states, uint8_t* d_ws, float thr,
+                               int max_outsync, hipStream_t st);
+hipError_t dvbs_pack_bits_launch(const uint8_t* d_bits, const int* d_nbits, const int* d_nblk, int nstreams, int nblocks, uint8_t* const* d_out_ptrs,
+                                 int cap, int* d_out_count, hipStream_t st);
 hipError_t dvbs_deinterleave_launch(const uint8_t* d_in, long stream_stride, int nstreams, int nbytes, uint8_t* d_out, uint8_t* d_hist,
                                     hipStream_t st);
 

@@ -25,6 +25,8 @@ namespace {
 // ------------------------------------------------------------------------------- host-side table builders
 // (own restatement of the SDR++ tap generators and the reference's constellation / PL constants; the CPU
 //  oracle builds the same tables independently in oracle/s2chain.cpp)
+}  // namespace
+namespace s2 {
 std::vector<float> make_rrc_taps(int count, double beta, double Ts) {
     const double PI = 3.14159265358979323846, SQ2 = 1.41421356237309504880;
     double limit = Ts / (4.0 * beta), half = (double)count / 2.0;
@@ -42,9 +44,10 @@ std::vector<float> make_rrc_taps(int count, double beta, double Ts) {
     return taps;
 }
 
-std::vector<float> make_gardner_bank() {   // gardner.cpp:154-159: 128 phases x 8 taps, Nuttall-windowed sinc
+// gardner.cpp:154-159 (128 phases x 8 taps) and complex_fd.cpp:152-157 (256 x 256): Nuttall-windowed sinc, polyphase bank
+std::vector<float> make_polyphase_bank(int phases, int tpp) {
     const double PI = 3.14159265358979323846;
-    const int phases = GARDNER_PHASES, tpp = GARDNER_TAPS, count = phases * tpp;
+    const int count = phases * tpp;
     double omega = 2.0 * PI * (0.5 / (double)phases), half = (double)count / 2.0, corr = (double)phases * omega / PI;
     const double coefs[4] = {0.355768, 0.487396, 0.144232, 0.012604};
     std::vector<float> bank((size_t)count, 0.f);
@@ -57,6 +60,9 @@ std::vector<float> make_gardner_bank() {   // gardner.cpp:154-159: 128 phases x 
     }
     return bank;
 }
+}  // namespace s2
+namespace {
+std::vector<float> make_gardner_bank() { return make_polyphase_bank(GARDNER_PHASES, GARDNER_TAPS); }
 
 struct HostConstel {
     int constel, bits, states;
@@ -213,6 +219,8 @@ int get_constel(dvbs2gpu_ctx* ctx, const ModcodParams& mp, ConstelTables** out) 
     return 0;
 }
 
+}  // namespace
+namespace s2 {
 int get_rrc(dvbs2gpu_ctx* ctx, int ntaps, float alpha, double Ts, float** out) {
     std::lock_guard<std::mutex> l(ctx->mtx);
     int key = ntaps * 100000 + (int)lround(alpha * 1000) * 10 + (int)lround(Ts);
@@ -233,6 +241,8 @@ void critically_damped(float bw, float* alpha, float* beta) {   // SDR++ PhaseCo
     *alpha = (float)((4.0 * damping * bw) / den);
     *beta = (float)((4.0 * (double)bw * bw) / den);
 }
+}  // namespace s2
+namespace {
 
 inline size_t fe_capacity(int n) { return (size_t)2 * n + n / 16 + 256; }
 

@@ -80,6 +80,48 @@ struct S2PlTablesDev {
     const uint8_t* rn;         // [131072]
 };
 
+// ---------------------------------------------------------------- DVB-S front end (demod::QPSK_ALT, qpsk_alt.cpp)
+constexpr int FD_PHASES = 256, FD_TAPS = 256;   // complex_fd.h:33
+constexpr int DVBS_SOFT_BLOCK = 8192;           // dvbs_defines.h:3
+
+// Loop state of one DVB-S stream: FastAGC, FLL (+ band-edge FIR delay line), RRC FIR delay line, COMPLEX_FD (+ PCL, delay line),
+// Costas<4>, and the soft-bit block FIFO fill of DVBSymToSoftBlock.
+struct DvbsStreamState {
+    float agc_gain;
+    float fll_phase, fll_freq;
+    cf32 fll_hist[RRC_MAX_TAPS - 1];
+    cf32 rrc_hist[RRC_MAX_TAPS - 1];
+    float fd_phase, fd_freq;
+    int fd_offset, fd_spsctr;
+    cf32 fd_hist[FD_TAPS - 1];
+    float costas_phase, costas_freq;
+    int n_sym;          // symbols produced by the last call
+    int soft_fill;      // soft bits waiting in the block FIFO (after the last call: < 8192)
+    int n_blocks;       // whole 8192-soft blocks handed to the Viterbi decoder in the last call
+};
+struct DvbsLoopCoefs {
+    float agc_rate;
+    float fll_beta, fll_min_freq, fll_max_freq;
+    float fd_alpha, fd_beta, fd_min_freq, fd_max_freq;
+    float cos_alpha, cos_beta, cos_min_freq, cos_max_freq;
+    int ntaps;          // RRC and band-edge filter length
+};
+struct DvbsStreamWork {
+    const cf32* in;     // 2-sps input of this call
+    int count;
+    cf32* buf_a;        // [count]: AGC output, later RRC output
+    cf32* buf_b;        // [count]: FLL output
+    cf32* sym;          // [count/2 + 64]: symbols after COMPLEX_FD + Costas
+    int8_t* soft;       // soft-bit FIFO (capacity count + 2*8192 + 128)
+    DvbsStreamState* st;
+};
+// AGC -> FLL -> RRC -> COMPLEX_FD + Costas -> soft slicer into the per-stream block FIFO
+hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int max_count, DvbsLoopCoefs coefs, const cf32* d_bandedge,
+                                const float* d_rrc, const float* d_fd_bank, hipStream_t st);
+
+hipError_t dvbs_soft_count_launch(const DvbsStreamWork* d_work, int nstreams, int* d_nblocks, hipStream_t st);
+hipError_t dvbs_soft_compact_launch(const DvbsStreamWork* d_work, int nstreams, hipStream_t st);
+
 hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCoefs coefs, const float* d_bank, hipStream_t st);
 hipError_t s2_rrc_decim_launch(const S2StreamWork* d_work, int nstreams, int max_count, const float* d_taps, int ntaps, hipStream_t st);
 // windows: d_win[w] = pointer to raw symbols of candidate window w; outputs best_pos / best_match per window

@@ -654,6 +654,272 @@ __global__ __launch_bounds__(256) void s2_fifo_compact_kernel(const S2StreamWork
     for (int i = blockIdx.x * 256 + threadIdx.x; i < fill - cur; i += gridDim.x * 256) dst[i] = src[i];
 }
 
+// ================================================================================================ DVB-S front end (a17)
+// demod::QPSK_ALT::process (common/dsp/demod/qpsk_alt.cpp:136-144): FastAGC -> FLL -> RRC FIR -> COMPLEX_FD -> Costas<4>,
+// then DVBSymToSoftBlock's conversion into the 8192-soft block FIFO (dvbs_syms_to_soft.cpp:24-42).
+__device__ __forceinline__ float fast_amplitude(cf32 v) {   // SDR++ complex_t::fastAmplitude
+    const float re_abs = fabsf(v.re), im_abs = fabsf(v.im);
+    return re_abs > im_abs ? re_abs + 0.4f * im_abs : im_abs + 0.4f * re_abs;
+}
+__device__ __forceinline__ void pcl_wrap_pi(float& phase) {
+    const float PI_F = 3.14159265358979323846f;
+    const float delta = PI_F - (-PI_F);
+    while (phase > PI_F) phase -= delta;
+    while (phase < -PI_F) phase += delta;
+}
+
+// LANE = STREAM: the AGC gain recurrence (as in s2_agc_nco_kernel); writes y = x*gain
+__global__ __launch_bounds__(64) void dvbs_agc_kernel(const DvbsStreamWork* __restrict__ work, int nstreams, DvbsLoopCoefs co) {
+    const int lane = threadIdx.x, s = blockIdx.x * 64 + lane;
+    const bool act = s < nstreams;
+    const DvbsStreamWork w = work[act ? s : 0];
+    const int n = act ? w.count : 0;
+    float gain = w.st->agc_gain;
+    const cf32* in = w.in;
+    cf32* out = w.buf_a;
+    int nmax = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+    for (int i = 0; i < nmax; ++i) {
+        if (i < n) {
+            const cf32 y = cscale(in[i], gain);
+            out[i] = y;
+            const float a = camp(y);
+            gain += (1.0f - a) * co.agc_rate;
+            gain = gain > 10e6f ? 10e6f : gain;
+        }
+    }
+    if (act) w.st->agc_gain = gain;
+}
+
+// ONE WAVE PER STREAM.  loop::FLL::process (fll.cpp:135-149): every sample is rotated by the loop phase and fed to the two
+// band-edge FIRs whose amplitude difference steers the loop -- a feedback through two 65-tap complex dot products per sample.
+// The dot products run as a SYSTOLIC ARRAY over the lanes: lane k holds tap k and a running sum; each new sample x[m] adds
+// x[m]*t[k] to the running sum of output m+64-k and the sums move one lane up (DPP wave_shr:1), so every output accumulates its
+// terms in tap order 0..64 (the order of VOLK's generic kernel) while only the LAST term (tap 64, the newest sample) sits in the
+// loop's serial chain.  Lanes 0..63 = taps 0..63; tap 64 is applied by all lanes to the sum leaving lane 63.
+__global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __restrict__ work, DvbsLoopCoefs co,
+                                                      const cf32* __restrict__ bandedge) {
+    __shared__ cf32 ytile[64];
+    __shared__ cf32 xtile[64];
+    const int lane = threadIdx.x;
+    const DvbsStreamWork w = work[blockIdx.x];
+    DvbsStreamState* st = w.st;
+    const int n = w.count, T = co.ntaps, H = T - 1;     // the systolic layout needs T == 65 (checked on the host)
+    const cf32 tl = bandedge[lane], th = bandedge[T + lane];
+    const cf32 tl_last = bandedge[T - 1], th_last = bandedge[2 * T - 1];
+    float phase = st->fll_phase, freq = st->fll_freq;
+    // running sums from the delay line: lane k holds, for output n' = m0 + 63 - k, the terms of taps 0..k
+    cf32 al{0.f, 0.f}, ah{0.f, 0.f};
+    for (int jt = 0; jt <= lane; ++jt) {
+        // term jt of output n' uses sample index n' - 64 + jt relative to the new data, i.e. history slot H + (n' - 64 + jt) with n' = 63 - lane
+        const cf32 xs = st->fll_hist[H + (63 - lane) - 64 + jt];
+        al = cadd(al, cmul(xs, bandedge[jt]));
+        ah = cadd(ah, cmul(xs, bandedge[T + jt]));
+    }
+    cf32 last_x[1];
+    (void)last_x;
+    for (int base = 0; base < n; base += 64) {
+        const int m = min(64, n - base);
+        __syncthreads();
+        if (lane < m) ytile[lane] = w.buf_a[base + lane];
+        __syncthreads();
+        for (int k = 0; k < m; ++k) {
+            const cf32 x = cmul(ytile[k], phasor_fast(-phase));
+            // complete this sample's two outputs: partial sum leaving lane 63 + newest sample * last tap
+            cf32 pl, ph;
+            pl.re = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al.re), 63));
+            pl.im = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al.im), 63));
+            ph.re = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ah.re), 63));
+            ph.im = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ah.im), 63));
+            const cf32 lo = cadd(pl, cmul(x, tl_last)), hi = cadd(ph, cmul(x, th_last));
+            const float err = fast_amplitude(hi) - fast_amplitude(lo);
+            // PhaseControlLoop::advance with alpha = 0 (fll.cpp:26)
+            freq += co.fll_beta * err;
+            freq = freq > co.fll_max_freq ? co.fll_max_freq : (freq < co.fll_min_freq ? co.fll_min_freq : freq);
+            phase += freq;
+            pcl_wrap_pi(phase);
+            if (lane == 0) xtile[k] = x;
+            // systolic step: sums move one lane up, lane 0 starts the sum of output m + 64
+            cf32 sl, sh;
+            sl.re = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, al.re), 0x138, 0xf, 0xf, false));
+            sl.im = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, al.im), 0x138, 0xf, 0xf, false));
+            sh.re = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ah.re), 0x138, 0xf, 0xf, false));
+            sh.im = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ah.im), 0x138, 0xf, 0xf, false));
+            al = cadd(sl, cmul(x, tl));
+            ah = cadd(sh, cmul(x, th));
+        }
+        __syncthreads();
+        if (lane < m) w.buf_b[base + lane] = xtile[lane];
+    }
+    __syncthreads();
+    // new delay line = last H samples of [old delay line ++ rotated samples of this call]
+    for (int i = lane; i < H; i += 64) {
+        const int p = n - H + i;
+        const cf32 v = p >= 0 ? w.buf_b[p] : st->fll_hist[H + p];
+        __syncthreads();
+        xtile[i & 63] = v;
+        __syncthreads();
+        st->fll_hist[i] = xtile[i & 63];
+    }
+    if (lane == 0) { st->fll_phase = phase; st->fll_freq = freq; }
+}
+
+// RRC FIR at the input rate (SDR++ filter::FIR, taps accumulated in order); grid (x: sample tiles, y: stream); in = buf_b, out = buf_a
+__global__ __launch_bounds__(256) void dvbs_rrc_kernel(const DvbsStreamWork* __restrict__ work, const float* __restrict__ taps_g, int ntaps) {
+    __shared__ float taps[RRC_MAX_TAPS];
+    for (int i = threadIdx.x; i < ntaps; i += 256) taps[i] = taps_g[i];
+    __syncthreads();
+    const DvbsStreamWork w = work[blockIdx.y];
+    const DvbsStreamState* st = w.st;
+    const int n = w.count, H = ntaps - 1;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        cf32 acc{0.f, 0.f};
+        for (int k = 0; k < ntaps; ++k) {
+            const int p = i + k;
+            const cf32 v = p < H ? st->rrc_hist[p] : w.buf_b[p - H];
+            acc.re += v.re * taps[k];
+            acc.im += v.im * taps[k];
+        }
+        w.buf_a[i] = acc;
+    }
+}
+__global__ __launch_bounds__(128) void dvbs_rrc_state_kernel(const DvbsStreamWork* __restrict__ work, int ntaps) {
+    const DvbsStreamWork w = work[blockIdx.x];
+    DvbsStreamState* st = w.st;
+    const int n = w.count, H = ntaps - 1;
+    __shared__ cf32 nh[RRC_MAX_TAPS];
+    for (int i = threadIdx.x; i < H; i += 128) {
+        const int p = n + i;
+        nh[i] = p < H ? st->rrc_hist[p] : w.buf_b[p - H];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < H; i += 128) st->rrc_hist[i] = nh[i];
+}
+
+// 256-tap complex x real dot product over the wave: 4 taps per lane in order, then a fixed pairwise tree (lane l += lane l + s,
+// s = 32..1) -- the documented order of the engine for COMPLEX_FD (oracle/dvbs_fe.cpp fd_dot).  Result valid in lane 0.
+__device__ __forceinline__ cf32 fd_dot_wave(const cf32 (&x)[4], const float* __restrict__ t, int lane) {
+    float ar = 0.f, ai = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const float tt = t[lane + 64 * q]; ar += x[q].re * tt; ai += x[q].im * tt; }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { ar = ar + __shfl_down(ar, s); ai = ai + __shfl_down(ai, s); }
+    return cf32{__shfl(ar, 0), __shfl(ai, 0)};
+}
+
+// ONE WAVE PER STREAM: clock_recovery::COMPLEX_FD::process (complex_fd.cpp:89-150, 256 phases x 256 taps, outSps = 1) followed by
+// loop::Costas<4> on every produced symbol (feed-forward after the timing loop).  The interpolator bank (256 KB) stays in L2.
+constexpr int FD_TILE = 512;
+__global__ __launch_bounds__(64) void dvbs_fd_costas_kernel(const DvbsStreamWork* __restrict__ work, DvbsLoopCoefs co,
+                                                            const float* __restrict__ bank) {
+    __shared__ cf32 win[FD_TILE + FD_TAPS];      // [255 history][tile]
+    __shared__ cf32 ostage[FD_TILE / 2 + 72];
+    const int lane = threadIdx.x;
+    const DvbsStreamWork w = work[blockIdx.x];
+    DvbsStreamState* st = w.st;
+    const int n = w.count;
+    PclDev pcl{co.fd_alpha, co.fd_beta, st->fd_phase, st->fd_freq, co.fd_min_freq, co.fd_max_freq};
+    PclDev cos{co.cos_alpha, co.cos_beta, st->costas_phase, st->costas_freq, co.cos_min_freq, co.cos_max_freq};
+    int offset = st->fd_offset, spsctr = st->fd_spsctr, outCount = 0;
+    for (int i = lane; i < FD_TAPS - 1; i += 64) win[i] = st->fd_hist[i];
+    __syncthreads();
+    for (int base = 0; base < n; base += FD_TILE) {
+        const int m = min(FD_TILE, n - base);
+        for (int i = lane; i < m; i += 64) win[FD_TAPS - 1 + i] = w.buf_a[base + i];
+        __syncthreads();
+        int nout = 0;
+        for (int guard = 0; guard < 4 * FD_TILE && offset < base + m; ++guard) {
+            int phase = (int)floorf(pcl.phase * (float)FD_PHASES);
+            phase = phase < 0 ? 0 : (phase > FD_PHASES - 1 ? FD_PHASES - 1 : phase);
+            cf32 x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q] = win[(offset - base) + lane + 64 * q];
+            const cf32 outVal = fd_dot_wave(x, bank + (size_t)phase * FD_TAPS, lane);
+            cf32 dfdt;
+            if (phase == 0) {
+                const cf32 fT1 = fd_dot_wave(x, bank + (size_t)(phase + 1) * FD_TAPS, lane);
+                dfdt = csub(fT1, outVal);
+            } else if (phase == FD_PHASES - 1) {
+                const cf32 fT_1 = fd_dot_wave(x, bank + (size_t)(phase - 1) * FD_TAPS, lane);
+                dfdt = csub(outVal, fT_1);
+            } else {
+                const cf32 fT1 = fd_dot_wave(x, bank + (size_t)(phase + 1) * FD_TAPS, lane);
+                const cf32 fT_1 = fd_dot_wave(x, bank + (size_t)(phase - 1) * FD_TAPS, lane);
+                dfdt = cscale(csub(fT1, fT_1), 0.5f);
+            }
+            float error = spsctr == 0 ? ((outVal.re * dfdt.re) + (outVal.im * dfdt.im)) : 0.f;
+            spsctr++;
+            if (spsctr >= 1) spsctr = 0;                 // outSps = 1 (qpsk_alt.cpp:22)
+            error = error > 1.0f ? 1.0f : error;
+            error = error < -1.0f ? -1.0f : error;
+            pcl.advance(error);
+            const float delta = floorf(pcl.phase);
+            offset = (int)((float)offset + delta);       // `offset += delta` with an int offset and a float delta
+            pcl.phase -= delta;
+            // Costas<4> (SDR++ loop/costas.h): derotate, decision-directed QPSK error, clamp, advance
+            const cf32 v = cmul(outVal, phasor_fast(-cos.phase));
+            float cerr = ((v.re > 0 ? 1.0f : -1.0f) * v.im) - ((v.im > 0 ? 1.0f : -1.0f) * v.re);
+            cerr = cerr > 1.0f ? 1.0f : (cerr < -1.0f ? -1.0f : cerr);
+            cos.advance(cerr);
+            cos.wrap_pi();
+            if (lane == 0) ostage[nout] = v;
+            ++nout;
+        }
+        __syncthreads();
+        for (int i = lane; i < nout; i += 64) w.sym[outCount + i] = ostage[i];
+        outCount += nout;
+        // slide the 255-sample history
+        cf32 h[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int i = lane + 64 * q; h[q] = i < FD_TAPS - 1 ? win[m + i] : cf32{0.f, 0.f}; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int i = lane + 64 * q; if (i < FD_TAPS - 1) win[i] = h[q]; }
+        __syncthreads();
+    }
+    for (int i = lane; i < FD_TAPS - 1; i += 64) st->fd_hist[i] = win[i];
+    if (lane == 0) {
+        st->fd_phase = pcl.phase; st->fd_freq = pcl.freq; st->fd_offset = offset - n; st->fd_spsctr = spsctr;
+        st->costas_phase = cos.phase; st->costas_freq = cos.freq;
+        st->n_sym = outCount;
+    }
+}
+
+// DVBSymToSoftBlock: symbols -> int8 soft pairs appended to the stream's block FIFO; grid (x: tiles, y: stream)
+__global__ __launch_bounds__(256) void dvbs_soft_fifo_kernel(const DvbsStreamWork* __restrict__ work) {
+    const DvbsStreamWork w = work[blockIdx.y];
+    const DvbsStreamState* st = w.st;
+    const int ns = st->n_sym, fill = st->soft_fill;
+    const float* __restrict__ sy = reinterpret_cast<const float*>(w.sym);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * ns; i += gridDim.x * 256) {
+        const float x = sy[i] * 100;
+        w.soft[fill + i] = x < -127.0f ? (int8_t)-127 : (x > 127.0f ? (int8_t)127 : (int8_t)x);
+    }
+}
+__global__ __launch_bounds__(64) void dvbs_soft_count_kernel(const DvbsStreamWork* __restrict__ work, int nstreams, int* __restrict__ nblocks_out) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= nstreams) return;
+    DvbsStreamState* st = work[s].st;
+    const int fill = st->soft_fill + 2 * st->n_sym;
+    st->n_blocks = fill / DVBS_SOFT_BLOCK;
+    st->soft_fill = fill;                      // (reduced by the blocks consumed in dvbs_soft_compact_kernel, after the decoder ran)
+    nblocks_out[s] = fill / DVBS_SOFT_BLOCK;
+}
+__global__ __launch_bounds__(256) void dvbs_soft_compact_kernel(const DvbsStreamWork* __restrict__ work) {
+    const DvbsStreamWork w = work[blockIdx.x];
+    DvbsStreamState* st = w.st;
+    const int used = st->n_blocks * DVBS_SOFT_BLOCK, rest = st->soft_fill - used;
+    __shared__ int8_t tmp[DVBS_SOFT_BLOCK];
+    if (used > 0) {
+        for (int i = threadIdx.x; i < rest; i += 256) tmp[i] = w.soft[used + i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < rest; i += 256) w.soft[i] = tmp[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) st->soft_fill = rest;
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 hipError_t s2_collect_launch(const S2StreamWork* d_work, int nstreams, int* d_nsym, float* d_nco, hipStream_t st) {
     hipLaunchKernelGGL(s2_collect_kernel, dim3((nstreams + 255) / 256), dim3(256), 0, st, d_work, nstreams, d_nsym, d_nco);
@@ -666,6 +932,26 @@ hipError_t s2_scatter_out_launch(const S2StreamWork* d_work, const S2FrameRef* d
 }
 hipError_t s2_fifo_compact_launch(const S2StreamWork* d_work, int nstreams, const int* d_cur_fill, hipStream_t st) {
     hipLaunchKernelGGL(s2_fifo_compact_kernel, dim3(16, nstreams), dim3(256), 0, st, d_work, d_cur_fill);
+    return hipGetLastError();
+}
+hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int max_count, DvbsLoopCoefs coefs, const cf32* d_bandedge,
+                                const float* d_rrc, const float* d_fd_bank, hipStream_t st) {
+    hipLaunchKernelGGL(dvbs_agc_kernel, dim3((nstreams + 63) / 64), dim3(64), 0, st, d_work, nstreams, coefs);
+    hipLaunchKernelGGL(dvbs_fll_kernel, dim3(nstreams), dim3(64), 0, st, d_work, coefs, d_bandedge);
+    int gx = (max_count + 255) / 256;
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    hipLaunchKernelGGL(dvbs_rrc_kernel, dim3(gx, nstreams), dim3(256), 0, st, d_work, d_rrc, coefs.ntaps);
+    hipLaunchKernelGGL(dvbs_rrc_state_kernel, dim3(nstreams), dim3(128), 0, st, d_work, coefs.ntaps);
+    hipLaunchKernelGGL(dvbs_fd_costas_kernel, dim3(nstreams), dim3(64), 0, st, d_work, coefs, d_fd_bank);
+    hipLaunchKernelGGL(dvbs_soft_fifo_kernel, dim3(gx, nstreams), dim3(256), 0, st, d_work);
+    return hipGetLastError();
+}
+hipError_t dvbs_soft_count_launch(const DvbsStreamWork* d_work, int nstreams, int* d_nblocks, hipStream_t st) {
+    hipLaunchKernelGGL(dvbs_soft_count_kernel, dim3((nstreams + 63) / 64), dim3(64), 0, st, d_work, nstreams, d_nblocks);
+    return hipGetLastError();
+}
+hipError_t dvbs_soft_compact_launch(const DvbsStreamWork* d_work, int nstreams, hipStream_t st) {
+    hipLaunchKernelGGL(dvbs_soft_compact_kernel, dim3(nstreams), dim3(256), 0, st, d_work);
     return hipGetLastError();
 }
 hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCoefs coefs, const float* d_bank, hipStream_t st) {

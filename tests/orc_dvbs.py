@@ -116,3 +116,89 @@ class OracleViterbi:
             ps = int(st[3])
             stats[b] = [np.float32(st[0]).view(np.int32), int(st[1]), int(st[2]), ps // 16, ps % 16]
         return bits, nbits, stats
+
+
+# ------------------------------------------------------------------ DVB-S front end (oracle/dvbs_fe.cpp)
+class QpskAltCfg(C.Structure):
+    _fields_ = [('symbolrate', C.c_double), ('samplerate', C.c_double), ('rrc_taps', C.c_int), ('rrc_alpha', C.c_float),
+                ('agc_rate', C.c_float), ('costas_bw', C.c_float), ('fll_bw', C.c_float), ('omega_gain', C.c_float),
+                ('mu_gain', C.c_float), ('omega_rel_limit', C.c_float)]
+
+
+_fe_bound = False
+
+
+def LF():
+    global _fe_bound
+    l = L()
+    if not _fe_bound:
+        l.orc_qpskalt_default_cfg.argtypes = [C.POINTER(QpskAltCfg)]
+        l.orc_qpskalt_default_cfg.restype = None
+        l.orc_qpskalt_create.argtypes = [C.POINTER(QpskAltCfg)]
+        l.orc_qpskalt_create.restype = VP
+        l.orc_qpskalt_destroy.argtypes = [VP]
+        l.orc_qpskalt_destroy.restype = None
+        l.orc_qpskalt_process.argtypes = [VP, C.c_int, VP, VP]
+        l.orc_qpskalt_stage.argtypes = [VP, C.c_int, C.c_int, VP, VP]
+        l.orc_qpskalt_state.argtypes = [VP, VP]
+        l.orc_qpskalt_state.restype = None
+        l.orc_dvbs_modulate.argtypes = [VP, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint64, VP]
+        l.orc_dvbs_modulate.restype = None
+        _fe_bound = True
+    return l
+
+
+def qpsk_alt_default_cfg(**kw):
+    c = QpskAltCfg()
+    LF().orc_qpskalt_default_cfg(C.byref(c))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def dvbs_tx_bits(rate, n_tx_bits, seed):
+    """transmitted (punctured) bit stream of a random message: returns (tx bits uint8 [n_tx_bits], info bits)"""
+    rng = np.random.default_rng(seed)
+    keep = puncture_keep_mask(rate, n_tx_bits + 64)
+    nbits = len(keep) // 2 + 8
+    bits = rng.integers(0, 2, nbits, dtype=np.uint8)
+    mother = cc_encode(bits)[:len(keep)]
+    return np.ascontiguousarray(mother[keep][:n_tx_bits]), bits
+
+
+def dvbs_iq(rate, nsym, seed, esn0_db=12.0, cfo=0.0, timing=0.0, phase0=0.0):
+    """complex64 [2*nsym] at 2 sps of a DVB-S inner-coded QPSK stream (no RS / interleaver: inner code only)"""
+    tx, bits = dvbs_tx_bits(rate, 2 * nsym, seed)
+    out = np.zeros(2 * nsym, np.complex64)
+    LF().orc_dvbs_modulate(P(tx), nsym, esn0_db, cfo, timing, phase0, seed, P(out))
+    return out, bits
+
+
+class OracleQpskAlt:
+    def __init__(self, cfg=None):
+        self.l = LF()
+        self.cfg = cfg or qpsk_alt_default_cfg()
+        self.h = VP(self.l.orc_qpskalt_create(C.byref(self.cfg)))
+
+    def __del__(self):
+        try:
+            self.l.orc_qpskalt_destroy(self.h)
+        except Exception:
+            pass
+
+    def process(self, iq):
+        iq = np.ascontiguousarray(iq, np.complex64)
+        out = np.zeros(iq.size // 2 + 64, np.complex64)
+        n = self.l.orc_qpskalt_process(self.h, iq.size, P(iq), P(out))
+        return out[:n]
+
+    def stage(self, which, x):
+        x = np.ascontiguousarray(x, np.complex64)
+        out = np.zeros(x.size + 64, np.complex64)
+        n = self.l.orc_qpskalt_stage(self.h, which, x.size, P(x), P(out))
+        return out[:n]
+
+    def state(self):
+        s = np.zeros(8, np.float32)
+        self.l.orc_qpskalt_state(self.h, P(s))
+        return s
