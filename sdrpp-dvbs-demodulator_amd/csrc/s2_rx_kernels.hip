@@ -97,9 +97,9 @@ __device__ __forceinline__ cf32 phasor_fast(float x) {
 }
 
 // The front end is split along its dependency structure:
-//   s2_agc_nco_kernel  LANE = STREAM.  The AGC gain and NCO phase recurrences depend only on the input, are strictly serial in
+//   agc_pc_kernel      LANE = STREAM.  The AGC gain and NCO phase recurrences depend only on the input, are strictly serial in
 //                      time and ~40 instructions per sample: one lane runs one stream, a wave 64 streams, and the per-sample
-//                      (gain, phase) pairs go to the stream's scratch area.  Per-lane input reads walk whole 64-byte sectors.
+//                      (gain, phase) pairs go to the stream's scratch area; a second wave of the workgroup moves the tiles.
 //   s2_gardner_kernel  EIGHT LANES PER STREAM (polyphase arm x re/im), 8 streams per wave.  Tiles of 64 samples per stream are
 //                      staged through LDS by all 64 lanes -- y = x*gain, z = y*phasor(-phase), the parallel part of
 //                      FastAGC/FreqShift; the loads of the next tile stay in flight during the loop -- then every lane group
@@ -114,56 +114,104 @@ constexpr int G_PITCH = G_TILE + 9;   // 7 history + tile, odd pitch spreads the
 
 __device__ __forceinline__ size_t fe_scratch_offset(int n) { return (size_t)n + n / 16 + 128; }
 
-__global__ __launch_bounds__(64) void s2_agc_nco_kernel(const S2StreamWork* __restrict__ work, int nstreams, S2LoopCoefs co) {
-    const int lane = threadIdx.x, s = blockIdx.x * 64 + lane;
-    const bool act = s < nstreams;
-    const S2StreamWork w = work[act ? s : 0];
-    const int n = act ? w.count : 0;
-    S2StreamState* st = w.st;
-    float gain = st->agc_gain, nph = st->nco_phase;
-    const float nfr = st->nco_freq;
-    // (generic pointers on purpose: measured on MI355X, flat loads/stores are faster here than global ones -- with a single
-    // counter for loads and stores in flight the compiler has to drain the stores before it can consume a prefetched load)
-    const cf32* in = w.in;
-    cf32* gp = w.fe_out + fe_scratch_offset(n);
-    int nmax = n, nmin = act ? n : 0x7fffffff;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { nmax = max(nmax, __shfl_xor(nmax, o)); nmin = min(nmin, __shfl_xor(nmin, o)); }
-    constexpr int U = 8;
-    auto sample = [&](cf32 x, int idx) {
-        gp[idx] = cf32{gain, nph};
+// ---- serial per-sample recurrences, LANE = STREAM, with the memory traffic on a second wave ------------------------------
+// Workgroup = 2 waves for 64 streams.  Wave 0 runs the recurrences of its 64 streams out of LDS tiles (in place: the result
+// overwrites the input slot); wave 1 moves the tiles: coalesced row loads of the next tile, coalesced row stores of the
+// previous one, double-buffered.  The compute wave never issues a global access, so no memory latency and no store drain
+// (loads and stores share one counter on this hardware) ever enters the serial chain.
+constexpr int AG_T = 32;                 // samples per stream per tile
+struct AgcS2Traits {                     // FastAGC gain + FreqShift phase recurrences; result = (gain, phase) per sample
+    typedef S2StreamWork Work;
+    typedef S2LoopCoefs Coefs;
+    struct Regs { float gain, nph, nfr; };
+    static __device__ __forceinline__ const cf32* in_ptr(const Work& w) { return w.in; }
+    static __device__ __forceinline__ cf32* out_ptr(const Work& w) { return w.fe_out + fe_scratch_offset(w.count); }
+    static __device__ __forceinline__ Regs load(const Work& w) { return Regs{w.st->agc_gain, w.st->nco_phase, w.st->nco_freq}; }
+    static __device__ __forceinline__ void store(const Work& w, const Regs& r) { w.st->agc_gain = r.gain; w.st->nco_phase = r.nph; }
+    static __device__ __forceinline__ cf32 step(Regs& r, cf32 x, const Coefs& co) {
+        const cf32 res{r.gain, r.nph};
         // FastAGC (SDR++ loop/fast_agc.h as used at module_dvbs2_demod.cpp:222)
-        cf32 y = cscale(x, gain);
-        float a = camp(y);
-        gain += (1.0f - a) * co.agc_rate;
-        gain = gain > 10e6f ? 10e6f : gain;
+        const cf32 y = cscale(x, r.gain);
+        const float a = camp(y);
+        r.gain += (1.0f - a) * co.agc_rate;
+        r.gain = r.gain > 10e6f ? 10e6f : r.gain;
         // FreqShift phase accumulator (common/dsp/demod/freq_shift.cpp)
-        nph += nfr;
-        while ((double)nph > 6.283185307179586) nph = (float)((double)nph - 6.283185307179586);
-        while ((double)nph < -6.283185307179586) nph = (float)((double)nph + 6.283185307179586);
-    };
-    // main part: whole chunks that exist in every stream of the wave, no per-sample guards; next chunk's loads in flight
-    const int nfull = act ? (nmin / U) * U : 0;
-    int i = 0;
-    if (nfull > 0) {
-        cf32 nx[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) nx[u] = in[u];
-        for (; i < nfull; i += U) {
-            cf32 x[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) x[u] = nx[u];
-            if (i + U < nfull) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) nx[u] = in[i + U + u];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) sample(x[u], i + u);
-        }
+        r.nph += r.nfr;
+        while ((double)r.nph > 6.283185307179586) r.nph = (float)((double)r.nph - 6.283185307179586);
+        while ((double)r.nph < -6.283185307179586) r.nph = (float)((double)r.nph + 6.283185307179586);
+        return res;
     }
-    for (; i < nmax; ++i)
-        if (i < n) sample(in[i], i);
-    if (act) { st->agc_gain = gain; st->nco_phase = nph; }
+};
+struct AgcDvbsTraits {                   // FastAGC only; result = scaled sample
+    typedef DvbsStreamWork Work;
+    typedef DvbsLoopCoefs Coefs;
+    struct Regs { float gain; };
+    static __device__ __forceinline__ const cf32* in_ptr(const Work& w) { return w.in; }
+    static __device__ __forceinline__ cf32* out_ptr(const Work& w) { return w.buf_a; }
+    static __device__ __forceinline__ Regs load(const Work& w) { return Regs{w.st->agc_gain}; }
+    static __device__ __forceinline__ void store(const Work& w, const Regs& r) { w.st->agc_gain = r.gain; }
+    static __device__ __forceinline__ cf32 step(Regs& r, cf32 x, const Coefs& co) {
+        const cf32 y = cscale(x, r.gain);
+        const float a = camp(y);
+        r.gain += (1.0f - a) * co.agc_rate;
+        r.gain = r.gain > 10e6f ? 10e6f : r.gain;
+        return y;
+    }
+};
+
+template <class TR>
+__global__ __launch_bounds__(128) void agc_pc_kernel(const typename TR::Work* __restrict__ work, int nstreams, typename TR::Coefs co) {
+    __shared__ cf32 buf[2][64][AG_T + 1];
+    __shared__ const cf32* s_in[64];
+    __shared__ cf32* s_out[64];
+    __shared__ int s_n[64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, s = blockIdx.x * 64 + lane;
+    const bool act = s < nstreams;
+    const typename TR::Work w = work[act ? s : 0];
+    const int n = act ? w.count : 0;
+    typename TR::Regs regs = TR::load(w);
+    if (wave == 0) { s_in[lane] = TR::in_ptr(w); s_out[lane] = TR::out_ptr(w); s_n[lane] = n; }
+    int nmax = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+    const int ntiles = (nmax + AG_T - 1) / AG_T;
+    __syncthreads();
+    // tile movers (wave 1): lanes 0..31 handle row 2q, lanes 32..63 row 2q+1; a row of a tile is 256 contiguous bytes
+    const int half = lane >> 5, col = lane & 31;
+    auto load_tile = [&](int t, cf32 (*B)[AG_T + 1]) {
+        cf32 v[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int row = 2 * q + half, idx = t * AG_T + col;
+            v[q] = idx < s_n[row] ? ldg(s_in[row] + idx) : cf32{0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < 32; ++q) B[2 * q + half][col] = v[q];
+    };
+    auto store_tile = [&](int t, cf32 (*B)[AG_T + 1]) {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int row = 2 * q + half, idx = t * AG_T + col;
+            if (idx < s_n[row]) stg(s_out[row] + idx, B[row][col]);
+        }
+    };
+    if (wave == 1 && ntiles > 0) load_tile(0, buf[0]);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        if (wave == 0) {
+            cf32(*B)[AG_T + 1] = buf[t & 1];
+            const int m = min(AG_T, n - t * AG_T);
+#pragma unroll 4
+            for (int i = 0; i < AG_T; ++i)
+                if (i < m) B[lane][i] = TR::step(regs, B[lane][i], co);
+        } else {
+            if (t >= 1) store_tile(t - 1, buf[(t - 1) & 1]);
+            if (t + 1 < ntiles) load_tile(t + 1, buf[(t + 1) & 1]);
+        }
+        __syncthreads();
+    }
+    if (wave == 1 && ntiles > 0) store_tile(ntiles - 1, buf[(ntiles - 1) & 1]);
+    if (wave == 0 && act) TR::store(w, regs);
 }
 
 #define DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)(v)), (ctrl), 0xf, 0xf, false))
@@ -668,30 +716,6 @@ __device__ __forceinline__ void pcl_wrap_pi(float& phase) {
     while (phase < -PI_F) phase += delta;
 }
 
-// LANE = STREAM: the AGC gain recurrence (as in s2_agc_nco_kernel); writes y = x*gain
-__global__ __launch_bounds__(64) void dvbs_agc_kernel(const DvbsStreamWork* __restrict__ work, int nstreams, DvbsLoopCoefs co) {
-    const int lane = threadIdx.x, s = blockIdx.x * 64 + lane;
-    const bool act = s < nstreams;
-    const DvbsStreamWork w = work[act ? s : 0];
-    const int n = act ? w.count : 0;
-    float gain = w.st->agc_gain;
-    const cf32* in = w.in;
-    cf32* out = w.buf_a;
-    int nmax = n;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
-    for (int i = 0; i < nmax; ++i) {
-        if (i < n) {
-            const cf32 y = cscale(in[i], gain);
-            out[i] = y;
-            const float a = camp(y);
-            gain += (1.0f - a) * co.agc_rate;
-            gain = gain > 10e6f ? 10e6f : gain;
-        }
-    }
-    if (act) w.st->agc_gain = gain;
-}
-
 // ONE WAVE PER STREAM.  loop::FLL::process (fll.cpp:135-149): every sample is rotated by the loop phase and fed to the two
 // band-edge FIRs whose amplitude difference steers the loop -- a feedback through two 65-tap complex dot products per sample.
 // The dot products run as a SYSTOLIC ARRAY over the lanes: lane k holds tap k and a running sum; each new sample x[m] adds
@@ -936,7 +960,7 @@ hipError_t s2_fifo_compact_launch(const S2StreamWork* d_work, int nstreams, cons
 }
 hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int max_count, DvbsLoopCoefs coefs, const cf32* d_bandedge,
                                 const float* d_rrc, const float* d_fd_bank, hipStream_t st) {
-    hipLaunchKernelGGL(dvbs_agc_kernel, dim3((nstreams + 63) / 64), dim3(64), 0, st, d_work, nstreams, coefs);
+    hipLaunchKernelGGL(agc_pc_kernel<AgcDvbsTraits>, dim3((nstreams + 63) / 64), dim3(128), 0, st, d_work, nstreams, coefs);
     hipLaunchKernelGGL(dvbs_fll_kernel, dim3(nstreams), dim3(64), 0, st, d_work, coefs, d_bandedge);
     int gx = (max_count + 255) / 256;
     gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
@@ -955,7 +979,7 @@ hipError_t dvbs_soft_compact_launch(const DvbsStreamWork* d_work, int nstreams, 
     return hipGetLastError();
 }
 hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCoefs coefs, const float* d_bank, hipStream_t st) {
-    hipLaunchKernelGGL(s2_agc_nco_kernel, dim3((nstreams + 63) / 64), dim3(64), 0, st, d_work, nstreams, coefs);
+    hipLaunchKernelGGL(agc_pc_kernel<AgcS2Traits>, dim3((nstreams + 63) / 64), dim3(128), 0, st, d_work, nstreams, coefs);
     hipLaunchKernelGGL(s2_gardner_kernel, dim3((nstreams + G_SPW - 1) / G_SPW), dim3(64), 0, st, d_work, nstreams, coefs, d_bank);
     return hipGetLastError();
 }

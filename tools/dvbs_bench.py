@@ -46,5 +46,38 @@ def main():
         vit.close()
 
 
+
+
+def demod_bench():
+    """whole DVB-S receive path (front end + slicer + Viterbi), BASELINE config D shape: rate 1/2 QPSK at 2 sps"""
+    import time
+    import torch
+    import __graft_entry__ as g
+    import orc_dvbs as od
+    pkg = g.load_package()
+    eng = pkg.Engine(0)
+    nsym = 65536
+    iq, _ = od.dvbs_iq(0, nsym, seed=1, esn0_db=12.0, cfo=1e-3, timing=0.3)
+    for S in (1, 64, 1024):
+        bank = pkg.DvbsDemodBank(eng, S, max_samples=iq.size)
+        tin = [torch.from_numpy(iq).cuda() for _ in range(S)]
+        tout = [torch.zeros(iq.size + 4 * 8192, dtype=torch.uint8, device='cuda') for _ in range(S)]
+        bank.process_batch(tin, tout)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            nb = bank.process_batch(tin, tout)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        st = bank.stats()[0]
+        print('DVB-S bank: %d streams x %d symbols per call: %.2f ms = %.2f Msym/s total, %.3f Msym/s per stream (lock %d rate %d ber %.3f, %d bits out)'
+              % (S, nsym, dt * 1e3, S * nsym / dt / 1e6, nsym / dt / 1e6, st.state, st.rate, st.ber, nb[0]))
+        bank.close()
+
+
 if __name__ == '__main__':
-    main()
+    if os.environ.get('DVBS_DEMOD_BENCH'):
+        demod_bench()
+    else:
+        main()
