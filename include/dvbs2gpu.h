@@ -156,6 +156,13 @@ int dvbs2gpu_demod_process(dvbs2gpu_demod* d, int count, const float* h_iq, uint
 int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const float* const* d_iq, const int* counts,
                                  uint8_t* const* d_out, int out_cap, int* out_bytes);
 
+/* Throughput mode for dvbs2gpu_demod_process_batch: with `on` != 0 the FEC (LDPC, BCH, descrambler) of call k runs on its own
+ * HIP stream while call k+1 runs the front end, PL sync and frame loops of the next samples; the BBFRAMEs (and stats) of call
+ * k are delivered by call k+1 into ITS output buffers (the reference delivers frames late as well: it holds them until 16 have
+ * queued, module_dvbs2_demod.cpp:343-347).  Needs the same streams in the same order on every call, all with one
+ * configuration.  A call with all counts 0 collects the last frames; switching the mode off drops uncollected ones. */
+int dvbs2gpu_set_pipelined(dvbs2gpu_ctx* ctx, int on);
+
 /* Stats of the frames completed by the last process call of this handle (the public fields the GUI polls,
  * module_dvbs2_demod.h:82-87, one record per frame). */
 typedef struct dvbs2gpu_frame_stats {

@@ -71,6 +71,7 @@ PROTOTYPES = {
     'dvbs2gpu_demod_get_kbch': (_i, [_vp]),
     'dvbs2gpu_demod_process': (_i, [_vp, _i, _vp, _vp, _i]),
     'dvbs2gpu_demod_process_batch': (_i, [C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), _i, C.POINTER(_i)]),
+    'dvbs2gpu_set_pipelined': (_i, [_vp, _i]),
     'dvbs2gpu_demod_get_stats': (_i, [_vp, C.POINTER(FrameStats), _i]),
     'dvbs2gpu_demod_get_nco_freq': (C.c_float, [_vp]),
     'dvbs2gpu_demod_get_tap': (_i, [_vp, _i, _vp, _i]),
@@ -232,6 +233,10 @@ class Engine:
         self._check(self.lib.dvbs2gpu_demap_batch(self.h, int(modcod), int(bool(shortframes)), int(bool(pilots)), _ptr(frames),
                                                   frames.shape[0], _ptr(llr), self._stream()))
         return llr
+
+    def set_pipelined(self, on):
+        """FEC of call k overlaps the front end of call k+1; BBFRAMEs are delivered one process_batch call later"""
+        self._check(self.lib.dvbs2gpu_set_pipelined(self.h, int(bool(on))))
 
     def default_cfg(self, modcod, shortframes=False, pilots=False, **kw):
         c = DemodCfg()

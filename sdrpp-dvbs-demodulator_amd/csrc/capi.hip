@@ -208,6 +208,9 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
     }
     if (ctx->d_prbs) (void)hipFree(ctx->d_prbs);
     ctx->ws_msg.release(); ctx->ws_hard.release(); ctx->ws_syn.release(); ctx->ws_misc.release();
+    if (ctx->fe_stream) (void)hipStreamDestroy(ctx->fe_stream);
+    if (ctx->fec_stream) (void)hipStreamDestroy(ctx->fec_stream);
+    if (ctx->ev_llr) (void)hipEventDestroy(ctx->ev_llr);
     delete ctx;
 }
 

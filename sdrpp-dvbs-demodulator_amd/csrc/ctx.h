@@ -71,6 +71,14 @@ struct dvbs2gpu_ctx {
     std::map<int, s2::ConstelTables> constel; // by modcod (gammas depend on it)
     std::map<int, float*> rrc;                // by ntaps*1000 + round(alpha*100) (Ts = 2)
     s2::Workspace ws_rx[8];
+    // pipelined FEC (s2_demod.hip): with pipeline_fec set, dvbs2gpu_demod_process_batch runs the FEC of call k on fec_stream
+    // while call k+1's front end runs on fe_stream; BBFRAMEs of call k are delivered by call k+1
+    int pipeline_fec = 0;
+    hipStream_t fe_stream = nullptr, fec_stream = nullptr;
+    hipEvent_t ev_llr = nullptr;
+    void* pending_fec = nullptr;              // s2::PendingFec*
+    s2::Workspace ws_fecbuf[2][3];            // per parity: LLRs | BBFRAMEs | frame refs + first[] + trials + corrections
+    int fec_parity = 0;
     // DVB-S front end (dvbs_demod.hip)
     float* d_fd_bank = nullptr;               // COMPLEX_FD interpolator bank, 256 x 256
     std::map<int, s2::cf32*> bandedge;        // FLL band-edge taps [2][ntaps] by ntaps*100000 + round(alpha*1000)*10 + sps

@@ -305,8 +305,22 @@ int demod_reset_state(dvbs2gpu_demod* d) {
 }
 
 // Runs one group of streams that share (modcod, shortframes, pilots) and loop coefficients.
+// FEC job launched by one pipelined call and delivered by the next
+struct PendingFec {
+    int n = 0, nf = 0, kb = 0;
+    std::vector<dvbs2gpu_demod*> dm;
+    std::vector<int> first;
+    std::vector<S2FrameStats> hstats;
+    std::vector<std::vector<float>> frame_bm;
+    const S2FrameRef* d_frames = nullptr;
+    const int* d_first = nullptr;
+    const uint8_t* d_bb = nullptr;
+    const int32_t* d_trials = nullptr;
+    const int32_t* d_corr = nullptr;
+};
+
 int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts,
-                  uint8_t* const* d_out, int out_cap, int* out_bytes, hipStream_t st) {
+                  uint8_t* const* d_out, int out_cap, int* out_bytes, hipStream_t st, bool pipelined) {
     dvbs2gpu_demod* d0 = dm[0];
     const ModcodParams& mp = d0->mp;
     const int raw = mp.plframe, kb = mp.fec.kbch / 8, N = mp.fec.N;
@@ -440,7 +454,19 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         int32_t* d_trials = (int32_t*)(d_stats + nf);
         int32_t* d_corr = d_trials + nf;
         int* d_first = (int*)((char*)ws_work.p + sizeof(S2StreamWork) * n);
-        Workspace &ws_pll = ctx->ws_rx[3], &ws_llr = ctx->ws_rx[4], &ws_bb = ctx->ws_rx[5];
+        const int par = ctx->fec_parity;
+        Workspace &ws_pll = ctx->ws_rx[3];
+        Workspace &ws_llr = pipelined ? ctx->ws_fecbuf[par][0] : ctx->ws_rx[4];
+        Workspace &ws_bb = pipelined ? ctx->ws_fecbuf[par][1] : ctx->ws_rx[5];
+        if (pipelined) {
+            // the FEC job keeps its own copy of the frame table and its result arrays (phase A of the next call reuses ws_rx[2])
+            Workspace& wj = ctx->ws_fecbuf[par][2];
+            if ((rc = wj.ensure(sizeof(S2FrameRef) * nf + sizeof(int) * (n + 1) + sizeof(int32_t) * 2 * nf + 64))) return rc;
+            d_trials = (int32_t*)((char*)wj.p + sizeof(S2FrameRef) * nf + sizeof(int) * (n + 1));
+            d_corr = d_trials + nf;
+            HIP_TRY(hipMemcpyAsync(wj.p, frames.data(), sizeof(S2FrameRef) * nf, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync((char*)wj.p + sizeof(S2FrameRef) * nf, first.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, st));
+        }
         if ((rc = ws_pll.ensure((size_t)nf * raw * sizeof(cf32)))) return rc;
         if ((rc = ws_llr.ensure((size_t)nf * N))) return rc;
         if ((rc = ws_bb.ensure((size_t)nf * kb))) return rc;
@@ -455,10 +481,14 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         const int force = d0->cfg.force_ldpc_iters > 0;
         const int mt = force ? d0->cfg.force_ldpc_iters : d0->cfg.max_ldpc_trials;
         // keep a copy of the demapper output for the tap before LDPC consumes it? LDPC does not modify d_llr.
-        if ((rc = fec_run(ctx, mp.fec, d_llr, nf, mt, force, d_bb, d_trials, d_corr, st))) return rc;
+        if (!pipelined) {
+            if ((rc = fec_run(ctx, mp.fec, d_llr, nf, mt, force, d_bb, d_trials, d_corr, st))) return rc;
+            HIP_TRY(hipMemcpyAsync(trials.data(), d_trials, sizeof(int32_t) * nf, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(corr.data(), d_corr, sizeof(int32_t) * nf, hipMemcpyDeviceToHost, st));
+        } else {
+            HIP_TRY(hipEventRecord(ctx->ev_llr, st));
+        }
         HIP_TRY(hipMemcpyAsync(hstats.data(), d_stats, sizeof(S2FrameStats) * nf, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(trials.data(), d_trials, sizeof(int32_t) * nf, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(corr.data(), d_corr, sizeof(int32_t) * nf, hipMemcpyDeviceToHost, st));
         for (int i = 0; i < n; ++i) {
             int cnt = first[i + 1] - first[i];
             dm[i]->tap_pll = d_pll + (size_t)first[i] * raw;
@@ -467,7 +497,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
             out_bytes[i] = bytes;
         }
-        HIP_TRY(s2_scatter_out_launch(d_work, d_frames, d_first, nf, kb, d_bb, st));
+        if (!pipelined) HIP_TRY(s2_scatter_out_launch(d_work, d_frames, d_first, nf, kb, d_bb, st));
     } else {
         for (int i = 0; i < n; ++i) { out_bytes[i] = 0; dm[i]->tap_pll = nullptr; dm[i]->tap_llr = nullptr; }
     }
@@ -485,13 +515,75 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         if (cur[i] > 0) { d->fifo_fill -= cur[i]; d->fifo_cur ^= 1; }
         d->nco_freq_host = nco[i];
     }
-    for (int i = 0; i < n; ++i) {
-        for (int f = first[i]; f < first[i + 1]; ++f) {
-            S2FrameStats s = hstats[f];
-            s.best_match = frame_bm[i][f - first[i]];
-            s.ldpc_trials = trials[f]; s.bch_corr = corr[f];
-            dm[i]->stats.push_back(s);
+    if (!pipelined) {
+        for (int i = 0; i < n; ++i) {
+            for (int f = first[i]; f < first[i + 1]; ++f) {
+                S2FrameStats s = hstats[f];
+                s.best_match = frame_bm[i][f - first[i]];
+                s.ldpc_trials = trials[f]; s.bch_corr = corr[f];
+                dm[i]->stats.push_back(s);
+            }
         }
+        return 0;
+    }
+    // ---- pipelined: deliver the previous call's FEC job into this call's output buffers, then start this call's job
+    hipStream_t sf = ctx->fec_stream;
+    PendingFec* prev = (PendingFec*)ctx->pending_fec;
+    ctx->pending_fec = nullptr;
+    std::unique_ptr<PendingFec> prev_guard(prev);
+    for (int i = 0; i < n; ++i) out_bytes[i] = 0;
+    if (prev) {
+        if (prev->n != n || memcmp(prev->dm.data(), dm, sizeof(dvbs2gpu_demod*) * n) != 0) {
+            HIP_TRY(hipStreamSynchronize(sf));
+            last_error() = "pipelined mode needs the same streams in the same order on every call";
+            return DVBS2GPU_ERR_ARG;
+        }
+        HIP_TRY(hipStreamSynchronize(sf));                 // FEC of the previous call (ran during this call's front end)
+        Workspace& wo = ctx->ws_rx[6];
+        if ((rc = wo.ensure(sizeof(uint8_t*) * n))) return rc;
+        HIP_TRY(hipMemcpyAsync(wo.p, d_out, sizeof(uint8_t*) * n, hipMemcpyHostToDevice, sf));
+        std::vector<int32_t> ptr(prev->nf), pco(prev->nf);
+        HIP_TRY(hipMemcpyAsync(ptr.data(), prev->d_trials, sizeof(int32_t) * prev->nf, hipMemcpyDeviceToHost, sf));
+        HIP_TRY(hipMemcpyAsync(pco.data(), prev->d_corr, sizeof(int32_t) * prev->nf, hipMemcpyDeviceToHost, sf));
+        for (int i = 0; i < n; ++i) {
+            int bytes = (prev->first[i + 1] - prev->first[i]) * prev->kb;
+            if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
+            out_bytes[i] = bytes;
+        }
+        HIP_TRY(s2_scatter_out2_launch((uint8_t* const*)wo.p, prev->d_frames, prev->d_first, prev->nf, prev->kb, prev->d_bb, sf));
+        HIP_TRY(hipStreamSynchronize(sf));
+        for (int i = 0; i < n; ++i) {
+            dm[i]->stats.clear();
+            for (int f = prev->first[i]; f < prev->first[i + 1]; ++f) {
+                S2FrameStats s = prev->hstats[f];
+                s.best_match = prev->frame_bm[i][f - prev->first[i]];
+                s.ldpc_trials = ptr[f]; s.bch_corr = pco[f];
+                dm[i]->stats.push_back(s);
+            }
+        }
+    } else {
+        for (int i = 0; i < n; ++i) dm[i]->stats.clear();
+    }
+    if (nf > 0) {
+        const int par = ctx->fec_parity;
+        Workspace& wj = ctx->ws_fecbuf[par][2];
+        S2FrameRef* j_frames = (S2FrameRef*)wj.p;
+        int* j_first = (int*)((char*)wj.p + sizeof(S2FrameRef) * nf);
+        int32_t* j_trials = (int32_t*)((char*)wj.p + sizeof(S2FrameRef) * nf + sizeof(int) * (n + 1));
+        int32_t* j_corr = j_trials + nf;
+        auto job = std::make_unique<PendingFec>();
+        job->n = n; job->nf = nf; job->kb = kb;
+        job->dm.assign(dm, dm + n);
+        job->first = first; job->hstats = hstats; job->frame_bm = frame_bm;
+        job->d_frames = j_frames; job->d_first = j_first; job->d_bb = (const uint8_t*)ctx->ws_fecbuf[par][1].p;
+        job->d_trials = j_trials; job->d_corr = j_corr;
+        HIP_TRY(hipStreamWaitEvent(sf, ctx->ev_llr, 0));
+        const int force = d0->cfg.force_ldpc_iters > 0;
+        const int mt = force ? d0->cfg.force_ldpc_iters : d0->cfg.max_ldpc_trials;
+        if ((rc = fec_run(ctx, mp.fec, (const int8_t*)ctx->ws_fecbuf[par][0].p, nf, mt, force, (uint8_t*)ctx->ws_fecbuf[par][1].p, j_trials, j_corr, sf)))
+            return rc;
+        ctx->pending_fec = job.release();
+        ctx->fec_parity ^= 1;
     }
     return 0;
 }
@@ -559,6 +651,24 @@ int dvbs2gpu_demod_set_params(dvbs2gpu_demod* d, int modcod, int shortframes, in
 
 int dvbs2gpu_demod_get_kbch(dvbs2gpu_demod* d) { return d ? d->mp.fec.kbch : DVBS2GPU_ERR_ARG; }
 
+int dvbs2gpu_set_pipelined(dvbs2gpu_ctx* ctx, int on) {
+    if (!ctx) return DVBS2GPU_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (on && !ctx->fe_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->fe_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->fec_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_llr, hipEventDisableTiming));
+    }
+    if (!on && ctx->pending_fec) {
+        // frames of the last pipelined call that nobody collected are dropped (collect them with a zero-count call first)
+        HIP_TRY(hipStreamSynchronize(ctx->fec_stream));
+        delete (PendingFec*)ctx->pending_fec;
+        ctx->pending_fec = nullptr;
+    }
+    ctx->pipeline_fec = on ? 1 : 0;
+    return 0;
+}
+
 int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const float* const* d_iq, const int* counts,
                                  uint8_t* const* d_out, int out_cap, int* out_bytes) {
     if (!demods || n <= 0 || !d_iq || !counts || !d_out || !out_bytes) return DVBS2GPU_ERR_ARG;
@@ -579,7 +689,9 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
         std::vector<int> gc, gb(idx.size());
         std::vector<uint8_t*> go;
         for (int k : idx) { g.push_back(demods[k]); gi.push_back((const cf32*)d_iq[k]); gc.push_back(counts[k]); go.push_back(d_out[k]); }
-        int rc = process_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), nullptr);
+        const bool pipe = ctx->pipeline_fec && (int)idx.size() == n;   // pipelining needs the whole batch to be one configuration group
+        if (ctx->pipeline_fec && !pipe) { last_error() = "pipelined mode needs all streams of the batch to share one configuration"; return DVBS2GPU_ERR_ARG; }
+        int rc = process_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), pipe ? ctx->fe_stream : nullptr, pipe);
         if (rc) return rc;
         for (size_t k = 0; k < idx.size(); ++k) out_bytes[idx[k]] = gb[k];
     }
@@ -601,7 +713,7 @@ int dvbs2gpu_demod_process(dvbs2gpu_demod* d, int count, const float* h_iq, uint
     int bytes = 0;
     int cap = (d->fifo_cap / d->mp.plframe + 2) * (d->mp.fec.kbch / 8);
     dvbs2gpu_demod* dd = d;
-    int rc = process_group(d->ctx, &dd, 1, &in, &count, &dout, cap, &bytes, nullptr);
+    int rc = process_group(d->ctx, &dd, 1, &in, &count, &dout, cap, &bytes, nullptr, false);
     if (rc) return rc;
     if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
     if (bytes) HIP_TRY(hipMemcpy(h_out, d->d_out, bytes, hipMemcpyDeviceToHost));

@@ -134,6 +134,8 @@ hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const
 hipError_t s2_collect_launch(const S2StreamWork* d_work, int nstreams, int* d_nsym, float* d_nco, hipStream_t st);
 hipError_t s2_scatter_out_launch(const S2StreamWork* d_work, const S2FrameRef* d_frames, const int* d_first, int nframes, int kb,
                                  const uint8_t* d_bb, hipStream_t st);
+hipError_t s2_scatter_out2_launch(uint8_t* const* d_outs, const S2FrameRef* d_frames, const int* d_first, int nframes, int kb,
+                                  const uint8_t* d_bb, hipStream_t st);
 hipError_t s2_fifo_compact_launch(const S2StreamWork* d_work, int nstreams, const int* d_cur_fill /*[2*nstreams]: cur, fill*/, hipStream_t st);
 hipError_t s2_demap_launch(S2ConstelDev con, int rate, int shortframe, int slots, int pilots, int plframe, const cf32* d_pllout,
                            int nframes, int8_t* d_llr, int N, hipStream_t st);

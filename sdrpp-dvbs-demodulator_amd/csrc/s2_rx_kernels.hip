@@ -119,7 +119,7 @@ __device__ __forceinline__ size_t fe_scratch_offset(int n) { return (size_t)n + 
 // overwrites the input slot); wave 1 moves the tiles: coalesced row loads of the next tile, coalesced row stores of the
 // previous one, double-buffered.  The compute wave never issues a global access, so no memory latency and no store drain
 // (loads and stores share one counter on this hardware) ever enters the serial chain.
-constexpr int AG_T = 32;                 // samples per stream per tile
+constexpr int AG_T = 16;                 // samples per stream per tile (17 KB of LDS: fits beside a resident LDPC workgroup)
 struct AgcS2Traits {                     // FastAGC gain + FreqShift phase recurrences; result = (gain, phase) per sample
     typedef S2StreamWork Work;
     typedef S2LoopCoefs Coefs;
@@ -176,22 +176,24 @@ __global__ __launch_bounds__(128) void agc_pc_kernel(const typename TR::Work* __
     for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
     const int ntiles = (nmax + AG_T - 1) / AG_T;
     __syncthreads();
-    // tile movers (wave 1): lanes 0..31 handle row 2q, lanes 32..63 row 2q+1; a row of a tile is 256 contiguous bytes
-    const int half = lane >> 5, col = lane & 31;
+    // tile movers (wave 1): each instruction moves 64/AG_T rows of a tile, AG_T*8 contiguous bytes per row
+    const int half = lane / AG_T, col = lane % AG_T;
+    constexpr int RPI = 64 / AG_T;        // rows per load/store instruction
+    constexpr int NQ = 64 / RPI;          // instructions per tile
     auto load_tile = [&](int t, cf32 (*B)[AG_T + 1]) {
-        cf32 v[32];
+        cf32 v[NQ];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const int row = 2 * q + half, idx = t * AG_T + col;
+        for (int q = 0; q < NQ; ++q) {
+            const int row = RPI * q + half, idx = t * AG_T + col;
             v[q] = idx < s_n[row] ? ldg(s_in[row] + idx) : cf32{0.f, 0.f};
         }
 #pragma unroll
-        for (int q = 0; q < 32; ++q) B[2 * q + half][col] = v[q];
+        for (int q = 0; q < NQ; ++q) B[RPI * q + half][col] = v[q];
     };
     auto store_tile = [&](int t, cf32 (*B)[AG_T + 1]) {
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const int row = 2 * q + half, idx = t * AG_T + col;
+        for (int q = 0; q < NQ; ++q) {
+            const int row = RPI * q + half, idx = t * AG_T + col;
             if (idx < s_n[row]) stg(s_out[row] + idx, B[row][col]);
         }
     };
@@ -496,7 +498,8 @@ __device__ void soft_calc_dev(const S2ConstelDev& C, cf32 sample, int8_t* bits_o
 constexpr int FL_LPS = 16;
 constexpr int FL_SPW = 64 / FL_LPS;
 
-__global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* __restrict__ work, int nstreams,
+// (at most 128 VGPRs: must fit on a SIMD beside three resident LDPC waves when the FEC of the previous call overlaps, s2_demod.hip)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void s2_frame_loops_kernel(const S2StreamWork* __restrict__ work, int nstreams,
                                                             const S2FrameRef* __restrict__ frames, const int* __restrict__ first,
                                                             S2LoopCoefs co, S2PlTablesDev T, S2ConstelDev C, int pls_code, int slots,
                                                             int pilots, int pilot_blocks, int plframe, cf32* __restrict__ pllout,
@@ -690,6 +693,15 @@ __global__ __launch_bounds__(256) void s2_scatter_out_kernel(const S2StreamWork*
     const int f = blockIdx.x;
     const int s = frames[f].stream;
     uint8_t* __restrict__ dst = work[s].out + (size_t)(f - first[s]) * kb;
+    const uint8_t* __restrict__ src = bb + (size_t)f * kb;
+    for (int i = threadIdx.x; i < kb; i += 256) dst[i] = src[i];
+}
+// pipelined delivery: the BBFRAMEs of the PREVIOUS call go to the output buffers of the current one
+__global__ __launch_bounds__(256) void s2_scatter_out2_kernel(uint8_t* const* __restrict__ outs, const S2FrameRef* __restrict__ frames,
+                                                              const int* __restrict__ first, int kb, const uint8_t* __restrict__ bb) {
+    const int f = blockIdx.x;
+    const int s = frames[f].stream;
+    uint8_t* __restrict__ dst = outs[s] + (size_t)(f - first[s]) * kb;
     const uint8_t* __restrict__ src = bb + (size_t)f * kb;
     for (int i = threadIdx.x; i < kb; i += 256) dst[i] = src[i];
 }
@@ -952,6 +964,11 @@ hipError_t s2_collect_launch(const S2StreamWork* d_work, int nstreams, int* d_ns
 hipError_t s2_scatter_out_launch(const S2StreamWork* d_work, const S2FrameRef* d_frames, const int* d_first, int nframes, int kb,
                                  const uint8_t* d_bb, hipStream_t st) {
     hipLaunchKernelGGL(s2_scatter_out_kernel, dim3(nframes), dim3(256), 0, st, d_work, d_frames, d_first, kb, d_bb);
+    return hipGetLastError();
+}
+hipError_t s2_scatter_out2_launch(uint8_t* const* d_outs, const S2FrameRef* d_frames, const int* d_first, int nframes, int kb,
+                                  const uint8_t* d_bb, hipStream_t st) {
+    hipLaunchKernelGGL(s2_scatter_out2_kernel, dim3(nframes), dim3(256), 0, st, d_outs, d_frames, d_first, kb, d_bb);
     return hipGetLastError();
 }
 hipError_t s2_fifo_compact_launch(const S2StreamWork* d_work, int nstreams, const int* d_cur_fill, hipStream_t st) {

@@ -212,3 +212,50 @@ def test_demod_error_codes(engine, pkg):
     c = engine.default_cfg(11, True)     # short-frame 9/10 does not exist
     with pytest.raises(pkg.Dvbs2GpuError):
         engine.demod(c)
+
+
+def test_pipelined_batch_delivers_the_same_frames_one_call_later(engine, pkg):
+    """throughput mode (dvbs2gpu_set_pipelined): FEC of call k overlaps call k+1; outputs and stats are those of the
+    synchronous mode, shifted by one call; a zero-sample call collects the tail"""
+    import torch
+    S, calls = 6, 5
+    cfgkw = dict(modcod=11, short=0, pilots=0)
+    iqs = []
+    for s in range(S):
+        iq, bb, _ = orc.transmit(11, 0, 0, nframes=calls, seed=900 + s, esn0_db=12.0, cfo=1e-3, timing=0.25, phase0=0.3)
+        iqs.append(iq)
+    info = pkg.modcod_info(11, False, False)
+    kb = info['kbch'] // 8
+    chunk = iqs[0].size // calls
+    cfg = engine.default_cfg(11, False, False)
+
+    def run(pipelined):
+        demods = [engine.demod(cfg, max_samples=chunk) for _ in range(S)]
+        tout = [torch.zeros(4 * kb, dtype=torch.uint8, device='cuda') for _ in range(S)]
+        engine.set_pipelined(pipelined)
+        outs = []
+        try:
+            for c in range(calls + (1 if pipelined else 0)):
+                if c < calls:
+                    tin = [torch.from_numpy(iqs[s][c * chunk:(c + 1) * chunk]).cuda() for s in range(S)]
+                else:
+                    tin = [torch.empty(0, dtype=torch.complex64, device='cuda') for _ in range(S)]
+                nb = engine.process_batch(demods, tin, tout)
+                outs.append(([tout[s][:nb[s]].cpu().numpy().copy() for s in range(S)],
+                             [[(x.ldpc_trials, x.bch_corrections, x.detected_modcod) for x in d.stats()] for d in demods]))
+        finally:
+            engine.set_pipelined(False)
+            for d in demods:
+                d.close()
+        return outs
+
+    sync = run(False)
+    pipe = run(True)
+    assert all(len(x) == 0 for x in pipe[0][0])                     # nothing can be ready in the first call
+    total = 0
+    for c in range(calls):
+        for s in range(S):
+            assert np.array_equal(pipe[c + 1][0][s], sync[c][0][s]), (c, s)
+            assert pipe[c + 1][1][s] == sync[c][1][s], (c, s)
+            total += len(sync[c][0][s])
+    assert total >= S * (calls - 2) * kb
