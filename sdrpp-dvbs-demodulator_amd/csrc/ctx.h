@@ -53,6 +53,7 @@ struct ConstelTables {          // device tables of one constellation (type, gam
     S2ConstelDev dev;
     int8_t* d_bits = nullptr;
     float* d_err = nullptr;
+    cf32* d_pts = nullptr;
 };
 
 }  // namespace s2

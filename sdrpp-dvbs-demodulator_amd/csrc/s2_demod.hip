@@ -199,6 +199,12 @@ int get_constel(dvbs2gpu_ctx* ctx, const ModcodParams& mp, ConstelTables** out) 
         T.dev.constel = H.constel; T.dev.bits = H.bits; T.dev.states = H.states;
         T.dev.amp = H.amp; T.dev.sca = H.sca; T.dev.prescale = H.prescale;
         for (int i = 0; i < 32; ++i) T.dev.pts[i] = i < H.states ? H.pts[i] : cf32{0, 0};
+        {
+            std::vector<cf32> pv(T.dev.pts, T.dev.pts + 32);
+            int rcp = upload(pv, &T.d_pts);
+            if (rcp) return rcp;
+            T.dev.pts_g = T.d_pts;
+        }
         T.dev.lut_bits = nullptr; T.dev.lut_err = nullptr;
         if (H.bits != 5) {   // make_lut(256), constellation.cpp:272-291 -- built with the host libm, uploaded
             std::vector<int8_t> lb((size_t)65536 * H.bits);

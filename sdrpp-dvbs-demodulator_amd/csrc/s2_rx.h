@@ -71,6 +71,7 @@ struct S2ConstelDev {
     const int8_t* lut_bits;    // [256][256][bits]   (null for 32APSK)
     const float* lut_err;      // [256][256]
     cf32 pts[32];
+    const cf32* pts_g;         // the same points in global memory
 };
 
 struct S2PlTablesDev {

@@ -199,6 +199,9 @@ __global__ __launch_bounds__(128) void agc_pc_kernel(const typename TR::Work* __
     };
     if (wave == 1 && ntiles > 0) load_tile(0, buf[0]);
     __syncthreads();
+    // the serial chains are latency-critical and issue little: win the issue arbitration against throughput kernels (the LDPC
+    // decoder of the previous call shares the SIMDs in the pipelined mode)
+    if (wave == 0) __builtin_amdgcn_s_setprio(3);
     for (int t = 0; t < ntiles; ++t) {
         if (wave == 0) {
             cf32(*B)[AG_T + 1] = buf[t & 1];
@@ -270,6 +273,7 @@ __global__ __launch_bounds__(64) void s2_gardner_kernel(const S2StreamWork* __re
     };
     issue(0);
     __syncthreads();
+    __builtin_amdgcn_s_setprio(3);       // latency-critical serial loop (see agc_pc_kernel)
     for (int base = 0; base < nmax; base += G_TILE) {
         commit(base);
         __syncthreads();
@@ -488,6 +492,22 @@ __device__ void soft_calc_dev(const S2ConstelDev& C, cf32 sample, int8_t* bits_o
     if (phase_err) *phase_err = cphase(cmul(sample, cconj(closest)));
 }
 
+// Phase error only, for the PLL of the frame loops, NOT inlined and fed with scalars + a global-memory copy of the points: the
+// 32APSK path would otherwise set the register budget of the serial frame-loop kernel, which must stay under 128 VGPRs to share
+// a SIMD with three resident LDPC waves in the pipelined mode (s2_demod.hip).
+__device__ __attribute__((noinline)) float soft_phase_err_noinline(const cf32* __restrict__ pts, int states, float amp, float prescale, cf32 sample) {
+    if (amp != 1) sample = cscale(sample, amp);
+    if (prescale != 1) sample = cscale(sample, prescale);
+    float min_dist = 3.402823466e+38f;
+    cf32 closest{0.f, 0.f};
+    for (int i = 0; i < states; i++) {
+        const cf32 p = pts[i];
+        float dist = camp(csub(sample, p));
+        if (dist < min_dist) { min_dist = dist; closest = p; }
+    }
+    return cphase(cmul(sample, cconj(closest)));
+}
+
 // ONE WAVE PER STREAM (see the front end): the PLL / PLHDR phase recurrences are serial per symbol and run as
 // uniform code; lanes do the coalesced symbol loads/stores, the FED terms and the PLSC codeword search.
 // SIXTEEN LANES PER STREAM, 4 streams per wave.  The FED / PLL / PLHDR recurrences are serial per stream and the phase-error
@@ -498,8 +518,7 @@ __device__ void soft_calc_dev(const S2ConstelDev& C, cf32 sample, int8_t* bits_o
 constexpr int FL_LPS = 16;
 constexpr int FL_SPW = 64 / FL_LPS;
 
-// (at most 128 VGPRs: must fit on a SIMD beside three resident LDPC waves when the FEC of the previous call overlaps, s2_demod.hip)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void s2_frame_loops_kernel(const S2StreamWork* __restrict__ work, int nstreams,
+__global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* __restrict__ work, int nstreams,
                                                             const S2FrameRef* __restrict__ frames, const int* __restrict__ first,
                                                             S2LoopCoefs co, S2PlTablesDev T, S2ConstelDev C, int pls_code, int slots,
                                                             int pilots, int pilot_blocks, int plframe, cf32* __restrict__ pllout,
@@ -520,6 +539,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void s2_f
     const float PI_F = 3.14159265358979323846f;
     const cf32* __restrict__ plsc = T.plsc + (size_t)pls_code * 64;
     const int f0 = first[sc], nf = act ? first[sc + 1] - f0 : 0;
+    __builtin_amdgcn_s_setprio(3);       // latency-critical serial loops (see agc_pc_kernel)
     int nfmax = nf;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nfmax = max(nfmax, __shfl_xor(nfmax, o));
@@ -583,7 +603,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void s2_f
                     bool is_pilot = next_pilot >= 0 && i >= next_pilot && i < next_pilot + 36;
                     if (!is_pilot) {
                         if (C.bits != 5) error = C.lut_err[lut_index(tmp_val.re) * 256 + lut_index(tmp_val.im)];
-                        else soft_calc_dev(C, tmp_val, nullptr, &error);
+                        else error = soft_phase_err_noinline(C.pts_g, C.states, C.amp, C.prescale, tmp_val);
                     } else {
                         error = cphase(cmul(descr, cf32{0.707f, -0.707f}));
                         if (i == next_pilot + 35) { ++pb; next_pilot = pb < pilot_blocks ? pilot_start(pb) : -1; }
