@@ -141,7 +141,7 @@ static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, 
     int grid = ctx->num_cus * C->blocks_per_cu;
     if (grid > (nframes + 1) / 2) grid = (nframes + 1) / 2;
     size_t need = (size_t)grid * 2 * C->R * C->rec_dwords * sizeof(uint32_t);
-    if ((rc = ctx->ws_msg.ensure(need))) return rc;
+    if ((rc = ctx->ws_msg.ensure(need + 256))) return rc;   // + the dynamic work counter
     if (!d_trials) {
         if ((rc = ctx->ws_misc.ensure((size_t)nframes * 2 * sizeof(int32_t)))) return rc;
         d_trials = (int32_t*)ctx->ws_misc.p;
@@ -151,7 +151,7 @@ static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, 
         d_hard = (uint8_t*)ctx->ws_hard.p; hard_stride = f.K / 8;
     }
     HIP_TRY(ldpc_decode_launch(*C, d_llr, nframes, max_trials, force, d_hard, hard_stride, d_post, d_trials,
-                               (uint32_t*)ctx->ws_msg.p, grid, st));
+                               (uint32_t*)ctx->ws_msg.p, grid, st, (unsigned int*)((char*)ctx->ws_msg.p + need)));
     return 0;
 }
 }  // namespace s2

@@ -37,6 +37,8 @@ struct LdpcKernelArgs {
     int pent_base;         // offset of the pair-format link table inside ents[] (ldpc_plan.h)
     int max_trials, force;
     int hard_stride;
+    unsigned int* work_ctr;     // optional: frames beyond the first gridDim.x*2 are claimed dynamically (workgroups slowed by
+                                // co-resident kernels of the pipelined mode then simply take fewer frames)
     unsigned long long* prof;   // development aid (-DLDPC_PROF builds only): per-wave phase cycle sums of workgroup 0
 };
 
@@ -441,7 +443,9 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS, 3) void ldpc_decode_kernel(con
     uint32_t* __restrict__ cw = s_cw[fs];
     uint8_t* __restrict__ cres = s_cres[fs];
 
-    for (int f0 = blockIdx.x * LDPC_FPB; f0 < A.nframes; f0 += gridDim.x * LDPC_FPB) {
+    __shared__ int s_next;
+    int f0 = blockIdx.x * LDPC_FPB;
+    while (f0 < A.nframes) {
         const int f = f0 + fs;
         const bool valid = f < A.nframes;
         const bool lane_ok = (j < 360) && valid;
@@ -539,6 +543,13 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS, 3) void ldpc_decode_kernel(con
                 }
             }
         }
+        if (A.work_ctr) {
+            if (threadIdx.x == 0) s_next = (int)(gridDim.x * LDPC_FPB + atomicAdd(A.work_ctr, (unsigned int)LDPC_FPB));
+            lds_barrier();
+            f0 = s_next;
+        } else {
+            f0 += gridDim.x * LDPC_FPB;
+        }
         lds_barrier();
     }
 }
@@ -599,8 +610,13 @@ unsigned long long* g_ldpc_prof = nullptr;   // set by tools/ldpc_prof.py throug
 
 hipError_t ldpc_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nframes, int max_trials, int force,
                               uint8_t* hard, int hard_stride, int8_t* post, int32_t* trials, uint32_t* msg_ws, int grid,
-                              hipStream_t stream) {
+                              hipStream_t stream, unsigned int* work_ctr) {
     LdpcKernelArgs A;
+    A.work_ctr = work_ctr;
+    if (work_ctr) {
+        hipError_t e = hipMemsetAsync(work_ctr, 0, sizeof(unsigned int), stream);
+        if (e != hipSuccess) return e;
+    }
     A.llr = llr; A.hard = hard; A.post = post; A.trials = trials; A.msg_ws = msg_ws;
     A.nframes = nframes; A.N = C.N; A.K = C.K; A.R = C.R; A.q = C.q; A.pent_base = C.pent_base;
     A.max_trials = max_trials; A.force = force; A.hard_stride = hard_stride;

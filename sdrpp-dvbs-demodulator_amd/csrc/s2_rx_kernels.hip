@@ -510,23 +510,27 @@ __device__ __attribute__((noinline)) float soft_phase_err_noinline(const cf32* _
 
 // ONE WAVE PER STREAM (see the front end): the PLL / PLHDR phase recurrences are serial per symbol and run as
 // uniform code; lanes do the coalesced symbol loads/stores, the FED terms and the PLSC codeword search.
-// SIXTEEN LANES PER STREAM, 4 streams per wave.  The FED / PLL / PLHDR recurrences are serial per stream and the phase-error
+// EIGHT LANES PER STREAM, 8 streams per wave.  The FED / PLL / PLHDR recurrences are serial per stream and the phase-error
 // LUT lookup sits in the PLL's chain, so a stream is latency-bound whatever the lane count; the first version (one wave per
-// stream, 64 lanes running the same chain) was issue-bound with 4 waves per SIMD instead.  A 16-lane row is also the natural
-// DPP unit: the PLSC codeword search reduces inside it with row rotations.  Groups whose stream has fewer frames in this call
-// shadow a frame of another group (same code path, nothing stored, state restored afterwards).
-constexpr int FL_LPS = 16;
+// stream, 64 lanes running the same chain) was issue-bound with 4 waves per SIMD instead, and every redundant lane group also
+// takes issue slots from the LDPC decoder that shares the SIMDs in the pipelined mode (16 lanes per stream: 28 ms beside it,
+// LDPC 74 ms).  Groups whose stream has fewer frames in this call shadow a frame of another group (same code path, nothing
+// stored, state restored afterwards).
+constexpr int FL_LPS = 8;
 constexpr int FL_SPW = 64 / FL_LPS;
+constexpr int FL_TILE = 44;          // PLL symbols staged per round (>= 36: the FED reuses the tile for a pilot block, and
+                                     // 44 complex = the 88 FED terms that alias the output tile); small: the
+                                     // workgroup has to fit into the LDS an LDPC workgroup leaves free (pipelined mode)
 
 __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* __restrict__ work, int nstreams,
                                                             const S2FrameRef* __restrict__ frames, const int* __restrict__ first,
                                                             S2LoopCoefs co, S2PlTablesDev T, S2ConstelDev C, int pls_code, int slots,
                                                             int pilots, int pilot_blocks, int plframe, cf32* __restrict__ pllout,
                                                             S2FrameStats* __restrict__ stats) {
-    __shared__ cf32 tile[FL_SPW][64];
-    __shared__ cf32 otile[FL_SPW][64];
-    __shared__ uint8_t rnt[64];
-    __shared__ float fedt[FL_SPW][96];
+    __shared__ cf32 tile[FL_SPW][FL_TILE];      // (also holds a 36-symbol pilot block for the FED)
+    __shared__ cf32 otile[FL_SPW][FL_TILE];
+    __shared__ uint8_t rnt[FL_TILE];
+    float (*fedt)[2 * FL_TILE] = reinterpret_cast<float (*)[2 * FL_TILE]>(otile);   // FED terms live in the (then unused) output tile
     __shared__ cf32 hdr_sym[FL_SPW][90];
     const int lane = threadIdx.x, g = lane / FL_LPS, gl = lane % FL_LPS;
     const int s0 = blockIdx.x * FL_SPW, s = s0 + g;
@@ -584,8 +588,8 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
         if (nco_freq < -0.3f * PI_F) nco_freq = -0.3f * PI_F;
         // ---- PLL (dvbs2_pll.cpp:34-86), 64-symbol tiles
         int next_pilot = (pilots && pilot_blocks > 0) ? pilot_start(0) : -1, pb = 0;
-        for (int base = 0; base < plframe; base += 64) {
-            const int m = min(64, plframe - base);
+        for (int base = 0; base < plframe; base += FL_TILE) {
+            const int m = min(FL_TILE, plframe - base);
             __syncthreads();
             for (int i = gl; i < m; i += FL_LPS) tile[g][i] = fr[base + i];
             if (lane < m) {
@@ -648,10 +652,8 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
             int dd = __popcll((T.plsc_code[c] ^ plheader) & ((1ull << 60) - 1));
             key = min(key, dd * 128 + c);
         }
-        key = min(key, __builtin_amdgcn_update_dpp(key, key, 0x121, 0xf, 0xf, false));   // row_ror 1, 2, 4, 8: all-reduce in the row
-        key = min(key, __builtin_amdgcn_update_dpp(key, key, 0x122, 0xf, 0xf, false));
-        key = min(key, __builtin_amdgcn_update_dpp(key, key, 0x124, 0xf, 0xf, false));
-        key = min(key, __builtin_amdgcn_update_dpp(key, key, 0x128, 0xf, 0xf, false));
+#pragma unroll
+        for (int o = FL_LPS / 2; o > 0; o >>= 1) key = min(key, __shfl_xor(key, o));      // all-reduce inside the lane group
         if (gl == 0 && fact) {
             const int best = key & 127;
             S2FrameStats stt;
