@@ -33,6 +33,9 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 MODCOD = 14          # 8PSK 3/4
 RATE, SHORT = 6, 0
+WORKLOAD = ('DVB-S2 8PSK 3/4 normal FECFRAME (MODCOD 14), pilots off, 27.5 Msym/s-class streams at 2 sps, '
+            'Es/N0 14 dB, 50 forced LDPC iterations, IQ in -> BBFRAMEs out')
+PILOTS = 0           # (tools/config_sweep.py re-runs main() with other MODCOD / RATE / SHORT / PILOTS / ESN0_DB values)
 ITERS = 50
 ESN0_DB = 14.0
 HBM_PEAK_GBS = 8000.0
@@ -49,15 +52,15 @@ def make_blocks(frames, seed, eng=None, pkg=None):
     cands = []
     ncand = 3 * DISTINCT
     for b in range(ncand):
-        iq, bb, _ = orc.transmit(MODCOD, 0, 0, nframes=frames, seed=0xD5B2 + 64 * seed + b, esn0_db=ESN0_DB, cfo=0.0, timing=0.3,
+        iq, bb, _ = orc.transmit(MODCOD, SHORT, PILOTS, nframes=frames, seed=0xD5B2 + 64 * seed + b, esn0_db=ESN0_DB, cfo=0.0, timing=0.3,
                                  phase0=0.1, lead_symbols=0, circular=1)
         cands.append((iq, {bytes(x) for x in bb}))
     if eng is None:
         return [c[0] for c in cands[:DISTINCT]], [c[1] for c in cands[:DISTINCT]]
     import torch
-    info = pkg.modcod_info(MODCOD, False, False)
+    info = pkg.modcod_info(MODCOD, bool(SHORT), bool(PILOTS))
     kb = info['kbch'] // 8
-    cfg = eng.default_cfg(MODCOD, False, False, force_ldpc_iters=0)
+    cfg = eng.default_cfg(MODCOD, bool(SHORT), bool(PILOTS), force_ldpc_iters=0)
     demods = [eng.demod(cfg, max_samples=cands[0][0].size) for _ in range(ncand)]
     tin = [torch.from_numpy(c[0]).cuda() for c in cands]
     tout = [torch.zeros((frames + 2) * kb, dtype=torch.uint8, device='cuda') for _ in range(ncand)]
@@ -84,7 +87,7 @@ def cpu_baseline(frames_block, budget_s=10.0):
     per-symbol times add."""
     import orc
     p = orc.fec_params(RATE, SHORT)
-    sym_per_frame = 21690
+    sym_per_frame = orc.modcod_params(MODCOD, SHORT, PILOTS)['plframe']
     ncores = os.cpu_count() or 1
     R = orc.ref()
     rng = np.random.default_rng(1)
@@ -130,7 +133,7 @@ def cpu_baseline(frames_block, budget_s=10.0):
     fec_frames_per_s = nfec / tfec
     # ---- front-end leg (oracle; FEC skipped with force_ldpc_iters = -1)
     blk = frames_block[0]
-    rxs = [orc.OracleRx(orc.default_cfg(MODCOD, 0, 0, force_ldpc_iters=-1)) for _ in range(ncores)]
+    rxs = [orc.OracleRx(orc.default_cfg(MODCOD, SHORT, PILOTS, force_ldpc_iters=-1)) for _ in range(ncores)]
 
     def fe(i):
         rxs[i].process(blk)
@@ -187,14 +190,14 @@ def main():
     dev = torch.device('cuda', local_rank)
     eng = pkg.Engine(local_rank)
 
-    info = pkg.modcod_info(MODCOD, False, False)
+    info = pkg.modcod_info(MODCOD, bool(SHORT), bool(PILOTS))
     sym = info['plframe_symbols']
     kb = info['kbch'] // 8
     S, F = args.streams, args.frames
     blocks, sent = make_blocks(F, seed=rank, eng=eng, pkg=pkg)
     d_blocks = [torch.from_numpy(b).to(dev) for b in blocks]
     nsamp = blocks[0].size
-    cfg = eng.default_cfg(MODCOD, False, False, force_ldpc_iters=ITERS)
+    cfg = eng.default_cfg(MODCOD, bool(SHORT), bool(PILOTS), force_ldpc_iters=ITERS)
     demods = [eng.demod(cfg, max_samples=nsamp) for _ in range(S)]
     tin = [d_blocks[s % DISTINCT] for s in range(S)]
     tout = [torch.zeros((F + 2) * kb, dtype=torch.uint8, device=dev) for _ in range(S)]
@@ -254,7 +257,7 @@ def main():
     tri = torch.empty((nfr,), dtype=torch.int32, device=dev)
 
     def ldpc_only():
-        eng.lib.dvbs2gpu_ldpc_decode_batch(eng.h, RATE, 0, llr.data_ptr(), nfr, ITERS, 1, hard.data_ptr(), None, tri.data_ptr(), eng._stream())
+        eng.lib.dvbs2gpu_ldpc_decode_batch(eng.h, RATE, SHORT, llr.data_ptr(), nfr, ITERS, 1, hard.data_ptr(), None, tri.data_ptr(), eng._stream())
     ldpc_only()
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True)
@@ -268,7 +271,7 @@ def main():
     k_ms = e0.elapsed_time(e1) / nk
     bytes_per_frame = ITERS * 4 * info['ldpc_edges'] + info['ldpc_n'] + info['kbch'] // 8
     achieved = bytes_per_frame * nfr / (k_ms * 1e-3) / 1e9
-    plan = eng.ldpc_plan_info(RATE, False)
+    plan = eng.ldpc_plan_info(RATE, bool(SHORT))
     # PMC traffic of this very launch shape, collected offline (counters need their own rocprofv3 passes) and committed
     traffic, traffic_note = None, None
     tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_ldpc_traffic.json')
@@ -285,13 +288,12 @@ def main():
             'value': round(value, 3), 'unit': 'Msymbols/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'int8 (FEC) / f32 (demod)', 'data': 'synthetic',
-            'config': {'workload': 'DVB-S2 8PSK 3/4 normal FECFRAME (MODCOD 14), pilots off, 27.5 Msym/s-class streams at 2 sps, '
-                                   'Es/N0 14 dB, 50 forced LDPC iterations, IQ in -> BBFRAMEs out',
+            'config': {'workload': WORKLOAD,
                        'streams_per_gpu': S, 'frames_per_stream_per_step': F, 'symbols_per_frame': sym,
                        'parallelism': 'independent transponder streams sharded over GPUs, no data-path collective',
                        'all_frames_delivered': frames_ok, 'output_bit_exact': exact,
                        'fec_pipelined_across_steps': pipelined},
-            'roofline': {'bound': 'hbm', 'kernel': 'ldpc_decode_kernel<12,4,false>', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+            'roofline': {'bound': 'hbm', 'kernel': 'ldpc_decode_kernel<%d,%d,%s>' % (plan['max_deg'], plan['rec_dwords'], 'true' if plan.get('irregular') else 'false'), 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                          'traffic_unit': 'bytes per launch (fabric-side FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_note,
                          'algorithmic_bytes_per_launch': bytes_per_frame * nfr,
