@@ -149,6 +149,11 @@ __device__ __forceinline__ void lds_read_pair_i8(uint32_t a_lo, uint32_t a_hi, u
     asm volatile("ds_read_i8_d16 %0, %2\n\tds_read_i8_d16_hi %1, %3" : "=&v"(r_lo), "=&v"(r_hi) : "v"(a_lo), "v"(a_hi) : "memory");
 }
 __device__ __forceinline__ void lds_pairs_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Byte stores straight out of the halves of a packed register (ds_write_b8 takes bits 7:0, ds_write_b8_d16_hi bits 23:16): no
+// VALU work to extract or narrow the value.  The compiler does not count these against lgkmcnt: lds_pairs_wait() before the
+// next barrier.
+__device__ __forceinline__ void lds_write_lo_i8(uint32_t addr, uint32_t packed) { asm volatile("ds_write_b8 %0, %1" ::"v"(addr), "v"(packed) : "memory"); }
+__device__ __forceinline__ void lds_write_hi_i8(uint32_t addr, uint32_t packed) { asm volatile("ds_write_b8_d16_hi %0, %1" ::"v"(addr), "v"(packed) : "memory"); }
 
 // One sweep step for one layer.  CONF = layer has intra-layer shared bits (links 0..nc-1), IRREG = the
 // code has layers of different degree (short tables C1, C4, C7, C8, C9).
@@ -184,15 +189,20 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
         uint32_t SX = 0;
         uint32_t XR[NP], XH[NP];
         const uint32_t JJ = (uint32_t)j * 0x10001u;
+        // the layer's pair table in one go (wide scalar loads up front instead of one load + wait per pair)
+        constexpr int NPW = 2 * ((MAXDEG + 1) / 2);
+        uint32_t pw[NPW];
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) pw[i] = pents[i];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             bool absent[2] = {false, false};     // uniform (table) absence; the missing previous parity bit of row 0 is per lane
             uint32_t la[2] = {lbase, lbase};
             if (2 * p < MAXDEG) {
                 // both table links of the pair at once: (j + sp) mod 360 + 360*r in packed uint16 (pair table, ldpc_plan.h)
-                u16x2 T = __builtin_bit_cast(u16x2, JJ) + __builtin_bit_cast(u16x2, pents[2 * p]);
+                u16x2 T = __builtin_bit_cast(u16x2, JJ) + __builtin_bit_cast(u16x2, pw[2 * p]);
                 T = __builtin_elementwise_min(T, (u16x2)(T - (u16x2){360, 360}));
-                const uint32_t AD = __builtin_bit_cast(uint32_t, (u16x2)(T + __builtin_bit_cast(u16x2, pents[2 * p + 1])));
+                const uint32_t AD = __builtin_bit_cast(uint32_t, (u16x2)(T + __builtin_bit_cast(u16x2, pw[2 * p + 1])));
                 la[0] = lbase + (AD & 0xffffu);
                 la[1] = lbase + (AD >> 16);
             }
@@ -355,7 +365,11 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
             const s16x2 other = ne * NDB + MIN1B;
             const s16x2 neg = from_bits2(SXB ^ bits2(V[p])) >> 15;                   // 0 or -1
             s16x2 nm = pclamp2(from_bits2(bits2(other) ^ bits2(neg)) - neg, -32, 31);
-            const s16x2 pn = pclamp2(V[p] + nm, -128, 127);
+            // (the sum goes through an empty asm: otherwise the compiler recognises an int8 saturating add and legalises it
+            // half by half -- 4 shifts, 2 v_add_i16 clamp, 2 shifts, a shuffle -- instead of v_pk_add + v_pk_max + v_pk_min)
+            uint32_t sum_bits = bits2(V[p] + nm);
+            asm volatile("" : "+v"(sum_bits));
+            const s16x2 pn = pclamp2(from_bits2(sum_bits), -128, 127);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int k = 2 * p + h;
@@ -368,7 +382,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                 }
                 if (wr) {
                     const uint32_t a = (k < MAXDEG) ? addr[k] : lbase + (uint32_t)(k == MAXDEG ? own : prev);
-                    LDS_I8(a) = (int8_t)pn[h];
+                    if (h == 0) lds_write_lo_i8(a, bits2(pn)); else lds_write_hi_i8(a, bits2(pn));
                 }
             }
             NM[p] = nm;
@@ -380,6 +394,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
             else rec_out[w] = 0;
         }
         rec_store<REC>(rec_out, rec_out_ptr);
+        lds_pairs_wait();
     }
 #undef LINK_IN
 #undef LINK_MG
