@@ -339,25 +339,37 @@ __global__ __launch_bounds__(64) void s2_gardner_kernel(const S2StreamWork* __re
 // ------------------------------------------------------------------------------------------------ RRC + /2
 // grid (x: symbol tiles, y: stream).  Only the samples the decimator keeps are filtered.
 __global__ __launch_bounds__(256) void s2_rrc_decim_kernel(const S2StreamWork* __restrict__ work, const float* __restrict__ taps_g, int ntaps) {
+    // a block = 256 consecutive kept symbols of one stream; their 2*256 + ntaps - 2 input samples go through LDS once (each is
+    // used by up to (ntaps+1)/2 outputs: reading them from L2 per output cost 46 GB per step and competed with the LDPC messages)
     __shared__ float taps[RRC_MAX_TAPS];
+    __shared__ float sre[2 * 256 + RRC_MAX_TAPS], sim[2 * 256 + RRC_MAX_TAPS];
     for (int i = threadIdx.x; i < ntaps; i += 256) taps[i] = taps_g[i];
-    __syncthreads();
     const S2StreamWork w = work[blockIdx.y];
     const S2StreamState* st = w.st;
     const int n = st->n_fe_out;
     const int first = st->cr_samp ? 0 : 1;            // first kept index (module_dvbs2_demod.cpp:231-239)
     const int nsym = n > first ? (n - first + 1) / 2 : 0;
     const int H = ntaps - 1;
-    for (int m = blockIdx.x * 256 + threadIdx.x; m < nsym; m += gridDim.x * 256) {
-        const int i = 2 * m + first;
-        cf32 acc{0.f, 0.f};
-        for (int k = 0; k < ntaps; ++k) {
-            int p = i + k;                            // index into [history(H) ++ fe_out]
-            cf32 v = p < H ? st->rrc_hist[p] : w.fe_out[p - H];
-            acc.re += v.re * taps[k];
-            acc.im += v.im * taps[k];
+    for (int m0 = blockIdx.x * 256; m0 < nsym; m0 += gridDim.x * 256) {
+        const int i0 = 2 * m0 + first;                // index of the block's first window in [history(H) ++ fe_out]
+        const int cnt = min(256, nsym - m0);
+        const int need = 2 * (cnt - 1) + ntaps;
+        __syncthreads();
+        for (int q = threadIdx.x; q < need; q += 256) {
+            const int p = i0 + q;
+            const cf32 v = p < H ? st->rrc_hist[p] : w.fe_out[p - H];
+            sre[q] = v.re; sim[q] = v.im;
         }
-        w.fifo[w.fifo_fill + m] = acc;
+        __syncthreads();
+        if ((int)threadIdx.x < cnt) {
+            const int o = 2 * threadIdx.x;
+            cf32 acc{0.f, 0.f};
+            for (int k = 0; k < ntaps; ++k) {
+                acc.re += sre[o + k] * taps[k];
+                acc.im += sim[o + k] * taps[k];
+            }
+            w.fifo[w.fifo_fill + m0 + threadIdx.x] = acc;
+        }
     }
 }
 // state update after all symbols of the call are out: delay line, decimator phase, symbol count
