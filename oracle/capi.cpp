@@ -266,3 +266,23 @@ void orc_dvbs_modulate(const uint8_t* bits, int nsym, double esn0_db, double cfo
     memcpy(out, v.data(), v.size() * sizeof(cf));
 }
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------- DVB-S tail (dvbs_tail.cpp)
+#include "dvbs_tail.h"
+extern "C" {
+void* orc_tsdef_create() { return new TsDeframer(); }
+void orc_tsdef_destroy(void* h) { delete (TsDeframer*)h; }
+int orc_tsdef_work(void* h, const uint8_t* bits, int size, uint8_t* out, int* errs2) {
+    TsDeframer* d = (TsDeframer*)h;
+    int n = d->work(bits, size, out);
+    if (errs2) { errs2[0] = d->errors_nor; errs2[1] = d->errors_inv; }
+    return n;
+}
+void* orc_dvbsrs_create() { return new DvbsRs(); }
+void orc_dvbsrs_destroy(void* h) { delete (DvbsRs*)h; }
+int orc_dvbsrs_decode(void* h, uint8_t* data204) { return ((DvbsRs*)h)->decode(data204); }
+int orc_rs255_decode(const uint8_t* enc255, uint8_t* msg239) { return rs255_decode(enc255, msg239); }
+void* orc_dvbsdescr_create() { return new DvbsDescrambler(); }
+void orc_dvbsdescr_destroy(void* h) { delete (DvbsDescrambler*)h; }
+void orc_dvbsdescr_work(void* h, uint8_t* frm1632) { ((DvbsDescrambler*)h)->descramble(frm1632); }
+}  // extern "C"

@@ -118,3 +118,22 @@ void* ref_forney_create() { return new dsp::dvbs::DVBSInterleaving(); }
 void ref_forney_deinterleave(void* h, uint8_t* in, uint8_t* out) { ((dsp::dvbs::DVBSInterleaving*)h)->deinterleave(in, out); }
 void ref_rotate_soft(int8_t* soft, int size, int phase, int iqswap) { rotate_soft(soft, size, (phase_t)phase, iqswap != 0); }
 }
+
+// ---------------------------------------------------------------------------------- DVB-S tail: deframer, RS(204,188), descrambler
+#include "dvbs/dvbs_ts_deframer.h"
+#include "dvbs/dvbs_reedsolomon.h"
+#include "dvbs/dvbs_scrambling.h"
+extern "C" {
+void* ref_tsdef_create() {
+    auto* d = new deframing::DVBS_TS_Deframer();
+    // the reference leaves its 13 056-bit shifter uninitialised; feed zeros so that runs are reproducible
+    std::vector<uint8_t> z(1632 * 8, 0), o(16 * 1632);
+    d->work(z.data(), (int)z.size(), o.data());
+    return d;
+}
+int ref_tsdef_work(void* h, uint8_t* bits, int size, uint8_t* out) { return ((deframing::DVBS_TS_Deframer*)h)->work(bits, size, out); }
+void* ref_dvbsrs_create() { return new dsp::dvbs::DVBSReedSolomon(); }
+int ref_dvbsrs_decode(void* h, uint8_t* data204) { return ((dsp::dvbs::DVBSReedSolomon*)h)->decode(data204); }
+void* ref_dvbsdescr_create() { return new dsp::dvbs::DVBSScrambling(); }
+void ref_dvbsdescr_work(void* h, uint8_t* frm) { ((dsp::dvbs::DVBSScrambling*)h)->descramble(frm); }
+}
