@@ -262,6 +262,24 @@ int dvbs2gpu_dvbs_demod_get_stats(dvbs2gpu_dvbs_demod* d, dvbs2gpu_viterbi_stats
  * element count; copies at most cap elements when h_dst != NULL. */
 int dvbs2gpu_dvbs_demod_get_tap(dvbs2gpu_dvbs_demod* d, int stream, int which, void* h_dst, int cap);
 
+/* ------------------------------------------------------------------ DVB-S tail (row f: after the Viterbi decoder)
+ * Replaces DVBSDefra::process / DVBS_TS_Deframer::work (dvbs/dvbs_defra.cpp:5-9, dvbs_ts_deframer.cpp:37-92), the per-frame
+ * loop of DVBSDemod::process (module_dvbs_demod.cpp:83-99): DVBSInterleaving::deinterleave, 8 x DVBSReedSolomon::decode
+ * (dvbs_reedsolomon.h:26-47 over libcorrect, common/correct/reed-solomon/decode.c:299-380), DVBSScrambling::descramble
+ * (dvbs_scrambling.h:28-42) and the 188-byte copies, for `nstreams` independent streams with persistent state.
+ * d_bits[i]: DEVICE pointer to counts[i] decoded bits (one per byte, the Viterbi output); d_ts[i]: DEVICE buffer of cap bytes that
+ * receives the 188-byte TS packets of every frame found; out_bytes[i] (host).  Frame k of a call is taken at byte offset
+ * 1632*k of the deframer output (the reference indexes 204*k, SURVEY Q5: wrong for k >= 1).  On a failed RS decode the
+ * reference's wrapper emits the previous packet's message; so does this.  Synchronous on `stream`. */
+typedef struct dvbs2gpu_dvbs_tail dvbs2gpu_dvbs_tail;
+int dvbs2gpu_dvbs_tail_create(dvbs2gpu_ctx* ctx, int nstreams, int max_bits, dvbs2gpu_dvbs_tail** out);
+int dvbs2gpu_dvbs_tail_reset(dvbs2gpu_dvbs_tail* t);
+void dvbs2gpu_dvbs_tail_destroy(dvbs2gpu_dvbs_tail* t);
+int dvbs2gpu_dvbs_tail_process_batch(dvbs2gpu_dvbs_tail* t, const uint8_t* const* d_bits, const int* counts, uint8_t* const* d_ts, int cap,
+                                     int* out_bytes, void* stream);
+/* h_out11 = {frames of the last call, errors_nor, errors_inv, RS error counts of the last frame's 8 packets} */
+int dvbs2gpu_dvbs_tail_get_stats(dvbs2gpu_dvbs_tail* t, int stream, int32_t* h_out11);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,6 +95,11 @@ PROTOTYPES = {
     'dvbs2gpu_dvbs_demod_process_batch': (_i, [_vp, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), _i, C.POINTER(_i)]),
     'dvbs2gpu_dvbs_demod_get_stats': (_i, [_vp, _vp]),
     'dvbs2gpu_dvbs_demod_get_tap': (_i, [_vp, _i, _i, _vp, _i]),
+    'dvbs2gpu_dvbs_tail_create': (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    'dvbs2gpu_dvbs_tail_reset': (_i, [_vp]),
+    'dvbs2gpu_dvbs_tail_destroy': (None, [_vp]),
+    'dvbs2gpu_dvbs_tail_process_batch': (_i, [_vp, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), _i, C.POINTER(_i), _vp]),
+    'dvbs2gpu_dvbs_tail_get_stats': (_i, [_vp, _i, C.POINTER(C.c_int32)]),
 }
 
 _lib = None
@@ -473,3 +478,33 @@ class DvbsDemodBank(_Handle):
         a = np.zeros(8, np.float32)
         self.eng._check(self.lib.dvbs2gpu_dvbs_demod_get_tap(self.h, stream, 1, C.c_void_p(a.ctypes.data), 8))
         return a
+
+
+class DvbsTailBank(_Handle):
+    """TS deframer + Forney de-interleaver + RS(204,188) + energy dispersal for `nstreams` DVB-S streams (module_dvbs_demod.cpp:82-99)."""
+    _destroy = 'dvbs2gpu_dvbs_tail_destroy'
+
+    def __init__(self, engine, nstreams=1, max_bits=1 << 18):
+        self.eng, self.lib, self.nstreams, self.max_bits = engine, engine.lib, nstreams, max_bits
+        h = C.c_void_p()
+        engine._check(self.lib.dvbs2gpu_dvbs_tail_create(engine.h, nstreams, max_bits, C.byref(h)))
+        self.h = h
+
+    def reset(self):
+        self.eng._check(self.lib.dvbs2gpu_dvbs_tail_reset(self.h))
+
+    def process_batch(self, bit_tensors, out_tensors):
+        """bit_tensors[i]: uint8 CUDA 1-D (one bit per byte); out_tensors[i]: uint8 CUDA buffers -> list of byte counts"""
+        n = self.nstreams
+        pin = (C.c_void_p * n)(*[t.data_ptr() for t in bit_tensors])
+        cnt = (C.c_int * n)(*[int(t.numel()) for t in bit_tensors])
+        pout = (C.c_void_p * n)(*[t.data_ptr() for t in out_tensors])
+        nb = (C.c_int * n)()
+        cap = min(int(t.numel()) for t in out_tensors)
+        self.eng._check(self.lib.dvbs2gpu_dvbs_tail_process_batch(self.h, pin, cnt, pout, cap, nb, self.eng._stream()))
+        return list(nb)
+
+    def stats(self, stream=0):
+        a = (C.c_int32 * 11)()
+        self.eng._check(self.lib.dvbs2gpu_dvbs_tail_get_stats(self.h, stream, a))
+        return {'frames': a[0], 'errors_nor': a[1], 'errors_inv': a[2], 'rs_errors': list(a[3:11])}

@@ -129,3 +129,142 @@ int dvbs2gpu_forney_deinterleave_batch(dvbs2gpu_forney* h, const uint8_t* d_in, 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------- DVB-S tail
+// TS deframer -> Forney de-interleaver -> RS(204,188) -> energy dispersal removal -> 188-byte TS packets: the rest of
+// DVBSDemod::process after vit.process (module_dvbs_demod.cpp:82-99), for a bank of streams.
+struct dvbs2gpu_dvbs_tail {
+    dvbs2gpu_ctx* ctx = nullptr;
+    int nstreams = 0, max_bits = 0, max_frames = 0;
+    long v_stride = 0, frames_stride = 0;
+    uint8_t* d_hist[2] = {nullptr, nullptr};   // last 13055 bits, double-buffered
+    int cur = 0;
+    uint8_t* d_v = nullptr;
+    int* d_hit = nullptr;
+    int* d_nframes = nullptr;
+    int* d_errs = nullptr;
+    uint8_t* d_frames = nullptr;
+    uint8_t* d_deint = nullptr;
+    uint8_t* d_forney = nullptr;
+    uint8_t* d_status = nullptr;
+    int* d_rs_err = nullptr;
+    uint8_t* d_gf = nullptr;
+    uint8_t* d_prbs = nullptr;
+    DvbsTailState* d_state = nullptr;
+    void* d_args = nullptr;                    // [in ptrs][out ptrs][counts][out bytes]
+};
+
+extern "C" {
+
+int dvbs2gpu_dvbs_tail_create(dvbs2gpu_ctx* ctx, int nstreams, int max_bits, dvbs2gpu_dvbs_tail** out) {
+    if (!ctx || !out || nstreams <= 0 || max_bits <= 0) return DVBS2GPU_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    auto t = new dvbs2gpu_dvbs_tail();
+    t->ctx = ctx; t->nstreams = nstreams; t->max_bits = max_bits;
+    t->max_frames = max_bits / (1632 * 8) + 3;
+    t->v_stride = ((long)max_bits + 1632 * 8 + 63) & ~63L;
+    t->frames_stride = (long)t->max_frames * 1632;
+    // tables: GF(256) exp[512] ++ log[256] (field.h, polynomial 0x11d); PRBS bytes after a reset (dvbs_scrambling.h)
+    std::vector<uint8_t> gf(768, 0), prbs(32767);
+    {
+        unsigned e = 1;
+        gf[0] = 1;
+        for (unsigned i = 1; i < 512; i++) {
+            e *= 2;
+            e = e > 255 ? (e ^ 0x11d) : e;
+            gf[i] = (uint8_t)e;
+            if (i < 256) gf[512 + e] = (uint8_t)i;
+        }
+        int reg = 0xa9;
+        for (int i = 0; i < 32767; ++i) {
+            int v = 0;
+            for (int k = 0; k < 8; ++k) {
+                int fb = ((reg >> 13) ^ (reg >> 14)) & 1;
+                reg = ((reg << 1) | fb) & 0x7fff;
+                v = (v << 1) | fb;
+            }
+            prbs[i] = (uint8_t)v;
+        }
+    }
+    const size_t n = (size_t)nstreams;
+    hipError_t e = hipSuccess;
+    auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) { e = hipMalloc(p, bytes); if (e == hipSuccess) e = hipMemset(*p, 0, bytes); } };
+    A((void**)&t->d_hist[0], n * 1632 * 8); A((void**)&t->d_hist[1], n * 1632 * 8);
+    A((void**)&t->d_v, n * (size_t)t->v_stride);
+    A((void**)&t->d_hit, n * t->max_frames * sizeof(int)); A((void**)&t->d_nframes, n * sizeof(int)); A((void**)&t->d_errs, n * 2 * sizeof(int));
+    A((void**)&t->d_frames, n * (size_t)t->frames_stride); A((void**)&t->d_deint, n * (size_t)t->frames_stride);
+    A((void**)&t->d_forney, n * DVBS_FORNEY_HIST);
+    A((void**)&t->d_status, n * t->max_frames * 8); A((void**)&t->d_rs_err, n * t->max_frames * 8 * sizeof(int));
+    A((void**)&t->d_gf, 768); A((void**)&t->d_prbs, 32767);
+    A((void**)&t->d_state, n * sizeof(DvbsTailState));
+    A(&t->d_args, n * (2 * sizeof(void*) + 2 * sizeof(int)));
+    if (e != hipSuccess) { dvbs2gpu_dvbs_tail_destroy(t); return fail_hip(e, "hipMalloc(dvbs tail)"); }
+    HIP_TRY(hipMemcpy(t->d_gf, gf.data(), 768, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t->d_prbs, prbs.data(), 32767, hipMemcpyHostToDevice));
+    *out = t;
+    int rc = dvbs2gpu_dvbs_tail_reset(t);
+    if (rc) { dvbs2gpu_dvbs_tail_destroy(t); *out = nullptr; }
+    return rc;
+}
+int dvbs2gpu_dvbs_tail_reset(dvbs2gpu_dvbs_tail* t) {
+    if (!t) return DVBS2GPU_ERR_ARG;
+    HIP_TRY(hipSetDevice(t->ctx->device));
+    const size_t n = (size_t)t->nstreams;
+    HIP_TRY(hipMemset(t->d_hist[0], 0, n * 1632 * 8)); HIP_TRY(hipMemset(t->d_hist[1], 0, n * 1632 * 8));
+    HIP_TRY(hipMemset(t->d_forney, 0, n * DVBS_FORNEY_HIST));
+    HIP_TRY(hipMemset(t->d_errs, 0, n * 2 * sizeof(int)));
+    std::vector<DvbsTailState> st(n);
+    memset(st.data(), 0, n * sizeof(DvbsTailState));
+    for (auto& s : st) s.prbs_pos = -1;
+    HIP_TRY(hipMemcpy(t->d_state, st.data(), n * sizeof(DvbsTailState), hipMemcpyHostToDevice));
+    t->cur = 0;
+    return 0;
+}
+void dvbs2gpu_dvbs_tail_destroy(dvbs2gpu_dvbs_tail* t) {
+    if (!t) return;
+    void* ps[] = {t->d_hist[0], t->d_hist[1], t->d_v, t->d_hit, t->d_nframes, t->d_errs, t->d_frames, t->d_deint, t->d_forney, t->d_status,
+                  t->d_rs_err, t->d_gf, t->d_prbs, t->d_state, t->d_args};
+    for (void* p : ps) if (p) (void)hipFree(p);
+    delete t;
+}
+int dvbs2gpu_dvbs_tail_process_batch(dvbs2gpu_dvbs_tail* t, const uint8_t* const* d_bits, const int* counts, uint8_t* const* d_ts, int cap,
+                                     int* out_bytes, void* stream) {
+    if (!t || !d_bits || !counts || !d_ts || !out_bytes || cap < 0) return DVBS2GPU_ERR_ARG;
+    HIP_TRY(hipSetDevice(t->ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int n = t->nstreams;
+    for (int i = 0; i < n; ++i) {
+        if (counts[i] < 0 || counts[i] > t->max_bits) { last_error() = "bit count exceeds max_bits"; return DVBS2GPU_ERR_ARG; }
+        if (counts[i] > 0 && !d_bits[i]) return DVBS2GPU_ERR_ARG;
+    }
+    char* a = (char*)t->d_args;
+    const uint8_t** d_in = (const uint8_t**)a;
+    uint8_t** d_out = (uint8_t**)(a + sizeof(void*) * n);
+    int* d_cnt = (int*)(a + 2 * sizeof(void*) * n);
+    int* d_ob = d_cnt + n;
+    HIP_TRY(hipMemcpyAsync(d_in, d_bits, sizeof(void*) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_out, d_ts, sizeof(void*) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_cnt, counts, sizeof(int) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(dvbs_tail_launch(d_in, d_cnt, n, t->max_bits, t->d_hist[t->cur], t->d_hist[t->cur ^ 1], t->d_v, t->v_stride, t->max_frames, t->d_hit,
+                             t->d_nframes, t->d_errs, t->d_frames, t->d_deint, t->frames_stride, t->d_forney, t->d_status, t->d_gf, t->d_prbs,
+                             t->d_state, d_out, cap, d_ob, t->d_rs_err, st));
+    t->cur ^= 1;
+    HIP_TRY(hipMemcpyAsync(out_bytes, d_ob, sizeof(int) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+/* per stream: frames found by the last call, errors_nor, errors_inv of the deframer (stats_deframer_err = min of the two,
+ * module_dvbs_demod.cpp:116) and the RS error counts of the last frame's 8 packets (stats_rs_avg = their mean, :115) */
+int dvbs2gpu_dvbs_tail_get_stats(dvbs2gpu_dvbs_tail* t, int stream, int32_t* h_out11) {
+    if (!t || stream < 0 || stream >= t->nstreams || !h_out11) return DVBS2GPU_ERR_ARG;
+    HIP_TRY(hipSetDevice(t->ctx->device));
+    int nf = 0, er[2] = {0, 0};
+    HIP_TRY(hipMemcpy(&nf, t->d_nframes + stream, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(er, t->d_errs + 2 * stream, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    h_out11[0] = nf; h_out11[1] = er[0]; h_out11[2] = er[1];
+    for (int i = 0; i < 8; ++i) h_out11[3 + i] = 0;
+    if (nf > 0) HIP_TRY(hipMemcpy(h_out11 + 3, t->d_rs_err + (size_t)stream * t->max_frames * 8 + (size_t)(nf - 1) * 8, 8 * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

@@ -345,9 +345,11 @@ __global__ __launch_bounds__(64) void dvbs_viterbi_kernel(const int8_t* in_all, 
 
 // ------------------------------------------------------------------------------------------------ Forney de-interleaver
 // out[n] = in[n - 204*(11 - n%12)] over the continuous byte stream; hist = last 2244 bytes of the previous calls
-__global__ __launch_bounds__(256) void dvbs_deinterleave_kernel(const uint8_t* __restrict__ in, long stream_stride, int nbytes,
-                                                                uint8_t* __restrict__ out, const uint8_t* __restrict__ hist) {
+__global__ __launch_bounds__(256) void dvbs_deinterleave_kernel(const uint8_t* __restrict__ in, long stream_stride, int nbytes_all,
+                                                                const int* __restrict__ nframes, uint8_t* __restrict__ out,
+                                                                const uint8_t* __restrict__ hist) {
     const int s = blockIdx.y;
+    const int nbytes = nframes ? nframes[s] * 1632 : nbytes_all;      // per-stream length (tail pipeline) or uniform
     const uint8_t* __restrict__ src = in + (long)s * stream_stride;
     uint8_t* __restrict__ dst = out + (long)s * stream_stride;
     const uint8_t* __restrict__ h = hist + (long)s * DVBS_FORNEY_HIST;
@@ -357,9 +359,11 @@ __global__ __launch_bounds__(256) void dvbs_deinterleave_kernel(const uint8_t* _
     }
 }
 // new history = last 2244 bytes of [hist ++ in]
-__global__ __launch_bounds__(256) void dvbs_deinterleave_hist_kernel(const uint8_t* __restrict__ in, long stream_stride, int nbytes, uint8_t* hist) {
+__global__ __launch_bounds__(256) void dvbs_deinterleave_hist_kernel(const uint8_t* __restrict__ in, long stream_stride, int nbytes_all,
+                                                                     const int* __restrict__ nframes, uint8_t* hist) {
     __shared__ uint8_t tmp[DVBS_FORNEY_HIST];
     const int s = blockIdx.x;
+    const int nbytes = nframes ? nframes[s] * 1632 : nbytes_all;
     const uint8_t* __restrict__ src = in + (long)s * stream_stride;
     uint8_t* h = hist + (long)s * DVBS_FORNEY_HIST;
     for (int i = threadIdx.x; i < DVBS_FORNEY_HIST; i += 256) {
@@ -416,8 +420,318 @@ hipError_t dvbs_deinterleave_launch(const uint8_t* d_in, long stream_stride, int
                                     hipStream_t st) {
     int gx = (nbytes + 255) / 256;
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(dvbs_deinterleave_kernel, dim3(gx, nstreams), dim3(256), 0, st, d_in, stream_stride, nbytes, d_out, d_hist);
-    hipLaunchKernelGGL(dvbs_deinterleave_hist_kernel, dim3(nstreams), dim3(256), 0, st, d_in, stream_stride, nbytes, d_hist);
+    hipLaunchKernelGGL(dvbs_deinterleave_kernel, dim3(gx, nstreams), dim3(256), 0, st, d_in, stream_stride, nbytes, (const int*)nullptr, d_out, d_hist);
+    hipLaunchKernelGGL(dvbs_deinterleave_hist_kernel, dim3(nstreams), dim3(256), 0, st, d_in, stream_stride, nbytes, (const int*)nullptr, d_hist);
+    return hipGetLastError();
+}
+
+// ================================================================================================ DVB-S tail (after the Viterbi)
+// DVBS_TS_Deframer::work (dvbs/dvbs_ts_deframer.cpp:37-92): a 13 056-bit window slides over the bit stream one bit at a time; a
+// frame (8 x 204 bytes) is emitted whenever the 8 sync bytes at 1632-bit spacing match B8 47 47 .. (or the inverted pattern)
+// with at most 8 bit errors.  The reference shifts the whole window per bit; here every window position is tested in
+// parallel on a byte-at-every-bit-offset view of the stream, hits are compacted in order, frames are gathered at stride 8.
+//   state per stream: the last 13 055 bits (unpacked), errors_nor / errors_inv of the last hit
+constexpr int TSD_WIN = 1632 * 8;
+
+// v[p] = bits p .. p+7 of [history(13055) ++ input(n)] packed MSB first, for p = 0 .. n + 13055 - 8
+__global__ __launch_bounds__(256) void dvbs_tsdef_pack_kernel(const uint8_t* const* __restrict__ in_ptrs, const int* __restrict__ counts,
+                                                              const uint8_t* __restrict__ hist, uint8_t* __restrict__ v, long v_stride) {
+    const int s = blockIdx.y, n = counts[s];
+    const uint8_t* __restrict__ in = in_ptrs[s];
+    const uint8_t* __restrict__ h = hist + (long)s * TSD_WIN;
+    uint8_t* __restrict__ vo = v + (long)s * v_stride;
+    const int total = n + (TSD_WIN - 1) - 7;          // number of byte positions
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < total; p += gridDim.x * 256) {
+        unsigned b = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = p + k;
+            const unsigned bit = q < TSD_WIN - 1 ? h[q] : in[q - (TSD_WIN - 1)];
+            b = (b << 1) | (bit & 1u);
+        }
+        vo[p] = (uint8_t)b;
+    }
+}
+// one workgroup per stream: test every window end position t (window start = t in the v[] indexing), ordered compaction of hits
+__global__ __launch_bounds__(256) void dvbs_tsdef_find_kernel(const int* __restrict__ counts, const uint8_t* __restrict__ v, long v_stride,
+                                                              int max_frames, int* __restrict__ hit_pos, int* __restrict__ nframes,
+                                                              int* __restrict__ errs) {
+    __shared__ int s_base, s_wave[4], s_last[2];
+    const int s = blockIdx.x, n = counts[s], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t* __restrict__ vv = v + (long)s * v_stride;
+    if (tid == 0) { s_base = 0; s_last[0] = errs[2 * s]; s_last[1] = errs[2 * s + 1]; }
+    __syncthreads();
+    for (int t0 = 0; t0 < n; t0 += 256) {
+        const int t = t0 + tid;          // after pushing input bit t the window starts at stream position t (v index t)
+        int en = 99, ei = 99;
+        if (t < n) {
+            en = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) en += __popc((unsigned)(vv[t + 1632 * i] ^ (i == 0 ? 0xB8u : 0x47u)));
+            ei = 64 - en;
+        }
+        const bool hit = en <= 8 || ei <= 8;
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (hit) {
+            const int idx = off + __popcll(m & ((1ull << lane) - 1ull));
+            if (idx < max_frames) hit_pos[(long)s * max_frames + idx] = en <= 8 ? t : (t | 0x40000000);
+        }
+        // errors_nor / errors_inv follow the LAST hit (dvbs_ts_deframer.cpp:71-72,82-83)
+        const int tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (tot > 0) {
+            // highest hit lane of the highest hitting wave
+            int last_wave = s_wave[3] ? 3 : (s_wave[2] ? 2 : (s_wave[1] ? 1 : 0));
+            if (wave == last_wave && hit && (m >> lane) == 1ull) { s_last[0] = en <= 8 ? en : 0; s_last[1] = en <= 8 ? 0 : ei; }
+        }
+        __syncthreads();
+        if (tid == 0) s_base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) { nframes[s] = min(s_base, max_frames); errs[2 * s] = s_last[0]; errs[2 * s + 1] = s_last[1]; }
+}
+// frames out (byte k of a frame = v[start + 8k], inverted for an inverted hit) + new history; grid (max_frames + 1, nstreams)
+__global__ __launch_bounds__(256) void dvbs_tsdef_emit_kernel(const uint8_t* const* __restrict__ in_ptrs, const int* __restrict__ counts,
+                                                              const uint8_t* __restrict__ v, long v_stride, int max_frames,
+                                                              const int* __restrict__ hit_pos, const int* __restrict__ nframes,
+                                                              uint8_t* __restrict__ frames, long frames_stride, const uint8_t* __restrict__ hist_old,
+                                                              uint8_t* __restrict__ hist_next) {
+    const int s = blockIdx.y, f = blockIdx.x;
+    if (f == max_frames) {                       // the extra block of each stream writes the new history: last 13055 bits
+        const int n = counts[s];
+        const uint8_t* __restrict__ in = in_ptrs[s];
+        uint8_t* __restrict__ hn = hist_next + (long)s * TSD_WIN;
+        for (int q = threadIdx.x; q < TSD_WIN - 1; q += 256) {
+            // new history = last 13055 bits of [old history ++ input]
+            const int p = n + q;                 // position in [old history ++ input]
+            const int hq = p - (TSD_WIN - 1);    // input index, or < 0: still old history
+            hn[q] = (uint8_t)((hq >= 0 ? in[hq] : hist_old[(long)s * TSD_WIN + p]) & 1u);
+        }
+        return;
+    }
+    if (f >= nframes[s]) return;
+    const int hp = hit_pos[(long)s * max_frames + f];
+    const int start = hp & 0x3fffffff;
+    const unsigned inv = (hp & 0x40000000) ? 0xffu : 0u;
+    const uint8_t* __restrict__ vv = v + (long)s * v_stride + start;
+    uint8_t* __restrict__ o = frames + (long)s * frames_stride + (long)f * 1632;
+    for (int k = threadIdx.x; k < 1632; k += 256) o[k] = (uint8_t)(vv[8 * k] ^ inv);
+}
+
+// ---- RS(204,188) = RS(255,239) shortened, GF(256) poly 0x11d, generator roots alpha^0..alpha^15.  ONE WAVE PER PACKET.
+// correct_reed_solomon_decode (common/correct/reed-solomon/decode.c:299-380): syndromes, Berlekamp-Massey exactly as written there
+// (:31-121: its result for more than 8 errors depends on the variant), Chien search, Forney.  Field arithmetic through
+// log/exp tables (field.h); lanes hold 4 coefficients each.
+struct Gf256Dev { const uint8_t* ex; const uint8_t* lg; };
+__device__ __forceinline__ unsigned gf_mul(const uint8_t* ex, const uint8_t* lg, unsigned a, unsigned b) { return (a == 0 || b == 0) ? 0u : ex[lg[a] + lg[b]]; }
+__device__ __forceinline__ unsigned gf_div(const uint8_t* ex, const uint8_t* lg, unsigned a, unsigned b) { return (a == 0 || b == 0) ? 0u : ex[255 + lg[a] - lg[b]]; }
+
+// status per packet: 1 = message produced (possibly corrected), 0 = decoder gave up (output comes from the previous packet)
+__global__ __launch_bounds__(64) void dvbs_rs_kernel(uint8_t* __restrict__ deint, long stream_stride, const int* __restrict__ nframes,
+                                                     int max_packets, uint8_t* __restrict__ status, int* __restrict__ rs_err,
+                                                     const uint8_t* __restrict__ gf_tab) {
+    __shared__ uint8_t ex[512], lg[256];
+    __shared__ uint8_t recv[256];
+    __shared__ uint8_t syn[16];
+    __shared__ uint8_t loc[64], last[64], ev[16], der[16], roots[16];
+    __shared__ int s_order, s_nroots;
+    const int lane = threadIdx.x, s = blockIdx.y, p = blockIdx.x;
+    if (p >= nframes[s] * 8) return;
+    for (int i = lane; i < 512; i += 64) ex[i] = gf_tab[i];
+    for (int i = lane; i < 256; i += 64) lg[i] = gf_tab[512 + i];
+    uint8_t* __restrict__ pkt = deint + (long)s * stream_stride + (long)p * 204;
+    // received polynomial: coeff[i] = encoded[254 - i], encoded = 51 zeros ++ 204 bytes  ->  coeff[i] = pkt[203 - i] for i < 204, else 0
+    for (int i = lane; i < 256; i += 64) recv[i] = i < 204 ? pkt[203 - i] : 0;
+    __syncthreads();
+    // syndromes S_r = sum_i coeff[i] * alpha^(r i): each lane its 4 coefficients (i = lane + 64 q; only i < 204 non-zero)
+    unsigned myS[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) myS[r] = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = lane + 64 * q;
+        const unsigned c = recv[i];
+        if (c) {
+            const unsigned lc = lg[c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) myS[r] ^= ex[(lc + (unsigned)(r * i) % 255u) % 255u];
+        }
+    }
+    unsigned anynz = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        unsigned x = myS[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x ^= __shfl_xor(x, o);
+        if (lane == 0) syn[r] = (uint8_t)x;
+        anynz |= x;
+    }
+    if (anynz == 0) { if (lane == 0) { status[(long)s * max_packets + p] = 1; rs_err[(long)s * max_packets + p] = 0; } return; }   // clean packet
+    __syncthreads();
+    if (lane == 0) {
+        // Berlekamp-Massey, reed_solomon_find_error_locator with num_erasures = 0
+        for (int i = 0; i < 64; ++i) { loc[i] = 0; last[i] = 0; }
+        loc[0] = 1; last[0] = 1;
+        unsigned loc_order = 0, last_order = 0, numerrors = 0, delay = 1, last_disc = 1;
+        for (unsigned i = 0; i < 16; ++i) {
+            unsigned disc = syn[i];
+            for (unsigned j = 1; j <= numerrors; ++j) disc ^= gf_mul(ex, lg, loc[j], syn[i - j]);
+            if (!disc) { delay++; continue; }
+            if (2 * numerrors <= i) {
+                for (int j = (int)last_order; j >= 0; --j) last[j + delay] = (uint8_t)gf_div(ex, lg, gf_mul(ex, lg, last[j], disc), last_disc);
+                for (int j = (int)delay - 1; j >= 0; --j) last[j] = 0;
+                for (unsigned j = 0; j <= last_order + delay; ++j) { uint8_t t = loc[j]; loc[j] ^= last[j]; last[j] = t; }
+                const unsigned t = loc_order;
+                loc_order = last_order + delay;
+                last_order = t;
+                numerrors = i + 1 - numerrors;
+                last_disc = disc;
+                delay = 1;
+                continue;
+            }
+            for (int j = (int)last_order; j >= 0; --j) loc[j + delay] ^= (uint8_t)gf_div(ex, lg, gf_mul(ex, lg, last[j], disc), last_disc);
+            loc_order = (last_order + delay > loc_order) ? last_order + delay : loc_order;
+            delay++;
+        }
+        s_order = (int)loc_order;
+        s_nroots = 0;
+    }
+    __syncthreads();
+    const int order = s_order;
+    // Chien search: Lambda(e) for every field element e = 1..255 (0 is never a root: Lambda(0) = 1), roots in increasing e
+    for (int q = 0; q < 4; ++q) {
+        const int e = lane + 64 * q;
+        unsigned val = 1;                       // e == 0 -> coeff[0] = 1 (not a root); computed properly for e >= 1
+        if (e >= 1) {
+            val = 0;
+            const unsigned le = lg[e] % 255u;
+            for (int i = 0; i <= order && i < 64; ++i) {
+                const unsigned c = loc[i];
+                if (c) val ^= ex[(lg[c] % 255u + (le * (unsigned)i) % 255u) % 255u];
+            }
+        }
+        const bool isroot = (e >= 1) && val == 0;
+        const unsigned long long m = __ballot(isroot);
+        const int base = s_nroots;
+        if (isroot) {
+            const int idx = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (idx < 16) roots[idx] = (uint8_t)e;
+        }
+        __syncthreads();
+        if (lane == 0) s_nroots = base + __popcll(m);
+        __syncthreads();
+    }
+    if (s_nroots != order || order > 16) { if (lane == 0) status[(long)s * max_packets + p] = 0; return; }
+    if (lane == 0) {
+        // error evaluator = Lambda * S mod x^16 (polynomial.c:17-30), formal derivative (:74-87)
+        for (int i = 0; i < 16; ++i) { ev[i] = 0; der[i] = 0; }
+        for (int i = 0; i <= order && i <= 15; ++i)
+            for (int j = 0; j <= 15 - i; ++j) ev[i + j] ^= (uint8_t)gf_mul(ex, lg, loc[i], syn[j]);
+        for (int i = 0; i <= order - 1 && i < 16; ++i) der[i] = ((i + 1) & 1) ? loc[i + 1] : 0;
+    }
+    __syncthreads();
+    int fixed = 0;
+    if (lane < order) {
+        const unsigned root = roots[lane];
+        const unsigned lr = lg[root] % 255u;
+        unsigned num = 0, den = 0;
+        for (int i = 0; i < 16; ++i) {
+            if (ev[i]) num ^= ex[(lg[ev[i]] % 255u + (lr * (unsigned)i) % 255u) % 255u];
+            if (i <= order - 1 && der[i]) den ^= ex[(lg[der[i]] % 255u + (lr * (unsigned)i) % 255u) % 255u];
+        }
+        const unsigned rinv = ex[(255u - lr) % 255u];                        // field_pow(root, -1)
+        const unsigned val = gf_mul(ex, lg, rinv, gf_div(ex, lg, num, den));
+        const unsigned locn = lg[rinv] % 255u;                              // log(1/root), 0 for 1/root == 1
+        if (locn < 204) pkt[203 - locn] ^= (uint8_t)val;                    // (locations >= 204 hit the zero padding: not part of the packet)
+        fixed = (locn >= 16 && locn < 204 && val != 0) ? 1 : 0;             // the wrapper counts changed MESSAGE bytes (dvbs_reedsolomon.h:38-42)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) fixed += __shfl_xor(fixed, o);
+    if (lane == 0) { status[(long)s * max_packets + p] = 1; rs_err[(long)s * max_packets + p] = fixed; }
+}
+
+// ---- per stream, in packet order: the wrapper's stale-output rule for failed packets (dvbs_reedsolomon.h:26-47), energy
+// dispersal removal (dvbs_scrambling.h:28-42) and the 188-byte TS packets (module_dvbs_demod.cpp:93-99).  ONE WAVE PER STREAM.
+// DvbsTailState (kernels.h): prbs_pos = PRBS bytes consumed since the last reset, -1: never reset (register 0: all-zero sequence);
+// last_msg = message part of the RS wrapper's obuffer (bytes 51..238)
+__global__ __launch_bounds__(64) void dvbs_ts_finish_kernel(uint8_t* __restrict__ deint, long stream_stride, const int* __restrict__ nframes,
+                                                            int max_packets, const uint8_t* __restrict__ status, const uint8_t* __restrict__ prbs_tab,
+                                                            DvbsTailState* __restrict__ state, uint8_t* const* __restrict__ out_ptrs, int cap,
+                                                            int* __restrict__ out_bytes, int* __restrict__ rs_err) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int npk = nframes[s] * 8;
+    DvbsTailState* st = state + s;
+    int pos = st->prbs_pos;
+    unsigned lastm[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) lastm[q] = (lane + 64 * q) < 188 ? st->last_msg[lane + 64 * q] : 0u;
+    uint8_t* __restrict__ out = out_ptrs[s];
+    int nout = 0;
+    for (int p = 0; p < npk; ++p) {
+        uint8_t* __restrict__ pkt = deint + (long)s * stream_stride + (long)p * 204;
+        const int ok = status[(long)s * max_packets + p];
+        unsigned d[3];
+        int diff = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int i = lane + 64 * q;
+            unsigned rx = i < 188 ? pkt[i] : 0u;
+            if (!ok) { diff += (i < 188 && rx != lastm[q]) ? 1 : 0; rx = lastm[q]; }     // decoder gave up: previous message comes out
+            d[q] = rx;
+        }
+        if (ok) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) lastm[q] = d[q];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) diff += __shfl_xor(diff, o);
+        if (lane == 0 && !ok) rs_err[(long)s * max_packets + p] = diff;
+        // energy dispersal: first byte B8 resets the generator, otherwise one PRBS byte is skipped
+        const unsigned first = __shfl((int)d[0], 0);
+        int base;                               // PRBS byte index of packet byte 1
+        if (first == 0xB8u) { base = 0; pos = 187; }
+        else if (pos >= 0) { base = pos + 1; pos += 188; }
+        else base = -1;
+        if (pos >= 32767 * 8) pos -= 32767 * 8;  // (sequence of PRBS bytes repeats every 32767 bytes)
+        if (nout + 188 <= cap) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int i = lane + 64 * q;
+                if (i < 188) {
+                    unsigned x = d[q];
+                    if (i == 0) x = 0x47;
+                    else if (base >= 0) x ^= prbs_tab[(base + i - 1) % 32767];
+                    out[nout + i] = (uint8_t)x;
+                }
+            }
+            nout += 188;
+        }
+    }
+    if (lane == 0) { st->prbs_pos = pos; out_bytes[s] = nout; }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) if ((lane + 64 * q) < 188) st->last_msg[lane + 64 * q] = (uint8_t)lastm[q];
+}
+
+hipError_t dvbs_tail_launch(const uint8_t* const* d_in_ptrs, const int* d_counts, int nstreams, int max_bits, uint8_t* d_hist, uint8_t* d_hist_next,
+                            uint8_t* d_v, long v_stride, int max_frames, int* d_hit_pos, int* d_nframes, int* d_errs, uint8_t* d_frames,
+                            uint8_t* d_deint, long frames_stride, uint8_t* d_forney_hist, uint8_t* d_status, const uint8_t* d_gf, const uint8_t* d_prbs,
+                            DvbsTailState* d_state, uint8_t* const* d_out_ptrs, int cap, int* d_out_bytes, int* d_rs_err, hipStream_t st) {
+    int gx = (max_bits + TSD_WIN + 255) / 256;
+    gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+    hipLaunchKernelGGL(dvbs_tsdef_pack_kernel, dim3(gx, nstreams), dim3(256), 0, st, d_in_ptrs, d_counts, d_hist, d_v, v_stride);
+    hipLaunchKernelGGL(dvbs_tsdef_find_kernel, dim3(nstreams), dim3(256), 0, st, d_counts, d_v, v_stride, max_frames, d_hit_pos, d_nframes, d_errs);
+    hipLaunchKernelGGL(dvbs_tsdef_emit_kernel, dim3(max_frames + 1, nstreams), dim3(256), 0, st, d_in_ptrs, d_counts, d_v, v_stride, max_frames,
+                       d_hit_pos, d_nframes, d_frames, frames_stride, d_hist, d_hist_next);
+    int gd = (max_frames * 1632 + 255) / 256;
+    gd = gd < 1 ? 1 : (gd > 64 ? 64 : gd);
+    hipLaunchKernelGGL(dvbs_deinterleave_kernel, dim3(gd, nstreams), dim3(256), 0, st, d_frames, frames_stride, 0, d_nframes, d_deint, d_forney_hist);
+    hipLaunchKernelGGL(dvbs_deinterleave_hist_kernel, dim3(nstreams), dim3(256), 0, st, d_frames, frames_stride, 0, d_nframes, d_forney_hist);
+    hipLaunchKernelGGL(dvbs_rs_kernel, dim3(max_frames * 8, nstreams), dim3(64), 0, st, d_deint, frames_stride, d_nframes, max_frames * 8, d_status, d_rs_err, d_gf);
+    hipLaunchKernelGGL(dvbs_ts_finish_kernel, dim3(nstreams), dim3(64), 0, st, d_deint, frames_stride, d_nframes, max_frames * 8, d_status, d_prbs,
+                       d_state, d_out_ptrs, cap, d_out_bytes, d_rs_err);
     return hipGetLastError();
 }
 

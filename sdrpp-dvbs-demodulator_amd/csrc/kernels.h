@@ -70,6 +70,15 @@ hipError_t dvbs_cc_decode_launch(const uint8_t* d_in, long stream_stride, int bl
 hipError_t dvbs_viterbi_launch(const int8_t* d_soft, const int8_t* const* d_soft_ptrs, const int* d_nblk, int nstreams, int nblocks,
                                uint8_t* d_bits, int* d_nbits, DvbsVitStats* d_stats, DvbsVitState* d_states, uint8_t* d_ws, float thr,
                                int max_outsync, hipStream_t st);
+struct DvbsTailState {     // per stream: energy-dispersal phase + the RS wrapper's last decoded message (dvbs_kernels.hip)
+    int prbs_pos;
+    int pad;
+    uint8_t last_msg[192];
+};
+hipError_t dvbs_tail_launch(const uint8_t* const* d_in_ptrs, const int* d_counts, int nstreams, int max_bits, uint8_t* d_hist, uint8_t* d_hist_next,
+                            uint8_t* d_v, long v_stride, int max_frames, int* d_hit_pos, int* d_nframes, int* d_errs, uint8_t* d_frames,
+                            uint8_t* d_deint, long frames_stride, uint8_t* d_forney_hist, uint8_t* d_status, const uint8_t* d_gf, const uint8_t* d_prbs,
+                            DvbsTailState* d_state, uint8_t* const* d_out_ptrs, int cap, int* d_out_bytes, int* d_rs_err, hipStream_t st);
 hipError_t dvbs_pack_bits_launch(const uint8_t* d_bits, const int* d_nbits, const int* d_nblk, int nstreams, int nblocks, uint8_t* const* d_out_ptrs,
                                  int cap, int* d_out_count, hipStream_t st);
 hipError_t dvbs_deinterleave_launch(const uint8_t* d_in, long stream_stride, int nstreams, int nbytes, uint8_t* d_out, uint8_t* d_hist,

@@ -1,0 +1,135 @@
+"""GPU parity tests for the DVB-S tail (TS deframer -> Forney -> RS(204,188) -> energy dispersal -> TS packets) through the C ABI,
+bit-exact against the CPU oracle (oracle/dvbs_tail.cpp, itself pinned against the reference sources)."""
+import numpy as np
+import pytest
+import orc_dvbs as od
+import orc_dvbs_tail as ot
+from orc_dvbs import P, VP
+
+pytestmark = pytest.mark.gpu
+
+
+class OracleTail:
+    """DVBSDemod::process after vit.process, frame k at stride 1632"""
+
+    def __init__(self):
+        self.o, self.ol = ot.L(), od.L()
+        self.hd, self.hf = VP(self.o.orc_tsdef_create()), VP(self.ol.orc_forney_create())
+        self.hr, self.hs = VP(self.o.orc_dvbsrs_create()), VP(self.o.orc_dvbsdescr_create())
+        self.last_rs = [0] * 8
+        self.errs = np.zeros(2, np.int32)
+
+    def process(self, bits):
+        bits = np.ascontiguousarray(bits, np.uint8)
+        frames = np.zeros(1632 * (bits.size // 13056 + 4), np.uint8)
+        nf = self.o.orc_tsdef_work(self.hd, P(bits), bits.size, P(frames), P(self.errs)) if bits.size else 0
+        out = []
+        for k in range(nf):
+            f = np.ascontiguousarray(frames[1632 * k:1632 * (k + 1)])
+            d = np.zeros(1632, np.uint8)
+            self.ol.orc_forney_deinterleave(self.hf, P(f), P(d))
+            for i in range(8):
+                pkt = np.ascontiguousarray(d[204 * i:204 * (i + 1)])
+                self.last_rs[i] = self.o.orc_dvbsrs_decode(self.hr, P(pkt))
+                d[204 * i:204 * i + 188] = pkt[:188]
+            self.o.orc_dvbsdescr_work(self.hs, P(d))
+            for i in range(8):
+                out.append(d[204 * i:204 * i + 188].copy())
+        return (np.concatenate(out) if out else np.zeros(0, np.uint8)), nf
+
+
+def _streams(nbits):
+    rng = np.random.default_rng(21)
+    cases = []
+    bits, ts = ot.dvbs_outer_tx(64, seed=30)
+    cases.append(('clean', bits[:nbits]))
+    b2, _ = ot.dvbs_outer_tx(64, seed=31)
+    cases.append(('ber1e-3', (b2 ^ (rng.random(b2.size) < 1e-3))[:nbits].astype(np.uint8)))
+    b3, _ = ot.dvbs_outer_tx(64, seed=32)
+    cases.append(('ber8e-3_rs_failures', (b3 ^ (rng.random(b3.size) < 8e-3))[:nbits].astype(np.uint8)))      # many packets beyond t = 8
+    b4, _ = ot.dvbs_outer_tx(64, seed=33)
+    cases.append(('inverted', (1 - b4)[:nbits].astype(np.uint8)))
+    b5, _ = ot.dvbs_outer_tx(64, seed=34)
+    cases.append(('offset_777', np.concatenate([rng.integers(0, 2, 777, dtype=np.uint8), b5])[:nbits]))
+    cases.append(('noise', rng.integers(0, 2, nbits, dtype=np.uint8)))
+    b6, _ = ot.dvbs_outer_tx(64, seed=35)
+    x = b6.copy()
+    x[30000:30000 + 13056] = rng.integers(0, 2, 13056)            # a burst wipes one frame: sync lost for one group
+    cases.append(('burst', x[:nbits]))
+    return cases
+
+
+def test_tail_bit_exact_vs_oracle_over_chunked_calls(engine, pkg):
+    import torch
+    nbits = 64 * 204 * 8
+    cases = _streams(nbits)
+    S = len(cases)
+    bank = pkg.DvbsTailBank(engine, S, max_bits=70000)
+    oracles = [OracleTail() for _ in range(S)]
+    pos = 0
+    total = [0] * S
+    for chunk in (4096, 6144, 13056, 1, 40001, 7, 65536, nbits):
+        tin, exp = [], []
+        for s in range(S):
+            seg = cases[s][1][pos:pos + chunk]
+            tin.append(torch.from_numpy(np.ascontiguousarray(seg)).cuda())
+            exp.append(oracles[s].process(seg))
+        tout = [torch.zeros(188 * 8 * 8, dtype=torch.uint8, device='cuda') for _ in range(S)]
+        nb = bank.process_batch(tin, tout)
+        for s in range(S):
+            e, nf = exp[s]
+            assert nb[s] == e.size, (cases[s][0], pos, nb[s], e.size)
+            assert np.array_equal(tout[s][:nb[s]].cpu().numpy(), e), (cases[s][0], pos)
+            st = bank.stats(s)
+            assert st['frames'] == nf
+            if nf:
+                assert st['rs_errors'] == oracles[s].last_rs, (cases[s][0], st, oracles[s].last_rs)
+            assert (st['errors_nor'], st['errors_inv']) == tuple(int(x) for x in oracles[s].errs), cases[s][0]
+            total[s] += nf
+        pos += chunk
+        if pos >= nbits:
+            break
+    assert total[0] >= 7 and total[5] == 0                     # the clean stream found its frames, noise never syncs
+    bank.close()
+
+
+def test_tail_recovers_transmitted_ts_packets(engine, pkg):
+    import torch
+    bits, ts = ot.dvbs_outer_tx(96, seed=50)
+    rng = np.random.default_rng(51)
+    bits = (bits ^ (rng.random(bits.size) < 2e-3)).astype(np.uint8)
+    bank = pkg.DvbsTailBank(engine, 1, max_bits=bits.size)
+    out = torch.zeros(188 * 96, dtype=torch.uint8, device='cuda')
+    nb = bank.process_batch([torch.from_numpy(bits).cuda()], [out])
+    got = out[:nb[0]].cpu().numpy().reshape(-1, 188)
+    assert len(got) == 96 and (got[:, 0] == 0x47).all()
+    sent = {bytes(t) for t in ts}
+    hits = sum(bytes(g) in sent for g in got[16:])               # the de-interleaver needs 11 packets of history
+    assert hits == len(got) - 16
+    bank.close()
+
+
+def test_dvbs_end_to_end_iq_to_ts(engine, pkg):
+    """IQ -> QPSK_ALT front end -> slicer -> Viterbi -> deframer -> de-interleaver -> RS -> descrambler == transmitted TS packets"""
+    import torch
+    npk = 240
+    obits, ts = ot.dvbs_outer_tx(npk, seed=60)
+    # inner code: rate 1/2 mother code over the outer bit stream, then QPSK
+    enc = od.cc_encode(obits)
+    nsym = enc.size // 2
+    iq = np.zeros(2 * nsym, np.complex64)
+    od.LF().orc_dvbs_modulate(P(np.ascontiguousarray(enc)), nsym, 9.0, 5e-4, 0.3, 0.2, 7, P(iq))
+    rx = pkg.DvbsDemodBank(engine, 1, max_samples=65536)
+    tail = pkg.DvbsTailBank(engine, 1, max_bits=80000)
+    got = []
+    for p in range(0, iq.size, 65536):
+        bits = rx.process(iq[p:p + 65536])
+        out = torch.zeros(188 * 64, dtype=torch.uint8, device='cuda')
+        nb = tail.process_batch([torch.from_numpy(bits).cuda()], [out])
+        got.append(out[:nb[0]].cpu().numpy())
+    got = np.concatenate(got).reshape(-1, 188)
+    sent = {bytes(t) for t in ts}
+    hits = sum(bytes(g) in sent for g in got)
+    # minus loop acquisition / Viterbi lock at the start and the interleaver's 11-packet history
+    assert len(got) >= 120 and hits >= len(got) - 24, (len(got), hits)
+    rx.close(); tail.close()
