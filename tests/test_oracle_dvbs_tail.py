@@ -124,3 +124,41 @@ def test_full_tail_recovers_ts_packets():
     for g in got[16:]:
         hits += any(np.array_equal(g, t) for t in ts)
     assert hits >= len(got[16:]) - 1, (hits, len(got))
+
+
+def test_tail_golden_vectors():
+    """committed vectors generated from the reference (tests/golden/make_golden_dvbs.py)"""
+    import json, os, hashlib
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'dvbs_golden.json')) as f:
+        G = json.load(f)
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    o = ot.L()
+    rng = np.random.default_rng(G['rs']['seed'])
+    h = VP(o.orc_dvbsrs_create())
+    outs, errs = [], []
+    for ne in [0, 1, 3, 8, 9, 12, 0, 8, 20, 40, 2, 9, 9, 0, 7, 8, 8, 10, 11, 0] * 2:
+        msg = rng.integers(0, 256, 188, dtype=np.uint8)
+        cw = ot.rs_encode_204(msg)
+        pos = rng.choice(204, ne, replace=False)
+        cw[pos] ^= rng.integers(1, 256, ne, dtype=np.uint8)
+        errs.append(int(o.orc_dvbsrs_decode(h, P(cw))))
+        outs.append(cw.copy())
+    assert errs == G['rs']['errors'] and sha(np.concatenate(outs)) == G['rs']['sha']
+    rng = np.random.default_rng(G['descramble']['seed'])
+    h = VP(o.orc_dvbsdescr_create())
+    outs = []
+    for rep in range(12):
+        frm = rng.integers(0, 256, 1632, dtype=np.uint8)
+        for k in range(8):
+            frm[204 * k] = 0xB8 if (rep % 3 != 0 and k == (rep % 8)) else 0x47
+        o.orc_dvbsdescr_work(h, P(frm))
+        outs.append(frm.copy())
+    assert sha(np.concatenate(outs)) == G['descramble']['sha']
+    bits, _ = ot.dvbs_outer_tx(48, seed=G['deframer']['seeds'][0])
+    rng = np.random.default_rng(G['deframer']['seeds'][1])
+    stream = np.concatenate([rng.integers(0, 2, 777, dtype=np.uint8), bits, 1 - bits[:1632 * 8 * 2]])
+    stream = (stream ^ (rng.random(stream.size) < 0.002)).astype(np.uint8)
+    h = VP(o.orc_tsdef_create())
+    out = np.zeros(1632 * 32, np.uint8)
+    nf = o.orc_tsdef_work(h, P(stream), int(stream.size), P(out), None)
+    assert nf == G['deframer']['frames'] and sha(out[:1632 * nf]) == G['deframer']['sha']
