@@ -868,23 +868,34 @@ __global__ __launch_bounds__(128) void dvbs_rrc_state_kernel(const DvbsStreamWor
 }
 
 // 256-tap complex x real dot product over the wave: 4 taps per lane in order, then a fixed pairwise tree (lane l += lane l + s,
-// s = 32..1) -- the documented order of the engine for COMPLEX_FD (oracle/dvbs_fe.cpp fd_dot).  Result valid in lane 0.
-__device__ __forceinline__ cf32 fd_dot_wave(const cf32 (&x)[4], const float* __restrict__ t, int lane) {
+// s = 32..1) -- the documented order of the engine for COMPLEX_FD (oracle/dvbs_fe.cpp fd_dot).  Result valid in lane 0 and
+// broadcast.  Levels 32 and 16 cross DPP rows (ds_bpermute), levels 8..1 are row shifts (v_add with a DPP operand).
+__device__ __forceinline__ float fd_tree(float a) {
+    a = a + __shfl_down(a, 32);
+    a = a + __shfl_down(a, 16);
+    a = a + DPP_F(a, 0x108);      // row_shl:8  -> lane l reads lane l + 8
+    a = a + DPP_F(a, 0x104);
+    a = a + DPP_F(a, 0x102);
+    a = a + DPP_F(a, 0x101);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 0));
+}
+__device__ __forceinline__ cf32 fd_dot_wave(const cf32 (&x)[4], const float* t, int lane) {
     float ar = 0.f, ai = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const float tt = t[lane + 64 * q]; ar += x[q].re * tt; ai += x[q].im * tt; }
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) { ar = ar + __shfl_down(ar, s); ai = ai + __shfl_down(ai, s); }
-    return cf32{__shfl(ar, 0), __shfl(ai, 0)};
+    return cf32{fd_tree(ar), fd_tree(ai)};
 }
 
 // ONE WAVE PER STREAM: clock_recovery::COMPLEX_FD::process (complex_fd.cpp:89-150, 256 phases x 256 taps, outSps = 1) followed by
-// loop::Costas<4> on every produced symbol (feed-forward after the timing loop).  The interpolator bank (256 KB) stays in L2.
+// loop::Costas<4> on every produced symbol (feed-forward after the timing loop).  The interpolator bank is 256 KB; the loop
+// phase moves slowly, so a window of FD_WROWS consecutive bank rows is kept in LDS and re-centred when the phase leaves it.
 constexpr int FD_TILE = 512;
+constexpr int FD_WROWS = 16;
 __global__ __launch_bounds__(64) void dvbs_fd_costas_kernel(const DvbsStreamWork* __restrict__ work, DvbsLoopCoefs co,
                                                             const float* __restrict__ bank) {
     __shared__ cf32 win[FD_TILE + FD_TAPS];      // [255 history][tile]
     __shared__ cf32 ostage[FD_TILE / 2 + 72];
+    __shared__ float brow[FD_WROWS * FD_TAPS];   // bank rows [wlo, wlo + FD_WROWS)
     const int lane = threadIdx.x;
     const DvbsStreamWork w = work[blockIdx.x];
     DvbsStreamState* st = w.st;
@@ -892,8 +903,10 @@ __global__ __launch_bounds__(64) void dvbs_fd_costas_kernel(const DvbsStreamWork
     PclDev pcl{co.fd_alpha, co.fd_beta, st->fd_phase, st->fd_freq, co.fd_min_freq, co.fd_max_freq};
     PclDev cos{co.cos_alpha, co.cos_beta, st->costas_phase, st->costas_freq, co.cos_min_freq, co.cos_max_freq};
     int offset = st->fd_offset, spsctr = st->fd_spsctr, outCount = 0;
+    int wlo = -1000;                             // no window yet
     for (int i = lane; i < FD_TAPS - 1; i += 64) win[i] = st->fd_hist[i];
     __syncthreads();
+    __builtin_amdgcn_s_setprio(3);               // latency-critical serial loop (see agc_pc_kernel)
     for (int base = 0; base < n; base += FD_TILE) {
         const int m = min(FD_TILE, n - base);
         for (int i = lane; i < m; i += 64) win[FD_TAPS - 1 + i] = w.buf_a[base + i];
@@ -902,22 +915,25 @@ __global__ __launch_bounds__(64) void dvbs_fd_costas_kernel(const DvbsStreamWork
         for (int guard = 0; guard < 4 * FD_TILE && offset < base + m; ++guard) {
             int phase = (int)floorf(pcl.phase * (float)FD_PHASES);
             phase = phase < 0 ? 0 : (phase > FD_PHASES - 1 ? FD_PHASES - 1 : phase);
+            const int pm = phase > 0 ? phase - 1 : phase, pp = phase < FD_PHASES - 1 ? phase + 1 : phase;
+            if (pm < wlo || pp > wlo + FD_WROWS - 1) {                       // re-centre the row window (uniform branch)
+                wlo = phase - FD_WROWS / 2;
+                wlo = wlo < 0 ? 0 : (wlo > FD_PHASES - FD_WROWS ? FD_PHASES - FD_WROWS : wlo);
+                __syncthreads();
+                for (int i = lane; i < FD_WROWS * FD_TAPS; i += 64) brow[i] = bank[(size_t)wlo * FD_TAPS + i];
+                __syncthreads();
+            }
             cf32 x[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) x[q] = win[(offset - base) + lane + 64 * q];
-            const cf32 outVal = fd_dot_wave(x, bank + (size_t)phase * FD_TAPS, lane);
+            const cf32 outVal = fd_dot_wave(x, brow + (phase - wlo) * FD_TAPS, lane);
+            // derivative of the signal from the neighbouring phases (complex_fd.cpp:103-120)
+            const cf32 fT1 = fd_dot_wave(x, brow + (pp - wlo) * FD_TAPS, lane);
+            const cf32 fT_1 = fd_dot_wave(x, brow + (pm - wlo) * FD_TAPS, lane);
             cf32 dfdt;
-            if (phase == 0) {
-                const cf32 fT1 = fd_dot_wave(x, bank + (size_t)(phase + 1) * FD_TAPS, lane);
-                dfdt = csub(fT1, outVal);
-            } else if (phase == FD_PHASES - 1) {
-                const cf32 fT_1 = fd_dot_wave(x, bank + (size_t)(phase - 1) * FD_TAPS, lane);
-                dfdt = csub(outVal, fT_1);
-            } else {
-                const cf32 fT1 = fd_dot_wave(x, bank + (size_t)(phase + 1) * FD_TAPS, lane);
-                const cf32 fT_1 = fd_dot_wave(x, bank + (size_t)(phase - 1) * FD_TAPS, lane);
-                dfdt = cscale(csub(fT1, fT_1), 0.5f);
-            }
+            if (phase == 0) dfdt = csub(fT1, outVal);
+            else if (phase == FD_PHASES - 1) dfdt = csub(outVal, fT_1);
+            else dfdt = cscale(csub(fT1, fT_1), 0.5f);
             float error = spsctr == 0 ? ((outVal.re * dfdt.re) + (outVal.im * dfdt.im)) : 0.f;
             spsctr++;
             if (spsctr >= 1) spsctr = 0;                 // outSps = 1 (qpsk_alt.cpp:22)
