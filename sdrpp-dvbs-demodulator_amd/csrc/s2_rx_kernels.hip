@@ -570,11 +570,13 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
         const cf32* __restrict__ fr = frames[f].sym;
         cf32* __restrict__ out = pllout + (size_t)f * plframe;
         // ---- coarse frequency error detector (dvbs2_fed.h): terms in parallel, summed in the reference's order
+        #pragma unroll 1
         for (int i = gl; i < 88; i += FL_LPS) {
             cf32 r2 = (i + 2) < 26 ? T.sof[i + 2] : plsc[i + 2 - 26];
             cf32 r0 = i < 26 ? T.sof[i] : plsc[i - 26];
             fedt[g][i] = cmul(cmul(cmul(fr[i + 2], cconj(r2)), cconj(fr[i])), r0).im;
         }
+        #pragma unroll 1
         for (int i = gl; i < 90; i += FL_LPS) hdr_sym[g][i] = fr[i];
         __syncthreads();
         float err = 0.f, symcnt = 90 - 2;
@@ -603,6 +605,7 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
         for (int base = 0; base < plframe; base += FL_TILE) {
             const int m = min(FL_TILE, plframe - base);
             __syncthreads();
+            #pragma unroll 1
             for (int i = gl; i < m; i += FL_LPS) tile[g][i] = fr[base + i];
             if (lane < m) {
                 int gi = base + lane;
@@ -660,6 +663,7 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
         hdr.wrap_pi();
         // codeword search: minimum distance, lowest index among the minima (the reference scans 0..127 with strict '<')
         int key = 0x7fffffff;
+        #pragma unroll 1
         for (int c = gl; c < 128; c += FL_LPS) {
             int dd = __popcll((T.plsc_code[c] ^ plheader) & ((1ull << 60) - 1));
             key = min(key, dd * 128 + c);
