@@ -602,16 +602,31 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
         if (nco_freq < -0.3f * PI_F) nco_freq = -0.3f * PI_F;
         // ---- PLL (dvbs2_pll.cpp:34-86), 64-symbol tiles
         int next_pilot = (pilots && pilot_blocks > 0) ? pilot_start(0) : -1, pb = 0;
+        // the next tile's symbols and Gold-sequence values are fetched into registers while the serial loop runs on the current one
+        constexpr int NPF = (FL_TILE + FL_LPS - 1) / FL_LPS;
+        cf32 pf[NPF];
+        int prn = 0;
+        auto fetch = [&](int base) {
+#pragma unroll
+            for (int t = 0; t < NPF; ++t) {
+                const int i = gl + t * FL_LPS;
+                if (i < FL_TILE && base + i < plframe) pf[t] = ldg(fr + base + i);
+            }
+            const int gi = base + lane;
+            prn = (lane < FL_TILE && gi < plframe && gi >= 90) ? T.rn[gi - 90] : 0;
+        };
+        fetch(0);
         for (int base = 0; base < plframe; base += FL_TILE) {
             const int m = min(FL_TILE, plframe - base);
             __syncthreads();
-            #pragma unroll 1
-            for (int i = gl; i < m; i += FL_LPS) tile[g][i] = fr[base + i];
-            if (lane < m) {
-                int gi = base + lane;
-                rnt[lane] = gi >= 90 ? T.rn[gi - 90] : 0;
+#pragma unroll
+            for (int t = 0; t < NPF; ++t) {
+                const int i = gl + t * FL_LPS;
+                if (i < m) tile[g][i] = pf[t];
             }
+            if (lane < m) rnt[lane] = (uint8_t)prn;
             __syncthreads();
+            if (base + FL_TILE < plframe) fetch(base + FL_TILE);
             for (int k = 0; k < m; ++k) {
                 const int i = base + k;
                 cf32 tmp_val = cmul(tile[g][k], phasor_fast(-pll.phase));
