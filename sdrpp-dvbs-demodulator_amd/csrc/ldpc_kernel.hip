@@ -129,12 +129,19 @@ __device__ __forceinline__ s16x2 pmax2(s16x2 a, s16x2 b) { return __builtin_elem
 __device__ __forceinline__ s16x2 pclamp2(s16x2 v, int lo, int hi) { return pmin2(pmax2(v, splat2(lo)), splat2(hi)); }
 __device__ __forceinline__ uint32_t bits2(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ s16x2 from_bits2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
-// message bytes k, k+1 (k even) of a record, sign-extended into the two halves: one v_perm + one packed shift
+// The packed row arithmetic works on values scaled by 256 ("Q8": the int8 quantity sits in the HIGH byte of each 16-bit half):
+// the 16-bit saturating add/subtract of the hardware (v_pk_add_i16 / v_pk_sub_i16 with clamp) then IS the int8 saturation of the
+// reference's SIMD lanes, and message bytes drop into place with one v_perm, no sign extension.  Only the high byte of a half
+// is ever consumed (a positive saturation leaves 0xff below it).  Magnitude sentinel ("no link"): 127 (real ones are <= 126).
+constexpr int Q8_NONE = 127 << 8;
+__device__ __forceinline__ s16x2 q8(int v) { return s16x2{(short)(v << 8), (short)(v << 8)}; }
+__device__ __forceinline__ s16x2 sat_sub2(s16x2 a, s16x2 b) { return __builtin_elementwise_sub_sat(a, b); }
+__device__ __forceinline__ s16x2 sat_add2(s16x2 a, s16x2 b) { return __builtin_elementwise_add_sat(a, b); }
+// message bytes k, k+1 (k even) of a record into the high bytes of the two halves: one v_perm
 template <int REC>
 __device__ __forceinline__ s16x2 rec_pair(const uint32_t (&rec)[REC], int k) {
     const uint32_t w = rec[k >> 2];
-    const uint32_t t = (k & 2) ? __builtin_amdgcn_perm(0u, w, 0x030c020cu) : __builtin_amdgcn_perm(0u, w, 0x010c000cu);
-    return from_bits2(t) >> 8;
+    return from_bits2((k & 2) ? __builtin_amdgcn_perm(0u, w, 0x030c020cu) : __builtin_amdgcn_perm(0u, w, 0x010c000cu));
 }
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -146,7 +153,7 @@ __device__ __forceinline__ uint32_t lds_offset(const int8_t* p) { return (uint32
 // two registers and one v_or joins them (still 1 VALU op per pair instead of 2 sign extensions + a byte permute).
 // Issue only; lds_pairs_wait() below orders the results.
 __device__ __forceinline__ void lds_read_pair_i8(uint32_t a_lo, uint32_t a_hi, uint32_t& r_lo, uint32_t& r_hi) {
-    asm volatile("ds_read_i8_d16 %0, %2\n\tds_read_i8_d16_hi %1, %3" : "=&v"(r_lo), "=&v"(r_hi) : "v"(a_lo), "v"(a_hi) : "memory");
+    asm volatile("ds_read_u8_d16 %0, %2\n\tds_read_u8_d16_hi %1, %3" : "=&v"(r_lo), "=&v"(r_hi) : "v"(a_lo), "v"(a_hi) : "memory");
 }
 __device__ __forceinline__ void lds_pairs_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // Byte stores straight out of the halves of a packed register (ds_write_b8 takes bits 7:0, ds_write_b8_d16_hi bits 23:16): no
@@ -180,12 +187,12 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
     const int own = A.K + 360 * layer + j;
     const bool has_prev = (layer | j) != 0;
     const int prev = layer ? own - 360 : A.K + 360 * (A.q - 1) + j - 1;
-#define LINK_IN(k) ((int)V[(k) >> 1][(k) & 1])
-#define LINK_MG(k) ((int)G[(k) >> 1][(k) & 1])
-#define LINK_SET(k, v, m) do { V[(k) >> 1][(k) & 1] = (short)(v); G[(k) >> 1][(k) & 1] = (short)(m); } while (0)
+#define LINK_IN(k) ((int)V[(k) >> 1][(k) & 1] >> 8)
+#define LINK_MG(k) ((int)G[(k) >> 1][(k) & 1] >> 8)
+#define LINK_SET(k, v, m) do { V[(k) >> 1][(k) & 1] = (short)((v) << 8); G[(k) >> 1][(k) & 1] = (short)((m) << 8); } while (0)
     PROF_T(t_a);
     if (active) {
-        s16x2 MIN0 = splat2(255), MIN1 = splat2(255);
+        s16x2 MIN0 = splat2(Q8_NONE), MIN1 = splat2(Q8_NONE);
         uint32_t SX = 0;
         uint32_t XR[NP], XH[NP];
         const uint32_t JJ = (uint32_t)j * 0x10001u;
@@ -226,22 +233,24 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             asm volatile("" : "+v"(XR[p]), "+v"(XH[p]));
-            const s16x2 X = from_bits2(XR[p] | XH[p]);
+            // byte of the low load -> bits 15:8, byte of the high load (it sits in bits 23:16) -> bits 31:24
+            const s16x2 X = from_bits2(__builtin_amdgcn_perm(XH[p], XR[p], 0x060c000cu));
             bool absent[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int k = 2 * p + h;
                 absent[h] = (k < MAXDEG) ? (IRREG && k >= deg) : (k > MAXDEG + 1);
             }
-            s16x2 v = pclamp2(X - rec_pair<REC>(rec_in, 2 * p), -128, 127);
-            s16x2 g = pclamp2(pmax2(v, splat2(0) - v) - splat2(1), 0, 126);          // mag_of
+            s16x2 v = sat_sub2(X, rec_pair<REC>(rec_in, 2 * p));                     // int8 saturation by the 16-bit clamp
+            const s16x2 av = pmax2(v, sat_sub2(splat2(0), v));
+            s16x2 g = pmin2(__builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, av), (u16x2){256, 256})), q8(126));   // mag_of
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int k = 2 * p + h;
-                if (absent[h]) { v[h] = 0; g[h] = 255; }
-                if (k == MAXDEG + 1 && !has_prev) { v[h] = 0; g[h] = 255; }
+                if (absent[h]) { v[h] = 0; g[h] = (short)Q8_NONE; }
+                if (k == MAXDEG + 1 && !has_prev) { v[h] = 0; g[h] = (short)Q8_NONE; }
                 if constexpr (CONF) {
-                    if (k < MAXC && k < nc && ((late >> k) & 1)) { v[h] = 0; g[h] = 255; }   // joins the totals at its level
+                    if (k < MAXC && k < nc && ((late >> k) & 1)) { v[h] = 0; g[h] = (short)Q8_NONE; }   // joins the totals at its level
                 }
             }
             V[p] = v; G[p] = g;
@@ -250,7 +259,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
             SX ^= bits2(v);
         }
         // merge the even-link and odd-link halves
-        const int a0 = MIN0[0], b0 = MIN0[1], a1 = MIN1[0], b1 = MIN1[1];
+        const int a0 = MIN0[0] >> 8, b0 = MIN0[1] >> 8, a1 = MIN1[0] >> 8, b1 = MIN1[1] >> 8;
         min0 = min(a0, b0);
         min1 = min(max(a0, b0), min(a1, b1));
         sx = (int)(short)(SX ^ (SX >> 16));
@@ -354,7 +363,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
     PROF_T(t_c);
     PROF_ADD(CONF ? 5 : 1, t_b, t_c);
     if (active) {
-        const s16x2 MIN0B = splat2(min0), MIN1B = splat2(min1), NDB = splat2(min0 - min1);
+        const s16x2 MIN0B = q8(min0), MIN1B = q8(min1), NDB = q8(min0 - min1);
         const uint32_t SXB = ((uint32_t)sx & 0xffffu) * 0x10001u;
         s16x2 NM[NP + 1];
         NM[NP] = splat2(0);
@@ -364,12 +373,9 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
             const s16x2 ne = pmin2(G[p] - MIN0B, splat2(1));
             const s16x2 other = ne * NDB + MIN1B;
             const s16x2 neg = from_bits2(SXB ^ bits2(V[p])) >> 15;                   // 0 or -1
-            s16x2 nm = pclamp2(from_bits2(bits2(other) ^ bits2(neg)) - neg, -32, 31);
-            // (the sum goes through an empty asm: otherwise the compiler recognises an int8 saturating add and legalises it
-            // half by half -- 4 shifts, 2 v_add_i16 clamp, 2 shifts, a shuffle -- instead of v_pk_add + v_pk_max + v_pk_min)
-            uint32_t sum_bits = bits2(V[p] + nm);
-            asm volatile("" : "+v"(sum_bits));
-            const s16x2 pn = pclamp2(from_bits2(sum_bits), -128, 127);
+            s16x2 nm = pmin2(pmax2(from_bits2(bits2(other) ^ bits2(neg)) - neg, q8(-32)), q8(31));
+            // new posterior: 16-bit saturating add = int8 saturation; >> 8 brings the bytes to bits 7:0 / 23:16 for the stores
+            const s16x2 pn = from_bits2(bits2(sat_add2(V[p], nm)) >> 8);   // (bits 15:8 then hold junk; the byte stores do not look at them)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int k = 2 * p + h;
@@ -390,7 +396,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
         uint32_t rec_out[REC];
 #pragma unroll
         for (int w = 0; w < REC; ++w) {
-            if (2 * w < NP) rec_out[w] = __builtin_amdgcn_perm(bits2(NM[2 * w + 1 <= NP ? 2 * w + 1 : NP]), bits2(NM[2 * w]), 0x06040200u);
+            if (2 * w < NP) rec_out[w] = __builtin_amdgcn_perm(bits2(NM[2 * w + 1 <= NP ? 2 * w + 1 : NP]), bits2(NM[2 * w]), 0x07050301u);
             else rec_out[w] = 0;
         }
         rec_store<REC>(rec_out, rec_out_ptr);
