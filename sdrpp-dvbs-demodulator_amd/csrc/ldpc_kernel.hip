@@ -363,7 +363,10 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
     PROF_T(t_c);
     PROF_ADD(CONF ? 5 : 1, t_b, t_c);
     if (active) {
-        const s16x2 MIN0B = q8(min0), MIN1B = q8(min1), NDB = q8(min0 - min1);
+        // equality test against the true minimum; the selected magnitude is limited to 32 once per row (the per-link clamp to
+        // [-32, 31] then only needs its upper side)
+        const int min0c = min(min0, 32), min1c = min(min1, 32);
+        const s16x2 MIN0B = q8(min0), MIN1CB = q8(min1c), NDB = q8(min0c - min1c);
         const uint32_t SXB = ((uint32_t)sx & 0xffffu) * 0x10001u;
         s16x2 NM[NP + 1];
         NM[NP] = splat2(0);
@@ -371,9 +374,9 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
         for (int p = 0; p < NP; ++p) {
             // new_msg for both links: other = (mag == min0) ? min1 : min0  ==  min1 + (mag != min0) * (min0 - min1)
             const s16x2 ne = pmin2(G[p] - MIN0B, splat2(1));
-            const s16x2 other = ne * NDB + MIN1B;
+            const s16x2 other = ne * NDB + MIN1CB;
             const s16x2 neg = from_bits2(SXB ^ bits2(V[p])) >> 15;                   // 0 or -1
-            s16x2 nm = pmin2(pmax2(from_bits2(bits2(other) ^ bits2(neg)) - neg, q8(-32)), q8(31));
+            s16x2 nm = pmin2(from_bits2(bits2(other) ^ bits2(neg)) - neg, q8(31));
             // new posterior: 16-bit saturating add = int8 saturation; >> 8 brings the bytes to bits 7:0 / 23:16 for the stores
             const s16x2 pn = from_bits2(bits2(sat_add2(V[p], nm)) >> 8);   // (bits 15:8 then hold junk; the byte stores do not look at them)
 #pragma unroll
