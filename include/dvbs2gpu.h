@@ -280,6 +280,34 @@ int dvbs2gpu_dvbs_tail_process_batch(dvbs2gpu_dvbs_tail* t, const uint8_t* const
 /* h_out11 = {frames of the last call, errors_nor, errors_inv, RS error counts of the last frame's 8 packets} */
 int dvbs2gpu_dvbs_tail_get_stats(dvbs2gpu_dvbs_tail* t, int stream, int32_t* h_out11);
 
+/* ------------------------------------------------------------------ BBFRAME -> MPEG-TS / GSE parser (row f, rank 1)
+ * Replaces dsp::dvbs2::BBFrameTSParser (dvbs2/bbframe_ts_parser.h:68-112, .cpp:31-390), which the reference's sink handler runs
+ * on DVBS2Demod's output (main.cpp:532-558), for `nstreams` independent streams with persistent state (synchronisation,
+ * the TS packet cut by a frame boundary, three GSE reassembly slots).  BBFRAMEs are kbch/8 bytes each, as the engine emits them.
+ * MPEG-TS frames (TS/GS = 11) are packetised on the GPU: header CRC-8 / DFL / SYNCD checks, resynchronisation at SYNCD, one
+ * 0x47 + 187-byte packet per 188 bytes of data field.  A stream that carries a GSE frame (TS/GS = 01) in a call is parsed, for
+ * that call, by the library's native host parser (GSE -> GRE, fragment reassembly with CRC-32), sharing the same state.
+ * Where the reference is undefined the library does this: a GSE packet that would extend beyond the end of the input of the
+ * call ends the parsing of its frame; a PDU that does not fit into the rest of the output buffer or whose reassembled length
+ * is negative is dropped; a fragment overflowing the 64 KiB reassembly buffer frees its slot.
+ * cap must be >= nframes*kbch/8 + 376, else DVBS2GPU_ERR_CAPACITY (the reference stops with "BUFF OVF!" when fewer than 189
+ * bytes are left, .cpp:178,206; with this bound a TS-only call never gets there). */
+typedef struct dvbs2gpu_bbts dvbs2gpu_bbts;
+int dvbs2gpu_bbts_create(dvbs2gpu_ctx* ctx, int nstreams, int kbch_bits, int max_frames, dvbs2gpu_bbts** out);
+/* BBFrameTSParser::setFrameSize (.cpp:31-42): new frame size, synchronisation of every stream forgotten */
+int dvbs2gpu_bbts_set_frame_size(dvbs2gpu_bbts* b, int kbch_bits);
+void dvbs2gpu_bbts_destroy(dvbs2gpu_bbts* b);
+/* d_bb[i]: DEVICE pointer to nframes[i] BBFRAMEs; d_out[i]: DEVICE buffer of cap bytes; out_bytes[i] (host) = bytes produced
+ * (work()'s return value per stream).  Synchronous on `stream`. */
+int dvbs2gpu_bbts_process_batch(dvbs2gpu_bbts* b, const uint8_t* const* d_bb, const int* nframes, uint8_t* const* d_out, int cap,
+                                int* out_bytes, void* stream);
+/* BBFrameTSParser::work for a bank with nstreams == 1 and host buffers: returns the bytes written to h_ts or a negative error */
+int dvbs2gpu_bbts_work(dvbs2gpu_bbts* b, const uint8_t* h_bb, int cnt, uint8_t* h_ts, int cap);
+/* h_out[0..10] = last_header {ts_gs, sis_mis, ccm_acm, issyi, npd, ro, isi, upl, dfl, sync, syncd}, [11] last_gse_crc_err,
+ * [12] last_bb_cnt, [13] last_bb_proc, [14] last_ts_errs (main.cpp reads these for its status lines); n_out >= 15;
+ * with n_out >= 17 also [15] synched, [16] bytes of the carried partial packet */
+int dvbs2gpu_bbts_get_stats(dvbs2gpu_bbts* b, int stream, int32_t* h_out, int n_out);
+
 #ifdef __cplusplus
 }
 #endif

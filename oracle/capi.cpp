@@ -286,3 +286,21 @@ void* orc_dvbsdescr_create() { return new DvbsDescrambler(); }
 void orc_dvbsdescr_destroy(void* h) { delete (DvbsDescrambler*)h; }
 void orc_dvbsdescr_work(void* h, uint8_t* frm1632) { ((DvbsDescrambler*)h)->descramble(frm1632); }
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------- BBFRAME -> TS / GSE parser (bbframe_ts.cpp)
+#include "bbframe_ts.h"
+extern "C" {
+void* orc_bbts_create(int kbch_bits) { auto p = new BbTsParser(); p->set_frame_size(kbch_bits); return p; }
+void orc_bbts_destroy(void* h) { delete (BbTsParser*)h; }
+void orc_bbts_set_frame_size(void* h, int kbch_bits) { ((BbTsParser*)h)->set_frame_size(kbch_bits); }
+int orc_bbts_work(void* h, const uint8_t* bb, int cnt, uint8_t* out, int cap) { return ((BbTsParser*)h)->work(bb, cnt, out, cap); }
+// {ts_gs, sis_mis, ccm_acm, issyi, npd, ro, isi, upl, dfl, sync, syncd, last_gse_crc_err, last_bb_cnt, last_bb_proc, last_ts_errs, synched, count}
+void orc_bbts_get_stats(void* h, int32_t* o17) {
+    const BbTsParser* p = (const BbTsParser*)h;
+    const BbHeader& q = p->last_header;
+    const int v[17] = {q.ts_gs, q.sis_mis, q.ccm_acm, q.issyi, q.npd, q.ro, q.isi, q.upl, q.dfl, q.sync, q.syncd,
+                       p->last_gse_crc_err, p->last_bb_cnt, p->last_bb_proc, p->last_ts_errs, p->synched, p->count};
+    for (int i = 0; i < 17; ++i) o17[i] = v[i];
+}
+unsigned orc_bbts_crc8_bits(const uint8_t* in, int nbits) { return bbts_crc8_bits(in, nbits); }
+}  // extern "C"

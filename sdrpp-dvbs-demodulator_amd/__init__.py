@@ -100,6 +100,12 @@ PROTOTYPES = {
     'dvbs2gpu_dvbs_tail_destroy': (None, [_vp]),
     'dvbs2gpu_dvbs_tail_process_batch': (_i, [_vp, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), _i, C.POINTER(_i), _vp]),
     'dvbs2gpu_dvbs_tail_get_stats': (_i, [_vp, _i, C.POINTER(C.c_int32)]),
+    'dvbs2gpu_bbts_create': (_i, [_vp, _i, _i, _i, C.POINTER(_vp)]),
+    'dvbs2gpu_bbts_set_frame_size': (_i, [_vp, _i]),
+    'dvbs2gpu_bbts_destroy': (None, [_vp]),
+    'dvbs2gpu_bbts_process_batch': (_i, [_vp, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), _i, C.POINTER(_i), _vp]),
+    'dvbs2gpu_bbts_work': (_i, [_vp, _vp, _i, _vp, _i]),
+    'dvbs2gpu_bbts_get_stats': (_i, [_vp, _i, C.POINTER(C.c_int32), _i]),
 }
 
 _lib = None
@@ -508,3 +514,48 @@ class DvbsTailBank(_Handle):
         a = (C.c_int32 * 11)()
         self.eng._check(self.lib.dvbs2gpu_dvbs_tail_get_stats(self.h, stream, a))
         return {'frames': a[0], 'errors_nor': a[1], 'errors_inv': a[2], 'rs_errors': list(a[3:11])}
+
+
+class BbTsParserBank(_Handle):
+    """BBFRAME -> MPEG-TS / GSE parser for `nstreams` DVB-S2 streams: dsp::dvbs2::BBFrameTSParser (bbframe_ts_parser.cpp:104-390),
+    the consumer of DVBS2Demod's output in the reference's sink handler (main.cpp:532-558)."""
+    _destroy = 'dvbs2gpu_bbts_destroy'
+    HEADER_FIELDS = ('ts_gs', 'sis_mis', 'ccm_acm', 'issyi', 'npd', 'ro', 'isi', 'upl', 'dfl', 'sync', 'syncd')
+
+    def __init__(self, engine, nstreams=1, kbch_bits=48408, max_frames=16):
+        self.eng, self.lib, self.nstreams, self.kbch, self.max_frames = engine, engine.lib, nstreams, kbch_bits, max_frames
+        h = C.c_void_p()
+        engine._check(self.lib.dvbs2gpu_bbts_create(engine.h, nstreams, kbch_bits, max_frames, C.byref(h)))
+        self.h = h
+
+    def set_frame_size(self, kbch_bits):
+        self.eng._check(self.lib.dvbs2gpu_bbts_set_frame_size(self.h, kbch_bits))
+        self.kbch = kbch_bits
+
+    def process_batch(self, bb_tensors, out_tensors):
+        """bb_tensors[i]: uint8 CUDA, a whole number of kbch/8-byte BBFRAMEs; out_tensors[i]: uint8 CUDA buffers -> byte counts"""
+        n, fb = self.nstreams, self.kbch // 8
+        pin = (C.c_void_p * n)(*[t.data_ptr() for t in bb_tensors])
+        cnt = (C.c_int * n)(*[int(t.numel()) // fb for t in bb_tensors])
+        pout = (C.c_void_p * n)(*[t.data_ptr() for t in out_tensors])
+        nb = (C.c_int * n)()
+        cap = min(int(t.numel()) for t in out_tensors)
+        self.eng._check(self.lib.dvbs2gpu_bbts_process_batch(self.h, pin, cnt, pout, cap, nb, self.eng._stream()))
+        return list(nb)
+
+    def work(self, bbframes, cap=None):
+        """BBFrameTSParser::work on host buffers (bank of one stream): numpy uint8 in -> numpy uint8 out"""
+        import numpy as np
+        bb = np.ascontiguousarray(bbframes, np.uint8).reshape(-1)
+        cnt = bb.size // (self.kbch // 8)
+        cap = cap if cap is not None else bb.size + 376
+        out = np.zeros(max(cap, 1), np.uint8)
+        n = self.eng._check(self.lib.dvbs2gpu_bbts_work(self.h, C.c_void_p(bb.ctypes.data), cnt, C.c_void_p(out.ctypes.data), cap))
+        return out[:n].copy()
+
+    def stats(self, stream=0):
+        a = (C.c_int32 * 17)()
+        self.eng._check(self.lib.dvbs2gpu_bbts_get_stats(self.h, stream, a, 17))
+        d = {k: a[i] for i, k in enumerate(self.HEADER_FIELDS)}
+        d.update(last_gse_crc_err=a[11], last_bb_cnt=a[12], last_bb_proc=a[13], last_ts_errs=a[14], synched=a[15], count=a[16])
+        return d

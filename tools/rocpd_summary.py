@@ -7,7 +7,7 @@ from collections import defaultdict
 
 
 def short(n):
-    n = n.split('(')[0] if len(n) > 120 else n
+    n = (n.split('(')[0] or n) if len(n) > 120 else n
     return n[:160]
 
 
