@@ -19,7 +19,7 @@ eng.lib.dvbs2gpu_debug_set_prof(C.c_void_p(buf.data_ptr()))
 eng.ldpc_decode(llr, rate, bool(short), max_trials=iters, force=True)
 torch.cuda.synchronize()
 b = buf.cpu().numpy().reshape(6, 16)
-names = ['free:S1', 'free:(none)', 'free:S3', 'barrier', 'conf:S1', 'chain:mid', 'conf:S3', 'prefetch/top', 'level:mid']
+names = ['free:S1', 'free:(none)', 'free:S3', 'barrier', 'conf:S1', 'chain:mid', 'conf:S3', 'prefetch/top', 'level:mid', 'ch:publish', 'ch:bar1', 'ch:walk', 'ch:bar2']
 print(pi)
 for w in range(6):
-    print('wave', w, ' '.join('%s=%.0f' % (names[i], b[w, i] / iters) for i in range(9)), 'total/iter=%.0f cycles' % (b[w, :8].sum() / iters))
+    print('wave', w, ' '.join('%s=%.0f' % (names[i], b[w, i] / iters) for i in range(len(names))), 'total/iter=%.0f cycles' % (b[w, :8].sum() / iters))
