@@ -138,9 +138,10 @@ static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, 
     int rc = get_ldpc(ctx, f.code_index, &C);
     if (rc) return rc;
     // workgroups hold LDPC_FPB = 2 frame slots (ldpc_kernel.hip)
+    const int fpb = ldpc_frames_per_block();
     int grid = ctx->num_cus * C->blocks_per_cu;
-    if (grid > (nframes + 1) / 2) grid = (nframes + 1) / 2;
-    size_t need = (size_t)grid * 2 * C->R * C->rec_dwords * sizeof(uint32_t);
+    if (grid > (nframes + fpb - 1) / fpb) grid = (nframes + fpb - 1) / fpb;
+    size_t need = (size_t)grid * fpb * C->R * C->rec_dwords * sizeof(uint32_t);
     if ((rc = ctx->ws_msg.ensure(need + 256))) return rc;   // + the dynamic work counter
     if (!d_trials) {
         if ((rc = ctx->ws_misc.ensure((size_t)nframes * 2 * sizeof(int32_t)))) return rc;

@@ -506,7 +506,10 @@ __device__ __forceinline__ bool rows_bad(const int8_t* __restrict__ post, const 
 // workgroup barriers are shared (half the barrier cost per frame), the serial chain / level phases of the two
 // frames overlap, and one 12-wave workgroup per CU always gets 3 waves on each SIMD (two independent 6-wave
 // workgroups only co-reside when the dispatcher happens to start them on complementary SIMDs).
-constexpr int LDPC_FPB = 2;          // frame slots per workgroup
+#ifndef LDPC_FPB_N
+#define LDPC_FPB_N 2
+#endif
+constexpr int LDPC_FPB = LDPC_FPB_N;  // frame slots per workgroup (1: development variant, two independent workgroups per CU)
 constexpr int LDPC_TPS = 384;        // threads per slot
 
 template <int MAXDEG, int REC, bool IRREG>
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS, 3) void ldpc_decode_kernel(con
             }
             if (j == 0) s_done[fs] = done;
             lds_barrier();
-            if (s_done[0] && s_done[1]) break;
+            if (s_done[0] && s_done[LDPC_FPB - 1]) break;
             // ---- one layered sweep (LDPCDecoder::update), descriptors / records / row words prefetched one layer ahead
             const bool active = lane_ok && !done;
             const bool first = (it == 0);
@@ -683,6 +686,8 @@ static int occupancy_ldpc(int N) {
             default: break;                                                                \
         }                                                                                  \
     }
+
+int ldpc_frames_per_block() { return LDPC_FPB; }
 
 int ldpc_blocks_per_cu(int max_deg, int irregular, int N) {
     LDPC_DISPATCH(occupancy_ldpc, N)
