@@ -162,24 +162,29 @@ __device__ __forceinline__ void lds_pairs_wait() { asm volatile("s_waitcnt lgkmc
 __device__ __forceinline__ void lds_write_lo_i8(uint32_t addr, uint32_t packed) { asm volatile("ds_write_b8 %0, %1" ::"v"(addr), "v"(packed) : "memory"); }
 __device__ __forceinline__ void lds_write_hi_i8(uint32_t addr, uint32_t packed) { asm volatile("ds_write_b8_d16_hi %0, %1" ::"v"(addr), "v"(packed) : "memory"); }
 
-// One row of the chain walk (KIND 1 layers) on Q8 values held in the low half of a register.  x8: the posterior the previous
-// row's E link left (clean low byte).  Hand-off word w of the row: bits 15:0 = mL ^ SM (Q8; SM = 0xffff when the row's sign
-// product is negative, so the low byte is 0x00 / 0xff and doubles as the mask), bits 23:16 = min(qE, 32), bits 31:24 = in_E.
-// Per row the reference computes  vL = sat8(x - mL), mag = min(qE, max(|vL| - 1, 0)), nm = clamp(+-mag, -32, 31) with the
-// sign of vL (flipped when SM), x' = sat8(in_E + nm).  Here: a negative sign product is folded into the subtraction
-// (~x - ~mL = mL - x, the low 0xff bytes cancel), +-mag with the sign of v is clamp(v, -mag, mag) because mag < |v| whenever
-// v != 0, and in_E is added as the half {in_E, qc}: the low byte cannot carry and is cleared afterwards.
-__device__ __forceinline__ uint32_t chain_step(uint32_t x8, uint32_t w) {
-    typedef short s16;
-    typedef unsigned short u16;
-    const s16 SM = (s16)(int8_t)(w & 0xffu), mS = (s16)w, vEq = (s16)(w >> 16);
-    const u16 qc = (u16)((w >> 8) & 0xff00u);
-    const s16 v = __builtin_elementwise_sub_sat((s16)((s16)x8 ^ SM), mS);
-    const s16 av = __builtin_elementwise_max(v, __builtin_elementwise_sub_sat((s16)0, v));
-    const u16 mg = __builtin_elementwise_min((u16)(__builtin_elementwise_sub_sat((u16)av, (u16)256) & 0xff00u), qc);
-    s16 nm = __builtin_elementwise_min(__builtin_elementwise_max(v, (s16)(-(s16)mg)), (s16)mg);
-    nm = __builtin_elementwise_min(nm, (s16)(31 << 8));
-    return (uint32_t)(int)__builtin_elementwise_add_sat(vEq, nm) & 0xffffff00u;   // (only the low half is ever used)
+// One row of the chain walk (KIND 1 layers).  Per row the reference computes, from the posterior x the previous row's E link
+// left:  vL = sat8(x - mL), mag = min(qE, max(|vL| - 1, 0)), nm = clamp(+-mag, -32, 31) with the sign of vL (flipped when the
+// row's sign product is negative: s = -1), x' = sat8(in_E + nm).  As a function of x that is
+//     x' = sat8(E' + s * (clamp(x, m + 1, m + CA) + clamp(x, m - CB, m - 1))),   E' = in_E - 2 s m,
+// with (CA, CB) = (min(qE, 31) + 1, min(qE, 32) + 1) for s = +1 and swapped for s = -1: the dead zone |x - m| <= 1, the unit
+// slope and the two saturation levels are the two clamps, checked exhaustively against the reference form over
+// x, in_E in int8, m in [-32, 31], all qE, both signs.  Hand-off record of a row: {L1 | L2 << 16, H1 | H2 << 16, s | E' << 16}
+// (int16 halves) = the operands of v_pk_max_i16, v_pk_min_i16 and v_mad_i16: 5 VALU operations on the serial path.
+struct ChainRec { uint32_t lo, hi, se; };
+__device__ __forceinline__ ChainRec chain_record(int m, int qE, int vE, int sneg /* 0 or -1 */) {
+    const int sig = 1 | sneg;
+    const int c31 = min(qE, 31), c32 = min(qE, 32);
+    const int CA = (sneg ? c32 : c31) + 1, CB = (sneg ? c31 : c32) + 1;
+    ChainRec r;
+    r.lo = ((uint32_t)(m + 1) & 0xffffu) | ((uint32_t)(m - CB) << 16);
+    r.hi = ((uint32_t)(m + CA) & 0xffffu) | ((uint32_t)(m - 1) << 16);
+    r.se = ((uint32_t)sig & 0xffffu) | ((uint32_t)(vE - 2 * sig * m) << 16);
+    return r;
+}
+__device__ __forceinline__ int chain_step(int x, uint32_t lo, uint32_t hi, uint32_t se) {
+    const int q1 = min(max(x, (int)(short)lo), (int)(short)hi);
+    const int q2 = min(max(x, (int)lo >> 16), (int)hi >> 16);
+    return clamp8(((int)se >> 16) + (int)(short)se * (q1 + q2));
 }
 
 // One sweep step for one layer.  CONF = layer has intra-layer shared bits (links 0..nc-1), IRREG = the
@@ -190,7 +195,7 @@ template <int MAXDEG, int REC, int KIND, bool IRREG>
 __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const LdpcKernelArgs& A, const uint32_t* __restrict__ ents,
                                              const uint32_t* __restrict__ pents, const LdpcLayerDesc L, uint32_t rowword, int layer, int j, bool active,
                                              const uint32_t (&rec_in)[REC], uint32_t* __restrict__ rec_out_ptr,
-                                             uint32_t* __restrict__ cw, uint16_t* __restrict__ cres) {
+                                             uint32_t* __restrict__ cw, uint8_t* __restrict__ cres) {
     constexpr int NL = MAXDEG + 2;
     constexpr int NP = (NL + 1) / 2;
     // KIND 0: no shared bits in the layer; 1: one shared pair resolved by the chain walk (links 0, 1 only); 2: general levels
@@ -306,11 +311,10 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                     }
                 }
                 if ((late >> 1) & 1) {
-                    // hand-off word in the walk's own number format (see chain_step)
+                    // hand-off record in the walk's own form (see chain_step)
                     const int qE = (late & 1u) ? 255 : ((LINK_MG(0) == min0) ? min1 : min0);
-                    const uint32_t SM = ((sx ^ LINK_IN(0)) >> 31) & 0xffffu;
-                    const uint32_t mS = (((uint32_t)rec_byte<REC>(rec_in, 1) & 0xffu) << 8) ^ SM;
-                    cw[j] = mS | ((uint32_t)min(qE, 32) << 16) | ((uint32_t)LINK_IN(0) << 24);
+                    const ChainRec r = chain_record(rec_byte<REC>(rec_in, 1), qE, LINK_IN(0), (sx ^ LINK_IN(0)) >> 31);
+                    cw[3 * j] = r.lo; cw[3 * j + 1] = r.hi; cw[3 * j + 2] = r.se;
                 }
             }
             PROF_T(t_m1);
@@ -320,55 +324,54 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                 // lane c walks rows c + k*d, k = 1..T with T = floor(359 / d): rows k < T exist for every lane, row T only
                 // where c + T*d < 360.  Only this wave is running (the others wait at the barrier), so the walk is bound by
                 // the instructions it issues: uniform trip count (scalar loop), two rows per trip, the hand-off record of a
-                // row re-fetched into the register pair just consumed (two rows of LDS latency cover), plain address
-                // increments -- 16 instructions per row, written out so that they stay that way.
+                // row re-fetched into the registers just consumed (two rows of LDS latency cover), plain address
+                // increments -- 11 instructions per row, written out so that they stay that way.
                 const uint32_t eL = ents[1];
                 const int T = 359 / chain_d;
-                uint32_t x8 = ((uint32_t)post[link_addr(eL, j + chain_d)] & 0xffu) << 8;   // written by the level-1 row j (its E link)
+                int x = post[link_addr(eL, j + chain_d)];                 // written by the level-1 row j (its E link)
                 // (records beyond row 359 are fetched but never used: the addresses stay inside the workgroup's LDS allocation)
-                uint32_t wa = cw[j + chain_d], wb = cw[j + 2 * chain_d];
-                uint32_t pa = lds_offset(reinterpret_cast<const int8_t*>(cw + j + 3 * chain_d)), pb = pa + 4u * (uint32_t)chain_d;
-                uint32_t ra = lds_offset(reinterpret_cast<const int8_t*>(cres + j + chain_d)), rb = ra + 2u * (uint32_t)chain_d;
-                const uint32_t sa = 8u * (uint32_t)chain_d, sr = 4u * (uint32_t)chain_d;
-                const uint32_t c256 = 256u, c31 = 31u << 8;
+                const uint32_t* c1 = cw + 3 * (j + chain_d);
+                const uint32_t* c2 = c1 + 3 * chain_d;
+                uint32_t al = c1[0], ah = c1[1], as = c1[2], bl = c2[0], bh = c2[1], bs = c2[2];
+                uint32_t pa = lds_offset(reinterpret_cast<const int8_t*>(c2 + 3 * chain_d)), pb = pa + 12u * (uint32_t)chain_d;
+                uint32_t ra = lds_offset(reinterpret_cast<const int8_t*>(cres + j + chain_d)), rb = ra + (uint32_t)chain_d;
+                const uint32_t sa = 24u * (uint32_t)chain_d, sr = 2u * (uint32_t)chain_d;
+                const int cm128 = -128, c127 = 127;
                 const int ntrips = (T - 1) >> 1;
-                asm volatile("" : "+v"(wa), "+v"(wb), "+v"(x8));     // (consumes the loads here, so that the compiler's own wait is not placed inside the loop)
+                asm volatile("" : "+v"(al), "+v"(ah), "+v"(as), "+v"(bl), "+v"(bh), "+v"(bs), "+v"(x));   // (consumes the loads here, so that the compiler's own wait is not placed inside the loop)
                 for (int t = 0; t < ntrips; ++t) {
-                    uint32_t t0, t1, t2;
-                    // LDS operations complete in order: when a row's arithmetic starts, the three younger ones (the other row's
-                    // write and fetch, this row's write) may still be in flight -> lgkmcnt(3)
-#define CHAIN_ROW(W, PA, RA)                                                                                                       \
-                    "ds_write_b16 %[" RA "], %[x]\n\t"                                                                                   \
-                    "s_waitcnt lgkmcnt(3)\n\t"                                                                                           \
-                    "v_xor_b32_sdwa %[t0], sext(%[" W "]), %[x] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"  \
-                    "v_sub_i16 %[t1], %[t0], %[" W "] clamp\n\t"                                                                         \
-                    "v_sub_i16 %[t0], 0, %[t1] clamp\n\t"                                                                                \
-                    "v_max_i16_e32 %[t0], %[t1], %[t0]\n\t"                                                                              \
-                    "v_sub_u16_e64 %[t0], %[t0], %[c256] clamp\n\t"                                                                      \
-                    "v_min_u16_sdwa %[t0], %[t0], %[" W "] dst_sel:BYTE_1 dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2\n\t"     \
-                    "v_add_u32_e32 %[" RA "], %[sr], %[" RA "]\n\t"   /* (also the wait state a dst_sel write needs before its use) */   \
-                    "v_sub_u16_e32 %[t2], 0, %[t0]\n\t"                                                                                  \
-                    "v_max_i16_e32 %[t1], %[t1], %[t2]\n\t"                                                                              \
-                    "v_min3_i16 %[t1], %[t1], %[t0], %[c31]\n\t"                                                                         \
-                    "v_add_i16 %[t1], %[" W "], %[t1] op_sel:[1,0,0] clamp\n\t"                                                          \
-                    "v_and_b32_e32 %[x], 0xffffff00, %[t1]\n\t"                                                                          \
-                    "ds_read_b32 %[" W "], %[" PA "]\n\t"                                                                                \
-                    "v_add_u32_e32 %[" PA "], %[sa], %[" PA "]\n\t"
-                    asm volatile(CHAIN_ROW("wa", "pa", "ra") CHAIN_ROW("wb", "pb", "rb")
-                                 : [x] "+v"(x8), [wa] "+v"(wa), [wb] "+v"(wb), [pa] "+v"(pa), [pb] "+v"(pb), [ra] "+v"(ra), [rb] "+v"(rb),
-                                   [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
-                                 : [sa] "s"(sa), [sr] "s"(sr), [c256] "s"(c256), [c31] "s"(c31)
+                    uint32_t t0;
+                    // LDS operations complete in order: when a row's arithmetic starts, the five younger ones (the other row's
+                    // write and three fetches, this row's write) may still be in flight -> lgkmcnt(5)
+#define CHAIN_ROW(L, H, S, PA, RA)                                                                  \
+                    "ds_write_b8 %[" RA "], %[x]\n\t"                                                     \
+                    "s_waitcnt lgkmcnt(5)\n\t"                                                            \
+                    "v_pk_max_i16 %[t0], %[x], %[" L "] op_sel_hi:[0,1]\n\t"                              \
+                    "v_pk_min_i16 %[t0], %[t0], %[" H "]\n\t"                                             \
+                    "v_add_i16 %[t0], %[t0], %[t0] op_sel:[0,1,0]\n\t"                                    \
+                    "v_mad_i16 %[t0], %[t0], %[" S "], %[" S "] op_sel:[0,0,1,0]\n\t"                     \
+                    "v_med3_i16 %[x], %[t0], %[cm128], %[c127]\n\t"                                       \
+                    "ds_read_b32 %[" L "], %[" PA "]\n\t"                                                 \
+                    "ds_read_b32 %[" H "], %[" PA "] offset:4\n\t"                                        \
+                    "ds_read_b32 %[" S "], %[" PA "] offset:8\n\t"                                        \
+                    "v_add_u32_e32 %[" PA "], %[sa], %[" PA "]\n\t"                                       \
+                    "v_add_u32_e32 %[" RA "], %[sr], %[" RA "]\n\t"
+                    asm volatile(CHAIN_ROW("al", "ah", "as", "pa", "ra") CHAIN_ROW("bl", "bh", "bs", "pb", "rb")
+                                 : [x] "+v"(x), [al] "+v"(al), [ah] "+v"(ah), [as] "+v"(as), [bl] "+v"(bl), [bh] "+v"(bh), [bs] "+v"(bs),
+                                   [pa] "+v"(pa), [pb] "+v"(pb), [ra] "+v"(ra), [rb] "+v"(rb), [t0] "=&v"(t0)
+                                 : [sa] "s"(sa), [sr] "s"(sr), [cm128] "v"(cm128), [c127] "v"(c127)
                                  : "memory");
 #undef CHAIN_ROW
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wa), "+v"(wb)::"memory");
-                uint16_t* pr = reinterpret_cast<uint16_t*>(cres) + j + chain_d * (1 + 2 * ntrips);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(al), "+v"(ah), "+v"(as), "+v"(x)::"memory");
+                x = (int)(short)x;
+                uint8_t* pr = reinterpret_cast<uint8_t*>(cres) + j + chain_d * (1 + 2 * ntrips);
                 if ((T - 1) & 1) {
-                    pr[0] = (uint16_t)x8;
-                    x8 = chain_step(x8, wa);
+                    pr[0] = (uint8_t)x;
+                    x = chain_step(x, al, ah, as);
                     pr += chain_d;
                 }
-                if (j + T * chain_d < 360) pr[0] = (uint16_t)x8;
+                if (j + T * chain_d < 360) pr[0] = (uint8_t)x;
             }
             PROF_T(t_m3);
             lds_barrier();
@@ -376,7 +379,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
             PROF_ADD(9, t_m0, t_m1); PROF_ADD(10, t_m1, t_m2); PROF_ADD(11, t_m2, t_m3); PROF_ADD(12, t_m3, t_m4);
             if (active) {
                 if ((late >> 1) & 1) {
-                    int v = clamp8((int)(int8_t)(cres[j] >> 8) - rec_byte<REC>(rec_in, 1));
+                    int v = clamp8((int)(int8_t)cres[j] - rec_byte<REC>(rec_in, 1));
                     int m = mag_of(v);
                     LINK_SET(1, v, m);
                     ROW_ACCUM(v, m);
@@ -420,7 +423,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
         }
     }
     PROF_T(t_c);
-    PROF_ADD(CONF ? 5 : 1, t_b, t_c);
+    PROF_ADD(KIND == 2 ? 8 : (CONF ? 5 : 1), t_b, t_c);
     if (active) {
         // equality test against the true minimum; the selected magnitude is limited to 32 once per row (the per-link clamp to
         // [-32, 31] then only needs its upper side)
@@ -518,8 +521,8 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS, 3) void ldpc_decode_kernel(con
     extern __shared__ __attribute__((aligned(16))) int8_t post_all[];
     __shared__ int s_flag[LDPC_FPB][8];
     __shared__ int s_done[LDPC_FPB];
-    __shared__ uint32_t s_cw[LDPC_FPB][360];      // chain-walk hand-off words (conflict layers with a single shared pair)
-    __shared__ uint16_t s_cres[LDPC_FPB][384];
+    __shared__ uint32_t s_cw[LDPC_FPB][3 * 360];  // chain-walk hand-off records (conflict layers with a single shared pair)
+    __shared__ uint8_t s_cres[LDPC_FPB][384];
     const int fs = threadIdx.x / LDPC_TPS;
     const int j = threadIdx.x - fs * LDPC_TPS;
     const int N = A.N, K = A.K, R = A.R, q = A.q;
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS, 3) void ldpc_decode_kernel(con
     int8_t* __restrict__ post = post_all + (size_t)fs * npad;
     uint32_t* __restrict__ msg = A.msg_ws + ((size_t)blockIdx.x * LDPC_FPB + fs) * (size_t)R * REC;
     uint32_t* __restrict__ cw = s_cw[fs];
-    uint16_t* __restrict__ cres = s_cres[fs];
+    uint8_t* __restrict__ cres = s_cres[fs];
 
     __shared__ int s_next;
     int f0 = blockIdx.x * LDPC_FPB;

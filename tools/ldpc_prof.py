@@ -22,4 +22,4 @@ b = buf.cpu().numpy().reshape(6, 16)
 names = ['free:S1', 'free:(none)', 'free:S3', 'barrier', 'conf:S1', 'chain:mid', 'conf:S3', 'prefetch/top', 'level:mid', 'ch:publish', 'ch:bar1', 'ch:walk', 'ch:bar2']
 print(pi)
 for w in range(6):
-    print('wave', w, ' '.join('%s=%.0f' % (names[i], b[w, i] / iters) for i in range(len(names))), 'total/iter=%.0f cycles' % (b[w, :8].sum() / iters))
+    print('wave', w, ' '.join('%s=%.0f' % (names[i], b[w, i] / iters) for i in range(len(names))), 'total/iter=%.0f cycles' % ((b[w, :9].sum()) / iters))
