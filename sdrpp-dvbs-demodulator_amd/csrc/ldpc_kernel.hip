@@ -168,22 +168,21 @@ __device__ __forceinline__ void lds_write_hi_i8(uint32_t addr, uint32_t packed) 
 //     x' = sat8(E' + s * (clamp(x, m + 1, m + CA) + clamp(x, m - CB, m - 1))),   E' = in_E - 2 s m,
 // with (CA, CB) = (min(qE, 31) + 1, min(qE, 32) + 1) for s = +1 and swapped for s = -1: the dead zone |x - m| <= 1, the unit
 // slope and the two saturation levels are the two clamps, checked exhaustively against the reference form over
-// x, in_E in int8, m in [-32, 31], all qE, both signs.  Hand-off record of a row: {L1 | L2 << 16, H1 | H2 << 16, s | E' << 16}
-// (int16 halves) = the operands of v_pk_max_i16, v_pk_min_i16 and v_mad_i16: 5 VALU operations on the serial path.
-struct ChainRec { uint32_t lo, hi, se; };
+// x, in_E in int8, m in [-32, 31], all qE, both signs.  Hand-off record of a row: two dwords, the four clamp limits as bytes and
+// {s, E'} as halves (operands the compiler picks apart with SDWA selects): two clamps, an add and a multiply-add per row.
+struct ChainRec { uint32_t lim, se; };   // lim = bytes {L1, H1, L2, H2} (each within [-66, 65]), se = s | E' << 16
 __device__ __forceinline__ ChainRec chain_record(int m, int qE, int vE, int sneg /* 0 or -1 */) {
     const int sig = 1 | sneg;
     const int c31 = min(qE, 31), c32 = min(qE, 32);
     const int CA = (sneg ? c32 : c31) + 1, CB = (sneg ? c31 : c32) + 1;
     ChainRec r;
-    r.lo = ((uint32_t)(m + 1) & 0xffffu) | ((uint32_t)(m - CB) << 16);
-    r.hi = ((uint32_t)(m + CA) & 0xffffu) | ((uint32_t)(m - 1) << 16);
+    r.lim = ((uint32_t)(m + 1) & 0xffu) | (((uint32_t)(m + CA) & 0xffu) << 8) | (((uint32_t)(m - CB) & 0xffu) << 16) | ((uint32_t)(m - 1) << 24);
     r.se = ((uint32_t)sig & 0xffffu) | ((uint32_t)(vE - 2 * sig * m) << 16);
     return r;
 }
-__device__ __forceinline__ int chain_step(int x, uint32_t lo, uint32_t hi, uint32_t se) {
-    const int q1 = min(max(x, (int)(short)lo), (int)(short)hi);
-    const int q2 = min(max(x, (int)lo >> 16), (int)hi >> 16);
+__device__ __forceinline__ int chain_step(int x, uint32_t lim, uint32_t se) {
+    const int q1 = min(max(x, (int)(int8_t)lim), (int)(int8_t)(lim >> 8));
+    const int q2 = min(max(x, (int)(int8_t)(lim >> 16)), (int)lim >> 24);
     return clamp8(((int)se >> 16) + (int)(short)se * (q1 + q2));
 }
 
@@ -314,7 +313,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                     // hand-off record in the walk's own form (see chain_step)
                     const int qE = (late & 1u) ? 255 : ((LINK_MG(0) == min0) ? min1 : min0);
                     const ChainRec r = chain_record(rec_byte<REC>(rec_in, 1), qE, LINK_IN(0), (sx ^ LINK_IN(0)) >> 31);
-                    cw[3 * j] = r.lo; cw[3 * j + 1] = r.hi; cw[3 * j + 2] = r.se;
+                    reinterpret_cast<uint2*>(cw)[j] = make_uint2(r.lim, r.se);
                 }
             }
             PROF_T(t_m1);
@@ -323,52 +322,35 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
             if (j < chain_d && active) {
                 // lane c walks rows c + k*d, k = 1..T with T = floor(359 / d): rows k < T exist for every lane, row T only
                 // where c + T*d < 360.  Only this wave is running (the others wait at the barrier), so the walk is bound by
-                // the instructions it issues: uniform trip count (scalar loop), two rows per trip, the hand-off record of a
-                // row re-fetched into the registers just consumed (two rows of LDS latency cover), plain address
-                // increments -- 11 instructions per row, written out so that they stay that way.
+                // the instructions it issues: uniform trip count (scalar loop), two rows per trip, hand-off records fetched two
+                // rows ahead, plain address increments.  (A hand-scheduled assembly version of this loop -- 11 instructions
+                // per row -- was bit-exact on its own and 1 % faster, but produced wrong frames when the front-end kernels of
+                // the pipelined mode shared the CUs; the cause was not found, so the loop is left to the compiler.)
                 const uint32_t eL = ents[1];
                 const int T = 359 / chain_d;
                 int x = post[link_addr(eL, j + chain_d)];                 // written by the level-1 row j (its E link)
-                // (records beyond row 359 are fetched but never used: the addresses stay inside the workgroup's LDS allocation)
-                const uint32_t* c1 = cw + 3 * (j + chain_d);
-                const uint32_t* c2 = c1 + 3 * chain_d;
-                uint32_t al = c1[0], ah = c1[1], as = c1[2], bl = c2[0], bh = c2[1], bs = c2[2];
-                uint32_t pa = lds_offset(reinterpret_cast<const int8_t*>(c2 + 3 * chain_d)), pb = pa + 12u * (uint32_t)chain_d;
-                uint32_t ra = lds_offset(reinterpret_cast<const int8_t*>(cres + j + chain_d)), rb = ra + (uint32_t)chain_d;
-                const uint32_t sa = 24u * (uint32_t)chain_d, sr = 2u * (uint32_t)chain_d;
-                const int cm128 = -128, c127 = 127;
-                const int ntrips = (T - 1) >> 1;
-                asm volatile("" : "+v"(al), "+v"(ah), "+v"(as), "+v"(bl), "+v"(bh), "+v"(bs), "+v"(x));   // (consumes the loads here, so that the compiler's own wait is not placed inside the loop)
-                for (int t = 0; t < ntrips; ++t) {
-                    uint32_t t0;
-                    // LDS operations complete in order: when a row's arithmetic starts, the five younger ones (the other row's
-                    // write and three fetches, this row's write) may still be in flight -> lgkmcnt(5)
-#define CHAIN_ROW(L, H, S, PA, RA)                                                                  \
-                    "ds_write_b8 %[" RA "], %[x]\n\t"                                                     \
-                    "s_waitcnt lgkmcnt(5)\n\t"                                                            \
-                    "v_pk_max_i16 %[t0], %[x], %[" L "] op_sel_hi:[0,1]\n\t"                              \
-                    "v_pk_min_i16 %[t0], %[t0], %[" H "]\n\t"                                             \
-                    "v_add_i16 %[t0], %[t0], %[t0] op_sel:[0,1,0]\n\t"                                    \
-                    "v_mad_i16 %[t0], %[t0], %[" S "], %[" S "] op_sel:[0,0,1,0]\n\t"                     \
-                    "v_med3_i16 %[x], %[t0], %[cm128], %[c127]\n\t"                                       \
-                    "ds_read_b32 %[" L "], %[" PA "]\n\t"                                                 \
-                    "ds_read_b32 %[" H "], %[" PA "] offset:4\n\t"                                        \
-                    "ds_read_b32 %[" S "], %[" PA "] offset:8\n\t"                                        \
-                    "v_add_u32_e32 %[" PA "], %[sa], %[" PA "]\n\t"                                       \
-                    "v_add_u32_e32 %[" RA "], %[sr], %[" RA "]\n\t"
-                    asm volatile(CHAIN_ROW("al", "ah", "as", "pa", "ra") CHAIN_ROW("bl", "bh", "bs", "pb", "rb")
-                                 : [x] "+v"(x), [al] "+v"(al), [ah] "+v"(ah), [as] "+v"(as), [bl] "+v"(bl), [bh] "+v"(bh), [bs] "+v"(bs),
-                                   [pa] "+v"(pa), [pb] "+v"(pb), [ra] "+v"(ra), [rb] "+v"(rb), [t0] "=&v"(t0)
-                                 : [sa] "s"(sa), [sr] "s"(sr), [cm128] "v"(cm128), [c127] "v"(c127)
-                                 : "memory");
-#undef CHAIN_ROW
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(al), "+v"(ah), "+v"(as), "+v"(x)::"memory");
-                x = (int)(short)x;
-                uint8_t* pr = reinterpret_cast<uint8_t*>(cres) + j + chain_d * (1 + 2 * ntrips);
-                if ((T - 1) & 1) {
+                const uint2* c = reinterpret_cast<const uint2*>(cw) + j + chain_d;
+                uint8_t* pr = reinterpret_cast<uint8_t*>(cres) + j + chain_d;
+                // records are fetched two rows ahead (those beyond row 359 are read but never used: the addresses stay inside
+                // the workgroup's LDS allocation)
+                uint2 ra = c[0], rb = c[chain_d];
+                c += 2 * chain_d;
+                int k = 1;
+                for (; k + 2 <= T; k += 2) {
+                    const uint2 na = c[0];
                     pr[0] = (uint8_t)x;
-                    x = chain_step(x, al, ah, as);
+                    x = chain_step(x, ra.x, ra.y);
+                    ra = na;
+                    const uint2 nb = c[chain_d];
+                    pr[chain_d] = (uint8_t)x;
+                    x = chain_step(x, rb.x, rb.y);
+                    rb = nb;
+                    c += 2 * chain_d;
+                    pr += 2 * chain_d;
+                }
+                if (k < T) {
+                    pr[0] = (uint8_t)x;
+                    x = chain_step(x, ra.x, ra.y);
                     pr += chain_d;
                 }
                 if (j + T * chain_d < 360) pr[0] = (uint8_t)x;
@@ -521,7 +503,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS, 3) void ldpc_decode_kernel(con
     extern __shared__ __attribute__((aligned(16))) int8_t post_all[];
     __shared__ int s_flag[LDPC_FPB][8];
     __shared__ int s_done[LDPC_FPB];
-    __shared__ uint32_t s_cw[LDPC_FPB][3 * 360];  // chain-walk hand-off records (conflict layers with a single shared pair)
+    __shared__ uint32_t s_cw[LDPC_FPB][2 * 360];  // chain-walk hand-off records (conflict layers with a single shared pair)
     __shared__ uint8_t s_cres[LDPC_FPB][384];
     const int fs = threadIdx.x / LDPC_TPS;
     const int j = threadIdx.x - fs * LDPC_TPS;
