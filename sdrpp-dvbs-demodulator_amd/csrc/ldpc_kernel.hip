@@ -197,10 +197,13 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                                              uint32_t* __restrict__ cw, uint8_t* __restrict__ cres) {
     constexpr int NL = MAXDEG + 2;
     constexpr int NP = (NL + 1) / 2;
-    // KIND 0: no shared bits in the layer; 1: one shared pair resolved by the chain walk (links 0, 1 only); 2: general levels
+    // KIND 0: no shared bits in the layer; 1: one shared pair resolved by the chain walk (links 0, 1 only); 2: general levels;
+    // 3: levels, at most 4 shared links
     constexpr bool CONF = KIND != 0;
     constexpr int MAXC_ALL = MAXDEG < LDPC_MAX_CONFLICT_LINKS ? MAXDEG : LDPC_MAX_CONFLICT_LINKS;
-    constexpr int MAXC = KIND == 1 ? (MAXDEG < 2 ? MAXDEG : 2) : MAXC_ALL;
+    // KIND 3 = KIND 2 for layers with at most 4 shared links: the per-level code only tests those (every tested link costs scalar
+    // branches per level whether or not a row uses it)
+    constexpr int MAXC = KIND == 1 ? (MAXDEG < 2 ? MAXDEG : 2) : KIND == 3 ? (MAXDEG < 4 ? MAXDEG : 4) : MAXC_ALL;
     s16x2 V[NP], G[NP];        // extrinsic inputs and their offset magnitudes
     uint32_t addr[MAXDEG];     // LDS byte addresses of the table links' posteriors
     const uint32_t lbase = lds_offset(post);
@@ -405,7 +408,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
         }
     }
     PROF_T(t_c);
-    PROF_ADD(KIND == 2 ? 8 : (CONF ? 5 : 1), t_b, t_c);
+    PROF_ADD(KIND >= 2 ? 8 : (CONF ? 5 : 1), t_b, t_c);
     if (active) {
         // equality test against the true minimum; the selected magnitude is limited to 32 once per row (the per-link clamp to
         // [-32, 31] then only needs its upper side)
@@ -498,7 +501,7 @@ constexpr int LDPC_FPB = LDPC_FPB_N;  // frame slots per workgroup (1: developme
 constexpr int LDPC_TPS = 384;        // threads per slot
 
 template <int MAXDEG, int REC, bool IRREG>
-__global__ __launch_bounds__(LDPC_FPB * LDPC_TPS, 3) void ldpc_decode_kernel(const LdpcLayerDesc* __restrict__ layers, const uint32_t* __restrict__ ents,
+__global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_per_eu(MAXDEG <= 12 ? 4 : 3))) void ldpc_decode_kernel(const LdpcLayerDesc* __restrict__ layers, const uint32_t* __restrict__ ents,
                                                                                const uint32_t* __restrict__ rows, LdpcKernelArgs A) {
     extern __shared__ __attribute__((aligned(16))) int8_t post_all[];
     __shared__ int s_flag[LDPC_FPB][8];
@@ -579,6 +582,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS, 3) void ldpc_decode_kernel(con
                 const uint32_t* __restrict__ pe = ents + A.pent_base + layer * (2 * ((MAXDEG + 1) / 2));
                 if ((L.depth_nc & 0xffffu) == 1) layer_update<MAXDEG, REC, 0, IRREG>(post, A, ents + L.ent_off, pe, L, 1u, layer, j, active, rec, rp, cw, cres);
                 else if ((L.deg >> 16) > 0) layer_update<MAXDEG, REC, 1, IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, rec, rp, cw, cres);
+                else if ((L.depth_nc >> 16) <= 4u) layer_update<MAXDEG, REC, 3, IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, rec, rp, cw, cres);
                 else layer_update<MAXDEG, REC, 2, IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, rec, rp, cw, cres);
                 PROF_T(t_e);
                 lds_barrier();
