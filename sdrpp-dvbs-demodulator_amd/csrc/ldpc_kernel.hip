@@ -386,10 +386,17 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                 // (blocking LICM of the per-link mask tests with an empty asm was measured slower on MI355X: r01 A/B variant "e")
                 const uint32_t late_l = late, early_l = early;
                 if (lvl > 1) {
+                    // (the <= 4-link variant fetches all its shared posteriors up front: one LDS round trip per level instead
+                    // of one per late link behind the per-link branches)
+                    int xs[MAXC];
+                    if constexpr (KIND == 3) {
+#pragma unroll
+                        for (int k = 0; k < MAXC; ++k) xs[k] = (int)LDS_I8(addr[k]);
+                    }
 #pragma unroll
                     for (int k = 0; k < MAXC; ++k) {
                         if (k < nc && ((late_l >> k) & 1)) {
-                            int v = clamp8((int)LDS_I8(addr[k]) - rec_byte<REC>(rec_in, k));
+                            int v = clamp8((KIND == 3 ? xs[k] : (int)LDS_I8(addr[k])) - rec_byte<REC>(rec_in, k));
                             int m = mag_of(v);
                             LINK_SET(k, v, m);
                             ROW_ACCUM(v, m);
