@@ -201,9 +201,9 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
     // 3: levels, at most 4 shared links
     constexpr bool CONF = KIND != 0;
     constexpr int MAXC_ALL = MAXDEG < LDPC_MAX_CONFLICT_LINKS ? MAXDEG : LDPC_MAX_CONFLICT_LINKS;
-    // KIND 3 = KIND 2 for layers with at most 4 shared links: the per-level code only tests those (every tested link costs scalar
+    // KIND 3 / 4 = KIND 2 for layers with at most 4 / 8 shared links: the per-level code only tests those (every tested link costs scalar
     // branches per level whether or not a row uses it)
-    constexpr int MAXC = KIND == 1 ? (MAXDEG < 2 ? MAXDEG : 2) : KIND == 3 ? (MAXDEG < 4 ? MAXDEG : 4) : MAXC_ALL;
+    constexpr int MAXC = KIND == 1 ? (MAXDEG < 2 ? MAXDEG : 2) : KIND == 3 ? (MAXDEG < 4 ? MAXDEG : 4) : KIND == 4 ? (MAXDEG < 8 ? MAXDEG : 8) : MAXC_ALL;
     s16x2 V[NP], G[NP];        // extrinsic inputs and their offset magnitudes
     uint32_t addr[MAXDEG];     // LDS byte addresses of the table links' posteriors
     const uint32_t lbase = lds_offset(post);
@@ -386,17 +386,17 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                 // (blocking LICM of the per-link mask tests with an empty asm was measured slower on MI355X: r01 A/B variant "e")
                 const uint32_t late_l = late, early_l = early;
                 if (lvl > 1) {
-                    // (the <= 4-link variant fetches all its shared posteriors up front: one LDS round trip per level instead
+                    // (the <= 4 / <= 8-link variants fetch all their shared posteriors up front: one LDS round trip per level instead
                     // of one per late link behind the per-link branches)
                     int xs[MAXC];
-                    if constexpr (KIND == 3) {
+                    if constexpr (KIND >= 3) {
 #pragma unroll
                         for (int k = 0; k < MAXC; ++k) xs[k] = (int)LDS_I8(addr[k]);
                     }
 #pragma unroll
                     for (int k = 0; k < MAXC; ++k) {
                         if (k < nc && ((late_l >> k) & 1)) {
-                            int v = clamp8((KIND == 3 ? xs[k] : (int)LDS_I8(addr[k])) - rec_byte<REC>(rec_in, k));
+                            int v = clamp8((KIND >= 3 ? xs[k] : (int)LDS_I8(addr[k])) - rec_byte<REC>(rec_in, k));
                             int m = mag_of(v);
                             LINK_SET(k, v, m);
                             ROW_ACCUM(v, m);
@@ -590,6 +590,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
                 if ((L.depth_nc & 0xffffu) == 1) layer_update<MAXDEG, REC, 0, IRREG>(post, A, ents + L.ent_off, pe, L, 1u, layer, j, active, rec, rp, cw, cres);
                 else if ((L.deg >> 16) > 0) layer_update<MAXDEG, REC, 1, IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, rec, rp, cw, cres);
                 else if ((L.depth_nc >> 16) <= 4u) layer_update<MAXDEG, REC, 3, IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, rec, rp, cw, cres);
+                else if (MAXDEG > 12 && (L.depth_nc >> 16) <= 8u) layer_update<MAXDEG, REC, (MAXDEG > 12 ? 4 : 2), IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, rec, rp, cw, cres);
                 else layer_update<MAXDEG, REC, 2, IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, rec, rp, cw, cres);
                 PROF_T(t_e);
                 lds_barrier();
