@@ -328,3 +328,29 @@ def test_pipelined_full_load_every_stream_bit_exact(engine, pkg):
         engine.set_pipelined(False)
         for d in demods:
             d.close()
+
+
+def test_every_qpsk_and_8psk_modcod_in_one_mixed_batch(engine, pkg):
+    """MODCODs 1..17 with normal and short frames (9/10 has no short frame) as 32 streams of ONE batch: every LDPC code of both
+    frame sizes goes through the full chain side by side; once the loops have settled every delivered BBFRAME is one that was sent."""
+    import torch
+    cases = [(m, s) for m in range(1, 18) for s in (0, 1) if not (s == 1 and m in (11, 17))]
+    nfr = {0: 7, 1: 20}
+    iqs, sent, demods, kbs = [], [], [], []
+    for m, s in cases:
+        iq, bb, _ = orc.transmit(m, s, 0, nframes=nfr[s], seed=100 + 2 * m + s, esn0_db=25.0, lead_symbols=300)   # (no carrier / timing offsets: this is about the codes, not the loops' acquisition)
+        iqs.append(torch.from_numpy(iq).cuda())
+        sent.append({bytes(b) for b in bb})
+        kbs.append(bb.shape[1])
+        demods.append(engine.demod(engine.default_cfg(m, bool(s), False), max_samples=iq.size))
+    cap = max((nfr[s] + 1) * kb for (m, s), kb in zip(cases, kbs))            # (one capacity for the whole batch)
+    tout = [torch.zeros(cap, dtype=torch.uint8, device='cuda') for _ in kbs]
+    try:
+        nb = engine.process_batch(demods, iqs, tout)
+    finally:
+        for d in demods:
+            d.close()
+    for i, (m, s) in enumerate(cases):
+        got = tout[i][:nb[i]].cpu().numpy().reshape(-1, kbs[i])
+        good = [bytes(x) in sent[i] for x in got]          # (frames caught during loop acquisition are delivered too, as the reference does)
+        assert len(got) >= nfr[s] - 3 and all(good[-3:]), (m, s, good)
