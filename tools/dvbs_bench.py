@@ -58,7 +58,7 @@ def demod_bench():
     eng = pkg.Engine(0)
     nsym = 65536
     iq, _ = od.dvbs_iq(0, nsym, seed=1, esn0_db=12.0, cfo=1e-3, timing=0.3)
-    for S in (1, 64, 1024):
+    for S in [int(x) for x in os.environ.get("DVBS_BANK_STREAMS", "1,64,1024").split(",")]:
         bank = pkg.DvbsDemodBank(eng, S, max_samples=iq.size)
         tin = [torch.from_numpy(iq).cuda() for _ in range(S)]
         tout = [torch.zeros(iq.size + 4 * 8192, dtype=torch.uint8, device='cuda') for _ in range(S)]
