@@ -354,3 +354,26 @@ def test_every_qpsk_and_8psk_modcod_in_one_mixed_batch(engine, pkg):
         got = tout[i][:nb[i]].cpu().numpy().reshape(-1, kbs[i])
         good = [bytes(x) in sent[i] for x in got]          # (frames caught during loop acquisition are delivered too, as the reference does)
         assert len(got) >= nfr[s] - 3 and all(good[-3:]), (m, s, good)
+
+
+def test_pipelined_mode_rejects_a_batch_of_different_configurations(engine, pkg):
+    """throughput mode is for one configuration group per batch (include/dvbs2gpu.h, dvbs2gpu_set_pipelined): a mixed batch is
+    refused with ERR_ARG and nothing is left half-done; the same batch runs in the synchronous mode"""
+    import torch
+    cases = [(4, 1), (14, 1)]
+    iqs = [orc.transmit(m, s, 0, nframes=6, seed=400 + m, esn0_db=25.0, lead_symbols=200)[0] for m, s in cases]
+    demods = [engine.demod(engine.default_cfg(m, bool(s), False), max_samples=iq.size) for (m, s), iq in zip(cases, iqs)]
+    tin = [torch.from_numpy(iq).cuda() for iq in iqs]
+    tout = [torch.zeros(8 * 2048, dtype=torch.uint8, device='cuda') for _ in cases]
+    try:
+        engine.set_pipelined(True)
+        with pytest.raises(pkg.Dvbs2GpuError) as ei:
+            engine.process_batch(demods, tin, tout)
+        assert ei.value.code == pkg.ERR_ARG
+        engine.set_pipelined(False)
+        nb = engine.process_batch(demods, tin, tout)
+        assert all(n > 0 for n in nb)
+    finally:
+        engine.set_pipelined(False)
+        for d in demods:
+            d.close()
