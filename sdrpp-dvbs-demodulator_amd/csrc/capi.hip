@@ -212,6 +212,12 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
     if (ctx->fe_stream) (void)hipStreamDestroy(ctx->fe_stream);
     if (ctx->fec_stream) (void)hipStreamDestroy(ctx->fec_stream);
     if (ctx->ev_llr) (void)hipEventDestroy(ctx->ev_llr);
+    for (int g = 0; g < dvbs2gpu_ctx::MAX_PIPE_GROUPS; ++g) {
+        if (ctx->ev_fec[g]) (void)hipEventDestroy(ctx->ev_fec[g]);
+        for (auto& par : ctx->ws_fecbuf[g]) for (auto& w : par) w.release();
+    }
+    for (auto& w : ctx->ws_rx) w.release();
+    for (auto& w : ctx->ws_dvbs) w.release();
     delete ctx;
 }
 

@@ -77,9 +77,13 @@ struct dvbs2gpu_ctx {
     int pipeline_fec = 0;
     hipStream_t fe_stream = nullptr, fec_stream = nullptr;
     hipEvent_t ev_llr = nullptr;
-    void* pending_fec = nullptr;              // s2::PendingFec*
-    s2::Workspace ws_fecbuf[2][3];            // per parity: LLRs | BBFRAMEs | frame refs + first[] + trials + corrections
-    int fec_parity = 0;
+    // one slot per configuration group of the batch (groups are formed in order of first appearance, so a slot keeps its
+    // streams from call to call): the job in flight, its buffers (double-buffered) and the event that marks its completion
+    static constexpr int MAX_PIPE_GROUPS = 16;
+    void* pending_fec[MAX_PIPE_GROUPS] = {};              // s2::PendingFec*
+    s2::Workspace ws_fecbuf[MAX_PIPE_GROUPS][2][3];       // per parity: LLRs | BBFRAMEs | frame refs + first[] + trials + corrections
+    int fec_parity[MAX_PIPE_GROUPS] = {};
+    hipEvent_t ev_fec[MAX_PIPE_GROUPS] = {};
     // DVB-S front end (dvbs_demod.hip)
     float* d_fd_bank = nullptr;               // COMPLEX_FD interpolator bank, 256 x 256
     std::map<int, s2::cf32*> bandedge;        // FLL band-edge taps [2][ntaps] by ntaps*100000 + round(alpha*1000)*10 + sps

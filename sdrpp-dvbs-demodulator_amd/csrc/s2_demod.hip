@@ -326,7 +326,7 @@ struct PendingFec {
 };
 
 int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts,
-                  uint8_t* const* d_out, int out_cap, int* out_bytes, hipStream_t st, bool pipelined) {
+                  uint8_t* const* d_out, int out_cap, int* out_bytes, hipStream_t st, bool pipelined, int slot) {
     dvbs2gpu_demod* d0 = dm[0];
     const ModcodParams& mp = d0->mp;
     const int raw = mp.plframe, kb = mp.fec.kbch / 8, N = mp.fec.N;
@@ -460,13 +460,13 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         int32_t* d_trials = (int32_t*)(d_stats + nf);
         int32_t* d_corr = d_trials + nf;
         int* d_first = (int*)((char*)ws_work.p + sizeof(S2StreamWork) * n);
-        const int par = ctx->fec_parity;
+        const int par = ctx->fec_parity[slot];
         Workspace &ws_pll = ctx->ws_rx[3];
-        Workspace &ws_llr = pipelined ? ctx->ws_fecbuf[par][0] : ctx->ws_rx[4];
-        Workspace &ws_bb = pipelined ? ctx->ws_fecbuf[par][1] : ctx->ws_rx[5];
+        Workspace &ws_llr = pipelined ? ctx->ws_fecbuf[slot][par][0] : ctx->ws_rx[4];
+        Workspace &ws_bb = pipelined ? ctx->ws_fecbuf[slot][par][1] : ctx->ws_rx[5];
         if (pipelined) {
             // the FEC job keeps its own copy of the frame table and its result arrays (phase A of the next call reuses ws_rx[2])
-            Workspace& wj = ctx->ws_fecbuf[par][2];
+            Workspace& wj = ctx->ws_fecbuf[slot][par][2];
             if ((rc = wj.ensure(sizeof(S2FrameRef) * nf + sizeof(int) * (n + 1) + sizeof(int32_t) * 2 * nf + 64))) return rc;
             d_trials = (int32_t*)((char*)wj.p + sizeof(S2FrameRef) * nf + sizeof(int) * (n + 1));
             d_corr = d_trials + nf;
@@ -532,10 +532,12 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         }
         return 0;
     }
-    // ---- pipelined: deliver the previous call's FEC job into this call's output buffers, then start this call's job
+    // ---- pipelined: deliver this group's job of the previous call into this call's output buffers, then start this call's job.
+    // Jobs of all groups run in order on the FEC stream; each is followed by its own event, and the delivery (scatter into the
+    // caller's buffers) runs on the front-end stream behind that event, so it never queues behind a later group's decoder.
     hipStream_t sf = ctx->fec_stream;
-    PendingFec* prev = (PendingFec*)ctx->pending_fec;
-    ctx->pending_fec = nullptr;
+    PendingFec* prev = (PendingFec*)ctx->pending_fec[slot];
+    ctx->pending_fec[slot] = nullptr;
     std::unique_ptr<PendingFec> prev_guard(prev);
     for (int i = 0; i < n; ++i) out_bytes[i] = 0;
     if (prev) {
@@ -544,20 +546,20 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             last_error() = "pipelined mode needs the same streams in the same order on every call";
             return DVBS2GPU_ERR_ARG;
         }
-        HIP_TRY(hipStreamSynchronize(sf));                 // FEC of the previous call (ran during this call's front end)
+        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_fec[slot], 0));   // FEC of the previous call (ran during this call's front end)
         Workspace& wo = ctx->ws_rx[6];
         if ((rc = wo.ensure(sizeof(uint8_t*) * n))) return rc;
-        HIP_TRY(hipMemcpyAsync(wo.p, d_out, sizeof(uint8_t*) * n, hipMemcpyHostToDevice, sf));
+        HIP_TRY(hipMemcpyAsync(wo.p, d_out, sizeof(uint8_t*) * n, hipMemcpyHostToDevice, st));
         std::vector<int32_t> ptr(prev->nf), pco(prev->nf);
-        HIP_TRY(hipMemcpyAsync(ptr.data(), prev->d_trials, sizeof(int32_t) * prev->nf, hipMemcpyDeviceToHost, sf));
-        HIP_TRY(hipMemcpyAsync(pco.data(), prev->d_corr, sizeof(int32_t) * prev->nf, hipMemcpyDeviceToHost, sf));
+        HIP_TRY(hipMemcpyAsync(ptr.data(), prev->d_trials, sizeof(int32_t) * prev->nf, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(pco.data(), prev->d_corr, sizeof(int32_t) * prev->nf, hipMemcpyDeviceToHost, st));
         for (int i = 0; i < n; ++i) {
             int bytes = (prev->first[i + 1] - prev->first[i]) * prev->kb;
             if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
             out_bytes[i] = bytes;
         }
-        HIP_TRY(s2_scatter_out2_launch((uint8_t* const*)wo.p, prev->d_frames, prev->d_first, prev->nf, prev->kb, prev->d_bb, sf));
-        HIP_TRY(hipStreamSynchronize(sf));
+        HIP_TRY(s2_scatter_out2_launch((uint8_t* const*)wo.p, prev->d_frames, prev->d_first, prev->nf, prev->kb, prev->d_bb, st));
+        HIP_TRY(hipStreamSynchronize(st));
         for (int i = 0; i < n; ++i) {
             dm[i]->stats.clear();
             for (int f = prev->first[i]; f < prev->first[i + 1]; ++f) {
@@ -571,8 +573,8 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         for (int i = 0; i < n; ++i) dm[i]->stats.clear();
     }
     if (nf > 0) {
-        const int par = ctx->fec_parity;
-        Workspace& wj = ctx->ws_fecbuf[par][2];
+        const int par = ctx->fec_parity[slot];
+        Workspace& wj = ctx->ws_fecbuf[slot][par][2];
         S2FrameRef* j_frames = (S2FrameRef*)wj.p;
         int* j_first = (int*)((char*)wj.p + sizeof(S2FrameRef) * nf);
         int32_t* j_trials = (int32_t*)((char*)wj.p + sizeof(S2FrameRef) * nf + sizeof(int) * (n + 1));
@@ -581,15 +583,17 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         job->n = n; job->nf = nf; job->kb = kb;
         job->dm.assign(dm, dm + n);
         job->first = first; job->hstats = hstats; job->frame_bm = frame_bm;
-        job->d_frames = j_frames; job->d_first = j_first; job->d_bb = (const uint8_t*)ctx->ws_fecbuf[par][1].p;
+        job->d_frames = j_frames; job->d_first = j_first; job->d_bb = (const uint8_t*)ctx->ws_fecbuf[slot][par][1].p;
         job->d_trials = j_trials; job->d_corr = j_corr;
         HIP_TRY(hipStreamWaitEvent(sf, ctx->ev_llr, 0));
         const int force = d0->cfg.force_ldpc_iters > 0;
         const int mt = force ? d0->cfg.force_ldpc_iters : d0->cfg.max_ldpc_trials;
-        if ((rc = fec_run(ctx, mp.fec, (const int8_t*)ctx->ws_fecbuf[par][0].p, nf, mt, force, (uint8_t*)ctx->ws_fecbuf[par][1].p, j_trials, j_corr, sf)))
+        if ((rc = fec_run(ctx, mp.fec, (const int8_t*)ctx->ws_fecbuf[slot][par][0].p, nf, mt, force, (uint8_t*)ctx->ws_fecbuf[slot][par][1].p, j_trials, j_corr, sf)))
             return rc;
-        ctx->pending_fec = job.release();
-        ctx->fec_parity ^= 1;
+        if (!ctx->ev_fec[slot]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fec[slot], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ctx->ev_fec[slot], sf));
+        ctx->pending_fec[slot] = job.release();
+        ctx->fec_parity[slot] ^= 1;
     }
     return 0;
 }
@@ -665,11 +669,10 @@ int dvbs2gpu_set_pipelined(dvbs2gpu_ctx* ctx, int on) {
         HIP_TRY(hipStreamCreateWithFlags(&ctx->fec_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&ctx->ev_llr, hipEventDisableTiming));
     }
-    if (!on && ctx->pending_fec) {
+    if (!on && ctx->fec_stream) {
         // frames of the last pipelined call that nobody collected are dropped (collect them with a zero-count call first)
         HIP_TRY(hipStreamSynchronize(ctx->fec_stream));
-        delete (PendingFec*)ctx->pending_fec;
-        ctx->pending_fec = nullptr;
+        for (auto& pj : ctx->pending_fec) { delete (PendingFec*)pj; pj = nullptr; }
     }
     ctx->pipeline_fec = on ? 1 : 0;
     return 0;
@@ -682,6 +685,7 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
     HIP_TRY(hipSetDevice(ctx->device));
     // group streams that share a configuration (order inside a group = caller's order)
     std::vector<char> done(n, 0);
+    int group_no = 0;
     for (int i = 0; i < n; ++i) {
         if (done[i]) continue;
         std::vector<int> idx;
@@ -695,9 +699,10 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
         std::vector<int> gc, gb(idx.size());
         std::vector<uint8_t*> go;
         for (int k : idx) { g.push_back(demods[k]); gi.push_back((const cf32*)d_iq[k]); gc.push_back(counts[k]); go.push_back(d_out[k]); }
-        const bool pipe = ctx->pipeline_fec && (int)idx.size() == n;   // pipelining needs the whole batch to be one configuration group
-        if (ctx->pipeline_fec && !pipe) { last_error() = "pipelined mode needs all streams of the batch to share one configuration"; return DVBS2GPU_ERR_ARG; }
-        int rc = process_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), pipe ? ctx->fe_stream : nullptr, pipe);
+        const bool pipe = ctx->pipeline_fec != 0;
+        if (pipe && group_no >= dvbs2gpu_ctx::MAX_PIPE_GROUPS) { last_error() = "pipelined mode handles at most 16 configuration groups per batch"; return DVBS2GPU_ERR_ARG; }
+        int rc = process_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), pipe ? ctx->fe_stream : nullptr, pipe, pipe ? group_no : 0);
+        ++group_no;
         if (rc) return rc;
         for (size_t k = 0; k < idx.size(); ++k) out_bytes[idx[k]] = gb[k];
     }
@@ -719,7 +724,7 @@ int dvbs2gpu_demod_process(dvbs2gpu_demod* d, int count, const float* h_iq, uint
     int bytes = 0;
     int cap = (d->fifo_cap / d->mp.plframe + 2) * (d->mp.fec.kbch / 8);
     dvbs2gpu_demod* dd = d;
-    int rc = process_group(d->ctx, &dd, 1, &in, &count, &dout, cap, &bytes, nullptr, false);
+    int rc = process_group(d->ctx, &dd, 1, &in, &count, &dout, cap, &bytes, nullptr, false, 0);
     if (rc) return rc;
     if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
     if (bytes) HIP_TRY(hipMemcpy(h_out, d->d_out, bytes, hipMemcpyDeviceToHost));

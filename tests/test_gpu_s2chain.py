@@ -356,24 +356,47 @@ def test_every_qpsk_and_8psk_modcod_in_one_mixed_batch(engine, pkg):
         assert len(got) >= nfr[s] - 3 and all(good[-3:]), (m, s, good)
 
 
-def test_pipelined_mode_rejects_a_batch_of_different_configurations(engine, pkg):
-    """throughput mode is for one configuration group per batch (include/dvbs2gpu.h, dvbs2gpu_set_pipelined): a mixed batch is
-    refused with ERR_ARG and nothing is left half-done; the same batch runs in the synchronous mode"""
+def test_pipelined_mixed_modcod_batch_equals_synchronous(engine, pkg):
+    """throughput mode with several FEC groups in flight at once (QPSK and 8PSK MODCODs, both frame sizes, in one batch: one job per
+    configuration group and call on the FEC stream): frames, their order and the per-frame stats of every stream equal the synchronous
+    mode's, one call later"""
     import torch
-    cases = [(4, 1), (14, 1)]
-    iqs = [orc.transmit(m, s, 0, nframes=6, seed=400 + m, esn0_db=25.0, lead_symbols=200)[0] for m, s in cases]
-    demods = [engine.demod(engine.default_cfg(m, bool(s), False), max_samples=iq.size) for (m, s), iq in zip(cases, iqs)]
-    tin = [torch.from_numpy(iq).cuda() for iq in iqs]
-    tout = [torch.zeros(8 * 2048, dtype=torch.uint8, device='cuda') for _ in cases]
-    try:
-        engine.set_pipelined(True)
-        with pytest.raises(pkg.Dvbs2GpuError) as ei:
-            engine.process_batch(demods, tin, tout)
-        assert ei.value.code == pkg.ERR_ARG
-        engine.set_pipelined(False)
-        nb = engine.process_batch(demods, tin, tout)
-        assert all(n > 0 for n in nb)
-    finally:
-        engine.set_pipelined(False)
-        for d in demods:
-            d.close()
+    cases = [(4, 0), (6, 1), (11, 0), (13, 0), (14, 1), (16, 0), (9, 1), (2, 0), (14, 1)]
+    nfr = {0: 6, 1: 16}
+    calls = 3
+    iqs, kbs = [], []
+    for k, (m, s) in enumerate(cases):
+        iq, bb, _ = orc.transmit(m, s, 0, nframes=nfr[s], seed=300 + k, esn0_db=25.0, lead_symbols=200)
+        iqs.append(iq)
+        kbs.append(bb.shape[1])
+    cap = max((nfr[s] + 1) * kb for (m, s), kb in zip(cases, kbs))
+
+    def run(pipelined):
+        demods = [engine.demod(engine.default_cfg(m, bool(s), False), max_samples=iq.size) for (m, s), iq in zip(cases, iqs)]
+        tout = [torch.zeros(cap, dtype=torch.uint8, device='cuda') for _ in cases]
+        engine.set_pipelined(pipelined)
+        outs = []
+        try:
+            for c in range(calls + (1 if pipelined else 0)):
+                tin = []
+                for iq in iqs:
+                    n = (iq.size // calls) & ~1
+                    part = iq[c * n:(c + 1) * n] if c < calls - 1 else (iq[c * n:] if c == calls - 1 else iq[:0])
+                    tin.append(torch.from_numpy(np.ascontiguousarray(part)).cuda() if part.size else torch.empty(0, dtype=torch.complex64, device='cuda'))
+                nb = engine.process_batch(demods, tin, tout)
+                outs.append(([tout[i][:nb[i]].cpu().numpy().copy() for i in range(len(cases))],
+                             [[(x.ldpc_trials, x.bch_corrections, x.detected_modcod) for x in d.stats()] for d in demods]))
+        finally:
+            engine.set_pipelined(False)
+            for d in demods:
+                d.close()
+        return outs
+
+    sync, pipe = run(False), run(True)
+    total = 0
+    for c in range(calls):
+        for i in range(len(cases)):
+            assert np.array_equal(pipe[c + 1][0][i], sync[c][0][i]), (c, cases[i])
+            assert pipe[c + 1][1][i] == sync[c][1][i], (c, cases[i])
+            total += sync[c][0][i].size // kbs[i]
+    assert all(x.size == 0 for x in pipe[0][0]) and total >= sum(nfr[s] for m, s in cases) - 3 * len(cases)
