@@ -326,7 +326,7 @@ struct PendingFec {
 };
 
 int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts,
-                  uint8_t* const* d_out, int out_cap, int* out_bytes, hipStream_t st, bool pipelined, int slot) {
+                  uint8_t* const* d_out, int out_cap, int* out_bytes, hipStream_t st, bool pipelined, int slot, const int* pre_nsym) {
     dvbs2gpu_demod* d0 = dm[0];
     const ModcodParams& mp = d0->mp;
     const int raw = mp.plframe, kb = mp.fec.kbch / 8, N = mp.fec.N;
@@ -356,13 +356,18 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     float* d_nco = (float*)(d_nsym + n);                                                          // [n]
     int* d_curfill = (int*)(d_nco + n);                                                           // [2n]
     HIP_TRY(hipMemcpyAsync(d_work, work.data(), sizeof(S2StreamWork) * n, hipMemcpyHostToDevice, st));
-    HIP_TRY(s2_frontend_launch(d_work, n, d0->co, ctx->d_gardner_bank, st));
-    HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st));
-    // symbol counts back (n_sym sits in each stream's state struct)
     std::vector<int> nsym(n);
-    HIP_TRY(s2_collect_launch(d_work, n, d_nsym, d_nco, st));
-    HIP_TRY(hipMemcpyAsync(nsym.data(), d_nsym, sizeof(int) * n, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (pre_nsym) {
+        // the MODCOD-independent stages already ran for the whole batch (frontend_prepass)
+        for (int i = 0; i < n; ++i) nsym[i] = pre_nsym[i];
+    } else {
+        HIP_TRY(s2_frontend_launch(d_work, n, d0->co, ctx->d_gardner_bank, st));
+        HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st));
+        // symbol counts back (n_sym sits in each stream's state struct)
+        HIP_TRY(s2_collect_launch(d_work, n, d_nsym, d_nco, st));
+        HIP_TRY(hipMemcpyAsync(nsym.data(), d_nsym, sizeof(int) * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
 
     // ---- 3: PL sync.  cur[i] = FIFO index where stream i's next window starts.
     std::vector<int> cur(n, 0), avail(n);
@@ -598,6 +603,49 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     return 0;
 }
 
+// AGC, NCO, Gardner, RRC + decimation do not depend on the MODCOD: for a batch of several configuration groups whose loop
+// coefficients and matched filter agree they run ONCE over all streams (these kernels are latency-bound: eight groups of 512
+// streams cost eight times one group of 4096).  Leaves the symbols in the streams' FIFOs exactly as process_group would.
+int frontend_prepass(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts, uint8_t* const* d_out,
+                     hipStream_t st, std::vector<int>* nsym_out) {
+    int rc;
+    if ((rc = get_rx_tables(ctx))) return rc;
+    dvbs2gpu_demod* d0 = dm[0];
+    float* d_taps;
+    if ((rc = get_rrc(ctx, d0->cfg.rrc_taps, d0->cfg.rrc_alpha, d0->cfg.samplerate / d0->cfg.symbolrate, &d_taps))) return rc;
+    std::vector<S2StreamWork> work(n);
+    int max_count = 0;
+    for (int i = 0; i < n; ++i) {
+        dvbs2gpu_demod* d = dm[i];
+        if (counts[i] < 0 || counts[i] > d->max_samples) { last_error() = "count exceeds max_samples"; return DVBS2GPU_ERR_ARG; }
+        work[i].in = d_iq[i]; work[i].count = counts[i]; work[i].fe_out = d->d_fe;
+        work[i].fifo = d->d_fifo[d->fifo_cur]; work[i].fifo_fill = d->fifo_fill; work[i].st = d->d_state;
+        work[i].fifo_next = d->d_fifo[d->fifo_cur ^ 1]; work[i].out = d_out[i];
+        max_count = std::max(max_count, counts[i]);
+    }
+    Workspace& ws = ctx->ws_rx[7];
+    if ((rc = ws.ensure(sizeof(S2StreamWork) * n + sizeof(int) * n + sizeof(float) * n + 64))) return rc;
+    S2StreamWork* d_work = (S2StreamWork*)ws.p;
+    int* d_nsym = (int*)((char*)ws.p + sizeof(S2StreamWork) * n);
+    float* d_nco = (float*)(d_nsym + n);
+    HIP_TRY(hipMemcpyAsync(d_work, work.data(), sizeof(S2StreamWork) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(s2_frontend_launch(d_work, n, d0->co, ctx->d_gardner_bank, st));
+    HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st));
+    nsym_out->assign(n, 0);
+    HIP_TRY(s2_collect_launch(d_work, n, d_nsym, d_nco, st));
+    HIP_TRY(hipMemcpyAsync(nsym_out->data(), d_nsym, sizeof(int) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+// what the pre-pass stages read from a configuration
+bool same_frontend(const dvbs2gpu_demod* a, const dvbs2gpu_demod* b) {
+    const S2LoopCoefs &x = a->co, &y = b->co;
+    return x.agc_rate == y.agc_rate && x.g_alpha == y.g_alpha && x.g_beta == y.g_beta && x.g_min_freq == y.g_min_freq && x.g_max_freq == y.g_max_freq &&
+           a->cfg.rrc_taps == b->cfg.rrc_taps && a->cfg.rrc_alpha == b->cfg.rrc_alpha && a->cfg.samplerate == b->cfg.samplerate &&
+           a->cfg.symbolrate == b->cfg.symbolrate;
+}
+
 }  // namespace
 
 extern "C" {
@@ -684,27 +732,47 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
     dvbs2gpu_ctx* ctx = demods[0]->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     // group streams that share a configuration (order inside a group = caller's order)
-    std::vector<char> done(n, 0);
-    int group_no = 0;
-    for (int i = 0; i < n; ++i) {
-        if (done[i]) continue;
-        std::vector<int> idx;
-        for (int k = i; k < n; ++k) {
-            if (done[k] || demods[k]->ctx != ctx) continue;
-            const dvbs2gpu_demod_cfg &a = demods[i]->cfg, &b = demods[k]->cfg;
-            if (memcmp(&a, &b, sizeof(a)) == 0) { idx.push_back(k); done[k] = 1; }
+    std::vector<std::vector<int>> groups;
+    {
+        std::vector<char> done(n, 0);
+        for (int i = 0; i < n; ++i) {
+            if (done[i]) continue;
+            if (demods[i]->ctx != ctx) { last_error() = "all streams of a batch must belong to one context"; return DVBS2GPU_ERR_ARG; }
+            std::vector<int> idx;
+            for (int k = i; k < n; ++k) {
+                if (done[k] || demods[k]->ctx != ctx) continue;
+                const dvbs2gpu_demod_cfg &a = demods[i]->cfg, &b = demods[k]->cfg;
+                if (memcmp(&a, &b, sizeof(a)) == 0) { idx.push_back(k); done[k] = 1; }
+            }
+            groups.push_back(std::move(idx));
         }
+    }
+    const bool pipe = ctx->pipeline_fec != 0;
+    if (pipe && (int)groups.size() > dvbs2gpu_ctx::MAX_PIPE_GROUPS) { last_error() = "pipelined mode handles at most 16 configuration groups per batch"; return DVBS2GPU_ERR_ARG; }
+    hipStream_t st = pipe ? ctx->fe_stream : nullptr;
+    // several groups with one front end: the MODCOD-independent stages run once for the whole batch
+    std::vector<int> pre_nsym;
+    bool merged = groups.size() > 1;
+    for (int i = 1; merged && i < n; ++i) merged = same_frontend(demods[0], demods[i]);
+    if (merged) {
+        int rc = frontend_prepass(ctx, demods, n, (const cf32* const*)d_iq, counts, d_out, st, &pre_nsym);
+        if (rc) return rc;
+    }
+    int group_no = 0;
+    for (const std::vector<int>& idx : groups) {
         std::vector<dvbs2gpu_demod*> g;
         std::vector<const cf32*> gi;
-        std::vector<int> gc, gb(idx.size());
+        std::vector<int> gc, gb(idx.size()), gn;
         std::vector<uint8_t*> go;
-        for (int k : idx) { g.push_back(demods[k]); gi.push_back((const cf32*)d_iq[k]); gc.push_back(counts[k]); go.push_back(d_out[k]); }
-        const bool pipe = ctx->pipeline_fec != 0;
-        if (pipe && group_no >= dvbs2gpu_ctx::MAX_PIPE_GROUPS) { last_error() = "pipelined mode handles at most 16 configuration groups per batch"; return DVBS2GPU_ERR_ARG; }
-        int rc = process_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), pipe ? ctx->fe_stream : nullptr, pipe, pipe ? group_no : 0);
-        ++group_no;
+        for (int k : idx) {
+            g.push_back(demods[k]); gi.push_back((const cf32*)d_iq[k]); gc.push_back(counts[k]); go.push_back(d_out[k]);
+            if (merged) gn.push_back(pre_nsym[k]);
+        }
+        int rc = process_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), st, pipe, pipe ? group_no : 0,
+                               merged ? gn.data() : nullptr);
         if (rc) return rc;
         for (size_t k = 0; k < idx.size(); ++k) out_bytes[idx[k]] = gb[k];
+        ++group_no;
     }
     return 0;
 }
@@ -724,7 +792,7 @@ int dvbs2gpu_demod_process(dvbs2gpu_demod* d, int count, const float* h_iq, uint
     int bytes = 0;
     int cap = (d->fifo_cap / d->mp.plframe + 2) * (d->mp.fec.kbch / 8);
     dvbs2gpu_demod* dd = d;
-    int rc = process_group(d->ctx, &dd, 1, &in, &count, &dout, cap, &bytes, nullptr, false, 0);
+    int rc = process_group(d->ctx, &dd, 1, &in, &count, &dout, cap, &bytes, nullptr, false, 0, nullptr);
     if (rc) return rc;
     if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
     if (bytes) HIP_TRY(hipMemcpy(h_out, d->d_out, bytes, hipMemcpyDeviceToHost));
