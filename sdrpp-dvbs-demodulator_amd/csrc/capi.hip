@@ -214,6 +214,9 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
     if (ctx->ev_llr) (void)hipEventDestroy(ctx->ev_llr);
     for (int g = 0; g < dvbs2gpu_ctx::MAX_PIPE_GROUPS; ++g) {
         if (ctx->ev_fec[g]) (void)hipEventDestroy(ctx->ev_fec[g]);
+        if (ctx->ev_llr_grp[g]) (void)hipEventDestroy(ctx->ev_llr_grp[g]);
+        if (ctx->grp_stream[g]) (void)hipStreamDestroy(ctx->grp_stream[g]);
+        for (auto& w : ctx->ws_grp[g]) w.release();
         for (auto& par : ctx->ws_fecbuf[g]) for (auto& w : par) w.release();
     }
     for (auto& w : ctx->ws_rx) w.release();

@@ -84,6 +84,11 @@ struct dvbs2gpu_ctx {
     s2::Workspace ws_fecbuf[MAX_PIPE_GROUPS][2][3];       // per parity: LLRs | BBFRAMEs | frame refs + first[] + trials + corrections
     int fec_parity[MAX_PIPE_GROUPS] = {};
     hipEvent_t ev_fec[MAX_PIPE_GROUPS] = {};
+    // several groups of one pipelined batch run their MODCOD-dependent stages side by side (one host thread and HIP stream each)
+    s2::Workspace ws_grp[MAX_PIPE_GROUPS][8];
+    hipStream_t grp_stream[MAX_PIPE_GROUPS] = {};
+    hipEvent_t ev_llr_grp[MAX_PIPE_GROUPS] = {};
+    std::mutex fec_mtx;                                   // FEC jobs are enqueued whole, one at a time (shared FEC workspaces, one stream)
     // DVB-S front end (dvbs_demod.hip)
     float* d_fd_bank = nullptr;               // COMPLEX_FD interpolator bank, 256 x 256
     std::map<int, s2::cf32*> bandedge;        // FLL band-edge taps [2][ntaps] by ntaps*100000 + round(alpha*1000)*10 + sps

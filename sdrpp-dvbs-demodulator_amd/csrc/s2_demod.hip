@@ -14,6 +14,8 @@
 //   6 LDPC / BCH / descramble over the pooled frames           ldpc_decode_kernel, bch_*, bb_descramble
 //   7 D2H (or D2D for the batch entry point) of BBFRAMEs + stats; FIFO remainder moved to the spare buffer
 #include "ctx.h"
+#include <list>
+#include <thread>
 #include <cmath>
 #include <algorithm>
 #include <memory>
@@ -326,8 +328,10 @@ struct PendingFec {
 };
 
 int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts,
-                  uint8_t* const* d_out, int out_cap, int* out_bytes, hipStream_t st, bool pipelined, int slot, const int* pre_nsym) {
+                  uint8_t* const* d_out, int out_cap, int* out_bytes, hipStream_t st, bool pipelined, int slot, const int* pre_nsym, bool own_ws) {
     dvbs2gpu_demod* d0 = dm[0];
+    Workspace* const W = own_ws ? ctx->ws_grp[slot] : ctx->ws_rx;      // per-call scratch: the group's own set when groups run side by side
+    const hipEvent_t ev_llr = own_ws ? ctx->ev_llr_grp[slot] : ctx->ev_llr;
     const ModcodParams& mp = d0->mp;
     const int raw = mp.plframe, kb = mp.fec.kbch / 8, N = mp.fec.N;
     int rc;
@@ -349,7 +353,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         max_count = std::max(max_count, counts[i]);
         d->stats.clear(); d->frame_ptrs.clear();
     }
-    Workspace& ws_work = ctx->ws_rx[0];
+    Workspace& ws_work = W[0];
     if ((rc = ws_work.ensure(sizeof(S2StreamWork) * n + sizeof(int) * (n + 1) + sizeof(int) * 4 * n + 64))) return rc;
     S2StreamWork* d_work = (S2StreamWork*)ws_work.p;
     int* d_nsym = (int*)((char*)ws_work.p + sizeof(S2StreamWork) * n + sizeof(int) * (n + 1));   // [n]
@@ -391,7 +395,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             }
         }
     }
-    Workspace& ws_win = ctx->ws_rx[1];
+    Workspace& ws_win = W[1];
     while (true) {
         // speculate: every complete window from cur[i] on is aligned
         std::vector<const cf32*> wins;
@@ -458,7 +462,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     std::vector<int32_t> trials(nf), corr(nf);
     uint8_t* d_bb = nullptr;
     if (nf > 0) {
-        Workspace& ws_fr = ctx->ws_rx[2];
+        Workspace& ws_fr = W[2];
         if ((rc = ws_fr.ensure(sizeof(S2FrameRef) * nf + sizeof(S2FrameStats) * nf + sizeof(int32_t) * 2 * nf + 64))) return rc;
         S2FrameRef* d_frames = (S2FrameRef*)ws_fr.p;
         S2FrameStats* d_stats = (S2FrameStats*)(d_frames + nf);
@@ -466,9 +470,9 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         int32_t* d_corr = d_trials + nf;
         int* d_first = (int*)((char*)ws_work.p + sizeof(S2StreamWork) * n);
         const int par = ctx->fec_parity[slot];
-        Workspace &ws_pll = ctx->ws_rx[3];
-        Workspace &ws_llr = pipelined ? ctx->ws_fecbuf[slot][par][0] : ctx->ws_rx[4];
-        Workspace &ws_bb = pipelined ? ctx->ws_fecbuf[slot][par][1] : ctx->ws_rx[5];
+        Workspace &ws_pll = W[3];
+        Workspace &ws_llr = pipelined ? ctx->ws_fecbuf[slot][par][0] : W[4];
+        Workspace &ws_bb = pipelined ? ctx->ws_fecbuf[slot][par][1] : W[5];
         if (pipelined) {
             // the FEC job keeps its own copy of the frame table and its result arrays (phase A of the next call reuses ws_rx[2])
             Workspace& wj = ctx->ws_fecbuf[slot][par][2];
@@ -497,7 +501,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             HIP_TRY(hipMemcpyAsync(trials.data(), d_trials, sizeof(int32_t) * nf, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(corr.data(), d_corr, sizeof(int32_t) * nf, hipMemcpyDeviceToHost, st));
         } else {
-            HIP_TRY(hipEventRecord(ctx->ev_llr, st));
+            HIP_TRY(hipEventRecord(ev_llr, st));
         }
         HIP_TRY(hipMemcpyAsync(hstats.data(), d_stats, sizeof(S2FrameStats) * nf, hipMemcpyDeviceToHost, st));
         for (int i = 0; i < n; ++i) {
@@ -552,7 +556,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             return DVBS2GPU_ERR_ARG;
         }
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_fec[slot], 0));   // FEC of the previous call (ran during this call's front end)
-        Workspace& wo = ctx->ws_rx[6];
+        Workspace& wo = W[6];
         if ((rc = wo.ensure(sizeof(uint8_t*) * n))) return rc;
         HIP_TRY(hipMemcpyAsync(wo.p, d_out, sizeof(uint8_t*) * n, hipMemcpyHostToDevice, st));
         std::vector<int32_t> ptr(prev->nf), pco(prev->nf);
@@ -590,13 +594,16 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         job->first = first; job->hstats = hstats; job->frame_bm = frame_bm;
         job->d_frames = j_frames; job->d_first = j_first; job->d_bb = (const uint8_t*)ctx->ws_fecbuf[slot][par][1].p;
         job->d_trials = j_trials; job->d_corr = j_corr;
-        HIP_TRY(hipStreamWaitEvent(sf, ctx->ev_llr, 0));
         const int force = d0->cfg.force_ldpc_iters > 0;
         const int mt = force ? d0->cfg.force_ldpc_iters : d0->cfg.max_ldpc_trials;
-        if ((rc = fec_run(ctx, mp.fec, (const int8_t*)ctx->ws_fecbuf[slot][par][0].p, nf, mt, force, (uint8_t*)ctx->ws_fecbuf[slot][par][1].p, j_trials, j_corr, sf)))
-            return rc;
-        if (!ctx->ev_fec[slot]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fec[slot], hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(ctx->ev_fec[slot], sf));
+        {
+            std::lock_guard<std::mutex> fl(ctx->fec_mtx);
+            HIP_TRY(hipStreamWaitEvent(sf, ev_llr, 0));
+            if ((rc = fec_run(ctx, mp.fec, (const int8_t*)ctx->ws_fecbuf[slot][par][0].p, nf, mt, force, (uint8_t*)ctx->ws_fecbuf[slot][par][1].p, j_trials, j_corr, sf)))
+                return rc;
+            if (!ctx->ev_fec[slot]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fec[slot], hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(ctx->ev_fec[slot], sf));
+        }
         ctx->pending_fec[slot] = job.release();
         ctx->fec_parity[slot] ^= 1;
     }
@@ -758,6 +765,16 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
         int rc = frontend_prepass(ctx, demods, n, (const cf32* const*)d_iq, counts, d_out, st, &pre_nsym);
         if (rc) return rc;
     }
+    struct GroupJob {
+        std::vector<int> idx, gc, gb, gn;
+        std::vector<dvbs2gpu_demod*> g;
+        std::vector<const cf32*> gi;
+        std::vector<uint8_t*> go;
+        int slot = 0, rc = 0;
+        std::string err;
+    };
+    std::list<GroupJob> jobs;
+    const bool side_by_side = pipe && merged;
     int group_no = 0;
     for (const std::vector<int>& idx : groups) {
         std::vector<dvbs2gpu_demod*> g;
@@ -768,11 +785,40 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
             g.push_back(demods[k]); gi.push_back((const cf32*)d_iq[k]); gc.push_back(counts[k]); go.push_back(d_out[k]);
             if (merged) gn.push_back(pre_nsym[k]);
         }
+        if (side_by_side) {
+            jobs.emplace_back();
+            GroupJob& J = jobs.back();
+            J.idx = idx; J.g = std::move(g); J.gi = std::move(gi); J.gc = std::move(gc); J.go = std::move(go); J.gn = std::move(gn);
+            J.gb.assign(idx.size(), 0); J.slot = group_no++;
+            continue;
+        }
         int rc = process_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), st, pipe, pipe ? group_no : 0,
-                               merged ? gn.data() : nullptr);
+                               merged ? gn.data() : nullptr, false);
         if (rc) return rc;
         for (size_t k = 0; k < idx.size(); ++k) out_bytes[idx[k]] = gb[k];
         ++group_no;
+    }
+    if (side_by_side) {
+        // the MODCOD-dependent stages (PL sync, frame loops, demapper, FEC hand-over, delivery) of the groups are independent and
+        // latency-bound: one host thread and HIP stream per group (the pre-pass above has completed; every group ends synchronised)
+        for (GroupJob& J : jobs) {
+            if (!ctx->grp_stream[J.slot]) HIP_TRY(hipStreamCreateWithFlags(&ctx->grp_stream[J.slot], hipStreamNonBlocking));
+            if (!ctx->ev_llr_grp[J.slot]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_llr_grp[J.slot], hipEventDisableTiming));
+        }
+        std::vector<std::thread> th;
+        for (GroupJob& J : jobs) {
+            th.emplace_back([&J, ctx, out_cap]() {
+                if (hipSetDevice(ctx->device) != hipSuccess) { J.rc = DVBS2GPU_ERR_HIP; J.err = "hipSetDevice"; return; }
+                J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
+                                     ctx->grp_stream[J.slot], true, J.slot, J.gn.data(), true);
+                if (J.rc) J.err = last_error();
+            });
+        }
+        for (auto& t : th) t.join();
+        for (GroupJob& J : jobs) {
+            if (J.rc) { last_error() = J.err; return J.rc; }
+            for (size_t k = 0; k < J.idx.size(); ++k) out_bytes[J.idx[k]] = J.gb[k];
+        }
     }
     return 0;
 }
@@ -792,7 +838,7 @@ int dvbs2gpu_demod_process(dvbs2gpu_demod* d, int count, const float* h_iq, uint
     int bytes = 0;
     int cap = (d->fifo_cap / d->mp.plframe + 2) * (d->mp.fec.kbch / 8);
     dvbs2gpu_demod* dd = d;
-    int rc = process_group(d->ctx, &dd, 1, &in, &count, &dout, cap, &bytes, nullptr, false, 0, nullptr);
+    int rc = process_group(d->ctx, &dd, 1, &in, &count, &dout, cap, &bytes, nullptr, false, 0, nullptr, false);
     if (rc) return rc;
     if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
     if (bytes) HIP_TRY(hipMemcpy(h_out, d->d_out, bytes, hipMemcpyDeviceToHost));

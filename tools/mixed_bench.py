@@ -3,6 +3,7 @@
 normal frames, 50 forced LDPC iterations) in ONE pipelined batch: eight configuration groups, one FEC job per group and call.
 Prints Msymbols/s over all streams and checks every delivered frame of the last step against the transmitted ones."""
 import os, sys, time, json
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '12')   # HIP runs at most this many streams concurrently (default 4): one per configuration group + FEC + front end
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
