@@ -807,12 +807,25 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
         }
         std::vector<std::thread> th;
         for (GroupJob& J : jobs) {
-            th.emplace_back([&J, ctx, out_cap]() {
-                if (hipSetDevice(ctx->device) != hipSuccess) { J.rc = DVBS2GPU_ERR_HIP; J.err = "hipSetDevice"; return; }
+            if (&J == &jobs.back()) break;            // (the last group runs on the calling thread, below)
+            try {
+                th.emplace_back([&J, ctx, out_cap]() {
+                    if (hipSetDevice(ctx->device) != hipSuccess) { J.rc = DVBS2GPU_ERR_HIP; J.err = "hipSetDevice"; return; }
+                    J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
+                                         ctx->grp_stream[J.slot], true, J.slot, J.gn.data(), true);
+                    if (J.rc) J.err = last_error();
+                });
+            } catch (...) {                           // no thread to be had: run the group here (no exception leaves the C ABI)
                 J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
                                      ctx->grp_stream[J.slot], true, J.slot, J.gn.data(), true);
                 if (J.rc) J.err = last_error();
-            });
+            }
+        }
+        {
+            GroupJob& J = jobs.back();
+            J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
+                                 ctx->grp_stream[J.slot], true, J.slot, J.gn.data(), true);
+            if (J.rc) J.err = last_error();
         }
         for (auto& t : th) t.join();
         for (GroupJob& J : jobs) {
