@@ -328,7 +328,7 @@ struct PendingFec {
 };
 
 int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts,
-                  uint8_t* const* d_out, int out_cap, int* out_bytes, hipStream_t st, bool pipelined, int slot, const int* pre_nsym, bool own_ws) {
+                  uint8_t* const* d_out, int out_cap, int* out_bytes, hipStream_t st, bool pipelined, int slot, const int* pre_nsym, bool own_ws, bool deliver_now) {
     dvbs2gpu_demod* d0 = dm[0];
     Workspace* const W = own_ws ? ctx->ws_grp[slot] : ctx->ws_rx;      // per-call scratch: the group's own set when groups run side by side
     const hipEvent_t ev_llr = own_ws ? ctx->ev_llr_grp[slot] : ctx->ev_llr;
@@ -545,39 +545,45 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     // Jobs of all groups run in order on the FEC stream; each is followed by its own event, and the delivery (scatter into the
     // caller's buffers) runs on the front-end stream behind that event, so it never queues behind a later group's decoder.
     hipStream_t sf = ctx->fec_stream;
+    for (int i = 0; i < n; ++i) out_bytes[i] = 0;
+    // results of a finished (or finishing) job -> the caller's output buffers and the per-frame stats of its streams
+    auto deliver = [&](PendingFec* job) -> int {
+        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_fec[slot], 0));
+        Workspace& wo = W[6];
+        int rc2;
+        if ((rc2 = wo.ensure(sizeof(uint8_t*) * n))) return rc2;
+        HIP_TRY(hipMemcpyAsync(wo.p, d_out, sizeof(uint8_t*) * n, hipMemcpyHostToDevice, st));
+        std::vector<int32_t> ptr(job->nf), pco(job->nf);
+        HIP_TRY(hipMemcpyAsync(ptr.data(), job->d_trials, sizeof(int32_t) * job->nf, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(pco.data(), job->d_corr, sizeof(int32_t) * job->nf, hipMemcpyDeviceToHost, st));
+        for (int i = 0; i < n; ++i) {
+            int bytes = (job->first[i + 1] - job->first[i]) * job->kb;
+            if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
+            out_bytes[i] = bytes;
+        }
+        HIP_TRY(s2_scatter_out2_launch((uint8_t* const*)wo.p, job->d_frames, job->d_first, job->nf, job->kb, job->d_bb, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int i = 0; i < n; ++i) {
+            dm[i]->stats.clear();
+            for (int f = job->first[i]; f < job->first[i + 1]; ++f) {
+                S2FrameStats s = job->hstats[f];
+                s.best_match = job->frame_bm[i][f - job->first[i]];
+                s.ldpc_trials = ptr[f]; s.bch_corr = pco[f];
+                dm[i]->stats.push_back(s);
+            }
+        }
+        return 0;
+    };
     PendingFec* prev = (PendingFec*)ctx->pending_fec[slot];
     ctx->pending_fec[slot] = nullptr;
     std::unique_ptr<PendingFec> prev_guard(prev);
-    for (int i = 0; i < n; ++i) out_bytes[i] = 0;
     if (prev) {
         if (prev->n != n || memcmp(prev->dm.data(), dm, sizeof(dvbs2gpu_demod*) * n) != 0) {
             HIP_TRY(hipStreamSynchronize(sf));
             last_error() = "pipelined mode needs the same streams in the same order on every call";
             return DVBS2GPU_ERR_ARG;
         }
-        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_fec[slot], 0));   // FEC of the previous call (ran during this call's front end)
-        Workspace& wo = W[6];
-        if ((rc = wo.ensure(sizeof(uint8_t*) * n))) return rc;
-        HIP_TRY(hipMemcpyAsync(wo.p, d_out, sizeof(uint8_t*) * n, hipMemcpyHostToDevice, st));
-        std::vector<int32_t> ptr(prev->nf), pco(prev->nf);
-        HIP_TRY(hipMemcpyAsync(ptr.data(), prev->d_trials, sizeof(int32_t) * prev->nf, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(pco.data(), prev->d_corr, sizeof(int32_t) * prev->nf, hipMemcpyDeviceToHost, st));
-        for (int i = 0; i < n; ++i) {
-            int bytes = (prev->first[i + 1] - prev->first[i]) * prev->kb;
-            if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
-            out_bytes[i] = bytes;
-        }
-        HIP_TRY(s2_scatter_out2_launch((uint8_t* const*)wo.p, prev->d_frames, prev->d_first, prev->nf, prev->kb, prev->d_bb, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        for (int i = 0; i < n; ++i) {
-            dm[i]->stats.clear();
-            for (int f = prev->first[i]; f < prev->first[i + 1]; ++f) {
-                S2FrameStats s = prev->hstats[f];
-                s.best_match = prev->frame_bm[i][f - prev->first[i]];
-                s.ldpc_trials = ptr[f]; s.bch_corr = pco[f];
-                dm[i]->stats.push_back(s);
-            }
-        }
+        if ((rc = deliver(prev))) return rc;      // FEC of the previous call (ran during this call's front end)
     } else {
         for (int i = 0; i < n; ++i) dm[i]->stats.clear();
     }
@@ -604,8 +610,13 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             if (!ctx->ev_fec[slot]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fec[slot], hipEventDisableTiming));
             HIP_TRY(hipEventRecord(ctx->ev_fec[slot], sf));
         }
-        ctx->pending_fec[slot] = job.release();
         ctx->fec_parity[slot] ^= 1;
+        if (deliver_now) {
+            // synchronous call with several groups side by side: the job is collected by the call that started it
+            if ((rc = deliver(job.get()))) return rc;
+        } else {
+            ctx->pending_fec[slot] = job.release();
+        }
     }
     return 0;
 }
@@ -774,7 +785,8 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
         std::string err;
     };
     std::list<GroupJob> jobs;
-    const bool side_by_side = pipe && merged;
+    // (synchronous calls collect each group's FEC job before they return)
+    const bool side_by_side = merged && (int)groups.size() <= dvbs2gpu_ctx::MAX_PIPE_GROUPS;
     int group_no = 0;
     for (const std::vector<int>& idx : groups) {
         std::vector<dvbs2gpu_demod*> g;
@@ -793,7 +805,7 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
             continue;
         }
         int rc = process_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), st, pipe, pipe ? group_no : 0,
-                               merged ? gn.data() : nullptr, false);
+                               merged ? gn.data() : nullptr, false, false);
         if (rc) return rc;
         for (size_t k = 0; k < idx.size(); ++k) out_bytes[idx[k]] = gb[k];
         ++group_no;
@@ -801,6 +813,7 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
     if (side_by_side) {
         // the MODCOD-dependent stages (PL sync, frame loops, demapper, FEC hand-over, delivery) of the groups are independent and
         // latency-bound: one host thread and HIP stream per group (the pre-pass above has completed; every group ends synchronised)
+        if (!ctx->fec_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->fec_stream, hipStreamNonBlocking));
         for (GroupJob& J : jobs) {
             if (!ctx->grp_stream[J.slot]) HIP_TRY(hipStreamCreateWithFlags(&ctx->grp_stream[J.slot], hipStreamNonBlocking));
             if (!ctx->ev_llr_grp[J.slot]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_llr_grp[J.slot], hipEventDisableTiming));
@@ -809,22 +822,22 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
         for (GroupJob& J : jobs) {
             if (&J == &jobs.back()) break;            // (the last group runs on the calling thread, below)
             try {
-                th.emplace_back([&J, ctx, out_cap]() {
+                th.emplace_back([&J, ctx, out_cap, pipe]() {
                     if (hipSetDevice(ctx->device) != hipSuccess) { J.rc = DVBS2GPU_ERR_HIP; J.err = "hipSetDevice"; return; }
                     J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
-                                         ctx->grp_stream[J.slot], true, J.slot, J.gn.data(), true);
+                                         ctx->grp_stream[J.slot], true, J.slot, J.gn.data(), true, !pipe);
                     if (J.rc) J.err = last_error();
                 });
             } catch (...) {                           // no thread to be had: run the group here (no exception leaves the C ABI)
                 J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
-                                     ctx->grp_stream[J.slot], true, J.slot, J.gn.data(), true);
+                                     ctx->grp_stream[J.slot], true, J.slot, J.gn.data(), true, !pipe);
                 if (J.rc) J.err = last_error();
             }
         }
         {
             GroupJob& J = jobs.back();
             J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
-                                 ctx->grp_stream[J.slot], true, J.slot, J.gn.data(), true);
+                                 ctx->grp_stream[J.slot], true, J.slot, J.gn.data(), true, !pipe);
             if (J.rc) J.err = last_error();
         }
         for (auto& t : th) t.join();
@@ -851,7 +864,7 @@ int dvbs2gpu_demod_process(dvbs2gpu_demod* d, int count, const float* h_iq, uint
     int bytes = 0;
     int cap = (d->fifo_cap / d->mp.plframe + 2) * (d->mp.fec.kbch / 8);
     dvbs2gpu_demod* dd = d;
-    int rc = process_group(d->ctx, &dd, 1, &in, &count, &dout, cap, &bytes, nullptr, false, 0, nullptr, false);
+    int rc = process_group(d->ctx, &dd, 1, &in, &count, &dout, cap, &bytes, nullptr, false, 0, nullptr, false, false);
     if (rc) return rc;
     if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
     if (bytes) HIP_TRY(hipMemcpy(h_out, d->d_out, bytes, hipMemcpyDeviceToHost));
