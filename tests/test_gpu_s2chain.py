@@ -400,3 +400,39 @@ def test_pipelined_mixed_modcod_batch_equals_synchronous(engine, pkg):
             assert pipe[c + 1][1][i] == sync[c][1][i], (c, cases[i])
             total += sync[c][0][i].size // kbs[i]
     assert all(x.size == 0 for x in pipe[0][0]) and total >= sum(nfr[s] for m, s in cases) - 3 * len(cases)
+
+
+def test_one_long_stream_cut_into_overlapping_segments(engine, pkg):
+    """a single transponder is a serial chain (0.69 Msym/s per stream), so a fast one has to be cut into
+    overlapping segments that run as independent streams, each re-acquiring its loops on a warm-up prefix.  One continuous QPSK 3/4
+    short-frame signal with carrier, phase and timing offsets is cut at arbitrary sample positions; behind its warm-up every segment must
+    deliver exactly its run of the transmitted BBFRAMEs, so the union is the transmitted sequence."""
+    import torch
+    m, s = 6, 1
+    total, own, warm = 8 + 6 * 10, 10, 8
+    iq, bb, _ = orc.transmit(m, s, 0, nframes=total, seed=77, esn0_db=14.0, cfo=3e-4, timing=0.3, phase0=0.4, lead_symbols=123)
+    index = {bytes(b): k for k, b in enumerate(bb)}
+    assert len(index) == total
+    plf = pkg.modcod_info(m, True, False)['plframe_symbols']
+    kb = bb.shape[1]
+    spf = 2 * plf                                            # samples per frame
+    nseg = (total - warm) // own
+    starts = [int((warm + g * own - warm - 0.37) * spf) + 2 * 123 for g in range(nseg)]      # not frame aligned
+    ends = [int((warm + (g + 1) * own + 1.2) * spf) + 2 * 123 for g in range(nseg)]           # (one frame beyond: PL sync confirms a frame by the next header)
+    segs = [iq[max(a, 0):min(b, iq.size)] for a, b in zip(starts, ends)]
+    demods = [engine.demod(engine.default_cfg(m, True, False), max_samples=max(x.size for x in segs)) for _ in segs]
+    tout = [torch.zeros((own + warm + 4) * kb, dtype=torch.uint8, device='cuda') for _ in segs]
+    try:
+        nb = engine.process_batch(demods, [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in segs], tout)
+    finally:
+        for d in demods:
+            d.close()
+    covered = set()
+    for g in range(nseg):
+        got = [index.get(bytes(x), -1) for x in tout[g][:nb[g]].cpu().numpy().reshape(-1, kb)]
+        good = [k for k in got if k >= 0]
+        assert good == list(range(good[0], good[0] + len(good))), (g, got)          # a contiguous run, in order
+        lo, hi = warm + g * own, warm + (g + 1) * own                                    # the segment's own frames
+        assert set(range(lo, min(hi, total - 1))) <= set(good), (g, lo, hi, got)
+        covered |= {k for k in good if lo <= k < hi}
+    assert covered >= set(range(warm, min(warm + nseg * own, total - 1)))               # the union is the transmitted sequence
