@@ -174,12 +174,37 @@ typedef struct dvbs2gpu_frame_stats {
 } dvbs2gpu_frame_stats;
 int dvbs2gpu_demod_get_stats(dvbs2gpu_demod* d, dvbs2gpu_frame_stats* h_out, int cap);
 float dvbs2gpu_demod_get_nco_freq(dvbs2gpu_demod* d);
+/* Where the frames FOUND by the last process call start: index of each frame's first symbol in the stream's symbol sequence
+ * (after timing recovery, one per symbol) since the last reset.  Returns the frame count.  (In the synchronous mode these are the
+ * frames the call delivered; in the throughput mode the ones the NEXT call will deliver.)  No reference counterpart: the segment
+ * receiver below orders and de-duplicates frames with it. */
+int dvbs2gpu_demod_get_frame_positions(dvbs2gpu_demod* d, int64_t* h_out, int cap);
 
 /* Debug taps of the last process call (device->host copies; for parity tests and the constellation
  * display callback d_handler, module_dvbs2_demod.cpp:337).  which: 0 = 1-sps symbols entering PL sync,
  * 1 = aligned raw PLFRAMEs, 2 = PLL output, (complex64, count in complex samples); 3 = LLRs (int8).
  * Returns the element count; copies at most cap elements when h_dst != NULL. */
 int dvbs2gpu_demod_get_tap(dvbs2gpu_demod* d, int which, void* h_dst, int cap);
+
+/* ------------------------------------------------------------------ segment receiver: ONE fast transponder
+ * A stream's loops are serial recurrences (one stream: 0.69 Msym/s on MI355X), so a single 27.5 Msym/s transponder cannot be
+ * followed sample by sample.  The segment receiver cuts a long chunk of one continuous IQ stream into `nsegments` overlapping
+ * segments of `own_frames` PLFRAMEs each (+ `warm_frames` of warm-up in front, own_frames >= warm_frames), runs them as
+ * independent streams of one dvbs2gpu_demod_process_batch call with freshly reset loops, orders the frames by the positions of
+ * dvbs2gpu_demod_get_frame_positions, drops duplicates where neighbours overlap and returns the BBFRAMEs in stream order; the
+ * tail of a chunk is the warm-up of the next call's first segment, so calls join without a gap.  No counterpart in the reference
+ * (one DVBS2Demod per transponder, serial): it returns the same BBFRAMEs wherever the reference would decode them, but it is a
+ * high-latency mode (a chunk is nsegments * own_frames frames long) and soft values are not bit-identical to a serial run.
+ * d_iq: DEVICE pointer to `count` complex samples (interleaved floats) continuing the stream, count <= dvbs2gpu_segrx_chunk_samples;
+ * d_out: DEVICE buffer; returns bytes written (kbch/8 per frame) or a negative error.  The context must be in synchronous mode. */
+typedef struct dvbs2gpu_segrx dvbs2gpu_segrx;
+int dvbs2gpu_segrx_create(dvbs2gpu_ctx* ctx, const dvbs2gpu_demod_cfg* cfg, int nsegments, int own_frames, int warm_frames, dvbs2gpu_segrx** out);
+int dvbs2gpu_segrx_reset(dvbs2gpu_segrx* r);
+void dvbs2gpu_segrx_destroy(dvbs2gpu_segrx* r);
+long long dvbs2gpu_segrx_chunk_samples(dvbs2gpu_segrx* r);
+int dvbs2gpu_segrx_process(dvbs2gpu_segrx* r, const float* d_iq, long long count, uint8_t* d_out, long long out_cap);
+/* h_out3 = {frame sightings of the last call, frames returned, frames seen only inside a warm-up (not returned)} */
+int dvbs2gpu_segrx_get_stats(dvbs2gpu_segrx* r, int32_t* h_out3);
 
 /* ================================================================== DVB-S inner code (rows a18-a20)
  * All buffers are DEVICE pointers; calls are asynchronous on `stream`.  Handles keep per-stream state in HBM. */

@@ -100,6 +100,13 @@ PROTOTYPES = {
     'dvbs2gpu_dvbs_tail_destroy': (None, [_vp]),
     'dvbs2gpu_dvbs_tail_process_batch': (_i, [_vp, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), _i, C.POINTER(_i), _vp]),
     'dvbs2gpu_dvbs_tail_get_stats': (_i, [_vp, _i, C.POINTER(C.c_int32)]),
+    'dvbs2gpu_demod_get_frame_positions': (_i, [_vp, C.POINTER(C.c_int64), _i]),
+    'dvbs2gpu_segrx_create': (_i, [_vp, C.POINTER(DemodCfg), _i, _i, _i, C.POINTER(_vp)]),
+    'dvbs2gpu_segrx_reset': (_i, [_vp]),
+    'dvbs2gpu_segrx_destroy': (None, [_vp]),
+    'dvbs2gpu_segrx_chunk_samples': (C.c_longlong, [_vp]),
+    'dvbs2gpu_segrx_process': (_i, [_vp, _vp, C.c_longlong, _vp, C.c_longlong]),
+    'dvbs2gpu_segrx_get_stats': (_i, [_vp, C.POINTER(C.c_int32)]),
     'dvbs2gpu_bbts_create': (_i, [_vp, _i, _i, _i, C.POINTER(_vp)]),
     'dvbs2gpu_bbts_set_frame_size': (_i, [_vp, _i]),
     'dvbs2gpu_bbts_destroy': (None, [_vp]),
@@ -559,3 +566,28 @@ class BbTsParserBank(_Handle):
         d = {k: a[i] for i, k in enumerate(self.HEADER_FIELDS)}
         d.update(last_gse_crc_err=a[11], last_bb_cnt=a[12], last_bb_proc=a[13], last_ts_errs=a[14], synched=a[15], count=a[16])
         return d
+
+
+class SegmentReceiver(_Handle):
+    """One fast transponder on the many-stream engine: a long chunk of one continuous IQ stream is cut into overlapping segments
+    that run as independent streams and are stitched back in order (include/dvbs2gpu.h, segment receiver)."""
+    _destroy = 'dvbs2gpu_segrx_destroy'
+
+    def __init__(self, engine, cfg, nsegments, own_frames, warm_frames):
+        self.eng, self.lib = engine, engine.lib
+        h = C.c_void_p()
+        engine._check(self.lib.dvbs2gpu_segrx_create(engine.h, C.byref(cfg), nsegments, own_frames, warm_frames, C.byref(h)))
+        self.h = h
+        self.chunk_samples = int(self.lib.dvbs2gpu_segrx_chunk_samples(self.h))
+
+    def reset(self):
+        self.eng._check(self.lib.dvbs2gpu_segrx_reset(self.h))
+
+    def process(self, iq, out):
+        """iq: complex64 CUDA 1-D (continues the stream), out: uint8 CUDA buffer -> bytes written"""
+        return self.eng._check(self.lib.dvbs2gpu_segrx_process(self.h, C.c_void_p(iq.data_ptr()), int(iq.numel()), C.c_void_p(out.data_ptr()), int(out.numel())))
+
+    def stats(self):
+        a = (C.c_int32 * 3)()
+        self.eng._check(self.lib.dvbs2gpu_segrx_get_stats(self.h, a))
+        return {'sightings': a[0], 'returned': a[1], 'warmup_only': a[2]}

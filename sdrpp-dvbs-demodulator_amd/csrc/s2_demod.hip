@@ -276,6 +276,8 @@ struct dvbs2gpu_demod {
     // results of the last call
     std::vector<S2FrameStats> stats;
     std::vector<const cf32*> frame_ptrs;     // aligned frames of the last call (device pointers into the old FIFO buffer)
+    std::vector<long long> frame_pos;        // index of their first symbol in the stream's 1-sps symbol sequence since the last reset
+    long long sym_base = 0;                  // symbols that have left the FIFO since the last reset
     int tap_sym_off = 0, tap_sym_cnt = 0, tap_fifo = 0;
     const cf32* tap_pll = nullptr;           // into ctx workspace, valid until the next call on this context
     const int8_t* tap_llr = nullptr;
@@ -308,7 +310,7 @@ int demod_reset_state(dvbs2gpu_demod* d) {
     st.agc_gain = 1.0f;
     st.g_freq = 1.0f;
     HIP_TRY(hipMemcpy(d->d_state, &st, sizeof(st), hipMemcpyHostToDevice));
-    d->fifo_fill = 0; d->pending_pos = 0; d->last_best_match = 0.f; d->nco_freq_host = 0.f;
+    d->fifo_fill = 0; d->pending_pos = 0; d->last_best_match = 0.f; d->nco_freq_host = 0.f; d->sym_base = 0; d->frame_pos.clear();
     return 0;
 }
 
@@ -351,7 +353,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         work[i].fifo = d->d_fifo[d->fifo_cur]; work[i].fifo_fill = d->fifo_fill; work[i].st = d->d_state;
         work[i].fifo_next = d->d_fifo[d->fifo_cur ^ 1]; work[i].out = d_out[i];
         max_count = std::max(max_count, counts[i]);
-        d->stats.clear(); d->frame_ptrs.clear();
+        d->stats.clear(); d->frame_ptrs.clear(); d->frame_pos.clear();
     }
     Workspace& ws_work = W[0];
     if ((rc = ws_work.ensure(sizeof(S2StreamWork) * n + sizeof(int) * (n + 1) + sizeof(int) * 4 * n + 64))) return rc;
@@ -454,7 +456,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     for (int i = 0; i < n; ++i) {
         first[i] = (int)frames.size();
         const cf32* base = dm[i]->d_fifo[dm[i]->fifo_cur];
-        for (int s : frame_start[i]) { frames.push_back(S2FrameRef{base + s, i, 0}); dm[i]->frame_ptrs.push_back(base + s); }
+        for (int s : frame_start[i]) { frames.push_back(S2FrameRef{base + s, i, 0}); dm[i]->frame_ptrs.push_back(base + s); dm[i]->frame_pos.push_back(dm[i]->sym_base + s); }
     }
     first[n] = (int)frames.size();
     const int nf = (int)frames.size();
@@ -527,7 +529,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     HIP_TRY(hipStreamSynchronize(st));
     for (int i = 0; i < n; ++i) {
         dvbs2gpu_demod* d = dm[i];
-        if (cur[i] > 0) { d->fifo_fill -= cur[i]; d->fifo_cur ^= 1; }
+        if (cur[i] > 0) { d->fifo_fill -= cur[i]; d->fifo_cur ^= 1; d->sym_base += cur[i]; }
         d->nco_freq_host = nco[i];
     }
     if (!pipelined) {
@@ -880,6 +882,13 @@ int dvbs2gpu_demod_get_stats(dvbs2gpu_demod* d, dvbs2gpu_frame_stats* h_out, int
 }
 
 float dvbs2gpu_demod_get_nco_freq(dvbs2gpu_demod* d) { return d ? d->nco_freq_host : 0.f; }
+
+int dvbs2gpu_demod_get_frame_positions(dvbs2gpu_demod* d, int64_t* h_out, int cap) {
+    if (!d) return DVBS2GPU_ERR_ARG;
+    const int n = (int)d->frame_pos.size();
+    for (int i = 0; h_out && i < std::min(n, cap); ++i) h_out[i] = d->frame_pos[i];
+    return n;
+}
 
 int dvbs2gpu_demod_get_tap(dvbs2gpu_demod* d, int which, void* h_dst, int cap) {
     if (!d) return DVBS2GPU_ERR_ARG;

@@ -436,3 +436,32 @@ def test_one_long_stream_cut_into_overlapping_segments(engine, pkg):
         assert set(range(lo, min(hi, total - 1))) <= set(good), (g, lo, hi, got)
         covered |= {k for k in good if lo <= k < hi}
     assert covered >= set(range(warm, min(warm + nseg * own, total - 1)))               # the union is the transmitted sequence
+
+
+@pytest.mark.parametrize('modcod,short,nseg,own,warm,total', [(6, 1, 6, 10, 8, 150), (14, 1, 5, 12, 10, 140)])
+def test_segment_receiver_returns_one_continuous_stream_in_order(engine, pkg, modcod, short, nseg, own, warm, total):
+    """dvbs2gpu_segrx_*: one continuous signal (carrier, phase and timing offsets) handed over in chunks of different lengths; the
+    returned BBFRAMEs are the transmitted ones, in order, without a duplicate or a gap (the loops' first acquisition at the very
+    start of the stream and the frames still waiting in the last chunk's tail aside)."""
+    import torch
+    iq, bb, _ = orc.transmit(modcod, short, 0, nframes=total, seed=91 + modcod, esn0_db=16.0, cfo=2e-4, timing=0.3, phase0=0.7, lead_symbols=211)
+    index = {bytes(b): k for k, b in enumerate(bb)}
+    assert len(index) == total
+    kb = bb.shape[1]
+    rx = pkg.SegmentReceiver(engine, engine.default_cfg(modcod, bool(short), False), nseg, own, warm)
+    d_iq = torch.from_numpy(iq).cuda()
+    out = torch.zeros((nseg * own + warm + 8) * kb, dtype=torch.uint8, device='cuda')
+    got, a, k = [], 0, 0
+    sizes = [rx.chunk_samples, rx.chunk_samples // 3 + 1001, rx.chunk_samples]
+    while a < iq.size:
+        n = min(sizes[k % len(sizes)], iq.size - a)
+        nbytes = rx.process(d_iq[a:a + n], out)
+        got += [index.get(bytes(x), -1) for x in out[:nbytes].cpu().numpy().reshape(-1, kb)]
+        a += n
+        k += 1
+    rx.close()
+    good = [g for g in got if g >= 0]
+    bad_positions = [i for i, g in enumerate(got) if g < 0]
+    assert all(i < 12 for i in bad_positions), (bad_positions, got[:20])            # only while the loops first acquire
+    assert good == list(range(good[0], good[0] + len(good))), got                     # in order, no duplicate, no gap
+    assert good[0] <= 12 and good[-1] >= total - 4, (good[0], good[-1])
