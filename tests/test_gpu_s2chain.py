@@ -465,3 +465,29 @@ def test_segment_receiver_returns_one_continuous_stream_in_order(engine, pkg, mo
     assert all(i < 12 for i in bad_positions), (bad_positions, got[:20])            # only while the loops first acquire
     assert good == list(range(good[0], good[0] + len(good))), got                     # in order, no duplicate, no gap
     assert good[0] <= 12 and good[-1] >= total - 4, (good[0], good[-1])
+
+
+def test_segment_receiver_with_calls_shorter_than_its_history(engine, pkg):
+    """chunks of 3 frames (shorter than the warm-up history the receiver keeps): every call re-acquires on the kept history and returns
+    only what the previous calls have not; still one ordered, gap-free sequence.  reset() starts a new stream."""
+    import torch
+    m, s, total = 6, 1, 70
+    iq, bb, _ = orc.transmit(m, s, 0, nframes=total, seed=17, esn0_db=16.0, cfo=2e-4, timing=0.3, phase0=1.1, lead_symbols=77)
+    index = {bytes(b): k for k, b in enumerate(bb)}
+    kb = bb.shape[1]
+    spf = 2 * pkg.modcod_info(m, True, False)['plframe_symbols']
+    rx = pkg.SegmentReceiver(engine, engine.default_cfg(m, True, False), 2, 8, 8)
+    d_iq = torch.from_numpy(iq).cuda()
+    out = torch.zeros(40 * kb, dtype=torch.uint8, device='cuda')
+    for rep in range(2):
+        got = []
+        for a in range(0, iq.size, 3 * spf + 10):
+            nbytes = rx.process(d_iq[a:a + 3 * spf + 10], out)
+            got += [index.get(bytes(x), -1) for x in out[:nbytes].cpu().numpy().reshape(-1, kb)]
+        good = [g for g in got if g >= 0]
+        assert all(i < 12 for i, g in enumerate(got) if g < 0), got
+        assert good == list(range(good[0], good[0] + len(good))) and good[0] <= 12 and good[-1] >= total - 4, got
+        rx.reset()
+    with pytest.raises(pkg.Dvbs2GpuError):
+        rx.process(torch.zeros(rx.chunk_samples + 2, dtype=torch.complex64, device='cuda'), out)
+    rx.close()
