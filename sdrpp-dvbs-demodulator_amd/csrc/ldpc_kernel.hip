@@ -363,14 +363,16 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
             PROF_T(t_m4);
             PROF_ADD(9, t_m0, t_m1); PROF_ADD(10, t_m1, t_m2); PROF_ADD(11, t_m2, t_m3); PROF_ADD(12, t_m3, t_m4);
             if (active) {
+                // both late inputs are fetched before either is used (one LDS round trip instead of two behind the branches)
+                const int xL = (int)(int8_t)cres[j], xE = (int)LDS_I8(addr[0]);
                 if ((late >> 1) & 1) {
-                    int v = clamp8((int)(int8_t)cres[j] - rec_byte<REC>(rec_in, 1));
+                    int v = clamp8(xL - rec_byte<REC>(rec_in, 1));
                     int m = mag_of(v);
                     LINK_SET(1, v, m);
                     ROW_ACCUM(v, m);
                 }
                 if (late & 1u) {
-                    int v = clamp8((int)LDS_I8(addr[0]) - rec_byte<REC>(rec_in, 0));
+                    int v = clamp8(xE - rec_byte<REC>(rec_in, 0));
                     int m = mag_of(v);
                     LINK_SET(0, v, m);
                     ROW_ACCUM(v, m);
