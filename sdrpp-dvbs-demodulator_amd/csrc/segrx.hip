@@ -149,15 +149,28 @@ int dvbs2gpu_segrx_process(dvbs2gpu_segrx* r, const float* d_iq, long long count
         i = j;
     }
     long long bytes = 0;
+    // frames of one segment sit back to back in its output buffer: consecutive ones leave in one copy
+    long long run_dst = 0; size_t run_src = 0, run_len = 0;
+    auto flush = [&]() -> int {
+        if (run_len) HIP_TRY(hipMemcpyAsync(d_out + run_dst, r->d_segout + run_src, run_len, hipMemcpyDeviceToDevice, nullptr));
+        run_len = 0;
+        return 0;
+    };
     for (const Found& k : keep) {
         if (!k.trusted && !k.decoded) { ++r->last_dropped; continue; }                                    // seen only inside a warm-up and not decodable there
         if (r->emitted_any && k.pos < r->last_emit + spf / 2) continue;                                   // the previous call returned it
         if (bytes + r->kb > out_cap) { g_err = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
-        HIP_TRY(hipMemcpyAsync(d_out + bytes, r->d_segout + (size_t)k.seg * r->out_stride + (size_t)k.idx * r->kb, (size_t)r->kb,
-                               hipMemcpyDeviceToDevice, nullptr));
+        const size_t src = (size_t)k.seg * r->out_stride + (size_t)k.idx * r->kb;
+        if (run_len && src == run_src + run_len) {
+            run_len += (size_t)r->kb;
+        } else {
+            if ((rc = flush())) return rc;
+            run_dst = bytes; run_src = src; run_len = (size_t)r->kb;
+        }
         bytes += r->kb;
         r->last_emit = k.pos; r->emitted_any = true; ++r->last_emitted;
     }
+    if ((rc = flush())) return rc;
     // ---- history for the next call: the last hist_cap samples of the stream
     if (n >= r->hist_cap) {
         HIP_TRY(hipMemcpyAsync(r->d_hist, d_iq + 2 * (n - r->hist_cap), sizeof(float) * 2 * r->hist_cap, hipMemcpyDeviceToDevice, nullptr));
