@@ -121,3 +121,14 @@ def test_ldpc_plan_matches_reference_row_order(pkg, rate, short):
         for b, lst in owner.items():
             for a in range(1, len(lst)):
                 assert lvl[lst[a][0]] > lvl[lst[a - 1][0]]        # the later row waits for the earlier one
+
+
+def test_header_is_plain_c(tmp_path):
+    """the drop-in boundary is a C ABI: include/dvbs2gpu.h must compile as C99 on its own (no C++, no torch types)"""
+    import subprocess
+    src = tmp_path / 'hdr.c'
+    src.write_text('#include "dvbs2gpu.h"\nint main(void) { return 0; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include')
+    r = subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I', inc, '-c', str(src), '-o', str(tmp_path / 'hdr.o')],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
