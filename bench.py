@@ -81,6 +81,38 @@ def make_blocks(frames, seed, eng=None, pkg=None):
     return [cands[i][0] for i in keep], [cands[i][1] for i in keep]
 
 
+def single_transponder(eng, pkg, nseg=512, own=8, warm=8, calls=3):
+    """side measurement (not `value`): ONE continuous 8PSK 3/4 transponder through the segment receiver (dvbs2gpu_segrx_*): its IQ is
+    cut into overlapping segments that run as independent streams and are stitched back in order -- the answer to "a stream's loops are
+    serial" for a single 27.5 Msym/s carrier.  LDPC with early exit (this is a receive path, not the forced-iteration stress)."""
+    import torch
+    import orc
+    period = 16
+    info = pkg.modcod_info(MODCOD, bool(SHORT), bool(PILOTS))
+    kb, sym = info['kbch'] // 8, info['plframe_symbols']
+    iq, bb, _ = orc.transmit(MODCOD, SHORT, PILOTS, nframes=period, seed=5, esn0_db=16.0, cfo=1e-4, timing=0.3, phase0=0.2, lead_symbols=0, circular=1)
+    index = {bytes(b): k for k, b in enumerate(bb)}
+    rx = pkg.SegmentReceiver(eng, eng.default_cfg(MODCOD, bool(SHORT), bool(PILOTS)), nseg, own, warm)
+    chunk = torch.from_numpy(iq).cuda().repeat(rx.chunk_samples // iq.size)
+    out = torch.zeros((nseg * own + warm + 8) * kb, dtype=torch.uint8, device='cuda')
+    seq, times = [], []
+    for _ in range(calls):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nbytes = rx.process(chunk, out)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        seq += [index.get(bytes(x), -1) for x in out[:nbytes].cpu().numpy().reshape(-1, kb)]
+    rx.close()
+    good = [k for k in seq if k >= 0]
+    steps = [(b - a) % period for a, b in zip(good, good[1:])]
+    dt = min(times[1:])
+    return {'value': round(nseg * own * sym / dt / 1e6, 1), 'unit': 'Msymbols/s of ONE continuous stream', 'ms_per_call': round(dt * 1e3, 1),
+            'segments': nseg, 'own_frames': own, 'warmup_frames': warm, 'chunk_symbols': nseg * own * sym,
+            'frames_returned': len(seq), 'frames_not_transmitted_ones': len(seq) - len(good), 'frames_out_of_sequence': sum(1 for s in steps if s != 1),
+            'realtime_factor_at_27.5_Msym_s': round(nseg * own * sym / dt / 27.5e6, 2)}
+
+
 def cpu_baseline(frames_block, budget_s=10.0):
     """CPU path on this box's host cores.  FEC: the reference's own code (oracle/_ref: LDPC with 16 frames in the
     16 int8 SSE4.1 lanes of one call, 50 iterations on noise LLRs = never converges = same work as the forced GPU
@@ -170,6 +202,7 @@ def main():
     ap.add_argument('--streams', type=int, default=4096, help='transponder streams per GPU')
     ap.add_argument('--frames', type=int, default=1, help='PLFRAMEs per stream per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-aux', action='store_true', help='skip the single-transponder (segment receiver) side measurement')
     ap.add_argument('--no-pipeline', action='store_true', help='run the FEC inside the call that produced the frames (no overlap with the next front end)')
     args = ap.parse_args()
 
@@ -313,6 +346,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(blocks)
+        if world == 1 and not args.no_aux:
+            line['single_transponder'] = single_transponder(eng, pkg)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

@@ -21,5 +21,5 @@ if __name__ == '__main__':
     name = sys.argv[1] if len(sys.argv) > 1 else 'qpsk12'
     for k, v in CONFIGS[name].items():
         setattr(bench, k, v)
-    sys.argv = [sys.argv[0]] + sys.argv[2:] + ['--no-cpu-baseline']
+    sys.argv = [sys.argv[0]] + sys.argv[2:] + ["--no-cpu-baseline", "--no-aux"]
     bench.main()

@@ -1,6 +1,6 @@
 cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 FRAMES=4096 ITERS=50 timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/probe1 -- python3 $R/tools/pmc_ldpc.py 6 > /dev/null 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/probe2 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipeline > $R/gpurun_out/probe2.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/probe2 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-aux --no-pipeline > $R/gpurun_out/probe2.log 2>&1
 cd $R
 python - <<'PY'
 import sqlite3,glob
