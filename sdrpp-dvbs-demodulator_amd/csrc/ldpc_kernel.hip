@@ -329,6 +329,8 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                 // rows ahead, plain address increments.  (A hand-scheduled assembly version of this loop -- 11 instructions
                 // per row -- was bit-exact on its own and 1 % faster, but produced wrong frames when the front-end kernels of
                 // the pipelined mode shared the CUs; the cause was not found, so the loop is left to the compiler.)
+                // the walker is the only wave of its slot that runs: co-resident front-end waves (priority 3) must not starve it
+                __builtin_amdgcn_s_setprio(3);
                 const uint32_t eL = ents[1];
                 const int T = 359 / chain_d;
                 int x = post[link_addr(eL, j + chain_d)];                 // written by the level-1 row j (its E link)
@@ -357,6 +359,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                     pr += chain_d;
                 }
                 if (j + T * chain_d < 360) pr[0] = (uint8_t)x;
+                __builtin_amdgcn_s_setprio(0);
             }
             PROF_T(t_m3);
             lds_barrier();
@@ -385,6 +388,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
         for (int lvl = 1; lvl <= depth; ++lvl) {
             if (lvl > 1) lds_barrier();
             if (active && level == (uint32_t)lvl) {
+                __builtin_amdgcn_s_setprio(3);       // few waves have rows at a level and everyone waits for them (see the chain walk)
                 // (blocking LICM of the per-link mask tests with an empty asm was measured slower on MI355X: r01 A/B variant "e")
                 const uint32_t late_l = late, early_l = early;
                 if (lvl > 1) {
@@ -412,6 +416,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                         LDS_I8(addr[k]) = (int8_t)clamp8(LINK_IN(k) + nm);
                     }
                 }
+                __builtin_amdgcn_s_setprio(0);
             }
         }
         }
