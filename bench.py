@@ -197,7 +197,7 @@ def cpu_baseline(frames_block, budget_s=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--streams', type=int, default=4096, help='transponder streams per GPU')
     ap.add_argument('--frames', type=int, default=1, help='PLFRAMEs per stream per step')
