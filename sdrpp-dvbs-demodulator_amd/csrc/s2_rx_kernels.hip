@@ -908,8 +908,8 @@ __device__ __forceinline__ cf32 fd_dot_wave(const cf32 (&x)[4], const float* t, 
 // ONE WAVE PER STREAM: clock_recovery::COMPLEX_FD::process (complex_fd.cpp:89-150, 256 phases x 256 taps, outSps = 1) followed by
 // loop::Costas<4> on every produced symbol (feed-forward after the timing loop).  The interpolator bank is 256 KB; the loop
 // phase moves slowly, so a window of FD_WROWS consecutive bank rows is kept in LDS and re-centred when the phase leaves it.
-constexpr int FD_TILE = 512;
-constexpr int FD_WROWS = 8;
+constexpr int FD_TILE = 256;
+constexpr int FD_WROWS = 4;
 __global__ __launch_bounds__(64) void dvbs_fd_costas_kernel(const DvbsStreamWork* __restrict__ work, DvbsLoopCoefs co,
                                                             const float* __restrict__ bank) {
     __shared__ cf32 win[FD_TILE + FD_TAPS];      // [255 history][tile]
