@@ -732,10 +732,10 @@ int dvbs2gpu_demod_get_kbch(dvbs2gpu_demod* d) { return d ? d->mp.fec.kbch : DVB
 int dvbs2gpu_set_pipelined(dvbs2gpu_ctx* ctx, int on) {
     if (!ctx) return DVBS2GPU_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    if (on && !ctx->fe_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&ctx->fe_stream, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&ctx->fec_stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_llr, hipEventDisableTiming));
+    if (on) {      // (the FEC stream may exist already: synchronous mixed batches use it too)
+        if (!ctx->fe_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->fe_stream, hipStreamNonBlocking));
+        if (!ctx->fec_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->fec_stream, hipStreamNonBlocking));
+        if (!ctx->ev_llr) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_llr, hipEventDisableTiming));
     }
     if (!on && ctx->fec_stream) {
         // frames of the last pipelined call that nobody collected are dropped (collect them with a zero-count call first)
