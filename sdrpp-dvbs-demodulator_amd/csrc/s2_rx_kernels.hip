@@ -80,6 +80,13 @@ __device__ __forceinline__ cf32 dot8(const cf32* x, const float* t) {
 // polynomials (~1 ULP).  Used instead of the device libm on the serial per-sample paths (~35 instructions
 // for both values, no slow-path branches).  sincos(0) = (0, 1) exactly.
 __device__ __forceinline__ cf32 phasor_fast(float x) {
+#ifdef S2_HW_SINCOS
+    // A/B switch, NOT used: the hardware's v_sin_f32 / v_cos_f32 (input in revolutions, ~1e-6 absolute error instead of ~1 ULP) make the
+    // serial kernels 6-16 % faster (DVB-S bank of 4096: 966 -> 1121 Msym/s, S2 headline +1.5 %) but the symbol-level comparison with
+    // the oracle (tests/test_gpu_s2chain.py::test_demod_end_to_end_vs_oracle) no longer holds, so the ~1-ULP polynomial stays
+    const float rv = x * 0.15915494309189535f;
+    return cf32{__builtin_amdgcn_cosf(rv), __builtin_amdgcn_sinf(rv)};
+#endif
     float ax = fabsf(x);
     int j = (int)(ax * 1.27323954473516f);
     j = (j + 1) & ~1;
