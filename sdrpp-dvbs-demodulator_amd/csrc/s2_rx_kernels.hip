@@ -102,6 +102,13 @@ __device__ __forceinline__ cf32 phasor_fast(float x) {
     if (x < 0.f) sn = -sn;
     return cf32{cs, sn};
 }
+// The hardware's v_sin_f32 / v_cos_f32 (argument in revolutions; ~1e-6 absolute error, sincos(0) = (0, 1) exactly): used by the
+// DVB-S loops (FLL, Costas), whose parity with the oracle is statistical while the loops run and exact at zero bandwidth (phase 0);
+// 3 instead of ~35 instructions in chains that are bound by the instructions they issue.
+__device__ __forceinline__ cf32 phasor_hw(float x) {
+    const float rv = x * 0.15915494309189535f;
+    return cf32{__builtin_amdgcn_cosf(rv), __builtin_amdgcn_sinf(rv)};
+}
 
 // The front end is split along its dependency structure:
 //   agc_pc_kernel      LANE = STREAM.  The AGC gain and NCO phase recurrences depend only on the input, are strictly serial in
@@ -821,7 +828,7 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
         if (lane < m) ytile[lane] = w.buf_a[base + lane];
         __syncthreads();
         for (int k = 0; k < m; ++k) {
-            const cf32 x = cmul(ytile[k], phasor_fast(-phase));
+            const cf32 x = cmul(ytile[k], phasor_hw(-phase));
             // complete this sample's two outputs: partial sum leaving lane 63 + newest sample * last tap
             cf32 pl, ph;
             pl.re = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al.re), 63));
@@ -970,7 +977,7 @@ __global__ __launch_bounds__(64) void dvbs_fd_costas_kernel(const DvbsStreamWork
             offset = (int)((float)offset + delta);       // `offset += delta` with an int offset and a float delta
             pcl.phase -= delta;
             // Costas<4> (SDR++ loop/costas.h): derotate, decision-directed QPSK error, clamp, advance
-            const cf32 v = cmul(outVal, phasor_fast(-cos.phase));
+            const cf32 v = cmul(outVal, phasor_hw(-cos.phase));
             float cerr = ((v.re > 0 ? 1.0f : -1.0f) * v.im) - ((v.im > 0 ? 1.0f : -1.0f) * v.re);
             cerr = cerr > 1.0f ? 1.0f : (cerr < -1.0f ? -1.0f : cerr);
             cos.advance(cerr);
