@@ -788,11 +788,13 @@ __device__ __forceinline__ float fast_amplitude(cf32 v) {   // SDR++ complex_t::
     const float re_abs = fabsf(v.re), im_abs = fabsf(v.im);
     return re_abs > im_abs ? re_abs + 0.4f * im_abs : im_abs + 0.4f * re_abs;
 }
+// CLAMP_PHASE with [-pi, pi] for loops whose phase moves by less than 2 pi per step (FLL: |freq| <= pi/2, Costas: pi/10 + alpha): the
+// reference's two while loops then run at most once each, and two selects give the same value without the divergent loop code
 __device__ __forceinline__ void pcl_wrap_pi(float& phase) {
     const float PI_F = 3.14159265358979323846f;
     const float delta = PI_F - (-PI_F);
-    while (phase > PI_F) phase -= delta;
-    while (phase < -PI_F) phase += delta;
+    phase = phase > PI_F ? phase - delta : phase;
+    phase = phase < -PI_F ? phase + delta : phase;
 }
 
 // ONE WAVE PER STREAM.  loop::FLL::process (fll.cpp:135-149): every sample is rotated by the loop phase and fed to the two
@@ -981,7 +983,7 @@ __global__ __launch_bounds__(64) void dvbs_fd_costas_kernel(const DvbsStreamWork
             float cerr = ((v.re > 0 ? 1.0f : -1.0f) * v.im) - ((v.im > 0 ? 1.0f : -1.0f) * v.re);
             cerr = cerr > 1.0f ? 1.0f : (cerr < -1.0f ? -1.0f : cerr);
             cos.advance(cerr);
-            cos.wrap_pi();
+            pcl_wrap_pi(cos.phase);
             if (lane == 0) ostage[nout] = v;
             ++nout;
         }
