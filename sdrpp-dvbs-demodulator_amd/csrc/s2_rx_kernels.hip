@@ -60,6 +60,14 @@ struct PclDev {
         freq = freq > maxFreq ? maxFreq : (freq < minFreq ? minFreq : freq);
         phase += freq + alpha * err;
     }
+    // the same for a phase that moved by less than 2 pi since it was last wrapped (every per-symbol advance of the PLL, PLHDR and
+    // Costas loops: |freq| <= pi, |alpha * err| << pi): the two while loops below run at most once each -> two selects, no divergent code
+    __device__ __forceinline__ void wrap_pi_once() {
+        const float PI_F = 3.14159265358979323846f;
+        const float delta = PI_F - (-PI_F);
+        phase = phase > PI_F ? phase - delta : phase;
+        phase = phase < -PI_F ? phase + delta : phase;
+    }
     __device__ __forceinline__ void wrap_pi() {   // CLAMP_PHASE with [-pi, pi]
         const float PI_F = 3.14159265358979323846f;
         const float delta = PI_F - (-PI_F);
@@ -664,7 +672,7 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
                 }
                 if (gl == 0) otile[g][k] = o;
                 pll.advance(error);
-                pll.wrap_pi();
+                pll.wrap_pi_once();
             }
             __syncthreads();
             if (fact)
@@ -685,7 +693,7 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
                 plheader = plheader << 1 | (unsigned long long)(!value);
             }
             hdr.advance(error);
-            hdr.wrap_pi();
+            hdr.wrap_pi_once();
         }
         hdr.phase += hdr.freq * (plframe - 91);
         hdr.advance(0.f);
