@@ -145,3 +145,31 @@ def test_output_space_rules():
     p = B.OracleBbTs(kbch)
     out = p.work(fr, cap=fr.size + 376)
     assert out.size == ((4 * D - 1) // 188) * 188
+
+
+def test_golden_vectors():
+    """tests/golden/bbts_golden.json (generator: tests/golden/make_golden_bbts.py): clean round trips whose expected output is the
+    transmitted packet sequence, and fuzzed sequences anchored on the restatement's own output (regression only: parity unpinned)"""
+    import hashlib
+    import json
+    import os
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bbts_golden.json')))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    for c in G['ts_round_trip']:
+        rng = np.random.default_rng(c['seed'])
+        D = c['dfl_bytes'] if c['dfl_bytes'] is not None else c['kbch'] // 8 - 10
+        pk = B.ts_packets(c['nframes'] * D // 188 + 2, rng)
+        fr = B.bbframes_from_ts(pk, c['kbch'], c['nframes'], c['dfl_bytes'])
+        assert sha(fr) == c['sha256_in']
+        p = B.OracleBbTs(c['kbch'])
+        out = np.concatenate([p.work(fr[:4]), p.work(fr[4:])])
+        assert sha(out) == c['sha256_out'] and out.size == 188 * c['packets_out']
+    for c in G['fuzz']:
+        rng = np.random.default_rng(c['seed'])
+        p = B.OracleBbTs(c['kbch'])
+        for call in range(c['calls']):
+            fr = B.fuzz_frames(rng, c['kbch'], int(rng.integers(0, 6)), ts_gs_choices=tuple(c['ts_gs_choices']), p_bad=0.2)
+            o = p.work(fr, cap=fr.size + 376)
+            st = p.stats()
+            assert sha(o) == c['sha256_out_per_call'][call]
+            assert [st['synched'], st['last_bb_proc'], st['last_gse_crc_err'], st['ts_gs'], int(o.size)] == c['state_per_call'][call]
