@@ -309,6 +309,11 @@ class Demod:
     def get_kbch(self):
         return self.lib.dvbs2gpu_demod_get_kbch(self.h)
 
+    def set_params(self, modcod, shortframes, pilots, sof_threshold=0.6, max_ldpc_trials=16):
+        """DVBS2Demod::setDemodParams (module_dvbs2_demod.cpp:118-168)"""
+        self.eng._check(self.lib.dvbs2gpu_demod_set_params(self.h, int(modcod), int(bool(shortframes)), int(bool(pilots)), float(sof_threshold), int(max_ldpc_trials)))
+        self.info = modcod_info(modcod, bool(shortframes), bool(pilots))
+
     def process(self, iq):
         """iq: numpy complex64 1-D (host, 2 sps) -> numpy uint8 [frames, kbch/8]"""
         import numpy as np

@@ -723,6 +723,7 @@ int dvbs2gpu_demod_set_params(dvbs2gpu_demod* d, int modcod, int shortframes, in
     int rc = demod_configure(d);
     if (rc) { d->cfg = saved; (void)demod_configure(d); return rc; }
     // setDemodParams restarts the PL sync buffer (dvbs2_pl_sync.cpp:51-79); loops keep running
+    d->sym_base += d->fifo_fill;      // (the dropped symbols still count on the stream's symbol axis)
     d->fifo_fill = 0; d->pending_pos = 0;
     return 0;
 }

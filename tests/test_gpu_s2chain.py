@@ -491,3 +491,33 @@ def test_segment_receiver_with_calls_shorter_than_its_history(engine, pkg):
     with pytest.raises(pkg.Dvbs2GpuError):
         rx.process(torch.zeros(rx.chunk_samples + 2, dtype=torch.complex64, device='cuda'), out)
     rx.close()
+
+
+def test_reset_and_set_params(engine, pkg):
+    """control plane of the handle: reset() (DVBS2Demod::reset, module_dvbs2_demod.cpp:98-116) makes the next run identical to a fresh
+    handle's; set_params (setDemodParams, :118-168) switches MODCOD / frame size between calls and restarts the PL sync buffer; a bad
+    MODCOD is refused with ERR_MODCOD and leaves the configuration alone"""
+    iq_a, bb_a, _ = orc.transmit(4, 1, 0, nframes=8, seed=501, esn0_db=20.0, lead_symbols=150)
+    iq_b, bb_b, _ = orc.transmit(14, 1, 0, nframes=10, seed=502, esn0_db=25.0, lead_symbols=90)
+    d = engine.demod(engine.default_cfg(4, True, False), max_samples=max(iq_a.size, iq_b.size))
+    first = d.process(iq_a)
+    st1 = [(x.ldpc_trials, x.bch_corrections, x.detected_modcod) for x in d.stats()]
+    d.reset()
+    again = d.process(iq_a)
+    assert np.array_equal(first, again) and st1 == [(x.ldpc_trials, x.bch_corrections, x.detected_modcod) for x in d.stats()]
+    fresh = engine.demod(engine.default_cfg(4, True, False), max_samples=iq_a.size)
+    assert np.array_equal(first, fresh.process(iq_a))
+    fresh.close()
+    sent_a = {bytes(x) for x in bb_a}
+    assert sum(bytes(x) in sent_a for x in first) >= 5
+    kb_a = d.get_kbch()
+    with pytest.raises(pkg.Dvbs2GpuError) as ei:
+        d.set_params(29, True, False)
+    assert ei.value.code == pkg.ERR_MODCOD and d.get_kbch() == kb_a
+    d.set_params(14, True, False)
+    assert d.get_kbch() == bb_b.shape[1] * 8 and d.get_kbch() != kb_a
+    out = d.process(iq_b)
+    sent_b = {bytes(x) for x in bb_b}
+    good = [bytes(x) in sent_b for x in out]
+    assert out.shape[1] == bb_b.shape[1] and sum(good) >= 5 and all(good[-3:]), good
+    d.close()
