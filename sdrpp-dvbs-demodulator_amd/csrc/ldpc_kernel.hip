@@ -281,8 +281,11 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                 }
             }
             V[p] = v; G[p] = g;
-            MIN1 = pmin2(MIN1, pmax2(MIN0, g));
-            MIN0 = pmin2(MIN0, g);
+            // two smallest magnitudes per half; every g is <= the "no link" sentinel the trackers start from, so the first two pairs need
+            // no comparison against it
+            if (p == 0) { MIN0 = g; }
+            else if (p == 1) { MIN1 = pmax2(MIN0, g); MIN0 = pmin2(MIN0, g); }
+            else { MIN1 = pmin2(MIN1, pmax2(MIN0, g)); MIN0 = pmin2(MIN0, g); }
             SX ^= bits2(v);
         }
         // merge the even-link and odd-link halves
