@@ -288,6 +288,23 @@ int dvbs2gpu_dvbs_demod_get_stats(dvbs2gpu_dvbs_demod* d, dvbs2gpu_viterbi_stats
  * element count; copies at most cap elements when h_dst != NULL. */
 int dvbs2gpu_dvbs_demod_get_tap(dvbs2gpu_dvbs_demod* d, int stream, int which, void* h_dst, int cap);
 
+/* ------------------------------------------------------------------ DVB-S segment receiver: ONE fast DVB-S carrier
+ * The DVB-S counterpart of dvbs2gpu_segrx_*: one continuous IQ stream is cut into `nsegments` overlapping segments of `own_symbols`
+ * (+ `warm_symbols` of warm-up in front, own >= warm >= 8192) that run as the streams of one receiver-bank call with fresh loops and
+ * a fresh Viterbi lock search; their decoded bit streams are joined where they overlap (the bits already handed out are searched for
+ * in the next segment's output) and returned as ONE bit stream in order (one bit per byte), ready for dvbs2gpu_dvbs_tail_*.  A segment
+ * that does not lock inside its overlap leaves a discontinuity (the deframer behind resynchronises); get_stats counts those.
+ * d_iq: DEVICE pointer to `count` complex samples continuing the stream (count <= chunk_samples); d_bits: DEVICE buffer of cap bytes;
+ * returns the number of bits written or a negative error.  No counterpart in the reference (one DVBSDemod per carrier, serial). */
+typedef struct dvbs2gpu_dvbs_segrx dvbs2gpu_dvbs_segrx;
+int dvbs2gpu_dvbs_segrx_create(dvbs2gpu_ctx* ctx, const dvbs2gpu_dvbs_cfg* cfg, int nsegments, int own_symbols, int warm_symbols, dvbs2gpu_dvbs_segrx** out);
+int dvbs2gpu_dvbs_segrx_reset(dvbs2gpu_dvbs_segrx* r);
+void dvbs2gpu_dvbs_segrx_destroy(dvbs2gpu_dvbs_segrx* r);
+long long dvbs2gpu_dvbs_segrx_chunk_samples(dvbs2gpu_dvbs_segrx* r);
+int dvbs2gpu_dvbs_segrx_process(dvbs2gpu_dvbs_segrx* r, const float* d_iq, long long count, uint8_t* d_bits, long long cap);
+/* h_out4 = {segments of the last call, joined by a match, without a match, bits returned} */
+int dvbs2gpu_dvbs_segrx_get_stats(dvbs2gpu_dvbs_segrx* r, int32_t* h_out4);
+
 /* ------------------------------------------------------------------ DVB-S tail (row f: after the Viterbi decoder)
  * Replaces DVBSDefra::process / DVBS_TS_Deframer::work (dvbs/dvbs_defra.cpp:5-9, dvbs_ts_deframer.cpp:37-92), the per-frame
  * loop of DVBSDemod::process (module_dvbs_demod.cpp:83-99): DVBSInterleaving::deinterleave, 8 x DVBSReedSolomon::decode

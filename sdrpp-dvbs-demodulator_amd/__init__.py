@@ -107,6 +107,12 @@ PROTOTYPES = {
     'dvbs2gpu_segrx_chunk_samples': (C.c_longlong, [_vp]),
     'dvbs2gpu_segrx_process': (_i, [_vp, _vp, C.c_longlong, _vp, C.c_longlong]),
     'dvbs2gpu_segrx_get_stats': (_i, [_vp, C.POINTER(C.c_int32)]),
+    'dvbs2gpu_dvbs_segrx_create': (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_vp)]),
+    'dvbs2gpu_dvbs_segrx_reset': (_i, [_vp]),
+    'dvbs2gpu_dvbs_segrx_destroy': (None, [_vp]),
+    'dvbs2gpu_dvbs_segrx_chunk_samples': (C.c_longlong, [_vp]),
+    'dvbs2gpu_dvbs_segrx_process': (_i, [_vp, _vp, C.c_longlong, _vp, C.c_longlong]),
+    'dvbs2gpu_dvbs_segrx_get_stats': (_i, [_vp, C.POINTER(C.c_int32)]),
     'dvbs2gpu_bbts_create': (_i, [_vp, _i, _i, _i, C.POINTER(_vp)]),
     'dvbs2gpu_bbts_set_frame_size': (_i, [_vp, _i]),
     'dvbs2gpu_bbts_destroy': (None, [_vp]),
@@ -596,3 +602,32 @@ class SegmentReceiver(_Handle):
         a = (C.c_int32 * 3)()
         self.eng._check(self.lib.dvbs2gpu_segrx_get_stats(self.h, a))
         return {'sightings': a[0], 'returned': a[1], 'warmup_only': a[2]}
+
+
+class DvbsSegmentReceiver(_Handle):
+    """One fast DVB-S carrier: overlapping segments through the receiver bank, decoded bit streams joined in order
+    (include/dvbs2gpu.h, DVB-S segment receiver)."""
+    _destroy = 'dvbs2gpu_dvbs_segrx_destroy'
+
+    def __init__(self, engine, nsegments, own_symbols, warm_symbols, **kw):
+        self.eng, self.lib = engine, engine.lib
+        self.cfg = DvbsCfg()
+        self.lib.dvbs2gpu_dvbs_demod_default_cfg(C.byref(self.cfg))
+        for k, v in kw.items():
+            setattr(self.cfg, k, v)
+        h = C.c_void_p()
+        engine._check(self.lib.dvbs2gpu_dvbs_segrx_create(engine.h, C.byref(self.cfg), nsegments, own_symbols, warm_symbols, C.byref(h)))
+        self.h = h
+        self.chunk_samples = int(self.lib.dvbs2gpu_dvbs_segrx_chunk_samples(self.h))
+
+    def reset(self):
+        self.eng._check(self.lib.dvbs2gpu_dvbs_segrx_reset(self.h))
+
+    def process(self, iq, out):
+        """iq: complex64 CUDA 1-D (continues the stream), out: uint8 CUDA buffer -> number of bits written (one per byte)"""
+        return self.eng._check(self.lib.dvbs2gpu_dvbs_segrx_process(self.h, C.c_void_p(iq.data_ptr()), int(iq.numel()), C.c_void_p(out.data_ptr()), int(out.numel())))
+
+    def stats(self):
+        a = (C.c_int32 * 4)()
+        self.eng._check(self.lib.dvbs2gpu_dvbs_segrx_get_stats(self.h, a))
+        return {'segments': a[0], 'matched': a[1], 'unmatched': a[2], 'bits': a[3]}

@@ -133,3 +133,37 @@ def test_dvbs_end_to_end_iq_to_ts(engine, pkg):
     # minus loop acquisition / Viterbi lock at the start and the interleaver's 11-packet history
     assert len(got) >= 120 and hits >= len(got) - 24, (len(got), hits)
     rx.close(); tail.close()
+
+
+def test_dvbs_segment_receiver_to_ts_packets(engine, pkg):
+    """one DVB-S carrier, IQ -> dvbs2gpu_dvbs_segrx_* (segments demodulated side by side, bit streams joined) -> dvbs2gpu_dvbs_tail_* ->
+    TS packets: after the start-up every packet that comes out is one that was sent, consecutive and without a gap (the joined stream is
+    one bit stream: the deframer keeps its lock across the joins)"""
+    import torch
+    npk = 1400
+    obits, ts = ot.dvbs_outer_tx(npk, seed=61)
+    enc = od.cc_encode(obits)
+    nsym = enc.size // 2
+    iq = np.zeros(2 * nsym, np.complex64)
+    od.LF().orc_dvbs_modulate(P(np.ascontiguousarray(enc)), nsym, 12.0, 1e-4, 0.3, 0.2, 7, P(iq))
+    nseg, own, warm = 4, 49152, 32768
+    rx = pkg.DvbsSegmentReceiver(engine, nseg, own, warm)
+    tail = pkg.DvbsTailBank(engine, 1, max_bits=2 * nseg * own * 2 + 4 * 65536)
+    d_iq = torch.from_numpy(iq).cuda()
+    bits = torch.zeros(2 * nseg * own * 2 + 4 * 65536, dtype=torch.uint8, device='cuda')
+    out = torch.zeros(188 * 1024, dtype=torch.uint8, device='cuda')
+    got, unmatched = [], 0
+    for k, a in enumerate(range(0, iq.size, rx.chunk_samples)):
+        nb = rx.process(d_iq[a:a + rx.chunk_samples], bits)
+        unmatched += rx.stats()['unmatched'] if k else 0        # (the very first segment starts cold: its end may not have settled)
+        nby = tail.process_batch([bits[:nb]], [out])
+        got.append(out[:nby[0]].cpu().numpy().copy())
+    got = np.concatenate(got).reshape(-1, 188)
+    index = {bytes(t): i for i, t in enumerate(ts)}
+    seq = [index.get(bytes(g), -1) for g in got]
+    assert unmatched == 0 and len(seq) >= npk - 200, (unmatched, len(seq))
+    bad = [i for i in range(1, len(seq)) if seq[i] < 0 or seq[i] != seq[i - 1] + 1]
+    # everything after the first call (its 218 k bits = 133 packets) is the transmitted packet sequence, consecutive, without a gap or a repeat
+    assert not bad or bad[-1] < 140, bad[-10:]
+    assert seq[-1] >= npk - 32, seq[-1]                          # (the interleaver holds 11 packets back, the deframer works in groups of 8)
+    rx.close(); tail.close()
