@@ -304,6 +304,10 @@ long long dvbs2gpu_dvbs_segrx_chunk_samples(dvbs2gpu_dvbs_segrx* r);
 int dvbs2gpu_dvbs_segrx_process(dvbs2gpu_dvbs_segrx* r, const float* d_iq, long long count, uint8_t* d_bits, long long cap);
 /* h_out4 = {segments of the last call, joined by a match, without a match, bits returned} */
 int dvbs2gpu_dvbs_segrx_get_stats(dvbs2gpu_dvbs_segrx* r, int32_t* h_out4);
+/* The join rule by itself, on HOST buffers (one bit per byte), no device work: where in bits[0, nbits) the stream whose last ntail bits
+ * are tail[] continues (the index of the first new bit), -1 when it is not found; *inverted = 1 when the match is on the complemented
+ * bits.  The last 256 bits of the tail must occur with at most 6 mismatches, anchored on one of three 64-bit keys inside them. */
+long long dvbs2gpu_dvbs_segrx_find_join(const uint8_t* h_tail, long long ntail, const uint8_t* h_bits, long long nbits, int* inverted);
 
 /* ------------------------------------------------------------------ DVB-S tail (row f: after the Viterbi decoder)
  * Replaces DVBSDefra::process / DVBS_TS_Deframer::work (dvbs/dvbs_defra.cpp:5-9, dvbs_ts_deframer.cpp:37-92), the per-frame

@@ -198,6 +198,17 @@ int dvbs2gpu_dvbs_segrx_process(dvbs2gpu_dvbs_segrx* r, const float* d_iq, long 
     return (int)std::min<long long>(written, 0x7fffffff);
 }
 
+/* host-only: the join rule by itself (no device work), see include/dvbs2gpu.h */
+long long dvbs2gpu_dvbs_segrx_find_join(const uint8_t* h_tail, long long ntail, const uint8_t* h_bits, long long nbits, int* inverted) {
+    int inv = 0;
+    if (!h_tail || !h_bits || ntail < 0 || nbits < 0) return DVBS2GPU_ERR_ARG;
+    const long long keep = std::min<long long>(ntail, TAILWIN);
+    const std::vector<uint8_t> tail(h_tail + (ntail - keep), h_tail + ntail);
+    const long at = find_continuation(tail, h_bits, (long)nbits, &inv);
+    if (inverted) *inverted = inv;
+    return at;
+}
+
 /* h_out4 = {segments of the last call, joined by a match, without a match (discontinuity / no output), bits returned} */
 int dvbs2gpu_dvbs_segrx_get_stats(dvbs2gpu_dvbs_segrx* r, int32_t* h_out4) {
     if (!r || !h_out4) return DVBS2GPU_ERR_ARG;

@@ -132,3 +132,46 @@ def test_header_is_plain_c(tmp_path):
     r = subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I', inc, '-c', str(src), '-o', str(tmp_path / 'hdr.o')],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def _find_join(pkg, tail, bits):
+    lib = pkg.load_library()
+    tail, bits = np.ascontiguousarray(tail, np.uint8), np.ascontiguousarray(bits, np.uint8)
+    inv = C.c_int(-1)
+    at = lib.dvbs2gpu_dvbs_segrx_find_join(C.c_void_p(tail.ctypes.data), tail.size, C.c_void_p(bits.ctypes.data), bits.size, C.byref(inv))
+    return int(at), inv.value
+
+
+def test_dvbs_segment_join_rule(pkg):
+    """host logic of the DVB-S segment receiver (csrc/dvbs_segrx.hip find_continuation): where a segment's decoded bits continue the
+    stream already handed out -- exact, inverted (QPSK's 180-degree ambiguity), with bit errors inside the window and inside a key"""
+    rng = np.random.default_rng(7)
+    stream = rng.integers(0, 2, 40000, dtype=np.uint8)
+    tail = stream[:20000]                                   # handed out so far
+    seg = stream[20000 - 7000:]                             # the next segment started 7000 bits earlier
+    assert _find_join(pkg, tail, seg) == (7000, 0)
+    assert _find_join(pkg, tail, seg ^ 1) == (7000, 1)
+    assert _find_join(pkg, tail[-300:], seg) == (7000, 0)   # 256 bits of tail are enough ...
+    assert _find_join(pkg, tail[-255:], seg)[0] == -1       # ... fewer are not
+    # the segment's unsettled start is garbage: irrelevant
+    s2 = seg.copy(); s2[:5000] = rng.integers(0, 2, 5000)
+    assert _find_join(pkg, tail, s2) == (7000, 0)
+    # six bit errors inside the 256-bit window but outside the last key
+    s3 = seg.copy(); s3[7000 - 256 + np.array([3, 40, 77, 120, 150, 180])] ^= 1
+    assert _find_join(pkg, tail, s3) == (7000, 0)
+    s3[7000 - 256 + 10] ^= 1                                # the seventh breaks it
+    assert _find_join(pkg, tail, s3)[0] == -1
+    # an error inside the last 64-bit key: the second key (64 bits earlier) anchors the match
+    s4 = seg.copy(); s4[7000 - 5] ^= 1
+    assert _find_join(pkg, tail, s4) == (7000, 0)
+    s4[7000 - 70] ^= 1                                      # ... and the third
+    assert _find_join(pkg, tail, s4) == (7000, 0)
+    s4[7000 - 130] ^= 1                                     # all three keys hit
+    assert _find_join(pkg, tail, s4)[0] == -1
+    # unrelated bits, short inputs, bad arguments
+    assert _find_join(pkg, tail, rng.integers(0, 2, 30000, dtype=np.uint8))[0] == -1
+    assert _find_join(pkg, tail, seg[:200])[0] == -1
+    assert _find_join(pkg, tail, seg[:7000]) == (7000, 0)   # the match may end exactly at the end of the segment
+    assert _find_join(pkg, tail, seg[:6999])[0] == -1
+    lib = pkg.load_library()
+    assert lib.dvbs2gpu_dvbs_segrx_find_join(None, 10, None, 10, None) == pkg.ERR_ARG
