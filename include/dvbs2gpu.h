@@ -326,6 +326,11 @@ int dvbs2gpu_dvbs_tail_process_batch(dvbs2gpu_dvbs_tail* t, const uint8_t* const
                                      int* out_bytes, void* stream);
 /* h_out11 = {frames of the last call, errors_nor, errors_inv, RS error counts of the last frame's 8 packets} */
 int dvbs2gpu_dvbs_tail_get_stats(dvbs2gpu_dvbs_tail* t, int stream, int32_t* h_out11);
+/* int DVBSDemod::process(int count, const complex_t* in, uint8_t* out) as a whole (module_dvbs_demod.cpp:78-99), host buffers, for a
+ * one-stream receiver bank `d` and a one-stream tail `t` (created with max_bits >= the bank's bit capacity: max_samples is enough):
+ * count complex samples in, the TS packets completed by this call out (188 bytes each); the decoded bits stay in HBM between the
+ * two halves.  Returns the bytes written or a negative error; packets that do not fit into cap are dropped, as by the tail.  Synchronous. */
+int dvbs2gpu_dvbs_process_ts(dvbs2gpu_dvbs_demod* d, dvbs2gpu_dvbs_tail* t, int count, const float* h_iq, uint8_t* h_ts, int cap);
 
 /* ------------------------------------------------------------------ BBFRAME -> MPEG-TS / GSE parser (row f, rank 1)
  * Replaces dsp::dvbs2::BBFrameTSParser (dvbs2/bbframe_ts_parser.h:68-112, .cpp:31-390), which the reference's sink handler runs

@@ -113,6 +113,7 @@ PROTOTYPES = {
     'dvbs2gpu_dvbs_segrx_chunk_samples': (C.c_longlong, [_vp]),
     'dvbs2gpu_dvbs_segrx_process': (_i, [_vp, _vp, C.c_longlong, _vp, C.c_longlong]),
     'dvbs2gpu_dvbs_segrx_get_stats': (_i, [_vp, C.POINTER(C.c_int32)]),
+    'dvbs2gpu_dvbs_process_ts': (_i, [_vp, _vp, _i, _vp, _vp, _i]),
     'dvbs2gpu_dvbs_segrx_find_join': (C.c_longlong, [_vp, C.c_longlong, _vp, C.c_longlong, C.POINTER(C.c_int)]),
     'dvbs2gpu_bbts_create': (_i, [_vp, _i, _i, _i, C.POINTER(_vp)]),
     'dvbs2gpu_bbts_set_frame_size': (_i, [_vp, _i]),

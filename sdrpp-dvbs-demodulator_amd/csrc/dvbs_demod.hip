@@ -21,6 +21,8 @@ struct dvbs2gpu_dvbs_demod {
     int8_t* d_soft = nullptr;       // [nstreams][soft_cap]
     cf32* d_in = nullptr;           // staging for the host entry point (stream 0)
     uint8_t* d_out = nullptr;
+    uint8_t* d_ts = nullptr;        // TS staging of dvbs2gpu_dvbs_process_ts
+    size_t ts_cap = 0;
     DvbsVitState* d_vstate = nullptr;
     uint8_t* d_vws = nullptr;
     cf32* d_bandedge = nullptr;
@@ -139,7 +141,7 @@ int dvbs2gpu_dvbs_demod_reset(dvbs2gpu_dvbs_demod* d) {
 void dvbs2gpu_dvbs_demod_destroy(dvbs2gpu_dvbs_demod* d) {
     if (!d) return;
     (void)hipFree(d->d_state); (void)hipFree(d->d_buf_a); (void)hipFree(d->d_buf_b); (void)hipFree(d->d_sym); (void)hipFree(d->d_soft);
-    (void)hipFree(d->d_in); (void)hipFree(d->d_out); (void)hipFree(d->d_vstate); (void)hipFree(d->d_vws); (void)hipFree(d->d_bandedge);
+    (void)hipFree(d->d_in); (void)hipFree(d->d_out); (void)hipFree(d->d_ts); (void)hipFree(d->d_vstate); (void)hipFree(d->d_vws); (void)hipFree(d->d_bandedge);
     delete d;
 }
 
@@ -205,6 +207,32 @@ int dvbs2gpu_dvbs_demod_process(dvbs2gpu_dvbs_demod* d, int count, const float* 
     if (rc) return rc;
     if (nb) HIP_TRY(hipMemcpy(h_bits, d->d_out, (size_t)nb, hipMemcpyDeviceToHost));
     return nb;
+}
+
+// The whole of DVBSDemod::process (module_dvbs_demod.cpp:78-99) on host buffers: samples in, TS packets out; the decoded bits stay in HBM
+int dvbs2gpu_dvbs_process_ts(dvbs2gpu_dvbs_demod* d, dvbs2gpu_dvbs_tail* t, int count, const float* h_iq, uint8_t* h_ts, int cap) {
+    if (!d || !t || d->nstreams != 1 || count < 0 || cap < 0 || (count > 0 && !h_iq) || (cap > 0 && !h_ts)) return DVBS2GPU_ERR_ARG;
+    if (count > d->max_samples) { last_error() = "count exceeds max_samples"; return DVBS2GPU_ERR_ARG; }
+    HIP_TRY(hipSetDevice(d->ctx->device));
+    if (!d->d_in) HIP_TRY(hipMalloc((void**)&d->d_in, sizeof(cf32) * (size_t)d->max_samples));
+    const size_t ocap = (size_t)d->max_blocks * DVBS_SOFT_BLOCK;
+    if (!d->d_out) HIP_TRY(hipMalloc((void**)&d->d_out, ocap));
+    if (!d->d_ts) {
+        d->ts_cap = (ocap / 13056 + 2) * 8 * 188;                 // a deframer frame (8 packets) per 13056 bits, plus the carried ones
+        HIP_TRY(hipMalloc((void**)&d->d_ts, d->ts_cap));
+    }
+    if (count) HIP_TRY(hipMemcpy(d->d_in, h_iq, sizeof(cf32) * (size_t)count, hipMemcpyHostToDevice));
+    const float* pi = (const float*)d->d_in;
+    uint8_t* po = d->d_out;
+    int nb = 0;
+    int rc = dvbs2gpu_dvbs_demod_process_batch(d, &pi, &count, &po, (int)ocap, &nb);
+    if (rc) return rc;
+    const uint8_t* pb = d->d_out;
+    uint8_t* pt = d->d_ts;
+    int nbytes = 0;
+    if ((rc = dvbs2gpu_dvbs_tail_process_batch(t, &pb, &nb, &pt, (int)std::min<size_t>(d->ts_cap, (size_t)cap), &nbytes, nullptr))) return rc;
+    if (nbytes) HIP_TRY(hipMemcpy(h_ts, d->d_ts, (size_t)nbytes, hipMemcpyDeviceToHost));
+    return nbytes;
 }
 
 int dvbs2gpu_dvbs_demod_get_stats(dvbs2gpu_dvbs_demod* d, dvbs2gpu_viterbi_stats* h_out) {
