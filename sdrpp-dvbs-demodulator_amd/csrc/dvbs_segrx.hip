@@ -93,6 +93,11 @@ int dvbs2gpu_dvbs_segrx_create(dvbs2gpu_ctx* ctx, const dvbs2gpu_dvbs_cfg* cfg, 
     r->hist_cap = r->warm_s + r->tail_s;
     r->seg_cap = r->hist_cap + r->own_s + r->tail_s + 64;
     r->bits_cap = r->seg_cap + 4 * 8192;                        // at most 1.75 bits per symbol = 0.875 per sample
+    if (r->bits_cap > 0x3fffffffL) {                             // per-segment counts are ints in the bank's entry
+        delete r;
+        g_err = "DVB-S segment receiver: a segment of this many symbols does not fit the bank's int counts";
+        return DVBS2GPU_ERR_ARG;
+    }
     int rc = dvbs2gpu_dvbs_demod_create(ctx, cfg, nsegments, (int)r->seg_cap, &r->bank);
     if (rc) { r->bank = nullptr; dvbs2gpu_dvbs_segrx_destroy(r); return rc; }
     hipError_t e = hipMalloc((void**)&r->d_hist, sizeof(float) * 2 * r->hist_cap);

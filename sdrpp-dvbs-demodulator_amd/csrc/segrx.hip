@@ -59,6 +59,11 @@ int dvbs2gpu_segrx_create(dvbs2gpu_ctx* ctx, const dvbs2gpu_demod_cfg* cfg, int 
     r->hist_cap = (long)(warm_frames + 2) * r->spf;
     r->seg_cap = (long)(warm_frames + own_frames + warm_frames / 2 + 4) * r->spf + 64;
     r->out_stride = (long)(warm_frames + own_frames + warm_frames / 2 + 6) * r->kb;
+    if (r->seg_cap > 0x3fffffffL || r->out_stride > 0x7fffffffL) {      // per-segment counts are ints in the batch entry
+        delete r;
+        g_err = "segment receiver: a segment of this many frames does not fit the batch entry's int counts";
+        return DVBS2GPU_ERR_ARG;
+    }
     r->dm.assign(nsegments, nullptr);
     for (int g = 0; g < nsegments; ++g) {
         if ((rc = dvbs2gpu_demod_create(ctx, cfg, (int)r->seg_cap, &r->dm[g]))) { dvbs2gpu_segrx_destroy(r); return rc; }

@@ -130,6 +130,10 @@ def test_dvbs_demod_error_codes(engine, pkg):
     assert engine.lib.dvbs2gpu_dvbs_demod_process(one.h, 2000, C.c_void_p(iq.ctypes.data), C.c_void_p(out.ctypes.data), 100) == pkg.ERR_ARG
     assert one.process(iq[:0]).size == 0
     bank.close(); one.close()
+    for nseg, own, warm in ((0, 16384, 8192), (2, 8192, 16384), (2, 16384, 4096), (1, 1 << 30, 8192)):   # the last: beyond the bank's int counts
+        with pytest.raises(pkg.Dvbs2GpuError) as e:
+            pkg.DvbsSegmentReceiver(engine, nseg, own, warm)
+        assert e.value.code == pkg.ERR_ARG
 
 
 def _match_offset(bits, ref):

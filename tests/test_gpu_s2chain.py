@@ -521,3 +521,16 @@ def test_reset_and_set_params(engine, pkg):
     good = [bytes(x) in sent_b for x in out]
     assert out.shape[1] == bb_b.shape[1] and sum(good) >= 5 and all(good[-3:]), good
     d.close()
+
+
+def test_segment_receiver_argument_checks(engine, pkg):
+    cfg = engine.default_cfg(14, False, False)
+    for nseg, own, warm in ((0, 4, 2), (2, 2, 4), (2, 4, 0), (1, 200000, 1)):       # the last: a segment longer than the batch entry's int counts
+        with pytest.raises(pkg.Dvbs2GpuError) as e:
+            pkg.SegmentReceiver(engine, cfg, nseg, own, warm)
+        assert e.value.code == pkg.ERR_ARG
+    with pytest.raises(pkg.Dvbs2GpuError) as e:
+        bad = engine.default_cfg(14, False, False)
+        bad.modcod = 77
+        pkg.SegmentReceiver(engine, bad, 2, 4, 2)
+    assert e.value.code == pkg.ERR_MODCOD
