@@ -130,6 +130,9 @@ __device__ __forceinline__ cf32 phasor_hw(float x) {
 //                      halves of the timing error, two DPP broadcasts to hand it to the whole group.
 // Many streams = many lanes: the batch fills the GPU, and nothing here is redundant across lanes (the first version ran the
 // serial chains once per wave, 64 lanes wide, and took 47 ms for 4096 x 43380 samples; this one ~4x less).
+#ifndef FE_PRIO
+#define FE_PRIO 2   // wave priority of the serial front-end loops (A/B switch; the decoder's parallel phases run at 0, its serial ones at 3)
+#endif
 constexpr int G_TILE = 64;     // samples per stream per staging tile
 constexpr int G_SPW = 8;       // streams per wave (8 lanes each)
 constexpr int G_PITCH = G_TILE + 9;   // 7 history + tile, odd pitch spreads the rows over the LDS banks
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(128) void agc_pc_kernel(const typename TR::Work* __
     __syncthreads();
     // the serial chains are latency-critical and issue little: win the issue arbitration against throughput kernels (the LDPC
     // decoder of the previous call shares the SIMDs in the pipelined mode)
-    if (wave == 0) __builtin_amdgcn_s_setprio(2);
+    if (wave == 0) __builtin_amdgcn_s_setprio(FE_PRIO);
     for (int t = 0; t < ntiles; ++t) {
         if (wave == 0) {
             cf32(*B)[AG_T + 1] = buf[t & 1];
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(64) void s2_gardner_kernel(const S2StreamWork* __re
     };
     issue(0);
     __syncthreads();
-    __builtin_amdgcn_s_setprio(2);       // latency-critical serial loop (see agc_pc_kernel)
+    __builtin_amdgcn_s_setprio(FE_PRIO);       // latency-critical serial loop (see agc_pc_kernel)
     for (int base = 0; base < nmax; base += G_TILE) {
         commit(base);
         __syncthreads();
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
     const float PI_F = 3.14159265358979323846f;
     const cf32* __restrict__ plsc = T.plsc + (size_t)pls_code * 64;
     const int f0 = first[sc], nf = act ? first[sc + 1] - f0 : 0;
-    __builtin_amdgcn_s_setprio(2);       // latency-critical serial loops (see agc_pc_kernel)
+    __builtin_amdgcn_s_setprio(FE_PRIO);       // latency-critical serial loops (see agc_pc_kernel)
     int nfmax = nf;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nfmax = max(nfmax, __shfl_xor(nfmax, o));
@@ -949,7 +952,7 @@ __global__ __launch_bounds__(64) void dvbs_fd_costas_kernel(const DvbsStreamWork
     int wlo = -1000;                             // no window yet
     for (int i = lane; i < FD_TAPS - 1; i += 64) win[i] = st->fd_hist[i];
     __syncthreads();
-    __builtin_amdgcn_s_setprio(2);               // latency-critical serial loop (see agc_pc_kernel)
+    __builtin_amdgcn_s_setprio(FE_PRIO);               // latency-critical serial loop (see agc_pc_kernel)
     for (int base = 0; base < n; base += FD_TILE) {
         const int m = min(FD_TILE, n - base);
         for (int i = lane; i < m; i += 64) win[FD_TAPS - 1 + i] = w.buf_a[base + i];
