@@ -73,6 +73,36 @@ def demod_bench():
         st = bank.stats()[0]
         print('DVB-S bank: %d streams x %d symbols per call: %.2f ms = %.2f Msym/s total, %.3f Msym/s per stream (lock %d rate %d ber %.3f, %d bits out)'
               % (S, nsym, dt * 1e3, S * nsym / dt / 1e6, nsym / dt / 1e6, st.state, st.rate, st.ber, nb[0]))
+        if os.environ.get('DVBS_WITH_TAIL'):      # the whole of DVBSDemod::process: + TS deframer, Forney, RS(204,188), energy dispersal
+            import orc_dvbs_tail as ot
+            ncall = 5
+            obits, ts = ot.dvbs_outer_tx(ncall * nsym // 1632 + 2, seed=3)          # a continuous outer-coded stream, one chunk per call
+            enc = od.cc_encode(obits)
+            ns2 = enc.size // 2
+            iq2 = np.zeros(2 * ns2, np.complex64)
+            od.LF().orc_dvbs_modulate(od.P(np.ascontiguousarray(enc)), ns2, 12.0, 1e-3, 0.3, 0.2, 7, od.P(iq2))
+            d2 = torch.from_numpy(iq2).cuda()
+            bank.reset()
+            tail = pkg.DvbsTailBank(eng, S, max_bits=2 * nsym + 4 * 8192)
+            tts = [torch.zeros(188 * 8 * 16, dtype=torch.uint8, device='cuda') for _ in range(S)]
+            def step(k):
+                part = d2[2 * nsym * k:2 * nsym * (k + 1)]
+                nb = bank.process_batch([part] * S, tout)
+                return tail.process_batch([tout[i][:nb[i]] for i in range(S)], tts)
+            step(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tot = 0
+            for k in range(1, ncall):
+                nby = step(k)
+                tot += nby[S - 1]
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t0) / (ncall - 1)
+            sent = {bytes(t) for t in ts}
+            last = tts[S - 1][:nby[S - 1]].cpu().numpy().reshape(-1, 188)
+            print('   with the tail (IQ -> TS packets, continuous outer-coded stream): %.2f ms per call = %.2f Msym/s total, %d TS packets per stream in %d calls, last call: %d of %d are transmitted ones'
+                  % (dt2 * 1e3, S * nsym / dt2 / 1e6, tot // 188, ncall - 1, sum(bytes(x) in sent for x in last), len(last)))
+            tail.close()
         bank.close()
 
 
