@@ -131,3 +131,32 @@ def test_ldpc_batch_larger_than_grid_and_empty(engine):
     e = torch.empty((0, p['N']), dtype=torch.int8, device='cuda')
     h, t, _ = engine.ldpc_decode(e, rate, True)
     assert h.shape[0] == 0
+
+
+def test_fec_round_trip_at_the_headline_batch_size(engine):
+    """BASELINE's headline shape -- 4096 normal frames of rate 3/4, 50 forced iterations, one launch -- through size-independent properties:
+    encode -> independent noise per frame -> decode returns every transmitted BBFRAME; frames with identical input (the noise repeats every
+    1024 frames) come out identical wherever they sit in the batch; the first frames equal the oracle's output bit for bit"""
+    import torch
+    rate, short, nf, ndistinct = 6, 0, 4096, 16
+    p = orc.fec_params(rate, short)
+    enc = [orc.encode_frame(rate, short, 500 + k) for k in range(ndistinct)]
+    bbs = np.stack([e[0] for e in enc])
+    bits = torch.from_numpy(np.stack([e[1] for e in enc])).cuda()
+    g = torch.Generator(device='cuda'); g.manual_seed(11)
+    sigma = 10 ** (-(MARGINAL_SNR[rate] + 1.0) / 20.0)
+    noise = torch.randn((1024, p['N']), generator=g, device='cuda').repeat(4, 1)
+    x = (1.0 - 2.0 * bits.float()).repeat(nf // ndistinct, 1)
+    llr = torch.clamp(torch.round((x + sigma * noise) * (2.0 / (sigma * sigma))), -127, 127).to(torch.int8)
+    out, trials, corr = engine.fec_decode(llr, rate, False, max_trials=50, force=True)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    want = np.tile(bbs, (nf // ndistinct, 1))
+    assert np.array_equal(out, want), int((out != want).any(axis=1).sum())
+    assert int((trials != 50).sum()) == 0 and int((corr < 0).sum()) == 0
+    hard, _, post = engine.ldpc_decode(llr, rate, False, max_trials=50, force=True, want_post=True)
+    post = post.cpu().numpy()
+    for k in range(1, 4):
+        assert np.array_equal(post[:1024], post[1024 * k:1024 * (k + 1)]), k
+    want_post, _ = oracle_ldpc(rate, short, llr[:3].cpu().numpy(), 50, force=1)
+    assert np.array_equal(post[:3], want_post)
