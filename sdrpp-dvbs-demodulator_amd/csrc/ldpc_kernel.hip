@@ -476,34 +476,43 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
     PROF_ADD(CONF ? 6 : 2, t_c, t_d);
 }
 
-// LDPCDecoder::bad (layered_decoder.hh:28-45) for the rows owned by lane j; true if any is unsatisfied.
+// LDPCDecoder::bad (layered_decoder.hh:28-45): true if any row is unsatisfied.  A row is bad when the sign product of its links'
+// posteriors is negative or when one of them is 0.  Every posterior belongs to at least one row (each parity bit to its own row), so the
+// second condition over all rows is "some posterior of the frame is 0": a dword scan shared by the slot's 384 threads instead of a compare
+// per link.  The sign products use the packed pair addresses of the sweep (two table links per address computation, ldpc_plan.h).
 template <int MAXDEG, bool IRREG>
 __device__ __forceinline__ bool rows_bad(const int8_t* __restrict__ post, const LdpcKernelArgs& A, const LdpcLayerDesc* __restrict__ layers,
-                                         const uint32_t* __restrict__ ents_all, int j) {
-    int badacc = 0;
-    for (int layer = 0; layer < A.q; ++layer) {
-        const LdpcLayerDesc L = layers[layer];
-        const uint32_t* __restrict__ ents = ents_all + L.ent_off;
-        const int deg = IRREG ? (int)(L.deg & 0xffffu) : MAXDEG;
-        const int own = A.K + 360 * layer + j;
-        int x = post[own];
-        int sx = x;
-        int zero = (x == 0);
-        if (layer | j) {
-            const int prev = layer ? own - 360 : A.K + 360 * (A.q - 1) + j - 1;
-            x = post[prev];
-            sx ^= x; zero |= (x == 0);
-        }
-#pragma unroll
-        for (int k = 0; k < MAXDEG; ++k) {
-            if (!IRREG || k < deg) {
-                x = post[link_addr(ents[k], j)];
-                sx ^= x; zero |= (x == 0);
-            }
-        }
-        badacc |= zero | ((sx >> 7) & 1);
+                                         const uint32_t* __restrict__ ents_all, int j, bool lane_ok, int tps) {
+    const uint8_t* __restrict__ pu = reinterpret_cast<const uint8_t*>(post);
+    uint32_t z = 0;
+    const uint32_t* __restrict__ pw4 = reinterpret_cast<const uint32_t*>(post);
+    for (int i = j; i < A.N / 4; i += tps) {
+        const uint32_t v = pw4[i];
+        z |= (v - 0x01010101u) & ~v;          // bit 7 of a byte set <=> that byte is 0 (or a borrow reached it from a zero byte below: still "a zero")
     }
-    return badacc != 0;
+    uint32_t sxacc = 0;
+    if (lane_ok) {
+        constexpr int NPW = 2 * ((MAXDEG + 1) / 2);
+        const uint32_t JJ = (uint32_t)j * 0x10001u;
+        for (int layer = 0; layer < A.q; ++layer) {
+            const uint32_t* __restrict__ pe = ents_all + A.pent_base + layer * NPW;
+            const int deg = IRREG ? (int)(layers[layer].deg & 0xffffu) : MAXDEG;
+            const int own = A.K + 360 * layer + j;
+            uint32_t sx = pu[own];
+            if (layer | j) sx ^= pu[layer ? own - 360 : A.K + 360 * (A.q - 1) + j - 1];
+#pragma unroll 2
+            for (int p = 0; p < (MAXDEG + 1) / 2; ++p) {
+                u16x2 T = __builtin_bit_cast(u16x2, JJ) + __builtin_bit_cast(u16x2, pe[2 * p]);
+                T = __builtin_elementwise_min(T, (u16x2)(T - (u16x2){360, 360}));
+                const uint32_t AD = __builtin_bit_cast(uint32_t, (u16x2)(T + __builtin_bit_cast(u16x2, pe[2 * p + 1])));
+                const uint32_t x0 = pu[AD & 0xffffu], x1 = pu[AD >> 16];
+                if (!IRREG || 2 * p < deg) sx ^= x0;
+                if (2 * p + 1 < MAXDEG && (!IRREG || 2 * p + 1 < deg)) sx ^= x1;
+            }
+            sxacc |= sx;
+        }
+    }
+    return ((z & 0x80808080u) | (sxacc & 0x80u)) != 0;
 }
 
 // TWO FRAMES PER WORKGROUP, in lockstep: 768 threads = 12 waves; threads [0,384) decode frame slot 0, [384,768)
@@ -557,7 +566,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
         while (true) {
             const bool check = !done && (!A.force || it == A.max_trials);
             if (check) {
-                bool bad = lane_ok ? rows_bad<MAXDEG, IRREG>(post, A, layers, ents, j) : false;
+                bool bad = valid ? rows_bad<MAXDEG, IRREG>(post, A, layers, ents, j, lane_ok, LDPC_TPS) : false;
                 unsigned long long b = __ballot(bad);
                 if ((j & 63) == 0) s_flag[fs][j >> 6] = (b != 0);
             }
