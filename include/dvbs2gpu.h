@@ -112,6 +112,21 @@ int dvbs2gpu_fec_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, cons
 int dvbs2gpu_demap_batch(dvbs2gpu_ctx* ctx, int modcod, int shortframes, int pilots, const float* d_frames, int nframes,
                          int8_t* d_llr, void* stream);
 
+/* S2Deinterleaver::deinterleave alone (s2_deinterleaver.cpp:72-136) on caller-supplied LLR frames, d_in / d_out [nframes][N]
+ * int8, out of place: the index function of the fused demapper above as a stage of its own (the parity tests push the
+ * reference's golden index ramps through it). */
+int dvbs2gpu_deinterleave_batch(dvbs2gpu_ctx* ctx, int modcod, int shortframes, const int8_t* d_in, int nframes, int8_t* d_out,
+                                void* stream);
+
+/* ------------------------------------------------------------------ shared math definitions, evaluated on the device
+ * The engine's float stages take sin/cos/atan2/exp/log from include/dvbs2gpu_math.h (where the reference calls libm:
+ * freq_shift.cpp:6, dvbs2_pll.cpp:39,50-75, dvbs2_plhdr_demod.cpp:35, fll.cpp:137, constellation.cpp:226,250,259).  This
+ * entry point evaluates those definitions element-wise on the GPU so that a test can compare them bit for bit with the
+ * host evaluation of the same header.  func: 0 sincos(a) -> out0 = sin, out1 = cos; 1 atan2(a, b) -> out0; 2 exp(a);
+ * 3 log(a); 4 the LLR clamp of constellation.cpp:263-270 (as float).  Device pointers, n elements. */
+int dvbs2gpu_math_eval(dvbs2gpu_ctx* ctx, int func, int n, const float* d_a, const float* d_b, float* d_out0, float* d_out1,
+                       void* stream);
+
 /* ------------------------------------------------------------------ full DVB-S2 demodulator (one stream)
  *
  * Mirror of dsp::dvbs2::DVBS2Demod (module_dvbs2_demod.h:51-160).  A handle is one transponder stream:
@@ -326,6 +341,26 @@ int dvbs2gpu_dvbs_tail_process_batch(dvbs2gpu_dvbs_tail* t, const uint8_t* const
                                      int* out_bytes, void* stream);
 /* h_out11 = {frames of the last call, errors_nor, errors_inv, RS error counts of the last frame's 8 packets} */
 int dvbs2gpu_dvbs_tail_get_stats(dvbs2gpu_dvbs_tail* t, int stream, int32_t* h_out11);
+/* Stage taps of the last call for one stream (host copies; returns the byte count, h_dst may be NULL to query it):
+ *   0  frames found by the deframer, 1632 bytes each (DVBS_TS_Deframer::work output, dvbs_ts_deframer.cpp:37-92)
+ *   1  the same frames after the Forney de-interleaver and the in-place RS correction, 8 x 204 bytes each
+ *   2  per packet: 1 = libcorrect produced a message, 0 = it gave up (decode.c:299-380)
+ *   3  per packet (int32): message bytes changed, the value DVBSReedSolomon::decode returns (dvbs_reedsolomon.h:26-47) */
+int dvbs2gpu_dvbs_tail_get_tap(dvbs2gpu_dvbs_tail* t, int stream, int which, void* h_dst, int cap);
+/* Stage entry (parity tests): RS(204,188) + the wrapper's stale-output rule + energy dispersal removal on `npackets` (a multiple of
+ * 8) 204-byte packets supplied by the caller as stream 0's de-interleaved frames -- DVBSReedSolomon::decode and
+ * DVBSScrambling::descramble without the deframer and the de-interleaver in front.  skip_rs != 0: the packets are taken as decoded
+ * (descrambler alone).  HOST pointers; returns the TS bytes written to h_ts (188 per packet); taps 1-3 above then hold the
+ * corrected packets, the decoder status and the error counts.  Advances stream 0's dispersal / last-message state. */
+int dvbs2gpu_dvbs_tail_rs_stage(dvbs2gpu_dvbs_tail* t, const uint8_t* h_packets, int npackets, int skip_rs, uint8_t* h_ts, int cap);
+/* Stage entry (parity tests): the de-puncturers and the soft rotation that run inside the Viterbi kernel, on HOST buffers.
+ *   mode 0  Depunc23 / Depunc56 ::depunc_static (depunc.h:16-38,108-137), period 3 / 6, h_state4[1] = shift
+ *   mode 1  ::depunc_cont (:46-80,139-185) with h_state4 = {is_first, changing_shift, got_extra, buf} carried across calls
+ *           (set_shift(s): {s > period - 1, s, 0, 128})
+ *   mode 2  rotate_soft (common/codings/rotation.cpp:4-63) for h_state4[0] = 0 / 1 (PHASE_0 / PHASE_90), signed bytes in and out
+ * h_out (out_cap >= 2*size + 2 bytes) keeps the caller's fill where the stage does not write.  Returns the output count. */
+int dvbs2gpu_dvbs_depuncture(dvbs2gpu_ctx* ctx, int period, int mode, const uint8_t* h_in, int size, uint8_t* h_out, int out_cap,
+                             int32_t* h_state4);
 /* int DVBSDemod::process(int count, const complex_t* in, uint8_t* out) as a whole (module_dvbs_demod.cpp:78-99), host buffers, for a
  * one-stream receiver bank `d` and a one-stream tail `t` (created with max_bits >= the bank's bit capacity: max_samples is enough):
  * count complex samples in, the TS packets completed by this call out (188 bytes each); the decoded bits stay in HBM between the

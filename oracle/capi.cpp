@@ -179,6 +179,18 @@ void orc_constellation_soft_calc(int constel, float g1, float g2, int n, const f
     Constellation C(constel, g1, g2);
     for (int i = 0; i < n; ++i) C.soft_calc(cf{samples[2 * i], samples[2 * i + 1]}, bits_out + (size_t)i * C.bits, err_out + i);
 }
+// host evaluation of include/dvbs2gpu_math.h (same func codes as dvbs2gpu_math_eval)
+void orc_math_eval(int func, int n, const float* a, const float* b, float* o0, float* o1) {
+    for (int i = 0; i < n; ++i) {
+        switch (func) {
+            case 0: dvbs2m::sincosf_det(a[i], &o0[i], &o1[i]); break;
+            case 1: o0[i] = dvbs2m::atan2f_det(a[i], b[i]); break;
+            case 2: o0[i] = dvbs2m::expf_det(a[i]); break;
+            case 3: o0[i] = dvbs2m::logf_det(a[i]); break;
+            default: o0[i] = (float)dvbs2m::llr_clamp_det(a[i]); break;
+        }
+    }
+}
 void orc_constellation_points(int constel, float g1, float g2, float* pts_out) {
     Constellation C(constel, g1, g2);
     for (int i = 0; i < C.states; ++i) { cf p = C.mod(i); pts_out[2 * i] = p.re; pts_out[2 * i + 1] = p.im; }

@@ -39,8 +39,7 @@ PlTables::PlTables() {
     for (int s = 0; s < 26; ++s) {
         int bit = (VALUE >> (25 - s)) & 1;
         int angle = bit * 2 + (s & 1);
-        sof[s].re = cosf(M_PI / 4 + 2 * M_PI * angle / 4);
-        sof[s].im = sinf(M_PI / 4 + 2 * M_PI * angle / 4);
+        sof[s] = phasor((float)(M_PI / 4 + 2 * M_PI * angle / 4));
     }
     const uint32_t G[6] = {0x55555555, 0x33333333, 0x0f0f0f0f, 0x00ff00ff, 0x0000ffff, 0xffffffff};
     const uint64_t SCR = 0x719d83c953422dfaull;
@@ -92,7 +91,8 @@ static inline cf pl_scramble(cf p, int r) {     // s2_scrambling.cpp:60-81
 // ------------------------------------------------------------------------------------------ constellation
 static cf polar(float r, int n, float i) {
     float a = i * 2 * M_PI / n;
-    return cf{r * cosf(a), r * sinf(a)};
+    cf u = phasor(a);
+    return cf{r * u.re, r * u.im};
 }
 
 Constellation::Constellation(int type_, float g1, float g2) : type(type_) {
@@ -151,13 +151,7 @@ Constellation::Constellation(int type_, float g1, float g2) : type(type_) {
 
 cf Constellation::mod(int sym) const { return cscale(cscale(pts[sym], 1.0f / amp), 1.0f / prescale); }
 
-static int8_t lut_clamp(float x) {   // constellation.cpp:263-270
-    while (x < -127 || x > 127) {
-        x *= 0.5;
-        if (!std::isfinite(x)) return (int8_t)x;
-    }
-    return (int8_t)x;
-}
+static int8_t lut_clamp(float x) { return dvbs2m::llr_clamp_det(x); }   // constellation.cpp:263-270 (non-finite -> 0, see the header)
 
 void Constellation::soft_calc(cf sample, int8_t* bits_out, float* phase_err) const {
     float tmp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -168,14 +162,14 @@ void Constellation::soft_calc(cf sample, int8_t* bits_out, float* phase_err) con
     for (int i = 0; i < states; i++) {
         float dist = camp(csub(sample, pts[i]));
         if (dist < min_dist) { min_dist = dist; closest = pts[i]; }
-        float d = expf(-dist / 1.0f);
+        float d = dvbs2m::expf_det(-dist / 1.0f);
         for (int j = 0; j < bits; j++) {
             if (((i >> j) & 1) == 0) tmp[2 * j + 0] += d;
             else tmp[2 * j + 1] += d;
         }
     }
     if (bits_out)
-        for (int i = 0; i < bits; i++) bits_out[bits - 1 - i] = lut_clamp((logf(tmp[2 * i + 1]) - logf(tmp[2 * i + 0])) * sca);
+        for (int i = 0; i < bits; i++) bits_out[bits - 1 - i] = lut_clamp((dvbs2m::logf_det(tmp[2 * i + 1]) - dvbs2m::logf_det(tmp[2 * i + 0])) * sca);
     if (phase_err) *phase_err = cphase(cmul(sample, cconj(closest)));
 }
 
@@ -519,7 +513,7 @@ void S2Rx::plhdr(const cf* in, cf* out, int* modcod, int* sh, int* pil) {   // d
     hdr_pcl.phase += hdr_pcl.freq * (mp.plframe - 91);
     hdr_pcl.advance(0);
     uint64_t plheader = 0;
-    const cf rot{(float)cos(-M_PI / 4), (float)sin(-M_PI / 4)};
+    const cf rot{(float)0.70710678118654757, (float)-0.70710678118654746};   // (cos, sin)(-pi/4) in double, cast (dvbs2_plhdr_demod.cpp:48)
     for (int y = 0; y < 64; y++) {
         bool value = cmul(out[26 + y], rot).re > 0;
         plheader = plheader << 1 | (uint64_t)(!value);

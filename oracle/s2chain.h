@@ -4,13 +4,16 @@
 // PARITY UNPINNED for every float stage that rests on SDR++ core / VOLK (FastAGC, FIR, tap generators,
 // PhaseControlLoop, phasor, the VOLK dot products): those libraries are not in /root/reference and the
 // reference has no tests, so these restate the call-site semantics of the plugin plus the textbook
-// definitions listed in SURVEY.md Appendix C.  What IS pinned here against the reference's own code:
+// definitions listed in SURVEY.md Appendix C.  sin/cos/atan2/exp/log are NOT the host libm's: they are the
+// engine's own straight-line IEEE definitions (include/dvbs2gpu_math.h), evaluated identically by x86 and
+// gfx950, so that the GPU path can be compared with this restatement bit for bit.  What IS pinned here against the reference's own code:
 // the S2 deinterleaver (compiled reference, oracle/_ref) and everything integer downstream (LDPC/BCH/BB).
 #pragma once
 #include <cstdint>
 #include <vector>
 #include <cmath>
 #include "oracle.h"
+#include "../include/dvbs2gpu_math.h"   // the engine's definition of sin/cos/atan2/exp/log (shared with the device code on purpose)
 
 namespace orc {
 
@@ -21,8 +24,8 @@ static inline cf cadd(cf a, cf b) { return cf{a.re + b.re, a.im + b.im}; }
 static inline cf csub(cf a, cf b) { return cf{a.re - b.re, a.im - b.im}; }
 static inline cf cscale(cf a, float s) { return cf{a.re * s, a.im * s}; }
 static inline float camp(cf a) { return sqrtf(a.re * a.re + a.im * a.im); }
-static inline float cphase(cf a) { return atan2f(a.im, a.re); }
-static inline cf phasor(float x) { return cf{cosf(x), sinf(x)}; }
+static inline float cphase(cf a) { return dvbs2m::atan2f_det(a.im, a.re); }
+static inline cf phasor(float x) { cf r; dvbs2m::sincosf_det(x, &r.im, &r.re); return r; }
 
 // SDR++ loop::PhaseControlLoop<float, CLAMP_PHASE> as used by the plugin
 struct Pcl {

@@ -63,6 +63,8 @@ PROTOTYPES = {
     'dvbs2gpu_bb_descramble_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
     'dvbs2gpu_fec_decode_batch': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'dvbs2gpu_demap_batch': (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
+    'dvbs2gpu_deinterleave_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
+    'dvbs2gpu_math_eval': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'dvbs2gpu_demod_default_cfg': (None, [_i, _i, _i, C.POINTER(DemodCfg)]),
     'dvbs2gpu_demod_create': (_i, [_vp, C.POINTER(DemodCfg), _i, C.POINTER(_vp)]),
     'dvbs2gpu_demod_destroy': (None, [_vp]),
@@ -100,6 +102,9 @@ PROTOTYPES = {
     'dvbs2gpu_dvbs_tail_destroy': (None, [_vp]),
     'dvbs2gpu_dvbs_tail_process_batch': (_i, [_vp, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), _i, C.POINTER(_i), _vp]),
     'dvbs2gpu_dvbs_tail_get_stats': (_i, [_vp, _i, C.POINTER(C.c_int32)]),
+    'dvbs2gpu_dvbs_tail_get_tap': (_i, [_vp, _i, _i, _vp, _i]),
+    'dvbs2gpu_dvbs_tail_rs_stage': (_i, [_vp, _vp, _i, _i, _vp, _i]),
+    'dvbs2gpu_dvbs_depuncture': (_i, [_vp, _i, _i, _vp, _i, _vp, _i, C.POINTER(C.c_int32)]),
     'dvbs2gpu_demod_get_frame_positions': (_i, [_vp, C.POINTER(C.c_int64), _i]),
     'dvbs2gpu_segrx_create': (_i, [_vp, C.POINTER(DemodCfg), _i, _i, _i, C.POINTER(_vp)]),
     'dvbs2gpu_segrx_reset': (_i, [_vp]),
@@ -259,6 +264,34 @@ class Engine:
         self._check(self.lib.dvbs2gpu_demap_batch(self.h, int(modcod), int(bool(shortframes)), int(bool(pilots)), _ptr(frames),
                                                   frames.shape[0], _ptr(llr), self._stream()))
         return llr
+
+    def deinterleave(self, llr, modcod, shortframes=False):
+        """S2Deinterleaver::deinterleave on int8 [F, N] frames (the demapper's index function as its own stage)"""
+        t = self.torch
+        assert llr.dtype == t.int8 and llr.is_cuda and llr.is_contiguous() and llr.dim() == 2
+        out = t.empty_like(llr)
+        self._check(self.lib.dvbs2gpu_deinterleave_batch(self.h, int(modcod), int(bool(shortframes)), _ptr(llr), llr.shape[0], _ptr(out), self._stream()))
+        return out
+
+    def dvbs_depuncture(self, period, mode, data, state4, fill=0):
+        """stage entry: the Viterbi kernel's de-puncturers / soft rotation on host bytes -> (output bytes incl. one byte beyond the
+        returned count, count, new state4)"""
+        import numpy as np
+        data = np.ascontiguousarray(data).view(np.uint8)
+        out = np.full(2 * data.size + 64, fill, np.uint8)
+        st = (C.c_int32 * 4)(*[int(x) for x in state4])
+        n = self._check(self.lib.dvbs2gpu_dvbs_depuncture(self.h, int(period), int(mode), C.c_void_p(data.ctypes.data), data.size,
+                                                          C.c_void_p(out.ctypes.data), out.size, st))
+        return out, n, list(st)
+
+    def math_eval(self, func, a, b=None):
+        """include/dvbs2gpu_math.h evaluated on the device (0 sincos, 1 atan2(a, b), 2 exp, 3 log, 4 LLR clamp) -> (out0, out1)"""
+        t = self.torch
+        assert a.dtype == t.float32 and a.is_cuda and a.is_contiguous()
+        o0, o1 = t.empty_like(a), t.empty_like(a)
+        self._check(self.lib.dvbs2gpu_math_eval(self.h, int(func), a.numel(), _ptr(a), _ptr(b) if b is not None else None, _ptr(o0),
+                                                _ptr(o1), self._stream()))
+        return o0, o1
 
     def set_pipelined(self, on):
         """FEC of call k overlaps the front end of call k+1; BBFRAMEs are delivered one process_batch call later"""
@@ -534,6 +567,24 @@ class DvbsTailBank(_Handle):
         a = (C.c_int32 * 11)()
         self.eng._check(self.lib.dvbs2gpu_dvbs_tail_get_stats(self.h, stream, a))
         return {'frames': a[0], 'errors_nor': a[1], 'errors_inv': a[2], 'rs_errors': list(a[3:11])}
+
+    def tap(self, which, stream=0):
+        """stage taps of the last call: 0 deframed frames, 1 packets after Forney + RS, 2 RS status, 3 RS error counts (int32)"""
+        import numpy as np
+        n = self.eng._check(self.lib.dvbs2gpu_dvbs_tail_get_tap(self.h, stream, which, None, 0))
+        a = np.zeros(n, np.uint8)
+        if n:
+            self.eng._check(self.lib.dvbs2gpu_dvbs_tail_get_tap(self.h, stream, which, C.c_void_p(a.ctypes.data), n))
+        return a.view(np.int32) if which == 3 else a
+
+    def rs_stage(self, packets, skip_rs=False):
+        """packets: numpy uint8 [n, 204] (n a multiple of 8) -> TS bytes uint8 [n, 188] (stage entry, stream 0)"""
+        import numpy as np
+        packets = np.ascontiguousarray(packets, np.uint8)
+        out = np.zeros(packets.shape[0] * 188, np.uint8)
+        n = self.eng._check(self.lib.dvbs2gpu_dvbs_tail_rs_stage(self.h, C.c_void_p(packets.ctypes.data), packets.shape[0], int(bool(skip_rs)),
+                                                                 C.c_void_p(out.ctypes.data), out.size))
+        return out[:n].reshape(-1, 188)
 
 
 class BbTsParserBank(_Handle):

@@ -18,6 +18,29 @@ int fail_hip(hipError_t e, const char* what) {
 
 // ---------------------------------------------------------------------------------------------------
 namespace s2 {
+int ws_acquire(dvbs2gpu_ctx* ctx, hipStream_t st) {
+    if (ctx->ws_used && ctx->ws_stream != st) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_ws, 0));
+    return 0;
+}
+int ws_release(dvbs2gpu_ctx* ctx, hipStream_t st) {
+    HIP_TRY(hipEventRecord(ctx->ev_ws, st));
+    ctx->ws_stream = st; ctx->ws_used = true;
+    return 0;
+}
+int ws_quiesce(dvbs2gpu_ctx* ctx) {
+    if (ctx->ws_used) HIP_TRY(hipEventSynchronize(ctx->ev_ws));
+    return 0;
+}
+bool fec_jobs_pending(dvbs2gpu_ctx* ctx) {
+    for (void* p : ctx->pending_fec) if (p) return true;
+    return false;
+}
+// the stage entry points share the context-wide FEC workspaces with the pipelined jobs on the FEC stream: refused while any is in flight
+static int stage_enter(dvbs2gpu_ctx* ctx, hipStream_t st) {
+    if (fec_jobs_pending(ctx)) { last_error() = "stage call while pipelined FEC jobs are in flight (collect them or leave the pipelined mode first)"; return DVBS2GPU_ERR_ARG; }
+    return ws_acquire(ctx, st);
+}
+
 int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
     std::lock_guard<std::mutex> l(ctx->mtx);
     auto it = ctx->ldpc.find(code_index);
@@ -193,6 +216,8 @@ int dvbs2gpu_create(int device, dvbs2gpu_ctx** out) {
     dvbs2gpu_ctx* c = new dvbs2gpu_ctx();
     c->device = device;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t ee = hipEventCreateWithFlags(&c->ev_ws, hipEventDisableTiming);
+    if (ee != hipSuccess) { delete c; return fail_hip(ee, "hipEventCreate"); }
     *out = c;
     return DVBS2GPU_OK;
 }
@@ -208,6 +233,21 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
         (void)hipFree(kv.second.d_log); (void)hipFree(kv.second.d_exp); (void)hipFree(kv.second.d_imap); (void)hipFree(kv.second.d_syn_tab);
     }
     if (ctx->d_prbs) (void)hipFree(ctx->d_prbs);
+    // receive-chain tables
+    if (ctx->d_gardner_bank) (void)hipFree(ctx->d_gardner_bank);
+    if (ctx->pl.sof) (void)hipFree((void*)ctx->pl.sof);
+    if (ctx->pl.plsc) (void)hipFree((void*)ctx->pl.plsc);
+    if (ctx->pl.plsc_code) (void)hipFree((void*)ctx->pl.plsc_code);
+    if (ctx->pl.rn) (void)hipFree((void*)ctx->pl.rn);
+    for (auto& kv : ctx->constel) {
+        if (kv.second.d_bits) (void)hipFree(kv.second.d_bits);
+        if (kv.second.d_err) (void)hipFree(kv.second.d_err);
+        if (kv.second.d_pts) (void)hipFree(kv.second.d_pts);
+    }
+    for (auto& kv : ctx->rrc) if (kv.second) (void)hipFree(kv.second);
+    if (ctx->d_fd_bank) (void)hipFree(ctx->d_fd_bank);
+    for (auto& kv : ctx->bandedge) if (kv.second) (void)hipFree(kv.second);
+    if (ctx->ev_ws) (void)hipEventDestroy(ctx->ev_ws);
     ctx->ws_msg.release(); ctx->ws_hard.release(); ctx->ws_syn.release(); ctx->ws_misc.release();
     if (ctx->fe_stream) (void)hipStreamDestroy(ctx->fe_stream);
     if (ctx->fec_stream) (void)hipStreamDestroy(ctx->fec_stream);
@@ -286,8 +326,13 @@ int dvbs2gpu_ldpc_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, con
     if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
     if (nframes == 0) return 0;
     if (!d_llr) return DVBS2GPU_ERR_ARG;
+    CallGuard guard(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
-    return ldpc_run(ctx, f, d_llr, nframes, max_trials, force, d_hard, f.K / 8, d_post, d_trials, (hipStream_t)stream);
+    int rc = stage_enter(ctx, (hipStream_t)stream);
+    if (rc) return rc;
+    rc = ldpc_run(ctx, f, d_llr, nframes, max_trials, force, d_hard, f.K / 8, d_post, d_trials, (hipStream_t)stream);
+    int rc2 = ws_release(ctx, (hipStream_t)stream);
+    return rc ? rc : rc2;
 }
 
 
@@ -298,8 +343,13 @@ int dvbs2gpu_bch_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, uint
     if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
     if (nframes == 0) return 0;
     if (!d_frames) return DVBS2GPU_ERR_ARG;
+    CallGuard guard(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
-    return bch_run(ctx, f, d_frames, nframes, d_corrections, (hipStream_t)stream);
+    int rc = stage_enter(ctx, (hipStream_t)stream);
+    if (rc) return rc;
+    rc = bch_run(ctx, f, d_frames, nframes, d_corrections, (hipStream_t)stream);
+    int rc2 = ws_release(ctx, (hipStream_t)stream);
+    return rc ? rc : rc2;
 }
 
 int dvbs2gpu_bb_descramble_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, const uint8_t* d_frames, int nframes, uint8_t* d_out,
@@ -323,8 +373,13 @@ int dvbs2gpu_fec_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, cons
     if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
     if (nframes == 0) return 0;
     if (!d_llr || !d_bbframes) return DVBS2GPU_ERR_ARG;
+    CallGuard guard(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
-    return fec_run(ctx, f, d_llr, nframes, max_trials, force, d_bbframes, d_trials, d_corrections, (hipStream_t)stream);
+    int rc = stage_enter(ctx, (hipStream_t)stream);
+    if (rc) return rc;
+    rc = fec_run(ctx, f, d_llr, nframes, max_trials, force, d_bbframes, d_trials, d_corrections, (hipStream_t)stream);
+    int rc2 = ws_release(ctx, (hipStream_t)stream);
+    return rc ? rc : rc2;
 }
 
 }  // extern "C"

@@ -61,7 +61,16 @@ struct ConstelTables {          // device tables of one constellation (type, gam
 struct dvbs2gpu_ctx {
     int device = 0;
     int num_cus = 256;
-    std::mutex mtx;
+    std::mutex mtx;                           // table caches (creation of LDPC / BCH / constellation / tap tables)
+    // One context may serve several handles and host threads (include/dvbs2gpu_host.hpp shares one per device between all blocks of
+    // the process), and every entry point below works in the context-wide workspaces (ws_*): whole calls are serialised by
+    // call_mtx (recursive: the segment receivers call process_batch from inside their own entry point).  The asynchronous stage
+    // entry points only ENQUEUE under the lock; ev_ws, recorded behind the last enqueued user of the shared FEC workspaces, makes a
+    // later user on a different stream wait for the earlier one (the message records and the LDPC work counter live there).
+    std::recursive_mutex call_mtx;
+    hipEvent_t ev_ws = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_used = false;
     std::map<int, s2::LdpcDeviceCode> ldpc;   // by code_index
     std::map<int, s2::BchDeviceCode> bch;     // by m*100 + t
     uint8_t* d_prbs = nullptr;                // BB scrambler sequence, 8100 bytes
@@ -96,6 +105,15 @@ struct dvbs2gpu_ctx {
 };
 
 namespace s2 {
+// serialises an entry point on its context; stage_* additionally order the shared FEC workspaces across streams
+struct CallGuard {
+    std::unique_lock<std::recursive_mutex> l;
+    explicit CallGuard(dvbs2gpu_ctx* ctx) : l(ctx->call_mtx) {}
+};
+int ws_acquire(dvbs2gpu_ctx* ctx, hipStream_t st);   // before enqueuing work that uses ws_msg / ws_hard / ws_syn / ws_misc on `st`
+int ws_release(dvbs2gpu_ctx* ctx, hipStream_t st);   // after it
+int ws_quiesce(dvbs2gpu_ctx* ctx);                   // host-side wait for the last asynchronous user (synchronous entry points)
+bool fec_jobs_pending(dvbs2gpu_ctx* ctx);
 int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out);
 int get_bch(dvbs2gpu_ctx* ctx, int m, int t, BchDeviceCode** out);
 int get_prbs(dvbs2gpu_ctx* ctx);

@@ -267,4 +267,69 @@ int dvbs2gpu_dvbs_tail_get_stats(dvbs2gpu_dvbs_tail* t, int stream, int32_t* h_o
     return 0;
 }
 
+/* taps of the last process_batch / rs_stage call of one stream (see include/dvbs2gpu.h) */
+int dvbs2gpu_dvbs_tail_get_tap(dvbs2gpu_dvbs_tail* t, int stream, int which, void* h_dst, int cap) {
+    if (!t || stream < 0 || stream >= t->nstreams || which < 0 || which > 3 || cap < 0) return DVBS2GPU_ERR_ARG;
+    HIP_TRY(hipSetDevice(t->ctx->device));
+    int nf = 0;
+    HIP_TRY(hipMemcpy(&nf, t->d_nframes + stream, sizeof(int), hipMemcpyDeviceToHost));
+    const void* src;
+    size_t bytes;
+    switch (which) {
+        case 0: src = t->d_frames + (size_t)stream * t->frames_stride; bytes = (size_t)nf * 1632; break;
+        case 1: src = t->d_deint + (size_t)stream * t->frames_stride; bytes = (size_t)nf * 1632; break;
+        case 2: src = t->d_status + (size_t)stream * t->max_frames * 8; bytes = (size_t)nf * 8; break;
+        default: src = t->d_rs_err + (size_t)stream * t->max_frames * 8; bytes = (size_t)nf * 8 * sizeof(int); break;
+    }
+    if (h_dst && bytes) HIP_TRY(hipMemcpy(h_dst, src, std::min(bytes, (size_t)cap), hipMemcpyDeviceToHost));
+    return (int)bytes;
+}
+int dvbs2gpu_dvbs_tail_rs_stage(dvbs2gpu_dvbs_tail* t, const uint8_t* h_packets, int npackets, int skip_rs, uint8_t* h_ts, int cap) {
+    if (!t || !h_packets || npackets <= 0 || npackets % 8 || npackets > t->max_frames * 8 || !h_ts || cap < 0) return DVBS2GPU_ERR_ARG;
+    HIP_TRY(hipSetDevice(t->ctx->device));
+    const int n = t->nstreams, nf = npackets / 8;
+    std::vector<int> nfr(n, 0);
+    nfr[0] = nf;
+    HIP_TRY(hipMemcpy(t->d_nframes, nfr.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t->d_deint, h_packets, (size_t)npackets * 204, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(t->d_status, 1, (size_t)n * t->max_frames * 8));
+    HIP_TRY(hipMemset(t->d_rs_err, 0, (size_t)n * t->max_frames * 8 * sizeof(int)));
+    uint8_t* d_ts = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_ts, (size_t)std::max(cap, 1) * n));
+    char* a = (char*)t->d_args;
+    uint8_t** d_out = (uint8_t**)(a + sizeof(void*) * n);
+    int* d_ob = (int*)(a + 2 * sizeof(void*) * n) + n;
+    std::vector<uint8_t*> outs(n);
+    for (int i = 0; i < n; ++i) outs[i] = d_ts + (size_t)i * std::max(cap, 1);
+    hipError_t e = hipMemcpy(d_out, outs.data(), sizeof(void*) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = dvbs_tail_rs_finish_launch(n, t->max_frames, t->d_nframes, t->d_deint, t->frames_stride, t->d_status, t->d_gf, t->d_prbs, t->d_state,
+                                                        d_out, cap, d_ob, t->d_rs_err, skip_rs, 0);
+    int nb = 0;
+    if (e == hipSuccess) e = hipMemcpy(&nb, d_ob, sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && nb > 0) e = hipMemcpy(h_ts, d_ts, (size_t)nb, hipMemcpyDeviceToHost);
+    (void)hipFree(d_ts);
+    if (e != hipSuccess) return fail_hip(e, "dvbs tail rs stage");
+    return nb;
+}
+int dvbs2gpu_dvbs_depuncture(dvbs2gpu_ctx* ctx, int period, int mode, const uint8_t* h_in, int size, uint8_t* h_out, int out_cap, int32_t* h_state4) {
+    if (!ctx || !h_in || !h_out || !h_state4 || size <= 0 || mode < 0 || mode > 2 || (mode != 2 && period != 3 && period != 6)) return DVBS2GPU_ERR_ARG;
+    if (out_cap < 2 * size + 2) return DVBS2GPU_ERR_CAPACITY;
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint8_t* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, (size_t)size + out_cap + 64));
+    uint8_t* d_in = d, *d_out = d + size;
+    int* d_st = (int*)(d + (((size_t)size + out_cap + 3) & ~(size_t)3));
+    int n = 0;
+    hipError_t e = hipMemcpy(d_in, h_in, size, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_out, h_out, out_cap, hipMemcpyHostToDevice);       // (bytes the stage does not write keep the caller's fill)
+    if (e == hipSuccess) e = hipMemcpy(d_st, h_state4, 4 * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = dvbs_depunc_stage_launch(period, mode, d_in, size, d_out, d_st, d_st + 4, 0);
+    if (e == hipSuccess) e = hipMemcpy(h_out, d_out, out_cap, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h_state4, d_st, 4 * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&n, d_st + 4, sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail_hip(e, "dvbs depuncture stage");
+    return n;
+}
+
 }  // extern "C"

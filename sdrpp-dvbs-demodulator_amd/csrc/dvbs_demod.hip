@@ -3,6 +3,7 @@
 // streams.  The TS deframer, Forney de-interleaver call, Reed-Solomon and energy dispersal that follow in the reference are the
 // next rows; the de-interleaver kernel itself is exposed separately (dvbs2gpu_forney_*).
 #include "ctx.h"
+#include "../../include/dvbs2gpu_math.h"
 #include <cmath>
 #include <algorithm>
 
@@ -52,8 +53,11 @@ std::vector<cf32> make_bandedge(const dvbs2gpu_dvbs_cfg& c) {   // FLL::createBa
         float tap = bb[i] / power;
         float k = (-N + (int)i) / (2.0f * sps);
         float a1 = -2.0f * PI_F * (1.0f + c.rrc_alpha) * k, a2 = 2.0f * PI_F * (1.0f + c.rrc_alpha) * k;
-        out[T - i - 1] = cf32{cosf(a1) * tap, sinf(a1) * tap};
-        out[T + T - i - 1] = cf32{cosf(a2) * tap, sinf(a2) * tap};
+        float s1, c1, s2, c2;   // the engine's own sin/cos (include/dvbs2gpu_math.h), like the oracle's tap builder
+        dvbs2m::sincosf_det(a1, &s1, &c1);
+        dvbs2m::sincosf_det(a2, &s2, &c2);
+        out[T - i - 1] = cf32{c1 * tap, s1 * tap};
+        out[T + T - i - 1] = cf32{c2 * tap, s2 * tap};
     }
     return out;
 }
@@ -88,10 +92,19 @@ int dvbs2gpu_dvbs_demod_create(dvbs2gpu_ctx* ctx, const dvbs2gpu_dvbs_cfg* cfg, 
     if (!ctx || !cfg || !out || nstreams <= 0 || max_samples <= 0) return DVBS2GPU_ERR_ARG;
     if (cfg->rrc_taps != 65) { last_error() = "the DVB-S front end is built for the reference's 65-tap filters (RRC_TAP_COUNT)"; return DVBS2GPU_ERR_ARG; }
     if (!(cfg->samplerate > 0) || !(cfg->symbolrate > 0)) return DVBS2GPU_ERR_ARG;
+    // the timing loop writes one symbol per `freq` input samples, freq >= omega * (1 - omega_rel_limit): the symbol / soft buffers are
+    // sized from that bound, and the kernel stages at most FD_TILE/2 + 72 symbols per 256-sample tile (omega_min >= 1.5 keeps it at 171)
+    {
+        const double omega_min = (cfg->samplerate / cfg->symbolrate) * (1.0 - (double)cfg->omega_rel_limit);
+        if (!(cfg->omega_rel_limit >= 0.f) || !(cfg->omega_rel_limit <= 0.25f) || !(omega_min >= 1.5) || !(cfg->samplerate / cfg->symbolrate <= 64.0)) {
+            last_error() = "samplerate/symbolrate * (1 - omega_rel_limit) must be >= 1.5 (and the ratio <= 64, omega_rel_limit in [0, 0.25])";
+            return DVBS2GPU_ERR_ARG;
+        }
+    }
     HIP_TRY(hipSetDevice(ctx->device));
     auto d = new dvbs2gpu_dvbs_demod();
     d->ctx = ctx; d->cfg = *cfg; d->nstreams = nstreams; d->max_samples = max_samples;
-    d->sym_cap = (size_t)max_samples / 2 + max_samples / 32 + 128;
+    d->sym_cap = (size_t)((double)max_samples / ((cfg->samplerate / cfg->symbolrate) * (1.0 - (double)cfg->omega_rel_limit))) + 130;
     d->soft_cap = (size_t)2 * d->sym_cap + 2 * DVBS_SOFT_BLOCK + 128;
     d->max_blocks = (int)(d->soft_cap / DVBS_SOFT_BLOCK);
     const float PI_F = 3.14159265358979323846f;
@@ -149,6 +162,7 @@ int dvbs2gpu_dvbs_demod_process_batch(dvbs2gpu_dvbs_demod* d, const float* const
                                       int* out_counts) {
     if (!d || !d_iq || !counts || !d_bits || !out_counts || cap < 0) return DVBS2GPU_ERR_ARG;
     dvbs2gpu_ctx* ctx = d->ctx;
+    CallGuard guard(ctx);                       // ws_dvbs[] are context-wide
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = nullptr;
     const int n = d->nstreams;

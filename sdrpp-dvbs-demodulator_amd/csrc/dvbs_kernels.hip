@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64) void dvbs_cc_decode_kernel(const uint8_t* in, l
 
 // ------------------------------------------------------------------------------------------------ Viterbi_DVBS::work
 // rotate_soft (rotation.cpp:4-63, phases 0 / 90 only: module_dvbs_demod.cpp:23) + signed_soft_to_unsigned (utils.cpp:11-20)
-__device__ __forceinline__ uint8_t soft_conv(const int8_t* in, int i, int phase) {
+__device__ __forceinline__ int soft_rotate(const int8_t* in, int i, int phase) {   // rotate_soft, PHASE_0 / PHASE_90, no IQ swap
     int s;
     if (phase == 0) { s = in[i]; if (s == -128) s = -127; }
     else {
@@ -129,7 +129,10 @@ __device__ __forceinline__ uint8_t soft_conv(const int8_t* in, int i, int phase)
         if (b == -128) b = -127;
         s = (i & 1) ? -a : b;
     }
-    int u = (s + 127) & 255;
+    return s;
+}
+__device__ __forceinline__ uint8_t soft_conv(const int8_t* in, int i, int phase) {
+    const int u = (soft_rotate(in, i, phase) + 127) & 255;      // signed_soft_to_unsigned: 128 is reserved for erasures
     return (uint8_t)(u == 128 ? 127 : u);
 }
 __device__ __forceinline__ int depunc_e(int period, int p) { return period == 3 ? (p == 1) : (p == 1 || p == 3 || p == 4 || p == 5); }
@@ -151,6 +154,19 @@ __device__ int depunc_pattern(int period, int p0, int lead, const uint8_t* in, i
         else out[pos] = x;
     }
     return lead + depunc_before(period, p0, size);
+}
+// Depunc23::depunc_cont / Depunc56::depunc_cont (depunc.h:46-80,139-185): one call over `size` inputs with the carried state
+// (is_first, changing_shift, got_extra, buf); returns the even number of bytes the decoder may use
+__device__ __forceinline__ int depunc_cont_wave(int period, int& first, int& shift, int& extra, int& buf, const uint8_t* in, int size,
+                                                uint8_t* out, int lane) {
+    int lead = 0;
+    if (first || extra) { if (lane == 0) out[0] = (uint8_t)buf; lead = 1; first = 0; extra = 0; }
+    const int p0 = shift % period;
+    int oo = depunc_pattern(period, p0, lead, in, size, out, lane);
+    shift = p0 + size;
+    __syncthreads();
+    if (oo & 1) { buf = out[oo - 1]; oo -= 1; extra = 1; }
+    return oo;
 }
 // viterbi_all.h:92-113
 __device__ int depunc34_wave(const uint8_t* in, uint8_t* out, int size, int shift, int lane) {
@@ -206,6 +222,35 @@ __device__ float reencode_ber(const uint8_t* bits, int frame, int& enc_state, ui
     const float errors = (float)wave_sum(err), total = (float)wave_sum(tot);
     __syncthreads();
     return (errors / total) * ratio;
+}
+
+// stage entry for the parity tests (dvbs2gpu_dvbs_depuncture): the device functions above on caller-supplied bytes, one wave.
+//   mode 0  Depunc23/56::depunc_static (lock search): state4[1] = shift
+//   mode 1  depunc_cont with the carried state4 = {is_first, changing_shift, got_extra, buf}
+//   mode 2  rotate_soft (state4[0] = phase 0 / 1 = 0 / 90 degrees), signed bytes out
+__global__ __launch_bounds__(64) void dvbs_depunc_stage_kernel(int period, int mode, const uint8_t* in, int size, uint8_t* out, int* state4, int* n_out) {
+    const int lane = threadIdx.x;
+    if (mode == 2) {
+        for (int i = lane; i < size; i += 64) out[i] = (uint8_t)(int8_t)soft_rotate((const int8_t*)in, i, state4[0]);
+        if (lane == 0) *n_out = size;
+        return;
+    }
+    int n;
+    if (mode == 0) {
+        const int shift = state4[1], lead = shift > period - 1;
+        if (lead && lane == 0) out[0] = 128;
+        n = depunc_pattern(period, shift % period, lead, in, size, out, lane);
+    } else {
+        int first = state4[0], shift = state4[1], extra = state4[2], buf = state4[3];
+        n = depunc_cont_wave(period, first, shift, extra, buf, in, size, out, lane);
+        __syncthreads();
+        if (lane == 0) { state4[0] = first; state4[1] = shift; state4[2] = extra; state4[3] = buf; }
+    }
+    if (lane == 0) *n_out = n;
+}
+hipError_t dvbs_depunc_stage_launch(int period, int mode, const uint8_t* d_in, int size, uint8_t* d_out, int* d_state4, int* d_n, hipStream_t st) {
+    hipLaunchKernelGGL(dvbs_depunc_stage_kernel, dim3(1), dim3(64), 0, st, period, mode, d_in, size, d_out, d_state4, d_n);
+    return hipGetLastError();
 }
 
 // in_ptrs / nblk (both optional): per-stream input base and block count (the demodulator's soft FIFOs); otherwise stream s reads
@@ -296,13 +341,7 @@ __global__ __launch_bounds__(64) void dvbs_viterbi_kernel(const int8_t* in_all, 
                 ber = reencode_ber(out, TEST / 2, enc[0], ber_enc, soft + d_shift, TEST, 2.5f, lane);
             } else if (rate == 1 || rate == 3) {
                 const int d = rate == 1 ? 0 : 1, period = rate == 1 ? 3 : 6;
-                int lead = 0;
-                if (dfirst[d] || dextra[d]) { if (lane == 0) depunc[0] = (uint8_t)dbuf[d]; lead = 1; dfirst[d] = 0; dextra[d] = 0; }
-                const int p0 = dshift[d] % period;
-                int oo = depunc_pattern(period, p0, lead, soft, BUF, depunc, lane);
-                dshift[d] = p0 + BUF;
-                __syncthreads();
-                if (oo & 1) { dbuf[d] = depunc[oo - 1]; oo -= 1; dextra[d] = 1; }
+                const int oo = depunc_cont_wave(period, dfirst[d], dshift[d], dextra[d], dbuf[d], soft, BUF, depunc, lane);
                 if (rate == 1) {
                     cc_decode_wave(depunc, 5462, ss[6], bs[6], dec, out, lane);
                     ber = reencode_ber(out, 1366, enc[1], ber_enc, depunc, 2560, 3.5f, lane);
@@ -713,6 +752,18 @@ __global__ __launch_bounds__(64) void dvbs_ts_finish_kernel(uint8_t* __restrict_
     if (lane == 0) { st->prbs_pos = pos; out_bytes[s] = nout; }
 #pragma unroll
     for (int q = 0; q < 3; ++q) if ((lane + 64 * q) < 188) st->last_msg[lane + 64 * q] = (uint8_t)lastm[q];
+}
+
+// stage entry for the parity tests: RS + stale-output rule + energy dispersal on packets the caller placed in d_deint (the deframer
+// and the Forney de-interleaver are bypassed); skip_rs: every packet counts as decoded (d_status preset to 1 by the caller)
+hipError_t dvbs_tail_rs_finish_launch(int nstreams, int max_frames, const int* d_nframes, uint8_t* d_deint, long frames_stride, uint8_t* d_status,
+                                      const uint8_t* d_gf, const uint8_t* d_prbs, DvbsTailState* d_state, uint8_t* const* d_out_ptrs, int cap,
+                                      int* d_out_bytes, int* d_rs_err, int skip_rs, hipStream_t st) {
+    if (!skip_rs)
+        hipLaunchKernelGGL(dvbs_rs_kernel, dim3(max_frames * 8, nstreams), dim3(64), 0, st, d_deint, frames_stride, d_nframes, max_frames * 8, d_status, d_rs_err, d_gf);
+    hipLaunchKernelGGL(dvbs_ts_finish_kernel, dim3(nstreams), dim3(64), 0, st, d_deint, frames_stride, d_nframes, max_frames * 8, d_status, d_prbs,
+                       d_state, d_out_ptrs, cap, d_out_bytes, d_rs_err);
+    return hipGetLastError();
 }
 
 hipError_t dvbs_tail_launch(const uint8_t* const* d_in_ptrs, const int* d_counts, int nstreams, int max_bits, uint8_t* d_hist, uint8_t* d_hist_next,

@@ -80,6 +80,10 @@ hipError_t dvbs_tail_launch(const uint8_t* const* d_in_ptrs, const int* d_counts
                             uint8_t* d_v, long v_stride, int max_frames, int* d_hit_pos, int* d_nframes, int* d_errs, uint8_t* d_frames,
                             uint8_t* d_deint, long frames_stride, uint8_t* d_forney_hist, uint8_t* d_status, const uint8_t* d_gf, const uint8_t* d_prbs,
                             DvbsTailState* d_state, uint8_t* const* d_out_ptrs, int cap, int* d_out_bytes, int* d_rs_err, hipStream_t st);
+hipError_t dvbs_tail_rs_finish_launch(int nstreams, int max_frames, const int* d_nframes, uint8_t* d_deint, long frames_stride, uint8_t* d_status,
+                                      const uint8_t* d_gf, const uint8_t* d_prbs, DvbsTailState* d_state, uint8_t* const* d_out_ptrs, int cap,
+                                      int* d_out_bytes, int* d_rs_err, int skip_rs, hipStream_t st);
+hipError_t dvbs_depunc_stage_launch(int period, int mode, const uint8_t* d_in, int size, uint8_t* d_out, int* d_state4, int* d_n, hipStream_t st);
 hipError_t dvbs_pack_bits_launch(const uint8_t* d_bits, const int* d_nbits, const int* d_nblk, int nstreams, int nblocks, uint8_t* const* d_out_ptrs,
                                  int cap, int* d_out_count, hipStream_t st);
 hipError_t dvbs_deinterleave_launch(const uint8_t* d_in, long stream_stride, int nstreams, int nbytes, uint8_t* d_out, uint8_t* d_hist,

@@ -14,6 +14,7 @@
 //   6 LDPC / BCH / descramble over the pooled frames           ldpc_decode_kernel, bch_*, bb_descramble
 //   7 D2H (or D2D for the batch entry point) of BBFRAMEs + stats; FIFO remainder moved to the spare buffer
 #include "ctx.h"
+#include "../../include/dvbs2gpu_math.h"
 #include <list>
 #include <thread>
 #include <cmath>
@@ -71,8 +72,9 @@ struct HostConstel {
     float amp = 1.0f, sca = 50.0f, prescale = 1.0f;
     cf32 pts[32];
     static cf32 polar(float r, int n, float i) {
-        float a = i * 2 * M_PI / n;
-        return cf32{r * cosf(a), r * sinf(a)};
+        float a = i * 2 * M_PI / n, sn, cs;
+        dvbs2m::sincosf_det(a, &sn, &cs);
+        return cf32{r * cs, r * sn};
     }
     static cf32 scale(cf32 a, float s) { return cf32{a.re * s, a.im * s}; }
     HostConstel(int type, float g1, float g2) : constel(type) {   // constellation.cpp:19-150
@@ -113,13 +115,7 @@ struct HostConstel {
             }
         }
     }
-    static int8_t clampv(float x) {   // constellation.cpp:263-270
-        while (x < -127 || x > 127) {
-            x *= 0.5;
-            if (!std::isfinite(x)) return (int8_t)x;
-        }
-        return (int8_t)x;
-    }
+    static int8_t clampv(float x) { return dvbs2m::llr_clamp_det(x); }   // constellation.cpp:263-270
     void soft_calc(cf32 sample, int8_t* bits_out, float* phase_err) const {   // constellation.cpp:205-261
         float tmp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (amp != 1) sample = scale(sample, amp);
@@ -130,32 +126,30 @@ struct HostConstel {
             float dre = sample.re - pts[i].re, dim = sample.im - pts[i].im;
             float dist = sqrtf(dre * dre + dim * dim);
             if (dist < min_dist) { min_dist = dist; closest = pts[i]; }
-            float d = expf(-dist / 1.0f);
+            float d = dvbs2m::expf_det(-dist / 1.0f);
             for (int j = 0; j < bits; j++) {
                 if (((i >> j) & 1) == 0) tmp[2 * j + 0] += d;
                 else tmp[2 * j + 1] += d;
             }
         }
-        for (int i = 0; i < bits; i++) bits_out[bits - 1 - i] = clampv((logf(tmp[2 * i + 1]) - logf(tmp[2 * i + 0])) * sca);
+        for (int i = 0; i < bits; i++) bits_out[bits - 1 - i] = clampv((dvbs2m::logf_det(tmp[2 * i + 1]) - dvbs2m::logf_det(tmp[2 * i + 0])) * sca);
         // sample * conj(closest)
         float pre = sample.re * closest.re - sample.im * (-closest.im), pim = sample.im * closest.re + sample.re * (-closest.im);
-        *phase_err = atan2f(pim, pre);
+        *phase_err = dvbs2m::atan2f_det(pim, pre);
     }
 };
 
 int get_rx_tables(dvbs2gpu_ctx* ctx) {
     std::lock_guard<std::mutex> l(ctx->mtx);
-    if (ctx->d_gardner_bank) return 0;
+    if (ctx->d_gardner_bank) return 0;       // (set last: a failed upload below leaves the tables "not built")
     int rc;
-    if ((rc = upload(make_gardner_bank(), &ctx->d_gardner_bank))) return rc;
     // SOF / PLSC / Gold sequence (s2_defs.h:15-80, s2_scrambling.cpp:9-28)
     std::vector<cf32> sof(26), plsc(128 * 64);
     std::vector<uint64_t> codes(128);
     const uint32_t VALUE = 0x18d2e82;
     for (int s = 0; s < 26; ++s) {
         int bit = (VALUE >> (25 - s)) & 1, angle = bit * 2 + (s & 1);
-        sof[s].re = cosf(M_PI / 4 + 2 * M_PI * angle / 4);
-        sof[s].im = sinf(M_PI / 4 + 2 * M_PI * angle / 4);
+        dvbs2m::sincosf_det((float)(M_PI / 4 + 2 * M_PI * angle / 4), &sof[s].im, &sof[s].re);
     }
     const uint32_t G[6] = {0x55555555, 0x33333333, 0x0f0f0f0f, 0x00ff00ff, 0x0000ffff, 0xffffffff};
     const uint64_t SCR = 0x719d83c953422dfaull;
@@ -182,12 +176,14 @@ int get_rx_tables(dvbs2gpu_ctx* ctx) {
     uint32_t stx = 0x00001, sty = 0x3ffff;
     for (int i = 0; i < 131072; ++i) { rn[i] = (uint8_t)((stx ^ sty) & 1); stx = lfsr_x(stx); sty = lfsr_y(sty); }
     for (int i = 0; i < 131072; ++i) { rn[i] |= (uint8_t)(((stx ^ sty) & 1) << 1); stx = lfsr_x(stx); sty = lfsr_y(sty); }
-    cf32 *d_sof, *d_plsc; uint64_t* d_codes; uint8_t* d_rn;
-    if ((rc = upload(sof, &d_sof))) return rc;
-    if ((rc = upload(plsc, &d_plsc))) return rc;
-    if ((rc = upload(codes, &d_codes))) return rc;
-    if ((rc = upload(rn, &d_rn))) return rc;
+    cf32 *d_sof = nullptr, *d_plsc = nullptr; uint64_t* d_codes = nullptr; uint8_t* d_rn = nullptr; float* d_bank = nullptr;
+    if ((rc = upload(sof, &d_sof)) || (rc = upload(plsc, &d_plsc)) || (rc = upload(codes, &d_codes)) || (rc = upload(rn, &d_rn)) ||
+        (rc = upload(make_gardner_bank(), &d_bank))) {
+        (void)hipFree(d_sof); (void)hipFree(d_plsc); (void)hipFree(d_codes); (void)hipFree(d_rn); (void)hipFree(d_bank);
+        return rc;
+    }
     ctx->pl.sof = d_sof; ctx->pl.plsc = d_plsc; ctx->pl.plsc_code = d_codes; ctx->pl.rn = d_rn;
+    ctx->d_gardner_bank = d_bank;
     return 0;
 }
 
@@ -208,7 +204,7 @@ int get_constel(dvbs2gpu_ctx* ctx, const ModcodParams& mp, ConstelTables** out) 
             T.dev.pts_g = T.d_pts;
         }
         T.dev.lut_bits = nullptr; T.dev.lut_err = nullptr;
-        if (H.bits != 5) {   // make_lut(256), constellation.cpp:272-291 -- built with the host libm, uploaded
+        if (H.bits != 5) {   // make_lut(256), constellation.cpp:272-291 -- built on the host with the shared math definitions, uploaded
             std::vector<int8_t> lb((size_t)65536 * H.bits);
             std::vector<float> le(65536);
             for (int x = 0; x < 256; ++x)
@@ -290,6 +286,10 @@ int demod_configure(dvbs2gpu_demod* d) {
     const dvbs2gpu_demod_cfg& c = d->cfg;
     if (!modcod_params(c.modcod, c.shortframes, c.pilots, &d->mp)) { last_error() = "unsupported MODCOD"; return DVBS2GPU_ERR_MODCOD; }
     if (c.rrc_taps < 1 || c.rrc_taps > RRC_MAX_TAPS) { last_error() = "rrc_taps out of range"; return DVBS2GPU_ERR_ARG; }
+    if (!(c.samplerate > 0) || !(c.symbolrate > 0)) { last_error() = "samplerate and symbolrate must be positive"; return DVBS2GPU_ERR_ARG; }
+    // the Gardner loop (omega = 1 sample per output, module_dvbs2_demod.cpp:49) emits at most count / (1 - omega_rel_limit) samples; the
+    // timing-recovery scratch (count + count/16 + 128) and the symbol FIFO are sized for a limit of a few percent (main.cpp:73: 0.02)
+    if (!(c.omega_rel_limit >= 0.f) || !(c.omega_rel_limit <= 0.05f)) { last_error() = "omega_rel_limit must be within [0, 0.05]"; return DVBS2GPU_ERR_ARG; }
     S2LoopCoefs& co = d->co;
     co.agc_rate = c.agc_rate;
     co.g_alpha = c.clock_mu_gain; co.g_beta = c.clock_omega_gain;
@@ -732,6 +732,7 @@ int dvbs2gpu_demod_get_kbch(dvbs2gpu_demod* d) { return d ? d->mp.fec.kbch : DVB
 
 int dvbs2gpu_set_pipelined(dvbs2gpu_ctx* ctx, int on) {
     if (!ctx) return DVBS2GPU_ERR_ARG;
+    CallGuard guard(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     if (on) {      // (the FEC stream may exist already: synchronous mixed batches use it too)
         if (!ctx->fe_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->fe_stream, hipStreamNonBlocking));
@@ -751,7 +752,9 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
                                  uint8_t* const* d_out, int out_cap, int* out_bytes) {
     if (!demods || n <= 0 || !d_iq || !counts || !d_out || !out_bytes) return DVBS2GPU_ERR_ARG;
     dvbs2gpu_ctx* ctx = demods[0]->ctx;
+    CallGuard guard(ctx);                       // the per-call workspaces are context-wide: one call at a time per context
     HIP_TRY(hipSetDevice(ctx->device));
+    { int rq = ws_quiesce(ctx); if (rq) return rq; }
     // group streams that share a configuration (order inside a group = caller's order)
     std::vector<std::vector<int>> groups;
     {
@@ -855,7 +858,9 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
 int dvbs2gpu_demod_process(dvbs2gpu_demod* d, int count, const float* h_iq, uint8_t* h_out, int out_cap) {
     if (!d || count < 0 || (count > 0 && !h_iq) || !h_out) return DVBS2GPU_ERR_ARG;
     if (count > d->max_samples) { last_error() = "count exceeds max_samples"; return DVBS2GPU_ERR_ARG; }
+    CallGuard guard(d->ctx);                    // the per-call workspaces are context-wide: one call at a time per context
     HIP_TRY(hipSetDevice(d->ctx->device));
+    { int rq = ws_quiesce(d->ctx); if (rq) return rq; }
     if (!d->d_in) {   // staging buffers of the host-pointer entry point, allocated on first use
         HIP_TRY(hipMalloc((void**)&d->d_in, (size_t)d->max_samples * sizeof(cf32)));
         int max_frames = d->fifo_cap / 3330 + 2;
@@ -935,6 +940,26 @@ int dvbs2gpu_demap_batch(dvbs2gpu_ctx* ctx, int modcod, int shortframes, int pil
     if (rc) return rc;
     HIP_TRY(s2_demap_launch(CT->dev, mp.rate, mp.shortframe, mp.slots, mp.pilots, mp.plframe, (const cf32*)d_frames, nframes, d_llr,
                             mp.fec.N, (hipStream_t)stream));
+    return 0;
+}
+
+int dvbs2gpu_deinterleave_batch(dvbs2gpu_ctx* ctx, int modcod, int shortframes, const int8_t* d_in, int nframes, int8_t* d_out, void* stream) {
+    if (!ctx || nframes < 0) return DVBS2GPU_ERR_ARG;
+    ModcodParams mp;
+    if (!modcod_params(modcod, shortframes, 0, &mp)) { last_error() = "unsupported MODCOD"; return DVBS2GPU_ERR_MODCOD; }
+    if (nframes == 0) return 0;
+    if (!d_in || !d_out || d_in == d_out) return DVBS2GPU_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(s2_deinterleave_launch(mp.constel, mp.rate, mp.bits, mp.fec.N, d_in, nframes, d_out, (hipStream_t)stream));
+    return 0;
+}
+
+int dvbs2gpu_math_eval(dvbs2gpu_ctx* ctx, int func, int n, const float* d_a, const float* d_b, float* d_out0, float* d_out1, void* stream) {
+    if (!ctx || n < 0 || func < 0 || func > 4) return DVBS2GPU_ERR_ARG;
+    if (n == 0) return 0;
+    if (!d_a || !d_out0 || (func == 1 && !d_b) || (func == 0 && !d_out1)) return DVBS2GPU_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(math_eval_launch(func, n, d_a, d_b, d_out0, d_out1, (hipStream_t)stream));
     return 0;
 }
 

@@ -138,6 +138,8 @@ hipError_t s2_scatter_out_launch(const S2StreamWork* d_work, const S2FrameRef* d
 hipError_t s2_scatter_out2_launch(uint8_t* const* d_outs, const S2FrameRef* d_frames, const int* d_first, int nframes, int kb,
                                   const uint8_t* d_bb, hipStream_t st);
 hipError_t s2_fifo_compact_launch(const S2StreamWork* d_work, int nstreams, const int* d_cur_fill /*[2*nstreams]: cur, fill*/, hipStream_t st);
+hipError_t s2_deinterleave_launch(int constel, int rate, int bits, int N, const int8_t* d_in, int nframes, int8_t* d_out, hipStream_t st);
+hipError_t math_eval_launch(int func, int n, const float* a, const float* b, float* o0, float* o1, hipStream_t st);
 hipError_t s2_demap_launch(S2ConstelDev con, int rate, int shortframe, int slots, int pilots, int plframe, const cf32* d_pllout,
                            int nframes, int8_t* d_llr, int N, hipStream_t st);
 

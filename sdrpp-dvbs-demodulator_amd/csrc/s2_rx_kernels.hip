@@ -1,6 +1,7 @@
 // DVB-S2 receive-chain kernels for gfx950 (compiled with -ffp-contract=off: every fp32 operation is a
-// separately rounded IEEE op in the order written, which is what the CPU restatement does; only the
-// libm calls -- cosf/sinf/atan2f/expf/logf -- may differ from the host's by ULPs).
+// separately rounded IEEE op in the order written, which is what the CPU restatement does).  sin/cos/atan2/exp/log
+// are the engine's own straight-line definitions (include/dvbs2gpu_math.h) -- no device libm, no hardware
+// v_sin/v_cos -- so these kernels are bit-identical to the CPU restatement that includes the same header.
 //
 // Replaces (reference file:line):
 //   loop::FastAGC<complex_t>::process (SDR++)          call site module_dvbs2_demod.cpp:220
@@ -20,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "s2_rx.h"
+#include "../../include/dvbs2gpu_math.h"
 #include "s2_params.h"
 
 namespace s2 {
@@ -30,8 +32,8 @@ __device__ __forceinline__ cf32 cadd(cf32 a, cf32 b) { return cf32{a.re + b.re, 
 __device__ __forceinline__ cf32 csub(cf32 a, cf32 b) { return cf32{a.re - b.re, a.im - b.im}; }
 __device__ __forceinline__ cf32 cscale(cf32 a, float s) { return cf32{a.re * s, a.im * s}; }
 __device__ __forceinline__ float camp(cf32 a) { return sqrtf(a.re * a.re + a.im * a.im); }
-__device__ __forceinline__ float cphase(cf32 a) { return atan2f(a.im, a.re); }
-__device__ __forceinline__ cf32 phasor(float x) { return cf32{cosf(x), sinf(x)}; }
+__device__ __forceinline__ float cphase(cf32 a) { return dvbs2m::atan2f_det(a.im, a.re); }
+__device__ __forceinline__ cf32 phasor(float x) { cf32 r; dvbs2m::sincosf_det(x, &r.im, &r.re); return r; }
 
 // pointers read out of device structs are generic ("flat") to the compiler; flat accesses count against the LDS counter as well
 // and serialise with the LDS reads of the serial loops.  These are known to be global memory.
@@ -84,39 +86,11 @@ __device__ __forceinline__ cf32 dot8(const cf32* x, const float* t) {
 }
 
 // ------------------------------------------------------------------------------------------------ front end
-// sin/cos for |x| <= a few pi: 3-term Cody-Waite reduction by pi/4 and the classic single-precision minimax
-// polynomials (~1 ULP).  Used instead of the device libm on the serial per-sample paths (~35 instructions
-// for both values, no slow-path branches).  sincos(0) = (0, 1) exactly.
-__device__ __forceinline__ cf32 phasor_fast(float x) {
-#ifdef S2_HW_SINCOS
-    // A/B switch, NOT used: the hardware's v_sin_f32 / v_cos_f32 (input in revolutions, ~1e-6 absolute error instead of ~1 ULP) make the
-    // serial kernels 6-16 % faster (DVB-S bank of 4096: 966 -> 1121 Msym/s, S2 headline +1.5 %) but the symbol-level comparison with
-    // the oracle (tests/test_gpu_s2chain.py::test_demod_end_to_end_vs_oracle) no longer holds, so the ~1-ULP polynomial stays
-    const float rv = x * 0.15915494309189535f;
-    return cf32{__builtin_amdgcn_cosf(rv), __builtin_amdgcn_sinf(rv)};
-#endif
-    float ax = fabsf(x);
-    int j = (int)(ax * 1.27323954473516f);
-    j = (j + 1) & ~1;
-    float y = (float)j;
-    float r = ((ax - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
-    float z = r * r;
-    float ps = r + r * z * ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f);
-    float pc = (1.0f - 0.5f * z) + z * z * ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f);
-    int q = (j >> 1) & 3;
-    float sn = (q & 1) ? pc : ps, cs = (q & 1) ? ps : pc;
-    if (q == 1 || q == 2) cs = -cs;
-    if (q >= 2) sn = -sn;
-    if (x < 0.f) sn = -sn;
-    return cf32{cs, sn};
-}
-// The hardware's v_sin_f32 / v_cos_f32 (argument in revolutions; ~1e-6 absolute error, sincos(0) = (0, 1) exactly): used by the
-// DVB-S loops (FLL, Costas), whose parity with the oracle is statistical while the loops run and exact at zero bandwidth (phase 0);
-// 3 instead of ~35 instructions in chains that are bound by the instructions they issue.
-__device__ __forceinline__ cf32 phasor_hw(float x) {
-    const float rv = x * 0.15915494309189535f;
-    return cf32{__builtin_amdgcn_cosf(rv), __builtin_amdgcn_sinf(rv)};
-}
+// sin/cos on the serial per-sample paths: the shared straight-line definition (~35 instructions for both values, no slow-path
+// branches).  The hardware's v_sin_f32 / v_cos_f32 would be 3 instructions (DVB-S bank +18 %, S2 headline +1.5 % when tried), but
+// their ~1e-6 absolute error has no CPU restatement, and parity with the oracle is the gate: every loop uses the shared definition.
+__device__ __forceinline__ cf32 phasor_fast(float x) { return phasor(x); }
+__device__ __forceinline__ cf32 phasor_hw(float x) { return phasor(x); }
 
 // The front end is split along its dependency structure:
 //   agc_pc_kernel      LANE = STREAM.  The AGC gain and NCO phase recurrences depend only on the input, are strictly serial in
@@ -509,9 +483,7 @@ __device__ void soft_calc_dev(const S2ConstelDev& C, cf32 sample, int8_t* bits_o
     for (int i = 0; i < C.states; i++) {
         float dist = camp(csub(sample, C.pts[i]));
         if (dist < min_dist) { min_dist = dist; closest = C.pts[i]; }
-        // exp/log through double: within ~0.5 ULP of the exact float result and subnormal-safe, so the int8 LLRs agree
-        // with the host libm version except on rare rounding ties (device expf also flushes subnormal results)
-        float dd = (float)exp((double)(-dist / 1.0f));
+        float dd = dvbs2m::expf_det(-dist / 1.0f);   // the shared definition: fp64 evaluation, one rounding, subnormal results kept
         for (int j = 0; j < C.bits; j++) {
             if (((i >> j) & 1) == 0) tmp[2 * j + 0] += dd;
             else tmp[2 * j + 1] += dd;
@@ -519,12 +491,8 @@ __device__ void soft_calc_dev(const S2ConstelDev& C, cf32 sample, int8_t* bits_o
     }
     if (bits_out)
         for (int i = 0; i < C.bits; i++) {
-            float x = ((float)log((double)tmp[2 * i + 1]) - (float)log((double)tmp[2 * i + 0])) * C.sca;
-            while (x < -127 || x > 127) {
-                x *= 0.5f;
-                if (!isfinite(x)) break;
-            }
-            bits_out[C.bits - 1 - i] = (int8_t)x;
+            float x = (dvbs2m::logf_det(tmp[2 * i + 1]) - dvbs2m::logf_det(tmp[2 * i + 0])) * C.sca;
+            bits_out[C.bits - 1 - i] = dvbs2m::llr_clamp_det(x);
         }
     if (phase_err) *phase_err = cphase(cmul(sample, cconj(closest)));
 }
@@ -729,6 +697,13 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
 }
 
 // ------------------------------------------------------------------------------------------------ demapper
+// where bit c (MSB first) of payload symbol j goes (s2_deinterleaver.cpp:72-136): QPSK swaps the pair (:80-84), the others are
+// column-row de-interleaved, 8PSK 3/5 with the columns reversed (:26-31)
+__device__ __forceinline__ int deint_pos(int constel, int rate, int bits, int rows, int j, int c) {
+    if (bits == 2) return 2 * j + (1 - c);
+    const int col = (constel == C_8PSK && rate == R3_5) ? (2 - c) : c;
+    return col * rows + j;
+}
 // grid (x: symbol tiles, y: frame).  LUT fetch + bit de-interleave fused: LLR c of payload symbol j goes to
 // column c (8PSK 3/5: columns reversed), QPSK just swaps the pair.
 __global__ __launch_bounds__(256) void s2_demap_kernel(S2ConstelDev C, int rate, int slots, int pilots, int plframe,
@@ -750,15 +725,16 @@ __global__ __launch_bounds__(256) void s2_demap_kernel(S2ConstelDev C, int rate,
         } else {
             soft_calc_dev(C, v, b, nullptr);
         }
-        if (bits == 2) {
-            out[2 * j + 1] = b[0]; out[2 * j] = b[1];
-        } else {
-            for (int c = 0; c < bits; ++c) {
-                int col = (C.constel == C_8PSK && rate == R3_5) ? (2 - c) : c;
-                out[col * rows + j] = b[c];
-            }
-        }
+        for (int c = 0; c < bits; ++c) out[deint_pos(C.constel, rate, bits, rows, j, c)] = b[c];
     }
+}
+// S2Deinterleaver::deinterleave alone (s2_deinterleaver.cpp:72-136) on caller-supplied int8 frames: the same index function as the
+// fused demapper; grid (x: tiles, y: frame)
+__global__ __launch_bounds__(256) void s2_deinterleave_kernel(int constel, int rate, int bits, int N, const int8_t* __restrict__ in,
+                                                              int8_t* __restrict__ out) {
+    const int f = blockIdx.y, rows = N / bits;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256)
+        out[(size_t)f * N + deint_pos(constel, rate, bits, rows, i / bits, i % bits)] = in[(size_t)f * N + i];
 }
 
 // ------------------------------------------------------------------------------------------------ call tails
@@ -1052,6 +1028,25 @@ __global__ __launch_bounds__(256) void dvbs_soft_compact_kernel(const DvbsStream
     if (threadIdx.x == 0) st->soft_fill = rest;
 }
 
+// ------------------------------------------------------------------------------------------------ math self-test
+// evaluates the shared definitions of include/dvbs2gpu_math.h on the device, one element per thread (dvbs2gpu_math_eval)
+__global__ __launch_bounds__(256) void math_eval_kernel(int func, int n, const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ o0, float* __restrict__ o1) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    switch (func) {
+        case 0: { float sn, cs; dvbs2m::sincosf_det(a[i], &sn, &cs); o0[i] = sn; o1[i] = cs; break; }
+        case 1: o0[i] = dvbs2m::atan2f_det(a[i], b[i]); break;
+        case 2: o0[i] = dvbs2m::expf_det(a[i]); break;
+        case 3: o0[i] = dvbs2m::logf_det(a[i]); break;
+        default: o0[i] = (float)dvbs2m::llr_clamp_det(a[i]); break;
+    }
+}
+hipError_t math_eval_launch(int func, int n, const float* a, const float* b, float* o0, float* o1, hipStream_t st) {
+    hipLaunchKernelGGL(math_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, st, func, n, a, b, o0, o1);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 hipError_t s2_collect_launch(const S2StreamWork* d_work, int nstreams, int* d_nsym, float* d_nco, hipStream_t st) {
     hipLaunchKernelGGL(s2_collect_kernel, dim3((nstreams + 255) / 256), dim3(256), 0, st, d_work, nstreams, d_nsym, d_nco);
@@ -1113,6 +1108,10 @@ hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const
                                  int pilot_blocks, int plframe, cf32* d_pllout, S2FrameStats* d_stats, hipStream_t st) {
     hipLaunchKernelGGL(s2_frame_loops_kernel, dim3((nstreams + FL_SPW - 1) / FL_SPW), dim3(64), 0, st, d_work, nstreams, d_frames, d_first, coefs,
                        tabs, con, pls_code, slots, pilots, pilot_blocks, plframe, d_pllout, d_stats);
+    return hipGetLastError();
+}
+hipError_t s2_deinterleave_launch(int constel, int rate, int bits, int N, const int8_t* d_in, int nframes, int8_t* d_out, hipStream_t st) {
+    hipLaunchKernelGGL(s2_deinterleave_kernel, dim3((N + 255) / 256, nframes), dim3(256), 0, st, constel, rate, bits, N, d_in, d_out);
     return hipGetLastError();
 }
 hipError_t s2_demap_launch(S2ConstelDev con, int rate, int shortframe, int slots, int pilots, int plframe, const cf32* d_pllout,

@@ -3,6 +3,8 @@
 //   host_mirror s2   <iq.cf32> <out.bb> <modcod> <short> <pilots> <chunk>     DVBS2Demod::process per chunk      -> BBFRAMEs
 //   host_mirror bbts <in.bb>   <out.ts> <kbch_bits> <frames_per_call>          BBFrameTSParser::work              -> TS packets
 //   host_mirror dvbs <iq.cf32> <out.ts> <chunk>                                DVBSDemod::process per chunk       -> TS packets
+//   host_mirror s2x2 <iqA> <outA> <modcodA> <shortA> <pilotsA> <iqB> <outB> <modcodB> <shortB> <pilotsB> <chunk>
+//                    two DVBS2Demod blocks on two worker threads at once (two plugin instances share the engine context)
 // Prints one status line per mode; exit code 0 = ran, 2 = usage, 3 = exception (e.g. no GPU: there is no CPU fallback).
 #include <dvbs2gpu_host.hpp>
 
@@ -11,6 +13,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <thread>
 
 using namespace dvbs2gpu_host;
 
@@ -57,6 +60,31 @@ int main(int argc, char** argv) {
             bool threw = false;
             try { demod.setDemodParams(99, false, false, 0.6f, 25); } catch (const std::runtime_error&) { threw = true; }
             std::printf("bad_modcod_throws=%d kbch_after=%d\n", (int)threw, demod.getKBCH());
+        } else if (mode == "s2x2" && argc == 13) {
+            const int chunk = atoi(argv[12]);
+            struct Job { const char* in; const char* out; int modcod, sh, pil; long total; std::string err; };
+            Job jobs[2] = {{argv[2], argv[3], atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), 0, ""}, {argv[7], argv[8], atoi(argv[9]), atoi(argv[10]), atoi(argv[11]), 0, ""}};
+            out.close();
+            auto worker = [&](Job* j) {
+                try {
+                    std::vector<char> data = slurp(j->in);
+                    std::ofstream o(j->out, std::ios::binary);
+                    std::vector<uint8_t> buf(STREAM_BUFFER_SIZE);
+                    dvbs2::DVBS2Demod demod;
+                    demod.init(2e6, 4e6, 0.0001f, 0.35f, 65, 0.00628f, 0.006f, omega_gain, mu_gain, nullptr, nullptr, j->modcod, j->sh != 0, j->pil != 0, 0.6f, 16, 0.02);
+                    const complex_t* iq = reinterpret_cast<const complex_t*>(data.data());
+                    const long n = (long)(data.size() / sizeof(complex_t));
+                    for (long a = 0; a < n; a += chunk) {
+                        const int got = demod.process((int)std::min<long>(chunk, n - a), iq + a, buf.data());
+                        o.write(reinterpret_cast<const char*>(buf.data()), got);
+                        j->total += got;
+                    }
+                } catch (const std::exception& e) { j->err = e.what(); }
+            };
+            std::thread ta(worker, &jobs[0]), tb(worker, &jobs[1]);
+            ta.join(); tb.join();
+            if (!jobs[0].err.empty() || !jobs[1].err.empty()) throw std::runtime_error(jobs[0].err + " " + jobs[1].err);
+            std::printf("s2x2 bytesA=%ld bytesB=%ld\n", jobs[0].total, jobs[1].total);
         } else if (mode == "bbts" && argc == 6) {
             const int kbch = atoi(argv[4]), per_call = atoi(argv[5]);
             dvbs2::BBFrameTSParser parser;

@@ -166,6 +166,8 @@ def _bind_chain():
     L.orc_constellation_soft_calc.restype = None
     L.orc_constellation_points.argtypes = [C.c_int, C.c_float, C.c_float, _f32p]
     L.orc_constellation_points.restype = None
+    L.orc_math_eval.argtypes = [C.c_int, C.c_int, _f32p, C.c_void_p, _f32p, _f32p]
+    L.orc_math_eval.restype = None
     L.orc_s2_deinterleave.argtypes = [C.c_int, C.c_int, C.c_int, _i8p, _i8p]
     L.orc_s2_deinterleave.restype = None
     L.orc_pl_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -245,3 +247,16 @@ class OracleRx:
         if n:
             self.L.orc_s2rx_tap(self.h, which, a.ctypes.data)
         return a
+
+
+def math_eval(func, a, b=None):
+    """host evaluation of include/dvbs2gpu_math.h (0 sincos, 1 atan2(a, b), 2 exp, 3 log, 4 LLR clamp) -> (out0, out1)"""
+    _bind_chain()
+    a = np.ascontiguousarray(a, np.float32)
+    o0, o1 = np.zeros_like(a), np.zeros_like(a)
+    bp = None
+    if b is not None:
+        b = np.ascontiguousarray(b, np.float32)
+        bp = b.ctypes.data
+    lib().orc_math_eval(int(func), a.size, a, bp, o0, o1)
+    return o0, o1

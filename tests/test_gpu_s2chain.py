@@ -1,36 +1,23 @@
 """GPU parity tests of the DVB-S2 receive chain (front end, PL sync, PLL/PLHDR, demapper) through the C ABI
 against the CPU oracle on the same synthetic IQ.
 
-Tolerances: the float stages differ from the oracle only through the device libm (cosf/sinf/atan2f), so
-symbols / PLL outputs are compared to 1e-4 (absolute, unit-amplitude signals -- the north star's bound);
-Once the NCO runs at a non-zero frequency its cosf/sinf ULP differences reach the timing loop, whose
-interpolator picks one of 128 polyphase arms by floor(mu*128): an ULP-level difference in mu occasionally
-selects the neighbouring arm for ONE output sample (error ~ slope/128), after which the loops re-converge.
-The Gardner TED is sign-directed (gardner.cpp:124) and evaluated at the zero crossings, so a sample with
-re or im ~ 0 can flip its sign on an ULP difference and kick mu by alpha*|dy/dt| (~4e-3 samples) until the
-loop pulls back (~1/alpha outputs).  Until the first NCO feedback (NCO frequency 0: cos(0), sin(0) exact) the
-two paths are bit-identical, which the test checks; afterwards the bound is statistical: the bulk of the
-samples within 1e-4, the excursions bounded by those kicks, and they re-converge.
-The decision-directed PLL reads its phase error from a 256x256 LUT: two trajectories that differ by less
-than a LUT cell see the same error, so a small difference is not pulled back (it random-walks at the 1e-4
-level), and a symbol next to a decision boundary can kick the two phases apart by alpha*pi/4 ~ 7e-3 rad
-until the loop decays it.  PLL outputs are therefore compared at 1e-3 for all but a few percent of samples.
-LLRs come out of a LUT indexed by those floats, so a sample that sits within 1e-4 of a LUT cell border may
-land in the neighbouring cell: a small fraction of LLR bytes may differ.  Everything after the LDPC
-decoder -- the BBFRAMEs -- must be bit-exact."""
+Tolerance: NONE.  Every fp32 operation of the float stages is a separately rounded IEEE operation in the same order on
+both sides (-ffp-contract=off), and sin/cos/atan2/exp/log are the engine's own straight-line definitions
+(include/dvbs2gpu_math.h, tests/test_det_math.py shows gfx950 and x86-64 evaluate them to the same bits), so symbols,
+aligned frames, PLL outputs, LLRs, per-frame statistics and BBFRAMEs are compared for EQUALITY, call by call, with the
+carrier / timing loops active.  (Round 1 used the device libm and could only compare statistically: the sign-directed
+Gardner TED and the LUT-quantised PLL turn a 1-ULP phasor difference into a different polyphase arm or LUT cell.)"""
 import numpy as np
 import pytest
 import orc
 
 pytestmark = pytest.mark.gpu
 
-SYM_TOL = 1e-4
-
-
-def close_enough(a, b, tol, what, max_frac=5e-3):
-    e = np.abs(a - b)
-    frac = float((e > tol).mean())
-    assert frac < max_frac and float(e.max()) < 0.08, (what, frac, float(e.max()))
+def same_bits(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    if a.dtype.kind in 'fc':
+        return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    return np.array_equal(a, b)
 
 
 @pytest.mark.parametrize('modcod,short,pilots', [(4, 1, 0), (14, 1, 0), (12, 1, 0), (19, 1, 0), (6, 1, 1), (14, 1, 1)])
@@ -52,112 +39,91 @@ def test_demap_bit_exact(engine, modcod, short, pilots):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
-def test_demap_32apsk_within_one_lsb(engine):
-    """32APSK is computed per symbol with expf/logf (constellation.cpp:319-321): device libm => +-1 LSB."""
+@pytest.mark.parametrize('modcod,short,pilots', [(27, 1, 1), (24, 0, 0), (28, 0, 1)])
+def test_demap_32apsk_bit_exact(engine, modcod, short, pilots):
+    """32APSK is computed per symbol with exp/log (constellation.cpp:205-261,319-321) -- the shared fp64 definitions on both
+    sides: the int8 LLRs are equal, including subnormal exp() results and the all-underflow (non-finite) case"""
     import torch
-    modcod, short, pilots = 27, 1, 1
     mp = orc.modcod_params(modcod, short, pilots)
     rng = np.random.default_rng(1)
-    fr = (rng.standard_normal((2, mp['plframe'])) + 1j * rng.standard_normal((2, mp['plframe']))).astype(np.complex64) * 0.7
+    F = 3
+    fr = (rng.standard_normal((F, mp['plframe'])) + 1j * rng.standard_normal((F, mp['plframe']))).astype(np.complex64) * 0.7
     fr[1, 90:400] *= 4          # far outside the constellation: exp() results go subnormal
+    fr[2, 90:300] *= 40         # every exp() underflows to 0: log(0) - log(0) is NaN -> LLR 0 by definition
+    fr[2, 300:400] = 0
     rx = orc.OracleRx(orc.default_cfg(modcod, short, pilots))
-    want = np.zeros((2, mp['N']), np.int8)
-    for f in range(2):
+    want = np.zeros((F, mp['N']), np.int8)
+    for f in range(F):
         rx.L.orc_s2rx_to_soft(rx.h, np.ascontiguousarray(fr[f]).view(np.float32), want[f])
-    got = engine.demap(torch.from_numpy(fr).cuda(), modcod, True, True).cpu().numpy()
-    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
-    # ULP differences in expf/logf move the float LLR by << 1; truncation to int8 then differs by at most 1,
-    # except at the reference's halving clamp (constellation.cpp:263-270): a value that crosses +-127 is halved,
-    # so e.g. 127.01 -> 63 while 126.99 -> 126.  Those outliers must be exactly such halving pairs, and rare.
-    out = d > 1
-    assert out.mean() < 2e-3 and (d > 0).mean() < 0.05
-    g2, w2 = got.astype(np.int32)[out], want.astype(np.int32)[out]
-    assert np.all((np.abs(2 * g2 - w2) <= 3) | (np.abs(2 * w2 - g2) <= 3))
+    got = engine.demap(torch.from_numpy(fr).cuda(), modcod, bool(short), bool(pilots)).cpu().numpy()
+    assert np.array_equal(got, want), int((got != want).sum())
+    assert np.abs(want[0].astype(np.int32)).max() > 60           # (the comparison is not about zeros)
 
 
 CASES = [
-    # modcod, short, pilots, esn0, nframes, chunk, frames that must decode
-    (4, 1, 0, 12.0, 8, 7919, 4),
-    (14, 1, 0, 16.0, 8, 20000, 4),
-    (14, 0, 0, 16.0, 4, 50000, 1),
-    (19, 1, 0, 30.0, 10, 1000000, 4),    # the reference's APSK path is fragile (AGC set point vs demapper prescale)
-    (6, 1, 1, 12.0, 8, 3001, 4),
+    # modcod, short, pilots, esn0, nframes, chunk, frames that must decode, max LDPC trials
+    # (how many frames decode is the reference receiver's acquisition behaviour -- its decision-directed loops are slow and fragile
+    #  at low SNR with a carrier offset; the oracle shows the same, frame by frame -- parity is the equality of everything)
+    (4, 1, 0, 12.0, 8, 7919, 4, 16),
+    (14, 1, 0, 16.0, 16, 20000, 4, 16),
+    (14, 0, 0, 16.0, 4, 50000, 1, 16),
+    (19, 1, 0, 30.0, 10, 1000000, 1, 16),   # the reference's APSK path is fragile (AGC set point vs demapper prescale)
+    (6, 1, 1, 12.0, 8, 3001, 4, 16),
+    (4, 0, 0, 10.0, 8, 40001, 4, 50),       # BASELINE config 2: QPSK 1/2 NORMAL frames, 50 iterations
+    (4, 0, 0, 3.0, 5, 40001, 0, 50),        # ... near threshold (threshold + 2 dB: the loops do not settle within 5 frames)
+    (14, 0, 0, 14.0, 6, 30011, 2, 50),      # BASELINE config 3 at the bench's SNR
+    (14, 0, 0, 9.0, 3, 30011, 0, 50),       # ... at threshold + 1 dB (SURVEY 8d)
+    (27, 1, 1, 15.0, 12, 6007, 0, 50),      # BASELINE config 5 stand-in: 32APSK 8/9 short + pilots at threshold - 1 dB: every frame
+                                            # runs into the iteration limit (max-iter stress)
+    (27, 1, 1, 30.0, 12, 6007, 4, 50),      # ... and the same chain decoding
 ]
 
 
-@pytest.mark.parametrize('modcod,short,pilots,esn0,nframes,chunk,min_good', CASES)
-def test_demod_end_to_end_vs_oracle(engine, modcod, short, pilots, esn0, nframes, chunk, min_good):
+@pytest.mark.parametrize('modcod,short,pilots,esn0,nframes,chunk,min_good,trials', CASES)
+def test_demod_end_to_end_vs_oracle(engine, modcod, short, pilots, esn0, nframes, chunk, min_good, trials):
+    """IQ with carrier offset 1e-3 rad/sample, timing offset 0.3 samples and a phase offset through both receivers in
+    chunks: every tap and every output byte of every call must be EQUAL"""
     iq, bb, _ = orc.transmit(modcod, short, pilots, nframes=nframes, seed=modcod, esn0_db=esn0, cfo=1e-3, timing=0.3, phase0=0.1,
                              lead_symbols=700)
-    cfg_o = orc.default_cfg(modcod, short, pilots)
-    rx = orc.OracleRx(cfg_o)
-    cfg_g = engine.default_cfg(modcod, bool(short), bool(pilots))
-    dm = engine.demod(cfg_g, max_samples=max(chunk, 4096))
-    outs_o, outs_g, decoded = [], [], []
-    acc = {'symbols': ([], []), 'frames': ([], []), 'pll': ([], [])}   # per-call taps, judged over the whole run
-    ncall = 0
-    for a in range(0, iq.size, chunk):
+    rx = orc.OracleRx(orc.default_cfg(modcod, short, pilots, max_ldpc_trials=trials))
+    dm = engine.demod(engine.default_cfg(modcod, bool(short), bool(pilots), max_ldpc_trials=trials), max_samples=max(chunk, 4096))
+    outs_g, decoded, nfr_seen, maxed = [], [], 0, 0
+    for ncall, a in enumerate(range(0, iq.size, chunk)):
         part = iq[a:a + chunk]
         o = rx.process(part)
         g = dm.process(part)
-        ncall += 1
-        # per-call outputs and taps
-        so, sg = rx.tap(0), dm.tap(0)
-        assert so.size == sg.size, ('symbol count', ncall, so.size, sg.size)
-        acc['symbols'][0].append(so); acc['symbols'][1].append(sg)
-        if ncall == 1 and so.size:   # NCO still at frequency 0: no libm value differs -> identical arithmetic
-            assert float(np.max(np.abs(so - sg))) < 1e-6
-        fo, fg = rx.tap(1), dm.tap(1)
-        assert fo.size == fg.size, ('frames found', ncall)
-        if fo.size:
-            po, pg = rx.tap(2), dm.tap(2)
-            acc['frames'][0].append(fo); acc['frames'][1].append(fg)
-            acc['pll'][0].append(po); acc['pll'][1].append(pg)
-            lo, lg = rx.tap(3), dm.tap(3)
-            # QPSK LLRs have a slope of ~850 LSB per unit amplitude (x3 prescale, x50 scale): a 1e-4 symbol difference moves
-            # an LLR by ~0.1 LSB, so up to ~10-20 % of the bytes may differ -- by one LSB, or by the reference's halving
-            # clamp (127.01 -> 63 vs 126.99 -> 126, constellation.cpp:263-270)
-            dl = np.abs(lo.astype(np.int32) - lg.astype(np.int32))
-            assert (dl > 0).mean() < 0.3, ('llr mismatch fraction', float((dl > 0).mean()))
-            big = dl > 2
-            a2, b2 = lo.astype(np.int32)[big], lg.astype(np.int32)[big]
-            halving = (np.abs(2 * a2 - b2) <= 4) | (np.abs(2 * b2 - a2) <= 4)
-            assert big.mean() < 0.05 and (big.sum() == 0 or halving.mean() > 0.5), (float(big.mean()), float(halving.mean()) if big.sum() else 1.0)
-            st_o, st_g = rx.tap(4), dm.stats()
-            assert len(st_o) == len(st_g)
-            for a_, b_ in zip(st_o, st_g):
-                assert abs(a_.best_match - b_.pl_sync_best_match) < 5e-3          # sums of ~57 symbol products
-                assert (a_.detect_modcod, a_.detect_short, a_.detect_pilots) == (b_.detected_modcod, b_.detected_shortframes, b_.detected_pilots)
-                assert abs(a_.fed_err - b_.coarse_freq_err) < 1e-3
-                ok = a_.ldpc_trials >= 0 and a_.bch_corr >= 0
-                decoded.append(ok)
-                if ok:   # a frame the oracle decodes must decode identically on the GPU
-                    assert b_.ldpc_trials >= 0 and b_.bch_corrections >= 0
-        assert o.shape == g.shape, ('frames out', ncall, o.shape, g.shape)
-        outs_o.append(o); outs_g.append(g)
-    close_enough(np.concatenate(acc['symbols'][0]), np.concatenate(acc['symbols'][1]), SYM_TOL * 1.5, 'symbols', max_frac=0.5)
-    close_enough(np.concatenate(acc['frames'][0]), np.concatenate(acc['frames'][1]), SYM_TOL * 1.5, 'frames', max_frac=0.5)
-    close_enough(np.concatenate(acc['pll'][0]), np.concatenate(acc['pll'][1]), 1e-3, 'pll', max_frac=0.5)
-    rms = float(np.sqrt(np.mean(np.abs(np.concatenate(acc['symbols'][0]) - np.concatenate(acc['symbols'][1])) ** 2)))
-    assert rms < 8e-3, rms
-    O = np.concatenate(outs_o); G = np.concatenate(outs_g)
-    # every frame the decoder converges on must be bit-exact (frames lost during acquisition are garbage on both sides:
-    # their bytes depend on LLRs that may differ in a few LUT cells, see the module docstring)
-    assert O.shape == G.shape and O.shape[0] >= nframes - 3 and len(decoded) == O.shape[0]
+        assert same_bits(rx.tap(0), dm.tap(0)), ('1-sps symbols', ncall)
+        assert same_bits(rx.tap(1), dm.tap(1)), ('aligned frames', ncall)
+        assert same_bits(rx.tap(2), dm.tap(2)), ('PLL output', ncall)
+        assert same_bits(rx.tap(3), dm.tap(3)), ('LLRs', ncall)
+        st_o, st_g = rx.tap(4), dm.stats()
+        assert len(st_o) == len(st_g)
+        for a_, b_ in zip(st_o, st_g):
+            assert np.float32(a_.best_match).view(np.uint32) == np.float32(b_.pl_sync_best_match).view(np.uint32)
+            assert np.float32(a_.fed_err).view(np.uint32) == np.float32(b_.coarse_freq_err).view(np.uint32)
+            assert (a_.detect_modcod, a_.detect_short, a_.detect_pilots) == (b_.detected_modcod, b_.detected_shortframes, b_.detected_pilots)
+            assert (a_.ldpc_trials, a_.bch_corr) == (b_.ldpc_trials, b_.bch_corrections)
+            decoded.append(a_.bch_corr >= 0)          # (a valid BCH codeword; the LDPC check may still have failed on parity bits)
+            maxed += a_.ldpc_trials < 0
+        nfr_seen += len(st_g)
+        assert o.shape == g.shape and np.array_equal(o, g), ('BBFRAMEs', ncall)
+        outs_g.append(g)
+        assert np.float32(dm.nco_freq()).view(np.uint32) == np.float32(rx.L.orc_s2rx_nco_freq(rx.h)).view(np.uint32)
+    G = np.concatenate(outs_g)
+    assert G.shape[0] >= nframes - 3 and len(decoded) == G.shape[0] == nfr_seen
     dec = np.array(decoded, bool)
     assert dec.sum() >= min_good, ('decodable frames', int(dec.sum()))
-    assert np.array_equal(O[dec], G[dec])
     sent = {bytes(b) for b in bb}
     assert all(bytes(x) in sent for x in G[dec])
-    assert abs(dm.nco_freq() - float(rx.L.orc_s2rx_nco_freq(rx.h))) < 2e-5
+    if modcod == 27 and esn0 < 20:
+        assert maxed >= nfr_seen - 2, ('config 5 stand-in is meant to run into the iteration limit', maxed, nfr_seen)
     dm.close()
 
 
 @pytest.mark.parametrize('chunk', [3001, 777, 65536])
 def test_front_end_is_bit_identical_without_nco_feedback(engine, chunk):
-    """fll_bw = 0 keeps the NCO at frequency 0 (cos 0 / sin 0 are exact everywhere), so AGC, NCO, Gardner, RRC,
-    decimator and PL sync involve no libm value: the GPU must then reproduce the oracle bit for bit, call by call,
-    for any chunking (odd sizes exercise the decimator phase and the delay lines across calls)."""
+    """fll_bw = 0 keeps the NCO at frequency 0: AGC, Gardner, RRC, decimator and PL sync alone, call by call, for any
+    chunking (odd sizes exercise the decimator phase and the delay lines across calls)."""
     modcod, short, pilots = 6, 1, 1
     iq, bb, _ = orc.transmit(modcod, short, pilots, nframes=5, seed=9, esn0_db=15.0, cfo=0.0, timing=0.37, phase0=0.1, lead_symbols=333)
     rx = orc.OracleRx(orc.default_cfg(modcod, short, pilots, fll_bw=0.0))
@@ -212,6 +178,11 @@ def test_demod_error_codes(engine, pkg):
     c = engine.default_cfg(11, True)     # short-frame 9/10 does not exist
     with pytest.raises(pkg.Dvbs2GpuError):
         engine.demod(c)
+    # configurations the buffers are not sized for are refused at creation (the timing loop's output rate is bounded by omega_rel_limit)
+    for kw in (dict(omega_rel_limit=0.2), dict(omega_rel_limit=-0.1), dict(symbolrate=0.0), dict(rrc_taps=0)):
+        with pytest.raises(pkg.Dvbs2GpuError) as e:
+            engine.demod(engine.default_cfg(14, **kw))
+        assert e.value.code == pkg.ERR_ARG, kw
 
 
 def test_pipelined_batch_delivers_the_same_frames_one_call_later(engine, pkg):

@@ -20,7 +20,7 @@ EXE = os.path.join(ROOT, 'tests', 'cpp', 'build', 'host_mirror')
 def host_mirror(pkg):
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
     cmd = ['g++', '-std=c++17', '-O1', '-Wall', '-Wextra', '-Werror', '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'cpp', 'host_mirror.cpp'),
-           '-o', EXE, '-L' + PKG_DIR, '-ldvbs2gpu', '-Wl,-rpath,' + PKG_DIR]
+           '-o', EXE, '-L' + PKG_DIR, '-ldvbs2gpu', '-Wl,-rpath,' + PKG_DIR, '-pthread']
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return EXE
@@ -68,6 +68,28 @@ def test_cpp_dvbs2demod_equals_ctypes_path(engine, host_mirror, tmp_path, modcod
     assert int(st['bytes']) == got.size and int(st['kbch']) == kb * 8 and int(st['detected_modcod']) == modcod
     assert (int(st['short']), int(st['pilots'])) == (short, pilots) and int(st['handler_calls']) >= 3
     assert out.splitlines()[1].split() == ['bad_modcod_throws=1', 'kbch_after=%d' % (kb * 8)]
+
+
+@pytest.mark.gpu
+def test_two_blocks_on_two_threads_share_one_context(engine, host_mirror, tmp_path):
+    """two plugin instances = two DVBS2Demod blocks, each on its own worker thread, both on the process-wide engine context of
+    dvbs2gpu_host.hpp (different MODCODs, many small process() calls racing each other): the context serialises whole calls, so each
+    block's output equals what it delivers when it runs alone"""
+    chunk = 4001
+    specs = [(4, 1, 0, 61), (14, 1, 0, 62)]
+    want = []
+    for k, (modcod, short, pilots, seed) in enumerate(specs):
+        iq, bb, _ = orc.transmit(modcod, short, pilots, nframes=14, seed=seed, esn0_db=15.0, cfo=2e-4, timing=0.3, phase0=0.2, lead_symbols=300)
+        iq.tofile(tmp_path / ('iq%d.cf32' % k))
+        dm = engine.demod(engine.default_cfg(modcod, bool(short), bool(pilots)))
+        want.append(np.concatenate([np.asarray(dm.process(iq[a:a + chunk])).reshape(-1) for a in range(0, iq.size, chunk)]))
+        dm.close()
+        assert want[-1].size >= 5 * bb.shape[1]
+    for rep in range(2):
+        rc, out, err = run(host_mirror, 's2x2', tmp_path / 'iq0.cf32', tmp_path / 'o0.bb', 4, 1, 0, tmp_path / 'iq1.cf32', tmp_path / 'o1.bb', 14, 1, 0, chunk)
+        assert rc == 0, err
+        for k in range(2):
+            assert np.array_equal(np.fromfile(tmp_path / ('o%d.bb' % k), np.uint8), want[k]), (rep, k)
 
 
 @pytest.mark.gpu
