@@ -165,7 +165,9 @@ static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, 
     int grid = ctx->num_cus * C->blocks_per_cu;
     if (grid > (nframes + fpb - 1) / fpb) grid = (nframes + fpb - 1) / fpb;
     size_t need = (size_t)grid * fpb * C->R * C->rec_dwords * sizeof(uint32_t);
-    if ((rc = ctx->ws_msg.ensure(need + 256))) return rc;   // + the dynamic work counter
+    need = (need + 255) & ~(size_t)255;
+    const size_t sgn_bytes = (size_t)grid * fpb * ldpc_sign_ws_bytes_per_slot();   // bit-packed signs for the syndrome check
+    if ((rc = ctx->ws_msg.ensure(need + 256 + sgn_bytes))) return rc;   // + the dynamic work counter + the sign scratch
     if (!d_trials) {
         if ((rc = ctx->ws_misc.ensure((size_t)nframes * 2 * sizeof(int32_t)))) return rc;
         d_trials = (int32_t*)ctx->ws_misc.p;
@@ -175,7 +177,8 @@ static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, 
         d_hard = (uint8_t*)ctx->ws_hard.p; hard_stride = f.K / 8;
     }
     HIP_TRY(ldpc_decode_launch(*C, d_llr, nframes, max_trials, force, d_hard, hard_stride, d_post, d_trials,
-                               (uint32_t*)ctx->ws_msg.p, grid, st, (unsigned int*)((char*)ctx->ws_msg.p + need)));
+                               (uint32_t*)ctx->ws_msg.p, grid, st, (unsigned int*)((char*)ctx->ws_msg.p + need),
+                               (uint32_t*)((char*)ctx->ws_msg.p + need + 256)));
     return 0;
 }
 }  // namespace s2

@@ -4,20 +4,22 @@
 // library under it (xdsopl-ldpc-pabr/layered_decoder.hh:23-133, algorithms.hh:206-277) -- bit-exact,
 // including the sequential row order (see ldpc_plan.h) and the int8 saturation rules.
 //
-// Mapping (one workgroup = one frame, persistent over the batch):
-//   * 384 threads; lane j < 360 owns row j of EVERY layer (a DVB-S2 layer = 360 rows, quasi-cyclic).
-//   * the N int8 posteriors of the frame live in LDS for the whole decode (64.8 KB normal frame ->
-//     2 frames per CU); information bits as [0,K), parity bits layer-major as K + 360*i + j.
-//     Row j of a layer reads byte 360*r + (j - s) mod 360 of each linked group: consecutive lanes ->
-//     consecutive bytes, conflict-free.
-//   * check->bit messages: one fixed-size record per row (REC dwords, 1 byte per link) in a per-workgroup
-//     global workspace.  Lane j re-reads only what lane j wrote, one coalesced vector load + store per
-//     row per iteration, prefetched one layer ahead; the workspace of all resident workgroups
-//     (<= 512 x ~260 KB) stays in L2 / Infinity Cache.
-//   * rows of a layer that share a bit are ordered by the plan's levels (barrier per level).
-// Arithmetic: int32 VALU emulating int8 saturating lanes.  Roofline: algorithmic bytes per frame =
-// iters*4*edges + N + K/8 against HBM 8 TB/s; real HBM traffic is ~N + K/8 per
-// frame because the state is on-chip -- the kernel is VALU/LDS-issue bound.
+// Mapping (one workgroup = TWO frames in lockstep, persistent over the batch; see ldpc_decode_kernel below):
+//   * 768 threads = 12 waves; threads [0,384) own frame slot 0, [384,768) slot 1; lane j < 360 of a slot owns row j of
+//     EVERY layer (a DVB-S2 layer = 360 rows, quasi-cyclic).
+//   * the N int8 posteriors of a frame live in LDS for the whole decode (64.8 KB per normal frame); information bits as
+//     [0,K), parity bits layer-major as K + 360*i + j.  Row j of a layer reads byte 360*r + (j - s) mod 360 of each linked
+//     group: consecutive lanes -> consecutive bytes, conflict-free.
+//   * check->bit messages: one fixed-size record per row (REC dwords, 1 byte per link) in a per-slot global workspace.
+//     Lane j re-reads only what lane j wrote, one coalesced vector load + store per row per iteration, prefetched one
+//     layer ahead; the workspace of all resident workgroups (512 slots x ~260 KB) stays in the Infinity Cache.
+//   * rows of a layer that share a bit follow the plan (ldpc_plan.h): chain walk for a single shared pair, levels otherwise.
+//   * arithmetic: packed int16 ("Q8", two links per VALU instruction) with the int8 saturation rules of the reference's
+//     SIMD lanes; the syndrome check before an iteration works on bit-packed sign vectors (quasi-cyclic: a layer's 360
+//     syndromes are XORs of cyclic shifts of 360-bit groups).
+// Roofline: algorithmic bytes per frame = iters*4*edges + N + K/8 against HBM 8 TB/s is the NOMINAL figure; real
+// HBM traffic is ~N + K/8 per frame because the state is on-chip -- the kernel is bound by VALU issue and by the latency of
+// its serial sections (profiles/).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "ldpc_plan.h"
@@ -37,6 +39,7 @@ struct LdpcKernelArgs {
     int pent_base;         // offset of the pair-format link table inside ents[] (ldpc_plan.h)
     int max_trials, force;
     int hard_stride;
+    uint32_t* sgn_ws;           // [gridDim.x * slots][SGN_WS_DWORDS]: bit-packed posterior signs for the syndrome check
     unsigned int* work_ctr;     // optional: frames beyond the first gridDim.x*2 are claimed dynamically (workgroups slowed by
                                 // co-resident kernels of the pipelined mode then simply take fewer frames)
     unsigned long long* prof;   // development aid (-DLDPC_PROF builds only): per-wave phase cycle sums of workgroup 0
@@ -478,41 +481,75 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
 
 // LDPCDecoder::bad (layered_decoder.hh:28-45): true if any row is unsatisfied.  A row is bad when the sign product of its links'
 // posteriors is negative or when one of them is 0.  Every posterior belongs to at least one row (each parity bit to its own row), so the
-// second condition over all rows is "some posterior of the frame is 0": a dword scan shared by the slot's 384 threads instead of a compare
-// per link.  The sign products use the packed pair addresses of the sweep (two table links per address computation, ldpc_plan.h).
-template <int MAXDEG, bool IRREG>
-__device__ __forceinline__ bool rows_bad(const int8_t* __restrict__ post, const LdpcKernelArgs& A, const LdpcLayerDesc* __restrict__ layers,
-                                         const uint32_t* __restrict__ ents_all, int j, bool lane_ok, int tps) {
-    const uint8_t* __restrict__ pu = reinterpret_cast<const uint8_t*>(post);
+// second condition over all rows is "some posterior of the frame is 0": a dword scan shared by the slot's 384 threads.  The first one is
+// evaluated on BIT VECTORS: the code is quasi-cyclic, so the 360 sign products of layer i are
+//     Y_i = P_i ^ P'_i ^ XOR_k rot(S_{r_k}, sp_k)            (S_r: signs of information group r, P_i: of parity group i)
+// -- XORs of cyclic shifts of 360-bit groups: ~15 shifted 64-bit fetches per (layer, 64-row word) instead of 15 byte gathers per row
+// (227 k LDS byte reads per check before).  Step 1 (sign_pack): every thread turns 8 posteriors into one sign byte (and scans them for
+// zeros); a group is stored as 360 bits followed by a copy of its first 64, so a shifted fetch never wraps; the 10 KB per frame go to a
+// per-slot global scratch (L2-resident; LDS has no room for them beside two frames and the co-resident front-end kernels).  Step 2
+// (syndromes_bad), after a workgroup barrier: lane t takes (layer, word) = (t / 6, t % 6).
+constexpr int SGN_GROUP_DW = 14;                                  // 56 bytes: 360 bits + the first 64 again (424), padded to dwords
+constexpr int SGN_WS_DWORDS = 180 * SGN_GROUP_DW + 16;            // per slot (N/360 <= 180 groups)
+
+__device__ __forceinline__ uint32_t sign_pack(const int8_t* __restrict__ post, int N, uint8_t* __restrict__ sg, int j, int tps) {
+    const uint2* __restrict__ p8 = reinterpret_cast<const uint2*>(post);
     uint32_t z = 0;
-    const uint32_t* __restrict__ pw4 = reinterpret_cast<const uint32_t*>(post);
-    for (int i = j; i < A.N / 4; i += tps) {
-        const uint32_t v = pw4[i];
-        z |= (v - 0x01010101u) & ~v;          // bit 7 of a byte set <=> that byte is 0 (or a borrow reached it from a zero byte below: still "a zero")
+    for (int idx = j; idx < N / 8; idx += tps) {
+        const uint2 v = p8[idx];
+        z |= ((v.x - 0x01010101u) & ~v.x) | ((v.y - 0x01010101u) & ~v.y);   // bit 7 of a byte set <=> that byte is 0 (or a borrow from a zero byte below: still "a zero")
+        // sign bits 7, 15, 23, 31 of a dword -> one nibble, LSB = lowest byte (the multiply adds four shifted copies; no two terms collide)
+        const uint32_t lo = ((((v.x >> 7) & 0x01010101u) * 0x01020408u) >> 24);
+        const uint32_t hi = ((((v.y >> 7) & 0x01010101u) * 0x01020408u) >> 24);
+        const uint32_t sb = lo | (hi << 4);
+        const int g = (int)(((uint32_t)idx * 1457u) >> 16);                  // idx / 45 for idx < 9000
+        const int o = idx - 45 * g;
+        uint8_t* __restrict__ d = sg + (SGN_GROUP_DW * 4) * g + o;
+        d[0] = (uint8_t)sb;
+        if (o < 8) d[45] = (uint8_t)sb;                                       // cyclic extension: bits 360..423 = bits 0..63
     }
-    uint32_t sxacc = 0;
-    if (lane_ok) {
-        constexpr int NPW = 2 * ((MAXDEG + 1) / 2);
-        const uint32_t JJ = (uint32_t)j * 0x10001u;
-        for (int layer = 0; layer < A.q; ++layer) {
-            const uint32_t* __restrict__ pe = ents_all + A.pent_base + layer * NPW;
-            const int deg = IRREG ? (int)(layers[layer].deg & 0xffffu) : MAXDEG;
-            const int own = A.K + 360 * layer + j;
-            uint32_t sx = pu[own];
-            if (layer | j) sx ^= pu[layer ? own - 360 : A.K + 360 * (A.q - 1) + j - 1];
-#pragma unroll 2
-            for (int p = 0; p < (MAXDEG + 1) / 2; ++p) {
-                u16x2 T = __builtin_bit_cast(u16x2, JJ) + __builtin_bit_cast(u16x2, pe[2 * p]);
-                T = __builtin_elementwise_min(T, (u16x2)(T - (u16x2){360, 360}));
-                const uint32_t AD = __builtin_bit_cast(uint32_t, (u16x2)(T + __builtin_bit_cast(u16x2, pe[2 * p + 1])));
-                const uint32_t x0 = pu[AD & 0xffffu], x1 = pu[AD >> 16];
-                if (!IRREG || 2 * p < deg) sx ^= x0;
-                if (2 * p + 1 < MAXDEG && (!IRREG || 2 * p + 1 < deg)) sx ^= x1;
-            }
-            sxacc |= sx;
+    return z & 0x80808080u;
+}
+// 64 sign bits of group g starting at bit a (0 <= a < 360), cyclic
+__device__ __forceinline__ unsigned long long sign_fetch(const uint32_t* __restrict__ S, int g, int a) {
+    const uint32_t* __restrict__ p = S + SGN_GROUP_DW * g + (a >> 5);
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+    const uint32_t sh = (uint32_t)a & 31u;
+    const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int MAXDEG, bool IRREG>
+__device__ __forceinline__ bool syndromes_bad(const LdpcKernelArgs& A, const LdpcLayerDesc* __restrict__ layers, const uint32_t* __restrict__ ents_all,
+                                              const uint32_t* __restrict__ S, int j, int tps) {
+    const int pg0 = A.K / 360;                           // first parity group
+    const int ntask = A.q * 6;
+    bool bad = false;
+    for (int t = j; t < ntask; t += tps) {
+        const int layer = (int)(((uint32_t)t * 10923u) >> 16), w = t - 6 * layer;     // t / 6 for t < 16384
+        const int a0 = 64 * w;
+        unsigned long long acc = sign_fetch(S, pg0 + layer, a0);
+        if (layer) acc ^= sign_fetch(S, pg0 + layer - 1, a0);
+        else {                                           // row (0, j) links parity bit (q-1, j-1); row (0, 0) has no such link
+            unsigned long long v = sign_fetch(S, pg0 + A.q - 1, a0 ? a0 - 1 : 359);
+            if (w == 0) v &= ~1ull;
+            acc ^= v;
         }
+        const uint32_t eoff = layers[layer].ent_off;
+        const int deg = IRREG ? (int)(layers[layer].deg & 0xffffu) : MAXDEG;
+        const uint32_t* __restrict__ e = ents_all + eoff;
+#pragma unroll
+        for (int k = 0; k < MAXDEG; ++k) {
+            if (!IRREG || k < deg) {
+                const uint32_t en = e[k];
+                int a = a0 + (int)(en & 0xffffu);
+                a = a >= 360 ? a - 360 : a;
+                acc ^= sign_fetch(S, (int)(en >> 16), a);
+            }
+        }
+        if (w == 5) acc &= (1ull << 40) - 1;             // rows 320..359
+        bad |= acc != 0;
     }
-    return ((z & 0x80808080u) | (sxacc & 0x80u)) != 0;
+    return bad;
 }
 
 // TWO FRAMES PER WORKGROUP, in lockstep: 768 threads = 12 waves; threads [0,384) decode frame slot 0, [384,768)
@@ -540,6 +577,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
     const int npad = (N + 15) & ~15;
     int8_t* __restrict__ post = post_all + (size_t)fs * npad;
     uint32_t* __restrict__ msg = A.msg_ws + ((size_t)blockIdx.x * LDPC_FPB + fs) * (size_t)R * REC;
+    uint32_t* __restrict__ sgn = A.sgn_ws + ((size_t)blockIdx.x * LDPC_FPB + fs) * SGN_WS_DWORDS;
     uint32_t* __restrict__ cw = s_cw[fs];
     uint8_t* __restrict__ cres = s_cres[fs];
 
@@ -561,12 +599,17 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
         }
         lds_barrier();
 
-        int it = 0, ret = 0;
+        int it = 0, ret = 0, trip = 0;
         bool done = !valid;
         while (true) {
             const bool check = !done && (!A.force || it == A.max_trials);
+            // (uniform over the workgroup: both slots run the same trips; in forced mode only the trip after the last sweep checks)
+            const bool any_check = !A.force || trip == A.max_trials;
+            uint32_t zflag = 0;
+            if (check && valid) zflag = sign_pack(post, N, reinterpret_cast<uint8_t*>(sgn), j, LDPC_TPS);
+            if (any_check) __syncthreads();              // the sign bytes went to global memory: full barrier (drains vmcnt), once per iteration
             if (check) {
-                bool bad = valid ? rows_bad<MAXDEG, IRREG>(post, A, layers, ents, j, lane_ok, LDPC_TPS) : false;
+                bool bad = valid ? (zflag != 0 || syndromes_bad<MAXDEG, IRREG>(A, layers, ents, sgn, j, LDPC_TPS)) : false;
                 unsigned long long b = __ballot(bad);
                 if ((j & 63) == 0) s_flag[fs][j >> 6] = (b != 0);
             }
@@ -617,6 +660,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
                 PROF_ADD(3, t_e, t_f);
             }
             if (!done) ++it;
+            ++trip;
         }
 
         // ---- outputs
@@ -704,6 +748,7 @@ static int occupancy_ldpc(int N) {
     }
 
 int ldpc_frames_per_block() { return LDPC_FPB; }
+size_t ldpc_sign_ws_bytes_per_slot() { return (size_t)SGN_WS_DWORDS * sizeof(uint32_t); }
 
 int ldpc_blocks_per_cu(int max_deg, int irregular, int N) {
     LDPC_DISPATCH(occupancy_ldpc, N)
@@ -714,9 +759,10 @@ unsigned long long* g_ldpc_prof = nullptr;   // set by tools/ldpc_prof.py throug
 
 hipError_t ldpc_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nframes, int max_trials, int force,
                               uint8_t* hard, int hard_stride, int8_t* post, int32_t* trials, uint32_t* msg_ws, int grid,
-                              hipStream_t stream, unsigned int* work_ctr) {
+                              hipStream_t stream, unsigned int* work_ctr, uint32_t* sgn_ws) {
     LdpcKernelArgs A;
     A.work_ctr = work_ctr;
+    A.sgn_ws = sgn_ws;
     if (work_ctr) {
         hipError_t e = hipMemsetAsync(work_ctr, 0, sizeof(unsigned int), stream);
         if (e != hipSuccess) return e;

@@ -46,7 +46,8 @@ def test_fll_and_costas_active_bit_exact(engine, pkg, costas_bw):
     """FLL active (the band-edge FIRs sit in the loop: systolic array over the lanes), with and without the Costas loop: the
     rotations use the shared sin/cos definition -> symbols and loop state equal the oracle's, chunked arbitrarily"""
     iq, _ = od.dvbs_iq(0, 24576, seed=2, esn0_db=12.0, cfo=2e-3, timing=0.2)
-    chunks = [5000, 16384, 777, iq.size - 5000 - 16384 - 777]
+    chunks = [5000, 16384, 777, 16384, iq.size - 5000 - 16384 - 777 - 16384]
+    assert 0 < chunks[-1] <= 16384
     okw = {} if costas_bw is None else {'costas_bw': costas_bw}
     gkw = {} if costas_bw is None else {'loop_bw': costas_bw}
     exp, rx = _oracle_chain(iq, chunks, **okw)
@@ -60,7 +61,7 @@ def test_fll_and_costas_active_bit_exact(engine, pkg, costas_bw):
     assert got.size == exp.size and np.array_equal(got.view(np.uint32), exp.view(np.uint32)), float(np.abs(got[:min(got.size, exp.size)] - exp[:min(got.size, exp.size)]).max())
     st, es = bank.loop_state(), rx.state()
     assert np.array_equal(st.view(np.uint32), es.view(np.uint32)), (st, es)
-    assert abs(st[2] - 2e-3) < 5e-4                                          # and the FLL did find the carrier offset
+    assert abs(abs(st[2]) - 2e-3) < 5e-4                                     # and the FLL did find the carrier offset (loop frequency = -offset)
     bank.close()
 
 
