@@ -1,22 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: Msymbols/s of the DVB-S2 demod + FEC hot path on MI355X.
 
-Workload (BASELINE.json configs[2], the one the metric is quoted on): DVB-S2 8PSK 3/4 normal FECFRAME
-(MODCOD 14, PLFRAME 21 690 symbols, LDPC table B7, BCH t=12), pilots off, LDPC forced to exactly 50 layered
-iterations per frame (no early exit).  `--streams` independent transponder streams per GPU, each a
-continuous synthetic 27.5 Msym/s-class signal (2 samples/symbol complex64 IQ, RRC 0.35, timing offset
-0.3 sample, AWGN Es/N0 14 dB) of `--frames` PLFRAMEs per step, resident in HBM when the timed region
-starts.  One step = one dvbs2gpu_demod_process_batch call = the whole hot path
+Workload (BASELINE.json configs[2], the one the metric is quoted on): DVB-S2 8PSK 3/4 normal FECFRAME (MODCOD 14, PLFRAME
+21 690 symbols, LDPC table B7, BCH t=12), pilots off, LDPC forced to exactly 50 layered iterations per frame (no early exit).
+`--streams` independent transponder streams per GPU, each a continuous synthetic 27.5 Msym/s-class signal built by the
+repo's own transmitter under the conditions of SURVEY 8(d): complex64 IQ at 2 samples/symbol, RRC 0.35, carrier offset
+1e-3 rad/sample, timing offset 0.3 sample, sampling-clock error ~10 ppm, AWGN.  `--distinct` (64) different signal blocks
+exist; every stream owns a PRIVATE copy in HBM, cyclically shifted by a stream-specific amount, so the streams' loops run in
+different phases and the IQ (11 GB for 4096 streams x 8 frames) cannot be served from the Infinity Cache.  One step = one
+dvbs2gpu_demod_process_batch call of `--frames` (8) PLFRAMEs per stream = the whole hot path
   IQ -> AGC -> NCO -> Gardner -> RRC -> /2 -> PL sync -> FED/PLL/PLHDR -> soft demap + de-interleave
      -> LDPC (50 it) -> BCH -> BB descramble -> BBFRAMEs
-over every stream; the streams keep their loop state from step to step (the IQ block is periodic, so the
-signal is seamless).  value = PLFRAME symbols consumed per second, all GPUs.
+over every stream; the streams keep their loop state from step to step (the blocks are periodic, so the signals are
+seamless).  value = PLFRAME symbols consumed per second, all GPUs.  No candidate blocks are discarded: the fraction of the
+delivered frames that equal a transmitted BBFRAME is REPORTED (the reference's decision-directed loops, which the engine
+reproduces bit for bit, lose frames at low SNR), and every delivered frame of every stream is compared on the device.
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --config mixed64 [--gpus N]            BASELINE config 4 (64 mixed-MODCOD transponders, strong scaling)
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the LDPC decoder, HIP-event timed in
-here on the stream it is launched on) and `cpu_baseline` (rank 0, N=1 only: the reference's own FEC code
-compiled into oracle/_ref when that build travelled, else the oracle port, plus the oracle front end).
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = the LDPC decoder: hipEvent pairs around every launch INSIDE
+the timed steps, on the stream it runs on, plus a stand-alone launch), `cpu_baseline` (rank 0, N=1: the reference's own FEC code
+compiled into oracle/_ref when that build travelled, else the oracle port, plus the oracle front end) and `secondary` (configs
+2, 5, D and the mixed-MODCOD batch).
 """
 import argparse
 import json
@@ -27,132 +33,232 @@ import time
 
 import numpy as np
 
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '12')   # mixed batches run one HIP stream per configuration group (default: 4 hardware queues)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 MODCOD = 14          # 8PSK 3/4
 RATE, SHORT = 6, 0
-WORKLOAD = ('DVB-S2 8PSK 3/4 normal FECFRAME (MODCOD 14), pilots off, 27.5 Msym/s-class streams at 2 sps, '
-            'Es/N0 14 dB, 50 forced LDPC iterations, IQ in -> BBFRAMEs out')
-PILOTS = 0           # (tools/config_sweep.py re-runs main() with other MODCOD / RATE / SHORT / PILOTS / ESN0_DB values)
+PILOTS = 0
 ITERS = 50
-ESN0_DB = 14.0
+# SURVEY 8(d) asks for threshold + 1 dB (9 dB for 8PSK 3/4).  The reference receiver the engine reproduces (decision-directed PLL on a
+# 256x256 LUT, AGC set point vs demapper prescale) delivers NO frame at 9 dB with a 1e-3 carrier offset -- the CPU oracle shows
+# the same -- and all of them from 11 dB on: 11 dB is the lowest level at which the comparison with the transmitted frames means
+# something.  The decoder's work does not depend on it (50 forced iterations).
+ESN0_DB = 11.0
+CFO = 1e-3           # rad/sample
+PPM = 10.0           # sampling-clock error
 HBM_PEAK_GBS = 8000.0
-DISTINCT = 4         # distinct periodic IQ blocks; stream s replays block s % DISTINCT
-PREROLL = 10         # untimed frames per stream before the warm-up: loop acquisition (AGC, Gardner, PL sync, PLL)
+DISTINCT = 64
+PREROLL_FRAMES = 24  # untimed frames per stream before the warm-up: loop acquisition (AGC, Gardner, PL sync, PLL)
+WORKLOAD = ('DVB-S2 8PSK 3/4 normal FECFRAME (MODCOD 14), pilots off, 27.5 Msym/s-class streams at 2 sps, carrier offset 1e-3 rad/sample, '
+            'clock error ~10 ppm, Es/N0 %.0f dB, 50 forced LDPC iterations, IQ in -> BBFRAMEs out' % ESN0_DB)
 
 
-def make_blocks(frames, seed, eng=None, pkg=None):
-    """periodic IQ blocks built by the repo's own transmitter (oracle/s2chain.cpp, bench/test infrastructure).
-    The reference's decision-directed PLL can sit in a pi/4 false lock for many frames on 8PSK (the oracle and
-    the engine agree on that frame by frame), so candidate blocks are pre-rolled through the engine and only blocks on
-    which the demodulator has converged (delivers the transmitted BBFRAMEs) are used for the timed streams."""
+def make_block(modcod, short, pilots, frames, seed, esn0_db, cfo=CFO, ppm=PPM):
+    """one periodic IQ block from the repo's transmitter (oracle/s2chain.cpp, bench/test infrastructure): `frames` PLFRAMEs, resampled so
+    that the sampling clock is ~ppm off, carrier offset rounded so that the block repeats seamlessly.  -> (iq, bbframes)"""
     import orc
-    cands = []
-    ncand = 4 * DISTINCT
-    for b in range(ncand):
-        iq, bb, _ = orc.transmit(MODCOD, SHORT, PILOTS, nframes=frames, seed=0xD5B2 + 64 * seed + b, esn0_db=ESN0_DB, cfo=0.0, timing=0.3,
-                                 phase0=0.1, lead_symbols=0, circular=1)
-        cands.append((iq, {bytes(x) for x in bb}))
-    if eng is None:
-        return [c[0] for c in cands[:DISTINCT]], [c[1] for c in cands[:DISTINCT]]
+    mp = orc.modcod_params(modcod, short, pilots)
+    ns = frames * mp['plframe']
+    nsamp = 2 * ns + (int(round(2 * ns * ppm * 1e-6)) if ppm else 0)
+    c = 2 * np.pi * round(cfo * nsamp / (2 * np.pi)) / nsamp if cfo else 0.0
+    iq, bb, _ = orc.transmit(modcod, short, pilots, nframes=frames, seed=seed, esn0_db=esn0_db, cfo=c, timing=0.3, phase0=0.1, lead_symbols=0,
+                             circular=1, nsamples=nsamp if nsamp != 2 * ns else 0)
+    return iq, bb
+
+
+class FrameChecker:
+    """device-side comparison of every delivered BBFRAME with the transmitted ones of its stream's block: a 64-bit hash finds the
+    candidate, then the bytes are compared in full"""
+
+    def __init__(self, torch, dev, sent, block_of_stream, kb, cap_frames):
+        self.t, self.dev, self.kb, self.cap = torch, dev, kb, cap_frames
+        g = torch.Generator(device='cpu'); g.manual_seed(1234)
+        self.w = (torch.randint(1, 2 ** 62, (kb,), generator=g, dtype=torch.int64) | 1).to(dev)
+        self.sent = torch.from_numpy(np.stack(sent)).to(dev)                      # [D, F, kb]
+        self.hs = self._hash(self.sent)                                           # [D, F]
+        self.block = torch.as_tensor(block_of_stream, dtype=torch.int64, device=dev)
+
+    def _hash(self, frames):
+        out = []
+        for a in range(0, frames.shape[0], 256):                                  # (chunks bound the int64 temporary)
+            out.append((frames[a:a + 256].to(self.t.int64) * self.w).sum(-1))
+        return self.t.cat(out)
+
+    def check(self, out_all, nbytes):
+        """out_all uint8 [S, cap*kb]; nbytes list -> dict(delivered, equal, out_of_order)"""
+        t = self.t
+        S = out_all.shape[0]
+        fr = out_all.view(S, self.cap, self.kb)
+        nfr = t.as_tensor(nbytes, dtype=t.int64, device=self.dev) // self.kb
+        valid = t.arange(self.cap, device=self.dev)[None, :] < nfr[:, None]
+        h = self._hash(fr)                                                        # [S, cap]
+        hs = self.hs[self.block]                                                  # [S, F]
+        eq = h[:, :, None] == hs[:, None, :]
+        idx = eq.to(t.int8).argmax(-1)                                            # [S, cap]
+        same = t.zeros_like(valid)
+        for a in range(0, S, 256):
+            exp = self.sent[self.block[a:a + 256, None], idx[a:a + 256]]          # [256, cap, kb]
+            same[a:a + 256] = (exp == fr[a:a + 256]).all(-1)
+        good = same & eq.any(-1) & valid
+        F = hs.shape[1]
+        both = good[:, 1:] & good[:, :-1]
+        ooo = both & (idx[:, 1:] != (idx[:, :-1] + 1) % F)
+        return dict(delivered=int(valid.sum().item()), equal=int(good.sum().item()), out_of_order=int(ooo.sum().item()))
+
+
+class S2Run:
+    """S streams of one configuration: private IQ copies, demodulator handles, output buffers, checker"""
+
+    def __init__(self, eng, pkg, dev, modcod, short, pilots, esn0_db, S, F, distinct, seed, iters=ITERS, force=True):
+        import torch
+        self.eng, self.dev, self.S, self.F = eng, dev, S, F
+        info = pkg.modcod_info(modcod, bool(short), bool(pilots))
+        self.info, self.sym, self.kb = info, info['plframe_symbols'], info['kbch'] // 8
+        D = min(distinct, S)
+        blocks = [make_block(modcod, short, pilots, F, 0xD5B2 + 1000 * seed + b, esn0_db) for b in range(D)]
+        self.blocks_host = [b[0] for b in blocks]
+        nsamp = blocks[0][0].size
+        self.nsamp = nsamp
+        d_blocks = [torch.from_numpy(b[0]).to(dev) for b in blocks]
+        # private, cyclically shifted copy per stream (even shifts keep the 2-sps phase; the shift differs from stream to stream)
+        self.iq = torch.empty((S, nsamp), dtype=torch.complex64, device=dev)
+        for s in range(S):
+            self.iq[s] = torch.roll(d_blocks[s % D], 2 * ((s // D) * 7919 % (nsamp // 2)))
+        del d_blocks
+        cfg = eng.default_cfg(modcod, bool(short), bool(pilots), force_ldpc_iters=iters if force else 0, max_ldpc_trials=iters)
+        self.demods = [eng.demod(cfg, max_samples=nsamp) for _ in range(S)]
+        self.tin = [self.iq[s] for s in range(S)]
+        self.cap = F + 2
+        self.out = torch.zeros((S, self.cap * self.kb), dtype=torch.uint8, device=dev)
+        self.tout = [self.out[s] for s in range(S)]
+        self.empty = [torch.empty(0, dtype=torch.complex64, device=dev) for _ in range(S)]
+        self.checker = FrameChecker(torch, dev, [b[1] for b in blocks], [s % D for s in range(S)], self.kb, self.cap)
+
+    def step(self):
+        return self.eng.process_batch(self.demods, self.tin, self.tout)
+
+    def flush(self):
+        return self.eng.process_batch(self.demods, self.empty, self.tout)
+
+    def check(self, nb):
+        return self.checker.check(self.out, nb)
+
+    def close(self):
+        for d in self.demods:
+            d.close()
+        self.demods = []
+        self.iq = self.out = None
+
+
+def time_steps(run, steps, warmup, barrier, pipelined):
+    """preroll + warm-up (untimed), then `steps` timed steps between barriers; verifies the last timed step and the flush"""
     import torch
-    info = pkg.modcod_info(MODCOD, bool(SHORT), bool(PILOTS))
-    kb = info['kbch'] // 8
-    cfg = eng.default_cfg(MODCOD, bool(SHORT), bool(PILOTS), force_ldpc_iters=0)
-    demods = [eng.demod(cfg, max_samples=cands[0][0].size) for _ in range(ncand)]
-    tin = [torch.from_numpy(c[0]).cuda() for c in cands]
-    tout = [torch.zeros((frames + 2) * kb, dtype=torch.uint8, device='cuda') for _ in range(ncand)]
-    good = [0] * ncand
-    for step in range(PREROLL):
-        nb = eng.process_batch(demods, tin, tout)
-        for i in range(ncand):
-            got = tout[i][:nb[i]].cpu().numpy().reshape(-1, kb)
-            ok = nb[i] == frames * kb and all(bytes(x) in cands[i][1] for x in got)
-            good[i] = good[i] + 1 if ok else 0
-    for d in demods:
-        d.close()
-    keep = [i for i in range(ncand) if good[i] >= 3][:DISTINCT]
-    if not keep:
-        raise RuntimeError('none of %d candidate blocks converged in %d frames' % (ncand, PREROLL))
-    while len(keep) < DISTINCT:        # (never seen: 5..10 of 12 converge for the seeds of ranks 0..7) reuse what converged
-        keep.append(keep[len(keep) % len(set(keep))])
-    return [cands[i][0] for i in keep], [cands[i][1] for i in keep]
+    eng = run.eng
+    eng.set_pipelined(pipelined)
+    for _ in range(max(1, -(-PREROLL_FRAMES // run.F))):
+        run.step()
+    for _ in range(warmup):
+        run.step()
+    eng.stage_times()                      # reset the per-stage sums
+    barrier()
+    t0 = time.perf_counter()
+    nb = None
+    for _ in range(steps):
+        nb = run.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    stages = eng.stage_times()
+    acc = run.check(nb)
+    if pipelined:
+        nb2 = run.flush()                  # the frames of the last timed step (delivered one call later)
+        a2 = run.check(nb2)
+        acc = {k: acc[k] + a2[k] for k in acc}
+        eng.set_pipelined(False)
+    return dt, stages, acc
 
 
-def single_transponder(eng, pkg, nseg=512, own=8, warm=8, calls=3):
-    """side measurement (not `value`): ONE continuous 8PSK 3/4 transponder through the segment receiver (dvbs2gpu_segrx_*): its IQ is
-    cut into overlapping segments that run as independent streams and are stitched back in order -- the answer to "a stream's loops are
-    serial" for a single 27.5 Msym/s carrier.  LDPC with early exit (this is a receive path, not the forced-iteration stress)."""
+def ldpc_alone(eng, info, rate, short, nfr, dev, iters=ITERS):
+    """the decoder alone at the batch size of one step: forced mode and the normal mode on noise that never converges"""
     import torch
-    import orc
-    period = 16
-    info = pkg.modcod_info(MODCOD, bool(SHORT), bool(PILOTS))
-    kb, sym = info['kbch'] // 8, info['plframe_symbols']
-    iq, bb, _ = orc.transmit(MODCOD, SHORT, PILOTS, nframes=period, seed=5, esn0_db=16.0, cfo=1e-4, timing=0.3, phase0=0.2, lead_symbols=0, circular=1)
-    index = {bytes(b): k for k, b in enumerate(bb)}
-    rx = pkg.SegmentReceiver(eng, eng.default_cfg(MODCOD, bool(SHORT), bool(PILOTS)), nseg, own, warm)
-    chunk = torch.from_numpy(iq).cuda().repeat(rx.chunk_samples // iq.size)
-    out = torch.zeros((nseg * own + warm + 8) * kb, dtype=torch.uint8, device='cuda')
-    seq, times = [], []
-    for _ in range(calls):
+    llr = torch.randint(-40, 41, (nfr, info['ldpc_n']), dtype=torch.int8, device=dev)
+    hard = torch.empty((nfr, info['ldpc_k'] // 8), dtype=torch.uint8, device=dev)
+    tri = torch.empty((nfr,), dtype=torch.int32, device=dev)
+    res = {}
+    for name, force in (('forced', 1), ('normal', 0)):
+        def go():
+            eng._check(eng.lib.dvbs2gpu_ldpc_decode_batch(eng.h, rate, short, llr.data_ptr(), nfr, iters, force, hard.data_ptr(), None, tri.data_ptr(), eng._stream()))
+        go()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        nbytes = rx.process(chunk, out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        go()
+        e1.record()
         torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
-        seq += [index.get(bytes(x), -1) for x in out[:nbytes].cpu().numpy().reshape(-1, kb)]
-    rx.close()
-    good = [k for k in seq if k >= 0]
-    steps = [(b - a) % period for a, b in zip(good, good[1:])]
-    dt = min(times[1:])
-    return {'value': round(nseg * own * sym / dt / 1e6, 1), 'unit': 'Msymbols/s of ONE continuous stream', 'ms_per_call': round(dt * 1e3, 1),
-            'segments': nseg, 'own_frames': own, 'warmup_frames': warm, 'chunk_symbols': nseg * own * sym,
-            'frames_returned': len(seq), 'frames_not_transmitted_ones': len(seq) - len(good), 'frames_out_of_sequence': sum(1 for s in steps if s != 1),
-            'realtime_factor_at_27.5_Msym_s': round(nseg * own * sym / dt / 27.5e6, 2)}
+        res[name] = e0.elapsed_time(e1)
+        res[name + '_all_ran'] = bool(((tri == -1) | (tri == iters)).all().item())
+    return res
 
 
-def cpu_baseline(frames_block, budget_s=10.0):
-    """CPU path on this box's host cores.  FEC: the reference's own code (oracle/_ref: LDPC with 16 frames in the
-    16 int8 SSE4.1 lanes of one call, 50 iterations on noise LLRs = never converges = the sweeps of the forced GPU
-    run plus the reference's syndrome check before every iteration, which the forced GPU mode evaluates once -- see
-    roofline.kernel_ms_normal_mode_same_iterations for the GPU doing the same --, + BCH + descrambler) when it travelled, else the oracle's scalar port.  Front end: the oracle restatement
-    (the reference's float blocks need SDR++/VOLK, not buildable here).  Both legs run on all cores; the
-    per-symbol times add."""
+def cpu_info():
+    model, phys = None, None
+    try:
+        cores = set()
+        phys_id = core_id = None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name') and model is None:
+                model = line.split(':', 1)[1].strip()
+            elif line.startswith('physical id'):
+                phys_id = line.split(':', 1)[1].strip()
+            elif line.startswith('core id'):
+                core_id = line.split(':', 1)[1].strip()
+                cores.add((phys_id, core_id))
+        phys = len(cores) or None
+    except OSError:
+        pass
+    return model, phys
+
+
+def cpu_baseline(block_iq, budget_s=12.0):
+    """CPU path on this box's host cores.  FEC: the reference's own code (oracle/_ref) the way its library was designed to be used --
+    a PERSISTENT decoder object per thread (tables built once), 16 frames in the 16 int8 SSE4.1 lanes of one call, 50 iterations on
+    noise LLRs (never converges: the sweeps of the forced GPU run plus the reference's syndrome check before every iteration), then
+    per frame the hard-decision repack, BCH and descrambler.  Without oracle/_ref: the oracle's scalar port.  Front end: the oracle
+    restatement (the reference's float blocks need SDR++/VOLK, not buildable here).  Both legs run on all logical CPUs; the per-symbol
+    times add."""
+    import ctypes as C
     import orc
     p = orc.fec_params(RATE, SHORT)
     sym_per_frame = orc.modcod_params(MODCOD, SHORT, PILOTS)['plframe']
-    ncores = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
+    model, phys = cpu_info()
     R = orc.ref()
     rng = np.random.default_rng(1)
 
-    def run_threads(fn):
-        counts = [0] * ncores
-        stop = time.time() + budget_s / 2
+    def run_threads(fn, seconds):
+        counts = [0] * ncpu
+        stop = time.time() + seconds
 
         def worker(i):
             while time.time() < stop:
                 counts[i] += fn(i)
         t0 = time.time()
-        th = [threading.Thread(target=worker, args=(i,)) for i in range(ncores)]
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(ncpu)]
         [t.start() for t in th]
         [t.join() for t in th]
         return sum(counts), time.time() - t0
 
-    # ---- FEC leg
-    if R is not None:
+    flags = None
+    if R is not None and hasattr(R, 'ref_fec16_create'):
         kind = 'reference'
-        noise = rng.integers(-40, 41, size=(16, p['N'])).astype(np.int8)
+        flags = R.ref_build_flags().decode()
+        lanes = np.ascontiguousarray(rng.integers(-40, 41, size=(p['N'], 16)).astype(np.int8))
+        objs = [C.c_void_p(R.ref_fec16_create(RATE, SHORT)) for _ in range(ncpu)]
 
         def fec(i):
-            b = noise.copy()
-            fr = np.zeros(p['K'] // 8, np.uint8)
-            R.ref_ldpc_decode_simd16(RATE, SHORT, b, ITERS, 1)
-            for f in range(16):
-                orc.lib().orc_hard_pack(b[f], p['K'], fr)
-                R.ref_bch_decode(RATE, SHORT, fr)
-                R.ref_bb_descramble(RATE, SHORT, fr)
+            R.ref_fec16_run(objs[i], lanes.ctypes.data, ITERS, None, 0)
             return 16
     else:
         kind = 'port'
@@ -164,27 +270,27 @@ def cpu_baseline(frames_block, budget_s=10.0):
             x = noise.copy()
             orc.lib().orc_fec_decode_frame(RATE, SHORT, x, ITERS, 1, bb, c)
             return 1
-    nfec, tfec = run_threads(fec)
+    nfec, tfec = run_threads(fec, budget_s * 0.6)
     fec_frames_per_s = nfec / tfec
     # ---- front-end leg (oracle; FEC skipped with force_ldpc_iters = -1)
-    blk = frames_block[0]
-    rxs = [orc.OracleRx(orc.default_cfg(MODCOD, SHORT, PILOTS, force_ldpc_iters=-1)) for _ in range(ncores)]
+    rxs = [orc.OracleRx(orc.default_cfg(MODCOD, SHORT, PILOTS, force_ldpc_iters=-1)) for _ in range(ncpu)]
 
     def fe(i):
-        rxs[i].process(blk)
-        return blk.size // 2
-    nsym, tfe = run_threads(fe)
+        rxs[i].process(block_iq)
+        return block_iq.size // 2
+    nsym, tfe = run_threads(fe, budget_s * 0.4)
     fe_sym_per_s = nsym / tfe
     t_per_sym = 1.0 / fe_sym_per_s + 1.0 / (fec_frames_per_s * sym_per_frame)
-    out = dict(value=round(1e-6 / t_per_sym, 4), unit='Msymbols/s', cores=ncores, kind=kind,
-               sample='%d threads: FEC leg %d frames in %.1f s (%s LDPC 50 it + BCH + descramble = %.3f Msym/s), front-end leg '
-                      '%d symbols in %.1f s (oracle AGC..demap = %.3f Msym/s); per-symbol times added'
-                      % (ncores, nfec, tfec, 'reference 16-lane SSE4.1' if kind == 'reference' else 'oracle scalar',
+    out = dict(value=round(1e-6 / t_per_sym, 4), unit='Msymbols/s', cores=ncpu, kind=kind, cpu_model=model, physical_cores=phys, logical_cpus=ncpu,
+               compiler_flags=flags or 'oracle: g++ -std=c++17 -O3 -ffp-contract=off',
+               sample='%d threads (one per logical CPU): FEC leg %d frames in %.1f s (%s LDPC 50 it + repack + BCH + descramble, persistent decoder '
+                      'objects = %.3f Msym/s), front-end leg %d symbols in %.1f s (oracle AGC..demap = %.3f Msym/s); per-symbol times added'
+                      % (ncpu, nfec, tfec, 'reference 16-lane SSE4.1' if kind == 'reference' else 'oracle scalar',
                          fec_frames_per_s * sym_per_frame / 1e6, nsym, tfe, fe_sym_per_s / 1e6),
                fec_only_msym_s=round(fec_frames_per_s * sym_per_frame / 1e6, 4), frontend_only_msym_s=round(fe_sym_per_s / 1e6, 4))
     if R is not None:
         # as-wired variant: one frame per decode call, single thread (bbframe_ldpc.cpp:123-139)
-        b = noise[0].copy()
+        b = rng.integers(-40, 41, size=(p['N'],)).astype(np.int8)
         t1 = time.time()
         n1 = 0
         while time.time() - t1 < 1.5:
@@ -195,15 +301,187 @@ def cpu_baseline(frames_block, budget_s=10.0):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ secondary configurations
+def secondary_s2(eng, pkg, dev, name, modcod, rate, short, pilots, esn0_db, S, F, steps):
+    import torch
+    run = S2Run(eng, pkg, dev, modcod, short, pilots, esn0_db, S, F, DISTINCT, seed=50 + modcod)
+
+    def barrier():
+        torch.cuda.synchronize()
+    dt, stages, acc = time_steps(run, steps, 1, barrier, True)
+    k = ldpc_alone(eng, run.info, rate, short, S * F, dev)
+    bpf = ITERS * 4 * run.info['ldpc_edges'] + run.info['ldpc_n'] + run.info['kbch'] // 8
+    out = {'config': name, 'value': round(S * F * steps * run.sym / dt / 1e6, 1), 'unit': 'Msymbols/s', 'ms_per_step': round(dt / steps * 1e3, 2),
+           'streams': S, 'frames_per_stream_per_step': F, 'esn0_db': esn0_db, 'frames_delivered': acc['delivered'],
+           'frames_equal_to_transmitted': acc['equal'], 'ldpc_kernel_ms_alone': round(k['forced'], 3),
+           'ldpc_nominal_hbm_frac': round(bpf * S * F / (k['forced'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    run.close()
+    torch.cuda.empty_cache()
+    return out
+
+
+def secondary_dvbs(eng, pkg, dev):
+    """BASELINE config D / 1: DVB-S QPSK 1/2, IQ -> decoded bits -> TS packets.  GPU: a bank of 4096 carriers and ONE carrier; CPU:
+    the oracle restatement of DVBSDemod::process on one thread (config 1's number, kind "port": SDR++/VOLK are not available)."""
+    import torch
+    import orc_dvbs as od
+    nsym = 65536
+    iq, _ = od.dvbs_iq(0, nsym, seed=1, esn0_db=12.0, cfo=1e-3, timing=0.3)
+    out = {'config': 'D: DVB-S QPSK 1/2, 2 sps, IQ -> Viterbi output (receiver bank, dvbs2gpu_dvbs_demod_*)'}
+    for S in (4096, 1):
+        bank = pkg.DvbsDemodBank(eng, S, max_samples=iq.size)
+        d_iq = torch.from_numpy(iq).to(dev)
+        tin = [d_iq for _ in range(S)]
+        tout = [torch.zeros(iq.size + 4 * 8192, dtype=torch.uint8, device=dev) for _ in range(S)]
+        bank.process_batch(tin, tout)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            bank.process_batch(tin, tout)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        st = bank.stats()[0]
+        out['bank_%d_msym_s' % S] = round(S * nsym / dt / 1e6, 2)
+        out['bank_%d_locked' % S] = bool(st.state == 1 and st.rate == 0)
+        bank.close()
+    # CPU (config 1): front end + slicer + Viterbi of the oracle, one stream, one thread, bounded sample
+    rx, o = od.OracleQpskAlt(), od.L()
+    sl, vit = od.VP(o.orc_dvbs_slicer_create()), od.OracleViterbi()
+    t0 = time.perf_counter()
+    done = 0
+    while time.perf_counter() - t0 < 4.0:
+        sy = np.ascontiguousarray(rx.process(iq))
+        soft = np.zeros(2 * sy.size + 8192, np.int8)
+        n = o.orc_dvbs_slicer_process(sl, sy.size, od.P(sy), od.P(soft))
+        if n:
+            vit.work(soft[:n].reshape(-1, 8192))
+        done += nsym
+    out['cpu_config1_msym_s'] = round(done / (time.perf_counter() - t0) / 1e6, 3)
+    out['cpu_config1_note'] = 'oracle restatement of DVBSDemod::process up to the Viterbi output, ONE stream on ONE host thread (kind "port")'
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ config 4: 64 mixed transponders
+MIXED_MODCODS = [4, 6, 7, 11, 12, 13, 14, 15]
+MIXED_ESN0 = {4: 8.0, 6: 10.0, 7: 11.0, 11: 14.0, 12: 12.0, 13: 13.0, 14: 14.0, 15: 16.0}
+MIXED_RATE = {4: 3, 6: 5, 7: 6, 11: 10, 12: 4, 13: 5, 14: 6, 15: 8}
+
+
+def mixed64(eng, pkg, dev, dd, steps, warmup, nt=64, sub=64, F=1):
+    """BASELINE config 4: `nt` transponders cycling over 8 QPSK / 8PSK MODCODs (normal frames, 50 forced iterations), each carried as
+    `sub` concurrently processed sub-streams (the sections one fast transponder is cut into for a GPU whose per-stream loops are serial;
+    nt x sub = 4096 streams, the shape of tools/mixed_bench.py at N = 1).  STRONG scaling: the transponder list is fixed and sharded
+    over the ranks (MODCOD-grouped, weighted); rank 0 owns table + configuration and broadcasts them; after every step the BBFRAMEs
+    and per-frame statistics are gathered to the egress rank 0, which reassembles them in transponder order and checks every frame."""
+    import torch
+    table = cfg = None
+    if dd.rank == 0:
+        table = []
+        for t in range(nt):
+            m = MIXED_MODCODS[t % len(MIXED_MODCODS)]
+            info = pkg.modcod_info(m, False, False)
+            table.append(dict(id=t, modcod=m, seed=900 + t, esn0_db=MIXED_ESN0[m], kb=info['kbch'] // 8, sym=info['plframe_symbols'],
+                              weight=float(info['ldpc_edges']) * ITERS + 40.0 * info['plframe_symbols']))
+        cfg = dict(sub=sub, frames=F, iters=ITERS, cfo=CFO, ppm=PPM)
+    table = dd.broadcast_object(table)
+    cfg = dd.broadcast_object(cfg)
+    assign = pkg_distribute(pkg).assign_transponders(table, dd.world)
+    mine = assign[dd.rank]
+    kbmax = max(t['kb'] for t in table)
+    cap = cfg['frames'] + 2
+    # local streams: transponder-major, `sub` sub-streams each
+    demods, tin, ids, kbs, syms, sent = [], [], [], [], [], []
+    iq_keep = []
+    for t in mine:
+        e = table[t]
+        iq, bb = make_block(e['modcod'], 0, 0, cfg['frames'], e['seed'], e['esn0_db'], cfg['cfo'], cfg['ppm'])
+        d_iq = torch.from_numpy(iq).to(dev)
+        c = eng.default_cfg(e['modcod'], False, False, force_ldpc_iters=cfg['iters'])
+        for k in range(cfg['sub']):
+            x = torch.roll(d_iq, 2 * (k * 7919 % (iq.size // 2)))
+            iq_keep.append(x)
+            demods.append(eng.demod(c, max_samples=iq.size))
+            tin.append(x)
+            ids.append(t * cfg['sub'] + k)
+            kbs.append(e['kb']); syms.append(e['sym'])
+        sent.append({bytes(x) for x in bb})
+    nloc = len(demods)
+    out = torch.zeros((max(nloc, 1), cap * kbmax), dtype=torch.uint8, device=dev)
+    tout = [out[i] for i in range(nloc)]
+    n_units = nt * cfg['sub']
+    total_sym_per_step = sum(t['sym'] for t in table) * cfg['sub'] * cfg['frames']
+
+    def step():
+        nb = eng.process_batch(demods, tin, tout) if nloc else []
+        # per-frame statistics of the step (LDPC trials, BCH corrections) travel with the frames
+        res = dd.gather_units(ids, out[:nloc], torch.as_tensor(nb, dtype=torch.int32, device=dev), n_units)
+        return nb, res
+
+    def barrier():
+        torch.cuda.synchronize()
+        dd.barrier()
+        torch.cuda.synchronize()
+
+    eng.set_pipelined(True)
+    for _ in range(PREROLL_FRAMES // cfg['frames'] + 2):
+        step()
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        nb, (g_out, g_cnt) = step()
+    barrier()
+    dt = dd.max_over_ranks(time.perf_counter() - t0)
+    # egress check: every unit's frames are transmitted frames of ITS transponder (input order restored by the gather)
+    bad = delivered = 0
+    if dd.rank == dd.egress:
+        host = g_out.cpu().numpy()
+        cnt = g_cnt.cpu().numpy()
+        all_sent = {}
+        for t in range(nt):
+            e = table[t]
+            _, bb = make_block(e['modcod'], 0, 0, cfg['frames'], e['seed'], e['esn0_db'], cfg['cfo'], cfg['ppm']) if t not in mine else (None, None)
+            all_sent[t] = {bytes(x) for x in bb} if bb is not None else sent[mine.index(t)]
+        for u in range(n_units):
+            t = u // cfg['sub']
+            kb = table[t]['kb']
+            fr = host[u, :cnt[u]].reshape(-1, kb)
+            delivered += len(fr)
+            bad += sum(bytes(x) not in all_sent[t] for x in fr)
+    if nloc:
+        eng.process_batch(demods, [torch.empty(0, dtype=torch.complex64, device=dev) for _ in demods], tout)
+    eng.set_pipelined(False)
+    for d in demods:
+        d.close()
+    res = {'config': '4: %d transponders, MODCODs %s cycled, normal frames, %d sub-streams each, %d PLFRAME(s) per stream per step, 50 forced LDPC iterations'
+                     % (nt, MIXED_MODCODS, cfg['sub'], cfg['frames']),
+           'value': round(total_sym_per_step * steps / dt / 1e6, 1), 'unit': 'Msymbols/s', 'scaling': 'strong', 'n_gpus': dd.world,
+           'ms_per_step': round(dt / steps * 1e3, 2), 'transponders_per_rank': [len(a) for a in assign],
+           'modcods_per_rank': [sorted({table[i]['modcod'] for i in a}) for a in assign],
+           'collectives': 'broadcast of table + configuration from rank 0; per step a gather of BBFRAMEs + byte counts to the egress rank 0 (in the timed region)',
+           'frames_at_egress_last_step': delivered, 'frames_not_transmitted_ones': bad}
+    return res
+
+
+def pkg_distribute(pkg):
+    import importlib
+    return importlib.import_module(pkg.__name__ + '.distribute')
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--config', default='headline', choices=['headline', 'mixed64'])
     ap.add_argument('--streams', type=int, default=4096, help='transponder streams per GPU')
-    ap.add_argument('--frames', type=int, default=1, help='PLFRAMEs per stream per step')
+    ap.add_argument('--frames', type=int, default=8, help='PLFRAMEs per stream per step')
+    ap.add_argument('--distinct', type=int, default=DISTINCT, help='distinct signal blocks (every stream gets a private, shifted copy)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-aux', action='store_true', help='skip the single-transponder (segment receiver) side measurement')
+    ap.add_argument('--no-secondary', action='store_true', help='skip configs 2, 5, D and the mixed-MODCOD batch')
     ap.add_argument('--no-pipeline', action='store_true', help='run the FEC inside the call that produced the frames (no overlap with the next front end)')
     args = ap.parse_args()
 
@@ -215,6 +493,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     dist = None
+    backend = 'nccl'
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -232,25 +511,8 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local_rank)
     eng = pkg.Engine(local_rank)
-
-    info = pkg.modcod_info(MODCOD, bool(SHORT), bool(PILOTS))
-    sym = info['plframe_symbols']
-    kb = info['kbch'] // 8
-    S, F = args.streams, args.frames
-    blocks, sent = make_blocks(F, seed=rank, eng=eng, pkg=pkg)
-    d_blocks = [torch.from_numpy(b).to(dev) for b in blocks]
-    nsamp = blocks[0].size
-    cfg = eng.default_cfg(MODCOD, bool(SHORT), bool(PILOTS), force_ldpc_iters=ITERS)
-    demods = [eng.demod(cfg, max_samples=nsamp) for _ in range(S)]
-    tin = [d_blocks[s % DISTINCT] for s in range(S)]
-    tout = [torch.zeros((F + 2) * kb, dtype=torch.uint8, device=dev) for _ in range(S)]
-
-    # throughput mode: FEC of step k overlaps the front end of step k+1 (two HIP streams); BBFRAMEs arrive one step later
-    pipelined = not args.no_pipeline
-    eng.set_pipelined(pipelined)
-
-    def step():
-        return eng.process_batch(demods, tin, tout)
+    eng.set_stage_timing(True)
+    dd = pkg_distribute(pkg).Distributor(dist, dev if backend == 'nccl' else 'cpu')
 
     def barrier():
         torch.cuda.synchronize()
@@ -258,84 +520,48 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(PREROLL):          # acquisition, untimed and not counted as warm-up
-        step()
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    nb = None
-    for _ in range(args.steps):
-        nb = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    if args.config == 'mixed64':
+        res = mixed64(eng, pkg, dev, dd, args.steps, args.warmup)
+        if rank == 0:
+            line = {'metric': 'Msymbols/s demod+FEC, 64 mixed-MODCOD DVB-S2 transponders @50 LDPC iters (BASELINE config 4)', 'value': res['value'],
+                    'unit': 'Msymbols/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': res['ms_per_step'],
+                    'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'int8 (FEC) / f32 (demod)', 'data': 'synthetic',
+                    'config': {'workload': res['config']}, 'mixed64': res}
+            print(json.dumps(line))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        eng.close()
+        return
 
-    def check_out(nbytes):
-        ok = all(n == F * kb for n in nbytes)
-        ex = ok
-        if ok:
-            for s in list(range(0, S, max(1, S // 16))) + list(range(min(S, DISTINCT))):
-                got = tout[s][:nbytes[s]].cpu().numpy().reshape(-1, kb)
-                ex = ex and all(bytes(x) in sent[s % DISTINCT] for x in got)
-        return ok, ex
+    S, F = args.streams, args.frames
+    pipelined = not args.no_pipeline
+    run = S2Run(eng, pkg, dev, MODCOD, SHORT, PILOTS, ESN0_DB, S, F, args.distinct, seed=rank)
+    dt, stages, acc = time_steps(run, args.steps, args.warmup, barrier, pipelined)
+    dt = dd.max_over_ranks(dt)
+    info, sym = run.info, run.sym
+    block0 = run.blocks_host[0]
+    iq_bytes = int(S) * run.nsamp * 8
+    run.close()
+    torch.cuda.empty_cache()
 
-    # parity of the timed output: every stream delivered F frames per step, each bit-exact one of the BBFRAMEs sent
-    frames_ok, exact = check_out(nb)
-    if pipelined:
-        # collect the frames of the last timed step (zero-sample call), same check; then leave the mode
-        empty = [torch.empty(0, dtype=torch.complex64, device=dev) for _ in range(S)]
-        nb_last = eng.process_batch(demods, empty, tout)
-        ok2, ex2 = check_out(nb_last)
-        frames_ok, exact = frames_ok and ok2, exact and ex2
-        eng.set_pipelined(False)
-
-    # dominant kernel (LDPC) alone, HIP events on its launch stream, same batch size as inside a step
     nfr = S * F
-    llr = torch.randint(-40, 41, (nfr, info['ldpc_n']), dtype=torch.int8, device=dev)
-    hard = torch.empty((nfr, info['ldpc_k'] // 8), dtype=torch.uint8, device=dev)
-    tri = torch.empty((nfr,), dtype=torch.int32, device=dev)
-
-    def ldpc_only():
-        eng.lib.dvbs2gpu_ldpc_decode_batch(eng.h, RATE, SHORT, llr.data_ptr(), nfr, ITERS, 1, hard.data_ptr(), None, tri.data_ptr(), eng._stream())
-    ldpc_only()
-    torch.cuda.synchronize()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    nk = 3
-    e0.record()
-    for _ in range(nk):
-        ldpc_only()
-    e1.record()
-    torch.cuda.synchronize()
-    k_ms = e0.elapsed_time(e1) / nk
-    # the same launch in the normal (early-exit) mode: this noise never converges, so it also runs ITERS iterations, with the reference's
-    # syndrome check (LDPCDecoder::bad) before every one; the forced mode evaluates the check once, after the last iteration, because its
-    # result cannot end the loop earlier
-    def ldpc_checked():
-        eng.lib.dvbs2gpu_ldpc_decode_batch(eng.h, RATE, SHORT, llr.data_ptr(), nfr, ITERS, 0, hard.data_ptr(), None, tri.data_ptr(), eng._stream())
-    ldpc_checked()
-    torch.cuda.synchronize()
-    e0.record()
-    ldpc_checked()
-    e1.record()
-    torch.cuda.synchronize()
-    k_ms_checked = e0.elapsed_time(e1)
-    checked_all_ran = bool((tri == -1).all().item())
+    k = ldpc_alone(eng, info, RATE, SHORT, nfr, dev)
     bytes_per_frame = ITERS * 4 * info['ldpc_edges'] + info['ldpc_n'] + info['kbch'] // 8
-    achieved = bytes_per_frame * nfr / (k_ms * 1e-3) / 1e9
     plan = eng.ldpc_plan_info(RATE, bool(SHORT))
-    # PMC traffic of this very launch shape, collected offline (counters need their own rocprofv3 passes) and committed
-    traffic, traffic_note = None, None
-    tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_ldpc_traffic.json')
+    # the decoder's launches as they ran INSIDE the timed steps (hipEvent pairs on the FEC stream, dvbs2gpu_get_stage_times)
+    l_ms, l_n, l_frames = stages['ldpc']
+    in_step_ms = l_ms / max(l_n, 1)
+    in_step_frames = l_frames / max(l_n, 1)
+    achieved = bytes_per_frame * in_step_frames / (in_step_ms * 1e-3) / 1e9 if l_n else None
+    achieved_alone = bytes_per_frame * nfr / (k['forced'] * 1e-3) / 1e9
+    traffic, traffic_note, issue = None, None, None
+    tp = os.path.join(ROOT, 'profiles', 'r02_ldpc_traffic.json')
     if os.path.exists(tp):
         tj = json.load(open(tp))
-        if tj['launch']['frames'] == nfr and tj['launch']['iterations'] == ITERS:
-            traffic = tj['traffic_bytes_per_launch']
-            traffic_note = tj['source'] + '; ' + tj['correction']
+        traffic = tj.get('traffic_bytes_per_launch')
+        traffic_note = tj.get('source')
+        issue = tj.get('valu_issue_fraction')
 
     if rank == 0:
         value = world * S * F * args.steps * sym / dt / 1e6
@@ -345,31 +571,55 @@ def main():
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'int8 (FEC) / f32 (demod)', 'data': 'synthetic',
             'config': {'workload': WORKLOAD,
-                       'streams_per_gpu': S, 'frames_per_stream_per_step': F, 'symbols_per_frame': sym,
+                       'streams_per_gpu': S, 'frames_per_stream_per_step': F, 'symbols_per_frame': sym, 'distinct_signal_blocks': min(args.distinct, S),
+                       'private_iq_copy_per_stream_bytes_total': iq_bytes,
                        'parallelism': 'independent transponder streams sharded over GPUs, no data-path collective',
-                       'all_frames_delivered': frames_ok, 'output_bit_exact': exact,
+                       'frames_delivered_checked': acc['delivered'], 'frames_equal_to_transmitted': acc['equal'],
+                       'fraction_equal_to_transmitted': round(acc['equal'] / max(acc['delivered'], 1), 5),
+                       'frames_out_of_sequence': acc['out_of_order'],
+                       'check': 'every delivered frame of every stream, last timed step + pipeline flush, on the device (hash + full byte compare)',
                        'fec_pipelined_across_steps': pipelined},
-            'roofline': {'bound': 'hbm', 'kernel': 'ldpc_decode_kernel<%d,%d,%s>' % (plan['max_deg'], plan['rec_dwords'], 'true' if plan.get('irregular') else 'false'), 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                         'traffic_unit': 'bytes per launch (fabric-side FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_note,
-                         'algorithmic_bytes_per_launch': bytes_per_frame * nfr,
-                         'kernel_ms': round(k_ms, 4), 'frames_per_launch': nfr, 'algorithmic_bytes_per_frame': bytes_per_frame,
-                         'ldpc_share_of_step': round(k_ms / (dt / args.steps * 1e3), 3),
-                         'syndrome_check': 'forced mode (the headline): evaluated once, after the last iteration; normal mode: before every iteration, as in the reference',
-                         'kernel_ms_normal_mode_same_iterations': round(k_ms_checked, 4) if checked_all_ran else None,
+            'roofline': {'bound': 'valu-issue + serial-section latency (measured); the HBM figure below is NOMINAL: algorithmic bytes against the 8 TB/s peak',
+                         'kernel': 'ldpc_decode_kernel<%d,%d,%s>' % (plan['max_deg'], plan['rec_dwords'], 'true' if plan.get('irregular') else 'false'),
+                         'achieved': round(achieved if achieved else achieved_alone, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round((achieved if achieved else achieved_alone) / HBM_PEAK_GBS, 4),
+                         'timing': 'average over the %d decoder launches inside the timed steps (hipEvent pairs on the FEC stream; the front end of the next step shares the CUs)' % l_n,
+                         'kernel_ms_in_step': round(in_step_ms, 4), 'frames_per_launch': int(in_step_frames),
+                         'kernel_ms_alone': round(k['forced'], 4), 'achieved_alone': round(achieved_alone, 1), 'frac_alone': round(achieved_alone / HBM_PEAK_GBS, 4),
+                         'kernel_ms_alone_normal_mode_same_iterations': round(k['normal'], 4) if k['normal_all_ran'] else None,
+                         'traffic': traffic, 'traffic_unit': 'bytes per launch (fabric-side FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_note,
+                         'valu_issue_fraction': issue,
+                         'algorithmic_bytes_per_frame': bytes_per_frame, 'algorithmic_bytes_per_launch': int(bytes_per_frame * in_step_frames),
+                         'ldpc_share_of_step': round(in_step_ms * l_n / (dt * 1e3), 3),
+                         'syndrome_check': 'forced mode (the headline): evaluated once, after the last iteration; normal mode: before every iteration, as in the reference (bit-vector form, see DESIGN.md)',
                          'note': 'posteriors stay in LDS; the message records (132 MB live) bounce through the Infinity Cache, whose hits the fabric-side counters include',
                          'plan': plan},
+            'stage_ms_per_step': {name: round(v[0] / args.steps, 3) for name, v in stages.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(blocks)
-        if world == 1 and not args.no_aux:
-            line['single_transponder'] = single_transponder(eng, pkg)
+            line['cpu_baseline'] = cpu_baseline(block0)
+        if world == 1 and not args.no_secondary:
+            sec = []
+            try:
+                sec.append(secondary_s2(eng, pkg, dev, '2: DVB-S2 QPSK 1/2 normal FECFRAME (MODCOD 4), same channel conditions, Es/N0 8 dB', 4, 3, 0, 0, 8.0, 2048, 4, 3))
+                sec.append(secondary_s2(eng, pkg, dev, '5 stand-in: DVB-S2 32APSK 8/9 SHORT FECFRAME + pilots (MODCOD 27; 9/10 short does not exist), Es/N0 20 dB', 27, 9, 1, 1, 20.0, 2048, 16, 3))
+                sec.append(secondary_dvbs(eng, pkg, dev))
+            except Exception as e:          # a secondary line must not take the headline down
+                sec.append({'error': repr(e)})
+            line['secondary'] = sec
+    if not args.no_secondary:
+        # BASELINE config 4 runs on every world size (strong scaling; at N = 1 it is the one-GPU number)
+        try:
+            m64 = mixed64(eng, pkg, dev, dd, 4, 1)
+        except Exception as e:
+            m64 = {'error': repr(e)}
+        if rank == 0:
+            line['mixed64'] = m64
+    if rank == 0:
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    for d in demods:
-        d.close()
     eng.close()
 
 

@@ -127,6 +127,29 @@ int dvbs2gpu_deinterleave_batch(dvbs2gpu_ctx* ctx, int modcod, int shortframes, 
 int dvbs2gpu_math_eval(dvbs2gpu_ctx* ctx, int func, int n, const float* d_a, const float* d_b, float* d_out0, float* d_out1,
                        void* stream);
 
+/* ------------------------------------------------------------------ per-stage device times
+ * The reference exposes its health through the stats fields the GUI polls (module_dvbs2_demod.h:82-87); a batched GPU engine also
+ * needs to show where a call's time goes.  With timing on, every stage of dvbs2gpu_demod_process[_batch] (and the FEC stage entry
+ * points) is bracketed by a hipEvent pair on the stream it is enqueued on -- also in the pipelined mode, where the FEC of call k
+ * runs beside the front end of call k+1, so ms[LDPC] is the decoder's time AS IT RAN inside the calls.  get_stage_times waits for
+ * the outstanding events, returns the sums since the previous get and resets them.  units: frames (LDPC, BCH) or 0. */
+#define DVBS2GPU_STAGE_FRONTEND 0  /* FastAGC + FreqShift + Gardner */
+#define DVBS2GPU_STAGE_RRC 1       /* RRC FIR + /2 */
+#define DVBS2GPU_STAGE_PLSYNC 2
+#define DVBS2GPU_STAGE_LOOPS 3     /* coarse FED, PLL, PLHDR demod */
+#define DVBS2GPU_STAGE_DEMAP 4     /* soft demap + bit de-interleave */
+#define DVBS2GPU_STAGE_LDPC 5
+#define DVBS2GPU_STAGE_BCH 6       /* BCH + BB descramble */
+#define DVBS2GPU_STAGE_DELIVER 7   /* BBFRAMEs into the caller's buffers */
+#define DVBS2GPU_STAGE_COUNT 8
+typedef struct dvbs2gpu_stage_times {
+    double ms[DVBS2GPU_STAGE_COUNT];
+    int64_t launches[DVBS2GPU_STAGE_COUNT];
+    int64_t units[DVBS2GPU_STAGE_COUNT];
+} dvbs2gpu_stage_times;
+int dvbs2gpu_set_stage_timing(dvbs2gpu_ctx* ctx, int on);
+int dvbs2gpu_get_stage_times(dvbs2gpu_ctx* ctx, dvbs2gpu_stage_times* out);
+
 /* ------------------------------------------------------------------ full DVB-S2 demodulator (one stream)
  *
  * Mirror of dsp::dvbs2::DVBS2Demod (module_dvbs2_demod.h:51-160).  A handle is one transponder stream:

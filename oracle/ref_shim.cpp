@@ -76,6 +76,45 @@ int ref_ldpc_decode_simd16(int rate, int shortframe, int8_t* frames, int max_tri
 
 int ref_simd_width(void) { return simd_type::SIZE; }
 
+// Persistent "library-intended" FEC object for the CPU baseline: tables built ONCE (BBFrameLDPC, LDPCDecoder::init, the thread's
+// BBFrameBCH, BBFrameDescrambler), then every call = one 16-lane LDPC decode (input already lane-interleaved: lanes[i*16 + l] = LLR i
+// of frame l, so no transposition is timed) + per frame the hard-decision repack of module_dvbs2_demod.cpp:357-360, BCH and descramble.
+struct RefFec16 {
+    BBFrameLDPC holder;
+    LDPCDecoder<simd_type, algorithm_type> dec;
+    BBFrameDescrambler descr;
+    int rate, sh, n, k;
+    std::vector<simd_type> buf;
+    std::vector<uint8_t> frame;
+    RefFec16(int r, int s) : holder(to_fs(s), to_rate(r)), descr(to_fs(s), to_rate(r)), rate(r), sh(s) {
+        dec.init(holder.get_instance());
+        n = s ? 16200 : 64800;
+        k = holder.dataSize();
+        buf.resize(n);
+        frame.resize(n / 8);
+    }
+};
+void* ref_fec16_create(int rate, int shortframe) { return new RefFec16(rate, shortframe); }
+void ref_fec16_destroy(void* h) { delete (RefFec16*)h; }
+// returns the decoder's raw trials value of the 16-lane call; bb_out (optional): 16 x kbch_bytes descrambled BBFRAMEs
+int ref_fec16_run(void* h, const int8_t* lanes, int max_trials, uint8_t* bb_out, int kbch_bytes) {
+    RefFec16* f = (RefFec16*)h;
+    const int W = simd_type::SIZE;
+    memcpy((void*)f->buf.data(), lanes, (size_t)f->n * W);
+    const int ret = f->dec(f->buf.data(), f->buf.data() + f->k, max_trials, W);
+    BBFrameBCH& bch = bch_for(f->rate, f->sh);
+    for (int l = 0; l < W; ++l) {
+        uint8_t* fr = f->frame.data();
+        memset(fr, 0, f->frame.size());
+        for (int i = 0; i < f->k; ++i) fr[i / 8] = (uint8_t)(fr[i / 8] << 1 | (reinterpret_cast<const int8_t*>(&f->buf[i])[l] < 0));
+        bch.decode(fr);
+        f->descr.work(fr);
+        if (bb_out) memcpy(bb_out + (size_t)l * kbch_bytes, fr, kbch_bytes);
+    }
+    return ret;
+}
+const char* ref_build_flags(void) { return REF_BUILD_FLAGS; }
+
 int ref_bch_decode(int rate, int shortframe, uint8_t* frame) { return bch_for(rate, shortframe).decode(frame); }
 
 void ref_bch_decode_many(int rate, int shortframe, uint8_t* frames, int nframes, int nbch_bytes, int* corr_out) {

@@ -148,6 +148,8 @@ struct TxCfg {
     double phase0;           // initial carrier phase
     int lead_symbols;        // random QPSK symbols before the first frame (sync acquisition run-in)
     int circular;            // != 0: pulse shaping wraps around, so the block can be repeated as a seamless stream
+    int nsamples;            // 0: exactly 2 samples per symbol; else the block is resampled to this many samples (sampling-clock error
+                             // of 2*symbols/nsamples - 1, e.g. -10 ppm: nsamples = 2*symbols*(1 + 1e-5)); with `circular` still seamless
 };
 // returns 2-sps IQ; bbframes_out gets nframes x kbch/8 bytes (what the receiver must output)
 std::vector<cf> s2_transmit(const TxCfg& t, std::vector<uint8_t>* bbframes_out, std::vector<cf>* symbols_out = nullptr);

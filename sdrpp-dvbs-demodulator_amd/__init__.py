@@ -40,6 +40,14 @@ class DemodCfg(C.Structure):
                 ('pilots', C.c_int32), ('sof_threshold', C.c_float), ('max_ldpc_trials', C.c_int32), ('force_ldpc_iters', C.c_int32)]
 
 
+STAGE_NAMES = ('frontend', 'rrc', 'plsync', 'loops', 'demap', 'ldpc', 'bch', 'deliver')
+
+
+class StageTimes(C.Structure):
+    """dvbs2gpu_stage_times"""
+    _fields_ = [('ms', C.c_double * 8), ('launches', C.c_int64 * 8), ('units', C.c_int64 * 8)]
+
+
 class FrameStats(C.Structure):
     """dvbs2gpu_frame_stats"""
     _fields_ = [('pl_sync_best_match', C.c_float), ('detected_modcod', C.c_int32), ('detected_shortframes', C.c_int32),
@@ -64,6 +72,8 @@ PROTOTYPES = {
     'dvbs2gpu_fec_decode_batch': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'dvbs2gpu_demap_batch': (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     'dvbs2gpu_deinterleave_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
+    'dvbs2gpu_set_stage_timing': (_i, [_vp, _i]),
+    'dvbs2gpu_get_stage_times': (_i, [_vp, _vp]),
     'dvbs2gpu_math_eval': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'dvbs2gpu_demod_default_cfg': (None, [_i, _i, _i, C.POINTER(DemodCfg)]),
     'dvbs2gpu_demod_create': (_i, [_vp, C.POINTER(DemodCfg), _i, C.POINTER(_vp)]),
@@ -292,6 +302,15 @@ class Engine:
         self._check(self.lib.dvbs2gpu_math_eval(self.h, int(func), a.numel(), _ptr(a), _ptr(b) if b is not None else None, _ptr(o0),
                                                 _ptr(o1), self._stream()))
         return o0, o1
+
+    def set_stage_timing(self, on):
+        self._check(self.lib.dvbs2gpu_set_stage_timing(self.h, int(bool(on))))
+
+    def stage_times(self):
+        """per-stage device times since the previous call: {stage: (ms, launches, units)}"""
+        st = StageTimes()
+        self._check(self.lib.dvbs2gpu_get_stage_times(self.h, C.byref(st)))
+        return {STAGE_NAMES[i]: (st.ms[i], st.launches[i], st.units[i]) for i in range(8)}
 
     def set_pipelined(self, on):
         """FEC of call k overlaps the front end of call k+1; BBFRAMEs are delivered one process_batch call later"""

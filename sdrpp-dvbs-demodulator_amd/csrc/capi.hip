@@ -48,7 +48,7 @@ int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
         LdpcPlan P = build_ldpc_plan(code_index);
         LdpcDeviceCode D;
         D.code_index = code_index;
-        D.N = P.N; D.K = P.K; D.R = P.R; D.q = P.q; D.max_deg = P.max_deg; D.irregular = (P.min_deg != P.max_deg); D.rec_dwords = P.rec_dwords; D.edges = P.edges; D.pent_base = P.pent_base;
+        D.N = P.N; D.K = P.K; D.R = P.R; D.q = P.q; D.max_deg = P.max_deg; D.irregular = (P.min_deg != P.max_deg); D.rec_dwords = P.rec_dwords; D.edges = P.edges; D.pent_base = P.pent_base; D.synd_base = P.synd_base;
         int rc;
         if ((rc = upload(P.layers, &D.d_layers))) return rc;
         if ((rc = upload(P.ents, &D.d_ents))) return rc;
@@ -146,7 +146,11 @@ int fec_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, int nfra
     int rc;
     if ((rc = ctx->ws_hard.ensure((size_t)nframes * (f.K / 8)))) return rc;
     uint8_t* hard = (uint8_t*)ctx->ws_hard.p;
-    if ((rc = ldpc_run(ctx, f, d_llr, nframes, max_trials, force, hard, f.K / 8, nullptr, d_trials, st))) return rc;
+    {
+        StageSpan sp(ctx->timers, ST_LDPC, st, nframes);
+        if ((rc = ldpc_run(ctx, f, d_llr, nframes, max_trials, force, hard, f.K / 8, nullptr, d_trials, st))) return rc;
+    }
+    StageSpan sp(ctx->timers, ST_BCH, st, nframes);
     if ((rc = bch_run(ctx, f, hard, nframes, d_corr, st))) return rc;
     if ((rc = get_prbs(ctx))) return rc;
     HIP_TRY(bb_descramble_launch(hard, f.K / 8, ctx->d_prbs, f.kbch / 8, nframes, d_bbframes, st));
@@ -251,6 +255,8 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
     if (ctx->d_fd_bank) (void)hipFree(ctx->d_fd_bank);
     for (auto& kv : ctx->bandedge) if (kv.second) (void)hipFree(kv.second);
     if (ctx->ev_ws) (void)hipEventDestroy(ctx->ev_ws);
+    for (auto& sp : ctx->timers.pending) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (auto e : ctx->timers.pool) (void)hipEventDestroy(e);
     ctx->ws_msg.release(); ctx->ws_hard.release(); ctx->ws_syn.release(); ctx->ws_misc.release();
     if (ctx->fe_stream) (void)hipStreamDestroy(ctx->fe_stream);
     if (ctx->fec_stream) (void)hipStreamDestroy(ctx->fec_stream);
@@ -265,6 +271,34 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
     for (auto& w : ctx->ws_rx) w.release();
     for (auto& w : ctx->ws_dvbs) w.release();
     delete ctx;
+}
+
+int dvbs2gpu_set_stage_timing(dvbs2gpu_ctx* ctx, int on) {
+    if (!ctx) return DVBS2GPU_ERR_ARG;
+    CallGuard guard(ctx);
+    std::lock_guard<std::mutex> l(ctx->timers.mtx);
+    ctx->timers.on = on != 0;
+    return 0;
+}
+int dvbs2gpu_get_stage_times(dvbs2gpu_ctx* ctx, dvbs2gpu_stage_times* out) {
+    if (!ctx || !out) return DVBS2GPU_ERR_ARG;
+    CallGuard guard(ctx);
+    HIP_TRY(hipSetDevice(ctx->device));
+    StageTimers& T = ctx->timers;
+    std::lock_guard<std::mutex> l(T.mtx);
+    for (auto& sp : T.pending) {
+        HIP_TRY(hipEventSynchronize(sp.b));
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) { T.ms[sp.stage] += ms; T.launches[sp.stage]++; T.units[sp.stage] += sp.units; }
+        T.pool.push_back(sp.a); T.pool.push_back(sp.b);
+    }
+    T.pending.clear();
+    static_assert(DVBS2GPU_STAGE_COUNT == ST_COUNT, "stage list");
+    for (int i = 0; i < ST_COUNT; ++i) {
+        out->ms[i] = T.ms[i]; out->launches[i] = T.launches[i]; out->units[i] = T.units[i];
+        T.ms[i] = 0; T.launches[i] = 0; T.units[i] = 0;
+    }
+    return 0;
 }
 
 // development aid: phase-cycle buffer (96 x u64, device memory) used by -DLDPC_PROF builds; not part of the public ABI
@@ -333,7 +367,10 @@ int dvbs2gpu_ldpc_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, con
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = stage_enter(ctx, (hipStream_t)stream);
     if (rc) return rc;
-    rc = ldpc_run(ctx, f, d_llr, nframes, max_trials, force, d_hard, f.K / 8, d_post, d_trials, (hipStream_t)stream);
+    {
+        StageSpan sp(ctx->timers, ST_LDPC, (hipStream_t)stream, nframes);
+        rc = ldpc_run(ctx, f, d_llr, nframes, max_trials, force, d_hard, f.K / 8, d_post, d_trials, (hipStream_t)stream);
+    }
     int rc2 = ws_release(ctx, (hipStream_t)stream);
     return rc ? rc : rc2;
 }

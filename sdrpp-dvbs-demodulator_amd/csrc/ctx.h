@@ -49,6 +49,39 @@ inline int upload(const std::vector<T>& v, T** dptr) {
     return 0;
 }
 
+// Per-stage device times (hipEvent pairs on the stream a stage is enqueued on), accumulated until dvbs2gpu_get_stage_times reads them.
+enum StageId { ST_FRONTEND = 0, ST_RRC, ST_PLSYNC, ST_LOOPS, ST_DEMAP, ST_LDPC, ST_BCH, ST_DELIVER, ST_COUNT };
+struct StageTimers {
+    bool on = false;
+    std::mutex mtx;
+    struct Span { int stage; hipEvent_t a, b; long units; };
+    std::vector<Span> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[ST_COUNT] = {};
+    long launches[ST_COUNT] = {}, units[ST_COUNT] = {};
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+// RAII span: records an event on `st` now and another when it goes out of scope (no-op while timing is off)
+struct StageSpan {
+    StageTimers* T; int stage; hipStream_t st; hipEvent_t a = nullptr; long units;
+    StageSpan(StageTimers& t, int stage_, hipStream_t st_, long units_ = 0) : T(&t), stage(stage_), st(st_), units(units_) {
+        if (!T->on) { T = nullptr; return; }
+        { std::lock_guard<std::mutex> l(T->mtx); a = T->get(); }
+        if (a) (void)hipEventRecord(a, st);
+    }
+    ~StageSpan() {
+        if (!T || !a) return;
+        std::lock_guard<std::mutex> l(T->mtx);
+        hipEvent_t b = T->get();
+        if (b) { (void)hipEventRecord(b, st); T->pending.push_back({stage, a, b, units}); }
+    }
+};
+
 struct ConstelTables {          // device tables of one constellation (type, gamma1, gamma2)
     S2ConstelDev dev;
     int8_t* d_bits = nullptr;
@@ -67,6 +100,7 @@ struct dvbs2gpu_ctx {
     // call_mtx (recursive: the segment receivers call process_batch from inside their own entry point).  The asynchronous stage
     // entry points only ENQUEUE under the lock; ev_ws, recorded behind the last enqueued user of the shared FEC workspaces, makes a
     // later user on a different stream wait for the earlier one (the message records and the LDPC work counter live there).
+    s2::StageTimers timers;
     std::recursive_mutex call_mtx;
     hipEvent_t ev_ws = nullptr;
     hipStream_t ws_stream = nullptr;

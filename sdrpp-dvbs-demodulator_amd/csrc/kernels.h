@@ -10,7 +10,7 @@ struct LdpcLayerDesc;
 // Device-resident plan of one LDPC code (built from ldpc_plan.h by the context, cached per code).
 struct LdpcDeviceCode {
     int code_index = -1;
-    int N = 0, K = 0, R = 0, q = 0, max_deg = 0, irregular = 0, rec_dwords = 0, edges = 0, pent_base = 0;
+    int N = 0, K = 0, R = 0, q = 0, max_deg = 0, irregular = 0, rec_dwords = 0, edges = 0, pent_base = 0, synd_base = 0;
     LdpcLayerDesc* d_layers = nullptr;
     uint32_t* d_ents = nullptr;
     uint32_t* d_rows = nullptr;

@@ -37,6 +37,7 @@ struct LdpcKernelArgs {
     uint32_t* msg_ws;      // [gridDim.x][R][REC]
     int nframes, N, K, R, q;
     int pent_base;         // offset of the pair-format link table inside ents[] (ldpc_plan.h)
+    int synd_base;         // offset of the syndrome-check table inside ents[] (ldpc_plan.h)
     int max_trials, force;
     int hard_stride;
     uint32_t* sgn_ws;           // [gridDim.x * slots][SGN_WS_DWORDS]: bit-packed posterior signs for the syndrome check
@@ -502,7 +503,7 @@ __device__ __forceinline__ uint32_t sign_pack(const int8_t* __restrict__ post, i
         const uint32_t lo = ((((v.x >> 7) & 0x01010101u) * 0x01020408u) >> 24);
         const uint32_t hi = ((((v.y >> 7) & 0x01010101u) * 0x01020408u) >> 24);
         const uint32_t sb = lo | (hi << 4);
-        const int g = (int)(((uint32_t)idx * 1457u) >> 16);                  // idx / 45 for idx < 9000
+        const int g = (int)((uint32_t)idx / 45u);
         const int o = idx - 45 * g;
         uint8_t* __restrict__ d = sg + (SGN_GROUP_DW * 4) * g + o;
         d[0] = (uint8_t)sb;
@@ -510,43 +511,29 @@ __device__ __forceinline__ uint32_t sign_pack(const int8_t* __restrict__ post, i
     }
     return z & 0x80808080u;
 }
-// 64 sign bits of group g starting at bit a (0 <= a < 360), cyclic
-__device__ __forceinline__ unsigned long long sign_fetch(const uint32_t* __restrict__ S, int g, int a) {
-    const uint32_t* __restrict__ p = S + SGN_GROUP_DW * g + (a >> 5);
-    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-    const uint32_t sh = (uint32_t)a & 31u;
-    const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
-    return ((unsigned long long)hi << 32) | lo;
-}
-template <int MAXDEG, bool IRREG>
-__device__ __forceinline__ bool syndromes_bad(const LdpcKernelArgs& A, const LdpcLayerDesc* __restrict__ layers, const uint32_t* __restrict__ ents_all,
-                                              const uint32_t* __restrict__ S, int j, int tps) {
-    const int pg0 = A.K / 360;                           // first parity group
+// the syndromes of 64 rows of one layer per lane: XOR of the 64-bit windows the plan's syndrome table names (ldpc_plan.h), one table
+// word and three sign dwords per link, all independent loads (two dependent global round trips per check in total)
+template <int MAXDEG>
+__device__ __forceinline__ bool syndromes_bad(const LdpcKernelArgs& A, const uint32_t* __restrict__ ents_all, const uint32_t* __restrict__ S, int j, int tps) {
     const int ntask = A.q * 6;
+    const uint32_t* __restrict__ tab = ents_all + A.synd_base;
     bool bad = false;
     for (int t = j; t < ntask; t += tps) {
-        const int layer = (int)(((uint32_t)t * 10923u) >> 16), w = t - 6 * layer;     // t / 6 for t < 16384
-        const int a0 = 64 * w;
-        unsigned long long acc = sign_fetch(S, pg0 + layer, a0);
-        if (layer) acc ^= sign_fetch(S, pg0 + layer - 1, a0);
-        else {                                           // row (0, j) links parity bit (q-1, j-1); row (0, 0) has no such link
-            unsigned long long v = sign_fetch(S, pg0 + A.q - 1, a0 ? a0 - 1 : 359);
-            if (w == 0) v &= ~1ull;
-            acc ^= v;
-        }
-        const uint32_t eoff = layers[layer].ent_off;
-        const int deg = IRREG ? (int)(layers[layer].deg & 0xffffu) : MAXDEG;
-        const uint32_t* __restrict__ e = ents_all + eoff;
+        uint32_t e[MAXDEG + 2];
 #pragma unroll
-        for (int k = 0; k < MAXDEG; ++k) {
-            if (!IRREG || k < deg) {
-                const uint32_t en = e[k];
-                int a = a0 + (int)(en & 0xffffu);
-                a = a >= 360 ? a - 360 : a;
-                acc ^= sign_fetch(S, (int)(en >> 16), a);
-            }
+        for (int k = 0; k < MAXDEG + 2; ++k) e[k] = tab[k * ntask + t];
+        unsigned long long acc = 0;
+#pragma unroll
+        for (int k = 0; k < MAXDEG + 2; ++k) {
+            const uint32_t* __restrict__ p = S + (e[k] & 0xffffu);         // (absent links: entry 0 -> a harmless read of the first dwords)
+            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+            const uint32_t sh = (e[k] >> 16) & 31u;
+            uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+            lo &= ~((e[k] >> 30) & 1u);                                      // row 0 of layer 0 has no previous parity bit
+            const uint32_t m = (uint32_t)((int)e[k] >> 31);                  // present?
+            acc ^= ((unsigned long long)(hi & m) << 32) | (lo & m);
         }
-        if (w == 5) acc &= (1ull << 40) - 1;             // rows 320..359
+        if (t - 6 * (t / 6) == 5) acc &= (1ull << 40) - 1;                   // rows 320..359
         bad |= acc != 0;
     }
     return bad;
@@ -609,7 +596,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
             if (check && valid) zflag = sign_pack(post, N, reinterpret_cast<uint8_t*>(sgn), j, LDPC_TPS);
             if (any_check) __syncthreads();              // the sign bytes went to global memory: full barrier (drains vmcnt), once per iteration
             if (check) {
-                bool bad = valid ? (zflag != 0 || syndromes_bad<MAXDEG, IRREG>(A, layers, ents, sgn, j, LDPC_TPS)) : false;
+                bool bad = valid ? (zflag != 0 || syndromes_bad<MAXDEG>(A, ents, sgn, j, LDPC_TPS)) : false;
                 unsigned long long b = __ballot(bad);
                 if ((j & 63) == 0) s_flag[fs][j >> 6] = (b != 0);
             }
@@ -768,7 +755,7 @@ hipError_t ldpc_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nf
         if (e != hipSuccess) return e;
     }
     A.llr = llr; A.hard = hard; A.post = post; A.trials = trials; A.msg_ws = msg_ws;
-    A.nframes = nframes; A.N = C.N; A.K = C.K; A.R = C.R; A.q = C.q; A.pent_base = C.pent_base;
+    A.nframes = nframes; A.N = C.N; A.K = C.K; A.R = C.R; A.q = C.q; A.pent_base = C.pent_base; A.synd_base = C.synd_base;
     A.max_trials = max_trials; A.force = force; A.hard_stride = hard_stride;
     A.prof = g_ldpc_prof;
     const int max_deg = C.max_deg, irregular = C.irregular;

@@ -50,6 +50,7 @@ struct LdpcPlan {
     std::vector<uint32_t> ents;   // per layer `deg` words sp | r<<16, then (from pent_base on) the pair-format table
     int pent_base = 0;            // pair table: per layer (max_deg+1)/2 pairs x 2 words {spA | spB<<16, 360*rA | 360*rB<<16}
     std::vector<uint32_t> rows;
+    int synd_base = 0;            // syndrome-check table (in ents[]): [max_deg + 2][q * 6] words, one per (link, layer, 64-row word), see below
 };
 
 inline LdpcPlan build_ldpc_plan(int code_index) {
@@ -149,6 +150,34 @@ inline LdpcPlan build_ldpc_plan(int code_index) {
             P.ents.push_back(w0);
             P.ents.push_back(w1);
         }
+    }
+    // syndrome-check table for the bit-vector form of LDPCDecoder::bad (ldpc_kernel.hip, syndromes_bad): task t = 6*layer + w covers rows
+    // 64w .. 64w+63 of a layer; entry [k][t] names the 64 sign bits link k contributes: bits 0..15 = dword index inside the packed sign
+    // scratch (14 dwords per 360-bit group: 14*g + (a >> 5)), bits 16..20 = a & 31 with a = (64w + sp) mod 360, bit 30 = drop bit 0
+    // (row 0 of layer 0 has no previous parity bit), bit 31 = present.  k < max_deg: information links, then own parity, previous parity.
+    P.synd_base = (int)P.ents.size();
+    {
+        const int ntask = d.q * 6, pg0 = d.K / 360;
+        auto entry = [](int g, int a, bool drop0) { return (uint32_t)(14 * g + (a >> 5)) | ((uint32_t)(a & 31) << 16) | (drop0 ? 1u << 30 : 0u) | (1u << 31); };
+        for (int k = 0; k < d.max_deg + 2; ++k)
+            for (int t = 0; t < ntask; ++t) {
+                const int layer = t / 6, w = t % 6;
+                const LdpcLayerDesc& L = P.layers[layer];
+                const int deg = (int)(L.deg & 0xffffu);
+                uint32_t e = 0;
+                if (k < d.max_deg) {
+                    if (k < deg) {
+                        const uint32_t en = P.ents[L.ent_off + k];
+                        e = entry((int)(en >> 16), (64 * w + (int)(en & 0xffffu)) % 360, false);
+                    }
+                } else if (k == d.max_deg) {
+                    e = entry(pg0 + layer, 64 * w, false);
+                } else {
+                    if (layer) e = entry(pg0 + layer - 1, 64 * w, false);
+                    else e = entry(pg0 + d.q - 1, (64 * w + 359) % 360, w == 0);
+                }
+                P.ents.push_back(e);
+            }
     }
     return P;
 }

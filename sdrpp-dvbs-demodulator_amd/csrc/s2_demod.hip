@@ -367,8 +367,8 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         // the MODCOD-independent stages already ran for the whole batch (frontend_prepass)
         for (int i = 0; i < n; ++i) nsym[i] = pre_nsym[i];
     } else {
-        HIP_TRY(s2_frontend_launch(d_work, n, d0->co, ctx->d_gardner_bank, st));
-        HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st));
+        { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(s2_frontend_launch(d_work, n, d0->co, ctx->d_gardner_bank, st)); }
+        { StageSpan sp(ctx->timers, ST_RRC, st); HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st)); }
         // symbol counts back (n_sym sits in each stream's state struct)
         HIP_TRY(s2_collect_launch(d_work, n, d_nsym, d_nco, st));
         HIP_TRY(hipMemcpyAsync(nsym.data(), d_nsym, sizeof(int) * n, hipMemcpyDeviceToHost, st));
@@ -414,7 +414,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         int* d_pos = (int*)(d_win + nw);
         float* d_bm = (float*)(d_pos + nw);
         HIP_TRY(hipMemcpyAsync(d_win, wins.data(), nw * sizeof(cf32*), hipMemcpyHostToDevice, st));
-        HIP_TRY(s2_plsync_launch(d_win, nw, raw, d_pos, d_bm, st));
+        { StageSpan sp(ctx->timers, ST_PLSYNC, st); HIP_TRY(s2_plsync_launch(d_win, nw, raw, d_pos, d_bm, st)); }
         std::vector<int> pos(nw);
         std::vector<float> bm(nw);
         HIP_TRY(hipMemcpyAsync(pos.data(), d_pos, nw * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -492,9 +492,12 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         d_bb = (uint8_t*)ws_bb.p;
         HIP_TRY(hipMemcpyAsync(d_frames, frames.data(), sizeof(S2FrameRef) * nf, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(d_first, first.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, st));
-        HIP_TRY(s2_frame_loops_launch(d_work, n, d_frames, d_first, d0->co, ctx->pl, CT->dev, d0->pls_code, mp.slots, mp.pilots,
-                                      mp.pilot_blocks, raw, d_pll, d_stats, st));
-        HIP_TRY(s2_demap_launch(CT->dev, mp.rate, mp.shortframe, mp.slots, mp.pilots, raw, d_pll, nf, d_llr, N, st));
+        {
+            StageSpan sp(ctx->timers, ST_LOOPS, st);
+            HIP_TRY(s2_frame_loops_launch(d_work, n, d_frames, d_first, d0->co, ctx->pl, CT->dev, d0->pls_code, mp.slots, mp.pilots,
+                                          mp.pilot_blocks, raw, d_pll, d_stats, st));
+        }
+        { StageSpan sp(ctx->timers, ST_DEMAP, st); HIP_TRY(s2_demap_launch(CT->dev, mp.rate, mp.shortframe, mp.slots, mp.pilots, raw, d_pll, nf, d_llr, N, st)); }
         const int force = d0->cfg.force_ldpc_iters > 0;
         const int mt = force ? d0->cfg.force_ldpc_iters : d0->cfg.max_ldpc_trials;
         // keep a copy of the demapper output for the tap before LDPC consumes it? LDPC does not modify d_llr.
@@ -514,7 +517,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
             out_bytes[i] = bytes;
         }
-        if (!pipelined) HIP_TRY(s2_scatter_out_launch(d_work, d_frames, d_first, nf, kb, d_bb, st));
+        if (!pipelined) { StageSpan sp(ctx->timers, ST_DELIVER, st); HIP_TRY(s2_scatter_out_launch(d_work, d_frames, d_first, nf, kb, d_bb, st)); }
     } else {
         for (int i = 0; i < n; ++i) { out_bytes[i] = 0; dm[i]->tap_pll = nullptr; dm[i]->tap_llr = nullptr; }
     }
@@ -563,7 +566,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
             out_bytes[i] = bytes;
         }
-        HIP_TRY(s2_scatter_out2_launch((uint8_t* const*)wo.p, job->d_frames, job->d_first, job->nf, job->kb, job->d_bb, st));
+        { StageSpan sp(ctx->timers, ST_DELIVER, st); HIP_TRY(s2_scatter_out2_launch((uint8_t* const*)wo.p, job->d_frames, job->d_first, job->nf, job->kb, job->d_bb, st)); }
         HIP_TRY(hipStreamSynchronize(st));
         for (int i = 0; i < n; ++i) {
             dm[i]->stats.clear();
@@ -649,8 +652,8 @@ int frontend_prepass(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const 
     int* d_nsym = (int*)((char*)ws.p + sizeof(S2StreamWork) * n);
     float* d_nco = (float*)(d_nsym + n);
     HIP_TRY(hipMemcpyAsync(d_work, work.data(), sizeof(S2StreamWork) * n, hipMemcpyHostToDevice, st));
-    HIP_TRY(s2_frontend_launch(d_work, n, d0->co, ctx->d_gardner_bank, st));
-    HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st));
+    { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(s2_frontend_launch(d_work, n, d0->co, ctx->d_gardner_bank, st)); }
+    { StageSpan sp(ctx->timers, ST_RRC, st); HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st)); }
     nsym_out->assign(n, 0);
     HIP_TRY(s2_collect_launch(d_work, n, d_nsym, d_nco, st));
     HIP_TRY(hipMemcpyAsync(nsym_out->data(), d_nsym, sizeof(int) * n, hipMemcpyDeviceToHost, st));

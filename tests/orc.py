@@ -82,6 +82,13 @@ def ref():
         L.ref_bb_descramble.restype = None
         L.ref_deinterleave.argtypes = [C.c_int, C.c_int, C.c_int, _i8p, _i8p]
         L.ref_deinterleave.restype = None
+        if hasattr(L, 'ref_fec16_create'):       # (a prebuilt oracle/_ref of an older checkout may lack these)
+            L.ref_fec16_create.argtypes = [C.c_int, C.c_int]
+            L.ref_fec16_create.restype = C.c_void_p
+            L.ref_fec16_destroy.argtypes = [C.c_void_p]
+            L.ref_fec16_destroy.restype = None
+            L.ref_fec16_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+            L.ref_build_flags.restype = C.c_char_p
         _ref = L
     return _ref
 
@@ -125,7 +132,7 @@ class DemodCfg(C.Structure):
 class TxCfg(C.Structure):
     _fields_ = [('modcod', C.c_int), ('shortframes', C.c_int), ('pilots', C.c_int), ('nframes', C.c_int), ('seed', C.c_uint64),
                 ('esn0_db', C.c_double), ('cfo', C.c_double), ('timing', C.c_double), ('phase0', C.c_double), ('lead_symbols', C.c_int),
-                ('circular', C.c_int)]
+                ('circular', C.c_int), ('nsamples', C.c_int)]
 
 
 class FrameStats(C.Structure):
@@ -200,13 +207,14 @@ def modcod_params(modcod, short=0, pilots=0):
     return d
 
 
-def transmit(modcod, short=0, pilots=0, nframes=2, seed=1, esn0_db=200.0, cfo=0.0, timing=0.0, phase0=0.0, lead_symbols=0, circular=0):
-    """-> (iq complex64 [n], bbframes uint8 [nframes, kbch/8], symbols complex64)"""
+def transmit(modcod, short=0, pilots=0, nframes=2, seed=1, esn0_db=200.0, cfo=0.0, timing=0.0, phase0=0.0, lead_symbols=0, circular=0, nsamples=0):
+    """-> (iq complex64 [n], bbframes uint8 [nframes, kbch/8], symbols complex64); nsamples != 0: resampled to that many samples
+    (sampling-clock error), default exactly 2 per symbol"""
     L = _bind_chain()
-    t = TxCfg(modcod, short, pilots, nframes, seed, esn0_db, cfo, timing, phase0, lead_symbols, circular)
+    t = TxCfg(modcod, short, pilots, nframes, seed, esn0_db, cfo, timing, phase0, lead_symbols, circular, nsamples)
     mp = modcod_params(modcod, short, pilots)
     nsym = lead_symbols + nframes * mp['plframe']
-    iq = np.zeros(2 * nsym, np.complex64)
+    iq = np.zeros(nsamples if nsamples else 2 * nsym, np.complex64)
     bb = np.zeros((nframes, mp['kbch'] // 8), np.uint8)
     syms = np.zeros(nsym, np.complex64)
     n = L.orc_s2_transmit(C.byref(t), iq.ctypes.data, iq.size, bb.ctypes.data, syms.ctypes.data, syms.size)

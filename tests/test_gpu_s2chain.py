@@ -264,41 +264,25 @@ def test_mixed_modcod_batch_matches_single(engine):
 
 def test_pipelined_full_load_every_stream_bit_exact(engine, pkg):
     """Throughput mode at the bench's load (2048 streams, 8PSK 3/4 normal frames, 50 forced LDPC iterations): the decoder of call k
-    shares the CUs with the front-end kernels of call k+1 for several multi-frame rounds per workgroup.  Every stream of the last
-    overlapped step and of the flush must deliver exactly a transmitted BBFRAME.  (Regression: a hand-scheduled LDPC chain-walk
-    loop was bit-exact alone and wrong only while front-end kernels were co-resident.)"""
+    shares the CUs with the front-end kernels of call k+1 for several multi-frame rounds per workgroup.  Every frame of every stream of
+    the last overlapped step and of the flush must be a transmitted BBFRAME, in sequence (bench.FrameChecker: device-side hash + full
+    byte compare).  (Regression: a hand-scheduled LDPC chain-walk loop was bit-exact alone and wrong only while front-end kernels were
+    co-resident.)"""
     import torch
     import bench as B
-    S = 2048
-    info = pkg.modcod_info(B.MODCOD, bool(B.SHORT), bool(B.PILOTS))
-    kb = info['kbch'] // 8
-    blocks, sent = B.make_blocks(1, seed=5, eng=engine, pkg=pkg)
-    d_blocks = [torch.from_numpy(b).cuda() for b in blocks]
-    cfg = engine.default_cfg(B.MODCOD, bool(B.SHORT), bool(B.PILOTS), force_ldpc_iters=B.ITERS)
-    demods = [engine.demod(cfg, max_samples=blocks[0].size) for _ in range(S)]
-    tin = [d_blocks[s % B.DISTINCT] for s in range(S)]
-    tout = [torch.zeros(3 * kb, dtype=torch.uint8, device='cuda') for _ in range(S)]
-    sets = [set(x) for x in sent]
-
-    def bad_streams(nb):
-        out = []
-        for s in range(S):
-            got = tout[s][:nb[s]].cpu().numpy().reshape(-1, kb)
-            if nb[s] != kb or not all(bytes(x) in sets[s % B.DISTINCT] for x in got):
-                out.append(s)
-        return out
-
+    S, F = 2048, 2
+    run = B.S2Run(engine, pkg, torch.device('cuda', 0), B.MODCOD, B.SHORT, B.PILOTS, 14.0, S, F, 16, seed=5)
     engine.set_pipelined(True)
     try:
-        for _ in range(B.PREROLL + 3):
-            nb = engine.process_batch(demods, tin, tout)
-        assert bad_streams(nb) == []
-        nb = engine.process_batch(demods, [torch.empty(0, dtype=torch.complex64, device='cuda') for _ in range(S)], tout)
-        assert bad_streams(nb) == []
+        for _ in range(B.PREROLL_FRAMES // F + 3):
+            nb = run.step()
+        a = run.check(nb)
+        assert a['delivered'] >= S * F - S // 8 and a['equal'] == a['delivered'] and a['out_of_order'] == 0, a
+        a = run.check(run.flush())
+        assert a['delivered'] >= S * F - S // 8 and a['equal'] == a['delivered'] and a['out_of_order'] == 0, a
     finally:
         engine.set_pipelined(False)
-        for d in demods:
-            d.close()
+        run.close()
 
 
 def test_every_qpsk_and_8psk_modcod_in_one_mixed_batch(engine, pkg):

@@ -13,22 +13,18 @@ F = int(os.environ.get('FRAMES', '4'))
 info = pkg.modcod_info(B.MODCOD, bool(B.SHORT), bool(B.PILOTS))
 kb = info['kbch'] // 8
 sym = info['plframe_symbols']
-blocks, sent = B.make_blocks(F, seed=0, eng=eng, pkg=pkg)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
 for S in (1, 8, 64, 512):
-    cfg = eng.default_cfg(B.MODCOD, bool(B.SHORT), bool(B.PILOTS), force_ldpc_iters=B.ITERS)
-    demods = [eng.demod(cfg, max_samples=blocks[0].size) for _ in range(S)]
-    tin = [torch.from_numpy(blocks[s % len(blocks)]).cuda() for s in range(S)]
-    tout = [torch.zeros((F + 2) * kb, dtype=torch.uint8, device='cuda') for _ in range(S)]
-    for _ in range(B.PREROLL // F + 2):
-        eng.process_batch(demods, tin, tout)
+    run = B.S2Run(eng, pkg, torch.device('cuda', 0), B.MODCOD, B.SHORT, B.PILOTS, 14.0, S, F, 4, seed=0)
+    for _ in range(B.PREROLL_FRAMES // F + 2):
+        run.step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     reps = 5
     for _ in range(reps):
-        nb = eng.process_batch(demods, tin, tout)
+        nb = run.step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    print('%4d stream(s) x %d frames per call: %.2f ms per call = %.3f Msym/s per stream, %.1f Msym/s total (frames out: %d)'
-          % (S, F, dt * 1e3, F * sym / dt / 1e6, S * F * sym / dt / 1e6, nb[0] // kb))
-    for d in demods:
-        d.close()
+    print('%4d stream(s) x %d frames per call: %.2f ms per call = %.3f Msym/s per stream, %.1f Msym/s total (frames out: %d, check %s)'
+          % (S, F, dt * 1e3, F * sym / dt / 1e6, S * F * sym / dt / 1e6, nb[0] // kb, run.check(nb)))
+    run.close()
