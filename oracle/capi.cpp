@@ -162,7 +162,7 @@ int orc_s2_transmit(const TxCfg* t, float* iq, int iq_cap, uint8_t* bbframes, fl
     std::vector<cf> syms;
     std::vector<cf> v = s2_transmit(*t, &bb, &syms);
     if (iq && (int)v.size() <= iq_cap) memcpy(iq, v.data(), v.size() * sizeof(cf));
-    if (bbframes) memcpy(bbframes, bb.data(), bb.size());
+    if (bbframes && !bb.empty()) memcpy(bbframes, bb.data(), bb.size());
     if (symbols && (int)syms.size() <= sym_cap) memcpy(symbols, syms.data(), syms.size() * sizeof(cf));
     return (int)v.size();
 }

@@ -261,6 +261,7 @@ DemodCfg default_cfg(int modcod, int shortframes, int pilots) {   // main.cpp:64
     c.omega_rel_limit = 0.02f;
     c.modcod = modcod; c.shortframes = shortframes; c.pilots = pilots;
     c.sof_threshold = 0.6f; c.max_ldpc_trials = 16; c.force_ldpc_iters = 0;
+    c.acm_vcm = 0; c.soft_plsc = 0; c.pilot_aided = 0;
     return c;
 }
 
@@ -293,6 +294,9 @@ S2Rx::S2Rx(const DemodCfg& c) : mp(mp_of(c)), cfg(c), constel(mp.constel, mp.g1,
     pls_code = cfg.modcod << 2 | (cfg.shortframes ? 2 : 0) | (cfg.pilots ? 1 : 0);
     ldpc = get_ldpc(mp.fec.code_index);
     bch = get_bch(mp.fec);
+    ccm = FrameCtx{mp, pls_code, &constel, ldpc, bch, false};
+    vcm_ctx.resize(128);
+    vcm_constel.resize(128);
     in_buffer.assign(mp.plframe, cf{0, 0});
     corr_buffer.assign(mp.plframe, cf{0, 0});
     reset();
@@ -308,6 +312,7 @@ void S2Rx::reset() {
                (float)(1.0 * (1.0 + cfg.omega_rel_limit)), false);
     cr_samp = false;
     in_ptr = 0; in_lim = mp.plframe; in_state = 0; best_pos = 0; last_bm = 0;
+    vfifo.clear(); vcm_synced = false;
     float a, b;
     critically_damped(cfg.loop_bw, &a, &b);
     pll_pcl.init(a, b, 0, -(float)M_PI, (float)M_PI, 0, -0.01f * (float)M_PI, 0.01f * (float)M_PI, true);
@@ -450,8 +455,10 @@ int S2Rx::plsync_internal(std::vector<cf>& out, float* best_match_out) {
 // symbol index (inside the PLFRAME) of pilot block b, standard layout
 static inline int pilot_start(int b) { return 90 + (b + 1) * 1440 + b * 36; }
 
-float S2Rx::coarse_fed(const cf* frame) const {   // dvbs2_fed.h:7-48 (pilot blocks at their standard positions)
+float S2Rx::coarse_fed(const cf* frame, const FrameCtx& fc) const {   // dvbs2_fed.h:7-48 (pilot blocks at their standard positions)
     const PlTables& T = pl_tables();
+    const s2::ModcodParams& mp = fc.mp;
+    const int pls_code = fc.pls_code;
     float err = 0, symcnt = 90 - 2;
     auto term = [&](cf a2, cf r2, cf a0, cf r0) { return cmul(cmul(cmul(a2, cconj(r2)), cconj(a0)), r0).im; };
     auto refsym = [&](int i) { return i < 26 ? T.sof[i] : T.plsc_sym[pls_code][i - 26]; };
@@ -475,13 +482,30 @@ float S2Rx::coarse_fed(const cf* frame) const {   // dvbs2_fed.h:7-48 (pilot blo
     return err / symcnt;
 }
 
-void S2Rx::pll(const cf* in, cf* out) {   // dvbs2_pll.cpp:34-86
+void S2Rx::pll(const cf* in, cf* out, const FrameCtx& fc) {   // dvbs2_pll.cpp:34-86
     const PlTables& T = pl_tables();
+    const s2::ModcodParams& mp = fc.mp;
+    const int pls_code = fc.pls_code;
+    const Constellation& constel = *fc.constel;
     const int total = mp.plframe;
     int next_pilot = mp.pilots && mp.pilot_blocks > 0 ? pilot_start(0) : -1, pb = 0;
+    // pilot-aided mode (own extension; off = the reference's loop): the known symbols -- the 90 header symbols
+    // and every 36-symbol pilot block -- additionally give a BLOCK estimate of the residual phase, the argument of the sum of
+    // (derotated symbol x conj(known symbol)); at the end of the block the loop phase is moved by it.  The decision-directed loop
+    // between the blocks is unchanged, but it can no longer stay in one of the constellation's rotational false locks.
+    cf acc{0, 0};
+    auto snap = [&]() {
+        if (!cfg.pilot_aided) return;
+        if (acc.re != 0.f || acc.im != 0.f) {
+            pll_pcl.phase += cphase(acc);
+            pll_pcl.advance(0.f);                       // (wraps the phase; the frequency moves by beta * 0)
+        }
+        acc = cf{0, 0};
+    };
     for (int i = 0; i < total; i++) {
         cf tmp_val = cmul(in[i], phasor(-pll_pcl.phase));
         float error = 0;
+        bool block_end = false;
         if (i >= 90) {
             cf descr = pl_descramble(tmp_val, T.Rn[i - 90]);
             bool is_pilot = false;
@@ -489,20 +513,55 @@ void S2Rx::pll(const cf* in, cf* out) {   // dvbs2_pll.cpp:34-86
             if (!is_pilot) {
                 constel.soft_lut(tmp_val, nullptr, &error);
             } else {
-                error = cphase(cmul(descr, cf{0.707f, -0.707f}));   // data-aided on the known (1+j)/sqrt2 pilot
-                if (i == next_pilot + 35) { ++pb; next_pilot = pb < mp.pilot_blocks ? pilot_start(pb) : -1; }
+                const cf pr = cmul(descr, cf{0.707f, -0.707f});
+                error = cphase(pr);   // data-aided on the known (1+j)/sqrt2 pilot
+                acc = cadd(acc, pr);
+                if (i == next_pilot + 35) { ++pb; next_pilot = pb < mp.pilot_blocks ? pilot_start(pb) : -1; block_end = true; }
             }
             out[i] = descr;
         } else {
-            if (i < 26) error = cphase(cmul(tmp_val, cconj(T.sof[i])));
-            else error = cphase(cmul(tmp_val, cconj(T.plsc_sym[pls_code][i - 26])));
+            const cf pr = cmul(tmp_val, cconj(i < 26 ? T.sof[i] : T.plsc_sym[pls_code][i - 26]));
+            error = cphase(pr);
+            acc = cadd(acc, pr);
+            block_end = i == 89;
             out[i] = (i & 1) ? cf{-tmp_val.re, tmp_val.im} : cf{tmp_val.im, tmp_val.re};
         }
         pll_pcl.advance(error);
+        if (block_end) snap();
     }
 }
 
-void S2Rx::plhdr(const cf* in, cf* out, int* modcod, int* sh, int* pil) {   // dvbs2_plhdr_demod.cpp:33-79
+int soft_plsc_decode(const float soft[64], float* ratio) {
+    const PlTables& T = pl_tables();
+    float best = 0.f;
+    int bi = 0;
+    for (int c = 0; c < 128; ++c) {
+        float m = 0.f;
+        for (int p = 0; p < 64; ++p) m += ((T.plsc_code[c] >> (63 - p)) & 1) ? -soft[p] : soft[p];
+        if (c == 0 || m > best) { best = m; bi = c; }
+    }
+    float tot = 0.f;
+    for (int p = 0; p < 64; ++p) tot += fabsf(soft[p]);
+    if (ratio) *ratio = tot > 0.f ? best / tot : 0.f;
+    return bi;
+}
+
+int S2Rx::pls_at(const cf* x, float* ratio, float* sofq) {
+    const PlTables& T = pl_tables();
+    cf z{0, 0};
+    float amp = 0.f;
+    for (int k = 0; k < 26; ++k) { z = cadd(z, cmul(x[k], cconj(T.sof[k]))); amp += camp(x[k]); }
+    *sofq = amp > 0.f ? camp(z) / amp : 0.f;
+    float soft[64];
+    for (int p = 0; p < 64; ++p) {
+        // pi/2-BPSK: even positions sit on +-(1+j)/sqrt2, odd ones on +-(-1+j)/sqrt2 (s2_defs.h:60-80); bit 0 = the + sign
+        const cf w = cmul(x[26 + p], cconj(z));
+        soft[p] = (p & 1) ? (w.im - w.re) : (w.re + w.im);
+    }
+    return soft_plsc_decode(soft, ratio);
+}
+
+void S2Rx::plhdr(const cf* in, cf* out, int* modcod, int* sh, int* pil, int plframe) {   // dvbs2_plhdr_demod.cpp:33-79
     const PlTables& T = pl_tables();
     for (int i = 0; i < 90; i++) {
         cf tmp_val = cmul(in[i], phasor(-hdr_pcl.phase));
@@ -510,7 +569,7 @@ void S2Rx::plhdr(const cf* in, cf* out, int* modcod, int* sh, int* pil) {   // d
         out[i] = (i & 1) ? cf{-tmp_val.re, tmp_val.im} : cf{tmp_val.im, tmp_val.re};
         hdr_pcl.advance(error);
     }
-    hdr_pcl.phase += hdr_pcl.freq * (mp.plframe - 91);
+    hdr_pcl.phase += hdr_pcl.freq * (plframe - 91);
     hdr_pcl.advance(0);
     uint64_t plheader = 0;
     const cf rot{(float)0.70710678118654757, (float)-0.70710678118654746};   // (cos, sin)(-pi/4) in double, cast (dvbs2_plhdr_demod.cpp:48)
@@ -519,6 +578,12 @@ void S2Rx::plhdr(const cf* in, cf* out, int* modcod, int* sh, int* pil) {   // d
         plheader = plheader << 1 | (uint64_t)(!value);
     }
     int best = 0, diffs = 64;
+    if (cfg.soft_plsc) {
+        // own extension: soft ML decode over all 64 bits of the demodulated header
+        float soft[64];
+        for (int y = 0; y < 64; y++) soft[y] = cmul(out[26 + y], rot).re;
+        best = soft_plsc_decode(soft, nullptr);
+    } else
     for (int c = 0; c < 128; c++) {
         uint64_t x = (T.plsc_code[c] ^ plheader) & ((1ull << 60) - 1);   // only bits 59..0 are compared (:71)
         int d = __builtin_popcountll(x);
@@ -527,7 +592,9 @@ void S2Rx::plhdr(const cf* in, cf* out, int* modcod, int* sh, int* pil) {   // d
     *modcod = (best >> 2) & 31; *sh = (best & 2) >> 1; *pil = best & 1;
 }
 
-void S2Rx::to_soft(const cf* pllout, int8_t* llr) const {   // dvbs2_bb_to_soft.cpp:7-33 with pilots skipped
+void S2Rx::to_soft(const cf* pllout, int8_t* llr, const FrameCtx& fc) const {   // dvbs2_bb_to_soft.cpp:7-33 with pilots skipped
+    const s2::ModcodParams& mp = fc.mp;
+    const Constellation& constel = *fc.constel;
     const int bits = mp.bits, N = mp.fec.N;
     std::vector<int8_t> soft(N);
     int sym = 90, idx = 0;
@@ -536,6 +603,123 @@ void S2Rx::to_soft(const cf* pllout, int8_t* llr) const {   // dvbs2_bb_to_soft.
         if (mp.pilots && ((slot + 1) % 16 == 0) && slot + 1 < mp.slots) sym += 36;
     }
     s2_deinterleave(mp.constel, mp.rate, mp.shortframe, soft.data(), llr);
+}
+
+const S2Rx::FrameCtx* S2Rx::ctx_for_pls(int pls) {
+    if (pls < 0 || pls > 127) return nullptr;
+    if (vcm_ctx[pls]) return vcm_ctx[pls].get();
+    const int modcod = pls >> 2, sh = (pls >> 1) & 1, pil = pls & 1;
+    auto fc = std::make_unique<FrameCtx>();
+    if (modcod == 0) {                                   // dummy PLFRAME: header + 36 unmodulated slots, nothing to decode
+        fc->mp = s2::ModcodParams{};
+        fc->mp.modcod = 0; fc->mp.plframe = VCM_DUMMY_PLFRAME; fc->mp.slots = 36;
+        fc->pls_code = pls; fc->constel = nullptr; fc->ldpc = nullptr; fc->bch = nullptr; fc->dummy = true;
+    } else {
+        s2::ModcodParams p;
+        if (!s2::modcod_params(modcod, sh, pil, &p)) return nullptr;
+        vcm_constel[pls] = std::make_unique<Constellation>(p.constel, p.g1, p.g2);
+        fc->mp = p; fc->pls_code = pls; fc->constel = vcm_constel[pls].get();
+        fc->ldpc = get_ldpc(p.fec.code_index); fc->bch = get_bch(p.fec); fc->dummy = false;
+    }
+    vcm_ctx[pls] = std::move(fc);
+    return vcm_ctx[pls].get();
+}
+
+// one aligned PLFRAME through FED -> NCO feedback -> PLL -> PLHDR -> demap -> FEC (module_dvbs2_demod.cpp:317-366)
+void S2Rx::process_frame(const cf* frame, const FrameCtx& fc, float best_match, uint8_t* out, int out_cap, int* outcnt) {
+    const s2::ModcodParams& m = fc.mp;
+    const int kb = m.fec.kbch / 8;
+    std::vector<cf> pllout(m.plframe), hdr(90);
+    std::vector<int8_t> llr(m.fec.N);
+    FrameStats st{};
+    st.best_match = best_match;
+    st.bbframe_bytes = kb;
+    float est = coarse_fed(frame, fc);   // module_dvbs2_demod.cpp:319-331
+    st.fed_err = est;
+    if (std::abs(est) < 0.02) nco_freq_ = nco_freq_ + est * (cfg.fll_bw / 100.0f);
+    else nco_freq_ = nco_freq_ + est * cfg.fll_bw;
+    if (nco_freq_ > 0.3f * (float)M_PI) nco_freq_ = 0.3f * (float)M_PI;
+    if (nco_freq_ < -0.3f * (float)M_PI) nco_freq_ = -0.3f * (float)M_PI;
+    pll(frame, pllout.data(), fc);
+    plhdr(frame, hdr.data(), &st.detect_modcod, &st.detect_short, &st.detect_pilots, m.plframe);
+    for (int k = 0; k < 90; ++k) pllout[k] = hdr[k];
+    to_soft(pllout.data(), llr.data(), fc);
+    dbg_frames.insert(dbg_frames.end(), frame, frame + m.plframe);
+    dbg_pll.insert(dbg_pll.end(), pllout.begin(), pllout.end());
+    dbg_llr.insert(dbg_llr.end(), llr.begin(), llr.end());
+    if (cfg.force_ldpc_iters < 0) { dbg_stats.push_back(st); return; }   // front-end timing only (bench cpu_baseline)
+    int mt = cfg.force_ldpc_iters ? cfg.force_ldpc_iters : cfg.max_ldpc_trials;
+    st.ldpc_trials = ldpc_decode(*fc.ldpc, llr.data(), mt, cfg.force_ldpc_iters ? 1 : 0);
+    std::vector<uint8_t> fr(m.fec.K / 8);
+    hard_pack(llr.data(), m.fec.K, fr.data());
+    st.bch_corr = bch_decode(*fc.bch, fr.data());
+    bb_descramble(fr.data(), kb);
+    if (*outcnt + kb <= out_cap) { memcpy(out + *outcnt, fr.data(), kb); *outcnt += kb; }
+    dbg_stats.push_back(st);
+}
+
+// ACM/VCM framing (own definition; the reference's PL sync assumes ONE frame length, dvbs2_pl_sync.cpp:81-165, and its GUI re-configures
+// the whole demodulator after 50 consistent PLS sightings, main.cpp:375-408).  Works on the FIFO of 1-sps symbols:
+//   not locked: the reference's differential SOF + PLSC correlator (dvbs2_pl_sync.cpp:111-143: it does not depend on the MODCOD) over the
+//               next VCM_ACQ_WINDOW offsets; the best one (same arg-max rule) becomes the frame start.
+//   locked:     soft PLS decode at the frame start (pls_at); a valid code with correlation ratio >= VCM_MIN_RATIO and SOF quality >=
+//               sof_threshold names the frame's MODCOD / size / pilots and thereby its length; the frame is handed on when all its
+//               symbols are in, the next header is expected right behind it.  Anything else drops the lock and the search resumes one
+//               symbol further.
+// Dummy PLFRAMEs (MODCOD 0) only advance the framing.  A frame's statistics report its PLS code and SOF quality.
+void S2Rx::vcm_walk(uint8_t* out, int out_cap, int* outcnt) {
+    size_t cur = 0;
+    while (true) {
+        const size_t avail = vfifo.size() - cur;
+        if (!vcm_synced) {
+            if (avail < (size_t)VCM_ACQ_WINDOW + 90) break;
+            const cf* w = &vfifo[cur];
+            const uint32_t dsof = 0x18d2e82u ^ (0x18d2e82u >> 1);
+            const uint64_t SCR = 0x719d83c953422dfaull;
+            const uint64_t dscr = SCR ^ (SCR >> 1);
+            double best_match = 0;
+            int bp = 0;
+            cf d90[90];
+            for (int ss = 0; ss < VCM_ACQ_WINDOW; ss++) {
+                d90[0] = cf{0, 0};
+                for (int k = 1; k < 90; ++k) d90[k] = cmul(cconj(w[ss + k - 1]), w[ss + k]);
+                cf csof{0, 0};
+                for (int i = 0; i < 26; ++i) {
+                    if (((dsof >> (25 - i)) ^ i) & 1) csof = cadd(csof, d90[i]);
+                    else csof = csub(csof, d90[i]);
+                }
+                cf cpl{0, 0};
+                for (int i = 1; i < 64; i += 2) {
+                    if ((dscr >> (63 - i)) & 1) cpl = csub(cpl, d90[26 + i]);
+                    else cpl = cadd(cpl, d90[26 + i]);
+                }
+                cf c0 = cadd(csof, cpl), c1 = csub(csof, cpl);
+                cf c = camp(c0) > camp(c1) ? c0 : c1;
+                cf d = cscale(c, 1.0f / (26 - 1 + 64 / 2));
+                double difference = camp(d);
+                if (difference > best_match && d.im > 0) { best_match = difference; bp = ss; }
+            }
+            if (best_match > 0) { cur += bp; vcm_synced = true; }
+            else cur += VCM_ACQ_WINDOW;
+            continue;
+        }
+        if (avail < 90) break;
+        float ratio, sofq;
+        const int pls = pls_at(&vfifo[cur], &ratio, &sofq);
+        const FrameCtx* fc = (ratio >= VCM_MIN_RATIO && sofq >= cfg.sof_threshold) ? ctx_for_pls(pls) : nullptr;
+        if (!fc) { vcm_synced = false; cur += 1; continue; }
+        if (avail < (size_t)fc->mp.plframe) break;
+        if (fc->dummy) {
+            FrameStats st{};
+            st.best_match = sofq; st.detect_modcod = 0; st.detect_short = (pls >> 1) & 1; st.detect_pilots = pls & 1;
+            st.ldpc_trials = 0; st.bch_corr = 0; st.bbframe_bytes = 0;
+            dbg_stats.push_back(st);
+        } else {
+            process_frame(&vfifo[cur], *fc, sofq, out, out_cap, outcnt);
+        }
+        cur += fc->mp.plframe;
+    }
+    vfifo.erase(vfifo.begin(), vfifo.begin() + cur);
 }
 
 int S2Rx::process(int count, const cf* in, uint8_t* out, int out_cap) {
@@ -552,9 +736,12 @@ int S2Rx::process(int count, const cf* in, uint8_t* out, int out_cap) {
     }
     dbg_symbols = syms;
     int outcnt = 0;
-    const int kb = mp.fec.kbch / 8;
-    std::vector<cf> frame, pllout(mp.plframe), hdr(90);
-    std::vector<int8_t> llr(mp.fec.N);
+    if (cfg.acm_vcm) {
+        vfifo.insert(vfifo.end(), syms.begin(), syms.end());
+        vcm_walk(out, out_cap, &outcnt);
+        return outcnt;
+    }
+    std::vector<cf> frame;
     for (size_t i = 0; i < syms.size(); ++i) {   // dvbs2_pl_sync.cpp:81-100
         in_buffer[in_ptr++] = syms[i];
         if (in_ptr >= in_lim) {
@@ -563,30 +750,7 @@ int S2Rx::process(int count, const cf* in, uint8_t* out, int out_cap) {
             last_bm = bm;
             in_ptr = 0;
             if (!got) continue;
-            FrameStats st{};
-            st.best_match = bm;
-            float est = coarse_fed(frame.data());   // module_dvbs2_demod.cpp:319-331
-            st.fed_err = est;
-            if (std::abs(est) < 0.02) nco_freq_ = nco_freq_ + est * (cfg.fll_bw / 100.0f);
-            else nco_freq_ = nco_freq_ + est * cfg.fll_bw;
-            if (nco_freq_ > 0.3f * (float)M_PI) nco_freq_ = 0.3f * (float)M_PI;
-            if (nco_freq_ < -0.3f * (float)M_PI) nco_freq_ = -0.3f * (float)M_PI;
-            pll(frame.data(), pllout.data());
-            plhdr(frame.data(), hdr.data(), &st.detect_modcod, &st.detect_short, &st.detect_pilots);
-            for (int k = 0; k < 90; ++k) pllout[k] = hdr[k];
-            to_soft(pllout.data(), llr.data());
-            dbg_frames.insert(dbg_frames.end(), frame.begin(), frame.end());
-            dbg_pll.insert(dbg_pll.end(), pllout.begin(), pllout.end());
-            dbg_llr.insert(dbg_llr.end(), llr.begin(), llr.end());
-            if (cfg.force_ldpc_iters < 0) { dbg_stats.push_back(st); continue; }   // front-end timing only (bench cpu_baseline)
-            int mt = cfg.force_ldpc_iters ? cfg.force_ldpc_iters : cfg.max_ldpc_trials;
-            st.ldpc_trials = ldpc_decode(*ldpc, llr.data(), mt, cfg.force_ldpc_iters ? 1 : 0);
-            std::vector<uint8_t> fr(mp.fec.K / 8);
-            hard_pack(llr.data(), mp.fec.K, fr.data());
-            st.bch_corr = bch_decode(*bch, fr.data());
-            bb_descramble(fr.data(), kb);
-            if (outcnt + kb <= out_cap) { memcpy(out + outcnt, fr.data(), kb); outcnt += kb; }
-            dbg_stats.push_back(st);
+            process_frame(frame.data(), ccm, bm, out, out_cap, &outcnt);
         }
     }
     return outcnt;
@@ -609,34 +773,57 @@ static double rrc_cont(double t, double beta) {   // unit-energy RRC, t in symbo
 }
 
 std::vector<cf> s2_transmit(const TxCfg& t, std::vector<uint8_t>* bbframes_out, std::vector<cf>* symbols_out) {
-    s2::ModcodParams mp;
-    if (!s2::modcod_params(t.modcod, t.shortframes, t.pilots, &mp)) throw std::runtime_error("bad MODCOD");
     const PlTables& T = pl_tables();
-    Constellation C(mp.constel, mp.g1, mp.g2);
-    const LdpcCode* ldpc = get_ldpc(mp.fec.code_index);
-    const BchCode* bch = get_bch(mp.fec);
-    // normalise payload points to unit average power (the standard's convention); header is unit amplitude
-    double pw = 0;
-    for (int v = 0; v < C.states; ++v) { cf p = C.mod(v); pw += (double)p.re * p.re + (double)p.im * p.im; }
-    float norm = (float)(1.0 / std::sqrt(pw / C.states));
-    const int pls = t.modcod << 2 | (t.shortframes ? 2 : 0) | (t.pilots ? 1 : 0);
-    const int kb = mp.fec.kbch / 8, N = mp.fec.N, bits = mp.bits;
+    // per-frame parameters: CCM = the configured MODCOD for every frame, ACM/VCM = the PLS code list, cycled
+    struct Per { s2::ModcodParams mp; std::unique_ptr<Constellation> C; const LdpcCode* ldpc; const BchCode* bch; float norm; bool dummy; };
+    std::map<int, Per> per;
+    auto get = [&](int pls) -> Per& {
+        auto it = per.find(pls);
+        if (it != per.end()) return it->second;
+        Per P;
+        const int modcod = pls >> 2;
+        if (modcod == 0) {
+            P.mp = s2::ModcodParams{}; P.mp.plframe = VCM_DUMMY_PLFRAME; P.mp.slots = 36; P.dummy = true; P.norm = 1.f; P.ldpc = nullptr; P.bch = nullptr;
+        } else {
+            if (!s2::modcod_params(modcod, (pls >> 1) & 1, pls & 1, &P.mp)) throw std::runtime_error("bad MODCOD");
+            P.C = std::make_unique<Constellation>(P.mp.constel, P.mp.g1, P.mp.g2);
+            P.ldpc = get_ldpc(P.mp.fec.code_index);
+            P.bch = get_bch(P.mp.fec);
+            // normalise payload points to unit average power (the standard's convention); header is unit amplitude
+            double pw = 0;
+            for (int v = 0; v < P.C->states; ++v) { cf p = P.C->mod(v); pw += (double)p.re * p.re + (double)p.im * p.im; }
+            P.norm = (float)(1.0 / std::sqrt(pw / P.C->states));
+            P.dummy = false;
+        }
+        return per.emplace(pls, std::move(P)).first->second;
+    };
+    const int ccm_pls = t.modcod << 2 | (t.shortframes ? 2 : 0) | (t.pilots ? 1 : 0);
     std::vector<cf> syms;
     uint64_t rs = t.seed ^ 0xABCDEF12345ull;
     for (int i = 0; i < t.lead_symbols; ++i) {
         uint64_t r = sm64(rs);
         syms.push_back(cf{(r & 1) ? 0.70710678f : -0.70710678f, (r & 2) ? 0.70710678f : -0.70710678f});
     }
-    if (bbframes_out) bbframes_out->assign((size_t)t.nframes * kb, 0);
-    std::vector<uint8_t> code(N), inter(N), fr(mp.fec.K / 8);
+    if (bbframes_out) bbframes_out->clear();
     for (int f = 0; f < t.nframes; ++f) {
-        std::fill(fr.begin(), fr.end(), 0);
+        const int pls = t.vcm_n > 0 ? t.vcm_pls[f % t.vcm_n] : ccm_pls;
+        Per& P = get(pls);
+        const s2::ModcodParams& mp = P.mp;
+        for (int i = 0; i < 26; ++i) syms.push_back(T.sof[i]);
+        for (int i = 0; i < 64; ++i) syms.push_back(T.plsc_sym[pls][i]);
+        int scr = 0;
+        if (P.dummy) {
+            for (int k = 0; k < 36 * 90; ++k) syms.push_back(pl_scramble(cf{0.70710678f, 0.70710678f}, T.Rn[scr++]));
+            continue;
+        }
+        const int kb = mp.fec.kbch / 8, N = mp.fec.N, bits = mp.bits;
+        std::vector<uint8_t> code(N), inter(N), fr(mp.fec.K / 8);
         make_bbframe(fr.data(), mp.fec.kbch, t.seed * 1000003ull + f);
-        if (bbframes_out) memcpy(&(*bbframes_out)[(size_t)f * kb], fr.data(), kb);
+        if (bbframes_out) bbframes_out->insert(bbframes_out->end(), fr.begin(), fr.begin() + kb);
         bb_descramble(fr.data(), kb);
-        bch_encode(*bch, fr.data());
+        bch_encode(*P.bch, fr.data());
         for (int i = 0; i < mp.fec.K; ++i) code[i] = (fr[i / 8] >> (7 - i % 8)) & 1;
-        ldpc_encode(*ldpc, code.data());
+        ldpc_encode(*P.ldpc, code.data());
         // bit interleaver = inverse of s2_deinterleave
         if (mp.constel == s2::C_QPSK) {
             for (int i = 0; i < N / 2; ++i) { inter[2 * i] = code[2 * i + 1]; inter[2 * i + 1] = code[2 * i]; }
@@ -647,15 +834,13 @@ std::vector<cf> s2_transmit(const TxCfg& t, std::vector<uint8_t>* bbframes_out, 
             for (int j = 0; j < rows; ++j)
                 for (int c = 0; c < bits; ++c) inter[bits * j + c] = code[col[c] + j];
         }
-        for (int i = 0; i < 26; ++i) syms.push_back(T.sof[i]);
-        for (int i = 0; i < 64; ++i) syms.push_back(T.plsc_sym[pls][i]);
-        int sidx = 0, scr = 0;
+        int sidx = 0;
         for (int slot = 0; slot < mp.slots; ++slot) {
             for (int k = 0; k < 90; ++k) {
                 int v = 0;
                 for (int b = 0; b < bits; ++b) v = (v << 1) | (inter[(size_t)sidx * bits + b] ^ 1);   // labels are complemented
                 ++sidx;
-                syms.push_back(pl_scramble(cscale(C.mod(v), norm), T.Rn[scr++]));
+                syms.push_back(pl_scramble(cscale(P.C->mod(v), P.norm), T.Rn[scr++]));
             }
             if (mp.pilots && ((slot + 1) % 16 == 0) && slot + 1 < mp.slots)
                 for (int k = 0; k < 36; ++k) syms.push_back(pl_scramble(cf{0.70710678f, 0.70710678f}, T.Rn[scr++]));

@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <vector>
 #include <cmath>
+#include <memory>
 #include "oracle.h"
 #include "../include/dvbs2gpu_math.h"   // the engine's definition of sin/cos/atan2/exp/log (shared with the device code on purpose)
 
@@ -86,10 +87,21 @@ struct DemodCfg {           // same fields / meaning as dvbs2gpu_demod_cfg in in
     int modcod, shortframes, pilots;
     float sof_threshold;
     int max_ldpc_trials, force_ldpc_iters;
+    int acm_vcm;       // 1: ACM/VCM receive mode -- the PL framing follows the PLS code of every frame (see S2Rx::vcm_walk)
+    int soft_plsc;     // 1: PLHDR demod decodes the PLS code by soft correlation over all 64 bits instead of the reference's 60-bit hard compare
+    int pilot_aided;   // 1: the PLL takes its error from the known header / pilot symbols only and coasts over the payload
 };
 DemodCfg default_cfg(int modcod, int shortframes, int pilots);
 
-struct FrameStats { float best_match; int detect_modcod, detect_short, detect_pilots; float fed_err; int ldpc_trials, bch_corr; };
+// soft ML decoder of the PLS code RM(64,7) (EN 302 307 5.5.2.4): argmax over the 128 scrambled codewords of sum_p soft[p] * (1 - 2 bit_p),
+// soft[p] > 0 <=> bit 0; sums in index order, lowest index wins ties.  *ratio = best metric / sum |soft| (1 = noiseless).
+int soft_plsc_decode(const float soft[64], float* ratio);
+
+constexpr int VCM_ACQ_WINDOW = 33282;        // acquisition search span = the longest PLFRAME (QPSK normal with pilots)
+constexpr float VCM_MIN_RATIO = 0.5f;        // PLS decodes below this correlation ratio count as "no header here"
+constexpr int VCM_DUMMY_PLFRAME = 3330;      // dummy PLFRAME (MODCOD 0): 36 unmodulated slots
+
+struct FrameStats { float best_match; int detect_modcod, detect_short, detect_pilots; float fed_err; int ldpc_trials, bch_corr; int bbframe_bytes; };
 
 // Mirror of DVBS2Demod (module_dvbs2_demod.cpp) with every frame LDPC-decoded and BBFRAMEs
 // emitted in the call that completes them.
@@ -106,6 +118,9 @@ public:
     std::vector<FrameStats> dbg_stats;
     float nco_freq() const { return nco_freq_; }
     s2::ModcodParams mp;
+    // what a frame is processed with: CCM = the configured MODCOD, ACM/VCM = the MODCOD its PLS code names
+    struct FrameCtx { s2::ModcodParams mp; int pls_code; const Constellation* constel; const LdpcCode* ldpc; const BchCode* bch; bool dummy; };
+    const FrameCtx* ctx_for_pls(int pls_code);       // nullptr: not a valid PLS code (reserved MODCODs, short 9/10)
 
 private:
     DemodCfg cfg;
@@ -123,18 +138,32 @@ private:
     int pls_code;
     std::vector<cf> work1, work2;
     const LdpcCode* ldpc; const BchCode* bch;
+    FrameCtx ccm;                                     // the configured MODCOD
+    std::vector<std::unique_ptr<FrameCtx>> vcm_ctx;  // by PLS code (lazily built)
+    std::vector<std::unique_ptr<Constellation>> vcm_constel;
+    // ACM/VCM framing state: symbols not yet consumed, locked?
+    std::vector<cf> vfifo; bool vcm_synced = false;
 
     int plsync_internal(std::vector<cf>& out, float* best_match);
+    void vcm_walk(uint8_t* out, int out_cap, int* outcnt);
+    void process_frame(const cf* frame, const FrameCtx& fc, float best_match, uint8_t* out, int out_cap, int* outcnt);
 public:
     // individual stages, exposed for stage-level parity tests
     void agc(int n, const cf* in, cf* out);
     void nco(int n, const cf* in, cf* out);
     int gardner(int n, const cf* in, cf* out);
     void rrc_filter(int n, const cf* in, cf* out);
-    float coarse_fed(const cf* frame) const;
-    void pll(const cf* frame, cf* out);
-    void plhdr(const cf* frame, cf* out, int* modcod, int* sh, int* pil);
-    void to_soft(const cf* pllout, int8_t* llr) const;
+    float coarse_fed(const cf* frame) const { return coarse_fed(frame, ccm); }
+    void pll(const cf* frame, cf* out) { pll(frame, out, ccm); }
+    void plhdr(const cf* frame, cf* out, int* modcod, int* sh, int* pil) { plhdr(frame, out, modcod, sh, pil, ccm.mp.plframe); }
+    void to_soft(const cf* pllout, int8_t* llr) const { to_soft(pllout, llr, ccm); }
+    float coarse_fed(const cf* frame, const FrameCtx& fc) const;
+    void pll(const cf* frame, cf* out, const FrameCtx& fc);
+    void plhdr(const cf* frame, cf* out, int* modcod, int* sh, int* pil, int plframe);
+    void to_soft(const cf* pllout, int8_t* llr, const FrameCtx& fc) const;
+    // PLS decode at an assumed SOF (ACM/VCM framing): phase reference from the 26 SOF symbols, soft decode of the 64 PLSC symbols.
+    // Returns the PLS code index 0..127; *ratio as soft_plsc_decode, *sofq = |sum x conj(sof)| / sum |x| over the SOF.
+    static int pls_at(const cf* hdr90, float* ratio, float* sofq);
 };
 
 // ---- synthetic transmitter (SURVEY 8d "Synthetic inputs")
@@ -150,6 +179,8 @@ struct TxCfg {
     int circular;            // != 0: pulse shaping wraps around, so the block can be repeated as a seamless stream
     int nsamples;            // 0: exactly 2 samples per symbol; else the block is resampled to this many samples (sampling-clock error
                              // of 2*symbols/nsamples - 1, e.g. -10 ppm: nsamples = 2*symbols*(1 + 1e-5)); with `circular` still seamless
+    int vcm_n;               // > 0: ACM/VCM stream -- frame f carries PLS code vcm_pls[f % vcm_n] (modcod << 2 | short << 1 | pilots; modcod 0 =
+    int vcm_pls[64];         // dummy PLFRAME) instead of (modcod, shortframes, pilots); bbframes_out then holds kbch/8 bytes per non-dummy frame
 };
 // returns 2-sps IQ; bbframes_out gets nframes x kbch/8 bytes (what the receiver must output)
 std::vector<cf> s2_transmit(const TxCfg& t, std::vector<uint8_t>* bbframes_out, std::vector<cf>* symbols_out = nullptr);

@@ -12,8 +12,11 @@
 // P <- P*alpha^(8i) + T_i[byte] with three 256-entry LDS tables per root (constant multiply split into
 // low/high byte); a frame is cut into 256 chunks, chunk partials are shifted by alpha^(i*bits_after) and
 // XOR-reduced.  Even syndromes are squares (binary code).  Bytes read per frame: nbch/8, once -- HBM-bound,
-// negligible next to the LDPC stage.  Correction (rare) runs one wave per frame: Berlekamp-Massey etc. on
-// lane 0, Chien search across the 64 lanes.
+// negligible next to the LDPC stage.  Correction runs one 256-thread workgroup per frame with non-zero syndromes: Berlekamp-
+// Massey and Forney on thread 0 (short, table-lookup bound), the Chien search over the whole field across the 256 threads with
+// per-term constant multipliers kept as split byte tables in LDS (a frame the LDPC decoder could not fix costs ~40 us here; the
+// first version -- one wave, a 64-bit modulo and a global table lookup per term and position -- took milliseconds, which only showed
+// once the benchmark input contained frames that do not decode).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
@@ -98,12 +101,18 @@ __global__ __launch_bounds__(256) void bch_syndromes_kernel(BchDeviceCode C, con
 
 __device__ __forceinline__ void xor_be_bit(uint8_t* buf, int pos) { buf[pos / 8] ^= (uint8_t)(1u << (7 - pos % 8)); }
 
-__global__ __launch_bounds__(64) void bch_correct_kernel(BchDeviceCode C, uint8_t* __restrict__ frames, int frame_stride, int nbch,
-                                                         int kbch, int nframes, const uint16_t* __restrict__ syn_in,
-                                                         int32_t* __restrict__ corrections) {
+constexpr int BCH_CT = 256;         // threads of a correction workgroup
+constexpr int BCH_MAXDEG = 24;      // a locator found from 2t <= 24 syndromes has degree <= 24
+__global__ __launch_bounds__(BCH_CT) void bch_correct_kernel(BchDeviceCode C, uint8_t* __restrict__ frames, int frame_stride, int nbch,
+                                                             int kbch, int nframes, const uint16_t* __restrict__ syn_in,
+                                                             int32_t* __restrict__ corrections) {
     __shared__ uint16_t s_loc[32];      // locator
     __shared__ uint16_t s_pos[32];      // locations
     __shared__ int s_deg, s_count, s_state;
+    __shared__ uint16_t s_C[40], s_B[40], s_d;       // Berlekamp-Massey: connection polynomial, its last copy, the discrepancy
+    __shared__ uint16_t s_ev[32], s_mag[32];         // Forney: error evaluator, magnitudes
+    __shared__ int s_edeg;
+    __shared__ uint16_t s_mul[BCH_MAXDEG][2][256];   // x * alpha^(BCH_CT * j): low-byte and high-byte tables of term j
     GfDev G{C.d_log, C.d_exp, C.N};
     const int NR = 2 * C.t;
     const int lane = threadIdx.x;
@@ -115,35 +124,41 @@ __global__ __launch_bounds__(64) void bch_correct_kernel(BchDeviceCode C, uint8_
             if (lane == 0 && corrections) corrections[f] = 0;
             continue;
         }
+        // Berlekamp-Massey (reed_solomon_error_correction.hh:226-276, count = 0) with the polynomials in LDS and the inner loops --
+        // discrepancy, T = C + d x^m B, B = C / d -- spread over the threads (the serial form with per-thread arrays lived in scratch
+        // memory: thousands of dependent memory round trips per frame)
+        if (lane <= NR) { s_C[lane] = lane == 0 ? 1 : 0; s_B[lane] = lane == 0 ? 1 : 0; }
+        if (lane == 0) { s_state = 0; s_count = 0; s_deg = 0; }
+        __syncthreads();
+        int L = 0;
+        for (int n = 0, m = 1; n < NR; ++n) {
+            // d = syn[n] + sum_{i=1..L} C[i] syn[n-i]: products by threads 1..L, XOR-reduced through LDS
+            uint32_t prod = 0;
+            if (lane >= 1 && lane <= L) prod = G.vmul(s_C[lane], syn[n - lane]);
+            if (lane == 0) prod = syn[n];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) prod ^= (uint32_t)__shfl_xor((int)prod, o);     // (L <= NR <= 24: everything sits in wave 0)
+            if (lane == 0) s_d = (uint16_t)prod;
+            __syncthreads();
+            const uint16_t d = s_d;
+            if (!d) {
+                ++m;
+            } else {
+                uint16_t tnew = 0;
+                if (lane <= NR) tnew = lane < m ? s_C[lane] : (uint16_t)(G.vmul(d, s_B[lane - m]) ^ s_C[lane]);
+                const bool grow = 2 * L <= n;
+                uint16_t bnew = 0;
+                if (grow && lane <= NR) bnew = G.vdiv(s_C[lane], d);
+                __syncthreads();
+                if (lane <= NR) { s_C[lane] = tnew; if (grow) s_B[lane] = bnew; }
+                if (grow) { L = n + 1 - L; m = 1; } else ++m;
+            }
+            __syncthreads();
+        }
         if (lane == 0) {
-            int nonzero = 0;
-            for (int i = 0; i < NR; ++i) nonzero += !!syn[i];
-            s_state = 0; s_count = 0; s_deg = 0;
+            const uint16_t* Cc = s_C;
+            int nonzero = 1;            // (a flagged frame has a non-zero syndrome)
             if (nonzero) {
-                // Berlekamp-Massey (reed_solomon_error_correction.hh:226-276, count = 0)
-                uint16_t Cc[33], B[33], T[33];
-                for (int i = 0; i <= NR; ++i) Cc[i] = 0;
-                Cc[0] = 1;
-                for (int i = 0; i <= NR; ++i) B[i] = Cc[i];
-                int L = 0;
-                for (int n = 0, m = 1; n < NR; ++n) {
-                    uint16_t d = syn[n];
-                    for (int i = 1; i <= L; ++i) d ^= G.vmul(Cc[i], syn[n - i]);
-                    if (!d) {
-                        ++m;
-                    } else {
-                        for (int i = 0; i < m; ++i) T[i] = Cc[i];
-                        for (int i = m; i <= NR; ++i) T[i] = (uint16_t)(G.vmul(d, B[i - m]) ^ Cc[i]);
-                        if (2 * L <= n) {
-                            L = n + 1 - L;
-                            for (int i = 0; i <= NR; ++i) B[i] = G.vdiv(Cc[i], d);
-                            m = 1;
-                        } else {
-                            ++m;
-                        }
-                        for (int i = 0; i <= NR; ++i) Cc[i] = T[i];
-                    }
-                }
                 int deg = L;
                 bool fail = false;
                 while (!Cc[deg])
@@ -181,18 +196,45 @@ __global__ __launch_bounds__(64) void bch_correct_kernel(BchDeviceCode C, uint8_
         }
         __syncthreads();
         if (s_state == 1) {
-            // Chien search: location i is a root iff sum_j locator[j]*alpha^(j*(i+1)) == 0  (:40-61)
+            // Chien search: location i is a root iff sum_j locator[j]*alpha^(j*(i+1)) == 0  (:40-61), i over the WHOLE field (the
+            // reference counts every root; locations in the shortened part make the frame uncorrectable further down).
+            // Thread t takes i = t, t + 256, ...: term j starts at locator[j]*alpha^(j*(t+1)) and is multiplied by the constant
+            // alpha^(256 j) per step -- a GF(2)-linear map, applied as two byte-table lookups in LDS.
             const int deg = s_deg;
-            int lg[25];
-            for (int jj = 0; jj <= deg && jj < 25; ++jj) lg[jj] = s_loc[jj] ? (int)G.LOG[s_loc[jj]] : -1;
-            for (int i = lane; i < C.N; i += 64) {
-                uint32_t sum = s_loc[0];
-                for (int jj = 1; jj <= deg; ++jj) {
-                    if (lg[jj] >= 0) {
-                        long e = (long)lg[jj] + (long)jj * (long)(i + 1);
-                        sum ^= G.EXP[(int)(e % C.N)];
+            for (int e = lane; e < deg * 512; e += BCH_CT) {
+                const int j = e >> 9, h = (e >> 8) & 1, x = e & 255;
+                const uint32_t v = h ? (uint32_t)x << 8 : (uint32_t)x;
+                uint16_t r = 0;
+                if (v && v <= (uint32_t)C.N) {            // (GF(2^14): the high-byte table only holds values below 2^14)
+                    const int sh = (int)(((long)BCH_CT * (j + 1)) % C.N);
+                    int lg2 = (int)G.LOG[v] + sh;
+                    if (lg2 >= C.N) lg2 -= C.N;
+                    r = G.EXP[lg2];
+                }
+                s_mul[j][h][x] = r;
+            }
+            uint32_t term[BCH_MAXDEG];
+#pragma unroll
+            for (int jj = 0; jj < BCH_MAXDEG; ++jj) {
+                term[jj] = 0;
+                if (jj < deg) {
+                    const uint16_t c = s_loc[jj + 1];
+                    if (c) {
+                        const long e = (long)G.LOG[c] + (long)(jj + 1) * (long)(lane + 1);
+                        term[jj] = G.EXP[(int)(e % C.N)];
                     }
                 }
+            }
+            __syncthreads();
+            const uint32_t c0 = s_loc[0];
+            for (int i = lane; i < C.N; i += BCH_CT) {
+                uint32_t sum = c0;
+#pragma unroll
+                for (int jj = 0; jj < BCH_MAXDEG; ++jj)
+                    if (jj < deg) {
+                        sum ^= term[jj];
+                        term[jj] = (uint32_t)s_mul[jj][0][term[jj] & 255u] ^ (uint32_t)s_mul[jj][1][term[jj] >> 8];
+                    }
                 if (!sum) {
                     int slot = atomicAdd(&s_count, 1);
                     if (slot < 32) s_pos[slot] = (uint16_t)i;
@@ -200,6 +242,45 @@ __global__ __launch_bounds__(64) void bch_correct_kernel(BchDeviceCode C, uint8_
             }
             __syncthreads();
             if (lane == 0) s_state = 2;
+        }
+        __syncthreads();
+        if (s_state == 2 && s_count >= s_deg && s_count <= 32 && s_count > 0) {
+            // Forney (:133-218), the evaluator uses `count` as locator degree: coefficient i by thread i, then one location per thread
+            const int count = s_count;
+            const int etmp = count < NR - 1 ? count : NR - 1;
+            if (lane <= etmp) {
+                uint16_t e = G.vmul(syn[lane], s_loc[0]);
+                for (int jj = 1; jj <= lane; ++jj) e ^= G.vmul(syn[lane - jj], s_loc[jj]);
+                s_ev[lane] = e;
+            }
+            __syncthreads();
+            if (lane == 0) {
+                int edeg = -1;
+                for (int i = 0; i <= etmp; ++i)
+                    if (s_ev[i]) edeg = i;
+                s_edeg = edeg;
+            }
+            __syncthreads();
+            if (lane < count) {
+                const int edeg = s_edeg;
+                uint16_t root = G.imul(s_pos[lane], 1), tmp = root;
+                uint16_t eval = s_ev[0];
+                for (int jj = 1; jj <= edeg; ++jj) {
+                    eval ^= G.vmuli(s_ev[jj], tmp);
+                    tmp = G.imul(tmp, root);
+                }
+                uint16_t mag = 0;
+                if (eval) {
+                    uint16_t deriv = s_loc[1];
+                    uint16_t root2 = G.imul(root, root), tmp2 = root2;
+                    for (int jj = 3; jj <= count; jj += 2) {
+                        deriv ^= G.vmuli(s_loc[jj], tmp2);
+                        tmp2 = G.imul(tmp2, root2);
+                    }
+                    mag = G.EXP[G.idiv(G.LOG[eval], G.LOG[deriv])];
+                }
+                s_mag[lane] = mag;
+            }
         }
         __syncthreads();
         if (lane == 0) {
@@ -211,31 +292,8 @@ __global__ __launch_bounds__(64) void bch_correct_kernel(BchDeviceCode C, uint8_
                 if (count < deg || count > 32) {
                     result = -1;
                 } else {
-                    // Forney (:133-218); the evaluator uses `count` as locator degree
-                    uint16_t evaluator[32], magnitudes[32];
-                    int etmp = count < NR - 1 ? count : NR - 1;
-                    int edeg = -1;
-                    for (int i = 0; i <= etmp; ++i) {
-                        evaluator[i] = G.vmul(syn[i], s_loc[0]);
-                        for (int jj = 1; jj <= i; ++jj) evaluator[i] ^= G.vmul(syn[i - jj], s_loc[jj]);
-                        if (evaluator[i]) edeg = i;
-                    }
-                    for (int i = 0; i < count; ++i) {
-                        uint16_t root = G.imul(s_pos[i], 1), tmp = root;
-                        uint16_t eval = evaluator[0];
-                        for (int jj = 1; jj <= edeg; ++jj) {
-                            eval ^= G.vmuli(evaluator[jj], tmp);
-                            tmp = G.imul(tmp, root);
-                        }
-                        if (!eval) { magnitudes[i] = 0; continue; }
-                        uint16_t deriv = s_loc[1];
-                        uint16_t root2 = G.imul(root, root), tmp2 = root2;
-                        for (int jj = 3; jj <= count; jj += 2) {
-                            deriv ^= G.vmuli(s_loc[jj], tmp2);
-                            tmp2 = G.imul(tmp2, root2);
-                        }
-                        magnitudes[i] = G.EXP[G.idiv(G.LOG[eval], G.LOG[deriv])];
-                    }
+                    // (magnitudes: computed by the threads above, see the Forney block before this section)
+                    const uint16_t* magnitudes = s_mag;
                     const int short_by = C.K_full - kbch;
                     if (count <= 0) {
                         result = count;
@@ -279,7 +337,7 @@ hipError_t bch_syndromes_launch(const BchDeviceCode& C, const uint8_t* frames, i
 hipError_t bch_correct_launch(const BchDeviceCode& C, uint8_t* frames, int frame_stride, int nbch, int kbch, int nframes,
                               const uint16_t* syn, int32_t* corrections, hipStream_t stream) {
     int grid = nframes < 2048 ? nframes : 2048;
-    hipLaunchKernelGGL(bch_correct_kernel, dim3(grid), dim3(64), 0, stream, C, frames, frame_stride, nbch, kbch, nframes, syn, corrections);
+    hipLaunchKernelGGL(bch_correct_kernel, dim3(grid), dim3(BCH_CT), 0, stream, C, frames, frame_stride, nbch, kbch, nframes, syn, corrections);
     return hipGetLastError();
 }
 hipError_t bb_descramble_launch(const uint8_t* frames, int frame_stride, const uint8_t* prbs, int out_bytes, int nframes,

@@ -126,18 +126,19 @@ class DemodCfg(C.Structure):
     _fields_ = [('symbolrate', C.c_double), ('samplerate', C.c_double), ('agc_rate', C.c_float), ('rrc_alpha', C.c_float),
                 ('rrc_taps', C.c_int), ('loop_bw', C.c_float), ('fll_bw', C.c_float), ('clock_omega_gain', C.c_float),
                 ('clock_mu_gain', C.c_float), ('omega_rel_limit', C.c_float), ('modcod', C.c_int), ('shortframes', C.c_int),
-                ('pilots', C.c_int), ('sof_threshold', C.c_float), ('max_ldpc_trials', C.c_int), ('force_ldpc_iters', C.c_int)]
+                ('pilots', C.c_int), ('sof_threshold', C.c_float), ('max_ldpc_trials', C.c_int), ('force_ldpc_iters', C.c_int),
+                ('acm_vcm', C.c_int), ('soft_plsc', C.c_int), ('pilot_aided', C.c_int)]
 
 
 class TxCfg(C.Structure):
     _fields_ = [('modcod', C.c_int), ('shortframes', C.c_int), ('pilots', C.c_int), ('nframes', C.c_int), ('seed', C.c_uint64),
                 ('esn0_db', C.c_double), ('cfo', C.c_double), ('timing', C.c_double), ('phase0', C.c_double), ('lead_symbols', C.c_int),
-                ('circular', C.c_int), ('nsamples', C.c_int)]
+                ('circular', C.c_int), ('nsamples', C.c_int), ('vcm_n', C.c_int), ('vcm_pls', C.c_int * 64)]
 
 
 class FrameStats(C.Structure):
     _fields_ = [('best_match', C.c_float), ('detect_modcod', C.c_int), ('detect_short', C.c_int), ('detect_pilots', C.c_int),
-                ('fed_err', C.c_float), ('ldpc_trials', C.c_int), ('bch_corr', C.c_int)]
+                ('fed_err', C.c_float), ('ldpc_trials', C.c_int), ('bch_corr', C.c_int), ('bbframe_bytes', C.c_int)]
 
 
 def _bind_chain():
@@ -207,11 +208,36 @@ def modcod_params(modcod, short=0, pilots=0):
     return d
 
 
+def pls_info(pls):
+    """(plframe symbols, kbch/8 bytes) of a PLS code modcod << 2 | short << 1 | pilots (modcod 0: dummy PLFRAME, no BBFRAME)"""
+    if pls >> 2 == 0:
+        return 3330, 0
+    mp = modcod_params(pls >> 2, (pls >> 1) & 1, pls & 1)
+    return mp['plframe'], mp['kbch'] // 8
+
+
+def transmit_vcm(pls_list, nframes, seed=1, esn0_db=200.0, cfo=0.0, timing=0.0, phase0=0.0, lead_symbols=0):
+    """ACM/VCM stream: frame f carries PLS code pls_list[f % len] -> (iq, [bbframe bytes per frame or None for dummy frames])"""
+    L = _bind_chain()
+    t = TxCfg(0, 0, 0, nframes, seed, esn0_db, cfo, timing, phase0, lead_symbols, 0, 0, len(pls_list), (C.c_int * 64)(*pls_list))
+    sizes = [pls_info(pls_list[f % len(pls_list)]) for f in range(nframes)]
+    nsym = lead_symbols + sum(s[0] for s in sizes)
+    iq = np.zeros(2 * nsym, np.complex64)
+    bb = np.zeros(sum(s[1] for s in sizes) + 8, np.uint8)
+    n = L.orc_s2_transmit(C.byref(t), iq.ctypes.data, iq.size, bb.ctypes.data, None, 0)
+    assert n == iq.size, (n, iq.size)
+    out, pos = [], 0
+    for plf, kb in sizes:
+        out.append(bb[pos:pos + kb].copy() if kb else None)
+        pos += kb
+    return iq, out
+
+
 def transmit(modcod, short=0, pilots=0, nframes=2, seed=1, esn0_db=200.0, cfo=0.0, timing=0.0, phase0=0.0, lead_symbols=0, circular=0, nsamples=0):
     """-> (iq complex64 [n], bbframes uint8 [nframes, kbch/8], symbols complex64); nsamples != 0: resampled to that many samples
     (sampling-clock error), default exactly 2 per symbol"""
     L = _bind_chain()
-    t = TxCfg(modcod, short, pilots, nframes, seed, esn0_db, cfo, timing, phase0, lead_symbols, circular, nsamples)
+    t = TxCfg(modcod, short, pilots, nframes, seed, esn0_db, cfo, timing, phase0, lead_symbols, circular, nsamples, 0)
     mp = modcod_params(modcod, short, pilots)
     nsym = lead_symbols + nframes * mp['plframe']
     iq = np.zeros(nsamples if nsamples else 2 * nsym, np.complex64)
@@ -237,10 +263,26 @@ class OracleRx:
 
     def process(self, iq):
         iq = np.ascontiguousarray(iq, np.complex64)
+        if self.cfg.acm_vcm:
+            return self.process_vcm(iq)
         cap = (iq.size // (2 * self.mp['plframe']) + 3) * (self.mp['kbch'] // 8)
         out = np.zeros(cap, np.uint8)
         n = self.L.orc_s2rx_process(self.h, iq.size, iq.view(np.float32), out, cap)
         return out[:n].reshape(-1, self.mp['kbch'] // 8)
+
+    def process_vcm(self, iq):
+        """ACM/VCM mode: -> list of BBFRAMEs (variable sizes, from the per-frame statistics' bbframe_bytes)"""
+        iq = np.ascontiguousarray(iq, np.complex64)
+        cap = iq.size // 2 + 65536           # (a frame yields fewer bytes than it has symbols)
+        out = np.zeros(cap, np.uint8)
+        n = self.L.orc_s2rx_process(self.h, iq.size, iq.view(np.float32), out, cap)
+        frames, pos = [], 0
+        for st in self.tap(4):
+            if st.bbframe_bytes:
+                frames.append(out[pos:pos + st.bbframe_bytes].copy())
+                pos += st.bbframe_bytes
+        assert pos == n, (pos, n)
+        return frames
 
     def tap(self, which):
         n = self.L.orc_s2rx_tap(self.h, which, None)
