@@ -92,7 +92,7 @@ class FrameChecker:
         t = self.t
         S = out_all.shape[0]
         fr = out_all.view(S, self.cap, self.kb)
-        nfr = t.as_tensor(nbytes, dtype=t.int64, device=self.dev) // self.kb
+        nfr = t.as_tensor(np.asarray(nbytes), dtype=t.int64, device=self.dev) // self.kb
         valid = t.arange(self.cap, device=self.dev)[None, :] < nfr[:, None]
         h = self._hash(fr)                                                        # [S, cap]
         hs = self.hs[self.block]                                                  # [S, F]
@@ -135,13 +135,15 @@ class S2Run:
         self.out = torch.zeros((S, self.cap * self.kb), dtype=torch.uint8, device=dev)
         self.tout = [self.out[s] for s in range(S)]
         self.empty = [torch.empty(0, dtype=torch.complex64, device=dev) for _ in range(S)]
+        self._step = eng.prepare_batch(self.demods, self.tin, self.tout)
+        self._flush = eng.prepare_batch(self.demods, self.empty, self.tout)
         self.checker = FrameChecker(torch, dev, [b[1] for b in blocks], [s % D for s in range(S)], self.kb, self.cap)
 
     def step(self):
-        return self.eng.process_batch(self.demods, self.tin, self.tout)
+        return self._step()
 
     def flush(self):
-        return self.eng.process_batch(self.demods, self.empty, self.tout)
+        return self._flush()
 
     def check(self, nb):
         return self.checker.check(self.out, nb)
@@ -412,10 +414,12 @@ def mixed64(eng, pkg, dev, dd, steps, warmup, nt=64, sub=64, F=1):
     n_units = nt * cfg['sub']
     total_sym_per_step = sum(t['sym'] for t in table) * cfg['sub'] * cfg['frames']
 
+    run_step = eng.prepare_batch(demods, tin, tout) if nloc else None
+
     def step():
-        nb = eng.process_batch(demods, tin, tout) if nloc else []
+        nb = run_step() if nloc else []
         # per-frame statistics of the step (LDPC trials, BCH corrections) travel with the frames
-        res = dd.gather_units(ids, out[:nloc], torch.as_tensor(nb, dtype=torch.int32, device=dev), n_units)
+        res = dd.gather_units(ids, out[:nloc], torch.as_tensor(np.asarray(nb), dtype=torch.int32, device=dev), n_units)
         return nb, res
 
     def barrier():

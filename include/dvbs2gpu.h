@@ -165,9 +165,22 @@ typedef struct dvbs2gpu_demod_cfg {
     float loop_bw, fll_bw;
     float clock_omega_gain, clock_mu_gain, omega_rel_limit;
     int32_t modcod, shortframes, pilots;
-    float sof_threshold;                 /* stored, unused -- as in the reference (dvbs2_pl_sync.cpp:140-142) */
+    float sof_threshold;                 /* stored, unused in CCM mode -- as in the reference (dvbs2_pl_sync.cpp:140-142); ACM/VCM mode:
+                                          * minimum SOF quality of a frame start */
     int32_t max_ldpc_trials;
     int32_t force_ldpc_iters;            /* 0 = normal early exit; n > 0 = benchmark mode, exactly n iterations */
+    /* Extensions beyond the reference's behaviour, all 0 by default (= reference-compatible, parity-tested against it):
+     * acm_vcm      SURVEY 8(f) rank 3.  The PL framing follows the PLS code of EVERY frame (soft RM(64,7) decode at the frame start
+     *              names MODCOD, frame size and pilots, hence the frame's length and its demapper / LDPC / BCH code); modcod /
+     *              shortframes / pilots above are ignored.  BBFRAMEs then differ in size: dvbs2gpu_frame_stats.bbframe_bytes.  The
+     *              reference only reports what it detected (dvbs2_plhdr_demod.cpp:43-64) and lets the GUI re-configure the whole
+     *              demodulator after 50 consistent sightings (main.cpp:375-408).
+     * soft_plsc    SURVEY 8(f) rank 4.  The PLHDR demodulator decodes the PLS code by soft correlation over all 64 code bits instead
+     *              of the reference's hard decisions compared on 60 bits (dvbs2_plhdr_demod.cpp:45-58,69-79).
+     * pilot_aided  SURVEY 8(f) rank 4.  The known symbols (PL header, pilot blocks) give the PLL a block phase estimate that is
+     *              applied at the end of each block, on top of the reference's decision-directed loop (dvbs2_pll.cpp:34-86): no
+     *              rotational false locks. */
+    int32_t acm_vcm, soft_plsc, pilot_aided;
 } dvbs2gpu_demod_cfg;
 
 typedef struct dvbs2gpu_demod dvbs2gpu_demod;
@@ -209,6 +222,7 @@ typedef struct dvbs2gpu_frame_stats {
     int32_t detected_modcod, detected_shortframes, detected_pilots;
     float coarse_freq_err;
     int32_t ldpc_trials, bch_corrections;
+    int32_t bbframe_bytes;               /* size of this frame's BBFRAME in the output (kbch/8; ACM/VCM: per frame, 0 for a dummy PLFRAME) */
 } dvbs2gpu_frame_stats;
 int dvbs2gpu_demod_get_stats(dvbs2gpu_demod* d, dvbs2gpu_frame_stats* h_out, int cap);
 float dvbs2gpu_demod_get_nco_freq(dvbs2gpu_demod* d);

@@ -642,6 +642,7 @@ void S2Rx::process_frame(const cf* frame, const FrameCtx& fc, float best_match, 
     if (nco_freq_ < -0.3f * (float)M_PI) nco_freq_ = -0.3f * (float)M_PI;
     pll(frame, pllout.data(), fc);
     plhdr(frame, hdr.data(), &st.detect_modcod, &st.detect_short, &st.detect_pilots, m.plframe);
+    if (cfg.acm_vcm) { st.detect_modcod = fc.pls_code >> 2; st.detect_short = (fc.pls_code >> 1) & 1; st.detect_pilots = fc.pls_code & 1; }   // what the framing decoded
     for (int k = 0; k < 90; ++k) pllout[k] = hdr[k];
     to_soft(pllout.data(), llr.data(), fc);
     dbg_frames.insert(dbg_frames.end(), frame, frame + m.plframe);

@@ -37,7 +37,8 @@ class DemodCfg(C.Structure):
     _fields_ = [('symbolrate', C.c_double), ('samplerate', C.c_double), ('agc_rate', C.c_float), ('rrc_alpha', C.c_float),
                 ('rrc_taps', C.c_int32), ('loop_bw', C.c_float), ('fll_bw', C.c_float), ('clock_omega_gain', C.c_float),
                 ('clock_mu_gain', C.c_float), ('omega_rel_limit', C.c_float), ('modcod', C.c_int32), ('shortframes', C.c_int32),
-                ('pilots', C.c_int32), ('sof_threshold', C.c_float), ('max_ldpc_trials', C.c_int32), ('force_ldpc_iters', C.c_int32)]
+                ('pilots', C.c_int32), ('sof_threshold', C.c_float), ('max_ldpc_trials', C.c_int32), ('force_ldpc_iters', C.c_int32),
+                ('acm_vcm', C.c_int32), ('soft_plsc', C.c_int32), ('pilot_aided', C.c_int32)]
 
 
 STAGE_NAMES = ('frontend', 'rrc', 'plsync', 'loops', 'demap', 'ldpc', 'bch', 'deliver')
@@ -51,7 +52,8 @@ class StageTimes(C.Structure):
 class FrameStats(C.Structure):
     """dvbs2gpu_frame_stats"""
     _fields_ = [('pl_sync_best_match', C.c_float), ('detected_modcod', C.c_int32), ('detected_shortframes', C.c_int32),
-                ('detected_pilots', C.c_int32), ('coarse_freq_err', C.c_float), ('ldpc_trials', C.c_int32), ('bch_corrections', C.c_int32)]
+                ('detected_pilots', C.c_int32), ('coarse_freq_err', C.c_float), ('ldpc_trials', C.c_int32), ('bch_corrections', C.c_int32),
+                ('bbframe_bytes', C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/dvbs2gpu.h
@@ -339,6 +341,24 @@ class Engine:
         self._check(self.lib.dvbs2gpu_demod_process_batch(hs, n, iq, cnt, out, cap, nb))
         return list(nb)
 
+    def prepare_batch(self, demods, iq_tensors, out_tensors):
+        """the argument arrays of process_batch built once for a fixed set of buffers (thousands of streams: building them per call costs
+        tens of milliseconds of Python); returns a callable that runs one call and returns the byte counts (numpy int32)"""
+        import numpy as np
+        n = len(demods)
+        hs = (C.c_void_p * n)(*[d.h for d in demods])
+        iq = (C.c_void_p * n)(*[t.data_ptr() for t in iq_tensors])
+        cnt = (C.c_int * n)(*[int(t.numel()) for t in iq_tensors])
+        out = (C.c_void_p * n)(*[t.data_ptr() for t in out_tensors])
+        nb = (C.c_int * n)()
+        cap = min(int(t.numel()) for t in out_tensors)
+        keep = (list(iq_tensors), list(out_tensors))
+
+        def run(_keep=keep):
+            self._check(self.lib.dvbs2gpu_demod_process_batch(hs, n, iq, cnt, out, cap, nb))
+            return np.frombuffer(nb, dtype=np.int32).copy()
+        return run
+
 
 class Demod:
     """One DVB-S2 transponder stream: mirror of DVBS2Demod (init/process/reset/setDemodParams/getKBCH)."""
@@ -378,12 +398,29 @@ class Demod:
         """iq: numpy complex64 1-D (host, 2 sps) -> numpy uint8 [frames, kbch/8]"""
         import numpy as np
         iq = np.ascontiguousarray(iq, np.complex64)
+        if self.cfg.acm_vcm:
+            return self.process_vcm(iq)
         kb = self.info['kbch'] // 8
         cap = (iq.size // (2 * self.info['plframe_symbols']) + 4) * kb
         out = np.zeros(cap, np.uint8)
         n = self.lib.dvbs2gpu_demod_process(self.h, int(iq.size), C.c_void_p(iq.ctypes.data), C.c_void_p(out.ctypes.data), cap)
         self.eng._check(n)
         return out[:n].reshape(-1, kb)
+
+    def process_vcm(self, iq):
+        """ACM/VCM mode: -> list of BBFRAMEs (numpy uint8, sizes from the per-frame statistics' bbframe_bytes)"""
+        import numpy as np
+        iq = np.ascontiguousarray(iq, np.complex64)
+        cap = iq.size // 2 + 65536 + 40000
+        out = np.zeros(cap, np.uint8)
+        n = self.eng._check(self.lib.dvbs2gpu_demod_process(self.h, int(iq.size), C.c_void_p(iq.ctypes.data), C.c_void_p(out.ctypes.data), cap))
+        frames, pos = [], 0
+        for st in self.stats():
+            if st.bbframe_bytes:
+                frames.append(out[pos:pos + st.bbframe_bytes].copy())
+                pos += st.bbframe_bytes
+        assert pos == n, (pos, n)
+        return frames
 
     def stats(self):
         n = self.lib.dvbs2gpu_demod_get_stats(self.h, None, 0)

@@ -254,6 +254,9 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
     for (auto& kv : ctx->rrc) if (kv.second) (void)hipFree(kv.second);
     if (ctx->d_fd_bank) (void)hipFree(ctx->d_fd_bank);
     for (auto& kv : ctx->bandedge) if (kv.second) (void)hipFree(kv.second);
+    if (ctx->d_vcm_mods) (void)hipFree(ctx->d_vcm_mods);
+    if (ctx->d_vcm_cons) (void)hipFree(ctx->d_vcm_cons);
+    for (auto& w : ctx->ws_vcm) w.release();
     if (ctx->ev_ws) (void)hipEventDestroy(ctx->ev_ws);
     for (auto& sp : ctx->timers.pending) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : ctx->timers.pool) (void)hipEventDestroy(e);

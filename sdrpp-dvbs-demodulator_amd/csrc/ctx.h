@@ -115,6 +115,12 @@ struct dvbs2gpu_ctx {
     std::map<int, s2::ConstelTables> constel; // by modcod (gammas depend on it)
     std::map<int, float*> rrc;                // by ntaps*1000 + round(alpha*100) (Ts = 2)
     s2::Workspace ws_rx[8];
+    // ACM/VCM mode (s2_demod.hip): what every PLS code means + the constellations it points to, on the device; per-call scratch
+    s2::S2VcmMod* d_vcm_mods = nullptr;
+    s2::S2ConstelDev* d_vcm_cons = nullptr;
+    std::vector<s2::S2VcmMod> h_vcm_mods;
+    std::vector<s2::FecParams> h_vcm_fec;     // by PLS code
+    s2::Workspace ws_vcm[12];
     // pipelined FEC (s2_demod.hip): with pipeline_fec set, dvbs2gpu_demod_process_batch runs the FEC of call k on fec_stream
     // while call k+1's front end runs on fe_stream; BBFRAMEs of call k are delivered by call k+1
     int pipeline_fec = 0;

@@ -20,6 +20,8 @@
 #include <cmath>
 #include <algorithm>
 #include <memory>
+#include <chrono>
+#include <string>
 
 using namespace s2;
 
@@ -277,6 +279,8 @@ struct dvbs2gpu_demod {
     int tap_sym_off = 0, tap_sym_cnt = 0, tap_fifo = 0;
     const cf32* tap_pll = nullptr;           // into ctx workspace, valid until the next call on this context
     const int8_t* tap_llr = nullptr;
+    std::vector<int> frame_len;              // ACM/VCM: PLFRAME length of each frame of the last call (CCM: empty = mp.plframe)
+    long long tap_pll_count = -1, tap_llr_count = -1;   // ACM/VCM: element counts of the taps (frames differ in size)
     float nco_freq_host = 0.f;
 };
 
@@ -300,6 +304,7 @@ int demod_configure(dvbs2gpu_demod* d) {
     co.hdr_min_freq = -1.0f * (float)M_PI; co.hdr_max_freq = 1.0f * (float)M_PI;
     co.fll_bw = c.fll_bw;
     co.rrc_taps = c.rrc_taps;
+    co.soft_plsc = c.soft_plsc ? 1 : 0; co.pilot_aided = c.pilot_aided ? 1 : 0;
     d->pls_code = c.modcod << 2 | (c.shortframes ? 2 : 0) | (c.pilots ? 1 : 0);
     return 0;
 }
@@ -329,8 +334,22 @@ struct PendingFec {
     const int32_t* d_corr = nullptr;
 };
 
+// development aid: DVBS2GPU_HOST_TIMING=1 prints where the HOST spends a call (ms since entry at each mark)
+struct HostMarks {
+    bool on; std::chrono::steady_clock::time_point t0; std::string line;
+    HostMarks() : on(getenv("DVBS2GPU_HOST_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) {
+        if (!on) return;
+        char b[64];
+        snprintf(b, sizeof(b), " %s=%.2f", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        line += b;
+    }
+    ~HostMarks() { if (on) fprintf(stderr, "[dvbs2gpu host]%s\n", line.c_str()); }
+};
+
 int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts,
                   uint8_t* const* d_out, int out_cap, int* out_bytes, hipStream_t st, bool pipelined, int slot, const int* pre_nsym, bool own_ws, bool deliver_now) {
+    HostMarks hm;
     dvbs2gpu_demod* d0 = dm[0];
     Workspace* const W = own_ws ? ctx->ws_grp[slot] : ctx->ws_rx;      // per-call scratch: the group's own set when groups run side by side
     const hipEvent_t ev_llr = own_ws ? ctx->ev_llr_grp[slot] : ctx->ev_llr;
@@ -372,7 +391,9 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         // symbol counts back (n_sym sits in each stream's state struct)
         HIP_TRY(s2_collect_launch(d_work, n, d_nsym, d_nco, st));
         HIP_TRY(hipMemcpyAsync(nsym.data(), d_nsym, sizeof(int) * n, hipMemcpyDeviceToHost, st));
+        hm.mark("fe_enqueued");
         HIP_TRY(hipStreamSynchronize(st));
+        hm.mark("fe_done");
     }
 
     // ---- 3: PL sync.  cur[i] = FIFO index where stream i's next window starts.
@@ -450,6 +471,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         if (!any) break;
     }
 
+    hm.mark("plsync_done");
     // ---- 4..6 on the pooled frames
     std::vector<S2FrameRef> frames;
     std::vector<int> first(n + 1, 0);
@@ -521,6 +543,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     } else {
         for (int i = 0; i < n; ++i) { out_bytes[i] = 0; dm[i]->tap_pll = nullptr; dm[i]->tap_llr = nullptr; }
     }
+    hm.mark("loops_enqueued");
     // ---- 7: FIFO remainder to the spare buffer, NCO frequency for the getter
     std::vector<int> curfill(2 * n);
     for (int i = 0; i < n; ++i) { curfill[2 * i] = cur[i]; curfill[2 * i + 1] = dm[i]->fifo_fill; }
@@ -530,6 +553,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     HIP_TRY(s2_collect_launch(d_work, n, d_nsym, d_nco, st));
     HIP_TRY(hipMemcpyAsync(nco.data(), d_nco, sizeof(float) * n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    hm.mark("frontend_all_done");
     for (int i = 0; i < n; ++i) {
         dvbs2gpu_demod* d = dm[i];
         if (cur[i] > 0) { d->fifo_fill -= cur[i]; d->fifo_cur ^= 1; d->sym_base += cur[i]; }
@@ -540,7 +564,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             for (int f = first[i]; f < first[i + 1]; ++f) {
                 S2FrameStats s = hstats[f];
                 s.best_match = frame_bm[i][f - first[i]];
-                s.ldpc_trials = trials[f]; s.bch_corr = corr[f];
+                s.ldpc_trials = trials[f]; s.bch_corr = corr[f]; s.bbframe_bytes = kb;
                 dm[i]->stats.push_back(s);
             }
         }
@@ -573,7 +597,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             for (int f = job->first[i]; f < job->first[i + 1]; ++f) {
                 S2FrameStats s = job->hstats[f];
                 s.best_match = job->frame_bm[i][f - job->first[i]];
-                s.ldpc_trials = ptr[f]; s.bch_corr = pco[f];
+                s.ldpc_trials = ptr[f]; s.bch_corr = pco[f]; s.bbframe_bytes = job->kb;
                 dm[i]->stats.push_back(s);
             }
         }
@@ -589,6 +613,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             return DVBS2GPU_ERR_ARG;
         }
         if ((rc = deliver(prev))) return rc;      // FEC of the previous call (ran during this call's front end)
+        hm.mark("prev_delivered");
     } else {
         for (int i = 0; i < n; ++i) dm[i]->stats.clear();
     }
@@ -616,11 +641,219 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             HIP_TRY(hipEventRecord(ctx->ev_fec[slot], sf));
         }
         ctx->fec_parity[slot] ^= 1;
+        hm.mark("fec_enqueued");
         if (deliver_now) {
             // synchronous call with several groups side by side: the job is collected by the call that started it
             if ((rc = deliver(job.get()))) return rc;
         } else {
             ctx->pending_fec[slot] = job.release();
+        }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- ACM/VCM mode
+// device tables: what each of the 128 PLS codes means and the constellation (LUTs) it uses
+int get_vcm_tables(dvbs2gpu_ctx* ctx) {
+    {
+        std::lock_guard<std::mutex> l(ctx->mtx);
+        if (ctx->d_vcm_mods) return 0;
+    }
+    std::vector<S2VcmMod> mods(128);
+    std::vector<FecParams> fec(128);
+    std::vector<S2ConstelDev> cons;
+    std::map<const ConstelTables*, int> con_index;
+    for (int pls = 0; pls < 128; ++pls) {
+        S2VcmMod& M = mods[pls];
+        memset(&M, 0, sizeof(M));
+        const int modcod = pls >> 2;
+        if (modcod == 0) { M.valid = 2; M.plframe = VCM_DUMMY_PLFRAME; M.slots = 36; continue; }
+        ModcodParams mp;
+        if (!modcod_params(modcod, (pls >> 1) & 1, pls & 1, &mp)) continue;
+        ConstelTables* CT;
+        int rc = get_constel(ctx, mp, &CT);
+        if (rc) return rc;
+        auto it = con_index.find(CT);
+        if (it == con_index.end()) { it = con_index.emplace(CT, (int)cons.size()).first; cons.push_back(CT->dev); }
+        M.valid = 1; M.plframe = mp.plframe; M.slots = mp.slots; M.pilots = mp.pilots; M.pilot_blocks = mp.pilot_blocks; M.bits = mp.bits;
+        M.rate = mp.rate; M.constel = mp.constel; M.N = mp.fec.N; M.kb = mp.fec.kbch / 8; M.con = it->second; M.code_index = mp.fec.code_index;
+        fec[pls] = mp.fec;
+    }
+    std::lock_guard<std::mutex> l(ctx->mtx);
+    if (ctx->d_vcm_mods) return 0;
+    S2VcmMod* dm = nullptr;
+    S2ConstelDev* dc = nullptr;
+    int rc;
+    if ((rc = upload(mods, &dm)) || (rc = upload(cons, &dc))) { (void)hipFree(dm); (void)hipFree(dc); return rc; }
+    ctx->h_vcm_mods = mods; ctx->h_vcm_fec = fec;
+    ctx->d_vcm_cons = dc;
+    ctx->d_vcm_mods = dm;
+    return 0;
+}
+
+// One group of ACM/VCM streams (same loop settings), synchronous: front end -> framing walk on the device -> [frame tables to the host:
+// pooling, grouping by LDPC code] -> per-frame-MODCOD loops + demapper -> one FEC job per code present -> BBFRAMEs of differing size
+// into the streams' output buffers in frame order.
+int process_vcm_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts, uint8_t* const* d_out,
+                      int out_cap, int* out_bytes, hipStream_t st) {
+    dvbs2gpu_demod* d0 = dm[0];
+    int rc;
+    if ((rc = get_rx_tables(ctx)) || (rc = get_vcm_tables(ctx))) return rc;
+    float* d_taps;
+    if ((rc = get_rrc(ctx, d0->cfg.rrc_taps, d0->cfg.rrc_alpha, d0->cfg.samplerate / d0->cfg.symbolrate, &d_taps))) return rc;
+    Workspace* const W = ctx->ws_vcm;
+    std::vector<S2StreamWork> work(n);
+    int max_count = 0, maxf = 0;
+    for (int i = 0; i < n; ++i) {
+        dvbs2gpu_demod* d = dm[i];
+        if (counts[i] < 0 || counts[i] > d->max_samples) { last_error() = "count exceeds max_samples"; return DVBS2GPU_ERR_ARG; }
+        work[i].in = d_iq[i]; work[i].count = counts[i]; work[i].fe_out = d->d_fe;
+        work[i].fifo = d->d_fifo[d->fifo_cur]; work[i].fifo_fill = d->fifo_fill; work[i].st = d->d_state;
+        work[i].fifo_next = d->d_fifo[d->fifo_cur ^ 1]; work[i].out = d_out[i];
+        max_count = std::max(max_count, counts[i]);
+        maxf = std::max(maxf, d->fifo_cap / VCM_DUMMY_PLFRAME + 2);
+        d->stats.clear(); d->frame_ptrs.clear(); d->frame_pos.clear(); d->frame_len.clear();
+        d->tap_pll = nullptr; d->tap_llr = nullptr; d->tap_pll_count = 0; d->tap_llr_count = 0;
+    }
+    if ((rc = W[0].ensure(sizeof(S2StreamWork) * n + sizeof(int) * (n + 1) + sizeof(int) * 8 * n + sizeof(float) * n + 64))) return rc;
+    S2StreamWork* d_work = (S2StreamWork*)W[0].p;
+    int* d_first = (int*)((char*)W[0].p + sizeof(S2StreamWork) * n);
+    int* d_counts = d_first + (n + 1);            // [4n]
+    int* d_curfill = d_counts + 4 * n;            // [2n]
+    int* d_nsym = d_curfill + 2 * n;              // [n]
+    float* d_nco = (float*)(d_nsym + n);          // [n]
+    if ((rc = W[1].ensure(sizeof(S2VcmFound) * (size_t)n * maxf))) return rc;
+    S2VcmFound* d_found = (S2VcmFound*)W[1].p;
+    HIP_TRY(hipMemcpyAsync(d_work, work.data(), sizeof(S2StreamWork) * n, hipMemcpyHostToDevice, st));
+    { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(s2_frontend_launch(d_work, n, d0->co, ctx->d_gardner_bank, st)); }
+    { StageSpan sp(ctx->timers, ST_RRC, st); HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st)); }
+    { StageSpan sp(ctx->timers, ST_PLSYNC, st); HIP_TRY(s2_vcm_walk_launch(d_work, n, ctx->pl, ctx->d_vcm_mods, d0->cfg.sof_threshold, maxf, d_found, d_counts, st)); }
+    std::vector<S2VcmFound> found((size_t)n * maxf);
+    std::vector<int> cnts(4 * n);
+    HIP_TRY(hipMemcpyAsync(cnts.data(), d_counts, sizeof(int) * 4 * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(found.data(), d_found, sizeof(S2VcmFound) * found.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // ---- pool the frames (stream-major, stream order), group them by LDPC code, lay out PLL output / LLRs / output bytes
+    std::vector<S2VcmFrame> frames;
+    std::vector<int> first(n + 1, 0);
+    std::vector<uint8_t*> dst;                     // per pooled frame: where its BBFRAME goes
+    std::map<int, std::vector<int>> groups;        // PLS-independent FEC identity (code index * 2 + frame size is implied by the index) -> pooled frame indices
+    std::map<int, int> group_pls;                  // a PLS code of the group (its FEC parameters)
+    long long pll_off = 0, llr_off = 0;
+    for (int i = 0; i < n; ++i) {
+        dvbs2gpu_demod* d = dm[i];
+        const int nf = cnts[4 * i], avail = cnts[4 * i + 2], nsym = cnts[4 * i + 3];
+        first[i] = (int)frames.size();
+        d->tap_sym_off = d->fifo_fill; d->tap_sym_cnt = nsym; d->tap_fifo = d->fifo_cur;
+        d->fifo_fill = avail;
+        if (d->fifo_fill > d->fifo_cap) { last_error() = "symbol FIFO overflow"; return DVBS2GPU_ERR_CAPACITY; }
+        const cf32* base = d->d_fifo[d->fifo_cur];
+        int obytes = 0;
+        for (int k = 0; k < nf; ++k) {
+            const S2VcmFound& F = found[(size_t)i * maxf + k];
+            const S2VcmMod& M = ctx->h_vcm_mods[F.pls];
+            S2VcmFrame fr;
+            fr.sym = base + F.offset; fr.stream = i; fr.pls = F.pls; fr.pll_off = pll_off; fr.llr_off = llr_off; fr.sofq = F.sofq; fr.dst_index = 0;
+            if (M.valid == 1) {
+                auto& g = groups[M.code_index];
+                fr.dst_index = (int)g.size();
+                g.push_back((int)frames.size());
+                group_pls[M.code_index] = F.pls;
+                if (obytes + M.kb > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
+                dst.push_back(d_out[i] + obytes);
+                obytes += M.kb;
+                pll_off += M.plframe; llr_off += M.N;
+                d->tap_pll_count += M.plframe; d->tap_llr_count += M.N;
+            } else {
+                dst.push_back(nullptr);
+            }
+            d->frame_ptrs.push_back(fr.sym); d->frame_len.push_back(M.plframe); d->frame_pos.push_back(d->sym_base + F.offset);
+            frames.push_back(fr);
+        }
+        out_bytes[i] = obytes;
+    }
+    first[n] = (int)frames.size();
+    const int nf = (int)frames.size();
+    std::vector<S2FrameStats> hstats(nf);
+    std::vector<int32_t> trials(nf, 0), corr(nf, 0);
+    if (nf > 0) {
+        if ((rc = W[2].ensure(sizeof(S2VcmFrame) * nf + sizeof(S2FrameStats) * nf + sizeof(uint8_t*) * nf + sizeof(int) * nf + 64))) return rc;
+        S2VcmFrame* d_frames = (S2VcmFrame*)W[2].p;
+        S2FrameStats* d_stats = (S2FrameStats*)(d_frames + nf);
+        uint8_t** d_dst = (uint8_t**)(d_stats + nf);
+        int* d_idx = (int*)(d_dst + nf);
+        if ((rc = W[3].ensure((size_t)std::max<long long>(pll_off, 1) * sizeof(cf32)))) return rc;
+        if ((rc = W[4].ensure((size_t)std::max<long long>(llr_off, 4)))) return rc;
+        cf32* d_pll = (cf32*)W[3].p;
+        int8_t* d_llr = (int8_t*)W[4].p;
+        HIP_TRY(hipMemcpyAsync(d_frames, frames.data(), sizeof(S2VcmFrame) * nf, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_first, first.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_dst, dst.data(), sizeof(uint8_t*) * nf, hipMemcpyHostToDevice, st));
+        { StageSpan sp(ctx->timers, ST_LOOPS, st); HIP_TRY(s2_vcm_loops_launch(d_work, n, d_frames, d_first, d0->co, ctx->pl, ctx->d_vcm_mods, ctx->d_vcm_cons, d_pll, d_stats, st)); }
+        { StageSpan sp(ctx->timers, ST_DEMAP, st); HIP_TRY(s2_vcm_demap_launch(d_frames, nf, ctx->d_vcm_mods, ctx->d_vcm_cons, d_pll, d_llr, st)); }
+        const int force = d0->cfg.force_ldpc_iters > 0;
+        const int mt = force ? d0->cfg.force_ldpc_iters : d0->cfg.max_ldpc_trials;
+        // one FEC job per LDPC code present in the call; group buffers: LLRs | BBFRAMEs | trials + corrections
+        std::vector<std::pair<int, std::vector<int32_t>>> results;     // (code, trials ++ corrections) filled after the sync
+        size_t off_idx = 0;
+        std::vector<int> all_idx;
+        for (auto& kv : groups) all_idx.insert(all_idx.end(), kv.second.begin(), kv.second.end());
+        HIP_TRY(hipMemcpyAsync(d_idx, all_idx.data(), sizeof(int) * all_idx.size(), hipMemcpyHostToDevice, st));
+        size_t llr_need = 0, bb_need = 0;
+        for (auto& kv : groups) {
+            const FecParams& f = ctx->h_vcm_fec[group_pls[kv.first]];
+            llr_need += (size_t)kv.second.size() * f.N; bb_need += (size_t)kv.second.size() * (f.kbch / 8 + 8);
+        }
+        if ((rc = W[5].ensure(llr_need + 64)) || (rc = W[6].ensure(bb_need + 64)) || (rc = W[7].ensure(sizeof(int32_t) * 2 * all_idx.size() + 64))) return rc;
+        size_t lo = 0, bo = 0, to = 0;
+        struct Out { int code; size_t to; int cnt; };
+        std::vector<Out> outs;
+        for (auto& kv : groups) {
+            const FecParams& f = ctx->h_vcm_fec[group_pls[kv.first]];
+            const int cnt = (int)kv.second.size(), kb = f.kbch / 8;
+            int8_t* g_llr = (int8_t*)W[5].p + lo;
+            uint8_t* g_bb = (uint8_t*)W[6].p + bo;
+            int32_t* g_tr = (int32_t*)W[7].p + to;
+            HIP_TRY(s2_vcm_gather_launch(d_frames, d_idx + off_idx, cnt, f.N, d_llr, g_llr, st));
+            if ((rc = fec_run(ctx, f, g_llr, cnt, mt, force, g_bb, g_tr, g_tr + cnt, st))) return rc;
+            // the group's index list, re-based onto the per-frame destination table
+            { StageSpan sp(ctx->timers, ST_DELIVER, st); HIP_TRY(s2_vcm_scatter_launch(d_idx + off_idx, cnt, kb, g_bb, d_dst, st)); }
+            outs.push_back(Out{kv.first, to, cnt});
+            off_idx += cnt; lo += (size_t)cnt * f.N; bo += (size_t)cnt * kb; bo = (bo + 7) & ~(size_t)7; to += 2 * (size_t)cnt;
+        }
+        std::vector<int32_t> tc(2 * all_idx.size());
+        HIP_TRY(hipMemcpyAsync(tc.data(), W[7].p, sizeof(int32_t) * tc.size(), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(hstats.data(), d_stats, sizeof(S2FrameStats) * nf, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (const Out& o : outs) {
+            const std::vector<int>& idx = groups[o.code];
+            for (int k = 0; k < o.cnt; ++k) { trials[idx[k]] = tc[o.to + k]; corr[idx[k]] = tc[o.to + o.cnt + k]; }
+        }
+        for (int i = 0; i < n; ++i)
+            if (first[i + 1] > first[i]) {
+                // taps: PLL output and LLRs of this stream's data frames are contiguous, in frame order
+                for (int f = first[i]; f < first[i + 1]; ++f)
+                    if (ctx->h_vcm_mods[frames[f].pls].valid == 1) { dm[i]->tap_pll = d_pll + frames[f].pll_off; dm[i]->tap_llr = d_llr + frames[f].llr_off; break; }
+            }
+    }
+    // ---- FIFO remainder to the spare buffer, NCO frequency for the getter
+    std::vector<int> curfill(2 * n);
+    for (int i = 0; i < n; ++i) { curfill[2 * i] = cnts[4 * i + 1]; curfill[2 * i + 1] = dm[i]->fifo_fill; }
+    HIP_TRY(hipMemcpyAsync(d_curfill, curfill.data(), sizeof(int) * 2 * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(s2_fifo_compact_launch(d_work, n, d_curfill, st));
+    std::vector<float> nco(n);
+    HIP_TRY(s2_collect_launch(d_work, n, d_nsym, d_nco, st));
+    HIP_TRY(hipMemcpyAsync(nco.data(), d_nco, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < n; ++i) {
+        dvbs2gpu_demod* d = dm[i];
+        const int cur = cnts[4 * i + 1];
+        if (cur > 0) { d->fifo_fill -= cur; d->fifo_cur ^= 1; d->sym_base += cur; }
+        d->nco_freq_host = nco[i];
+        for (int f = first[i]; f < first[i + 1]; ++f) {
+            S2FrameStats s = hstats[f];
+            s.ldpc_trials = trials[f]; s.bch_corr = corr[f];
+            d->stats.push_back(s);
         }
     }
     return 0;
@@ -683,6 +916,7 @@ void dvbs2gpu_demod_default_cfg(int modcod, int shortframes, int pilots, dvbs2gp
     c->omega_rel_limit = 0.02f;
     c->modcod = modcod; c->shortframes = shortframes; c->pilots = pilots;
     c->sof_threshold = 0.6f; c->max_ldpc_trials = 16; c->force_ldpc_iters = 0;
+    c->acm_vcm = 0; c->soft_plsc = 0; c->pilot_aided = 0;
 }
 
 int dvbs2gpu_demod_create(dvbs2gpu_ctx* ctx, const dvbs2gpu_demod_cfg* cfg, int max_samples, dvbs2gpu_demod** out) {
@@ -775,6 +1009,24 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
         }
     }
     const bool pipe = ctx->pipeline_fec != 0;
+    bool any_vcm = false;
+    for (int i = 0; i < n; ++i) any_vcm = any_vcm || demods[i]->cfg.acm_vcm != 0;
+    if (any_vcm) {
+        // ACM/VCM streams: group after group, synchronous (the FEC of a call depends on what its framing finds)
+        if (pipe) { last_error() = "ACM/VCM streams run in the synchronous mode (dvbs2gpu_set_pipelined(ctx, 0))"; return DVBS2GPU_ERR_ARG; }
+        for (const std::vector<int>& idx : groups) {
+            std::vector<dvbs2gpu_demod*> g;
+            std::vector<const cf32*> gi;
+            std::vector<int> gc, gb(idx.size());
+            std::vector<uint8_t*> go;
+            for (int k : idx) { g.push_back(demods[k]); gi.push_back((const cf32*)d_iq[k]); gc.push_back(counts[k]); go.push_back(d_out[k]); }
+            int rc = g[0]->cfg.acm_vcm ? process_vcm_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), nullptr)
+                                       : process_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), nullptr, false, 0, nullptr, false, false);
+            if (rc) return rc;
+            for (size_t k = 0; k < idx.size(); ++k) out_bytes[idx[k]] = gb[k];
+        }
+        return 0;
+    }
     if (pipe && (int)groups.size() > dvbs2gpu_ctx::MAX_PIPE_GROUPS) { last_error() = "pipelined mode handles at most 16 configuration groups per batch"; return DVBS2GPU_ERR_ARG; }
     hipStream_t st = pipe ? ctx->fe_stream : nullptr;
     // several groups with one front end: the MODCOD-independent stages run once for the whole batch
@@ -875,7 +1127,13 @@ int dvbs2gpu_demod_process(dvbs2gpu_demod* d, int count, const float* h_iq, uint
     int bytes = 0;
     int cap = (d->fifo_cap / d->mp.plframe + 2) * (d->mp.fec.kbch / 8);
     dvbs2gpu_demod* dd = d;
-    int rc = process_group(d->ctx, &dd, 1, &in, &count, &dout, cap, &bytes, nullptr, false, 0, nullptr, false, false);
+    int rc;
+    if (d->cfg.acm_vcm) {
+        cap = (d->fifo_cap / 3330 + 2) * 8100;       // the staging buffer's size (allocated above)
+        if (d->ctx->pipeline_fec) { last_error() = "ACM/VCM streams run in the synchronous mode (dvbs2gpu_set_pipelined(ctx, 0))"; return DVBS2GPU_ERR_ARG; }
+        rc = process_vcm_group(d->ctx, &dd, 1, &in, &count, &dout, cap, &bytes, nullptr);
+    } else
+    rc = process_group(d->ctx, &dd, 1, &in, &count, &dout, cap, &bytes, nullptr, false, 0, nullptr, false, false);
     if (rc) return rc;
     if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
     if (bytes) HIP_TRY(hipMemcpy(h_out, d->d_out, bytes, hipMemcpyDeviceToHost));
@@ -910,6 +1168,14 @@ int dvbs2gpu_demod_get_tap(dvbs2gpu_demod* d, int which, void* h_dst, int cap) {
             return n;
         }
         case 1: {
+            if (!d->frame_len.empty()) {           // ACM/VCM: frames of differing length, dummy PLFRAMEs included
+                long long n = 0, pos = 0;
+                for (int L : d->frame_len) n += L;
+                if (h_dst)
+                    for (int f = 0; f < nf && pos + d->frame_len[f] <= cap; pos += d->frame_len[f], ++f)
+                        HIP_TRY(hipMemcpy((cf32*)h_dst + pos, d->frame_ptrs[f], sizeof(cf32) * d->frame_len[f], hipMemcpyDeviceToHost));
+                return (int)n;
+            }
             int n = nf * raw;
             if (h_dst)
                 for (int f = 0; f < nf && (f + 1) * raw <= cap; ++f)
@@ -917,11 +1183,21 @@ int dvbs2gpu_demod_get_tap(dvbs2gpu_demod* d, int which, void* h_dst, int cap) {
             return n;
         }
         case 2: {
+            if (d->tap_pll_count >= 0 && d->cfg.acm_vcm) {
+                int n = (int)d->tap_pll_count;
+                if (h_dst && n && d->tap_pll) HIP_TRY(hipMemcpy(h_dst, d->tap_pll, sizeof(cf32) * std::min(n, cap), hipMemcpyDeviceToHost));
+                return n;
+            }
             int n = nf * raw;
             if (h_dst && n && d->tap_pll) HIP_TRY(hipMemcpy(h_dst, d->tap_pll, sizeof(cf32) * std::min(n, cap), hipMemcpyDeviceToHost));
             return n;
         }
         case 3: {
+            if (d->tap_llr_count >= 0 && d->cfg.acm_vcm) {
+                int n = (int)d->tap_llr_count;
+                if (h_dst && n && d->tap_llr) HIP_TRY(hipMemcpy(h_dst, d->tap_llr, (size_t)std::min(n, cap), hipMemcpyDeviceToHost));
+                return n;
+            }
             int n = nf * N;
             if (h_dst && n && d->tap_llr) HIP_TRY(hipMemcpy(h_dst, d->tap_llr, (size_t)std::min(n, cap), hipMemcpyDeviceToHost));
             return n;

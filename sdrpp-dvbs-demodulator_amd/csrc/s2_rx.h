@@ -26,6 +26,7 @@ struct S2StreamState {
     float hdr_phase, hdr_freq;
     int n_fe_out;     // outputs of the timing-recovery stage in the last call
     int n_sym;        // symbols appended to the PL-sync FIFO in the last call
+    int vcm_synced;   // ACM/VCM framing: locked to a frame start?
 };
 
 // loop coefficients shared by all streams of one configuration
@@ -36,6 +37,7 @@ struct S2LoopCoefs {
     float hdr_alpha, hdr_beta, hdr_min_freq, hdr_max_freq;
     float fll_bw;
     int rrc_taps;
+    int soft_plsc, pilot_aided;      // extensions (include/dvbs2gpu.h), 0 = the reference's behaviour
 };
 
 // per-call work description of one stream (array in device memory, one entry per stream of the batch)
@@ -62,6 +64,7 @@ struct S2FrameStats {        // == dvbs2gpu_frame_stats
     int detected_modcod, detected_short, detected_pilots;
     float fed_err;
     int ldpc_trials, bch_corr;
+    int bbframe_bytes;
 };
 
 // tables of one (constellation, gamma) pair
@@ -72,6 +75,31 @@ struct S2ConstelDev {
     const float* lut_err;      // [256][256]
     cf32 pts[32];
     const cf32* pts_g;         // the same points in global memory
+};
+
+// ---- ACM/VCM mode (include/dvbs2gpu.h, acm_vcm): every frame carries its own MODCOD
+constexpr int VCM_ACQ_WINDOW = 33282;        // acquisition search span = the longest PLFRAME (QPSK normal with pilots)
+constexpr float VCM_MIN_RATIO = 0.5f;        // PLS decodes below this correlation ratio count as "no header here"
+constexpr int VCM_DUMMY_PLFRAME = 3330;      // dummy PLFRAME (MODCOD 0): 36 unmodulated slots
+struct S2VcmMod {            // what a PLS code (modcod << 2 | short << 1 | pilots) means; device table [128]
+    int valid;               // 0 = not a valid code (reserved MODCODs, short 9/10), 1 = data frame, 2 = dummy PLFRAME
+    int plframe, slots, pilots, pilot_blocks, bits, rate, constel, N, kb;
+    int con;                 // index into the S2ConstelDev array
+    int code_index;          // LDPC code
+};
+struct S2VcmFound {          // a frame the walker found in a stream's FIFO
+    int offset;              // FIFO index of its first symbol
+    int pls;
+    float sofq;              // SOF quality at the frame start
+    int pad;
+};
+struct S2VcmFrame {          // pooled frame of a call (stream-major, in stream order)
+    const cf32* sym;
+    int stream, pls;
+    long long pll_off;       // element offset of this frame's PLL output
+    long long llr_off;       // byte offset of this frame's LLRs (frame order)
+    float sofq;
+    int dst_index;           // index inside its FEC group
 };
 
 struct S2PlTablesDev {
@@ -138,6 +166,16 @@ hipError_t s2_scatter_out_launch(const S2StreamWork* d_work, const S2FrameRef* d
 hipError_t s2_scatter_out2_launch(uint8_t* const* d_outs, const S2FrameRef* d_frames, const int* d_first, int nframes, int kb,
                                   const uint8_t* d_bb, hipStream_t st);
 hipError_t s2_fifo_compact_launch(const S2StreamWork* d_work, int nstreams, const int* d_cur_fill /*[2*nstreams]: cur, fill*/, hipStream_t st);
+// ACM/VCM path
+hipError_t s2_vcm_walk_launch(const S2StreamWork* d_work, int nstreams, S2PlTablesDev tabs, const S2VcmMod* d_mods, float sof_threshold, int maxf,
+                              S2VcmFound* d_found, int* d_counts /*[nstreams][4]: frames, consumed, avail, new symbols*/, hipStream_t st);
+hipError_t s2_vcm_loops_launch(const S2StreamWork* d_work, int nstreams, const S2VcmFrame* d_frames, const int* d_first, S2LoopCoefs coefs,
+                               S2PlTablesDev tabs, const S2VcmMod* d_mods, const S2ConstelDev* d_cons, cf32* d_pllout, S2FrameStats* d_stats,
+                               hipStream_t st);
+hipError_t s2_vcm_demap_launch(const S2VcmFrame* d_frames, int nframes, const S2VcmMod* d_mods, const S2ConstelDev* d_cons, const cf32* d_pllout,
+                               int8_t* d_llr, hipStream_t st);
+hipError_t s2_vcm_gather_launch(const S2VcmFrame* d_frames, const int* d_idx, int count, int N, const int8_t* d_llr, int8_t* d_grp, hipStream_t st);
+hipError_t s2_vcm_scatter_launch(const int* d_idx, int count, int kb, const uint8_t* d_bb, uint8_t* const* d_dst, hipStream_t st);
 hipError_t s2_deinterleave_launch(int constel, int rate, int bits, int N, const int8_t* d_in, int nframes, int8_t* d_out, hipStream_t st);
 hipError_t math_eval_launch(int func, int n, const float* a, const float* b, float* o0, float* o1, hipStream_t st);
 hipError_t s2_demap_launch(S2ConstelDev con, int rate, int shortframe, int slots, int pilots, int plframe, const cf32* d_pllout,

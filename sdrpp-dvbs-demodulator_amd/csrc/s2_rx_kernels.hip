@@ -595,6 +595,7 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
         if (nco_freq < -0.3f * PI_F) nco_freq = -0.3f * PI_F;
         // ---- PLL (dvbs2_pll.cpp:34-86), 64-symbol tiles
         int next_pilot = (pilots && pilot_blocks > 0) ? pilot_start(0) : -1, pb = 0;
+        cf32 pacc{0.f, 0.f};
         // the next tile's symbols and Gold-sequence values are fetched into registers while the serial loop runs on the current one
         constexpr int NPF = (FL_TILE + FL_LPS - 1) / FL_LPS;
         cf32 pf[NPF];
@@ -625,6 +626,7 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
                 cf32 tmp_val = cmul(tile[g][k], phasor_fast(-pll.phase));
                 float error = 0.f;
                 cf32 o;
+                bool block_end = false;
                 if (i >= 90) {
                     cf32 descr = pl_descramble(tmp_val, rnt[k]);
                     bool is_pilot = next_pilot >= 0 && i >= next_pilot && i < next_pilot + 36;
@@ -632,18 +634,31 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
                         if (C.bits != 5) error = C.lut_err[lut_index(tmp_val.re) * 256 + lut_index(tmp_val.im)];
                         else error = soft_phase_err_noinline(C.pts_g, C.states, C.amp, C.prescale, tmp_val);
                     } else {
-                        error = cphase(cmul(descr, cf32{0.707f, -0.707f}));
-                        if (i == next_pilot + 35) { ++pb; next_pilot = pb < pilot_blocks ? pilot_start(pb) : -1; }
+                        const cf32 pr = cmul(descr, cf32{0.707f, -0.707f});
+                        error = cphase(pr);
+                        if (co.pilot_aided) pacc = cadd(pacc, pr);
+                        if (i == next_pilot + 35) { ++pb; next_pilot = pb < pilot_blocks ? pilot_start(pb) : -1; block_end = true; }
                     }
                     o = descr;
                 } else {
-                    if (i < 26) error = cphase(cmul(tmp_val, cconj(T.sof[i])));
-                    else error = cphase(cmul(tmp_val, cconj(plsc[i - 26])));
+                    const cf32 pr = cmul(tmp_val, cconj(i < 26 ? T.sof[i] : plsc[i - 26]));
+                    error = cphase(pr);
+                    if (co.pilot_aided) pacc = cadd(pacc, pr);
+                    block_end = i == 89;
                     o = cf32{0.f, 0.f};   // header symbols come from the PLHDR demod below
                 }
                 if (gl == 0) otile[g][k] = o;
                 pll.advance(error);
                 pll.wrap_pi_once();
+                if (co.pilot_aided && block_end) {
+                    // pilot-aided mode (include/dvbs2gpu.h): the block estimate of the residual phase over the known symbols moves the loop phase
+                    if (pacc.re != 0.f || pacc.im != 0.f) {
+                        pll.phase += cphase(pacc);
+                        pll.advance(0.f);
+                        pll.wrap_pi();
+                    }
+                    pacc = cf32{0.f, 0.f};
+                }
             }
             __syncthreads();
             if (fact)
@@ -660,8 +675,9 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
             cf32 o = (i & 1) ? cf32{-tmp_val.re, tmp_val.im} : cf32{tmp_val.im, tmp_val.re};
             if (gl == 0 && fact) out[i] = o;
             if (i >= 26) {
-                bool value = cmul(o, rot).re > 0;
-                plheader = plheader << 1 | (unsigned long long)(!value);
+                const float sv = cmul(o, rot).re;
+                plheader = plheader << 1 | (unsigned long long)(!(sv > 0));
+                if (co.soft_plsc && gl == 0) hdr_sym[g][i - 26].re = sv;      // (slot i - 26 < i has been consumed: reuse it for the soft value)
             }
             hdr.advance(error);
             hdr.wrap_pi_once();
@@ -671,13 +687,34 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
         hdr.wrap_pi();
         // codeword search: minimum distance, lowest index among the minima (the reference scans 0..127 with strict '<')
         int key = 0x7fffffff;
-        #pragma unroll 1
-        for (int c = gl; c < 128; c += FL_LPS) {
-            int dd = __popcll((T.plsc_code[c] ^ plheader) & ((1ull << 60) - 1));
-            key = min(key, dd * 128 + c);
-        }
+        if (!co.soft_plsc) {
+            #pragma unroll 1
+            for (int c = gl; c < 128; c += FL_LPS) {
+                int dd = __popcll((T.plsc_code[c] ^ plheader) & ((1ull << 60) - 1));
+                key = min(key, dd * 128 + c);
+            }
 #pragma unroll
-        for (int o = FL_LPS / 2; o > 0; o >>= 1) key = min(key, __shfl_xor(key, o));      // all-reduce inside the lane group
+            for (int o = FL_LPS / 2; o > 0; o >>= 1) key = min(key, __shfl_xor(key, o));      // all-reduce inside the lane group
+        } else {
+            // soft ML decode over all 64 code bits (include/dvbs2gpu.h): metric_c = sum_p +-soft[p] in index order, highest wins, lowest c on ties
+            __syncthreads();
+            float bm = 0.f;
+            int bc = 0x7fffffff;
+            #pragma unroll 1
+            for (int c = gl; c < 128; c += FL_LPS) {
+                const unsigned long long code = T.plsc_code[c];
+                float mtr = 0.f;
+                for (int p = 0; p < 64; ++p) { const float sv = hdr_sym[g][p].re; mtr += ((code >> (63 - p)) & 1ull) ? -sv : sv; }
+                if (bc == 0x7fffffff || mtr > bm) { bm = mtr; bc = c; }
+            }
+#pragma unroll
+            for (int o = FL_LPS / 2; o > 0; o >>= 1) {
+                const float om = __shfl_xor(bm, o);
+                const int oc = __shfl_xor(bc, o);
+                if (om > bm || (om == bm && oc < bc)) { bm = om; bc = oc; }
+            }
+            key = bc;
+        }
         if (gl == 0 && fact) {
             const int best = key & 127;
             S2FrameStats stt;
@@ -735,6 +772,328 @@ __global__ __launch_bounds__(256) void s2_deinterleave_kernel(int constel, int r
     const int f = blockIdx.y, rows = N / bits;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256)
         out[(size_t)f * N + deint_pos(constel, rate, bits, rows, i / bits, i % bits)] = in[(size_t)f * N + i];
+}
+
+// ================================================================================================ ACM/VCM path (acm_vcm)
+// Own extension (include/dvbs2gpu.h): the reference's PL sync assumes ONE frame length (dvbs2_pl_sync.cpp:81-165)
+// and its GUI re-configures the demodulator after 50 consistent PLS sightings (main.cpp:375-408).  Here the framing follows the PLS
+// code of every frame.  The CPU oracle (oracle/s2chain.cpp, S2Rx::vcm_walk / pls_at / soft_plsc_decode) states the same rules.
+//
+// s2_vcm_walk_kernel -- ONE WORKGROUP PER STREAM walks the stream's symbol FIFO:
+//   not locked: the reference's differential SOF + PLSC correlator (it does not depend on the MODCOD) over the next VCM_ACQ_WINDOW
+//               offsets, same arg-max rule (strict '>', d.im > 0, lowest offset wins ties); the best offset becomes the frame start.
+//   locked:     soft PLS decode at the frame start: phase reference z = sum x[k] conj(sof[k]) over the 26 SOF symbols, soft value of
+//               PLSC symbol p = (w.re + w.im) for even p, (w.im - w.re) for odd p with w = x[26+p] conj(z) (pi/2-BPSK, s2_defs.h:60-80),
+//               metric of codeword c = sum_p +-soft[p] in index order, highest metric wins (lowest c on ties), ratio = metric /
+//               sum |soft|.  ratio >= VCM_MIN_RATIO, SOF quality |z| / sum |x| >= sof_threshold and a valid code: the frame (its
+//               length follows from the code) is recorded once all its symbols are in the FIFO, the next header is expected right
+//               behind it.  Otherwise the lock is dropped and the search resumes one symbol further.
+__global__ __launch_bounds__(256) void s2_vcm_walk_kernel(const S2StreamWork* __restrict__ work, S2PlTablesDev T, const S2VcmMod* __restrict__ mods,
+                                                          float sof_threshold, int maxf, S2VcmFound* __restrict__ found, int* __restrict__ counts) {
+    __shared__ cf32 d[256 + 96];
+    __shared__ float r_val[256];
+    __shared__ int r_idx[256];
+    __shared__ float soft[64];
+    __shared__ cf32 hx[90];
+    __shared__ float s_ratio, s_sofq;
+    __shared__ int s_pls;
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const S2StreamWork w = work[s];
+    S2StreamState* st = w.st;
+    const cf32* __restrict__ fifo = w.fifo;
+    const int nsym = st->n_sym;
+    const int avail_total = w.fifo_fill + nsym;
+    int synced = st->vcm_synced;
+    int cur = 0, nf = 0;
+    const uint32_t dsof = 0x18d2e82u ^ (0x18d2e82u >> 1);
+    const unsigned long long SCR = 0x719d83c953422dfaull;
+    const unsigned long long dscr = SCR ^ (SCR >> 1);
+    while (true) {
+        const int avail = avail_total - cur;
+        if (!synced) {
+            if (avail < VCM_ACQ_WINDOW + 90) break;
+            const cf32* __restrict__ x = fifo + cur;
+            float bestv = 0.f;
+            int besti = 0;
+            for (int base = 0; base < VCM_ACQ_WINDOW; base += 256) {
+                __syncthreads();
+                for (int k = tid; k < 256 + 90; k += 256) {
+                    const int a = base + k;
+                    cf32 v{0.f, 0.f};
+                    if (k >= 1 && a < VCM_ACQ_WINDOW + 90) v = cmul(cconj(x[a - 1]), x[a]);
+                    d[k] = v;
+                }
+                __syncthreads();
+                const int ss = base + tid;
+                if (ss < VCM_ACQ_WINDOW) {
+                    const cf32* dd = &d[tid];
+                    cf32 csof{0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 26; ++i) {
+                        cf32 v = (i == 0) ? cf32{0.f, 0.f} : dd[i];
+                        if (((dsof >> (25 - i)) ^ i) & 1) csof = cadd(csof, v);
+                        else csof = csub(csof, v);
+                    }
+                    cf32 cpl{0.f, 0.f};
+#pragma unroll
+                    for (int i = 1; i < 64; i += 2) {
+                        if ((dscr >> (63 - i)) & 1) cpl = csub(cpl, dd[26 + i]);
+                        else cpl = cadd(cpl, dd[26 + i]);
+                    }
+                    cf32 c0 = cadd(csof, cpl), c1 = csub(csof, cpl);
+                    cf32 c = camp(c0) > camp(c1) ? c0 : c1;
+                    cf32 dv = cscale(c, 1.0f / (26 - 1 + 64 / 2));
+                    float diff = camp(dv);
+                    if (diff > bestv && dv.im > 0) { bestv = diff; besti = ss; }
+                }
+            }
+            r_val[tid] = bestv; r_idx[tid] = besti;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if (tid < o) {
+                    float v2 = r_val[tid + o]; int i2 = r_idx[tid + o];
+                    float v1 = r_val[tid]; int i1 = r_idx[tid];
+                    if (v2 > v1 || (v2 == v1 && v2 > 0.f && i2 < i1)) { r_val[tid] = v2; r_idx[tid] = i2; }
+                }
+                __syncthreads();
+            }
+            const float bv = r_val[0];
+            const int bi = r_idx[0];
+            __syncthreads();
+            if (bv > 0.f) { cur += bi; synced = 1; }
+            else cur += VCM_ACQ_WINDOW;
+            continue;
+        }
+        if (avail < 90) break;
+        // ---- PLS decode at the expected frame start
+        __syncthreads();
+        if (tid < 90) hx[tid] = fifo[cur + tid];
+        __syncthreads();
+        cf32 z{0.f, 0.f};
+        float amp = 0.f;
+        for (int k = 0; k < 26; ++k) { z = cadd(z, cmul(hx[k], cconj(T.sof[k]))); amp += camp(hx[k]); }     // (every thread: the same sequential sums)
+        if (tid < 64) {
+            const cf32 wv = cmul(hx[26 + tid], cconj(z));
+            soft[tid] = (tid & 1) ? (wv.im - wv.re) : (wv.re + wv.im);
+        }
+        __syncthreads();
+        float mtr = 0.f;
+        if (tid < 128) {
+            const unsigned long long code = T.plsc_code[tid];
+            for (int p = 0; p < 64; ++p) mtr += ((code >> (63 - p)) & 1ull) ? -soft[p] : soft[p];
+        }
+        r_val[tid] = mtr; r_idx[tid] = tid;
+        __syncthreads();
+        for (int o = 64; o > 0; o >>= 1) {        // over the 128 codewords: highest metric, lowest index on ties
+            if (tid < o) {
+                float v2 = r_val[tid + o]; int i2 = r_idx[tid + o];
+                float v1 = r_val[tid]; int i1 = r_idx[tid];
+                if (v2 > v1 || (v2 == v1 && i2 < i1)) { r_val[tid] = v2; r_idx[tid] = i2; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            float tot = 0.f;
+            for (int p = 0; p < 64; ++p) tot += fabsf(soft[p]);
+            s_ratio = tot > 0.f ? r_val[0] / tot : 0.f;
+            s_sofq = amp > 0.f ? camp(z) / amp : 0.f;
+            s_pls = r_idx[0];
+        }
+        __syncthreads();
+        const int pls = s_pls;
+        const float ratio = s_ratio, sofq = s_sofq;
+        const S2VcmMod M = mods[pls];
+        const bool ok = ratio >= VCM_MIN_RATIO && sofq >= sof_threshold && M.valid != 0;
+        if (!ok) { synced = 0; cur += 1; continue; }
+        if (avail < M.plframe || nf >= maxf) break;
+        if (tid == 0) found[(size_t)s * maxf + nf] = S2VcmFound{cur, pls, sofq, 0};
+        ++nf;
+        cur += M.plframe;
+    }
+    if (tid == 0) {
+        st->vcm_synced = synced;
+        counts[4 * s] = nf; counts[4 * s + 1] = cur; counts[4 * s + 2] = avail_total; counts[4 * s + 3] = nsym;
+    }
+}
+
+// s2_vcm_loops_kernel -- ONE WAVE PER STREAM, its frames in order, every frame with the parameters of ITS PLS code: coarse FED + NCO
+// feedback, PLL, PLHDR demod exactly as in s2_frame_loops_kernel (same operation order), in the plain one-wave-per-stream form: the
+// serial recurrences run uniformly in all lanes, the lanes share the loads / stores and the parallel parts.
+__global__ __launch_bounds__(64) void s2_vcm_loops_kernel(const S2StreamWork* __restrict__ work, const S2VcmFrame* __restrict__ frames,
+                                                          const int* __restrict__ first, S2LoopCoefs co, S2PlTablesDev T,
+                                                          const S2VcmMod* __restrict__ mods, const S2ConstelDev* __restrict__ cons,
+                                                          cf32* __restrict__ pllout, S2FrameStats* __restrict__ stats) {
+    __shared__ cf32 tile[64];
+    __shared__ cf32 otile[64];
+    __shared__ uint8_t rnt[64];
+    __shared__ float fedt[96];
+    __shared__ cf32 hdr_sym[90];
+    __shared__ float hsoft[64];
+    const int lane = threadIdx.x, s = blockIdx.x;
+    S2StreamState* st = work[s].st;
+    PclDev pll{co.pll_alpha, co.pll_beta, st->pll_phase, st->pll_freq, co.pll_min_freq, co.pll_max_freq};
+    PclDev hdr{co.hdr_alpha, co.hdr_beta, st->hdr_phase, st->hdr_freq, co.hdr_min_freq, co.hdr_max_freq};
+    float nco_freq = st->nco_freq;
+    const float PI_F = 3.14159265358979323846f;
+    for (int f = first[s]; f < first[s + 1]; ++f) {
+        const S2VcmFrame F = frames[f];
+        const S2VcmMod M = mods[F.pls];
+        S2FrameStats stt;
+        stt.best_match = F.sofq; stt.ldpc_trials = 0; stt.bch_corr = 0; stt.fed_err = 0.f; stt.bbframe_bytes = M.valid == 1 ? M.kb : 0;
+        stt.detected_modcod = F.pls >> 2; stt.detected_short = (F.pls >> 1) & 1; stt.detected_pilots = F.pls & 1;
+        if (M.valid != 1) {                       // dummy PLFRAME: only the framing advances
+            if (lane == 0) stats[f] = stt;
+            continue;
+        }
+        const cf32* __restrict__ fr = F.sym;
+        cf32* __restrict__ out = pllout + F.pll_off;
+        const cf32* __restrict__ plsc = T.plsc + (size_t)F.pls * 64;
+        const int plframe = M.plframe, pilots = M.pilots, pilot_blocks = M.pilot_blocks;
+        const S2ConstelDev* __restrict__ C = cons + M.con;
+        const int cbits = C->bits;
+        // ---- coarse frequency error detector (dvbs2_fed.h): terms in parallel, summed in the reference's order
+        __syncthreads();
+        for (int i = lane; i < 88; i += 64) {
+            cf32 r2 = (i + 2) < 26 ? T.sof[i + 2] : plsc[i + 2 - 26];
+            cf32 r0 = i < 26 ? T.sof[i] : plsc[i - 26];
+            fedt[i] = cmul(cmul(cmul(fr[i + 2], cconj(r2)), cconj(fr[i])), r0).im;
+        }
+        for (int i = lane; i < 90; i += 64) hdr_sym[i] = fr[i];
+        __syncthreads();
+        float err = 0.f, symcnt = 90 - 2;
+        for (int i = 0; i < 88; ++i) err += fedt[i];
+        if (pilots) {
+            const cf32 p{0.707f, 0.707f};
+            for (int b = 0; b < pilot_blocks; ++b) {
+                const int start = pilot_start(b);
+                __syncthreads();
+                if (lane < 36) tile[lane] = pl_descramble(fr[start + lane], T.rn[start - 90 + lane]);
+                __syncthreads();
+                if (lane >= 2 && lane < 36) fedt[lane] = cmul(cmul(cmul(tile[lane], cconj(p)), cconj(tile[lane - 2])), p).im;
+                __syncthreads();
+                for (int i = 2; i < 36; ++i) err += fedt[i];
+                symcnt += 36 - 2;
+            }
+        }
+        const float est = err / symcnt;
+        if (fabsf(est) < 0.02) nco_freq = nco_freq + est * (co.fll_bw / 100.0f);
+        else nco_freq = nco_freq + est * co.fll_bw;
+        if (nco_freq > 0.3f * PI_F) nco_freq = 0.3f * PI_F;
+        if (nco_freq < -0.3f * PI_F) nco_freq = -0.3f * PI_F;
+        stt.fed_err = est;
+        // ---- PLL (dvbs2_pll.cpp:34-86)
+        int next_pilot = (pilots && pilot_blocks > 0) ? pilot_start(0) : -1, pb = 0;
+        cf32 pacc{0.f, 0.f};
+        for (int base = 0; base < plframe; base += 64) {
+            const int m = min(64, plframe - base);
+            __syncthreads();
+            if (lane < m) {
+                tile[lane] = fr[base + lane];
+                rnt[lane] = base + lane >= 90 ? T.rn[base + lane - 90] : 0;
+            }
+            __syncthreads();
+            for (int k = 0; k < m; ++k) {
+                const int i = base + k;
+                cf32 tmp_val = cmul(tile[k], phasor(-pll.phase));
+                float error = 0.f;
+                cf32 o;
+                bool block_end = false;
+                if (i >= 90) {
+                    cf32 descr = pl_descramble(tmp_val, rnt[k]);
+                    bool is_pilot = next_pilot >= 0 && i >= next_pilot && i < next_pilot + 36;
+                    if (!is_pilot) {
+                        if (cbits != 5) error = C->lut_err[lut_index(tmp_val.re) * 256 + lut_index(tmp_val.im)];
+                        else error = soft_phase_err_noinline(C->pts_g, C->states, C->amp, C->prescale, tmp_val);
+                    } else {
+                        const cf32 pr = cmul(descr, cf32{0.707f, -0.707f});
+                        error = cphase(pr);
+                        if (co.pilot_aided) pacc = cadd(pacc, pr);
+                        if (i == next_pilot + 35) { ++pb; next_pilot = pb < pilot_blocks ? pilot_start(pb) : -1; block_end = true; }
+                    }
+                    o = descr;
+                } else {
+                    const cf32 pr = cmul(tmp_val, cconj(i < 26 ? T.sof[i] : plsc[i - 26]));
+                    error = cphase(pr);
+                    if (co.pilot_aided) pacc = cadd(pacc, pr);
+                    block_end = i == 89;
+                    o = cf32{0.f, 0.f};
+                }
+                if (lane == 0) otile[k] = o;
+                pll.advance(error);
+                pll.wrap_pi_once();
+                if (co.pilot_aided && block_end) {
+                    if (pacc.re != 0.f || pacc.im != 0.f) {
+                        pll.phase += cphase(pacc);
+                        pll.advance(0.f);
+                        pll.wrap_pi();
+                    }
+                    pacc = cf32{0.f, 0.f};
+                }
+            }
+            __syncthreads();
+            if (lane < m && base + lane >= 90) out[base + lane] = otile[lane];
+        }
+        // ---- PL header demod (dvbs2_plhdr_demod.cpp:33-67): loop + header symbols; the frame's PLS code is the one the framing decoded
+        const cf32 rot{(float)0.70710678118654757, (float)-0.70710678118654746};
+        __syncthreads();
+        for (int i = 0; i < 90; ++i) {
+            cf32 tmp_val = cmul(hdr_sym[i], phasor(-hdr.phase));
+            float error = ((tmp_val.re > 0 ? 1.0f : -1.0f) * tmp_val.im) - ((tmp_val.im > 0 ? 1.0f : -1.0f) * tmp_val.re);
+            cf32 o = (i & 1) ? cf32{-tmp_val.re, tmp_val.im} : cf32{tmp_val.im, tmp_val.re};
+            if (lane == 0) out[i] = o;
+            hdr.advance(error);
+            hdr.wrap_pi_once();
+        }
+        hdr.phase += hdr.freq * (plframe - 91);
+        hdr.advance(0.f);
+        hdr.wrap_pi();
+        (void)hsoft; (void)rot;
+        if (lane == 0) stats[f] = stt;
+    }
+    if (lane == 0) {
+        st->pll_phase = pll.phase; st->pll_freq = pll.freq;
+        st->hdr_phase = hdr.phase; st->hdr_freq = hdr.freq;
+        st->nco_freq = nco_freq;
+    }
+}
+
+// soft demap + bit de-interleave of pooled frames with per-frame MODCOD; grid (x: symbol tiles, y: frame); LLRs in frame order
+__global__ __launch_bounds__(256) void s2_vcm_demap_kernel(const S2VcmFrame* __restrict__ frames, const S2VcmMod* __restrict__ mods,
+                                                           const S2ConstelDev* __restrict__ cons, const cf32* __restrict__ pllout,
+                                                           int8_t* __restrict__ llr) {
+    const S2VcmFrame F = frames[blockIdx.y];
+    const S2VcmMod M = mods[F.pls];
+    if (M.valid != 1) return;
+    const S2ConstelDev& C = cons[M.con];
+    const cf32* __restrict__ fr = pllout + F.pll_off;
+    int8_t* __restrict__ out = llr + F.llr_off;
+    const int nsym = M.slots * 90, bits = M.bits, rows = M.N / bits;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < nsym; j += gridDim.x * 256) {
+        int pos = 90 + j;
+        if (M.pilots) pos += 36 * (j / 1440);
+        const cf32 v = fr[pos];
+        int8_t b[5];
+        if (bits != 5) {
+            const int8_t* __restrict__ e = C.lut_bits + ((size_t)lut_index(v.re) * 256 + lut_index(v.im)) * bits;
+            for (int c = 0; c < bits; ++c) b[c] = e[c];
+        } else {
+            soft_calc_dev(C, v, b, nullptr);
+        }
+        for (int c = 0; c < bits; ++c) out[deint_pos(M.constel, M.rate, bits, rows, j, c)] = b[c];
+    }
+}
+// frames of one FEC group -> contiguous LLR block (the decoder takes [frames][N]); grid (x: tiles, y: frame of the group)
+__global__ __launch_bounds__(256) void s2_vcm_gather_kernel(const S2VcmFrame* __restrict__ frames, const int* __restrict__ idx, int N,
+                                                            const int8_t* __restrict__ llr, int8_t* __restrict__ grp) {
+    const int8_t* __restrict__ src = llr + frames[idx[blockIdx.y]].llr_off;
+    int8_t* __restrict__ dst = grp + (size_t)blockIdx.y * N;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N / 4; i += gridDim.x * 256) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(src)[i];
+}
+// BBFRAMEs of one FEC group -> their places in the streams' output buffers
+__global__ __launch_bounds__(256) void s2_vcm_scatter_kernel(const int* __restrict__ idx, int kb, const uint8_t* __restrict__ bb, uint8_t* const* __restrict__ dst) {
+    const uint8_t* __restrict__ src = bb + (size_t)blockIdx.x * kb;
+    uint8_t* __restrict__ d = dst[idx[blockIdx.x]];
+    for (int i = threadIdx.x; i < kb; i += 256) d[i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------------------ call tails
@@ -1108,6 +1467,30 @@ hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const
                                  int pilot_blocks, int plframe, cf32* d_pllout, S2FrameStats* d_stats, hipStream_t st) {
     hipLaunchKernelGGL(s2_frame_loops_kernel, dim3((nstreams + FL_SPW - 1) / FL_SPW), dim3(64), 0, st, d_work, nstreams, d_frames, d_first, coefs,
                        tabs, con, pls_code, slots, pilots, pilot_blocks, plframe, d_pllout, d_stats);
+    return hipGetLastError();
+}
+hipError_t s2_vcm_walk_launch(const S2StreamWork* d_work, int nstreams, S2PlTablesDev tabs, const S2VcmMod* d_mods, float sof_threshold, int maxf,
+                              S2VcmFound* d_found, int* d_counts, hipStream_t st) {
+    hipLaunchKernelGGL(s2_vcm_walk_kernel, dim3(nstreams), dim3(256), 0, st, d_work, tabs, d_mods, sof_threshold, maxf, d_found, d_counts);
+    return hipGetLastError();
+}
+hipError_t s2_vcm_loops_launch(const S2StreamWork* d_work, int nstreams, const S2VcmFrame* d_frames, const int* d_first, S2LoopCoefs coefs,
+                               S2PlTablesDev tabs, const S2VcmMod* d_mods, const S2ConstelDev* d_cons, cf32* d_pllout, S2FrameStats* d_stats,
+                               hipStream_t st) {
+    hipLaunchKernelGGL(s2_vcm_loops_kernel, dim3(nstreams), dim3(64), 0, st, d_work, d_frames, d_first, coefs, tabs, d_mods, d_cons, d_pllout, d_stats);
+    return hipGetLastError();
+}
+hipError_t s2_vcm_demap_launch(const S2VcmFrame* d_frames, int nframes, const S2VcmMod* d_mods, const S2ConstelDev* d_cons, const cf32* d_pllout,
+                               int8_t* d_llr, hipStream_t st) {
+    hipLaunchKernelGGL(s2_vcm_demap_kernel, dim3((360 * 90 + 255) / 256, nframes), dim3(256), 0, st, d_frames, d_mods, d_cons, d_pllout, d_llr);
+    return hipGetLastError();
+}
+hipError_t s2_vcm_gather_launch(const S2VcmFrame* d_frames, const int* d_idx, int count, int N, const int8_t* d_llr, int8_t* d_grp, hipStream_t st) {
+    hipLaunchKernelGGL(s2_vcm_gather_kernel, dim3(16, count), dim3(256), 0, st, d_frames, d_idx, N, d_llr, d_grp);
+    return hipGetLastError();
+}
+hipError_t s2_vcm_scatter_launch(const int* d_idx, int count, int kb, const uint8_t* d_bb, uint8_t* const* d_dst, hipStream_t st) {
+    hipLaunchKernelGGL(s2_vcm_scatter_kernel, dim3(count), dim3(256), 0, st, d_idx, kb, d_bb, d_dst);
     return hipGetLastError();
 }
 hipError_t s2_deinterleave_launch(int constel, int rate, int bits, int N, const int8_t* d_in, int nframes, int8_t* d_out, hipStream_t st) {

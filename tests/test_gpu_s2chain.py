@@ -489,3 +489,101 @@ def test_segment_receiver_argument_checks(engine, pkg):
         bad.modcod = 77
         pkg.SegmentReceiver(engine, bad, 2, 4, 2)
     assert e.value.code == pkg.ERR_MODCOD
+
+
+# ------------------------------------------------------------------------------------------------ extensions (include/dvbs2gpu.h)
+VCM_PLS = [(4 << 2) | 2, (14 << 2) | 2, (6 << 2) | 2 | 1, 0, (19 << 2) | 2, (27 << 2) | 2 | 1, 13 << 2, (12 << 2) | 2]
+
+
+@pytest.mark.parametrize('esn0,cfo,chunk', [(100.0, 0.0, 50000), (22.0, 1e-3, 30011), (22.0, 1e-3, 1000000)])
+def test_acm_vcm_stream_cycling_modcods_equals_oracle(engine, esn0, cfo, chunk):
+    """ONE stream whose frames cycle over seven MODCODs (QPSK, 8PSK, 16APSK, 32APSK; short and normal frames; with
+    and without pilots) and a dummy PLFRAME.  The framing follows the PLS code of every frame; symbols, aligned frames, PLL output, LLRs,
+    per-frame statistics (MODCOD, SOF quality, FED estimate, LDPC trials, BCH corrections, BBFRAME size) and the BBFRAME bytes must
+    EQUAL the oracle's, call by call, and the decoded frames are the transmitted ones in order."""
+    iq, bbs = orc.transmit_vcm(VCM_PLS, 26, seed=3, esn0_db=esn0, cfo=cfo, timing=0.3, phase0=0.2, lead_symbols=500)
+    rx = orc.OracleRx(orc.default_cfg(4, 1, 0, acm_vcm=1, max_ldpc_trials=25))
+    dm = engine.demod(engine.default_cfg(4, True, False, acm_vcm=1, max_ldpc_trials=25), max_samples=max(min(chunk, iq.size), 4096))
+    got_all, mods = [], []
+    for ncall, a in enumerate(range(0, iq.size, chunk)):
+        part = iq[a:a + chunk]
+        o = rx.process(part)
+        g = dm.process(part)
+        for t in range(4):
+            assert same_bits(rx.tap(t), dm.tap(t)), ('tap', t, ncall)
+        st_o, st_g = rx.tap(4), dm.stats()
+        assert len(st_o) == len(st_g), ncall
+        for a_, b_ in zip(st_o, st_g):
+            assert np.float32(a_.best_match).view(np.uint32) == np.float32(b_.pl_sync_best_match).view(np.uint32)
+            assert np.float32(a_.fed_err).view(np.uint32) == np.float32(b_.coarse_freq_err).view(np.uint32)
+            assert (a_.detect_modcod, a_.detect_short, a_.detect_pilots, a_.ldpc_trials, a_.bch_corr, a_.bbframe_bytes) == \
+                   (b_.detected_modcod, b_.detected_shortframes, b_.detected_pilots, b_.ldpc_trials, b_.bch_corrections, b_.bbframe_bytes)
+            mods.append(b_.detected_modcod)
+        assert len(o) == len(g) and all(np.array_equal(x, y) for x, y in zip(o, g)), ('BBFRAMEs', ncall)
+        got_all += g
+    sent = [bytes(b) for b in bbs if b is not None]
+    idx = [sent.index(bytes(x)) if bytes(x) in sent else -1 for x in got_all]
+    good = [k for k in idx if k >= 0]
+    assert len(good) >= len(sent) - 9 and good == list(range(good[0], good[0] + len(good))), idx      # (the acquisition window swallows the first frames)
+    assert len(set(mods)) >= 6 and 0 in mods, mods                                                    # dummy PLFRAMEs were recognised and skipped
+    dm.close()
+
+
+def test_acm_vcm_batch_of_streams_and_error_paths(engine, pkg):
+    """several ACM/VCM streams and a CCM stream in one process_batch call == each on its own handle; the pipelined mode refuses ACM/VCM"""
+    import torch
+    lists = [VCM_PLS, [(6 << 2) | 2, (14 << 2) | 2], [(13 << 2) | 2 | 1, 0, (4 << 2)]]
+    iqs, ref, dms = [], [], []
+    for k, pl in enumerate(lists):
+        iq, _ = orc.transmit_vcm(pl, 16, seed=20 + k, esn0_db=25.0, cfo=2e-4 * k, timing=0.1 * k, lead_symbols=300)
+        iqs.append(iq)
+        d = engine.demod(engine.default_cfg(4, True, False, acm_vcm=1), max_samples=iq.size)
+        ref.append(np.concatenate(d.process(iq) or [np.zeros(0, np.uint8)]))
+        d.close()
+        dms.append(engine.demod(engine.default_cfg(4, True, False, acm_vcm=1), max_samples=iq.size))
+    iq, _, _ = orc.transmit(14, 1, 0, nframes=6, seed=31, esn0_db=25.0, lead_symbols=200)
+    iqs.append(iq)
+    d = engine.demod(engine.default_cfg(14, True, False), max_samples=iq.size)
+    ref.append(d.process(iq).reshape(-1))
+    d.close()
+    dms.append(engine.demod(engine.default_cfg(14, True, False), max_samples=iq.size))
+    tin = [torch.from_numpy(i).cuda() for i in iqs]
+    tout = [torch.zeros(max(i.size for i in iqs) // 2 + 100000, dtype=torch.uint8, device='cuda') for _ in iqs]
+    nb = engine.process_batch(dms, tin, tout)
+    for s in range(len(iqs)):
+        assert nb[s] == ref[s].size and np.array_equal(tout[s][:nb[s]].cpu().numpy(), ref[s]), s
+    assert sum(nb) > 20000
+    engine.set_pipelined(True)
+    try:
+        with pytest.raises(pkg.Dvbs2GpuError) as e:
+            engine.process_batch(dms, tin, tout)
+        assert e.value.code == pkg.ERR_ARG
+    finally:
+        engine.set_pipelined(False)
+    for d in dms:
+        d.close()
+
+
+@pytest.mark.parametrize('modcod,short,pilots,esn0,flags', [(14, 1, 1, 12.0, dict(pilot_aided=1)), (27, 1, 1, 18.0, dict(pilot_aided=1, soft_plsc=1)),
+                                                            (4, 1, 0, 6.0, dict(soft_plsc=1)), (14, 1, 0, 14.0, dict(pilot_aided=1, soft_plsc=1))])
+def test_soft_plsc_and_pilot_aided_modes_equal_oracle(engine, modcod, short, pilots, esn0, flags):
+    """SURVEY 8(f) rank 4, behind flags (default off = the reference's behaviour, tested above): soft ML decode of the PLS code in the PLHDR
+    demodulator and the block phase estimate from header / pilot symbols in the PLL.  Same equality bar against the oracle."""
+    iq, bb, _ = orc.transmit(modcod, short, pilots, nframes=14, seed=70 + modcod, esn0_db=esn0, cfo=1e-3, timing=0.3, phase0=0.1, lead_symbols=400)
+    rx = orc.OracleRx(orc.default_cfg(modcod, short, pilots, max_ldpc_trials=30, **flags))
+    dm = engine.demod(engine.default_cfg(modcod, bool(short), bool(pilots), max_ldpc_trials=30, **flags), max_samples=20000)
+    ndec = 0
+    for ncall, a in enumerate(range(0, iq.size, 20000)):
+        part = iq[a:a + 20000]
+        o, g = rx.process(part), dm.process(part)
+        for t in range(4):
+            assert same_bits(rx.tap(t), dm.tap(t)), ('tap', t, ncall)
+        for a_, b_ in zip(rx.tap(4), dm.stats()):
+            assert (a_.detect_modcod, a_.detect_short, a_.detect_pilots, a_.ldpc_trials, a_.bch_corr) == \
+                   (b_.detected_modcod, b_.detected_shortframes, b_.detected_pilots, b_.ldpc_trials, b_.bch_corrections)
+            if 'soft_plsc' in flags and ncall > 1:
+                assert (b_.detected_modcod, b_.detected_shortframes, b_.detected_pilots) == (modcod, short, pilots)   # all 64 bits: size and pilots right too
+        assert np.array_equal(o, g)
+        ndec += len(g)
+    assert ndec >= 8
+    dm.close()
