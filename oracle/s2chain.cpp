@@ -715,6 +715,7 @@ void S2Rx::vcm_walk(uint8_t* out, int out_cap, int* outcnt) {
             st.best_match = sofq; st.detect_modcod = 0; st.detect_short = (pls >> 1) & 1; st.detect_pilots = pls & 1;
             st.ldpc_trials = 0; st.bch_corr = 0; st.bbframe_bytes = 0;
             dbg_stats.push_back(st);
+            dbg_frames.insert(dbg_frames.end(), vfifo.begin() + cur, vfifo.begin() + cur + fc->mp.plframe);   // (tap 1 shows every frame the framing found)
         } else {
             process_frame(&vfifo[cur], *fc, sofq, out, out_cap, outcnt);
         }
