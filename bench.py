@@ -563,7 +563,7 @@ def main():
     tp = os.path.join(ROOT, 'profiles', 'r02_ldpc_traffic.json')
     if os.path.exists(tp):
         tj = json.load(open(tp))
-        traffic = tj.get('traffic_bytes_per_launch')
+        traffic = tj.get('traffic_bytes_per_frame', 0) * in_step_frames or None     # (measured on a 4096-frame launch; the kernel's traffic is per frame)
         traffic_note = tj.get('source')
         issue = tj.get('valu_issue_fraction')
 
@@ -591,7 +591,7 @@ def main():
                          'kernel_ms_in_step': round(in_step_ms, 4), 'frames_per_launch': int(in_step_frames),
                          'kernel_ms_alone': round(k['forced'], 4), 'achieved_alone': round(achieved_alone, 1), 'frac_alone': round(achieved_alone / HBM_PEAK_GBS, 4),
                          'kernel_ms_alone_normal_mode_same_iterations': round(k['normal'], 4) if k['normal_all_ran'] else None,
-                         'traffic': traffic, 'traffic_unit': 'bytes per launch (fabric-side FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_note,
+                         'traffic': traffic, 'traffic_unit': 'bytes per launch (fabric-side FETCH_SIZE x2 + WRITE_SIZE, per frame x frames of the launch)', 'traffic_source': traffic_note,
                          'valu_issue_fraction': issue,
                          'algorithmic_bytes_per_frame': bytes_per_frame, 'algorithmic_bytes_per_launch': int(bytes_per_frame * in_step_frames),
                          'ldpc_share_of_step': round(in_step_ms * l_n / (dt * 1e3), 3),

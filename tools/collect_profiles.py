@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Development aid: turn the outputs of tools/profile_run.sh (gpurun_out/fin_<tag>/) into the committed summaries under profiles/:
+  <tag>_bench.json                 the bench line of that run
+  <tag>_bench_kernel_stats.csv     rocprofv3 --kernel-trace --stats summary of the pipelined bench (3 steps)
+  <tag>_bench_timeline.txt         every dispatch >= 2 ms with start / end (what overlaps what)
+  <tag>_ldpc_pmc.txt               the PMC passes over one forced LDPC launch (4096 frames x 50 iterations)
+  <tag>_ldpc_traffic.json          fabric traffic and VALU issue fraction derived from them (read by bench.py)"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+F, P = os.path.join(ROOT, 'gpurun_out', 'fin_' + tag), os.path.join(ROOT, 'profiles')
+rd = lambda n: open(os.path.join(F, n)).read()
+open(os.path.join(P, tag + '_bench.json'), 'w').write(rd('bench.json'))
+open(os.path.join(P, tag + '_bench_kernel_stats.csv'), 'w').write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary (tools/profile_run.sh)\n' + rd('kt.csv'))
+open(os.path.join(P, tag + '_bench_timeline.txt'), 'w').write('# start_ms end_ms duration_ms queue kernel -- dispatches >= 2 ms of the same run (tools/timeline.py); q=3: FEC stream, q=2: front-end stream\n' + rd('timeline.txt'))
+rows = [l.rstrip() for p in ('p1', 'p2', 'p3') for l in open(os.path.join(F, p + '.csv')) if 'ldpc_decode_kernel' in l]
+get = lambda c: [float(l.split(',')[-1]) for l in rows if '"' + c + '"' in l][0]
+dur_ns = [float(l.split(',')[3]) for l in rows if l.count(',') >= 6 and 'FETCH' not in l and 'SQ_' not in l and 'WRITE' not in l]
+ms = sum(dur_ns) / len(dur_ns) / 1e6
+frames, iters = 4096, 50
+head = ['# %s: PMC passes over ONE forced LDPC launch = the bench\'s dominant kernel (rate 3/4 normal, %d frames, %d iterations): tools/pmc_ldpc.py 6, FRAMES=%d ITERS=%d' % (tag, frames, iters, frames, iters),
+        '# separate passes: --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_*  (rocprofv3, ROCm 7.2; values summed over XCDs; FETCH/WRITE_SIZE unit = KB)']
+open(os.path.join(P, tag + '_ldpc_pmc.txt'), 'w').write('\n'.join(head + rows) + '\n')
+fetch, write, valu = get('FETCH_SIZE'), get('WRITE_SIZE'), get('SQ_INSTS_VALU')
+traffic = (2 * fetch + write) * 1024
+cus, simds, clk = 256, 4, 2.4e9
+t = {
+    'kernel': 'ldpc_decode_kernel<12,4,false>',
+    'launch': {'rate': '3/4 normal', 'frames': frames, 'iterations': iters, 'forced': True, 'kernel_ms': round(ms, 3)},
+    'source': 'profiles/%s_ldpc_pmc.txt (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc SQ_* in separate passes, tools/pmc_ldpc.py); gfx950: FETCH_SIZE tallies '
+              '128-B read requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE taken as is; both count fabric-side requests, Infinity-Cache hits '
+              'included; KB = 1024 B' % tag,
+    'fetch_size_kb': fetch, 'write_size_kb': write,
+    'traffic_bytes_per_launch': traffic, 'traffic_bytes_per_frame': traffic / frames,
+    'sq_insts_valu': valu,
+    'valu_issue_fraction': round(valu * 4 / (cus * simds * ms * 1e-3 * clk), 4),
+    'valu_issue_formula': 'SQ_INSTS_VALU x 4 cycles (a wave64 VALU instruction occupies its SIMD for 4 cycles) / (256 CUs x 4 SIMDs x kernel time x 2.4 GHz)',
+    'wait_fraction': round(get('SQ_WAIT_ANY') / get('SQ_WAVE_CYCLES'), 4),
+}
+json.dump(t, open(os.path.join(P, tag + '_ldpc_traffic.json'), 'w'), indent=2)
+print(json.dumps(t, indent=1))
