@@ -364,6 +364,32 @@ def secondary_dvbs(eng, pkg, dev):
     return out
 
 
+def small_batch(eng, pkg, dev, S=64, F=1):
+    """latency of a small synchronous call (SURVEY 8(d): per-stream ceiling): `S` transponders x `F` PLFRAME(s) of 8PSK 3/4, early-exit LDPC;
+    where the call's time goes (per-stage device times) and what the host adds on top (call time - sum of the stages)"""
+    import torch
+    run = S2Run(eng, pkg, dev, MODCOD, SHORT, PILOTS, 14.0, S, F, min(S, 16), seed=77, iters=16, force=False)
+    eng.set_pipelined(False)
+    for _ in range(PREROLL_FRAMES // F):
+        run.step()
+    torch.cuda.synchronize()
+    eng.stage_times()
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        nb = run.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    st = eng.stage_times()
+    acc = run.check(nb)
+    run.close()
+    dev_ms = sum(v[0] for v in st.values()) / reps
+    return {'config': 'small batch: %d transponders x %d PLFRAME per call, 8PSK 3/4 normal, synchronous mode, LDPC with early exit' % (S, F),
+            'ms_per_call': round(dt * 1e3, 3), 'msym_s_total': round(S * F * run.sym / dt / 1e6, 2), 'msym_s_per_stream': round(F * run.sym / dt / 1e6, 3),
+            'stage_ms_per_call': {k: round(v[0] / reps, 3) for k, v in st.items()}, 'host_and_gaps_ms_per_call': round(dt * 1e3 - dev_ms, 3),
+            'frames_delivered': acc['delivered'], 'frames_equal_to_transmitted': acc['equal']}
+
+
 # ------------------------------------------------------------------------------------------------ config 4: 64 mixed transponders
 MIXED_MODCODS = [4, 6, 7, 11, 12, 13, 14, 15]
 MIXED_ESN0 = {4: 8.0, 6: 10.0, 7: 11.0, 11: 14.0, 12: 12.0, 13: 13.0, 14: 14.0, 15: 16.0}
@@ -608,6 +634,8 @@ def main():
                 sec.append(secondary_s2(eng, pkg, dev, '2: DVB-S2 QPSK 1/2 normal FECFRAME (MODCOD 4), same channel conditions, Es/N0 8 dB', 4, 3, 0, 0, 8.0, 2048, 4, 3))
                 sec.append(secondary_s2(eng, pkg, dev, '5 stand-in: DVB-S2 32APSK 8/9 SHORT FECFRAME + pilots (MODCOD 27; 9/10 short does not exist), Es/N0 20 dB', 27, 9, 1, 1, 20.0, 2048, 16, 3))
                 sec.append(secondary_dvbs(eng, pkg, dev))
+                sec.append(small_batch(eng, pkg, dev, 64, 1))
+                sec.append(small_batch(eng, pkg, dev, 1, 4))
             except Exception as e:          # a secondary line must not take the headline down
                 sec.append({'error': repr(e)})
             line['secondary'] = sec

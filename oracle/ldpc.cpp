@@ -1,7 +1,7 @@
 // ORACLE (test infrastructure, CPU only) -- not part of the shipped engine.
 // Scalar restatement of the reference's layered offset-min-sum LDPC decoder.
-// Pinned bit-exact against the compiled reference (oracle/_ref, see oracle/Makefile and
-// tests/test_oracle_vs_ref.py) and against the fixtures in tests/golden/.
+// Pinned bit-exact against the compiled reference (oracle/_ref, see oracle/Makefile;
+// tests/test_oracle_golden.py::test_ldpc_oracle_equals_reference_on_random_frames) and against the fixtures in tests/golden/.
 //
 // Follows, function by function:
 //   LDPCDecoder::init        xdsopl-ldpc-pabr/layered_decoder.hh:79-120   (pos/cnc build + layer-major permutation)

@@ -15,7 +15,7 @@ open(os.path.join(P, tag + '_bench_kernel_stats.csv'), 'w').write('# rocprofv3 -
 open(os.path.join(P, tag + '_bench_timeline.txt'), 'w').write('# start_ms end_ms duration_ms queue kernel -- dispatches >= 2 ms of the same run (tools/timeline.py); q=3: FEC stream, q=2: front-end stream\n' + rd('timeline.txt'))
 rows = [l.rstrip() for p in ('p1', 'p2', 'p3') for l in open(os.path.join(F, p + '.csv')) if 'ldpc_decode_kernel' in l]
 get = lambda c: [float(l.split(',')[-1]) for l in rows if '"' + c + '"' in l][0]
-dur_ns = [float(l.split(',')[3]) for l in rows if l.count(',') >= 6 and 'FETCH' not in l and 'SQ_' not in l and 'WRITE' not in l]
+dur_ns = [float(l.split(',')[-4]) for l in rows if 'FETCH' not in l and 'SQ_' not in l and 'WRITE' not in l]   # (name,calls,total,AVERAGE,min,max,percentage)
 ms = sum(dur_ns) / len(dur_ns) / 1e6
 frames, iters = 4096, 50
 head = ['# %s: PMC passes over ONE forced LDPC launch = the bench\'s dominant kernel (rate 3/4 normal, %d frames, %d iterations): tools/pmc_ldpc.py 6, FRAMES=%d ITERS=%d' % (tag, frames, iters, frames, iters),
