@@ -106,6 +106,8 @@ class Distributor:
         counts [n_units]) with row u = unit u; elsewhere (None, None).  Rows are padded to the largest per-rank count so that one
         fixed-size gather carries everything; a second one carries ids + counts."""
         import torch
+        payload = payload.to(self.device)            # (gloo: collective buffers live on the host)
+        counts = counts.to(self.device)
         width = int(payload.shape[1]) if payload.dim() == 2 else 0
         if self.dist is None:
             out = torch.zeros((n_units, width), dtype=torch.uint8, device=self.device)
