@@ -164,8 +164,8 @@ static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, 
     LdpcDeviceCode* C;
     int rc = get_ldpc(ctx, f.code_index, &C);
     if (rc) return rc;
-    // workgroups hold LDPC_FPB = 2 frame slots (ldpc_kernel.hip)
-    const int fpb = ldpc_frames_per_block();
+    // workgroups hold 2 frame slots, or 1 for batches smaller than the device (ldpc_kernel.hip)
+    const int fpb = ldpc_frames_per_block(nframes, ctx->num_cus);
     int grid = ctx->num_cus * C->blocks_per_cu;
     if (grid > (nframes + fpb - 1) / fpb) grid = (nframes + fpb - 1) / fpb;
     size_t need = (size_t)grid * fpb * C->R * C->rec_dwords * sizeof(uint32_t);
@@ -181,7 +181,7 @@ static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, 
         d_hard = (uint8_t*)ctx->ws_hard.p; hard_stride = f.K / 8;
     }
     HIP_TRY(ldpc_decode_launch(*C, d_llr, nframes, max_trials, force, d_hard, hard_stride, d_post, d_trials,
-                               (uint32_t*)ctx->ws_msg.p, grid, st, (unsigned int*)((char*)ctx->ws_msg.p + need),
+                               (uint32_t*)ctx->ws_msg.p, grid, fpb, st, (unsigned int*)((char*)ctx->ws_msg.p + need),
                                (uint32_t*)((char*)ctx->ws_msg.p + need + 256)));
     return 0;
 }

@@ -18,10 +18,10 @@ struct LdpcDeviceCode {
 };
 
 int ldpc_blocks_per_cu(int max_deg, int irregular, int N);
-int ldpc_frames_per_block();
+int ldpc_frames_per_block(int nframes, int num_cus);
 hipError_t ldpc_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nframes, int max_trials, int force,
                               uint8_t* hard, int hard_stride, int8_t* post, int32_t* trials, uint32_t* msg_ws, int grid,
-                              hipStream_t stream, unsigned int* work_ctr, uint32_t* sgn_ws);
+                              int fpb, hipStream_t stream, unsigned int* work_ctr, uint32_t* sgn_ws);
 size_t ldpc_sign_ws_bytes_per_slot();
 
 // Device-resident tables of one BCH family (GF(2^m), t).

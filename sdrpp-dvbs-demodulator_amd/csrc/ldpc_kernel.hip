@@ -544,13 +544,12 @@ __device__ __forceinline__ bool syndromes_bad(const LdpcKernelArgs& A, const uin
 // workgroup barriers are shared (half the barrier cost per frame), the serial chain / level phases of the two
 // frames overlap, and one 12-wave workgroup per CU always gets 3 waves on each SIMD (two independent 6-wave
 // workgroups only co-reside when the dispatcher happens to start them on complementary SIMDs).
-#ifndef LDPC_FPB_N
-#define LDPC_FPB_N 2
-#endif
-constexpr int LDPC_FPB = LDPC_FPB_N;  // frame slots per workgroup (1: development variant, two independent workgroups per CU)
+// FPB = frame slots per workgroup.  2 is the throughput mapping above.  1 (a 384-thread workgroup = one frame) serves SMALL batches:
+// with fewer frames than CUs every frame gets a compute unit of its own instead of sharing one with a second frame -- twice the CUs
+// busy and no issue contention between the slots, which is what a few-transponder call (or one stream's frames) needs.
 constexpr int LDPC_TPS = 384;        // threads per slot
 
-template <int MAXDEG, int REC, bool IRREG>
+template <int MAXDEG, int REC, bool IRREG, int LDPC_FPB>
 __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_per_eu(MAXDEG <= 12 ? 4 : 3))) void ldpc_decode_kernel(const LdpcLayerDesc* __restrict__ layers, const uint32_t* __restrict__ ents,
                                                                                const uint32_t* __restrict__ rows, LdpcKernelArgs A) {
     extern __shared__ __attribute__((aligned(16))) int8_t post_all[];
@@ -688,22 +687,29 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
 }
 
 template <int MAXDEG, int REC, bool IRREG>
-static hipError_t launch_ldpc(const LdpcDeviceCode& C, const LdpcKernelArgs& A, int grid, hipStream_t stream) {
-    size_t lds = (size_t)((A.N + 15) / 16) * 16 * LDPC_FPB;
-    auto kern = ldpc_decode_kernel<MAXDEG, REC, IRREG>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(LDPC_FPB * LDPC_TPS), lds, stream, C.d_layers, C.d_ents, C.d_rows, A);
+static hipError_t launch_ldpc(const LdpcDeviceCode& C, const LdpcKernelArgs& A, int grid, int fpb, hipStream_t stream) {
+    size_t lds = (size_t)((A.N + 15) / 16) * 16 * fpb;
+    if (fpb == 1) {
+        auto kern = ldpc_decode_kernel<MAXDEG, REC, IRREG, 1>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(LDPC_TPS), lds, stream, C.d_layers, C.d_ents, C.d_rows, A);
+    } else {
+        auto kern = ldpc_decode_kernel<MAXDEG, REC, IRREG, 2>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * LDPC_TPS), lds, stream, C.d_layers, C.d_ents, C.d_rows, A);
+    }
     return hipGetLastError();
 }
 
 template <int MAXDEG, int REC, bool IRREG>
 static int occupancy_ldpc(int N) {
     int nb = 0;
-    size_t lds = (size_t)((N + 15) / 16) * 16 * LDPC_FPB;
-    auto kern = ldpc_decode_kernel<MAXDEG, REC, IRREG>;
+    size_t lds = (size_t)((N + 15) / 16) * 16 * 2;
+    auto kern = ldpc_decode_kernel<MAXDEG, REC, IRREG, 2>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, LDPC_FPB * LDPC_TPS, lds) != hipSuccess) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 2 * LDPC_TPS, lds) != hipSuccess) nb = 1;
     return nb < 1 ? 1 : nb;
 }
 
@@ -734,7 +740,8 @@ static int occupancy_ldpc(int N) {
         }                                                                                  \
     }
 
-int ldpc_frames_per_block() { return LDPC_FPB; }
+// frame slots per workgroup for a batch of `nframes` on a device with `num_cus` compute units (see FPB above)
+int ldpc_frames_per_block(int nframes, int num_cus) { return nframes <= num_cus ? 1 : 2; }
 size_t ldpc_sign_ws_bytes_per_slot() { return (size_t)SGN_WS_DWORDS * sizeof(uint32_t); }
 
 int ldpc_blocks_per_cu(int max_deg, int irregular, int N) {
@@ -745,7 +752,7 @@ int ldpc_blocks_per_cu(int max_deg, int irregular, int N) {
 unsigned long long* g_ldpc_prof = nullptr;   // set by tools/ldpc_prof.py through dvbs2gpu_debug_set_prof (PROF builds)
 
 hipError_t ldpc_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nframes, int max_trials, int force,
-                              uint8_t* hard, int hard_stride, int8_t* post, int32_t* trials, uint32_t* msg_ws, int grid,
+                              uint8_t* hard, int hard_stride, int8_t* post, int32_t* trials, uint32_t* msg_ws, int grid, int fpb,
                               hipStream_t stream, unsigned int* work_ctr, uint32_t* sgn_ws) {
     LdpcKernelArgs A;
     A.work_ctr = work_ctr;
@@ -759,7 +766,7 @@ hipError_t ldpc_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nf
     A.max_trials = max_trials; A.force = force; A.hard_stride = hard_stride;
     A.prof = g_ldpc_prof;
     const int max_deg = C.max_deg, irregular = C.irregular;
-    LDPC_DISPATCH(launch_ldpc, C, A, grid, stream)
+    LDPC_DISPATCH(launch_ldpc, C, A, grid, fpb, stream)
     return hipErrorInvalidValue;
 }
 
