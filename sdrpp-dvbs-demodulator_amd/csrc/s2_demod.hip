@@ -268,9 +268,7 @@ struct dvbs2gpu_demod {
     cf32* d_fifo[2] = {nullptr, nullptr};
     uint8_t* d_out = nullptr;    // staging for the host-pointer entry point
     int fifo_cap = 0, fifo_cur = 0, fifo_fill = 0;
-    // PL-sync state machine (dvbs2_pl_sync.cpp): 0 = next window starts at fifo[0]; pending_pos > 0 = state 1
-    int pending_pos = 0;
-    float last_best_match = 0.f;
+    // (the PL-sync state machine's state -- pending realign offset, last best_match -- lives in the device-side S2StreamState)
     // results of the last call
     std::vector<S2FrameStats> stats;
     std::vector<const cf32*> frame_ptrs;     // aligned frames of the last call (device pointers into the old FIFO buffer)
@@ -315,7 +313,7 @@ int demod_reset_state(dvbs2gpu_demod* d) {
     st.agc_gain = 1.0f;
     st.g_freq = 1.0f;
     HIP_TRY(hipMemcpy(d->d_state, &st, sizeof(st), hipMemcpyHostToDevice));
-    d->fifo_fill = 0; d->pending_pos = 0; d->last_best_match = 0.f; d->nco_freq_host = 0.f; d->sym_base = 0; d->frame_pos.clear();
+    d->fifo_fill = 0; d->nco_freq_host = 0.f; d->sym_base = 0; d->frame_pos.clear();
     return 0;
 }
 
@@ -381,96 +379,39 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     float* d_nco = (float*)(d_nsym + n);                                                          // [n]
     int* d_curfill = (int*)(d_nco + n);                                                           // [2n]
     HIP_TRY(hipMemcpyAsync(d_work, work.data(), sizeof(S2StreamWork) * n, hipMemcpyHostToDevice, st));
-    std::vector<int> nsym(n);
-    if (pre_nsym) {
-        // the MODCOD-independent stages already ran for the whole batch (frontend_prepass)
-        for (int i = 0; i < n; ++i) nsym[i] = pre_nsym[i];
-    } else {
+    if (!pre_nsym) {
+        // (with pre_nsym the MODCOD-independent stages already ran for the whole batch: frontend_prepass)
         { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(s2_frontend_launch(d_work, n, d0->co, ctx->d_gardner_bank, st)); }
         { StageSpan sp(ctx->timers, ST_RRC, st); HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st)); }
-        // symbol counts back (n_sym sits in each stream's state struct)
-        HIP_TRY(s2_collect_launch(d_work, n, d_nsym, d_nco, st));
-        HIP_TRY(hipMemcpyAsync(nsym.data(), d_nsym, sizeof(int) * n, hipMemcpyDeviceToHost, st));
-        hm.mark("fe_enqueued");
-        HIP_TRY(hipStreamSynchronize(st));
-        hm.mark("fe_done");
     }
-
-    // ---- 3: PL sync.  cur[i] = FIFO index where stream i's next window starts.
-    std::vector<int> cur(n, 0), avail(n);
+    // ---- 3: PL sync.  The 2-state realign machine of S2PLSyncBlock runs on the device, one workgroup per stream walking its windows
+    // in order (s2_ccm_walk_kernel); the host only pools the frame tables it gets back (ONE synchronisation for stages 1-3).
+    int maxf = 0;
+    for (int i = 0; i < n; ++i) maxf = std::max(maxf, dm[i]->fifo_cap / raw + 2);
+    Workspace& ws_win = W[1];
+    if ((rc = ws_win.ensure(sizeof(S2VcmFound) * (size_t)n * maxf + sizeof(int) * 4 * n + 64))) return rc;
+    S2VcmFound* d_found = (S2VcmFound*)ws_win.p;
+    int* d_counts = (int*)(d_found + (size_t)n * maxf);
+    { StageSpan sp(ctx->timers, ST_PLSYNC, st); HIP_TRY(s2_ccm_walk_launch(d_work, n, raw, maxf, d_found, d_counts, st)); }
+    std::vector<S2VcmFound> found((size_t)n * maxf);
+    std::vector<int> cnts(4 * n);
+    HIP_TRY(hipMemcpyAsync(cnts.data(), d_counts, sizeof(int) * 4 * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(found.data(), d_found, sizeof(S2VcmFound) * found.size(), hipMemcpyDeviceToHost, st));
+    hm.mark("fe_enqueued");
+    HIP_TRY(hipStreamSynchronize(st));
+    hm.mark("fe_done");
+    std::vector<int> cur(n, 0);
     std::vector<std::vector<int>> frame_start(n);
     std::vector<std::vector<float>> frame_bm(n);
-    std::vector<char> active(n, 1);
     for (int i = 0; i < n; ++i) {
         dvbs2gpu_demod* d = dm[i];
-        d->tap_sym_off = d->fifo_fill; d->tap_sym_cnt = nsym[i]; d->tap_fifo = d->fifo_cur;
-        d->fifo_fill += nsym[i];
-        avail[i] = d->fifo_fill;
+        const int nfi = cnts[4 * i], nsym_i = cnts[4 * i + 3];
+        d->tap_sym_off = d->fifo_fill; d->tap_sym_cnt = nsym_i; d->tap_fifo = d->fifo_cur;
+        d->fifo_fill = cnts[4 * i + 2];
         if (d->fifo_fill > d->fifo_cap) { last_error() = "symbol FIFO overflow"; return DVBS2GPU_ERR_CAPACITY; }
-        // state 1 carried over from the previous call: the realigned frame starts at pending_pos
-        if (d->pending_pos > 0) {
-            if (avail[i] >= raw + d->pending_pos) {
-                frame_start[i].push_back(d->pending_pos); frame_bm[i].push_back(d->last_best_match);
-                cur[i] = raw + d->pending_pos;
-                d->pending_pos = 0;
-            } else {
-                active[i] = 0;
-            }
-        }
+        cur[i] = cnts[4 * i + 1];
+        for (int k = 0; k < nfi; ++k) { frame_start[i].push_back(found[(size_t)i * maxf + k].offset); frame_bm[i].push_back(found[(size_t)i * maxf + k].sofq); }
     }
-    Workspace& ws_win = W[1];
-    while (true) {
-        // speculate: every complete window from cur[i] on is aligned
-        std::vector<const cf32*> wins;
-        std::vector<int> win_stream;
-        for (int i = 0; i < n; ++i) {
-            if (!active[i]) continue;
-            const cf32* base = dm[i]->d_fifo[dm[i]->fifo_cur];
-            for (int p = cur[i]; p + raw <= avail[i]; p += raw) { wins.push_back(base + p); win_stream.push_back(i); }
-        }
-        if (wins.empty()) break;
-        const int nw = (int)wins.size();
-        if ((rc = ws_win.ensure(nw * (sizeof(cf32*) + sizeof(int) + sizeof(float))))) return rc;
-        const cf32** d_win = (const cf32**)ws_win.p;
-        int* d_pos = (int*)(d_win + nw);
-        float* d_bm = (float*)(d_pos + nw);
-        HIP_TRY(hipMemcpyAsync(d_win, wins.data(), nw * sizeof(cf32*), hipMemcpyHostToDevice, st));
-        { StageSpan sp(ctx->timers, ST_PLSYNC, st); HIP_TRY(s2_plsync_launch(d_win, nw, raw, d_pos, d_bm, st)); }
-        std::vector<int> pos(nw);
-        std::vector<float> bm(nw);
-        HIP_TRY(hipMemcpyAsync(pos.data(), d_pos, nw * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(bm.data(), d_bm, nw * sizeof(float), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        std::vector<char> again(n, 0);
-        for (int w = 0; w < nw; ++w) {
-            int i = win_stream[w];
-            if (!active[i] || again[i]) continue;   // windows after a realign are stale
-            dvbs2gpu_demod* d = dm[i];
-            d->last_best_match = bm[w];
-            if (pos[w] == 0) {
-                frame_start[i].push_back(cur[i]); frame_bm[i].push_back(bm[w]);
-                cur[i] += raw;
-            } else {
-                // state 0 -> 1: this window is dropped, the next frame is window[pos:] + pos more symbols
-                if (avail[i] >= cur[i] + raw + pos[w]) {
-                    frame_start[i].push_back(cur[i] + pos[w]); frame_bm[i].push_back(bm[w]);
-                    cur[i] += raw + pos[w];
-                    again[i] = 1;
-                } else {
-                    // not enough symbols yet: keep the window at the FIFO head and wait (state 1)
-                    d->pending_pos = pos[w];
-                    active[i] = 0;
-                }
-            }
-        }
-        bool any = false;
-        for (int i = 0; i < n; ++i) {
-            if (!again[i]) active[i] = 0;   // all its windows consumed
-            else any = true;
-        }
-        if (!any) break;
-    }
-
     hm.mark("plsync_done");
     // ---- 4..6 on the pooled frames
     std::vector<S2FrameRef> frames;
@@ -961,7 +902,12 @@ int dvbs2gpu_demod_set_params(dvbs2gpu_demod* d, int modcod, int shortframes, in
     if (rc) { d->cfg = saved; (void)demod_configure(d); return rc; }
     // setDemodParams restarts the PL sync buffer (dvbs2_pl_sync.cpp:51-79); loops keep running
     d->sym_base += d->fifo_fill;      // (the dropped symbols still count on the stream's symbol axis)
-    d->fifo_fill = 0; d->pending_pos = 0;
+    d->fifo_fill = 0;
+    {   // PL-sync state back to 0 on the device as well
+        int zero_state[2] = {0, 0};
+        HIP_TRY(hipSetDevice(d->ctx->device));
+        HIP_TRY(hipMemcpy((char*)d->d_state + offsetof(S2StreamState, pl_pending), zero_state, sizeof(int), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 

@@ -27,6 +27,8 @@ struct S2StreamState {
     int n_fe_out;     // outputs of the timing-recovery stage in the last call
     int n_sym;        // symbols appended to the PL-sync FIFO in the last call
     int vcm_synced;   // ACM/VCM framing: locked to a frame start?
+    int pl_pending;   // S2PLSyncBlock state 1 (dvbs2_pl_sync.cpp:145-164): offset of the realigned frame inside the window kept at the FIFO head
+    float pl_last_bm; // S2PLSyncBlock::best_match of the last correlation
 };
 
 // loop coefficients shared by all streams of one configuration
@@ -166,6 +168,8 @@ hipError_t s2_scatter_out_launch(const S2StreamWork* d_work, const S2FrameRef* d
 hipError_t s2_scatter_out2_launch(uint8_t* const* d_outs, const S2FrameRef* d_frames, const int* d_first, int nframes, int kb,
                                   const uint8_t* d_bb, hipStream_t st);
 hipError_t s2_fifo_compact_launch(const S2StreamWork* d_work, int nstreams, const int* d_cur_fill /*[2*nstreams]: cur, fill*/, hipStream_t st);
+// PL sync with its 2-state realign machine on the device: one workgroup per stream walks the stream's complete windows in order
+hipError_t s2_ccm_walk_launch(const S2StreamWork* d_work, int nstreams, int raw, int maxf, S2VcmFound* d_found, int* d_counts, hipStream_t st);
 // ACM/VCM path
 hipError_t s2_vcm_walk_launch(const S2StreamWork* d_work, int nstreams, S2PlTablesDev tabs, const S2VcmMod* d_mods, float sof_threshold, int maxf,
                               S2VcmFound* d_found, int* d_counts /*[nstreams][4]: frames, consumed, avail, new symbols*/, hipStream_t st);

@@ -521,7 +521,10 @@ __device__ __attribute__((noinline)) float soft_phase_err_noinline(const cf32* _
 // takes issue slots from the LDPC decoder that shares the SIMDs in the pipelined mode (16 lanes per stream: 28 ms beside it,
 // LDPC 74 ms).  Groups whose stream has fewer frames in this call shadow a frame of another group (same code path, nothing
 // stored, state restored afterwards).
-constexpr int FL_LPS = 8;
+#ifndef FL_LPS_N
+#define FL_LPS_N 8
+#endif
+constexpr int FL_LPS = FL_LPS_N;
 constexpr int FL_SPW = 64 / FL_LPS;
 constexpr int FL_TILE = 44;          // PLL symbols staged per round (>= 36: the FED reuses the tile for a pilot block, and
                                      // 44 complex = the 88 FED terms that alias the output tile); small: the
@@ -772,6 +775,110 @@ __global__ __launch_bounds__(256) void s2_deinterleave_kernel(int constel, int r
     const int f = blockIdx.y, rows = N / bits;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256)
         out[(size_t)f * N + deint_pos(constel, rate, bits, rows, i / bits, i % bits)] = in[(size_t)f * N + i];
+}
+
+// ------------------------------------------------------------------------------------------------ PL sync walk (CCM)
+// S2PLSyncBlock::process / internal_process (dvbs2_pl_sync.cpp:81-165) for one stream per workgroup, on the stream's symbol FIFO: every
+// complete window of `raw` symbols from the FIFO head on is correlated (the brute-force differential SOF + PLSC correlation of
+// s2_plsync_kernel, same arg-max rule); best_pos == 0: the window is the frame; best_pos != 0 (state 0 -> 1): the frame is
+// window[pos:] plus `pos` more symbols -- taken if they are in, else the window stays at the FIFO head and the stream waits in state 1
+// (pl_pending) for the next call.  A frame carries the best_match of the correlation that placed it (the reference's member
+// variable).  Per stream out: the frames' FIFO offsets, consumed symbols, symbols available, symbols this call added.
+__global__ __launch_bounds__(256) void s2_ccm_walk_kernel(const S2StreamWork* __restrict__ work, int raw, int maxf, S2VcmFound* __restrict__ found,
+                                                          int* __restrict__ counts) {
+    __shared__ cf32 d[256 + 96];
+    __shared__ float r_val[256];
+    __shared__ int r_idx[256];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const S2StreamWork w = work[s];
+    S2StreamState* st = w.st;
+    const cf32* __restrict__ fifo = w.fifo;
+    const int nsym = st->n_sym;
+    const int avail = w.fifo_fill + nsym;
+    int pend = st->pl_pending, cur = 0, nf = 0;
+    float lastbm = st->pl_last_bm;
+    const uint32_t dsof = 0x18d2e82u ^ (0x18d2e82u >> 1);
+    const unsigned long long SCR = 0x719d83c953422dfaull;
+    const unsigned long long dscr = SCR ^ (SCR >> 1);
+    const int noff = raw - 90;
+    bool waiting = false;
+    if (pend > 0) {
+        if (avail >= raw + pend) {
+            if (tid == 0) found[(size_t)s * maxf + nf] = S2VcmFound{pend, 0, lastbm, 0};
+            ++nf;
+            cur = raw + pend;
+            pend = 0;
+        } else {
+            waiting = true;
+        }
+    }
+    while (!waiting && cur + raw <= avail && nf < maxf) {
+        const cf32* __restrict__ x = fifo + cur;
+        float bestv = 0.f;
+        int besti = 0;
+        for (int base = 0; base < noff; base += 256) {
+            __syncthreads();
+            for (int k = tid; k < 256 + 90; k += 256) {
+                const int a = base + k;
+                cf32 v{0.f, 0.f};
+                if (k >= 1 && a < raw) v = cmul(cconj(x[a - 1]), x[a]);
+                d[k] = v;
+            }
+            __syncthreads();
+            const int ss = base + tid;
+            if (ss < noff) {
+                const cf32* dd = &d[tid];
+                cf32 csof{0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 26; ++i) {
+                    cf32 v = (i == 0) ? cf32{0.f, 0.f} : dd[i];
+                    if (((dsof >> (25 - i)) ^ i) & 1) csof = cadd(csof, v);
+                    else csof = csub(csof, v);
+                }
+                cf32 cpl{0.f, 0.f};
+#pragma unroll
+                for (int i = 1; i < 64; i += 2) {
+                    if ((dscr >> (63 - i)) & 1) cpl = csub(cpl, dd[26 + i]);
+                    else cpl = cadd(cpl, dd[26 + i]);
+                }
+                cf32 c0 = cadd(csof, cpl), c1 = csub(csof, cpl);
+                cf32 c = camp(c0) > camp(c1) ? c0 : c1;
+                cf32 dv = cscale(c, 1.0f / (26 - 1 + 64 / 2));
+                float diff = camp(dv);
+                if (diff > bestv && dv.im > 0) { bestv = diff; besti = ss; }
+            }
+        }
+        r_val[tid] = bestv; r_idx[tid] = besti;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+                float v2 = r_val[tid + o]; int i2 = r_idx[tid + o];
+                float v1 = r_val[tid]; int i1 = r_idx[tid];
+                if (v2 > v1 || (v2 == v1 && v2 > 0.f && i2 < i1)) { r_val[tid] = v2; r_idx[tid] = i2; }
+            }
+            __syncthreads();
+        }
+        const float bm = r_val[0];
+        const int pos = bm > 0.f ? r_idx[0] : 0;
+        __syncthreads();
+        lastbm = bm;
+        if (pos == 0) {
+            if (tid == 0) found[(size_t)s * maxf + nf] = S2VcmFound{cur, 0, bm, 0};
+            ++nf;
+            cur += raw;
+        } else if (avail >= cur + raw + pos) {
+            if (tid == 0) found[(size_t)s * maxf + nf] = S2VcmFound{cur + pos, 0, bm, 0};
+            ++nf;
+            cur += raw + pos;
+        } else {
+            pend = pos;
+            waiting = true;
+        }
+    }
+    if (tid == 0) {
+        st->pl_pending = pend; st->pl_last_bm = lastbm;
+        counts[4 * s] = nf; counts[4 * s + 1] = cur; counts[4 * s + 2] = avail; counts[4 * s + 3] = nsym;
+    }
 }
 
 // ================================================================================================ ACM/VCM path (acm_vcm)
@@ -1467,6 +1574,10 @@ hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const
                                  int pilot_blocks, int plframe, cf32* d_pllout, S2FrameStats* d_stats, hipStream_t st) {
     hipLaunchKernelGGL(s2_frame_loops_kernel, dim3((nstreams + FL_SPW - 1) / FL_SPW), dim3(64), 0, st, d_work, nstreams, d_frames, d_first, coefs,
                        tabs, con, pls_code, slots, pilots, pilot_blocks, plframe, d_pllout, d_stats);
+    return hipGetLastError();
+}
+hipError_t s2_ccm_walk_launch(const S2StreamWork* d_work, int nstreams, int raw, int maxf, S2VcmFound* d_found, int* d_counts, hipStream_t st) {
+    hipLaunchKernelGGL(s2_ccm_walk_kernel, dim3(nstreams), dim3(256), 0, st, d_work, raw, maxf, d_found, d_counts);
     return hipGetLastError();
 }
 hipError_t s2_vcm_walk_launch(const S2StreamWork* d_work, int nstreams, S2PlTablesDev tabs, const S2VcmMod* d_mods, float sof_threshold, int maxf,
