@@ -4,15 +4,15 @@
 // all streams in one launch and pools their frames for the FEC kernels.
 //
 // Call anatomy (process / process_batch), all on one HIP stream:
-//   1 front end (AGC+NCO+Gardner, lane per stream)            s2_frontend_kernel
-//   2 RRC on the kept samples + /2, append to the symbol FIFO  s2_rrc_decim_kernel        -> D2H symbol counts
-//   3 PL sync: correlate every complete window of every stream s2_plsync_kernel           -> D2H best_pos
-//     host replays S2PLSyncBlock's two-state realign logic (dvbs2_pl_sync.cpp:102-165) on the results;
-//     only when a window is misaligned are the following windows of that stream re-correlated
-//   4 per-frame loops (FED -> NCO feedback, PLL, PLHDR)        s2_frame_loops_kernel
-//   5 soft demap + de-interleave                               s2_demap_kernel
-//   6 LDPC / BCH / descramble over the pooled frames           ldpc_decode_kernel, bch_*, bb_descramble
-//   7 D2H (or D2D for the batch entry point) of BBFRAMEs + stats; FIFO remainder moved to the spare buffer
+//   1 front end (AGC+NCO, lane per stream; Gardner, 8 lanes per stream)    agc_pc_kernel, s2_gardner_kernel
+//   2 RRC on the kept samples + /2, append to the symbol FIFO               s2_rrc_decim_kernel
+//   3 PL sync: every stream's complete windows, correlation + the 2-state
+//     realign machine of S2PLSyncBlock (dvbs2_pl_sync.cpp:102-165)          s2_ccm_walk_kernel       -> D2H frame tables (sync 1)
+//   4 per-frame loops (FED -> NCO feedback, PLL, PLHDR)                     s2_frame_loops_kernel
+//   5 soft demap + de-interleave                                            s2_demap_kernel
+//   6 LDPC / BCH / descramble over the pooled frames                        ldpc_decode_kernel, bch_*, bb_descramble
+//   7 D2H (or D2D for the batch entry point) of BBFRAMEs + stats; FIFO remainder moved to the spare buffer (sync 2)
+// ACM/VCM streams (cfg.acm_vcm): 3 = s2_vcm_walk_kernel, 4-5 with per-frame MODCOD tables, 6 = one FEC job per LDPC code present.
 #include "ctx.h"
 #include "../../include/dvbs2gpu_math.h"
 #include <list>

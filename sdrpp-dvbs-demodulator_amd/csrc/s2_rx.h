@@ -155,8 +155,6 @@ hipError_t dvbs_soft_compact_launch(const DvbsStreamWork* d_work, int nstreams, 
 
 hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCoefs coefs, const float* d_bank, hipStream_t st);
 hipError_t s2_rrc_decim_launch(const S2StreamWork* d_work, int nstreams, int max_count, const float* d_taps, int ntaps, hipStream_t st);
-// windows: d_win[w] = pointer to raw symbols of candidate window w; outputs best_pos / best_match per window
-hipError_t s2_plsync_launch(const cf32* const* d_win, int nwin, int raw, int* d_best_pos, float* d_best_match, hipStream_t st);
 // per-stream frame loops: frames of stream s are d_frames[first[s] .. first[s+1])
 hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const S2FrameRef* d_frames, const int* d_first,
                                  S2LoopCoefs coefs, S2PlTablesDev tabs, S2ConstelDev con, int pls_code, int slots, int pilots,

@@ -390,68 +390,6 @@ __global__ __launch_bounds__(128) void s2_rrc_state_kernel(const S2StreamWork* _
     }
 }
 
-// ------------------------------------------------------------------------------------------------ PL sync
-// One workgroup per candidate window: brute-force differential SOF+PLSC correlation at every offset
-// (dvbs2_pl_sync.cpp:111-143), arg-max with strict '>' = lowest offset wins ties.
-__global__ __launch_bounds__(256) void s2_plsync_kernel(const cf32* const* __restrict__ wins, int raw, int* __restrict__ best_pos,
-                                                        float* __restrict__ best_match) {
-    __shared__ cf32 d[256 + 96];
-    __shared__ float r_val[256];
-    __shared__ int r_idx[256];
-    const cf32* __restrict__ s = wins[blockIdx.x];
-    const int tid = threadIdx.x;
-    const uint32_t dsof = 0x18d2e82u ^ (0x18d2e82u >> 1);
-    const unsigned long long SCR = 0x719d83c953422dfaull;
-    const unsigned long long dscr = SCR ^ (SCR >> 1);
-    const int noff = raw - 90;
-    float bestv = 0.f;
-    int besti = 0;
-    for (int base = 0; base < noff; base += 256) {
-        __syncthreads();
-        // differential products d[k] = conj(s[base+k-1]) * s[base+k] for k = 1 .. 256+89
-        for (int k = tid; k < 256 + 90; k += 256) {
-            int a = base + k;
-            cf32 v{0.f, 0.f};
-            if (k >= 1 && a < raw) v = cmul(cconj(s[a - 1]), s[a]);
-            d[k] = v;
-        }
-        __syncthreads();
-        int ss = base + tid;
-        if (ss < noff) {
-            const cf32* dd = &d[tid];        // dd[i] = diffs[i] of this offset; diffs[0] is defined as 0
-            cf32 csof{0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 26; ++i) {
-                cf32 v = (i == 0) ? cf32{0.f, 0.f} : dd[i];
-                if (((dsof >> (25 - i)) ^ i) & 1) csof = cadd(csof, v);
-                else csof = csub(csof, v);
-            }
-            cf32 cpl{0.f, 0.f};
-#pragma unroll
-            for (int i = 1; i < 64; i += 2) {
-                if ((dscr >> (63 - i)) & 1) cpl = csub(cpl, dd[26 + i]);
-                else cpl = cadd(cpl, dd[26 + i]);
-            }
-            cf32 c0 = cadd(csof, cpl), c1 = csub(csof, cpl);
-            cf32 c = camp(c0) > camp(c1) ? c0 : c1;
-            cf32 dv = cscale(c, 1.0f / (26 - 1 + 64 / 2));
-            float diff = camp(dv);
-            if (diff > bestv && dv.im > 0) { bestv = diff; besti = ss; }   // per-thread scan is in ascending ss
-        }
-    }
-    r_val[tid] = bestv; r_idx[tid] = besti;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
-            float v2 = r_val[tid + o]; int i2 = r_idx[tid + o];
-            float v1 = r_val[tid]; int i1 = r_idx[tid];
-            if (v2 > v1 || (v2 == v1 && v2 > 0.f && i2 < i1)) { r_val[tid] = v2; r_idx[tid] = i2; }
-        }
-        __syncthreads();
-    }
-    if (tid == 0) { best_pos[blockIdx.x] = r_val[0] > 0.f ? r_idx[0] : 0; best_match[blockIdx.x] = r_val[0]; }
-}
-
 // ------------------------------------------------------------------------------------------------ frame loops
 __device__ __forceinline__ cf32 pl_descramble(cf32 p, int r) {
     switch (r) {
@@ -779,8 +717,9 @@ __global__ __launch_bounds__(256) void s2_deinterleave_kernel(int constel, int r
 
 // ------------------------------------------------------------------------------------------------ PL sync walk (CCM)
 // S2PLSyncBlock::process / internal_process (dvbs2_pl_sync.cpp:81-165) for one stream per workgroup, on the stream's symbol FIFO: every
-// complete window of `raw` symbols from the FIFO head on is correlated (the brute-force differential SOF + PLSC correlation of
-// s2_plsync_kernel, same arg-max rule); best_pos == 0: the window is the frame; best_pos != 0 (state 0 -> 1): the frame is
+// complete window of `raw` symbols from the FIFO head on is correlated -- brute force at every offset (dvbs2_pl_sync.cpp:111-143): 90
+// differential products, signed sums over the SOF and the odd PLSC positions, c = max |csof +- cplsc|, arg-max with strict '>' and
+// d.im > 0 = the lowest offset wins ties; best_pos == 0: the window is the frame; best_pos != 0 (state 0 -> 1): the frame is
 // window[pos:] plus `pos` more symbols -- taken if they are in, else the window stays at the FIFO head and the stream waits in state 1
 // (pl_pending) for the next call.  A frame carries the best_match of the correlation that placed it (the reference's member
 // variable).  Per stream out: the frames' FIFO offsets, consumed symbols, symbols available, symbols this call added.
@@ -1563,10 +1502,6 @@ hipError_t s2_rrc_decim_launch(const S2StreamWork* d_work, int nstreams, int max
     if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(s2_rrc_decim_kernel, dim3(gx, nstreams), dim3(256), 0, st, d_work, d_taps, ntaps);
     hipLaunchKernelGGL(s2_rrc_state_kernel, dim3(nstreams), dim3(128), 0, st, d_work, ntaps);
-    return hipGetLastError();
-}
-hipError_t s2_plsync_launch(const cf32* const* d_win, int nwin, int raw, int* d_best_pos, float* d_best_match, hipStream_t st) {
-    hipLaunchKernelGGL(s2_plsync_kernel, dim3(nwin), dim3(256), 0, st, d_win, raw, d_best_pos, d_best_match);
     return hipGetLastError();
 }
 hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const S2FrameRef* d_frames, const int* d_first,
