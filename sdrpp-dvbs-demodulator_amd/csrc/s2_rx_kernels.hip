@@ -104,6 +104,20 @@ __device__ __forceinline__ cf32 phasor_hw(float x) { return phasor(x); }
 //                      halves of the timing error, two DPP broadcasts to hand it to the whole group.
 // Many streams = many lanes: the batch fills the GPU, and nothing here is redundant across lanes (the first version ran the
 // serial chains once per wave, 64 lanes wide, and took 47 ms for 4096 x 43380 samples; this one ~4x less).
+// Wave priorities of the serial front-end kernels while the LDPC decoder of the previous call shares the SIMDs (pipelined mode; the
+// decoder's parallel phases run at 0, its serial ones at 3).  A/B on the bench (tools/ab_build.sh, 4096 streams x 8 frames): everything
+// at 2: step 474 ms (decoder launch 422 ms, front end 330 ms, i.e. 100 ms of slack on the front-end stream); the Gardner kernel -- the
+// largest consumer of issue slots among them -- at 0: decoder 393 ms, front end 391 ms, step 457 ms; the frame loops at 0 as well: the
+// front end becomes the critical path (479 ms).  So: Gardner yields to the decoder, the others keep their latency.
+#ifndef AGC_PRIO
+#define AGC_PRIO 2
+#endif
+#ifndef G_PRIO
+#define G_PRIO 0
+#endif
+#ifndef FL_PRIO
+#define FL_PRIO 2
+#endif
 #ifndef FE_PRIO
 #define FE_PRIO 2   // wave priority of the serial front-end loops (A/B switch; the decoder's parallel phases run at 0, its serial ones at 3)
 #endif
@@ -200,7 +214,7 @@ __global__ __launch_bounds__(128) void agc_pc_kernel(const typename TR::Work* __
     __syncthreads();
     // the serial chains are latency-critical and issue little: win the issue arbitration against throughput kernels (the LDPC
     // decoder of the previous call shares the SIMDs in the pipelined mode)
-    if (wave == 0) __builtin_amdgcn_s_setprio(FE_PRIO);
+    if (wave == 0) __builtin_amdgcn_s_setprio(AGC_PRIO);
     for (int t = 0; t < ntiles; ++t) {
         if (wave == 0) {
             cf32(*B)[AG_T + 1] = buf[t & 1];
@@ -272,7 +286,7 @@ __global__ __launch_bounds__(64) void s2_gardner_kernel(const S2StreamWork* __re
     };
     issue(0);
     __syncthreads();
-    __builtin_amdgcn_s_setprio(FE_PRIO);       // latency-critical serial loop (see agc_pc_kernel)
+    __builtin_amdgcn_s_setprio(G_PRIO);       // latency-critical serial loop (see agc_pc_kernel)
     for (int base = 0; base < nmax; base += G_TILE) {
         commit(base);
         __syncthreads();
@@ -489,7 +503,7 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
     const float PI_F = 3.14159265358979323846f;
     const cf32* __restrict__ plsc = T.plsc + (size_t)pls_code * 64;
     const int f0 = first[sc], nf = act ? first[sc + 1] - f0 : 0;
-    __builtin_amdgcn_s_setprio(FE_PRIO);       // latency-critical serial loops (see agc_pc_kernel)
+    __builtin_amdgcn_s_setprio(FL_PRIO);       // latency-critical serial loops (see agc_pc_kernel)
     int nfmax = nf;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nfmax = max(nfmax, __shfl_xor(nfmax, o));
