@@ -522,13 +522,20 @@ __device__ __forceinline__ bool syndromes_bad(const LdpcKernelArgs& A, const uin
         uint32_t e[MAXDEG + 2];
 #pragma unroll
         for (int k = 0; k < MAXDEG + 2; ++k) e[k] = tab[k * ntask + t];
-        unsigned long long acc = 0;
+        // all sign windows are fetched before any is used: two dependent global round trips per check, not one per link
+        uint32_t d0[MAXDEG + 2], d1[MAXDEG + 2], d2[MAXDEG + 2];
 #pragma unroll
         for (int k = 0; k < MAXDEG + 2; ++k) {
             const uint32_t* __restrict__ p = S + (e[k] & 0xffffu);         // (absent links: entry 0 -> a harmless read of the first dwords)
-            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+            d0[k] = p[0]; d1[k] = p[1]; d2[k] = p[2];
+        }
+#pragma unroll
+        for (int k = 0; k < MAXDEG + 2; ++k) asm volatile("" : "+v"(d0[k]), "+v"(d1[k]), "+v"(d2[k]));   // (keeps the loads ahead of the arithmetic)
+        unsigned long long acc = 0;
+#pragma unroll
+        for (int k = 0; k < MAXDEG + 2; ++k) {
             const uint32_t sh = (e[k] >> 16) & 31u;
-            uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+            uint32_t lo = __builtin_amdgcn_alignbit(d1[k], d0[k], sh), hi = __builtin_amdgcn_alignbit(d2[k], d1[k], sh);
             lo &= ~((e[k] >> 30) & 1u);                                      // row 0 of layer 0 has no previous parity bit
             const uint32_t m = (uint32_t)((int)e[k] >> 31);                  // present?
             acc ^= ((unsigned long long)(hi & m) << 32) | (lo & m);
