@@ -196,8 +196,8 @@ __device__ __forceinline__ int chain_step(int x, uint32_t lim, uint32_t se) {
 // [0, MAXDEG) are the table links, MAXDEG the row's own parity bit and MAXDEG+1 the previous parity bit.
 template <int MAXDEG, int REC, int KIND, bool IRREG>
 __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const LdpcKernelArgs& A, const uint32_t* __restrict__ ents,
-                                             const uint32_t* __restrict__ pents, const LdpcLayerDesc L, uint32_t rowword, int layer, int j, bool active,
-                                             const uint32_t (&rec_in)[REC], uint32_t* __restrict__ rec_out_ptr,
+                                             const uint32_t* __restrict__ pents, const LdpcLayerDesc L, uint32_t rowword, int layer, int j, bool active, bool live,
+                                             const uint32_t (&rec_in)[REC], uint32_t (&rec_out)[REC],
                                              uint32_t* __restrict__ cw, uint8_t* __restrict__ cres) {
     constexpr int NL = MAXDEG + 2;
     constexpr int NP = (NL + 1) / 2;
@@ -222,7 +222,17 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
 #define LINK_MG(k) ((int)G[(k) >> 1][(k) & 1] >> 8)
 #define LINK_SET(k, v, m) do { V[(k) >> 1][(k) & 1] = (short)((v) << 8); G[(k) >> 1][(k) & 1] = (short)((m) << 8); } while (0)
     PROF_T(t_a);
-    if (active) {
+    // Conflict kinds: EVERY lane of a live slot runs the input phase (idle lanes read valid LDS and never store).  Its results live
+    // across the barriers of the middle section; defined under a divergent condition they cost ~36 register initialisations per layer
+    // and wave.  A slot that is not live (frame finished or absent) only keeps the barrier count of its partner.
+    if constexpr (CONF) {
+        if (!live) {
+            if constexpr (KIND == 1) { lds_barrier(); lds_barrier(); }
+            else { const int depth = (int)(L.depth_nc & 0xffffu); for (int lvl = 2; lvl <= depth; ++lvl) lds_barrier(); }
+            return;
+        }
+    }
+    if (CONF || active) {
         s16x2 MIN0 = splat2(Q8_NONE), MIN1 = splat2(Q8_NONE);
         uint32_t SX = 0;
         uint32_t XR[NP], XH[NP];
@@ -464,13 +474,11 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
             }
             NM[p] = nm;
         }
-        uint32_t rec_out[REC];
 #pragma unroll
         for (int w = 0; w < REC; ++w) {
             if (2 * w < NP) rec_out[w] = __builtin_amdgcn_perm(bits2(NM[2 * w + 1 <= NP ? 2 * w + 1 : NP]), bits2(NM[2 * w]), 0x07050301u);
             else rec_out[w] = 0;
         }
-        rec_store<REC>(rec_out, rec_out_ptr);
         lds_pairs_wait();
     }
 #undef LINK_IN
@@ -618,6 +626,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
             if (s_done[0] && s_done[LDPC_FPB - 1]) break;
             // ---- one layered sweep (LDPCDecoder::update), descriptors / records / row words prefetched one layer ahead
             const bool active = lane_ok && !done;
+            const bool live = __builtin_amdgcn_readfirstlane((int)(valid && !done)) != 0;   // uniform over the slot's waves
             const bool first = (it == 0);
             uint32_t rec_next[REC];
 #pragma unroll
@@ -642,11 +651,22 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
                 PROF_T(t_h);
                 PROF_ADD(7, t_g, t_h);
                 const uint32_t* __restrict__ pe = ents + A.pent_base + layer * (2 * ((MAXDEG + 1) / 2));
-                if ((L.depth_nc & 0xffffu) == 1) layer_update<MAXDEG, REC, 0, IRREG>(post, A, ents + L.ent_off, pe, L, 1u, layer, j, active, rec, rp, cw, cres);
-                else if ((L.deg >> 16) > 0) layer_update<MAXDEG, REC, 1, IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, rec, rp, cw, cres);
-                else if ((L.depth_nc >> 16) <= 4u) layer_update<MAXDEG, REC, 3, IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, rec, rp, cw, cres);
-                else if (MAXDEG > 12 && (L.depth_nc >> 16) <= 8u) layer_update<MAXDEG, REC, (MAXDEG > 12 ? 4 : 2), IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, rec, rp, cw, cres);
-                else layer_update<MAXDEG, REC, 2, IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, rec, rp, cw, cres);
+                uint32_t ro[REC];
+#pragma unroll
+                for (int w = 0; w < REC; ++w) ro[w] = 0;
+                if ((L.depth_nc & 0xffffu) == 1) layer_update<MAXDEG, REC, 0, IRREG>(post, A, ents + L.ent_off, pe, L, 1u, layer, j, active, live, rec, ro, cw, cres);
+                else if ((L.deg >> 16) > 0) layer_update<MAXDEG, REC, 1, IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, live, rec, ro, cw, cres);
+                else if ((L.depth_nc >> 16) <= 4u) layer_update<MAXDEG, REC, 3, IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, live, rec, ro, cw, cres);
+                else if (MAXDEG > 12 && (L.depth_nc >> 16) <= 8u) layer_update<MAXDEG, REC, (MAXDEG > 12 ? 4 : 2), IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, live, rec, ro, cw, cres);
+                else layer_update<MAXDEG, REC, 2, IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, live, rec, ro, cw, cres);
+                // The prefetched record / row word of the next layer are claimed HERE, in uniform control flow and before this layer's
+                // record store is issued: the compiler's wait for those loads then sits where nothing recent is in flight.  Left to
+                // itself it put an s_waitcnt vmcnt(0) behind the store (the loop-carried copy of the prefetch registers, merged over
+                // paths with and without a store), i.e. every wave sat out the store's acknowledge before every layer barrier.
+#pragma unroll
+                for (int w = 0; w < REC; ++w) asm volatile("" : "+v"(rec_next[w]));
+                asm volatile("" : "+v"(rw_next));
+                if (active) rec_store<REC>(ro, rp);
                 PROF_T(t_e);
                 lds_barrier();
                 PROF_T(t_f);
