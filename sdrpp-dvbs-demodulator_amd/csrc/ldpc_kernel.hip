@@ -159,6 +159,14 @@ __device__ __forceinline__ uint32_t lds_offset(const int8_t* p) { return (uint32
 __device__ __forceinline__ void lds_read_pair_i8(uint32_t a_lo, uint32_t a_hi, uint32_t& r_lo, uint32_t& r_hi) {
     asm volatile("ds_read_u8_d16 %0, %2\n\tds_read_u8_d16_hi %1, %3" : "=&v"(r_lo), "=&v"(r_hi) : "v"(a_lo), "v"(a_hi) : "memory");
 }
+#define LDS_READY_CASE(n) case n: asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(r_lo), "+v"(r_hi) : : "memory"); break
+__device__ __forceinline__ void lds_pair_ready(int outstanding, uint32_t& r_lo, uint32_t& r_hi) {   // (constant after unrolling)
+    switch (outstanding) {
+        LDS_READY_CASE(0); LDS_READY_CASE(2); LDS_READY_CASE(4); LDS_READY_CASE(6); LDS_READY_CASE(8); LDS_READY_CASE(10); LDS_READY_CASE(12); LDS_READY_CASE(14);
+        default: asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(r_lo), "+v"(r_hi) : : "memory"); break;
+    }
+}
+#undef LDS_READY_CASE
 __device__ __forceinline__ void lds_pairs_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // Byte stores straight out of the halves of a packed register (ds_write_b8 takes bits 7:0, ds_write_b8_d16_hi bits 23:16): no
 // VALU work to extract or narrow the value.  The compiler does not count these against lgkmcnt: lds_pairs_wait() before the
@@ -196,7 +204,7 @@ __device__ __forceinline__ int chain_step(int x, uint32_t lim, uint32_t se) {
 // [0, MAXDEG) are the table links, MAXDEG the row's own parity bit and MAXDEG+1 the previous parity bit.
 template <int MAXDEG, int REC, int KIND, bool IRREG>
 __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const LdpcKernelArgs& A, const uint32_t* __restrict__ ents,
-                                             const uint32_t* __restrict__ pents, const LdpcLayerDesc L, uint32_t rowword, int layer, int j, bool active, bool live,
+                                             const uint32_t (&pw)[2 * ((MAXDEG + 1) / 2)], const LdpcLayerDesc L, uint32_t rowword, int layer, int j, bool active, bool live,
                                              const uint32_t (&rec_in)[REC], uint32_t (&rec_out)[REC],
                                              uint32_t* __restrict__ cw, uint8_t* __restrict__ cres) {
     constexpr int NL = MAXDEG + 2;
@@ -237,11 +245,6 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
         uint32_t SX = 0;
         uint32_t XR[NP], XH[NP];
         const uint32_t JJ = (uint32_t)j * 0x10001u;
-        // the layer's pair table in one go (wide scalar loads up front instead of one load + wait per pair)
-        constexpr int NPW = 2 * ((MAXDEG + 1) / 2);
-        uint32_t pw[NPW];
-#pragma unroll
-        for (int i = 0; i < NPW; ++i) pw[i] = pents[i];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             bool absent[2] = {false, false};     // uniform (table) absence; the missing previous parity bit of row 0 is per lane
@@ -270,10 +273,11 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
             }
             lds_read_pair_i8(la[0], la[1], XR[p], XH[p]);
         }
-        lds_pairs_wait();
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            asm volatile("" : "+v"(XR[p]), "+v"(XH[p]));
+            // staged wait: LDS returns in order, so pair p is complete once at most 2*(NP-1-p) operations are outstanding (anything
+            // else counted in lgkmcnt only makes this stricter) -- the arithmetic of the first pairs overlaps the later reads
+            lds_pair_ready(2 * (NP - 1 - p), XR[p], XH[p]);
             // byte of the low load -> bits 15:8, byte of the high load (it sits in bits 23:16) -> bits 31:24
             const s16x2 X = from_bits2(__builtin_amdgcn_perm(XH[p], XR[p], 0x060c000cu));
             bool absent[2];
@@ -633,6 +637,15 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
             for (int w = 0; w < REC; ++w) rec_next[w] = 0;
             if (!first && active) rec_load<REC>(rec_next, msg + (size_t)j * REC);
             LdpcLayerDesc Lnext = layers[0];
+            // the layer's pair table (link addresses) travels one layer ahead in scalar registers, like the descriptor: its scalar-cache
+            // latency is then off the path between a layer barrier and the first LDS read
+            constexpr int NPW = 2 * ((MAXDEG + 1) / 2);
+            constexpr bool PW_AHEAD = MAXDEG <= 12;   // (wider tables do not fit the scalar registers twice: measured 14 % slower for degree 28)
+            uint32_t pw_next[NPW];
+            if constexpr (PW_AHEAD) {
+#pragma unroll
+                for (int i = 0; i < NPW; ++i) pw_next[i] = ents[A.pent_base + i];
+            }
             uint32_t rw_next = 1;
             if ((Lnext.depth_nc & 0xffffu) > 1 && active) rw_next = rows[Lnext.row_off + j];
             for (int layer = 0; layer < q; ++layer) {
@@ -641,24 +654,30 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
 #pragma unroll
                 for (int w = 0; w < REC; ++w) rec[w] = rec_next[w];
                 const LdpcLayerDesc L = Lnext;
+                uint32_t pw[NPW];
+#pragma unroll
+                for (int i = 0; i < NPW; ++i) pw[i] = PW_AHEAD ? pw_next[i] : ents[A.pent_base + layer * NPW + i];
                 const uint32_t rw = rw_next;
                 uint32_t* rp = msg + ((size_t)layer * 360 + j) * REC;
                 if (layer + 1 < q) {
                     Lnext = layers[layer + 1];
+                    if constexpr (PW_AHEAD) {
+#pragma unroll
+                        for (int i = 0; i < NPW; ++i) pw_next[i] = ents[A.pent_base + (layer + 1) * NPW + i];
+                    }
                     if (!first && active) rec_load<REC>(rec_next, rp + 360 * REC);
                     if ((Lnext.depth_nc & 0xffffu) > 1 && active) rw_next = rows[Lnext.row_off + j];
                 }
                 PROF_T(t_h);
                 PROF_ADD(7, t_g, t_h);
-                const uint32_t* __restrict__ pe = ents + A.pent_base + layer * (2 * ((MAXDEG + 1) / 2));
                 uint32_t ro[REC];
 #pragma unroll
                 for (int w = 0; w < REC; ++w) ro[w] = 0;
-                if ((L.depth_nc & 0xffffu) == 1) layer_update<MAXDEG, REC, 0, IRREG>(post, A, ents + L.ent_off, pe, L, 1u, layer, j, active, live, rec, ro, cw, cres);
-                else if ((L.deg >> 16) > 0) layer_update<MAXDEG, REC, 1, IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, live, rec, ro, cw, cres);
-                else if ((L.depth_nc >> 16) <= 4u) layer_update<MAXDEG, REC, 3, IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, live, rec, ro, cw, cres);
-                else if (MAXDEG > 12 && (L.depth_nc >> 16) <= 8u) layer_update<MAXDEG, REC, (MAXDEG > 12 ? 4 : 2), IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, live, rec, ro, cw, cres);
-                else layer_update<MAXDEG, REC, 2, IRREG>(post, A, ents + L.ent_off, pe, L, rw, layer, j, active, live, rec, ro, cw, cres);
+                if ((L.depth_nc & 0xffffu) == 1) layer_update<MAXDEG, REC, 0, IRREG>(post, A, ents + L.ent_off, pw, L, 1u, layer, j, active, live, rec, ro, cw, cres);
+                else if ((L.deg >> 16) > 0) layer_update<MAXDEG, REC, 1, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres);
+                else if ((L.depth_nc >> 16) <= 4u) layer_update<MAXDEG, REC, 3, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres);
+                else if (MAXDEG > 12 && (L.depth_nc >> 16) <= 8u) layer_update<MAXDEG, REC, (MAXDEG > 12 ? 4 : 2), IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres);
+                else layer_update<MAXDEG, REC, 2, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres);
                 // The prefetched record / row word of the next layer are claimed HERE, in uniform control flow and before this layer's
                 // record store is issued: the compiler's wait for those loads then sits where nothing recent is in flight.  Left to
                 // itself it put an s_waitcnt vmcnt(0) behind the store (the loop-carried copy of the prefetch registers, merged over
