@@ -46,10 +46,21 @@ struct LdpcKernelArgs {
     unsigned long long* prof;   // development aid (-DLDPC_PROF builds only): per-wave phase cycle sums of workgroup 0
 };
 
-#ifdef LDPC_PROF
+#if defined(LDPC_PROF) && LDPC_PROF == 2
+// one probe per layer (after its barrier, wave 0 of workgroup 0): prof[128 + layer] = cycles of that layer step, prof[127] = the rest of
+// an iteration (check, loop top); the fine-grained probes below cost ~250 cycles each and distort what they measure
+#define PROF_T(var) do { } while (0)
+#define PROF_ADD(slot, t0, t1) do { } while (0)
+#define PROF_LAYER(idx) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_now = clock64(); A.prof[128 + (idx)] += t_now - t_layer; t_layer = t_now; } } while (0)
+#define PROF_LAYER_DECL unsigned long long t_layer = clock64()
+#elif defined(LDPC_PROF)
 #define PROF_T(var) unsigned long long var = clock64()
 #define PROF_ADD(slot, t0, t1) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) A.prof[((threadIdx.x >> 6) % 6) * 16 + (slot)] += (t1) - (t0); } while (0)
+#define PROF_LAYER(idx) do { } while (0)
+#define PROF_LAYER_DECL do { } while (0)
 #else
+#define PROF_LAYER(idx) do { } while (0)
+#define PROF_LAYER_DECL do { } while (0)
 #define PROF_T(var) do { } while (0)
 #define PROF_ADD(slot, t0, t1) do { } while (0)
 #endif
@@ -156,7 +167,11 @@ __device__ __forceinline__ uint32_t lds_offset(const int8_t* p) { return (uint32
 // MI355X runs with SRAM ECC, where a d16 load ZEROES the other half instead of preserving it, so the two halves land in
 // two registers and one v_or joins them (still 1 VALU op per pair instead of 2 sign extensions + a byte permute).
 // Issue only; lds_pairs_wait() below orders the results.
+#ifndef LDPC_EXP
+#define LDPC_EXP 0   // development switches for TIMING experiments (results wrong): 1 no message records, 2 no posterior stores, 4 no posterior loads
+#endif
 __device__ __forceinline__ void lds_read_pair_i8(uint32_t a_lo, uint32_t a_hi, uint32_t& r_lo, uint32_t& r_hi) {
+    if (LDPC_EXP & 4) { r_lo = a_lo & 0xffu; r_hi = (a_hi & 0xffu) << 16; return; }
     asm volatile("ds_read_u8_d16 %0, %2\n\tds_read_u8_d16_hi %1, %3" : "=&v"(r_lo), "=&v"(r_hi) : "v"(a_lo), "v"(a_hi) : "memory");
 }
 #define LDS_READY_CASE(n) case n: asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(r_lo), "+v"(r_hi) : : "memory"); break
@@ -171,8 +186,8 @@ __device__ __forceinline__ void lds_pairs_wait() { asm volatile("s_waitcnt lgkmc
 // Byte stores straight out of the halves of a packed register (ds_write_b8 takes bits 7:0, ds_write_b8_d16_hi bits 23:16): no
 // VALU work to extract or narrow the value.  The compiler does not count these against lgkmcnt: lds_pairs_wait() before the
 // next barrier.
-__device__ __forceinline__ void lds_write_lo_i8(uint32_t addr, uint32_t packed) { asm volatile("ds_write_b8 %0, %1" ::"v"(addr), "v"(packed) : "memory"); }
-__device__ __forceinline__ void lds_write_hi_i8(uint32_t addr, uint32_t packed) { asm volatile("ds_write_b8_d16_hi %0, %1" ::"v"(addr), "v"(packed) : "memory"); }
+__device__ __forceinline__ void lds_write_lo_i8(uint32_t addr, uint32_t packed) { if (LDPC_EXP & 2) { asm volatile("" :: "v"(addr), "v"(packed)); return; } asm volatile("ds_write_b8 %0, %1" ::"v"(addr), "v"(packed) : "memory"); }
+__device__ __forceinline__ void lds_write_hi_i8(uint32_t addr, uint32_t packed) { if (LDPC_EXP & 2) { asm volatile("" :: "v"(addr), "v"(packed)); return; } asm volatile("ds_write_b8_d16_hi %0, %1" ::"v"(addr), "v"(packed) : "memory"); }
 
 // One row of the chain walk (KIND 1 layers).  Per row the reference computes, from the posterior x the previous row's E link
 // left:  vL = sat8(x - mL), mag = min(qE, max(|vL| - 1, 0)), nm = clamp(+-mag, -32, 31) with the sign of vL (flipped when the
@@ -195,7 +210,9 @@ __device__ __forceinline__ ChainRec chain_record(int m, int qE, int vE, int sneg
 __device__ __forceinline__ int chain_step(int x, uint32_t lim, uint32_t se) {
     const int q1 = min(max(x, (int)(int8_t)lim), (int)(int8_t)(lim >> 8));
     const int q2 = min(max(x, (int)(int8_t)(lim >> 16)), (int)lim >> 24);
-    return clamp8(((int)se >> 16) + (int)(short)se * (q1 + q2));
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"((int)(short)se), "v"(q1 + q2), "v"((int)se >> 16));   // (left alone the compiler picks a quarter-rate 64-bit multiply-add here)
+    return clamp8(r);
 }
 
 // One sweep step for one layer.  CONF = layer has intra-layer shared bits (links 0..nc-1), IRREG = the
@@ -206,7 +223,7 @@ template <int MAXDEG, int REC, int KIND, bool IRREG>
 __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const LdpcKernelArgs& A, const uint32_t* __restrict__ ents,
                                              const uint32_t (&pw)[2 * ((MAXDEG + 1) / 2)], const LdpcLayerDesc L, uint32_t rowword, int layer, int j, bool active, bool live,
                                              const uint32_t (&rec_in)[REC], uint32_t (&rec_out)[REC],
-                                             uint32_t* __restrict__ cw, uint8_t* __restrict__ cres) {
+                                             uint32_t* __restrict__ cw, uint8_t* __restrict__ cres, const uint32_t* __restrict__ walk = nullptr) {
     constexpr int NL = MAXDEG + 2;
     constexpr int NP = (NL + 1) / 2;
     // KIND 0: no shared bits in the layer; 1: one shared pair resolved by the chain walk (links 0, 1 only); 2: general levels;
@@ -215,7 +232,9 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
     constexpr int MAXC_ALL = MAXDEG < LDPC_MAX_CONFLICT_LINKS ? MAXDEG : LDPC_MAX_CONFLICT_LINKS;
     // KIND 3 / 4 = KIND 2 for layers with at most 4 / 8 shared links: the per-level code only tests those (every tested link costs scalar
     // branches per level whether or not a row uses it)
-    constexpr int MAXC = KIND == 1 ? (MAXDEG < 2 ? MAXDEG : 2) : KIND == 3 ? (MAXDEG < 4 ? MAXDEG : 4) : KIND == 4 ? (MAXDEG < 8 ? MAXDEG : 8) : MAXC_ALL;
+    // KIND 6 = "quad walk" layers (at most 4 shared links, deep and narrow level structure): one wave walks the rows of levels >= 2 in
+    // level order, four lanes per row, see below
+    constexpr int MAXC = KIND == 1 ? (MAXDEG < 2 ? MAXDEG : 2) : (KIND == 3 || KIND == 6) ? (MAXDEG < 4 ? MAXDEG : 4) : KIND == 4 ? (MAXDEG < 8 ? MAXDEG : 8) : MAXC_ALL;
     s16x2 V[NP], G[NP];        // extrinsic inputs and their offset magnitudes
     uint32_t addr[MAXDEG];     // LDS byte addresses of the table links' posteriors
     const uint32_t lbase = lds_offset(post);
@@ -235,7 +254,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
     // and wave.  A slot that is not live (frame finished or absent) only keeps the barrier count of its partner.
     if constexpr (CONF) {
         if (!live) {
-            if constexpr (KIND == 1) { lds_barrier(); lds_barrier(); }
+            if constexpr (KIND == 1 || KIND == 6) { lds_barrier(); lds_barrier(); }
             else { const int depth = (int)(L.depth_nc & 0xffffu); for (int lvl = 2; lvl <= depth; ++lvl) lds_barrier(); }
             return;
         }
@@ -357,8 +376,10 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                 int x = post[link_addr(eL, j + chain_d)];                 // written by the level-1 row j (its E link)
                 const uint2* c = reinterpret_cast<const uint2*>(cw) + j + chain_d;
                 uint8_t* pr = reinterpret_cast<uint8_t*>(cres) + j + chain_d;
-                // records are fetched two rows ahead (those beyond row 359 are read but never used: the addresses stay inside
-                // the workgroup's LDS allocation)
+                // records are fetched two rows ahead (those beyond row 359 are read but never used: LDS reads past the allocation
+                // return zeros).  A four-row distance with hand-issued LDS traffic was tried: the long chain (d = 2) gained 7 %, every
+                // short one lost 5 % to the longer prologue.  The row costs ~85 cycles because ONE wave pays ~18 cycles of issue per
+                // LDS instruction and 5.4 per SDWA / VOP3 one (tools/ubench/valu.hip), not because it waits for its record.
                 uint2 ra = c[0], rb = c[chain_d];
                 c += 2 * chain_d;
                 int k = 1;
@@ -400,6 +421,118 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                     int m = mag_of(v);
                     LINK_SET(0, v, m);
                     ROW_ACCUM(v, m);
+                }
+            }
+        } else if constexpr (KIND == 6) {
+            (void)chain_d;
+            // ---- quad walk (ldpc_plan.h).  Rows of level 1 publish their early links; every other row leaves a hand-off record in
+            // cw[]: {min0, min1, sign of the totals over its links known so far, late mask, early mask} and one byte per shared link (its
+            // old message if the link is late, else its input value).  Wave 0 of the slot then walks the plan's step list: 16 rows per
+            // step, lane = (row, shared link).  A lane fetches its link's posterior, forms the link value (late links) and its magnitude;
+            // the four lanes of a row join the late links into the row totals with quad permutes; lanes of early links write the new
+            // posterior.  Steps of one level are independent, steps of consecutive levels are ordered by the in-order LDS pipeline of
+            // the one wave -- no workgroup barrier per level.  Late link values go back into the record for the output phase.
+            // (what the walker needs from global memory is fetched before the hand-off, so that its latency overlaps the barrier)
+            const uint32_t wk_ent = ents[(j & 3) < nc ? (j & 3) : 0];
+            const int wk_steps = (int)walk[0];
+            if (active) {
+                if (level == 1u) {
+#pragma unroll
+                    for (int k = 0; k < MAXC; ++k) {
+                        if (k < nc && ((early >> k) & 1)) {
+                            int nm = new_msg(LINK_IN(k), LINK_MG(k), min0, min1, sx);
+                            LDS_I8(addr[k]) = (int8_t)clamp8(LINK_IN(k) + nm);
+                        }
+                    }
+                } else {
+                    uint32_t lb = 0;
+#pragma unroll
+                    for (int k = 0; k < MAXC; ++k) {
+                        const int b = (k < nc && ((late >> k) & 1)) ? rec_byte<REC>(rec_in, k) : LINK_IN(k);
+                        lb |= ((uint32_t)b & 0xffu) << (8 * k);
+                    }
+                    const uint32_t hd = (uint32_t)min0 | ((uint32_t)min1 << 8) | (((uint32_t)sx >> 31) << 16) | ((late & 0xfu) << 20) | ((early & 0xfu) << 24);
+                    reinterpret_cast<uint2*>(cw)[j] = make_uint2(hd, lb);
+                }
+            }
+            lds_barrier();
+            if (j < 64 && live) {
+                __builtin_amdgcn_s_setprio(3);
+                const int k = j & 3, q = j >> 2;
+                const uint32_t ek = wk_ent;
+                const int spk = (int)(ek & 0xffffu);
+                const uint32_t basek = lbase + 360u * (ek >> 16);
+                const uint32_t scratch = lds_offset(reinterpret_cast<const int8_t*>(cres)) + (uint32_t)j;
+                const uint32_t cwb = lds_offset(reinterpret_cast<const int8_t*>(cw));
+                const int nsteps = wk_steps;
+                const uint32_t* __restrict__ list = walk + 1 + q;
+                // Two steps per trip, each with its own list register fetched two steps ahead (the list is followed by three empty steps, so
+                // the fetches need no bound test): the wait for the entry in use leaves the one younger fetch in flight.
+                auto step = [&](const uint32_t e) {
+                    const bool valid = e != 0xffffffffu && k < nc;
+                    const int row = valid ? (int)e : 0;
+                    const uint2 r = reinterpret_cast<const uint2*>(cw)[row];
+                    int t = row + spk;
+                    t = (int)min((uint32_t)t, (uint32_t)(t - 360));
+                    const uint32_t a = basek + (uint32_t)t;
+                    const int x = (int)LDS_I8(a);
+                    const int b = (int)__builtin_amdgcn_sbfe((int)r.y, 8 * k, 8);
+                    const bool lt = valid && ((r.x >> (20 + k)) & 1u), er = valid && ((r.x >> (24 + k)) & 1u);
+                    const int v = lt ? clamp8(x - b) : b;
+                    const int g = mag_of(v);
+                    // the row's late links joined across its four lanes: two smallest magnitudes and the sign
+                    int m0 = lt ? g : 255, m1 = 255, sg = lt ? v : 0;
+#define QUAD(x_, ctrl) __builtin_amdgcn_update_dpp(0, (x_), (ctrl), 0xf, 0xf, true)
+                    {
+                        const int o0 = QUAD(m0, 0xB1), o1 = QUAD(m1, 0xB1);                  // quad_perm [1,0,3,2]
+                        m1 = min(max(m0, o0), min(m1, o1)); m0 = min(m0, o0);
+                        sg ^= QUAD(sg, 0xB1);
+                    }
+                    {
+                        const int o0 = QUAD(m0, 0x4E), o1 = QUAD(m1, 0x4E);                  // quad_perm [2,3,0,1]
+                        m1 = min(max(m0, o0), min(m1, o1)); m0 = min(m0, o0);
+                        sg ^= QUAD(sg, 0x4E);
+                    }
+#undef QUAD
+                    const int q0 = (int)(r.x & 0xffu), q1 = (int)((r.x >> 8) & 0xffu);
+                    const int t1 = min(max(m0, q0), min(m1, q1)), t0 = min(m0, q0);
+                    const int ss = sg ^ (int)(r.x << 15);                                    // bit 31 = sign of the row's totals
+                    const int nm = new_msg(v, g, t0, t1, ss);
+                    LDS_I8(er ? a : scratch) = (int8_t)clamp8(v + nm);
+                    LDS_I8(valid ? cwb + 8u * (uint32_t)row + 4u + (uint32_t)k : scratch) = (int8_t)v;
+                };
+                // (issued by hand: the compiler sinks such a fetch to its use, or copies registers behind it, and then waits for it)
+#define LIST_FETCH(r, p) asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory")
+#define LIST_READY(r) asm volatile("s_waitcnt vmcnt(1)" : "+v"(r) : : "memory")
+                uint32_t eA, eB;
+                const uint32_t* lp = list;
+                LIST_FETCH(eA, lp); LIST_FETCH(eB, lp + 16);
+                lp += 32;
+                for (int i = 0; i < nsteps; i += 2) {
+                    LIST_READY(eA);
+                    step(eA);
+                    LIST_FETCH(eA, lp);
+                    LIST_READY(eB);
+                    if (i + 1 < nsteps) step(eB);
+                    LIST_FETCH(eB, lp + 16);
+                    lp += 32;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef LIST_FETCH
+#undef LIST_READY
+                __builtin_amdgcn_s_setprio(0);
+            }
+            lds_barrier();
+            if (active && level != 1u) {
+                const uint32_t lb = reinterpret_cast<const uint2*>(cw)[j].y;
+#pragma unroll
+                for (int k = 0; k < MAXC; ++k) {
+                    if (k < nc && ((late >> k) & 1)) {
+                        int v = (int)__builtin_amdgcn_sbfe((int)lb, 8 * k, 8);
+                        int m = mag_of(v);
+                        LINK_SET(k, v, m);
+                        ROW_ACCUM(v, m);
+                    }
                 }
             }
         } else {
@@ -605,6 +738,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
         lds_barrier();
 
         int it = 0, ret = 0, trip = 0;
+        PROF_LAYER_DECL;
         bool done = !valid;
         while (true) {
             const bool check = !done && (!A.force || it == A.max_trials);
@@ -628,6 +762,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
             if (j == 0) s_done[fs] = done;
             lds_barrier();
             if (s_done[0] && s_done[LDPC_FPB - 1]) break;
+            PROF_LAYER(-1);
             // ---- one layered sweep (LDPCDecoder::update), descriptors / records / row words prefetched one layer ahead
             const bool active = lane_ok && !done;
             const bool live = __builtin_amdgcn_readfirstlane((int)(valid && !done)) != 0;   // uniform over the slot's waves
@@ -635,7 +770,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
             uint32_t rec_next[REC];
 #pragma unroll
             for (int w = 0; w < REC; ++w) rec_next[w] = 0;
-            if (!first && active) rec_load<REC>(rec_next, msg + (size_t)j * REC);
+            if (!first && active && !(LDPC_EXP & 1)) rec_load<REC>(rec_next, msg + (size_t)j * REC);
             LdpcLayerDesc Lnext = layers[0];
             // the layer's pair table (link addresses) travels one layer ahead in scalar registers, like the descriptor: its scalar-cache
             // latency is then off the path between a layer barrier and the first LDS read
@@ -665,7 +800,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
 #pragma unroll
                         for (int i = 0; i < NPW; ++i) pw_next[i] = ents[A.pent_base + (layer + 1) * NPW + i];
                     }
-                    if (!first && active) rec_load<REC>(rec_next, rp + 360 * REC);
+                    if (!first && active && !(LDPC_EXP & 1)) rec_load<REC>(rec_next, rp + 360 * REC);
                     if ((Lnext.depth_nc & 0xffffu) > 1 && active) rw_next = rows[Lnext.row_off + j];
                 }
                 PROF_T(t_h);
@@ -674,6 +809,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
 #pragma unroll
                 for (int w = 0; w < REC; ++w) ro[w] = 0;
                 if ((L.depth_nc & 0xffffu) == 1) layer_update<MAXDEG, REC, 0, IRREG>(post, A, ents + L.ent_off, pw, L, 1u, layer, j, active, live, rec, ro, cw, cres);
+                else if ((L.deg >> 16) == LDPC_WALK_MARK) layer_update<MAXDEG, REC, 6, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres, rows + L.row_off + 360);
                 else if ((L.deg >> 16) > 0) layer_update<MAXDEG, REC, 1, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres);
                 else if ((L.depth_nc >> 16) <= 4u) layer_update<MAXDEG, REC, 3, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres);
                 else if (MAXDEG > 12 && (L.depth_nc >> 16) <= 8u) layer_update<MAXDEG, REC, (MAXDEG > 12 ? 4 : 2), IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres);
@@ -685,11 +821,13 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
 #pragma unroll
                 for (int w = 0; w < REC; ++w) asm volatile("" : "+v"(rec_next[w]));
                 asm volatile("" : "+v"(rw_next));
-                if (active) rec_store<REC>(ro, rp);
+                if (active && !(LDPC_EXP & 1)) rec_store<REC>(ro, rp);
+                if (LDPC_EXP & 1) asm volatile("" :: "v"(ro[0]), "v"(ro[REC - 1]));
                 PROF_T(t_e);
                 lds_barrier();
                 PROF_T(t_f);
                 PROF_ADD(3, t_e, t_f);
+                PROF_LAYER(layer);
             }
             if (!done) ++it;
             ++trip;

@@ -23,7 +23,7 @@ namespace s2 {
 
 struct LdpcLayerDesc {   // 16 bytes = one s_load_dwordx4 (all fields 32-bit: sub-dword fields would force vector loads)
     uint32_t ent_off;    // index of the layer's first link entry
-    uint32_t deg;        // bits 0..15: information-bit links per row in this layer; bits 16..31: chain step d (0 = none):
+    uint32_t deg;        // bits 0..15: information-bit links per row in this layer; bits 16..31: chain step d (0 = none, LDPC_WALK_MARK = quad-walk layer):
                          // d != 0 marks a layer whose only shared links are one pair (links 0 = "E", 1 = "L") with row j's
                          // E-bit == row (j+d)'s L-bit: its dependency chains j, j+d, j+2d.. are walked by d lanes with the
                          // shared posterior forwarded in a register (ldpc_kernel.hip, chain walk)
@@ -39,6 +39,14 @@ constexpr int LDPC_MAX_CONFLICT_LINKS = 12;
 #ifndef LDPC_CHAIN_MAX_D
 #define LDPC_CHAIN_MAX_D 180  // chain walk for every single shared pair (step d = 1..180, d lanes); 0 disables it
 #endif
+
+#ifndef LDPC_WALK_MIN_DEPTH
+#define LDPC_WALK_MIN_DEPTH 6     // quad-walk layers: at least this many levels ...
+#endif
+#ifndef LDPC_WALK_MAX_ROWS
+#define LDPC_WALK_MAX_ROWS 32     // ... of at most this many rows each (levels >= 2)
+#endif
+constexpr uint32_t LDPC_WALK_MARK = 0xfffeu;   // chain-step field of a quad-walk layer
 
 struct LdpcPlan {
     int code_index = -1;
@@ -125,6 +133,26 @@ inline LdpcPlan build_ldpc_plan(int code_index) {
             L.row_off = (uint32_t)P.rows.size();
             for (int j = 0; j < 360; ++j) P.rows.push_back(level[j] | (late[j] << 8) | (early[j] << 20));
             P.conflict_layers++;
+        }
+        // "quad walk" layers: at most 4 shared links and a deep, narrow level structure (few rows per level, e.g. B7 layer 42: 33 levels of
+        // 11 rows).  A workgroup barrier per level costs ~900 cycles with one or two waves working; instead ONE wave walks the rows of
+        // levels >= 2 in level order, four lanes per row (lane = shared link), 16 rows per step, ordered by the in-order LDS pipeline
+        // (ldpc_kernel.hip, KIND 6).  The step list follows the layer's 360 row words: [number of steps][steps x 16 row indices, ~0 = none].
+        if (l_nc > 0 && l_nc <= 4 && chain_d == 0 && (int)l_depth >= LDPC_WALK_MIN_DEPTH) {
+            std::vector<std::vector<uint32_t>> by_level(l_depth + 1);
+            for (int j = 0; j < 360; ++j) by_level[P.rows[L.row_off + j] & 0xffu].push_back((uint32_t)j);
+            size_t widest = 0;
+            for (uint32_t lv = 2; lv <= l_depth; ++lv) widest = std::max(widest, by_level[lv].size());
+            if ((int)widest <= LDPC_WALK_MAX_ROWS) {
+                std::vector<uint32_t> list;
+                for (uint32_t lv = 2; lv <= l_depth; ++lv)
+                    for (size_t o = 0; o < by_level[lv].size(); o += 16)
+                        for (size_t i = 0; i < 16; ++i) list.push_back(o + i < by_level[lv].size() ? by_level[lv][o + i] : 0xffffffffu);
+                P.rows.push_back((uint32_t)(list.size() / 16));
+                list.insert(list.end(), 48, 0xffffffffu);        // three empty steps: the walker fetches ahead without a bound test
+                P.rows.insert(P.rows.end(), list.begin(), list.end());
+                chain_d = LDPC_WALK_MARK;
+            }
         }
         L.deg |= chain_d << 16;
         L.depth_nc = l_depth | (l_nc << 16);
