@@ -223,6 +223,7 @@ int dvbs2gpu_create(int device, dvbs2gpu_ctx** out) {
     dvbs2gpu_ctx* c = new dvbs2gpu_ctx();
     c->device = device;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* v = getenv("DVBS2GPU_FE_SLICES")) { int k = atoi(v); if (k >= 1 && k <= s2::S2_FE_MAX_SLICES) c->fe_slices = k; }   // (A/B switch)
     hipError_t ee = hipEventCreateWithFlags(&c->ev_ws, hipEventDisableTiming);
     if (ee != hipSuccess) { delete c; return fail_hip(ee, "hipEventCreate"); }
     *out = c;
@@ -261,6 +262,10 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
     for (auto& sp : ctx->timers.pending) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : ctx->timers.pool) (void)hipEventDestroy(e);
     ctx->ws_msg.release(); ctx->ws_hard.release(); ctx->ws_syn.release(); ctx->ws_misc.release();
+    for (auto& kv : ctx->fe_aux) {
+        if (kv.second.aux) (void)hipStreamDestroy(kv.second.aux);
+        for (hipEvent_t e : kv.second.ev) if (e) (void)hipEventDestroy(e);
+    }
     if (ctx->fe_stream) (void)hipStreamDestroy(ctx->fe_stream);
     if (ctx->fec_stream) (void)hipStreamDestroy(ctx->fec_stream);
     if (ctx->ev_llr) (void)hipEventDestroy(ctx->ev_llr);

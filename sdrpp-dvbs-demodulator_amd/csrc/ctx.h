@@ -138,6 +138,10 @@ struct dvbs2gpu_ctx {
     hipStream_t grp_stream[MAX_PIPE_GROUPS] = {};
     hipEvent_t ev_llr_grp[MAX_PIPE_GROUPS] = {};
     std::mutex fec_mtx;                                   // FEC jobs are enqueued whole, one at a time (shared FEC workspaces, one stream)
+    // time-sliced front end (s2_rx_kernels.hip, s2_frontend_launch): per main stream one auxiliary stream + the slice events
+    struct FeAux { hipStream_t aux = nullptr; hipEvent_t ev[9] = {}; };
+    std::map<hipStream_t, FeAux> fe_aux;
+    int fe_slices = 4;                        // DVBS2GPU_FE_SLICES (1 = both stages back to back on the caller's stream)
     // DVB-S front end (dvbs_demod.hip)
     float* d_fd_bank = nullptr;               // COMPLEX_FD interpolator bank, 256 x 256
     std::map<int, s2::cf32*> bandedge;        // FLL band-edge taps [2][ntaps] by ntaps*100000 + round(alpha*1000)*10 + sps

@@ -44,7 +44,7 @@ constexpr int LDPC_MAX_CONFLICT_LINKS = 12;
 #define LDPC_WALK_MIN_DEPTH 6     // quad-walk layers: at least this many levels ...
 #endif
 #ifndef LDPC_WALK_MAX_ROWS
-#define LDPC_WALK_MAX_ROWS 32     // ... of at most this many rows each (levels >= 2)
+#define LDPC_WALK_MAX_ROWS 16     // ... of at most this many rows each (levels >= 2)
 #endif
 constexpr uint32_t LDPC_WALK_MARK = 0xfffeu;   // chain-step field of a quad-walk layer
 

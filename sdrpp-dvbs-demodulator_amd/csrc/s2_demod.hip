@@ -333,6 +333,24 @@ struct PendingFec {
 };
 
 // development aid: DVBS2GPU_HOST_TIMING=1 prints where the HOST spends a call (ms since entry at each mark)
+// AGC/NCO + timing recovery of a batch, time-sliced over the caller's stream and its auxiliary stream (ctx.h FeAux, created on first use)
+static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work, int n, const S2LoopCoefs& co, hipStream_t st) {
+    int nsub = ctx->fe_slices;
+    if (nsub > S2_FE_MAX_SLICES) nsub = S2_FE_MAX_SLICES;
+    dvbs2gpu_ctx::FeAux* fa = nullptr;
+    if (nsub > 1) {
+        std::lock_guard<std::mutex> l(ctx->mtx);
+        fa = &ctx->fe_aux[st];
+        if (!fa->aux) {
+            hipError_t e = hipStreamCreateWithFlags(&fa->aux, hipStreamNonBlocking);
+            if (e != hipSuccess) return e;
+            for (int i = 0; i <= S2_FE_MAX_SLICES; ++i)
+                if ((e = hipEventCreateWithFlags(&fa->ev[i], hipEventDisableTiming)) != hipSuccess) return e;
+        }
+    }
+    return s2_frontend_launch(d_work, n, co, ctx->d_gardner_bank, st, fa ? fa->aux : nullptr, fa ? fa->ev : nullptr, nsub);
+}
+
 struct HostMarks {
     bool on; std::chrono::steady_clock::time_point t0; std::string line;
     HostMarks() : on(getenv("DVBS2GPU_HOST_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
@@ -381,7 +399,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     HIP_TRY(hipMemcpyAsync(d_work, work.data(), sizeof(S2StreamWork) * n, hipMemcpyHostToDevice, st));
     if (!pre_nsym) {
         // (with pre_nsym the MODCOD-independent stages already ran for the whole batch: frontend_prepass)
-        { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(s2_frontend_launch(d_work, n, d0->co, ctx->d_gardner_bank, st)); }
+        { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st)); }
         { StageSpan sp(ctx->timers, ST_RRC, st); HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st)); }
     }
     // ---- 3: PL sync.  The 2-state realign machine of S2PLSyncBlock runs on the device, one workgroup per stream walking its windows
@@ -666,7 +684,7 @@ int process_vcm_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const
     if ((rc = W[1].ensure(sizeof(S2VcmFound) * (size_t)n * maxf))) return rc;
     S2VcmFound* d_found = (S2VcmFound*)W[1].p;
     HIP_TRY(hipMemcpyAsync(d_work, work.data(), sizeof(S2StreamWork) * n, hipMemcpyHostToDevice, st));
-    { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(s2_frontend_launch(d_work, n, d0->co, ctx->d_gardner_bank, st)); }
+    { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st)); }
     { StageSpan sp(ctx->timers, ST_RRC, st); HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st)); }
     { StageSpan sp(ctx->timers, ST_PLSYNC, st); HIP_TRY(s2_vcm_walk_launch(d_work, n, ctx->pl, ctx->d_vcm_mods, d0->cfg.sof_threshold, maxf, d_found, d_counts, st)); }
     std::vector<S2VcmFound> found((size_t)n * maxf);
@@ -826,7 +844,7 @@ int frontend_prepass(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const 
     int* d_nsym = (int*)((char*)ws.p + sizeof(S2StreamWork) * n);
     float* d_nco = (float*)(d_nsym + n);
     HIP_TRY(hipMemcpyAsync(d_work, work.data(), sizeof(S2StreamWork) * n, hipMemcpyHostToDevice, st));
-    { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(s2_frontend_launch(d_work, n, d0->co, ctx->d_gardner_bank, st)); }
+    { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st)); }
     { StageSpan sp(ctx->timers, ST_RRC, st); HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st)); }
     nsym_out->assign(n, 0);
     HIP_TRY(s2_collect_launch(d_work, n, d_nsym, d_nco, st));

@@ -115,6 +115,9 @@ __device__ __forceinline__ cf32 phasor_hw(float x) { return phasor(x); }
 #ifndef G_PRIO
 #define G_PRIO 0
 #endif
+#ifndef G_PRIO_DUTY
+#define G_PRIO_DUTY 0
+#endif
 #ifndef FL_PRIO
 #define FL_PRIO 2
 #endif
@@ -172,8 +175,15 @@ struct AgcDvbsTraits {                   // FastAGC only; result = scaled sample
     }
 };
 
+// Sample sub-range `sub` of `nsub` of a call's n samples (the time-sliced front end: the AGC / NCO recurrences of slice c+1 run beside the
+// timing loop of slice c; every stage keeps its state in the stream record, so slicing a call changes nothing in the results)
+__device__ __forceinline__ void fe_sub_range(int n, int sub, int nsub, int& lo, int& hi) {
+    lo = (int)((long long)n * sub / nsub);
+    hi = (int)((long long)n * (sub + 1) / nsub);
+}
+
 template <class TR>
-__global__ __launch_bounds__(128) void agc_pc_kernel(const typename TR::Work* __restrict__ work, int nstreams, typename TR::Coefs co) {
+__global__ __launch_bounds__(128) void agc_pc_kernel(const typename TR::Work* __restrict__ work, int nstreams, typename TR::Coefs co, int sub, int nsub) {
     __shared__ cf32 buf[2][64][AG_T + 1];
     __shared__ const cf32* s_in[64];
     __shared__ cf32* s_out[64];
@@ -181,9 +191,11 @@ __global__ __launch_bounds__(128) void agc_pc_kernel(const typename TR::Work* __
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, s = blockIdx.x * 64 + lane;
     const bool act = s < nstreams;
     const typename TR::Work w = work[act ? s : 0];
-    const int n = act ? w.count : 0;
+    int lo, hi;
+    fe_sub_range(act ? w.count : 0, sub, nsub, lo, hi);
+    const int n = hi - lo;
     typename TR::Regs regs = TR::load(w);
-    if (wave == 0) { s_in[lane] = TR::in_ptr(w); s_out[lane] = TR::out_ptr(w); s_n[lane] = n; }
+    if (wave == 0) { s_in[lane] = TR::in_ptr(w) + lo; s_out[lane] = TR::out_ptr(w) + lo; s_n[lane] = n; }
     int nmax = n;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
@@ -242,21 +254,24 @@ __device__ __forceinline__ T* readlane_ptr(T* p, int srclane) {
 }
 
 __global__ __launch_bounds__(64) void s2_gardner_kernel(const S2StreamWork* __restrict__ work, int nstreams, S2LoopCoefs co,
-                                                        const float* __restrict__ bank_g) {
+                                                        const float* __restrict__ bank_g, int sub, int nsub) {
     __shared__ __attribute__((aligned(16))) float bank[GARDNER_PHASES * GARDNER_TAPS];
     __shared__ float win[G_SPW * 2 * G_PITCH];          // [stream][re/im][7 history + tile]
     const int lane = threadIdx.x, g = lane >> 3, r = lane & 7, arm = r >> 1, c = r & 1;   // arm 0/1/2 = phase-1 / phase / phase+1, 3 = spare
     const int s0 = blockIdx.x * G_SPW, s = s0 + g;
     const bool act = s < nstreams;
     for (int i = lane; i < GARDNER_PHASES * GARDNER_TAPS; i += 64) bank[i] = bank_g[i];
-    const S2StreamWork w = work[act ? s : 0];
-    const int n = act ? w.count : 0;
+    S2StreamWork w = work[act ? s : 0];
+    int lo, hi;
+    fe_sub_range(act ? w.count : 0, sub, nsub, lo, hi);
+    const int n = hi - lo;
     S2StreamState* st = w.st;
     PclDev pcl{co.g_alpha, co.g_beta, st->g_phase, st->g_freq, co.g_min_freq, co.g_max_freq};
-    int offset = st->g_offset, spsctr = st->g_spsctr, outCount = 0;
+    int offset = st->g_offset, spsctr = st->g_spsctr, outCount = sub ? st->n_fe_out : 0;   // (later slices append to the call's output)
     float* row = &win[(g * 2 + c) * G_PITCH];           // aliases the staging writes below: no __restrict__
     auto outc = as_global(reinterpret_cast<float*>(w.fe_out) + c);
-    const cf32* gpp = w.fe_out + fe_scratch_offset(n);
+    const cf32* gpp = w.fe_out + fe_scratch_offset(w.count) + lo;
+    w.in += lo;
     if (arm == 0)
         for (int k = 0; k < GARDNER_TAPS - 1; ++k) row[k] = c ? st->g_hist[k].im : st->g_hist[k].re;
     int nmax = n;
@@ -288,6 +303,11 @@ __global__ __launch_bounds__(64) void s2_gardner_kernel(const S2StreamWork* __re
     __syncthreads();
     __builtin_amdgcn_s_setprio(G_PRIO);       // latency-critical serial loop (see agc_pc_kernel)
     for (int base = 0; base < nmax; base += G_TILE) {
+#if G_PRIO_DUTY > 0
+        // G_PRIO_DUTY of every 8 tiles run one priority level up: the balance point between "this kernel yields to the decoder" (the front
+        // end becomes the critical path) and "it does not" (the decoder does) lies between two priority levels
+        if ((((unsigned)base / G_TILE) & 7u) < (unsigned)G_PRIO_DUTY) __builtin_amdgcn_s_setprio(G_PRIO + 1); else __builtin_amdgcn_s_setprio(G_PRIO);
+#endif
         commit(base);
         __syncthreads();
         issue(base + G_TILE);
@@ -1487,7 +1507,7 @@ hipError_t s2_fifo_compact_launch(const S2StreamWork* d_work, int nstreams, cons
 }
 hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int max_count, DvbsLoopCoefs coefs, const cf32* d_bandedge,
                                 const float* d_rrc, const float* d_fd_bank, hipStream_t st) {
-    hipLaunchKernelGGL(agc_pc_kernel<AgcDvbsTraits>, dim3((nstreams + 63) / 64), dim3(128), 0, st, d_work, nstreams, coefs);
+    hipLaunchKernelGGL(agc_pc_kernel<AgcDvbsTraits>, dim3((nstreams + 63) / 64), dim3(128), 0, st, d_work, nstreams, coefs, 0, 1);
     hipLaunchKernelGGL(dvbs_fll_kernel, dim3(nstreams), dim3(64), 0, st, d_work, coefs, d_bandedge);
     int gx = (max_count + 255) / 256;
     gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
@@ -1505,9 +1525,27 @@ hipError_t dvbs_soft_compact_launch(const DvbsStreamWork* d_work, int nstreams, 
     hipLaunchKernelGGL(dvbs_soft_compact_kernel, dim3(nstreams), dim3(256), 0, st, d_work);
     return hipGetLastError();
 }
-hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCoefs coefs, const float* d_bank, hipStream_t st) {
-    hipLaunchKernelGGL(agc_pc_kernel<AgcS2Traits>, dim3((nstreams + 63) / 64), dim3(128), 0, st, d_work, nstreams, coefs);
-    hipLaunchKernelGGL(s2_gardner_kernel, dim3((nstreams + G_SPW - 1) / G_SPW), dim3(64), 0, st, d_work, nstreams, coefs, d_bank);
+// The two serial front-end stages, time-sliced: the call's samples go through in `nsub` slices; the AGC / NCO recurrences (64 streams
+// per wave, few waves) run on `aux` one slice ahead of the timing loop (8 streams per wave) on `st`, which waits for each slice's event.
+// Both are latency chains that leave most of the GPU idle, so side by side they cost the longer of the two instead of the sum.
+// ev: nsub + 1 events (the last one orders `aux` behind what `st` holds when the call starts).  nsub <= 1 or no aux stream: one slice on st.
+hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCoefs coefs, const float* d_bank, hipStream_t st, hipStream_t aux,
+                              hipEvent_t* ev, int nsub) {
+    const dim3 ga((nstreams + 63) / 64), gg((nstreams + G_SPW - 1) / G_SPW);
+    if (nsub <= 1 || !aux || !ev) {
+        hipLaunchKernelGGL(agc_pc_kernel<AgcS2Traits>, ga, dim3(128), 0, st, d_work, nstreams, coefs, 0, 1);
+        hipLaunchKernelGGL(s2_gardner_kernel, gg, dim3(64), 0, st, d_work, nstreams, coefs, d_bank, 0, 1);
+        return hipGetLastError();
+    }
+    hipError_t e;
+    if ((e = hipEventRecord(ev[nsub], st)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(aux, ev[nsub], 0)) != hipSuccess) return e;
+    for (int c = 0; c < nsub; ++c) {
+        hipLaunchKernelGGL(agc_pc_kernel<AgcS2Traits>, ga, dim3(128), 0, aux, d_work, nstreams, coefs, c, nsub);
+        if ((e = hipEventRecord(ev[c], aux)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(st, ev[c], 0)) != hipSuccess) return e;
+        hipLaunchKernelGGL(s2_gardner_kernel, gg, dim3(64), 0, st, d_work, nstreams, coefs, d_bank, c, nsub);
+    }
     return hipGetLastError();
 }
 hipError_t s2_rrc_decim_launch(const S2StreamWork* d_work, int nstreams, int max_count, const float* d_taps, int ntaps, hipStream_t st) {
