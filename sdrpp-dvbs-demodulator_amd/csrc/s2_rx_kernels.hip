@@ -135,7 +135,10 @@ __device__ __forceinline__ size_t fe_scratch_offset(int n) { return (size_t)n + 
 // overwrites the input slot); wave 1 moves the tiles: coalesced row loads of the next tile, coalesced row stores of the
 // previous one, double-buffered.  The compute wave never issues a global access, so no memory latency and no store drain
 // (loads and stores share one counter on this hardware) ever enters the serial chain.
-constexpr int AG_T = 16;                 // samples per stream per tile (17 KB of LDS: fits beside a resident LDPC workgroup)
+#ifndef AG_T_N
+#define AG_T_N 16
+#endif
+constexpr int AG_T = AG_T_N;             // samples per stream per tile (17 KB of LDS: fits beside a resident LDPC workgroup)
 struct AgcS2Traits {                     // FastAGC gain + FreqShift phase recurrences; result = (gain, phase) per sample
     typedef S2StreamWork Work;
     typedef S2LoopCoefs Coefs;
