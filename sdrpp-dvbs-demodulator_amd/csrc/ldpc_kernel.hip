@@ -46,7 +46,18 @@ struct LdpcKernelArgs {
     unsigned long long* prof;   // development aid (-DLDPC_PROF builds only): per-wave phase cycle sums of workgroup 0
 };
 
-#if defined(LDPC_PROF) && LDPC_PROF == 2
+#if defined(LDPC_PROF) && LDPC_PROF == 3
+// waypoints inside a layer step, first lane of wave 0 and of wave 5 of slot 0 (workgroup 0): prof[200 + 64*kind + 16*(wave==5) + i] = cycles from the
+// previous waypoint; kind 0 = free layer, 1 = chain layer.  i: 0 input phase, 1 hand-off, 2 barrier, 3 walk, 4 barrier, 5 late links, 6 output phase, 7 layer barrier
+#define PROF_MARK(kind, i) do { if ((kind) < 2 && blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 320)) { unsigned long long t_now = clock64(); A.prof[200 + 64 * (kind) + (threadIdx.x ? 16 : 0) + (i)] += t_now - t_mark; t_mark = t_now; } } while (0)
+#define PROF_MARK_DECL unsigned long long t_mark = clock64()
+#define PROF_MARK_PTR (&t_mark)
+#else
+#define PROF_MARK_PTR nullptr
+#define PROF_MARK(kind, i) do { } while (0)
+#define PROF_MARK_DECL do { } while (0)
+#endif
+#if defined(LDPC_PROF) && (LDPC_PROF == 2 || LDPC_PROF == 3)
 // one probe per layer (after its barrier, wave 0 of workgroup 0): prof[128 + layer] = cycles of that layer step, prof[127] = the rest of
 // an iteration (check, loop top); the fine-grained probes below cost ~250 cycles each and distort what they measure
 #define PROF_T(var) do { } while (0)
@@ -223,7 +234,10 @@ template <int MAXDEG, int REC, int KIND, bool IRREG>
 __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const LdpcKernelArgs& A, const uint32_t* __restrict__ ents,
                                              const uint32_t (&pw)[2 * ((MAXDEG + 1) / 2)], const LdpcLayerDesc L, uint32_t rowword, int layer, int j, bool active, bool live,
                                              const uint32_t (&rec_in)[REC], uint32_t (&rec_out)[REC],
-                                             uint32_t* __restrict__ cw, uint8_t* __restrict__ cres, const uint32_t* __restrict__ walk = nullptr) {
+                                             uint32_t* __restrict__ cw, uint8_t* __restrict__ cres, const uint32_t* __restrict__ walk = nullptr, unsigned long long* t_mark_p = nullptr) {
+#if defined(LDPC_PROF) && LDPC_PROF == 3
+    unsigned long long& t_mark = *t_mark_p;
+#endif
     constexpr int NL = MAXDEG + 2;
     constexpr int NP = (NL + 1) / 2;
     // KIND 0: no shared bits in the layer; 1: one shared pair resolved by the chain walk (links 0, 1 only); 2: general levels;
@@ -292,8 +306,11 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
             }
             lds_read_pair_i8(la[0], la[1], XR[p], XH[p]);
         }
+        PROF_MARK(KIND, 8);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
+            if (p == 1) PROF_MARK(KIND, 9);
+            if (p == NP - 1) PROF_MARK(KIND, 10);
             // staged wait: LDS returns in order, so pair p is complete once at most 2*(NP-1-p) operations are outstanding (anything
             // else counted in lgkmcnt only makes this stricter) -- the arithmetic of the first pairs overlaps the later reads
             lds_pair_ready(2 * (NP - 1 - p), XR[p], XH[p]);
@@ -333,6 +350,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
     }
     PROF_T(t_b);
     PROF_ADD(CONF ? 4 : 0, t_a, t_b);
+    PROF_MARK(KIND, 0);
     if constexpr (CONF) {
         const int chain_d = (int)(L.deg >> 16);
         if constexpr (KIND == 1) {
@@ -360,8 +378,10 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                 }
             }
             PROF_T(t_m1);
+            PROF_MARK(KIND, 1);
             lds_barrier();
             PROF_T(t_m2);
+            PROF_MARK(KIND, 2);
             if (j < chain_d && active) {
                 // lane c walks rows c + k*d, k = 1..T with T = floor(359 / d): rows k < T exist for every lane, row T only
                 // where c + T*d < 360.  Only this wave is running (the others wait at the barrier), so the walk is bound by
@@ -404,8 +424,10 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                 __builtin_amdgcn_s_setprio(0);
             }
             PROF_T(t_m3);
+            PROF_MARK(KIND, 3);
             lds_barrier();
             PROF_T(t_m4);
+            PROF_MARK(KIND, 4);
             PROF_ADD(9, t_m0, t_m1); PROF_ADD(10, t_m1, t_m2); PROF_ADD(11, t_m2, t_m3); PROF_ADD(12, t_m3, t_m4);
             if (active) {
                 // both late inputs are fetched before either is used (one LDS round trip instead of two behind the branches)
@@ -577,6 +599,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
     }
     PROF_T(t_c);
     PROF_ADD(KIND >= 2 ? 8 : (CONF ? 5 : 1), t_b, t_c);
+    PROF_MARK(KIND, 5);
     if (active) {
         // equality test against the true minimum; the selected magnitude is limited to 32 once per row (the per-link clamp to
         // [-32, 31] then only needs its upper side)
@@ -623,6 +646,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
 #undef LINK_SET
     PROF_T(t_d);
     PROF_ADD(CONF ? 6 : 2, t_c, t_d);
+    PROF_MARK(KIND, 6);
 }
 
 // LDPCDecoder::bad (layered_decoder.hh:28-45): true if any row is unsatisfied.  A row is bad when the sign product of its links'
@@ -739,6 +763,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
 
         int it = 0, ret = 0, trip = 0;
         PROF_LAYER_DECL;
+        PROF_MARK_DECL;
         bool done = !valid;
         while (true) {
             const bool check = !done && (!A.force || it == A.max_trials);
@@ -771,7 +796,9 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
 #pragma unroll
             for (int w = 0; w < REC; ++w) rec_next[w] = 0;
             if (!first && active && !(LDPC_EXP & 1)) rec_load<REC>(rec_next, msg + (size_t)j * REC);
-            LdpcLayerDesc Lnext = layers[0];
+            // The layer descriptors travel TWO layers ahead: the one of layer + 1 decides, at the top of a layer, whether that layer's row words
+            // are prefetched -- loaded only one layer ahead it was awaited right there, i.e. every layer began with a scalar-cache round trip.
+            LdpcLayerDesc Lnext = layers[0], Lnext2 = layers[q > 1 ? 1 : 0];
             // the layer's pair table (link addresses) travels one layer ahead in scalar registers, like the descriptor: its scalar-cache
             // latency is then off the path between a layer barrier and the first LDS read
             constexpr int NPW = 2 * ((MAXDEG + 1) / 2);
@@ -795,7 +822,8 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
                 const uint32_t rw = rw_next;
                 uint32_t* rp = msg + ((size_t)layer * 360 + j) * REC;
                 if (layer + 1 < q) {
-                    Lnext = layers[layer + 1];
+                    Lnext = Lnext2;
+                    Lnext2 = layers[layer + 2 < q ? layer + 2 : q - 1];
                     if constexpr (PW_AHEAD) {
 #pragma unroll
                         for (int i = 0; i < NPW; ++i) pw_next[i] = ents[A.pent_base + (layer + 1) * NPW + i];
@@ -808,9 +836,9 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
                 uint32_t ro[REC];
 #pragma unroll
                 for (int w = 0; w < REC; ++w) ro[w] = 0;
-                if ((L.depth_nc & 0xffffu) == 1) layer_update<MAXDEG, REC, 0, IRREG>(post, A, ents + L.ent_off, pw, L, 1u, layer, j, active, live, rec, ro, cw, cres);
+                if ((L.depth_nc & 0xffffu) == 1) layer_update<MAXDEG, REC, 0, IRREG>(post, A, ents + L.ent_off, pw, L, 1u, layer, j, active, live, rec, ro, cw, cres, nullptr, PROF_MARK_PTR);
                 else if ((L.deg >> 16) == LDPC_WALK_MARK) layer_update<MAXDEG, REC, 6, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres, rows + L.row_off + 360);
-                else if ((L.deg >> 16) > 0) layer_update<MAXDEG, REC, 1, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres);
+                else if ((L.deg >> 16) > 0) layer_update<MAXDEG, REC, 1, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres, nullptr, PROF_MARK_PTR);
                 else if ((L.depth_nc >> 16) <= 4u) layer_update<MAXDEG, REC, 3, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres);
                 else if (MAXDEG > 12 && (L.depth_nc >> 16) <= 8u) layer_update<MAXDEG, REC, (MAXDEG > 12 ? 4 : 2), IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres);
                 else layer_update<MAXDEG, REC, 2, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres);
@@ -821,6 +849,12 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
 #pragma unroll
                 for (int w = 0; w < REC; ++w) asm volatile("" : "+v"(rec_next[w]));
                 asm volatile("" : "+v"(rw_next));
+                // (the same for the scalar prefetches: claimed at the end of the layer, their wait does not open the next one)
+                asm volatile("" : "+s"(Lnext2.ent_off), "+s"(Lnext2.deg), "+s"(Lnext2.depth_nc), "+s"(Lnext2.row_off));
+                if constexpr (PW_AHEAD) {
+#pragma unroll
+                    for (int i = 0; i < NPW; ++i) asm volatile("" : "+s"(pw_next[i]));
+                }
                 if (active && !(LDPC_EXP & 1)) rec_store<REC>(ro, rp);
                 if (LDPC_EXP & 1) asm volatile("" :: "v"(ro[0]), "v"(ro[REC - 1]));
                 PROF_T(t_e);
@@ -828,6 +862,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
                 PROF_T(t_f);
                 PROF_ADD(3, t_e, t_f);
                 PROF_LAYER(layer);
+                PROF_MARK(((L.depth_nc & 0xffffu) == 1) ? 0 : (((L.deg >> 16) > 0 && (L.deg >> 16) != LDPC_WALK_MARK) ? 1 : 2), 7);
             }
             if (!done) ++it;
             ++trip;

@@ -32,3 +32,10 @@ if full[127:].any():   # PROF_LEVEL=2 build: one probe per layer
     print('rest of an iteration: %.0f   sum: %.0f' % (full[127] / iters, per.sum() + full[127] / iters))
     if full[65]:
         print('slot layers: level loops %.0f cycles per iteration, %.0f levels -> %.0f cycles per level' % (full[64] / iters, full[65] / iters, full[64] / full[65]))
+if full[200:328].any():   # PROF_LEVEL=3 build: waypoints
+    names = ['input', 'hand-off', 'barrier1', 'walk', 'barrier2', 'late links', 'output', 'layer barrier+top']
+    for kind, kn in ((0, 'free layers'), (1, 'chain layers')):
+        for who, wn in ((0, 'wave 0'), (1, 'wave 5')):
+            v = full[200 + 64 * kind + 16 * who: 200 + 64 * kind + 16 * who + 16] / iters
+            print('%-12s %s: ' % (kn, wn) + '  '.join('%s=%.0f' % (names[i], v[i]) for i in range(8)) + '   sum=%.0f' % v[:8].sum())
+            if v[8:11].any(): print('             input phase split: to reads issued=%.0f  first pair done=%.0f  up to last pair=%.0f  (the rest of "input" = last pair + merge)' % (v[8], v[9], v[10]))
