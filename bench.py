@@ -585,13 +585,14 @@ def main():
     in_step_frames = l_frames / max(l_n, 1)
     achieved = bytes_per_frame * in_step_frames / (in_step_ms * 1e-3) / 1e9 if l_n else None
     achieved_alone = bytes_per_frame * nfr / (k['forced'] * 1e-3) / 1e9
-    traffic, traffic_note, issue = None, None, None
+    traffic, traffic_note, issue, wcf = None, None, None, None
     tp = os.path.join(ROOT, 'profiles', 'r02_ldpc_traffic.json')
     if os.path.exists(tp):
         tj = json.load(open(tp))
         traffic = tj.get('traffic_bytes_per_frame', 0) * in_step_frames or None     # (measured on a 4096-frame launch; the kernel's traffic is per frame)
         traffic_note = tj.get('source')
         issue = tj.get('valu_issue_fraction')
+        wcf = tj.get('wave_cycles_fraction')
 
     if rank == 0:
         value = world * S * F * args.steps * sym / dt / 1e6
@@ -609,7 +610,7 @@ def main():
                        'frames_out_of_sequence': acc['out_of_order'],
                        'check': 'every delivered frame of every stream, last timed step + pipeline flush, on the device (hash + full byte compare)',
                        'fec_pipelined_across_steps': pipelined},
-            'roofline': {'bound': 'valu-issue + serial-section latency (measured); the HBM figure below is NOMINAL: algorithmic bytes against the 8 TB/s peak',
+            'roofline': {'bound': 'per-wave instruction issue + serial-section latency (measured, see wave_cycles_fraction); the HBM figure below is NOMINAL: algorithmic bytes against the 8 TB/s peak',
                          'kernel': 'ldpc_decode_kernel<%d,%d,%s>' % (plan['max_deg'], plan['rec_dwords'], 'true' if plan.get('irregular') else 'false'),
                          'achieved': round(achieved if achieved else achieved_alone, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round((achieved if achieved else achieved_alone) / HBM_PEAK_GBS, 4),
@@ -618,7 +619,7 @@ def main():
                          'kernel_ms_alone': round(k['forced'], 4), 'achieved_alone': round(achieved_alone, 1), 'frac_alone': round(achieved_alone / HBM_PEAK_GBS, 4),
                          'kernel_ms_alone_normal_mode_same_iterations': round(k['normal'], 4) if k['normal_all_ran'] else None,
                          'traffic': traffic, 'traffic_unit': 'bytes per launch (fabric-side FETCH_SIZE x2 + WRITE_SIZE, per frame x frames of the launch)', 'traffic_source': traffic_note,
-                         'valu_issue_fraction': issue,
+                         'valu_issue_fraction': issue, 'wave_cycles_fraction': wcf,
                          'algorithmic_bytes_per_frame': bytes_per_frame, 'algorithmic_bytes_per_launch': int(bytes_per_frame * in_step_frames),
                          'ldpc_share_of_step': round(in_step_ms * l_n / (dt * 1e3), 3),
                          'syndrome_check': 'forced mode (the headline): evaluated once, after the last iteration; normal mode: before every iteration, as in the reference (bit-vector form, see DESIGN.md)',

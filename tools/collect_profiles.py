@@ -13,8 +13,8 @@ rd = lambda n: open(os.path.join(F, n)).read()
 open(os.path.join(P, tag + '_bench.json'), 'w').write(rd('bench.json'))
 open(os.path.join(P, tag + '_bench_kernel_stats.csv'), 'w').write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary (tools/profile_run.sh)\n' + rd('kt.csv'))
 open(os.path.join(P, tag + '_bench_timeline.txt'), 'w').write('# start_ms end_ms duration_ms queue kernel -- dispatches >= 2 ms of the same run (tools/timeline.py); q=3: FEC stream, q=2: front-end stream\n' + rd('timeline.txt'))
-rows = [l.rstrip() for p in ('p1', 'p2', 'p3') for l in open(os.path.join(F, p + '.csv')) if 'ldpc_decode_kernel' in l]
-get = lambda c: [float(l.split(',')[-1]) for l in rows if '"' + c + '"' in l][0]
+rows = [l.rstrip() for p in ('p1', 'p2', 'p3', 'p4') if os.path.exists(os.path.join(F, p + '.csv')) for l in open(os.path.join(F, p + '.csv')) if 'ldpc_decode_kernel' in l]
+get = lambda c: ([float(l.split(',')[-1]) for l in rows if '"' + c + '"' in l] or [float('nan')])[0]
 dur_ns = [float(l.split(',')[-4]) for l in rows if 'FETCH' not in l and 'SQ_' not in l and 'WRITE' not in l]   # (name,calls,total,AVERAGE,min,max,percentage)
 ms = sum(dur_ns) / len(dur_ns) / 1e6
 frames, iters = 4096, 50
@@ -36,6 +36,12 @@ t = {
     'valu_issue_fraction': round(valu * 4 / (cus * simds * ms * 1e-3 * clk), 4),
     'valu_issue_formula': 'SQ_INSTS_VALU x 4 cycles (a wave64 VALU instruction occupies its SIMD for 4 cycles) / (256 CUs x 4 SIMDs x kernel time x 2.4 GHz)',
     'wait_fraction': round(get('SQ_WAIT_ANY') / get('SQ_WAVE_CYCLES'), 4),
+    # where a wave's resident cycles go (SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES, both in quad-cycles; fourth PMC pass)
+    'wave_cycles_fraction': {k: round(get(c) / get('SQ_WAVE_CYCLES'), 4) for k, c in (('valu', 'SQ_ACTIVE_INST_VALU'), ('scalar', 'SQ_ACTIVE_INST_SCA'),
+                             ('lds', 'SQ_ACTIVE_INST_LDS'), ('misc', 'SQ_ACTIVE_INST_MISC'), ('waiting_for_lds', 'SQ_WAIT_INST_LDS'))},
+    'reading': 'a wave executes an instruction in ~30 % of its resident cycles: one wave issues at most one VALU instruction per 4.5-5.5 cycles whatever shares its SIMD '
+               '(tools/ubench/valu_cu.hip: 4 waves per SIMD run at the single-wave rate), so the decoder is bound by the length of the per-wave instruction streams between '
+               'barriers and by its serial sections, not by SIMD throughput or memory',
 }
 json.dump(t, open(os.path.join(P, tag + '_ldpc_traffic.json'), 'w'), indent=2)
 print(json.dumps(t, indent=1))
