@@ -123,6 +123,40 @@ def test_ldpc_plan_matches_reference_row_order(pkg, rate, short):
                 assert lvl[lst[a][0]] > lvl[lst[a - 1][0]]        # the later row waits for the earlier one
 
 
+@pytest.mark.parametrize('rate,short', orc.ALL_CODES)
+def test_ldpc_plan_walk_lists(pkg, rate, short):
+    """quad-walk layers (csrc/ldpc_plan.h): the step list behind the layer's row words names every row of level >= 2 exactly once, never more
+    than 16 rows per step, all rows of a step on one level, levels in ascending order -- the single walker wave relies on exactly that"""
+    lib = pkg.load_library()
+    cnt = (C.c_int32 * 3)()
+    assert lib.dvbs2gpu_ldpc_plan_dump(rate, short, None, None, None, cnt) == 0
+    nl, ne, nr = list(cnt)
+    layers = np.zeros((nl, 4), np.uint32); ents = np.zeros(ne, np.uint32); rows = np.zeros(max(nr, 1), np.uint32)
+    assert lib.dvbs2gpu_ldpc_plan_dump(rate, short, layers.ctypes.data, ents.ctypes.data, rows.ctypes.data, cnt) == 0
+    WALK = 0xfffe
+    for i in range(nl):
+        off, deg, dn, row_off = (int(x) for x in layers[i])
+        if (deg >> 16) != WALK:
+            continue
+        depth, nc = dn & 0xffff, dn >> 16
+        assert 1 <= nc <= 4 and depth >= 2
+        lvl = (rows[row_off:row_off + 360] & 0xff).astype(np.int64)
+        nsteps = int(rows[row_off + 360])
+        lst = rows[row_off + 361:row_off + 361 + 16 * (nsteps + 3)].astype(np.int64).reshape(nsteps + 3, 16)
+        assert np.all(lst[nsteps:] == 0xffffffff)                   # the empty steps the walker's look-ahead may fetch
+        seen, last_level = [], 1
+        for st in range(nsteps):
+            r = lst[st][lst[st] != 0xffffffff]
+            assert 1 <= r.size <= 16 and np.all(r < 360)
+            lv = set(lvl[r].tolist())
+            assert len(lv) == 1
+            assert lv.pop() >= last_level
+            last_level = int(lvl[r[0]])
+            seen += r.tolist()
+        want = np.nonzero(lvl >= 2)[0]
+        assert sorted(seen) == want.tolist()
+
+
 def test_header_is_plain_c(tmp_path):
     """the drop-in boundary is a C ABI: include/dvbs2gpu.h must compile as C99 on its own (no C++, no torch types)"""
     import subprocess

@@ -598,3 +598,50 @@ def test_soft_plsc_and_pilot_aided_modes_equal_oracle(engine, modcod, short, pil
         ndec += len(g)
     assert ndec >= 8
     dm.close()
+
+
+@pytest.mark.gpu
+def test_time_sliced_front_end_changes_nothing(engine, pkg):
+    """the AGC/NCO and timing-recovery stages keep their state in the stream record, so running a call's samples as 1, 4 (default) or 8
+    time slices -- the AGC of slice c+1 beside the Gardner loop of slice c on an auxiliary stream -- must give the same bytes, call by call
+    (DVBS2GPU_FE_SLICES is read when a context is created)"""
+    import os, torch
+    modcod, S = 14, 6
+    iqs = []
+    for s in range(S):
+        iq, _, _ = orc.transmit(modcod, 1, 0, nframes=6, seed=500 + s, esn0_db=16.0, cfo=4e-4 * (s + 1), timing=0.13 * s, phase0=0.1, lead_symbols=200 + 37 * s)
+        iqs.append(iq)
+    n = min(i.size for i in iqs)
+    cuts = [0, n // 3 + 5, 2 * n // 3 - 11, n]
+
+    def run(eng):
+        dms = [eng.demod(eng.default_cfg(modcod, True, False), max_samples=n) for _ in range(S)]
+        kb = dms[0].info['kbch'] // 8
+        out = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            tin = [torch.from_numpy(np.ascontiguousarray(i[a:b])).cuda() for i in iqs]
+            tout = [torch.zeros(8 * kb, dtype=torch.uint8, device='cuda') for _ in range(S)]
+            nb = eng.process_batch(dms, tin, tout)
+            out.append([tout[s][:nb[s]].cpu().numpy().copy() for s in range(S)])
+            out.append([np.array([d.nco_freq()], np.float32) for d in dms])
+        for d in dms:
+            d.close()
+        return out
+
+    ref = run(engine)
+    assert sum(x.size for x in ref[0] + ref[2] + ref[4]) > 0
+    old = os.environ.get('DVBS2GPU_FE_SLICES')
+    try:
+        for k in ('1', '8'):
+            os.environ['DVBS2GPU_FE_SLICES'] = k
+            e2 = pkg.Engine(0)
+            got = run(e2)
+            e2.close()
+            for a, b in zip(ref, got):
+                for x, y in zip(a, b):
+                    assert np.array_equal(x, y)
+    finally:
+        if old is None:
+            os.environ.pop('DVBS2GPU_FE_SLICES', None)
+        else:
+            os.environ['DVBS2GPU_FE_SLICES'] = old
