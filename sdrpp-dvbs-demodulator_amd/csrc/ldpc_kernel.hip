@@ -76,6 +76,7 @@ struct LdpcKernelArgs {
 #define PROF_ADD(slot, t0, t1) do { } while (0)
 #endif
 
+#define LDPC_CW_DWORDS(maxdeg) ((maxdeg) > 12 ? 3 : 2)
 __device__ __forceinline__ int med3i(int a, int lo, int hi) { return min(max(a, lo), hi); }  // folds to v_med3_i32 for lo <= hi
 __device__ __forceinline__ int clamp8(int v) { return med3i(v, -128, 127); }
 
@@ -248,7 +249,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
     // branches per level whether or not a row uses it)
     // KIND 6 = "quad walk" layers (at most 4 shared links, deep and narrow level structure): one wave walks the rows of levels >= 2 in
     // level order, four lanes per row, see below
-    constexpr int MAXC = KIND == 1 ? (MAXDEG < 2 ? MAXDEG : 2) : (KIND == 3 || KIND == 6) ? (MAXDEG < 4 ? MAXDEG : 4) : KIND == 4 ? (MAXDEG < 8 ? MAXDEG : 8) : MAXC_ALL;
+    constexpr int MAXC = KIND == 1 ? (MAXDEG < 2 ? MAXDEG : 2) : KIND == 6 ? (MAXDEG > 12 ? 8 : (MAXDEG < 4 ? MAXDEG : 4)) : KIND == 3 ? (MAXDEG < 4 ? MAXDEG : 4) : KIND == 4 ? (MAXDEG < 8 ? MAXDEG : 8) : MAXC_ALL;
     s16x2 V[NP], G[NP];        // extrinsic inputs and their offset magnitudes
     uint32_t addr[MAXDEG];     // LDS byte addresses of the table links' posteriors
     const uint32_t lbase = lds_offset(post);
@@ -455,8 +456,14 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
             // posterior.  Steps of one level are independent, steps of consecutive levels are ordered by the in-order LDS pipeline of
             // the one wave -- no workgroup barrier per level.  Late link values go back into the record for the output phase.
             // (what the walker needs from global memory is fetched before the hand-off, so that its latency overlaps the barrier)
-            const uint32_t wk_ent = ents[(j & 3) < nc ? (j & 3) : 0];
-            const int wk_steps = (int)walk[0];
+            // Kernels for degree > 12 also walk layers with up to 8 shared links, eight lanes per row (8 rows per step, 12-byte records).
+            constexpr int WL = MAXDEG > 12 ? 8 : 4;                 // most lanes per row this kernel handles
+            constexpr int CWD = LDPC_CW_DWORDS(MAXDEG);             // record size in dwords: header + WL link bytes
+            const uint32_t whd = walk[0];
+            const int wk_steps = (int)(whd & 0xffffu);
+            const int lpr = WL == 8 ? (int)(whd >> 16) : 4;         // lanes per row of THIS layer (4 or 8)
+            const int wk_k = j & (lpr - 1);
+            const uint32_t wk_ent = ents[wk_k < nc ? wk_k : 0];
             if (active) {
                 if (level == 1u) {
 #pragma unroll
@@ -467,20 +474,25 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                         }
                     }
                 } else {
-                    uint32_t lb = 0;
+                    uint32_t lb[WL / 4];
+#pragma unroll
+                    for (int w = 0; w < WL / 4; ++w) lb[w] = 0;
 #pragma unroll
                     for (int k = 0; k < MAXC; ++k) {
                         const int b = (k < nc && ((late >> k) & 1)) ? rec_byte<REC>(rec_in, k) : LINK_IN(k);
-                        lb |= ((uint32_t)b & 0xffu) << (8 * k);
+                        lb[k >> 2] |= ((uint32_t)b & 0xffu) << (8 * (k & 3));
                     }
-                    const uint32_t hd = (uint32_t)min0 | ((uint32_t)min1 << 8) | (((uint32_t)sx >> 31) << 16) | ((late & 0xfu) << 20) | ((early & 0xfu) << 24);
-                    reinterpret_cast<uint2*>(cw)[j] = make_uint2(hd, lb);
+                    // header: min0, min1 (7 bits each: 127 stands for "none", every real magnitude is <= 126), sign of the totals, late mask, early mask
+                    const uint32_t hd = (uint32_t)min(min0, 127) | ((uint32_t)min(min1, 127) << 7) | (((uint32_t)sx >> 31) << 14) | ((late & 0xffu) << 15) | ((early & 0xffu) << 23);
+                    cw[CWD * j] = hd;
+#pragma unroll
+                    for (int w = 0; w < WL / 4; ++w) cw[CWD * j + 1 + w] = lb[w];
                 }
             }
             lds_barrier();
             if (j < 64 && live) {
                 __builtin_amdgcn_s_setprio(3);
-                const int k = j & 3, q = j >> 2;
+                const int k = wk_k, q = WL == 8 ? (lpr == 8 ? j >> 3 : j >> 2) : j >> 2;
                 const uint32_t ek = wk_ent;
                 const int spk = (int)(ek & 0xffffu);
                 const uint32_t basek = lbase + 360u * (ek >> 16);
@@ -493,35 +505,39 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                 auto step = [&](const uint32_t e) {
                     const bool valid = e != 0xffffffffu && k < nc;
                     const int row = valid ? (int)e : 0;
-                    const uint2 r = reinterpret_cast<const uint2*>(cw)[row];
+                    const uint32_t ra = cwb + (uint32_t)(4 * CWD) * (uint32_t)row;
+                    uint32_t hd;
+                    int b;
+                    if constexpr (CWD == 2) {        // header and link bytes in one 8-byte fetch
+                        const uint2 r = reinterpret_cast<const uint2*>(cw)[row];
+                        hd = r.x;
+                        b = (int)__builtin_amdgcn_sbfe((int)r.y, 8 * k, 8);
+                    } else {
+                        hd = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)ra;
+                        b = (int)LDS_I8(ra + 4u + (uint32_t)k);
+                    }
                     int t = row + spk;
                     t = (int)min((uint32_t)t, (uint32_t)(t - 360));
                     const uint32_t a = basek + (uint32_t)t;
                     const int x = (int)LDS_I8(a);
-                    const int b = (int)__builtin_amdgcn_sbfe((int)r.y, 8 * k, 8);
-                    const bool lt = valid && ((r.x >> (20 + k)) & 1u), er = valid && ((r.x >> (24 + k)) & 1u);
+                    const bool lt = valid && ((hd >> (15 + k)) & 1u), er = valid && ((hd >> (23 + k)) & 1u);
                     const int v = lt ? clamp8(x - b) : b;
                     const int g = mag_of(v);
-                    // the row's late links joined across its four lanes: two smallest magnitudes and the sign
+                    // the row's late links joined across its lanes: two smallest magnitudes and the sign
                     int m0 = lt ? g : 255, m1 = 255, sg = lt ? v : 0;
 #define QUAD(x_, ctrl) __builtin_amdgcn_update_dpp(0, (x_), (ctrl), 0xf, 0xf, true)
-                    {
-                        const int o0 = QUAD(m0, 0xB1), o1 = QUAD(m1, 0xB1);                  // quad_perm [1,0,3,2]
-                        m1 = min(max(m0, o0), min(m1, o1)); m0 = min(m0, o0);
-                        sg ^= QUAD(sg, 0xB1);
-                    }
-                    {
-                        const int o0 = QUAD(m0, 0x4E), o1 = QUAD(m1, 0x4E);                  // quad_perm [2,3,0,1]
-                        m1 = min(max(m0, o0), min(m1, o1)); m0 = min(m0, o0);
-                        sg ^= QUAD(sg, 0x4E);
-                    }
+#define JOIN(ctrl) do { const int o0 = QUAD(m0, ctrl), o1 = QUAD(m1, ctrl); m1 = min(max(m0, o0), min(m1, o1)); m0 = min(m0, o0); sg ^= QUAD(sg, ctrl); } while (0)
+                    JOIN(0xB1);                                                              // quad_perm [1,0,3,2]
+                    JOIN(0x4E);                                                              // quad_perm [2,3,0,1]
+                    if (WL == 8 && lpr == 8) JOIN(0x141);                                    // row_half_mirror: the other quad of the 8-lane group
+#undef JOIN
 #undef QUAD
-                    const int q0 = (int)(r.x & 0xffu), q1 = (int)((r.x >> 8) & 0xffu);
+                    const int q0 = (int)(hd & 0x7fu), q1 = (int)((hd >> 7) & 0x7fu);
                     const int t1 = min(max(m0, q0), min(m1, q1)), t0 = min(m0, q0);
-                    const int ss = sg ^ (int)(r.x << 15);                                    // bit 31 = sign of the row's totals
+                    const int ss = sg ^ (int)(hd << 17);                                     // bit 31 = sign of the row's totals
                     const int nm = new_msg(v, g, t0, t1, ss);
                     LDS_I8(er ? a : scratch) = (int8_t)clamp8(v + nm);
-                    LDS_I8(valid ? cwb + 8u * (uint32_t)row + 4u + (uint32_t)k : scratch) = (int8_t)v;
+                    LDS_I8(valid ? ra + 4u + (uint32_t)k : scratch) = (int8_t)v;
                 };
                 // (issued by hand: the compiler sinks such a fetch to its use, or copies registers behind it, and then waits for it)
 #define LIST_FETCH(r, p) asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory")
@@ -546,11 +562,13 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
             }
             lds_barrier();
             if (active && level != 1u) {
-                const uint32_t lb = reinterpret_cast<const uint2*>(cw)[j].y;
+                uint32_t lb[WL / 4];
+#pragma unroll
+                for (int w = 0; w < WL / 4; ++w) lb[w] = cw[CWD * j + 1 + w];
 #pragma unroll
                 for (int k = 0; k < MAXC; ++k) {
                     if (k < nc && ((late >> k) & 1)) {
-                        int v = (int)__builtin_amdgcn_sbfe((int)lb, 8 * k, 8);
+                        int v = (int)__builtin_amdgcn_sbfe((int)lb[k >> 2], 8 * (k & 3), 8);
                         int m = mag_of(v);
                         LINK_SET(k, v, m);
                         ROW_ACCUM(v, m);
@@ -731,7 +749,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
     extern __shared__ __attribute__((aligned(16))) int8_t post_all[];
     __shared__ int s_flag[LDPC_FPB][8];
     __shared__ int s_done[LDPC_FPB];
-    __shared__ uint32_t s_cw[LDPC_FPB][2 * 360];  // chain-walk hand-off records (conflict layers with a single shared pair)
+    __shared__ uint32_t s_cw[LDPC_FPB][LDPC_CW_DWORDS(MAXDEG) * 360];  // hand-off records of the chain walk (8 bytes per row) and of the quad walk (8 / 12)
     __shared__ uint8_t s_cres[LDPC_FPB][384];
     const int fs = threadIdx.x / LDPC_TPS;
     const int j = threadIdx.x - fs * LDPC_TPS;

@@ -137,18 +137,20 @@ inline LdpcPlan build_ldpc_plan(int code_index) {
         // "quad walk" layers: at most 4 shared links and a deep, narrow level structure (few rows per level, e.g. B7 layer 42: 33 levels of
         // 11 rows).  A workgroup barrier per level costs ~900 cycles with one or two waves working; instead ONE wave walks the rows of
         // levels >= 2 in level order, four lanes per row (lane = shared link), 16 rows per step, ordered by the in-order LDS pipeline
-        // (ldpc_kernel.hip, KIND 6).  The step list follows the layer's 360 row words: [number of steps][steps x 16 row indices, ~0 = none].
-        if (l_nc > 0 && l_nc <= 4 && chain_d == 0 && (int)l_depth >= LDPC_WALK_MIN_DEPTH) {
+        // (ldpc_kernel.hip, KIND 6).  The step list follows the layer's 360 row words: [number of steps | lanes per row << 16][steps x 16 row indices, ~0 = none].
+        const int walk_lpr = l_nc <= 4 ? 4 : 8;       // lanes per row: the kernels for degree > 12 also walk layers with up to 8 shared links
+        if (l_nc > 0 && (l_nc <= 4 || (l_nc <= 8 && d.max_deg > 12)) && chain_d == 0 && (int)l_depth >= LDPC_WALK_MIN_DEPTH) {
+            const size_t per_step = 64 / walk_lpr;
             std::vector<std::vector<uint32_t>> by_level(l_depth + 1);
             for (int j = 0; j < 360; ++j) by_level[P.rows[L.row_off + j] & 0xffu].push_back((uint32_t)j);
             size_t widest = 0;
             for (uint32_t lv = 2; lv <= l_depth; ++lv) widest = std::max(widest, by_level[lv].size());
-            if ((int)widest <= LDPC_WALK_MAX_ROWS) {
+            if (widest <= std::min<size_t>(per_step, LDPC_WALK_MAX_ROWS)) {
                 std::vector<uint32_t> list;
                 for (uint32_t lv = 2; lv <= l_depth; ++lv)
-                    for (size_t o = 0; o < by_level[lv].size(); o += 16)
-                        for (size_t i = 0; i < 16; ++i) list.push_back(o + i < by_level[lv].size() ? by_level[lv][o + i] : 0xffffffffu);
-                P.rows.push_back((uint32_t)(list.size() / 16));
+                    for (size_t o = 0; o < by_level[lv].size(); o += per_step)
+                        for (size_t i = 0; i < 16; ++i) list.push_back(i < per_step && o + i < by_level[lv].size() ? by_level[lv][o + i] : 0xffffffffu);
+                P.rows.push_back((uint32_t)(list.size() / 16) | ((uint32_t)walk_lpr << 16));
                 list.insert(list.end(), 48, 0xffffffffu);        // three empty steps: the walker fetches ahead without a bound test
                 P.rows.insert(P.rows.end(), list.begin(), list.end());
                 chain_d = LDPC_WALK_MARK;

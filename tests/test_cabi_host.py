@@ -126,7 +126,7 @@ def test_ldpc_plan_matches_reference_row_order(pkg, rate, short):
 @pytest.mark.parametrize('rate,short', orc.ALL_CODES)
 def test_ldpc_plan_walk_lists(pkg, rate, short):
     """quad-walk layers (csrc/ldpc_plan.h): the step list behind the layer's row words names every row of level >= 2 exactly once, never more
-    than 16 rows per step, all rows of a step on one level, levels in ascending order -- the single walker wave relies on exactly that"""
+    than 64 / (lanes per row) rows per step, all rows of a step on one level, levels in ascending order -- the single walker wave relies on exactly that"""
     lib = pkg.load_library()
     cnt = (C.c_int32 * 3)()
     assert lib.dvbs2gpu_ldpc_plan_dump(rate, short, None, None, None, cnt) == 0
@@ -139,15 +139,15 @@ def test_ldpc_plan_walk_lists(pkg, rate, short):
         if (deg >> 16) != WALK:
             continue
         depth, nc = dn & 0xffff, dn >> 16
-        assert 1 <= nc <= 4 and depth >= 2
         lvl = (rows[row_off:row_off + 360] & 0xff).astype(np.int64)
-        nsteps = int(rows[row_off + 360])
+        nsteps, lpr = int(rows[row_off + 360]) & 0xffff, int(rows[row_off + 360]) >> 16      # lanes per row: 4, or 8 in the kernels for degree > 12
+        assert lpr in (4, 8) and 1 <= nc <= lpr and depth >= 2
         lst = rows[row_off + 361:row_off + 361 + 16 * (nsteps + 3)].astype(np.int64).reshape(nsteps + 3, 16)
         assert np.all(lst[nsteps:] == 0xffffffff)                   # the empty steps the walker's look-ahead may fetch
         seen, last_level = [], 1
         for st in range(nsteps):
             r = lst[st][lst[st] != 0xffffffff]
-            assert 1 <= r.size <= 16 and np.all(r < 360)
+            assert 1 <= r.size <= 64 // lpr and np.all(r < 360)
             lv = set(lvl[r].tolist())
             assert len(lv) == 1
             assert lv.pop() >= last_level
