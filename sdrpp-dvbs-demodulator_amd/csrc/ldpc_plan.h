@@ -41,10 +41,7 @@ constexpr int LDPC_MAX_CONFLICT_LINKS = 12;
 #endif
 
 #ifndef LDPC_WALK_MIN_DEPTH
-#define LDPC_WALK_MIN_DEPTH 6     // quad-walk layers: at least this many levels ...
-#endif
-#ifndef LDPC_WALK_MAX_ROWS
-#define LDPC_WALK_MAX_ROWS 16     // ... of at most this many rows each (levels >= 2)
+#define LDPC_WALK_MIN_DEPTH 4     // quad-walk layers: at least this many levels (and cheaper than the per-level barriers by the cost model below)
 #endif
 constexpr uint32_t LDPC_WALK_MARK = 0xfffeu;   // chain-step field of a quad-walk layer
 
@@ -145,7 +142,14 @@ inline LdpcPlan build_ldpc_plan(int code_index) {
             for (int j = 0; j < 360; ++j) by_level[P.rows[L.row_off + j] & 0xffu].push_back((uint32_t)j);
             size_t widest = 0;
             for (uint32_t lv = 2; lv <= l_depth; ++lv) widest = std::max(widest, by_level[lv].size());
-            if (widest <= std::min<size_t>(per_step, LDPC_WALK_MAX_ROWS)) {
+            // cost model in cycles (per-layer profiles on MI355X, tools/ldpc_prof.py): a level of the owner-lane code ~930 (<= 4 shared links) or
+            // ~1600 (more), a walker step ~445 (4 lanes per row) or ~600 (8), ~1500 for the hand-off and its two barriers
+            size_t steps = 0;
+            for (uint32_t lv = 2; lv <= l_depth; ++lv) steps += (by_level[lv].size() + per_step - 1) / per_step;
+            const double cost_walk = 1500.0 + (double)steps * (walk_lpr == 4 ? 445.0 : 600.0);
+            const double cost_levels = (double)(l_depth - 1) * (l_nc <= 4 ? 930.0 : 1600.0);
+            (void)widest;
+            if (cost_walk < 0.9 * cost_levels) {
                 std::vector<uint32_t> list;
                 for (uint32_t lv = 2; lv <= l_depth; ++lv)
                     for (size_t o = 0; o < by_level[lv].size(); o += per_step)
