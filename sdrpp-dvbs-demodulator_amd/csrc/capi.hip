@@ -223,6 +223,7 @@ int dvbs2gpu_create(int device, dvbs2gpu_ctx** out) {
     dvbs2gpu_ctx* c = new dvbs2gpu_ctx();
     c->device = device;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* v = getenv("DVBS2GPU_DVBS_FE_SLICES")) { int k = atoi(v); if (k >= 1 && k <= 8) c->dvbs_fe_slices = k; }
     if (const char* v = getenv("DVBS2GPU_FE_SLICES")) { int k = atoi(v); if (k >= 1 && k <= s2::S2_FE_MAX_SLICES) c->fe_slices = k; }   // (A/B switch)
     hipError_t ee = hipEventCreateWithFlags(&c->ev_ws, hipEventDisableTiming);
     if (ee != hipSuccess) { delete c; return fail_hip(ee, "hipEventCreate"); }
@@ -265,6 +266,8 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
     for (auto& kv : ctx->fe_aux) {
         if (kv.second.aux) (void)hipStreamDestroy(kv.second.aux);
         for (hipEvent_t e : kv.second.ev) if (e) (void)hipEventDestroy(e);
+        for (hipStream_t a : kv.second.dvbs_aux) if (a) (void)hipStreamDestroy(a);
+        for (auto& row : kv.second.dvbs_ev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
     }
     if (ctx->fe_stream) (void)hipStreamDestroy(ctx->fe_stream);
     if (ctx->fec_stream) (void)hipStreamDestroy(ctx->fec_stream);

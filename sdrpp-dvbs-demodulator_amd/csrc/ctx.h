@@ -139,9 +139,10 @@ struct dvbs2gpu_ctx {
     hipEvent_t ev_llr_grp[MAX_PIPE_GROUPS] = {};
     std::mutex fec_mtx;                                   // FEC jobs are enqueued whole, one at a time (shared FEC workspaces, one stream)
     // time-sliced front end (s2_rx_kernels.hip, s2_frontend_launch): per main stream one auxiliary stream + the slice events
-    struct FeAux { hipStream_t aux = nullptr; hipEvent_t ev[9] = {}; };
+    struct FeAux { hipStream_t aux = nullptr; hipEvent_t ev[9] = {}; hipStream_t dvbs_aux[3] = {}; hipEvent_t dvbs_ev[3][9] = {}; };   // (dvbs_*: the DVB-S front end's three stage streams)
     std::map<hipStream_t, FeAux> fe_aux;
     int fe_slices = 4;                        // DVBS2GPU_FE_SLICES (1 = both stages back to back on the caller's stream)
+    int dvbs_fe_slices = 8;                   // DVBS2GPU_DVBS_FE_SLICES: time slices of a DVB-S call with few carriers (dvbs_demod.hip)
     // DVB-S front end (dvbs_demod.hip)
     float* d_fd_bank = nullptr;               // COMPLEX_FD interpolator bank, 256 x 256
     std::map<int, s2::cf32*> bandedge;        // FLL band-edge taps [2][ntaps] by ntaps*100000 + round(alpha*1000)*10 + sps

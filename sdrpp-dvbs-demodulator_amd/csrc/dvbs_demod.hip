@@ -158,6 +158,8 @@ void dvbs2gpu_dvbs_demod_destroy(dvbs2gpu_dvbs_demod* d) {
     delete d;
 }
 
+constexpr int DVBS_SLICE_MAX_STREAMS = 256;   // above this the wave-per-stream stages fill the GPU on their own
+
 int dvbs2gpu_dvbs_demod_process_batch(dvbs2gpu_dvbs_demod* d, const float* const* d_iq, const int* counts, uint8_t* const* d_bits, int cap,
                                       int* out_counts) {
     if (!d || !d_iq || !counts || !d_bits || !out_counts || cap < 0) return DVBS2GPU_ERR_ARG;
@@ -194,7 +196,24 @@ int dvbs2gpu_dvbs_demod_process_batch(dvbs2gpu_dvbs_demod* d, const float* const
     int* d_nblk = (int*)(base + off_nblk);
     int* d_cnt = (int*)(base + off_cnt);
     int* d_nbits = (int*)(base + off_nbits);
-    HIP_TRY(dvbs_frontend_launch(d_work, n, max_count, d->co, d->d_bandedge, d->d_rrc, ctx->d_fd_bank, st));
+    {
+        // few carriers: the four serial stages time-sliced over four streams (s2_rx_kernels.hip, dvbs_frontend_launch); a bank that fills
+        // the GPU runs them back to back
+        const int nsub = n <= DVBS_SLICE_MAX_STREAMS ? ctx->dvbs_fe_slices : 1;
+        dvbs2gpu_ctx::FeAux* fa = nullptr;
+        if (nsub > 1) {
+            std::lock_guard<std::mutex> l(ctx->mtx);
+            fa = &ctx->fe_aux[st];
+            if (!fa->dvbs_aux[0]) {
+                for (int a = 0; a < 3; ++a) {
+                    HIP_TRY(hipStreamCreateWithFlags(&fa->dvbs_aux[a], hipStreamNonBlocking));
+                    for (int i = 0; i < 9; ++i) HIP_TRY(hipEventCreateWithFlags(&fa->dvbs_ev[a][i], hipEventDisableTiming));
+                }
+            }
+        }
+        HIP_TRY(dvbs_frontend_launch(d_work, n, max_count, d->co, d->d_bandedge, d->d_rrc, ctx->d_fd_bank, st, fa ? fa->dvbs_aux : nullptr,
+                                     fa ? fa->dvbs_ev : nullptr, nsub));
+    }
     HIP_TRY(dvbs_soft_count_launch(d_work, n, d_nblk, st));
     HIP_TRY(dvbs_viterbi_launch(nullptr, (const int8_t* const*)(base + off_ptr_in), d_nblk, n, mb, (uint8_t*)wsb.p, d_nbits, nullptr, d->d_vstate,
                                 d->d_vws, d->cfg.viterbi_ber_threshold, d->cfg.viterbi_max_outsync, st));

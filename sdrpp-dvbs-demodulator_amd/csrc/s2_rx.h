@@ -148,7 +148,7 @@ struct DvbsStreamWork {
 };
 // AGC -> FLL -> RRC -> COMPLEX_FD + Costas -> soft slicer into the per-stream block FIFO
 hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int max_count, DvbsLoopCoefs coefs, const cf32* d_bandedge,
-                                const float* d_rrc, const float* d_fd_bank, hipStream_t st);
+                                const float* d_rrc, const float* d_fd_bank, hipStream_t st, hipStream_t* aux = nullptr, hipEvent_t (*ev)[9] = nullptr, int nsub = 1);
 
 hipError_t dvbs_soft_count_launch(const DvbsStreamWork* d_work, int nstreams, int* d_nblocks, hipStream_t st);
 hipError_t dvbs_soft_compact_launch(const DvbsStreamWork* d_work, int nstreams, hipStream_t st);

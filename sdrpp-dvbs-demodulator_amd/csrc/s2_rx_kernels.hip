@@ -1233,13 +1233,16 @@ __device__ __forceinline__ void pcl_wrap_pi(float& phase) {
 // terms in tap order 0..64 (the order of VOLK's generic kernel) while only the LAST term (tap 64, the newest sample) sits in the
 // loop's serial chain.  Lanes 0..63 = taps 0..63; tap 64 is applied by all lanes to the sum leaving lane 63.
 __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __restrict__ work, DvbsLoopCoefs co,
-                                                      const cf32* __restrict__ bandedge) {
+                                                      const cf32* __restrict__ bandedge, int sub, int nsub) {
     __shared__ cf32 ytile[64];
     __shared__ cf32 xtile[64];
     const int lane = threadIdx.x;
-    const DvbsStreamWork w = work[blockIdx.x];
+    DvbsStreamWork w = work[blockIdx.x];
     DvbsStreamState* st = w.st;
-    const int n = w.count, T = co.ntaps, H = T - 1;     // the systolic layout needs T == 65 (checked on the host)
+    int lo, hi;
+    fe_sub_range(w.count, sub, nsub, lo, hi);            // time slice of the call (dvbs_frontend_launch)
+    w.buf_a += lo; w.buf_b += lo;
+    const int n = hi - lo, T = co.ntaps, H = T - 1;     // the systolic layout needs T == 65 (checked on the host)
     const cf32 tl = bandedge[lane], th = bandedge[T + lane];
     const cf32 tl_last = bandedge[T - 1], th_last = bandedge[2 * T - 1];
     float phase = st->fll_phase, freq = st->fll_freq;
@@ -1300,13 +1303,16 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
 }
 
 // RRC FIR at the input rate (SDR++ filter::FIR, taps accumulated in order); grid (x: sample tiles, y: stream); in = buf_b, out = buf_a
-__global__ __launch_bounds__(256) void dvbs_rrc_kernel(const DvbsStreamWork* __restrict__ work, const float* __restrict__ taps_g, int ntaps) {
+__global__ __launch_bounds__(256) void dvbs_rrc_kernel(const DvbsStreamWork* __restrict__ work, const float* __restrict__ taps_g, int ntaps, int sub, int nsub) {
     __shared__ float taps[RRC_MAX_TAPS];
     for (int i = threadIdx.x; i < ntaps; i += 256) taps[i] = taps_g[i];
     __syncthreads();
-    const DvbsStreamWork w = work[blockIdx.y];
+    DvbsStreamWork w = work[blockIdx.y];
     const DvbsStreamState* st = w.st;
-    const int n = w.count, H = ntaps - 1;
+    int lo, hi;
+    fe_sub_range(w.count, sub, nsub, lo, hi);
+    w.buf_a += lo; w.buf_b += lo;
+    const int n = hi - lo, H = ntaps - 1;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         cf32 acc{0.f, 0.f};
         for (int k = 0; k < ntaps; ++k) {
@@ -1318,10 +1324,13 @@ __global__ __launch_bounds__(256) void dvbs_rrc_kernel(const DvbsStreamWork* __r
         w.buf_a[i] = acc;
     }
 }
-__global__ __launch_bounds__(128) void dvbs_rrc_state_kernel(const DvbsStreamWork* __restrict__ work, int ntaps) {
-    const DvbsStreamWork w = work[blockIdx.x];
+__global__ __launch_bounds__(128) void dvbs_rrc_state_kernel(const DvbsStreamWork* __restrict__ work, int ntaps, int sub, int nsub) {
+    DvbsStreamWork w = work[blockIdx.x];
     DvbsStreamState* st = w.st;
-    const int n = w.count, H = ntaps - 1;
+    int lo, hi;
+    fe_sub_range(w.count, sub, nsub, lo, hi);
+    w.buf_b += lo;
+    const int n = hi - lo, H = ntaps - 1;
     __shared__ cf32 nh[RRC_MAX_TAPS];
     for (int i = threadIdx.x; i < H; i += 128) {
         const int p = n + i;
@@ -1356,17 +1365,20 @@ __device__ __forceinline__ cf32 fd_dot_wave(const cf32 (&x)[4], const float* t, 
 constexpr int FD_TILE = 256;
 constexpr int FD_WROWS = 4;
 __global__ __launch_bounds__(64) void dvbs_fd_costas_kernel(const DvbsStreamWork* __restrict__ work, DvbsLoopCoefs co,
-                                                            const float* __restrict__ bank) {
+                                                            const float* __restrict__ bank, int sub, int nsub) {
     __shared__ cf32 win[FD_TILE + FD_TAPS];      // [255 history][tile]
     __shared__ cf32 ostage[FD_TILE / 2 + 72];
     __shared__ float brow[FD_WROWS * FD_TAPS];   // bank rows [wlo, wlo + FD_WROWS)
     const int lane = threadIdx.x;
-    const DvbsStreamWork w = work[blockIdx.x];
+    DvbsStreamWork w = work[blockIdx.x];
     DvbsStreamState* st = w.st;
-    const int n = w.count;
+    int lo, hi;
+    fe_sub_range(w.count, sub, nsub, lo, hi);
+    w.buf_a += lo;
+    const int n = hi - lo;
     PclDev pcl{co.fd_alpha, co.fd_beta, st->fd_phase, st->fd_freq, co.fd_min_freq, co.fd_max_freq};
     PclDev cos{co.cos_alpha, co.cos_beta, st->costas_phase, st->costas_freq, co.cos_min_freq, co.cos_max_freq};
-    int offset = st->fd_offset, spsctr = st->fd_spsctr, outCount = 0;
+    int offset = st->fd_offset, spsctr = st->fd_spsctr, outCount = sub ? st->n_sym : 0;   // (later slices append to the call's symbols)
     int wlo = -1000;                             // no window yet
     for (int i = lane; i < FD_TAPS - 1; i += 64) win[i] = st->fd_hist[i];
     __syncthreads();
@@ -1508,16 +1520,37 @@ hipError_t s2_fifo_compact_launch(const S2StreamWork* d_work, int nstreams, cons
     hipLaunchKernelGGL(s2_fifo_compact_kernel, dim3(16, nstreams), dim3(256), 0, st, d_work, d_cur_fill);
     return hipGetLastError();
 }
+// The serial stages of the DVB-S front end -- AGC (lane = stream), band-edge FLL, RRC, timing recovery + Costas (a wave per stream each) --
+// keep their state in the stream record, so a call's samples can go through in `nsub` time slices with the four stages on four streams
+// (aux[0..2] + st, events between them): slice c of a stage runs beside slice c+1 of the stage before it, and ONE carrier costs the
+// slowest stage instead of the sum (single carrier: 121 -> ~65 ms per 131 k samples).  A bank that fills the GPU anyway (nsub = 1) runs
+// the stages back to back on `st`.  ev: 3 rows of nsub + 1 events.
 hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int max_count, DvbsLoopCoefs coefs, const cf32* d_bandedge,
-                                const float* d_rrc, const float* d_fd_bank, hipStream_t st) {
-    hipLaunchKernelGGL(agc_pc_kernel<AgcDvbsTraits>, dim3((nstreams + 63) / 64), dim3(128), 0, st, d_work, nstreams, coefs, 0, 1);
-    hipLaunchKernelGGL(dvbs_fll_kernel, dim3(nstreams), dim3(64), 0, st, d_work, coefs, d_bandedge);
-    int gx = (max_count + 255) / 256;
+                                const float* d_rrc, const float* d_fd_bank, hipStream_t st, hipStream_t* aux, hipEvent_t (*ev)[9], int nsub) {
+    const dim3 ga((nstreams + 63) / 64);
+    const bool sliced = nsub > 1 && aux && ev;
+    if (!sliced) nsub = 1;
+    int gx = (max_count / nsub + 1 + 255) / 256;
     gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
-    hipLaunchKernelGGL(dvbs_rrc_kernel, dim3(gx, nstreams), dim3(256), 0, st, d_work, d_rrc, coefs.ntaps);
-    hipLaunchKernelGGL(dvbs_rrc_state_kernel, dim3(nstreams), dim3(128), 0, st, d_work, coefs.ntaps);
-    hipLaunchKernelGGL(dvbs_fd_costas_kernel, dim3(nstreams), dim3(64), 0, st, d_work, coefs, d_fd_bank);
-    hipLaunchKernelGGL(dvbs_soft_fifo_kernel, dim3(gx, nstreams), dim3(256), 0, st, d_work);
+    hipError_t e;
+    hipStream_t s0 = sliced ? aux[0] : st, s1 = sliced ? aux[1] : st, s2 = sliced ? aux[2] : st;
+    if (sliced) {
+        if ((e = hipEventRecord(ev[0][nsub], st)) != hipSuccess) return e;          // the slices start behind what `st` holds now
+        if ((e = hipStreamWaitEvent(s0, ev[0][nsub], 0)) != hipSuccess) return e;
+    }
+    for (int c = 0; c < nsub; ++c) {
+        hipLaunchKernelGGL(agc_pc_kernel<AgcDvbsTraits>, ga, dim3(128), 0, s0, d_work, nstreams, coefs, c, nsub);
+        if (sliced) { if ((e = hipEventRecord(ev[0][c], s0)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(s1, ev[0][c], 0)) != hipSuccess) return e; }
+        hipLaunchKernelGGL(dvbs_fll_kernel, dim3(nstreams), dim3(64), 0, s1, d_work, coefs, d_bandedge, c, nsub);
+        if (sliced) { if ((e = hipEventRecord(ev[1][c], s1)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(s2, ev[1][c], 0)) != hipSuccess) return e; }
+        hipLaunchKernelGGL(dvbs_rrc_kernel, dim3(gx, nstreams), dim3(256), 0, s2, d_work, d_rrc, coefs.ntaps, c, nsub);
+        hipLaunchKernelGGL(dvbs_rrc_state_kernel, dim3(nstreams), dim3(128), 0, s2, d_work, coefs.ntaps, c, nsub);
+        if (sliced) { if ((e = hipEventRecord(ev[2][c], s2)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(st, ev[2][c], 0)) != hipSuccess) return e; }
+        hipLaunchKernelGGL(dvbs_fd_costas_kernel, dim3(nstreams), dim3(64), 0, st, d_work, coefs, d_fd_bank, c, nsub);
+    }
+    int gs = (max_count + 255) / 256;
+    gs = gs < 1 ? 1 : (gs > 64 ? 64 : gs);
+    hipLaunchKernelGGL(dvbs_soft_fifo_kernel, dim3(gs, nstreams), dim3(256), 0, st, d_work);
     return hipGetLastError();
 }
 hipError_t dvbs_soft_count_launch(const DvbsStreamWork* d_work, int nstreams, int* d_nblocks, hipStream_t st) {

@@ -121,6 +121,44 @@ def test_dvbs_bank_batch_equals_single(engine, pkg):
     bank.close()
 
 
+def test_time_sliced_dvbs_front_end_changes_nothing(engine, pkg):
+    """small banks run AGC / FLL / RRC / timing + Costas as four time-sliced stages on four streams (every stage keeps its state in the stream
+    record); 1 slice (what a GPU-filling bank uses), 3 and the default 8 must give the same symbols, loop state and decoded bits, call by call
+    (DVBS2GPU_DVBS_FE_SLICES is read when a context is created)"""
+    import os
+    iq, _ = od.dvbs_iq(2, 30000, seed=7, esn0_db=9.0, cfo=8e-4, timing=0.41, phase0=0.3)
+    chunks = [4097, 12288, 900, 20000, iq.size - 4097 - 12288 - 900 - 20000]
+    assert min(chunks) > 0
+
+    def run(eng):
+        bank = pkg.DvbsDemodBank(eng, 1, max_samples=max(chunks))
+        out, pos = [], 0
+        for c in chunks:
+            bits = bank.process(iq[pos:pos + c])
+            out += [bits.copy(), bank.symbols().view(np.uint32).copy(), bank.loop_state().view(np.uint32).copy()]
+            pos += c
+        bank.close()
+        return out
+
+    ref = run(engine)
+    assert sum(x.size for x in ref[1::3]) > 20000
+    old = os.environ.get('DVBS2GPU_DVBS_FE_SLICES')
+    try:
+        for k in ('1', '3'):
+            os.environ['DVBS2GPU_DVBS_FE_SLICES'] = k
+            e2 = pkg.Engine(0)
+            got = run(e2)
+            e2.close()
+            assert len(got) == len(ref)
+            for a, b in zip(ref, got):
+                assert np.array_equal(a, b)
+    finally:
+        if old is None:
+            os.environ.pop('DVBS2GPU_DVBS_FE_SLICES', None)
+        else:
+            os.environ['DVBS2GPU_DVBS_FE_SLICES'] = old
+
+
 def test_dvbs_demod_error_codes(engine, pkg):
     import ctypes as C
     with pytest.raises(pkg.Dvbs2GpuError):
