@@ -315,7 +315,8 @@ def secondary_s2(eng, pkg, dev, name, modcod, rate, short, pilots, esn0_db, S, F
     bpf = ITERS * 4 * run.info['ldpc_edges'] + run.info['ldpc_n'] + run.info['kbch'] // 8
     out = {'config': name, 'value': round(S * F * steps * run.sym / dt / 1e6, 1), 'unit': 'Msymbols/s', 'ms_per_step': round(dt / steps * 1e3, 2),
            'streams': S, 'frames_per_stream_per_step': F, 'esn0_db': esn0_db, 'frames_delivered': acc['delivered'],
-           'frames_equal_to_transmitted': acc['equal'], 'ldpc_kernel_ms_alone': round(k['forced'], 3),
+           'frames_equal_to_transmitted': acc['equal'], 'stage_ms_per_step': {name: round(v[0] / steps, 2) for name, v in stages.items()},
+           'ldpc_kernel_ms_alone': round(k['forced'], 3),
            'ldpc_nominal_hbm_frac': round(bpf * S * F / (k['forced'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     run.close()
     torch.cuda.empty_cache()

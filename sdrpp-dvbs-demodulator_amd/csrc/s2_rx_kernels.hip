@@ -472,19 +472,32 @@ __device__ void soft_calc_dev(const S2ConstelDev& C, cf32 sample, int8_t* bits_o
     if (phase_err) *phase_err = cphase(cmul(sample, cconj(closest)));
 }
 
-// Phase error only, for the PLL of the frame loops, NOT inlined and fed with scalars + a global-memory copy of the points: the
-// 32APSK path would otherwise set the register budget of the serial frame-loop kernel, which must stay under 128 VGPRs to share
-// a SIMD with three resident LDPC waves in the pipelined mode (s2_demod.hip).
-__device__ __attribute__((noinline)) float soft_phase_err_noinline(const cf32* __restrict__ pts, int states, float amp, float prescale, cf32 sample) {
+// Phase error only (constellation_t::demod_soft_calc's closest-point search + phase), for the PLL of the frame loops with 32APSK.  NOT inlined and
+// fed with scalars + a copy of the points in LDS: the 32APSK path would otherwise set the register budget of the serial frame-loop kernel, which
+// must stay under 128 VGPRs to share a SIMD with three resident LDPC waves in the pipelined mode (s2_demod.hip).
+// The GSZ lanes of a stream's lane group all run the loop's chain with the same values, so they SHARE the search: lane gl takes the points
+// gl, gl + GSZ, ...; the group then reduces (distance, index) lexicographically -- the reference's "first point of strictly smallest distance".
+// (One lane scanning 32 points read from global memory cost 4.4 us per symbol: config 5's frame loops took 242 ms per step, now 45.)
+typedef __attribute__((address_space(3))) const float lds_cf32;   // (interleaved re, im)
+template <int GSZ>
+__device__ __attribute__((noinline)) float soft_phase_err_group(lds_cf32* __restrict__ pts, int states, float amp, float prescale, cf32 sample, int gl) {
     if (amp != 1) sample = cscale(sample, amp);
     if (prescale != 1) sample = cscale(sample, prescale);
-    float min_dist = 3.402823466e+38f;
-    cf32 closest{0.f, 0.f};
-    for (int i = 0; i < states; i++) {
-        const cf32 p = pts[i];
-        float dist = camp(csub(sample, p));
-        if (dist < min_dist) { min_dist = dist; closest = p; }
+    float bd = 3.402823466e+38f;
+    int bi = 64;
+    for (int i = gl; i < states; i += GSZ) {
+        const cf32 p{pts[2 * i], pts[2 * i + 1]};
+        const float dist = camp(csub(sample, p));
+        if (dist < bd) { bd = dist; bi = i; }                 // strict: the lowest index among this lane's equals stays
     }
+#pragma unroll
+    for (int o = GSZ / 2; o > 0; o >>= 1) {
+        const float od = __shfl_xor(bd, o);
+        const int oi = __shfl_xor(bi, o);
+        if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+    cf32 closest{0.f, 0.f};
+    if (bi < 64) closest = cf32{pts[2 * bi], pts[2 * bi + 1]};
     return cphase(cmul(sample, cconj(closest)));
 }
 
@@ -515,6 +528,8 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
     __shared__ uint8_t rnt[FL_TILE];
     float (*fedt)[2 * FL_TILE] = reinterpret_cast<float (*)[2 * FL_TILE]>(otile);   // FED terms live in the (then unused) output tile
     __shared__ cf32 hdr_sym[FL_SPW][90];
+    __shared__ cf32 s_pts[32];                 // constellation points for the 32APSK phase-error search (the other constellations use the LUT)
+    if (C.bits == 5 && threadIdx.x < 32) s_pts[threadIdx.x] = threadIdx.x < (unsigned)C.states ? C.pts_g[threadIdx.x] : cf32{0.f, 0.f};
     const int lane = threadIdx.x, g = lane / FL_LPS, gl = lane % FL_LPS;
     const int s0 = blockIdx.x * FL_SPW, s = s0 + g;
     const bool act = s < nstreams;
@@ -610,7 +625,7 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
                     bool is_pilot = next_pilot >= 0 && i >= next_pilot && i < next_pilot + 36;
                     if (!is_pilot) {
                         if (C.bits != 5) error = C.lut_err[lut_index(tmp_val.re) * 256 + lut_index(tmp_val.im)];
-                        else error = soft_phase_err_noinline(C.pts_g, C.states, C.amp, C.prescale, tmp_val);
+                        else error = soft_phase_err_group<FL_LPS>((lds_cf32*)reinterpret_cast<const float*>(s_pts), C.states, C.amp, C.prescale, tmp_val, gl);
                     } else {
                         const cf32 pr = cmul(descr, cf32{0.707f, -0.707f});
                         error = cphase(pr);
@@ -1012,6 +1027,7 @@ __global__ __launch_bounds__(64) void s2_vcm_loops_kernel(const S2StreamWork* __
     __shared__ float fedt[96];
     __shared__ cf32 hdr_sym[90];
     __shared__ float hsoft[64];
+    __shared__ cf32 v_pts[32];
     const int lane = threadIdx.x, s = blockIdx.x;
     S2StreamState* st = work[s].st;
     PclDev pll{co.pll_alpha, co.pll_beta, st->pll_phase, st->pll_freq, co.pll_min_freq, co.pll_max_freq};
@@ -1036,6 +1052,7 @@ __global__ __launch_bounds__(64) void s2_vcm_loops_kernel(const S2StreamWork* __
         const int cbits = C->bits;
         // ---- coarse frequency error detector (dvbs2_fed.h): terms in parallel, summed in the reference's order
         __syncthreads();
+        if (cbits == 5 && lane < 32) v_pts[lane] = lane < C->states ? C->pts_g[lane] : cf32{0.f, 0.f};   // (this frame's 32APSK points, see soft_phase_err_group)
         for (int i = lane; i < 88; i += 64) {
             cf32 r2 = (i + 2) < 26 ? T.sof[i + 2] : plsc[i + 2 - 26];
             cf32 r0 = i < 26 ? T.sof[i] : plsc[i - 26];
@@ -1086,7 +1103,7 @@ __global__ __launch_bounds__(64) void s2_vcm_loops_kernel(const S2StreamWork* __
                     bool is_pilot = next_pilot >= 0 && i >= next_pilot && i < next_pilot + 36;
                     if (!is_pilot) {
                         if (cbits != 5) error = C->lut_err[lut_index(tmp_val.re) * 256 + lut_index(tmp_val.im)];
-                        else error = soft_phase_err_noinline(C->pts_g, C->states, C->amp, C->prescale, tmp_val);
+                        else error = soft_phase_err_group<64>((lds_cf32*)reinterpret_cast<const float*>(v_pts), C->states, C->amp, C->prescale, tmp_val, lane);
                     } else {
                         const cf32 pr = cmul(descr, cf32{0.707f, -0.707f});
                         error = cphase(pr);
