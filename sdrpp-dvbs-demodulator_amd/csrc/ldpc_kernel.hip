@@ -76,6 +76,9 @@ struct LdpcKernelArgs {
 #define PROF_ADD(slot, t0, t1) do { } while (0)
 #endif
 
+#ifndef LDPC_WPE4_MAXDEG
+#define LDPC_WPE4_MAXDEG 28    // kernels up to this degree are held to 128 VGPRs (4 waves per SIMD: room for a front-end wave beside three decoder waves)
+#endif
 #define LDPC_CW_DWORDS(maxdeg) ((maxdeg) > 12 ? 3 : 2)
 __device__ __forceinline__ int med3i(int a, int lo, int hi) { return min(max(a, lo), hi); }  // folds to v_med3_i32 for lo <= hi
 __device__ __forceinline__ int clamp8(int v) { return med3i(v, -128, 127); }
@@ -744,7 +747,7 @@ __device__ __forceinline__ bool syndromes_bad(const LdpcKernelArgs& A, const uin
 constexpr int LDPC_TPS = 384;        // threads per slot
 
 template <int MAXDEG, int REC, bool IRREG, int LDPC_FPB>
-__global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_per_eu(MAXDEG <= 12 ? 4 : 3))) void ldpc_decode_kernel(const LdpcLayerDesc* __restrict__ layers, const uint32_t* __restrict__ ents,
+__global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_per_eu(MAXDEG <= LDPC_WPE4_MAXDEG ? 4 : 3))) void ldpc_decode_kernel(const LdpcLayerDesc* __restrict__ layers, const uint32_t* __restrict__ ents,
                                                                                const uint32_t* __restrict__ rows, LdpcKernelArgs A) {
     extern __shared__ __attribute__((aligned(16))) int8_t post_all[];
     __shared__ int s_flag[LDPC_FPB][8];
