@@ -142,6 +142,9 @@ struct dvbs2gpu_ctx {
     struct FeAux { hipStream_t aux = nullptr; hipEvent_t ev[9] = {}; hipStream_t dvbs_aux[3] = {}; hipEvent_t dvbs_ev[3][9] = {}; };   // (dvbs_*: the DVB-S front end's three stage streams)
     std::map<hipStream_t, FeAux> fe_aux;
     int fe_slices = 4;                        // DVBS2GPU_FE_SLICES (1 = both stages back to back on the caller's stream)
+    // balance of the two streams of the pipelined mode (s2_demod.hip): share of the timing loop's tiles that run one priority level up
+    int g_prio_duty = 0, g_prio_trend = 0;
+    bool g_prio_auto = true;                  // DVBS2GPU_G_PRIO_DUTY fixes the value
     int dvbs_fe_slices = 8;                   // DVBS2GPU_DVBS_FE_SLICES: time slices of a DVB-S call with few carriers (dvbs_demod.hip)
     // DVB-S front end (dvbs_demod.hip)
     float* d_fd_bank = nullptr;               // COMPLEX_FD interpolator bank, 256 x 256

@@ -337,6 +337,8 @@ struct PendingFec {
 static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work, int n, const S2LoopCoefs& co, hipStream_t st) {
     int nsub = ctx->fe_slices;
     if (nsub > S2_FE_MAX_SLICES) nsub = S2_FE_MAX_SLICES;
+    S2LoopCoefs cc = co;
+    cc.g_prio_duty = ctx->pipeline_fec ? ctx->g_prio_duty : 0;
     dvbs2gpu_ctx::FeAux* fa = nullptr;
     if (nsub > 1) {
         std::lock_guard<std::mutex> l(ctx->mtx);
@@ -348,7 +350,7 @@ static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work,
                 if ((e = hipEventCreateWithFlags(&fa->ev[i], hipEventDisableTiming)) != hipSuccess) return e;
         }
     }
-    return s2_frontend_launch(d_work, n, co, ctx->d_gardner_bank, st, fa ? fa->aux : nullptr, fa ? fa->ev : nullptr, nsub);
+    return s2_frontend_launch(d_work, n, cc, ctx->d_gardner_bank, st, fa ? fa->aux : nullptr, fa ? fa->ev : nullptr, nsub);
 }
 
 struct HostMarks {
@@ -366,6 +368,7 @@ struct HostMarks {
 int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts,
                   uint8_t* const* d_out, int out_cap, int* out_bytes, hipStream_t st, bool pipelined, int slot, const int* pre_nsym, bool own_ws, bool deliver_now) {
     HostMarks hm;
+    const auto t_entry = std::chrono::steady_clock::now();
     dvbs2gpu_demod* d0 = dm[0];
     Workspace* const W = own_ws ? ctx->ws_grp[slot] : ctx->ws_rx;      // per-call scratch: the group's own set when groups run side by side
     const hipEvent_t ev_llr = own_ws ? ctx->ev_llr_grp[slot] : ctx->ev_llr;
@@ -571,8 +574,24 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             last_error() = "pipelined mode needs the same streams in the same order on every call";
             return DVBS2GPU_ERR_ARG;
         }
+        const auto t_d0 = std::chrono::steady_clock::now();
         if ((rc = deliver(prev))) return rc;      // FEC of the previous call (ran during this call's front end)
         hm.mark("prev_delivered");
+        // Balance of the two streams: did this call have to wait for the previous call's FEC job (the decoder is the critical path: the timing
+        // loop should yield more) or was the job long done (the front end is: it should yield less)?  One step of the priority duty per two
+        // consistent calls; single-group batches only (the groups of a mixed batch share one front-end pass).
+        if (ctx->g_prio_auto && !own_ws && !pre_nsym) {
+            const auto t_d1 = std::chrono::steady_clock::now();
+            const double wait_ms = std::chrono::duration<double, std::milli>(t_d1 - t_d0).count();
+            const double call_ms = std::chrono::duration<double, std::milli>(t_d1 - t_entry).count();
+            const int verdict = wait_ms > 1.0 + 0.02 * call_ms ? -1 : (wait_ms < 0.5 ? +1 : 0);
+            if (verdict != 0 && verdict == ctx->g_prio_trend) {
+                ctx->g_prio_duty = std::min(7, std::max(0, ctx->g_prio_duty + verdict));
+                ctx->g_prio_trend = 0;
+            } else {
+                ctx->g_prio_trend = verdict;
+            }
+        }
     } else {
         for (int i = 0; i < n; ++i) dm[i]->stats.clear();
     }

@@ -40,6 +40,7 @@ struct S2LoopCoefs {
     float fll_bw;
     int rrc_taps;
     int soft_plsc, pilot_aided;      // extensions (include/dvbs2gpu.h), 0 = the reference's behaviour
+    int g_prio_duty;                 // scheduling only: of every 8 tiles of the timing loop, this many run one wave-priority level up (s2_demod.hip balances the two streams of the pipelined mode with it)
 };
 
 // per-call work description of one stream (array in device memory, one entry per stream of the batch)

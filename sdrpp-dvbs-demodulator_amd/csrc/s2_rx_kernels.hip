@@ -306,11 +306,10 @@ __global__ __launch_bounds__(64) void s2_gardner_kernel(const S2StreamWork* __re
     __syncthreads();
     __builtin_amdgcn_s_setprio(G_PRIO);       // latency-critical serial loop (see agc_pc_kernel)
     for (int base = 0; base < nmax; base += G_TILE) {
-#if G_PRIO_DUTY > 0
-        // G_PRIO_DUTY of every 8 tiles run one priority level up: the balance point between "this kernel yields to the decoder" (the front
-        // end becomes the critical path) and "it does not" (the decoder does) lies between two priority levels
-        if ((((unsigned)base / G_TILE) & 7u) < (unsigned)G_PRIO_DUTY) __builtin_amdgcn_s_setprio(G_PRIO + 1); else __builtin_amdgcn_s_setprio(G_PRIO);
-#endif
+        // co.g_prio_duty (+ the build's G_PRIO_DUTY) of every 8 tiles run one priority level up: the balance point between "this kernel yields to
+        // the decoder" (the front end becomes the critical path) and "it does not" (the decoder does) lies between two priority levels, and
+        // where it lies depends on the MODCOD -- the host moves it from call to call (s2_demod.hip)
+        if ((((unsigned)base / G_TILE) & 7u) < (unsigned)(co.g_prio_duty + G_PRIO_DUTY)) __builtin_amdgcn_s_setprio(G_PRIO + 1); else __builtin_amdgcn_s_setprio(G_PRIO);
         commit(base);
         __syncthreads();
         issue(base + G_TILE);
