@@ -513,23 +513,26 @@ __device__ __attribute__((noinline)) float soft_phase_err_group(lds_cf32* __rest
 #endif
 constexpr int FL_LPS = FL_LPS_N;
 constexpr int FL_SPW = 64 / FL_LPS;
-constexpr int FL_TILE = 44;          // PLL symbols staged per round (>= 36: the FED reuses the tile for a pilot block, and
-                                     // 44 complex = the 88 FED terms that alias the output tile); small: the
-                                     // workgroup has to fit into the LDS an LDPC workgroup leaves free (pipelined mode)
+constexpr int FL_TILE = 46;          // PLL symbols staged per round (>= 36: the FED reuses the tile for a pilot block; input + output
+                                     // tile together hold the 90 header symbols for the PLHDR loop and the 88 FED terms); small: THREE
+                                     // workgroups have to fit into the 24 KB of LDS an LDPC workgroup leaves free -- a mixed batch launches
+                                     // one kernel per configuration group, and with two 11.7 KB workgroups per CU plus a stray third the
+                                     // decoder workgroup of that CU could not start before the frame loops had finished (pipelined mode)
 
 __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* __restrict__ work, int nstreams,
                                                             const S2FrameRef* __restrict__ frames, const int* __restrict__ first,
                                                             S2LoopCoefs co, S2PlTablesDev T, S2ConstelDev C, int pls_code, int slots,
                                                             int pilots, int pilot_blocks, int plframe, cf32* __restrict__ pllout,
                                                             S2FrameStats* __restrict__ stats) {
-    __shared__ cf32 tile[FL_SPW][FL_TILE];      // (also holds a 36-symbol pilot block for the FED)
-    __shared__ cf32 otile[FL_SPW][FL_TILE];
+    static_assert(2 * FL_TILE >= 90 && 2 * FL_TILE >= 88 && FL_TILE >= 36, "input + output tile hold the 90 header symbols; the output tile alone the 88 FED terms");
+    __shared__ cf32 tiles[FL_SPW][2 * FL_TILE]; // per stream: [input tile | output tile]
     __shared__ uint8_t rnt[FL_TILE];
-    float (*fedt)[2 * FL_TILE] = reinterpret_cast<float (*)[2 * FL_TILE]>(otile);   // FED terms live in the (then unused) output tile
-    __shared__ cf32 hdr_sym[FL_SPW][90];
     __shared__ cf32 s_pts[32];                 // constellation points for the 32APSK phase-error search (the other constellations use the LUT)
     if (C.bits == 5 && threadIdx.x < 32) s_pts[threadIdx.x] = threadIdx.x < (unsigned)C.states ? C.pts_g[threadIdx.x] : cf32{0.f, 0.f};
     const int lane = threadIdx.x, g = lane / FL_LPS, gl = lane % FL_LPS;
+    cf32* const tl = &tiles[g][0];                      // input tile (also a 36-symbol pilot block for the FED; with the output tile: the 90 header symbols)
+    cf32* const ot = &tiles[g][FL_TILE];                // output tile
+    float* const fd = reinterpret_cast<float*>(ot);     // FED terms live in the (then unused) output tile
     const int s0 = blockIdx.x * FL_SPW, s = s0 + g;
     const bool act = s < nstreams;
     const int sc = act ? s : s0;
@@ -559,24 +562,22 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
         for (int i = gl; i < 88; i += FL_LPS) {
             cf32 r2 = (i + 2) < 26 ? T.sof[i + 2] : plsc[i + 2 - 26];
             cf32 r0 = i < 26 ? T.sof[i] : plsc[i - 26];
-            fedt[g][i] = cmul(cmul(cmul(fr[i + 2], cconj(r2)), cconj(fr[i])), r0).im;
+            fd[i] = cmul(cmul(cmul(fr[i + 2], cconj(r2)), cconj(fr[i])), r0).im;
         }
-        #pragma unroll 1
-        for (int i = gl; i < 90; i += FL_LPS) hdr_sym[g][i] = fr[i];
         __syncthreads();
         float err = 0.f, symcnt = 90 - 2;
-        for (int i = 0; i < 88; ++i) err += fedt[g][i];
+        for (int i = 0; i < 88; ++i) err += fd[i];
         if (pilots) {
             const cf32 p{0.707f, 0.707f};
             for (int b = 0; b < pilot_blocks; ++b) {
                 int start = pilot_start(b);
                 __syncthreads();
-                for (int i = gl; i < 36; i += FL_LPS) tile[g][i] = pl_descramble(fr[start + i], T.rn[start - 90 + i]);
+                for (int i = gl; i < 36; i += FL_LPS) tl[i] = pl_descramble(fr[start + i], T.rn[start - 90 + i]);
                 __syncthreads();
                 for (int i = gl; i < 36; i += FL_LPS)
-                    if (i >= 2) fedt[g][i] = cmul(cmul(cmul(tile[g][i], cconj(p)), cconj(tile[g][i - 2])), p).im;
+                    if (i >= 2) fd[i] = cmul(cmul(cmul(tl[i], cconj(p)), cconj(tl[i - 2])), p).im;
                 __syncthreads();
-                for (int i = 2; i < 36; ++i) err += fedt[g][i];
+                for (int i = 2; i < 36; ++i) err += fd[i];
                 symcnt += 36 - 2;
             }
         }
@@ -608,14 +609,14 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
 #pragma unroll
             for (int t = 0; t < NPF; ++t) {
                 const int i = gl + t * FL_LPS;
-                if (i < m) tile[g][i] = pf[t];
+                if (i < m) tl[i] = pf[t];
             }
             if (lane < m) rnt[lane] = (uint8_t)prn;
             __syncthreads();
             if (base + FL_TILE < plframe) fetch(base + FL_TILE);
             for (int k = 0; k < m; ++k) {
                 const int i = base + k;
-                cf32 tmp_val = cmul(tile[g][k], phasor_fast(-pll.phase));
+                cf32 tmp_val = cmul(tl[k], phasor_fast(-pll.phase));
                 float error = 0.f;
                 cf32 o;
                 bool block_end = false;
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
                     block_end = i == 89;
                     o = cf32{0.f, 0.f};   // header symbols come from the PLHDR demod below
                 }
-                if (gl == 0) otile[g][k] = o;
+                if (gl == 0) ot[k] = o;
                 pll.advance(error);
                 pll.wrap_pi_once();
                 if (co.pilot_aided && block_end) {
@@ -655,21 +656,25 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
             __syncthreads();
             if (fact)
                 for (int i = gl; i < m; i += FL_LPS)
-                    if (base + i >= 90) out[base + i] = otile[g][i];
+                    if (base + i >= 90) out[base + i] = ot[i];
         }
         // ---- PL header demod (dvbs2_plhdr_demod.cpp:33-67)
+        // (the 90 header symbols are staged now, over the input + output tiles the PLL loop is through with)
+        __syncthreads();
+        #pragma unroll 1
+        for (int i = gl; i < 90; i += FL_LPS) tl[i] = fr[i];
         unsigned long long plheader = 0;
         const cf32 rot{(float)0.70710678118654757, (float)-0.70710678118654746};   // (cos(-pi/4), sin(-pi/4)) in double, cast
         __syncthreads();
         for (int i = 0; i < 90; ++i) {
-            cf32 tmp_val = cmul(hdr_sym[g][i], phasor_fast(-hdr.phase));
+            cf32 tmp_val = cmul(tl[i], phasor_fast(-hdr.phase));
             float error = ((tmp_val.re > 0 ? 1.0f : -1.0f) * tmp_val.im) - ((tmp_val.im > 0 ? 1.0f : -1.0f) * tmp_val.re);
             cf32 o = (i & 1) ? cf32{-tmp_val.re, tmp_val.im} : cf32{tmp_val.im, tmp_val.re};
             if (gl == 0 && fact) out[i] = o;
             if (i >= 26) {
                 const float sv = cmul(o, rot).re;
                 plheader = plheader << 1 | (unsigned long long)(!(sv > 0));
-                if (co.soft_plsc && gl == 0) hdr_sym[g][i - 26].re = sv;      // (slot i - 26 < i has been consumed: reuse it for the soft value)
+                if (co.soft_plsc && gl == 0) tl[i - 26].re = sv;      // (slot i - 26 < i has been consumed: reuse it for the soft value)
             }
             hdr.advance(error);
             hdr.wrap_pi_once();
@@ -696,7 +701,7 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
             for (int c = gl; c < 128; c += FL_LPS) {
                 const unsigned long long code = T.plsc_code[c];
                 float mtr = 0.f;
-                for (int p = 0; p < 64; ++p) { const float sv = hdr_sym[g][p].re; mtr += ((code >> (63 - p)) & 1ull) ? -sv : sv; }
+                for (int p = 0; p < 64; ++p) { const float sv = tl[p].re; mtr += ((code >> (63 - p)) & 1ull) ? -sv : sv; }
                 if (bc == 0x7fffffff || mtr > bm) { bm = mtr; bc = c; }
             }
 #pragma unroll
