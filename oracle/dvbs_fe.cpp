@@ -6,7 +6,7 @@
 // /root/reference and the reference has no vectors for this path; the restatement follows the call sites above and the
 // definitions listed in SURVEY.md Appendix C.  Summation orders: the band-edge and RRC FIRs accumulate tap 0..n-1 in order (VOLK's
 // generic kernels); the three 256-tap interpolator dot products of COMPLEX_FD use 64 interleaved partial sums and a fixed
-// pairwise tree (fd_dot) -- VOLK picks a SIMD kernel at run time there, so the reference's own order is machine dependent.
+// tree (fd_dot: pairwise inside groups of 16, then the four group sums) -- VOLK picks a SIMD kernel at run time there, so the reference's own order is machine dependent.
 #include "dvbs_fe.h"
 #include <cmath>
 #include <cstring>
@@ -122,9 +122,13 @@ cf fd_dot(const cf* x, const float* t) {
         for (int q = 0; q < 4; ++q) { ar += x[l + 64 * q].re * t[l + 64 * q]; ai += x[l + 64 * q].im * t[l + 64 * q]; }
         pr[l] = ar; pi[l] = ai;
     }
-    for (int s = 32; s >= 1; s >>= 1)
-        for (int l = 0; l < s; ++l) { pr[l] = pr[l] + pr[l + s]; pi[l] = pi[l] + pi[l + s]; }
-    return cf{pr[0], pi[0]};
+    // fixed tree: inside each group of 16 partial sums pairwise at distance 8, 4, 2, 1, then (group 0 + group 1) + (group 2 + group 3)
+    // (on the GPU: four DPP row shifts and three additions of the row leaders -- no cross-row permute)
+    for (int r = 0; r < 4; ++r)
+        for (int s = 8; s >= 1; s >>= 1)
+            for (int l = 0; l < s; ++l) { pr[16 * r + l] = pr[16 * r + l] + pr[16 * r + l + s]; pi[16 * r + l] = pi[16 * r + l] + pi[16 * r + l + s]; }
+    const float r01 = pr[0] + pr[16], r23 = pr[32] + pr[48], i01 = pi[0] + pi[16], i23 = pi[32] + pi[48];
+    return cf{r01 + r23, i01 + i23};
 }
 
 int QpskAlt::complex_fd(int count, const cf* in, cf* out) {   // complex_fd.cpp:89-150

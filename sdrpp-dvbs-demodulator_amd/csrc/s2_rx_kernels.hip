@@ -1361,30 +1361,40 @@ __global__ __launch_bounds__(128) void dvbs_rrc_state_kernel(const DvbsStreamWor
     for (int i = threadIdx.x; i < H; i += 128) st->rrc_hist[i] = nh[i];
 }
 
-// 256-tap complex x real dot product over the wave: 4 taps per lane in order, then a fixed pairwise tree (lane l += lane l + s,
-// s = 32..1) -- the documented order of the engine for COMPLEX_FD (oracle/dvbs_fe.cpp fd_dot).  Result valid in lane 0 and
-// broadcast.  Levels 32 and 16 cross DPP rows (ds_bpermute), levels 8..1 are row shifts (v_add with a DPP operand).
+// 256-tap complex x real dot product over the wave: 4 taps per lane in order, then a fixed tree -- inside each row of 16 lanes pairwise at
+// distance 8, 4, 2, 1 (row shifts: v_add with a DPP operand), then (row 0 + row 1) + (row 2 + row 3) (two forms of those three additions, same bits) -- the documented order of the engine for COMPLEX_FD (oracle/dvbs_fe.cpp fd_dot).  (The first version put the distances 32
+// and 16 first: two dependent ds_bpermute round trips per sum, twelve LDS-crossbar instructions per symbol.)
+template <bool LAT>
 __device__ __forceinline__ float fd_tree(float a) {
-    a = a + __shfl_down(a, 32);
-    a = a + __shfl_down(a, 16);
-    a = a + DPP_F(a, 0x108);      // row_shl:8  -> lane l reads lane l + 8
+    a = a + DPP_F(a, 0x108);      // row_shl:8  -> lane l reads lane l + 8 of its row (zero beyond the row: only the row's lane 0 matters)
     a = a + DPP_F(a, 0x104);
     a = a + DPP_F(a, 0x102);
     a = a + DPP_F(a, 0x101);
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 0));
+    if constexpr (LAT) {
+        // few carriers (one wave alone on its SIMD: the chain's latency counts): the four row leaders by v_readlane, three scalar-operand adds
+        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 0));
+        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 16));
+        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 32));
+        const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 48));
+        return (r0 + r1) + (r2 + r3);
+    } else {
+        // a bank that fills the SIMDs (VALU issue counts): the same two additions through the LDS crossbar
+        a = a + __shfl_down(a, 16);       // lane 0: row 0 + row 1, lane 32: row 2 + row 3
+        a = a + __shfl_down(a, 32);       // lane 0: (row 0 + row 1) + (row 2 + row 3)
+        return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 0));
+    }
 }
+template <bool LAT>
 __device__ __forceinline__ cf32 fd_dot_wave(const cf32 (&x)[4], const float* t, int lane) {
     float ar = 0.f, ai = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const float tt = t[lane + 64 * q]; ar += x[q].re * tt; ai += x[q].im * tt; }
-    return cf32{fd_tree(ar), fd_tree(ai)};
+    return cf32{fd_tree<LAT>(ar), fd_tree<LAT>(ai)};
 }
-
-// ONE WAVE PER STREAM: clock_recovery::COMPLEX_FD::process (complex_fd.cpp:89-150, 256 phases x 256 taps, outSps = 1) followed by
-// loop::Costas<4> on every produced symbol (feed-forward after the timing loop).  The interpolator bank is 256 KB; the loop
 // phase moves slowly, so a window of FD_WROWS consecutive bank rows is kept in LDS and re-centred when the phase leaves it.
 constexpr int FD_TILE = 256;
 constexpr int FD_WROWS = 4;
+template <bool LAT>
 __global__ __launch_bounds__(64) void dvbs_fd_costas_kernel(const DvbsStreamWork* __restrict__ work, DvbsLoopCoefs co,
                                                             const float* __restrict__ bank, int sub, int nsub) {
     __shared__ cf32 win[FD_TILE + FD_TAPS];      // [255 history][tile]
@@ -1423,10 +1433,10 @@ __global__ __launch_bounds__(64) void dvbs_fd_costas_kernel(const DvbsStreamWork
             cf32 x[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) x[q] = win[(offset - base) + lane + 64 * q];
-            const cf32 outVal = fd_dot_wave(x, brow + (phase - wlo) * FD_TAPS, lane);
+            const cf32 outVal = fd_dot_wave<LAT>(x, brow + (phase - wlo) * FD_TAPS, lane);
             // derivative of the signal from the neighbouring phases (complex_fd.cpp:103-120)
-            const cf32 fT1 = fd_dot_wave(x, brow + (pp - wlo) * FD_TAPS, lane);
-            const cf32 fT_1 = fd_dot_wave(x, brow + (pm - wlo) * FD_TAPS, lane);
+            const cf32 fT1 = fd_dot_wave<LAT>(x, brow + (pp - wlo) * FD_TAPS, lane);
+            const cf32 fT_1 = fd_dot_wave<LAT>(x, brow + (pm - wlo) * FD_TAPS, lane);
             cf32 dfdt;
             if (phase == 0) dfdt = csub(fT1, outVal);
             else if (phase == FD_PHASES - 1) dfdt = csub(outVal, fT_1);
@@ -1567,7 +1577,8 @@ hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int 
         hipLaunchKernelGGL(dvbs_rrc_kernel, dim3(gx, nstreams), dim3(256), 0, s2, d_work, d_rrc, coefs.ntaps, c, nsub);
         hipLaunchKernelGGL(dvbs_rrc_state_kernel, dim3(nstreams), dim3(128), 0, s2, d_work, coefs.ntaps, c, nsub);
         if (sliced) { if ((e = hipEventRecord(ev[2][c], s2)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(st, ev[2][c], 0)) != hipSuccess) return e; }
-        hipLaunchKernelGGL(dvbs_fd_costas_kernel, dim3(nstreams), dim3(64), 0, st, d_work, coefs, d_fd_bank, c, nsub);
+        if (sliced) hipLaunchKernelGGL(dvbs_fd_costas_kernel<true>, dim3(nstreams), dim3(64), 0, st, d_work, coefs, d_fd_bank, c, nsub);
+        else hipLaunchKernelGGL(dvbs_fd_costas_kernel<false>, dim3(nstreams), dim3(64), 0, st, d_work, coefs, d_fd_bank, c, nsub);
     }
     int gs = (max_count + 255) / 256;
     gs = gs < 1 ? 1 : (gs > 64 ? 64 : gs);
