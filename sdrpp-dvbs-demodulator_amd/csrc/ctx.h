@@ -139,7 +139,7 @@ struct dvbs2gpu_ctx {
     hipEvent_t ev_llr_grp[MAX_PIPE_GROUPS] = {};
     std::mutex fec_mtx;                                   // FEC jobs are enqueued whole, one at a time (shared FEC workspaces, one stream)
     // time-sliced front end (s2_rx_kernels.hip, s2_frontend_launch): per main stream one auxiliary stream + the slice events
-    struct FeAux { hipStream_t aux = nullptr; hipEvent_t ev[9] = {}; hipStream_t dvbs_aux[3] = {}; hipEvent_t dvbs_ev[3][9] = {}; };   // (dvbs_*: the DVB-S front end's three stage streams)
+    struct FeAux { hipStream_t aux = nullptr; hipEvent_t ev[9] = {}; hipStream_t dvbs_aux[4] = {}; hipEvent_t dvbs_ev[4][9] = {}; };   // (dvbs_*: the DVB-S receiver's stage streams: AGC, FLL, RRC, soft FIFO + Viterbi)
     std::map<hipStream_t, FeAux> fe_aux;
     int fe_slices = 4;                        // DVBS2GPU_FE_SLICES (1 = both stages back to back on the caller's stream)
     // balance of the two streams of the pipelined mode (s2_demod.hip): share of the timing loop's tiles that run one priority level up

@@ -181,7 +181,7 @@ int dvbs2gpu_dvbs_demod_process_batch(dvbs2gpu_dvbs_demod* d, const float* const
     const int mb = d->max_blocks;
     Workspace& ws = ctx->ws_dvbs[0];
     const size_t off_ptr_in = sizeof(DvbsStreamWork) * n, off_ptr_out = off_ptr_in + sizeof(void*) * n, off_nblk = off_ptr_out + sizeof(void*) * n;
-    const size_t off_cnt = off_nblk + sizeof(int) * n, off_nbits = off_cnt + sizeof(int) * n, total = off_nbits + sizeof(int) * (size_t)n * mb;
+    const size_t off_cnt = off_nblk + sizeof(int) * n, off_blk0 = off_cnt + sizeof(int) * n, off_nbits = off_blk0 + sizeof(int) * n, total = off_nbits + sizeof(int) * (size_t)n * mb;
     int rc;
     if ((rc = ws.ensure(total + 64))) return rc;
     Workspace& wsb = ctx->ws_dvbs[1];
@@ -196,27 +196,48 @@ int dvbs2gpu_dvbs_demod_process_batch(dvbs2gpu_dvbs_demod* d, const float* const
     int* d_nblk = (int*)(base + off_nblk);
     int* d_cnt = (int*)(base + off_cnt);
     int* d_nbits = (int*)(base + off_nbits);
-    {
-        // few carriers: the four serial stages time-sliced over four streams (s2_rx_kernels.hip, dvbs_frontend_launch); a bank that fills
-        // the GPU runs them back to back
-        const int nsub = n <= DVBS_SLICE_MAX_STREAMS ? ctx->dvbs_fe_slices : 1;
-        dvbs2gpu_ctx::FeAux* fa = nullptr;
-        if (nsub > 1) {
-            std::lock_guard<std::mutex> l(ctx->mtx);
-            fa = &ctx->fe_aux[st];
-            if (!fa->dvbs_aux[0]) {
-                for (int a = 0; a < 3; ++a) {
-                    HIP_TRY(hipStreamCreateWithFlags(&fa->dvbs_aux[a], hipStreamNonBlocking));
-                    for (int i = 0; i < 9; ++i) HIP_TRY(hipEventCreateWithFlags(&fa->dvbs_ev[a][i], hipEventDisableTiming));
-                }
-            }
+    int* d_blk0 = (int*)(base + off_blk0);
+    // few carriers: the serial stages time-sliced over their own streams (s2_rx_kernels.hip, dvbs_frontend_launch): AGC, FLL, RRC, timing
+    // recovery + Costas, and -- behind every timing-recovery slice -- the slice's soft FIFO append and the Viterbi decoding of the blocks it
+    // completed; a bank that fills the GPU runs the stages back to back
+    const int nsub = n <= DVBS_SLICE_MAX_STREAMS ? ctx->dvbs_fe_slices : 1;
+    dvbs2gpu_ctx::FeAux* fa = nullptr;
+    if (nsub > 1) {
+        std::lock_guard<std::mutex> l(ctx->mtx);
+        fa = &ctx->fe_aux[st];
+        if (!fa->dvbs_aux[0]) {
+            for (int a = 0; a < 2; ++a) HIP_TRY(hipStreamCreateWithFlags(&fa->dvbs_aux[a], hipStreamNonBlocking));
+            for (int a = 0; a < 4; ++a)
+                for (int i = 0; i < 9; ++i) HIP_TRY(hipEventCreateWithFlags(&fa->dvbs_ev[a][i], hipEventDisableTiming));
         }
-        HIP_TRY(dvbs_frontend_launch(d_work, n, max_count, d->co, d->d_bandedge, d->d_rrc, ctx->d_fd_bank, st, fa ? fa->dvbs_aux : nullptr,
-                                     fa ? fa->dvbs_ev : nullptr, nsub));
     }
-    HIP_TRY(dvbs_soft_count_launch(d_work, n, d_nblk, st));
-    HIP_TRY(dvbs_viterbi_launch(nullptr, (const int8_t* const*)(base + off_ptr_in), d_nblk, n, mb, (uint8_t*)wsb.p, d_nbits, nullptr, d->d_vstate,
-                                d->d_vws, d->cfg.viterbi_ber_threshold, d->cfg.viterbi_max_outsync, st));
+    struct Hook : DvbsSliceHook {
+        dvbs2gpu_dvbs_demod* d; dvbs2gpu_ctx::FeAux* fa; const DvbsStreamWork* d_work; const int8_t* const* d_in_ptrs; int n, max_count, nsub, mb;
+        int* d_blk0; int* d_nblk; int* d_nbits; uint8_t* d_bits; hipStream_t st;
+        hipError_t after_timing(int c) override {
+            hipStream_t sv = fa->dvbs_aux[0];        // behind the AGC slices, which were all enqueued before the first timing-recovery slice
+            hipError_t e;
+            if ((e = hipEventRecord(fa->dvbs_ev[3][c], st)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(sv, fa->dvbs_ev[3][c], 0)) != hipSuccess) return e;
+            if ((e = dvbs_soft_slice_launch(d_work, n, max_count, c, nsub, d_blk0, d_nblk, sv)) != hipSuccess) return e;
+            return dvbs_viterbi_launch(nullptr, d_in_ptrs, d_nblk, n, mb, d_bits, d_nbits, nullptr, d->d_vstate, d->d_vws, d->cfg.viterbi_ber_threshold,
+                                       d->cfg.viterbi_max_outsync, sv, d_blk0);
+        }
+    } hook;
+    hook.d = d; hook.fa = fa; hook.d_work = d_work; hook.d_in_ptrs = (const int8_t* const*)(base + off_ptr_in); hook.n = n; hook.max_count = max_count;
+    hook.nsub = nsub; hook.mb = mb; hook.d_blk0 = d_blk0; hook.d_nblk = d_nblk; hook.d_nbits = d_nbits; hook.d_bits = (uint8_t*)wsb.p; hook.st = st;
+    HIP_TRY(dvbs_frontend_launch(d_work, n, max_count, d->co, d->d_bandedge, d->d_rrc, ctx->d_fd_bank, st, fa ? fa->dvbs_aux : nullptr,
+                                 fa ? fa->dvbs_ev : nullptr, nsub, fa ? &hook : nullptr));
+    if (fa) {
+        // the last slice's decoder run ends the Viterbi stream's work for this call
+        HIP_TRY(hipEventRecord(fa->dvbs_ev[3][8], fa->dvbs_aux[0]));
+        HIP_TRY(hipStreamWaitEvent(st, fa->dvbs_ev[3][8], 0));
+        HIP_TRY(dvbs_soft_count_launch(d_work, n, d_nblk, st));          // (FIFO fill and block count of the whole call, for the packing and the compaction)
+    } else {
+        HIP_TRY(dvbs_soft_count_launch(d_work, n, d_nblk, st));
+        HIP_TRY(dvbs_viterbi_launch(nullptr, (const int8_t* const*)(base + off_ptr_in), d_nblk, n, mb, (uint8_t*)wsb.p, d_nbits, nullptr, d->d_vstate,
+                                    d->d_vws, d->cfg.viterbi_ber_threshold, d->cfg.viterbi_max_outsync, st));
+    }
     HIP_TRY(dvbs_pack_bits_launch((const uint8_t*)wsb.p, d_nbits, d_nblk, n, mb, (uint8_t* const*)(base + off_ptr_out), cap, d_cnt, st));
     HIP_TRY(dvbs_soft_compact_launch(d_work, n, st));
     HIP_TRY(hipMemcpyAsync(out_counts, d_cnt, sizeof(int) * n, hipMemcpyDeviceToHost, st));

@@ -257,7 +257,7 @@ hipError_t dvbs_depunc_stage_launch(int period, int mode, const uint8_t* d_in, i
 // in_all + s*nblocks*8192 and runs `nblocks` blocks.  Outputs are always laid out [stream][nblocks][...].
 __global__ __launch_bounds__(64) void dvbs_viterbi_kernel(const int8_t* in_all, const int8_t* const* in_ptrs, const int* nblk, int nblocks,
                                                           uint8_t* out_all, int* out_n, DvbsVitStats* stats,
-                                                          DvbsVitState* states, uint8_t* ws, float thr, int max_outsync) {
+                                                          DvbsVitState* states, uint8_t* ws, float thr, int max_outsync, const int* blk0) {
     const int lane = threadIdx.x, s = blockIdx.x;
     DvbsVitState* sp = states + s;
     uint8_t* w = ws + (size_t)s * DVBS_VIT_WS_BYTES;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(64) void dvbs_viterbi_kernel(const int8_t* in_all, 
     const int TEST = 2048, BUF = 8192;
     const int8_t* in_base = in_ptrs ? in_ptrs[s] : in_all + (size_t)s * nblocks * BUF;
     const int my_blocks = nblk ? min(nblk[s], nblocks) : nblocks;
-    for (int blk = 0; blk < my_blocks; ++blk) {
+    for (int blk = blk0 ? blk0[s] : 0; blk < my_blocks; ++blk) {       // (blk0: blocks an earlier time slice of the call has decoded)
         const int8_t* in = in_base + (size_t)blk * BUF;
         uint8_t* out = out_all + ((size_t)s * nblocks + blk) * BUF;
         if (state == 0) {                                     // ST_IDLE: viterbi_all.cpp:76-204
@@ -450,9 +450,9 @@ hipError_t dvbs_cc_decode_launch(const uint8_t* d_in, long stream_stride, int bl
 }
 hipError_t dvbs_viterbi_launch(const int8_t* d_soft, const int8_t* const* d_soft_ptrs, const int* d_nblk, int nstreams, int nblocks,
                                uint8_t* d_bits, int* d_nbits, DvbsVitStats* d_stats, DvbsVitState* d_states, uint8_t* d_ws, float thr,
-                               int max_outsync, hipStream_t st) {
+                               int max_outsync, hipStream_t st, const int* d_blk0) {
     hipLaunchKernelGGL(dvbs_viterbi_kernel, dim3(nstreams), dim3(64), 0, st, d_soft, d_soft_ptrs, d_nblk, nblocks, d_bits, d_nbits, d_stats,
-                       d_states, d_ws, thr, max_outsync);
+                       d_states, d_ws, thr, max_outsync, d_blk0);
     return hipGetLastError();
 }
 hipError_t dvbs_deinterleave_launch(const uint8_t* d_in, long stream_stride, int nstreams, int nbytes, uint8_t* d_out, uint8_t* d_hist,

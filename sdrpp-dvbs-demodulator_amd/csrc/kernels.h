@@ -71,7 +71,7 @@ hipError_t dvbs_cc_decode_launch(const uint8_t* d_in, long stream_stride, int bl
                                  uint8_t* d_out, long out_stream_stride, unsigned long long* d_dec_ws, int* d_state, hipStream_t st);
 hipError_t dvbs_viterbi_launch(const int8_t* d_soft, const int8_t* const* d_soft_ptrs, const int* d_nblk, int nstreams, int nblocks,
                                uint8_t* d_bits, int* d_nbits, DvbsVitStats* d_stats, DvbsVitState* d_states, uint8_t* d_ws, float thr,
-                               int max_outsync, hipStream_t st);
+                               int max_outsync, hipStream_t st, const int* d_blk0 = nullptr);
 struct DvbsTailState {     // per stream: energy-dispersal phase + the RS wrapper's last decoded message (dvbs_kernels.hip)
     int prbs_pos;
     int pad;

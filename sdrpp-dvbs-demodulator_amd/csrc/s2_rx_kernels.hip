@@ -1476,19 +1476,32 @@ __global__ __launch_bounds__(64) void dvbs_fd_costas_kernel(const DvbsStreamWork
         st->fd_phase = pcl.phase; st->fd_freq = pcl.freq; st->fd_offset = offset - n; st->fd_spsctr = spsctr;
         st->costas_phase = cos.phase; st->costas_freq = cos.freq;
         st->n_sym = outCount;
+        st->n_sym_slice[sub] = outCount;
     }
 }
 
 // DVBSymToSoftBlock: symbols -> int8 soft pairs appended to the stream's block FIFO; grid (x: tiles, y: stream)
-__global__ __launch_bounds__(256) void dvbs_soft_fifo_kernel(const DvbsStreamWork* __restrict__ work) {
+// sub / nsub: the symbols the timing recovery's slice `sub` produced (nsub == 1: the whole call)
+__global__ __launch_bounds__(256) void dvbs_soft_fifo_kernel(const DvbsStreamWork* __restrict__ work, int sub, int nsub) {
     const DvbsStreamWork w = work[blockIdx.y];
     const DvbsStreamState* st = w.st;
-    const int ns = st->n_sym, fill = st->soft_fill;
+    const int first = (nsub > 1 && sub) ? st->n_sym_slice[sub - 1] : 0, ns = nsub > 1 ? st->n_sym_slice[sub] : st->n_sym, fill = st->soft_fill;
     const float* __restrict__ sy = reinterpret_cast<const float*>(w.sym);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * ns; i += gridDim.x * 256) {
+    for (int i = 2 * first + blockIdx.x * 256 + threadIdx.x; i < 2 * ns; i += gridDim.x * 256) {
         const float x = sy[i] * 100;
         w.soft[fill + i] = x < -127.0f ? (int8_t)-127 : (x > 127.0f ? (int8_t)127 : (int8_t)x);
     }
+}
+// whole blocks in the FIFO after slice `sub`, and the first one no earlier slice has decoded (the Viterbi launch of the slice takes [blk0, nblk))
+__global__ __launch_bounds__(64) void dvbs_soft_avail_kernel(const DvbsStreamWork* __restrict__ work, int nstreams, int sub, int* __restrict__ blk0,
+                                                            int* __restrict__ nblk) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= nstreams) return;
+    DvbsStreamState* st = work[s].st;
+    const int avail = (st->soft_fill + 2 * st->n_sym_slice[sub]) / DVBS_SOFT_BLOCK;
+    blk0[s] = sub ? st->vit_done : 0;
+    nblk[s] = avail;
+    st->vit_done = avail;
 }
 __global__ __launch_bounds__(64) void dvbs_soft_count_kernel(const DvbsStreamWork* __restrict__ work, int nstreams, int* __restrict__ nblocks_out) {
     const int s = blockIdx.x * 64 + threadIdx.x;
@@ -1551,38 +1564,51 @@ hipError_t s2_fifo_compact_launch(const S2StreamWork* d_work, int nstreams, cons
     hipLaunchKernelGGL(s2_fifo_compact_kernel, dim3(16, nstreams), dim3(256), 0, st, d_work, d_cur_fill);
     return hipGetLastError();
 }
-// The serial stages of the DVB-S front end -- AGC (lane = stream), band-edge FLL, RRC, timing recovery + Costas (a wave per stream each) --
-// keep their state in the stream record, so a call's samples can go through in `nsub` time slices with the four stages on four streams
-// (aux[0..2] + st, events between them): slice c of a stage runs beside slice c+1 of the stage before it, and ONE carrier costs the
-// slowest stage instead of the sum (single carrier: 121 -> ~65 ms per 131 k samples).  A bank that fills the GPU anyway (nsub = 1) runs
-// the stages back to back on `st`.  ev: 3 rows of nsub + 1 events.
+// The serial stages of the DVB-S receiver -- AGC (lane = stream), band-edge FLL, RRC, timing recovery + Costas (a wave per stream each), and the
+// Viterbi decoder behind them -- keep their state in the stream record, so a call's samples can go through in `nsub` time slices with the stages
+// on three streams: aux[0] runs the AGC slices ahead and later the soft FIFO + Viterbi slices (the hook), aux[1] the FLL and RRC slices, `st`
+// the timing recovery; events between them.  Slice c of a stage runs beside slice c+1 of the stage before it, and ONE carrier costs the slowest
+// stage instead of the sum (116 -> 53 ms per 131 k samples).  Three streams + the caller's: HIP's default of 4 hardware queues is enough.  A
+// bank that fills the GPU anyway (nsub = 1) runs the stages back to back on `st`.  ev: 4 rows of nsub + 1 events.
 hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int max_count, DvbsLoopCoefs coefs, const cf32* d_bandedge,
-                                const float* d_rrc, const float* d_fd_bank, hipStream_t st, hipStream_t* aux, hipEvent_t (*ev)[9], int nsub) {
+                                const float* d_rrc, const float* d_fd_bank, hipStream_t st, hipStream_t* aux, hipEvent_t (*ev)[9], int nsub, DvbsSliceHook* hook) {
     const dim3 ga((nstreams + 63) / 64);
     const bool sliced = nsub > 1 && aux && ev;
     if (!sliced) nsub = 1;
     int gx = (max_count / nsub + 1 + 255) / 256;
     gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
     hipError_t e;
-    hipStream_t s0 = sliced ? aux[0] : st, s1 = sliced ? aux[1] : st, s2 = sliced ? aux[2] : st;
+    hipStream_t s0 = sliced ? aux[0] : st, s1 = sliced ? aux[1] : st;
     if (sliced) {
         if ((e = hipEventRecord(ev[0][nsub], st)) != hipSuccess) return e;          // the slices start behind what `st` holds now
         if ((e = hipStreamWaitEvent(s0, ev[0][nsub], 0)) != hipSuccess) return e;
     }
-    for (int c = 0; c < nsub; ++c) {
+    for (int c = 0; c < nsub; ++c) {                                                 // the AGC runs ahead (cheapest stage)
         hipLaunchKernelGGL(agc_pc_kernel<AgcDvbsTraits>, ga, dim3(128), 0, s0, d_work, nstreams, coefs, c, nsub);
-        if (sliced) { if ((e = hipEventRecord(ev[0][c], s0)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(s1, ev[0][c], 0)) != hipSuccess) return e; }
+        if (sliced && (e = hipEventRecord(ev[0][c], s0)) != hipSuccess) return e;
+    }
+    for (int c = 0; c < nsub; ++c) {
+        if (sliced && (e = hipStreamWaitEvent(s1, ev[0][c], 0)) != hipSuccess) return e;
         hipLaunchKernelGGL(dvbs_fll_kernel, dim3(nstreams), dim3(64), 0, s1, d_work, coefs, d_bandedge, c, nsub);
-        if (sliced) { if ((e = hipEventRecord(ev[1][c], s1)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(s2, ev[1][c], 0)) != hipSuccess) return e; }
-        hipLaunchKernelGGL(dvbs_rrc_kernel, dim3(gx, nstreams), dim3(256), 0, s2, d_work, d_rrc, coefs.ntaps, c, nsub);
-        hipLaunchKernelGGL(dvbs_rrc_state_kernel, dim3(nstreams), dim3(128), 0, s2, d_work, coefs.ntaps, c, nsub);
-        if (sliced) { if ((e = hipEventRecord(ev[2][c], s2)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(st, ev[2][c], 0)) != hipSuccess) return e; }
+        hipLaunchKernelGGL(dvbs_rrc_kernel, dim3(gx, nstreams), dim3(256), 0, s1, d_work, d_rrc, coefs.ntaps, c, nsub);
+        hipLaunchKernelGGL(dvbs_rrc_state_kernel, dim3(nstreams), dim3(128), 0, s1, d_work, coefs.ntaps, c, nsub);
+        if (sliced) { if ((e = hipEventRecord(ev[2][c], s1)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(st, ev[2][c], 0)) != hipSuccess) return e; }
         if (sliced) hipLaunchKernelGGL(dvbs_fd_costas_kernel<true>, dim3(nstreams), dim3(64), 0, st, d_work, coefs, d_fd_bank, c, nsub);
         else hipLaunchKernelGGL(dvbs_fd_costas_kernel<false>, dim3(nstreams), dim3(64), 0, st, d_work, coefs, d_fd_bank, c, nsub);
+        if (sliced && hook && (e = hook->after_timing(c)) != hipSuccess) return e;       // (soft FIFO + Viterbi of the slice, on aux[0])
     }
-    int gs = (max_count + 255) / 256;
+    if (!(sliced && hook)) {
+        int gs = (max_count + 255) / 256;
+        gs = gs < 1 ? 1 : (gs > 64 ? 64 : gs);
+        hipLaunchKernelGGL(dvbs_soft_fifo_kernel, dim3(gs, nstreams), dim3(256), 0, st, d_work, 0, 1);
+    }
+    return hipGetLastError();
+}
+hipError_t dvbs_soft_slice_launch(const DvbsStreamWork* d_work, int nstreams, int max_count, int sub, int nsub, int* d_blk0, int* d_nblk, hipStream_t st) {
+    int gs = (max_count / nsub + 1 + 255) / 256;
     gs = gs < 1 ? 1 : (gs > 64 ? 64 : gs);
-    hipLaunchKernelGGL(dvbs_soft_fifo_kernel, dim3(gs, nstreams), dim3(256), 0, st, d_work);
+    hipLaunchKernelGGL(dvbs_soft_fifo_kernel, dim3(gs, nstreams), dim3(256), 0, st, d_work, sub, nsub);
+    hipLaunchKernelGGL(dvbs_soft_avail_kernel, dim3((nstreams + 63) / 64), dim3(64), 0, st, d_work, nstreams, sub, d_blk0, d_nblk);
     return hipGetLastError();
 }
 hipError_t dvbs_soft_count_launch(const DvbsStreamWork* d_work, int nstreams, int* d_nblocks, hipStream_t st) {
