@@ -139,13 +139,13 @@ struct dvbs2gpu_ctx {
     hipEvent_t ev_llr_grp[MAX_PIPE_GROUPS] = {};
     std::mutex fec_mtx;                                   // FEC jobs are enqueued whole, one at a time (shared FEC workspaces, one stream)
     // time-sliced front end (s2_rx_kernels.hip, s2_frontend_launch): per main stream one auxiliary stream + the slice events
-    struct FeAux { hipStream_t aux = nullptr; hipEvent_t ev[9] = {}; hipStream_t dvbs_aux[4] = {}; hipEvent_t dvbs_ev[4][9] = {}; };   // (dvbs_*: the DVB-S receiver's stage streams: AGC, FLL, RRC, soft FIFO + Viterbi)
+    struct FeAux { hipStream_t aux = nullptr; hipEvent_t ev[9] = {}; hipStream_t dvbs_aux[4] = {}; hipEvent_t dvbs_ev[4][s2::DVBS_FE_MAX_SLICES + 1] = {}; };   // (dvbs_*: the DVB-S receiver's stage streams: AGC, FLL, RRC, soft FIFO + Viterbi)
     std::map<hipStream_t, FeAux> fe_aux;
     int fe_slices = 4;                        // DVBS2GPU_FE_SLICES (1 = both stages back to back on the caller's stream)
     // balance of the two streams of the pipelined mode (s2_demod.hip): share of the timing loop's tiles that run one priority level up
     int g_prio_duty = 0, g_prio_trend = 0;
     bool g_prio_auto = true;                  // DVBS2GPU_G_PRIO_DUTY fixes the value
-    int dvbs_fe_slices = 8;                   // DVBS2GPU_DVBS_FE_SLICES: time slices of a DVB-S call with few carriers (dvbs_demod.hip)
+    int dvbs_fe_slices = 24;                 // DVBS2GPU_DVBS_FE_SLICES: time slices of a DVB-S call with few carriers (dvbs_demod.hip)
     // DVB-S front end (dvbs_demod.hip)
     float* d_fd_bank = nullptr;               // COMPLEX_FD interpolator bank, 256 x 256
     std::map<int, s2::cf32*> bandedge;        // FLL band-edge taps [2][ntaps] by ntaps*100000 + round(alpha*1000)*10 + sps

@@ -208,7 +208,7 @@ int dvbs2gpu_dvbs_demod_process_batch(dvbs2gpu_dvbs_demod* d, const float* const
         if (!fa->dvbs_aux[0]) {
             for (int a = 0; a < 2; ++a) HIP_TRY(hipStreamCreateWithFlags(&fa->dvbs_aux[a], hipStreamNonBlocking));
             for (int a = 0; a < 4; ++a)
-                for (int i = 0; i < 9; ++i) HIP_TRY(hipEventCreateWithFlags(&fa->dvbs_ev[a][i], hipEventDisableTiming));
+                for (int i = 0; i <= DVBS_FE_MAX_SLICES; ++i) HIP_TRY(hipEventCreateWithFlags(&fa->dvbs_ev[a][i], hipEventDisableTiming));
         }
     }
     struct Hook : DvbsSliceHook {
@@ -219,6 +219,9 @@ int dvbs2gpu_dvbs_demod_process_batch(dvbs2gpu_dvbs_demod* d, const float* const
             hipError_t e;
             if ((e = hipEventRecord(fa->dvbs_ev[3][c], st)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(sv, fa->dvbs_ev[3][c], 0)) != hipSuccess) return e;
+            // (alternating the Costas slices between `st` and `sv`, which carry about the same load without them, was slower: every hand-over
+            // between two streams costs tens of microseconds and ties the two chains together)
+            if ((e = dvbs_costas_launch(d_work, n, d->co, c, nsub, sv)) != hipSuccess) return e;
             if ((e = dvbs_soft_slice_launch(d_work, n, max_count, c, nsub, d_blk0, d_nblk, sv)) != hipSuccess) return e;
             return dvbs_viterbi_launch(nullptr, d_in_ptrs, d_nblk, n, mb, d_bits, d_nbits, nullptr, d->d_vstate, d->d_vws, d->cfg.viterbi_ber_threshold,
                                        d->cfg.viterbi_max_outsync, sv, d_blk0);
@@ -230,8 +233,8 @@ int dvbs2gpu_dvbs_demod_process_batch(dvbs2gpu_dvbs_demod* d, const float* const
                                  fa ? fa->dvbs_ev : nullptr, nsub, fa ? &hook : nullptr));
     if (fa) {
         // the last slice's decoder run ends the Viterbi stream's work for this call
-        HIP_TRY(hipEventRecord(fa->dvbs_ev[3][8], fa->dvbs_aux[0]));
-        HIP_TRY(hipStreamWaitEvent(st, fa->dvbs_ev[3][8], 0));
+        HIP_TRY(hipEventRecord(fa->dvbs_ev[3][DVBS_FE_MAX_SLICES], fa->dvbs_aux[0]));
+        HIP_TRY(hipStreamWaitEvent(st, fa->dvbs_ev[3][DVBS_FE_MAX_SLICES], 0));
         HIP_TRY(dvbs_soft_count_launch(d_work, n, d_nblk, st));          // (FIFO fill and block count of the whole call, for the packing and the compaction)
     } else {
         HIP_TRY(dvbs_soft_count_launch(d_work, n, d_nblk, st));

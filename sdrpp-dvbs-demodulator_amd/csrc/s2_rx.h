@@ -130,7 +130,7 @@ struct DvbsStreamState {
     int n_sym;          // symbols produced by the last call
     int soft_fill;      // soft bits waiting in the block FIFO (after the last call: < 8192)
     int n_blocks;       // whole 8192-soft blocks handed to the Viterbi decoder in the last call
-    int n_sym_slice[8]; // symbols of the call after each time slice (dvbs_frontend_launch); the soft-FIFO / Viterbi slices read these
+    int n_sym_slice[32]; // symbols of the call after each time slice (dvbs_frontend_launch); the soft-FIFO / Viterbi slices read these
     int vit_done;       // blocks of the call already decoded by earlier slices
 };
 struct DvbsLoopCoefs {
@@ -150,10 +150,12 @@ struct DvbsStreamWork {
     DvbsStreamState* st;
 };
 // AGC -> FLL -> RRC -> COMPLEX_FD + Costas -> soft slicer into the per-stream block FIFO
+constexpr int DVBS_FE_MAX_SLICES = 32;      // (n_sym_slice[] of the stream state, the event rows of the stage streams)
 struct DvbsSliceHook { virtual hipError_t after_timing(int slice) = 0; virtual ~DvbsSliceHook() {} };   // called after the timing-recovery launch of every slice
 hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int max_count, DvbsLoopCoefs coefs, const cf32* d_bandedge,
-                                const float* d_rrc, const float* d_fd_bank, hipStream_t st, hipStream_t* aux = nullptr, hipEvent_t (*ev)[9] = nullptr, int nsub = 1,
+                                const float* d_rrc, const float* d_fd_bank, hipStream_t st, hipStream_t* aux = nullptr, hipEvent_t (*ev)[DVBS_FE_MAX_SLICES + 1] = nullptr, int nsub = 1,
                                 DvbsSliceHook* hook = nullptr);
+hipError_t dvbs_costas_launch(const DvbsStreamWork* d_work, int nstreams, DvbsLoopCoefs coefs, int sub, int nsub, hipStream_t st);
 hipError_t dvbs_soft_slice_launch(const DvbsStreamWork* d_work, int nstreams, int max_count, int sub, int nsub, int* d_blk0, int* d_nblk, hipStream_t st);
 
 hipError_t dvbs_soft_count_launch(const DvbsStreamWork* d_work, int nstreams, int* d_nblocks, hipStream_t st);

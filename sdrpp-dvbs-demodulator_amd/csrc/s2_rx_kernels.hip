@@ -55,11 +55,15 @@ __device__ __forceinline__ float fsel(bool c, float a, float b) {
     return __builtin_bit_cast(float, (__builtin_bit_cast(int, a) & m) | (__builtin_bit_cast(int, b) & ~m));
 }
 
+// x > hi ? hi : (x < lo ? lo : x) as ONE v_med3_f32 (the compare-select form costs a compare, a wait state and a select per bound in
+// loops whose speed is their instruction count).  Same value for every x that is not a NaN (lo < hi, neither of them a zero: the
+// hardware orders -0 < +0); a NaN -- which the reference would carry in its loop state for ever -- comes out as a bound instead.
+__device__ __forceinline__ float clamp_med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 struct PclDev {
     float alpha, beta, phase, freq, minFreq, maxFreq;
     __device__ __forceinline__ void advance(float err) {
         freq += beta * err;
-        freq = freq > maxFreq ? maxFreq : (freq < minFreq ? minFreq : freq);
+        freq = clamp_med3(freq, minFreq, maxFreq);
         phase += freq + alpha * err;
     }
     // the same for a phase that moved by less than 2 pi since it was last wrapped (every per-symbol advance of the PLL, PLHDR and
@@ -341,8 +345,7 @@ __global__ __launch_bounds__(64) void s2_gardner_kernel(const S2StreamWork* __re
                 const float eh = DPP_F(eq, 0x114);                           // row_shr:4: r = 4..7 <- r = 0..3
                 float error = spsctr == 0 ? (r < 4 ? eq : eh) : 0.f;
                 spsctr = spsctr >= 1 ? 0 : spsctr + 1;
-                error = error > 1.0f ? 1.0f : error;
-                error = error < -1.0f ? -1.0f : error;
+                error = clamp_med3(error, -1.0f, 1.0f);
                 pcl.advance(error);
                 const float delta = floorf(pcl.phase);
                 offset = (int)((float)offset + delta);
@@ -1294,7 +1297,7 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
             const float err = fast_amplitude(hi) - fast_amplitude(lo);
             // PhaseControlLoop::advance with alpha = 0 (fll.cpp:26)
             freq += co.fll_beta * err;
-            freq = freq > co.fll_max_freq ? co.fll_max_freq : (freq < co.fll_min_freq ? co.fll_min_freq : freq);
+            freq = clamp_med3(freq, co.fll_min_freq, co.fll_max_freq);
             phase += freq;
             pcl_wrap_pi(phase);
             if (lane == 0) xtile[k] = x;
@@ -1361,45 +1364,70 @@ __global__ __launch_bounds__(128) void dvbs_rrc_state_kernel(const DvbsStreamWor
     for (int i = threadIdx.x; i < H; i += 128) st->rrc_hist[i] = nh[i];
 }
 
-// 256-tap complex x real dot product over the wave: 4 taps per lane in order, then a fixed tree -- inside each row of 16 lanes pairwise at
-// distance 8, 4, 2, 1 (row shifts: v_add with a DPP operand), then (row 0 + row 1) + (row 2 + row 3) (two forms of those three additions, same bits) -- the documented order of the engine for COMPLEX_FD (oracle/dvbs_fe.cpp fd_dot).  (The first version put the distances 32
-// and 16 first: two dependent ds_bpermute round trips per sum, twelve LDS-crossbar instructions per symbol.)
-template <bool LAT>
-__device__ __forceinline__ float fd_tree(float a) {
-    a = a + DPP_F(a, 0x108);      // row_shl:8  -> lane l reads lane l + 8 of its row (zero beyond the row: only the row's lane 0 matters)
-    a = a + DPP_F(a, 0x104);
-    a = a + DPP_F(a, 0x102);
-    a = a + DPP_F(a, 0x101);
-    if constexpr (LAT) {
-        // few carriers (one wave alone on its SIMD: the chain's latency counts): the four row leaders by v_readlane, three scalar-operand adds
-        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 0));
-        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 16));
-        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 32));
-        const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 48));
-        return (r0 + r1) + (r2 + r3);
-    } else {
-        // a bank that fills the SIMDs (VALU issue counts): the same two additions through the LDS crossbar
-        a = a + __shfl_down(a, 16);       // lane 0: row 0 + row 1, lane 32: row 2 + row 3
-        a = a + __shfl_down(a, 32);       // lane 0: (row 0 + row 1) + (row 2 + row 3)
-        return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 0));
-    }
+// Three 256-tap complex x real dot products over the wave (the interpolated sample and its two neighbours in phase: the same 256
+// samples against three adjacent bank rows).  4 taps per lane in order, then the engine's documented tree for COMPLEX_FD
+// (oracle/dvbs_fe.cpp fd_dot): inside each row of 16 lanes pairwise at distance 8, 4, 2, 1, then (row 0 + row 1) + (row 2 + row 3).
+// The six sums (re / im of the three products) go through that tree TOGETHER: after the step at distance d only half of the lanes of a
+// sum still matter, so the other half carries another sum -- re in lanes 0..7 and im in lanes 8..15 of every row after distance 8, the
+// next product in the lanes with bit 2 set after distance 4, the third in the lanes with bit 1 set after distance 2: 17 DPP additions
+// and selects instead of 24 additions, and ONE register goes through the cross-row steps (gfx950's v_permlane16_swap / v_permlane32_swap:
+// no LDS crossbar, no v_readlane per row leader) instead of six.  Every pair of operands is the pair the plain tree adds, so the bits
+// are the plain tree's.  (First version: distances 32 and 16 first, twelve ds_bpermute per symbol; second: one tree per sum, four
+// v_readlane + three additions each, 63 instructions where this has 29.)
+typedef float fd_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float fd_rows_sum(float u) {
+    const int ui = __builtin_bit_cast(int, u);
+    const auto h = __builtin_amdgcn_permlane16_swap(ui, ui, false, false);      // {row 0, row 0, row 2, row 2}, {row 1, row 1, row 3, row 3}
+    const float s = __builtin_bit_cast(float, (int)h[0]) + __builtin_bit_cast(float, (int)h[1]);
+    const int si = __builtin_bit_cast(int, s);
+    const auto g = __builtin_amdgcn_permlane32_swap(si, si, false, false);      // {rows 0 + 1} x 4, {rows 2 + 3} x 4
+    return __builtin_bit_cast(float, (int)g[0]) + __builtin_bit_cast(float, (int)g[1]);
 }
-template <bool LAT>
-__device__ __forceinline__ cf32 fd_dot_wave(const cf32 (&x)[4], const float* t, int lane) {
-    float ar = 0.f, ai = 0.f;
+__device__ __forceinline__ void fd_dot3_wave(const cf32 (&x)[4], const float* t0, const float* tp, const float* tm, int lane,
+                                             cf32& o, cf32& p, cf32& m) {
+    fd_f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+    // (a row's taps lie lane-major in LDS: lane l finds its taps l, l + 64, l + 128, l + 192 side by side -- one ds_read_b128 per row)
+    const float4 v0 = *reinterpret_cast<const float4*>(t0 + 4 * lane), vp = *reinterpret_cast<const float4*>(tp + 4 * lane),
+                 vm = *reinterpret_cast<const float4*>(tm + 4 * lane);
+    const float c0[4] = {v0.x, v0.y, v0.z, v0.w}, cp[4] = {vp.x, vp.y, vp.z, vp.w}, cm[4] = {vm.x, vm.y, vm.z, vm.w};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const float tt = t[lane + 64 * q]; ar += x[q].re * tt; ai += x[q].im * tt; }
-    return cf32{fd_tree<LAT>(ar), fd_tree<LAT>(ai)};
+    for (int q = 0; q < 4; ++q) {
+        const fd_f2 xv = {x[q].re, x[q].im};
+        a0 = a0 + xv * c0[q];
+        a1 = a1 + xv * cp[q];
+        a2 = a2 + xv * cm[q];
+    }
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+    // (every DPP read is outside the selects: all lanes execute it)
+    // distance 8 (row_ror:8 pairs lane l with lane l ^ 8): re sums in lanes 0..7, im sums in lanes 8..15
+    const float x0 = a0.x + DPP_F(a0.x, 0x128), y0 = a0.y + DPP_F(a0.y, 0x128);
+    const float x1 = a1.x + DPP_F(a1.x, 0x128), y1 = a1.y + DPP_F(a1.y, 0x128);
+    const float x2 = a2.x + DPP_F(a2.x, 0x128), y2 = a2.y + DPP_F(a2.y, 0x128);
+    const float r0 = b3 ? y0 : x0, r1 = b3 ? y1 : x1, r2 = b3 ? y2 : x2;
+    // distance 4: o in the lanes with bit 2 clear (row_shl:4: lane l reads l + 4), p in those with bit 2 set (row_shr:4); m apart
+    const float s0 = r0 + DPP_F(r0, 0x104), s1 = r1 + DPP_F(r1, 0x114);
+    const float s = b2 ? s1 : s0;
+    const float t = r2 + DPP_F(r2, 0x104);
+    // distance 2: o / p in the lanes with bit 1 clear, m in those with bit 1 set; distance 1
+    const float u0 = s + DPP_F(s, 0x102), u1 = t + DPP_F(t, 0x112);
+    float u = b1 ? u1 : u0;
+    u = u + DPP_F(u, 0x101);
+    u = fd_rows_sum(u);
+    o.re = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u), 0));
+    o.im = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u), 8));
+    p.re = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u), 4));
+    p.im = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u), 12));
+    m.re = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u), 2));
+    m.im = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u), 10));
 }
 // phase moves slowly, so a window of FD_WROWS consecutive bank rows is kept in LDS and re-centred when the phase leaves it.
 constexpr int FD_TILE = 256;
 constexpr int FD_WROWS = 4;
-template <bool LAT>
-__global__ __launch_bounds__(64) void dvbs_fd_costas_kernel(const DvbsStreamWork* __restrict__ work, DvbsLoopCoefs co,
+__global__ __launch_bounds__(64) void dvbs_fd_kernel(const DvbsStreamWork* __restrict__ work, DvbsLoopCoefs co,
                                                             const float* __restrict__ bank, int sub, int nsub) {
     __shared__ cf32 win[FD_TILE + FD_TAPS];      // [255 history][tile]
     __shared__ cf32 ostage[FD_TILE / 2 + 72];
-    __shared__ float brow[FD_WROWS * FD_TAPS];   // bank rows [wlo, wlo + FD_WROWS)
+    __shared__ __attribute__((aligned(16))) float brow[FD_WROWS * FD_TAPS];   // bank rows [wlo, wlo + FD_WROWS), each lane-major: [lane][tap lane + 64 q]
     const int lane = threadIdx.x;
     DvbsStreamWork w = work[blockIdx.x];
     DvbsStreamState* st = w.st;
@@ -1408,7 +1436,6 @@ __global__ __launch_bounds__(64) void dvbs_fd_costas_kernel(const DvbsStreamWork
     w.buf_a += lo;
     const int n = hi - lo;
     PclDev pcl{co.fd_alpha, co.fd_beta, st->fd_phase, st->fd_freq, co.fd_min_freq, co.fd_max_freq};
-    PclDev cos{co.cos_alpha, co.cos_beta, st->costas_phase, st->costas_freq, co.cos_min_freq, co.cos_max_freq};
     int offset = st->fd_offset, spsctr = st->fd_spsctr, outCount = sub ? st->n_sym : 0;   // (later slices append to the call's symbols)
     int wlo = -1000;                             // no window yet
     for (int i = lane; i < FD_TAPS - 1; i += 64) win[i] = st->fd_hist[i];
@@ -1427,16 +1454,15 @@ __global__ __launch_bounds__(64) void dvbs_fd_costas_kernel(const DvbsStreamWork
                 wlo = phase - FD_WROWS / 2;
                 wlo = wlo < 0 ? 0 : (wlo > FD_PHASES - FD_WROWS ? FD_PHASES - FD_WROWS : wlo);
                 __syncthreads();
-                for (int i = lane; i < FD_WROWS * FD_TAPS; i += 64) brow[i] = bank[(size_t)wlo * FD_TAPS + i];
+                for (int i = lane; i < FD_WROWS * FD_TAPS; i += 64) brow[(i & ~255) + 4 * lane + ((i >> 6) & 3)] = bank[(size_t)wlo * FD_TAPS + i];
                 __syncthreads();
             }
             cf32 x[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) x[q] = win[(offset - base) + lane + 64 * q];
-            const cf32 outVal = fd_dot_wave<LAT>(x, brow + (phase - wlo) * FD_TAPS, lane);
-            // derivative of the signal from the neighbouring phases (complex_fd.cpp:103-120)
-            const cf32 fT1 = fd_dot_wave<LAT>(x, brow + (pp - wlo) * FD_TAPS, lane);
-            const cf32 fT_1 = fd_dot_wave<LAT>(x, brow + (pm - wlo) * FD_TAPS, lane);
+            // the interpolated sample and, for the derivative of the signal, its neighbours in phase (complex_fd.cpp:103-120)
+            cf32 outVal, fT1, fT_1;
+            fd_dot3_wave(x, brow + (phase - wlo) * FD_TAPS, brow + (pp - wlo) * FD_TAPS, brow + (pm - wlo) * FD_TAPS, lane, outVal, fT1, fT_1);
             cf32 dfdt;
             if (phase == 0) dfdt = csub(fT1, outVal);
             else if (phase == FD_PHASES - 1) dfdt = csub(outVal, fT_1);
@@ -1444,19 +1470,12 @@ __global__ __launch_bounds__(64) void dvbs_fd_costas_kernel(const DvbsStreamWork
             float error = spsctr == 0 ? ((outVal.re * dfdt.re) + (outVal.im * dfdt.im)) : 0.f;
             spsctr++;
             if (spsctr >= 1) spsctr = 0;                 // outSps = 1 (qpsk_alt.cpp:22)
-            error = error > 1.0f ? 1.0f : error;
-            error = error < -1.0f ? -1.0f : error;
+            error = clamp_med3(error, -1.0f, 1.0f);
             pcl.advance(error);
             const float delta = floorf(pcl.phase);
             offset = (int)((float)offset + delta);       // `offset += delta` with an int offset and a float delta
             pcl.phase -= delta;
-            // Costas<4> (SDR++ loop/costas.h): derotate, decision-directed QPSK error, clamp, advance
-            const cf32 v = cmul(outVal, phasor_hw(-cos.phase));
-            float cerr = ((v.re > 0 ? 1.0f : -1.0f) * v.im) - ((v.im > 0 ? 1.0f : -1.0f) * v.re);
-            cerr = cerr > 1.0f ? 1.0f : (cerr < -1.0f ? -1.0f : cerr);
-            cos.advance(cerr);
-            pcl_wrap_pi(cos.phase);
-            if (lane == 0) ostage[nout] = v;
+            if (lane == 0) ostage[nout] = outVal;       // (the Costas loop has its own kernel, below)
             ++nout;
         }
         __syncthreads();
@@ -1474,10 +1493,51 @@ __global__ __launch_bounds__(64) void dvbs_fd_costas_kernel(const DvbsStreamWork
     for (int i = lane; i < FD_TAPS - 1; i += 64) st->fd_hist[i] = win[i];
     if (lane == 0) {
         st->fd_phase = pcl.phase; st->fd_freq = pcl.freq; st->fd_offset = offset - n; st->fd_spsctr = spsctr;
-        st->costas_phase = cos.phase; st->costas_freq = cos.freq;
         st->n_sym = outCount;
         st->n_sym_slice[sub] = outCount;
     }
+}
+
+// Costas<4> (SDR++ loop/costas.h: derotate, decision-directed QPSK error, clamp, advance) over the symbols the timing recovery's slice
+// `sub` produced, in place.  LANE = STREAM: the loop only depends on the symbol sequence, not on the timing loop, so it does not belong in
+// that kernel's wave-wide instruction stream (it was a third of it: 75 of 210 instructions per symbol, executed by 64 lanes for one result).
+// Here a bank's 64 streams share a wave, and with few carriers the slice runs on the Viterbi stream beside the next timing-recovery slice.
+// Symbols move in batches of 8 per lane (one 64-byte line), the next batch in flight while this one goes through the recurrence.
+__global__ __launch_bounds__(64) void dvbs_costas_kernel(const DvbsStreamWork* __restrict__ work, int nstreams, DvbsLoopCoefs co, int sub, int nsub) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= nstreams) return;
+    const DvbsStreamWork w = work[s];
+    DvbsStreamState* st = w.st;
+    const int first = (nsub > 1 && sub) ? st->n_sym_slice[sub - 1] : 0, last = nsub > 1 ? st->n_sym_slice[sub] : st->n_sym;
+    PclDev cos{co.cos_alpha, co.cos_beta, st->costas_phase, st->costas_freq, co.cos_min_freq, co.cos_max_freq};
+    auto one = [&](cf32 x) -> cf32 {
+        const cf32 v = cmul(x, phasor_hw(-cos.phase));
+        float cerr = ((v.re > 0 ? 1.0f : -1.0f) * v.im) - ((v.im > 0 ? 1.0f : -1.0f) * v.re);
+        cerr = clamp_med3(cerr, -1.0f, 1.0f);
+        cos.advance(cerr);
+        pcl_wrap_pi(cos.phase);
+        return v;
+    };
+    constexpr int B = 8;
+    __builtin_amdgcn_s_setprio(FE_PRIO);
+    cf32 cur[B], nxt[B];
+    int i = first;
+    if (i + B <= last) {
+#pragma unroll
+        for (int k = 0; k < B; ++k) cur[k] = w.sym[i + k];
+    }
+    for (; i + B <= last; i += B) {
+        if (i + 2 * B <= last) {
+#pragma unroll
+            for (int k = 0; k < B; ++k) nxt[k] = w.sym[i + B + k];
+        }
+#pragma unroll
+        for (int k = 0; k < B; ++k) w.sym[i + k] = one(cur[k]);
+#pragma unroll
+        for (int k = 0; k < B; ++k) cur[k] = nxt[k];
+    }
+    for (; i < last; ++i) w.sym[i] = one(w.sym[i]);
+    st->costas_phase = cos.phase; st->costas_freq = cos.freq;
 }
 
 // DVBSymToSoftBlock: symbols -> int8 soft pairs appended to the stream's block FIFO; grid (x: tiles, y: stream)
@@ -1571,7 +1631,7 @@ hipError_t s2_fifo_compact_launch(const S2StreamWork* d_work, int nstreams, cons
 // stage instead of the sum (116 -> 53 ms per 131 k samples).  Three streams + the caller's: HIP's default of 4 hardware queues is enough.  A
 // bank that fills the GPU anyway (nsub = 1) runs the stages back to back on `st`.  ev: 4 rows of nsub + 1 events.
 hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int max_count, DvbsLoopCoefs coefs, const cf32* d_bandedge,
-                                const float* d_rrc, const float* d_fd_bank, hipStream_t st, hipStream_t* aux, hipEvent_t (*ev)[9], int nsub, DvbsSliceHook* hook) {
+                                const float* d_rrc, const float* d_fd_bank, hipStream_t st, hipStream_t* aux, hipEvent_t (*ev)[DVBS_FE_MAX_SLICES + 1], int nsub, DvbsSliceHook* hook) {
     const dim3 ga((nstreams + 63) / 64);
     const bool sliced = nsub > 1 && aux && ev;
     if (!sliced) nsub = 1;
@@ -1593,15 +1653,19 @@ hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int 
         hipLaunchKernelGGL(dvbs_rrc_kernel, dim3(gx, nstreams), dim3(256), 0, s1, d_work, d_rrc, coefs.ntaps, c, nsub);
         hipLaunchKernelGGL(dvbs_rrc_state_kernel, dim3(nstreams), dim3(128), 0, s1, d_work, coefs.ntaps, c, nsub);
         if (sliced) { if ((e = hipEventRecord(ev[2][c], s1)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(st, ev[2][c], 0)) != hipSuccess) return e; }
-        if (sliced) hipLaunchKernelGGL(dvbs_fd_costas_kernel<true>, dim3(nstreams), dim3(64), 0, st, d_work, coefs, d_fd_bank, c, nsub);
-        else hipLaunchKernelGGL(dvbs_fd_costas_kernel<false>, dim3(nstreams), dim3(64), 0, st, d_work, coefs, d_fd_bank, c, nsub);
-        if (sliced && hook && (e = hook->after_timing(c)) != hipSuccess) return e;       // (soft FIFO + Viterbi of the slice, on aux[0])
+        hipLaunchKernelGGL(dvbs_fd_kernel, dim3(nstreams), dim3(64), 0, st, d_work, coefs, d_fd_bank, c, nsub);
+        if (sliced && hook) { if ((e = hook->after_timing(c)) != hipSuccess) return e; }  // (Costas, soft FIFO + Viterbi of the slice, on aux[0])
+        else hipLaunchKernelGGL(dvbs_costas_kernel, ga, dim3(64), 0, st, d_work, nstreams, coefs, c, nsub);
     }
     if (!(sliced && hook)) {
         int gs = (max_count + 255) / 256;
         gs = gs < 1 ? 1 : (gs > 64 ? 64 : gs);
         hipLaunchKernelGGL(dvbs_soft_fifo_kernel, dim3(gs, nstreams), dim3(256), 0, st, d_work, 0, 1);
     }
+    return hipGetLastError();
+}
+hipError_t dvbs_costas_launch(const DvbsStreamWork* d_work, int nstreams, DvbsLoopCoefs coefs, int sub, int nsub, hipStream_t st) {
+    hipLaunchKernelGGL(dvbs_costas_kernel, dim3((nstreams + 63) / 64), dim3(64), 0, st, d_work, nstreams, coefs, sub, nsub);
     return hipGetLastError();
 }
 hipError_t dvbs_soft_slice_launch(const DvbsStreamWork* d_work, int nstreams, int max_count, int sub, int nsub, int* d_blk0, int* d_nblk, hipStream_t st) {

@@ -122,8 +122,9 @@ def test_dvbs_bank_batch_equals_single(engine, pkg):
 
 
 def test_time_sliced_dvbs_front_end_changes_nothing(engine, pkg):
-    """small banks run AGC / FLL / RRC / timing + Costas as four time-sliced stages on four streams (every stage keeps its state in the stream
-    record); 1 slice (what a GPU-filling bank uses), 3 and the default 8 must give the same symbols, loop state and decoded bits, call by call
+    """small banks run AGC / FLL + RRC / timing recovery / Costas + soft FIFO + Viterbi as time-sliced stages on three streams (every stage keeps
+    its state in the stream record); 1 slice (what a GPU-filling bank uses), 3, 8, the maximum 32 and the default 24 must give the same symbols,
+    loop state and decoded bits, call by call
     (DVBS2GPU_DVBS_FE_SLICES is read when a context is created)"""
     import os
     iq, _ = od.dvbs_iq(2, 30000, seed=7, esn0_db=9.0, cfo=8e-4, timing=0.41, phase0=0.3)
@@ -144,7 +145,7 @@ def test_time_sliced_dvbs_front_end_changes_nothing(engine, pkg):
     assert sum(x.size for x in ref[1::3]) > 20000
     old = os.environ.get('DVBS2GPU_DVBS_FE_SLICES')
     try:
-        for k in ('1', '3'):
+        for k in ('1', '3', '8', '32'):
             os.environ['DVBS2GPU_DVBS_FE_SLICES'] = k
             e2 = pkg.Engine(0)
             got = run(e2)
