@@ -230,7 +230,7 @@ int dvbs2gpu_dvbs_demod_process_batch(dvbs2gpu_dvbs_demod* d, const float* const
     hook.d = d; hook.fa = fa; hook.d_work = d_work; hook.d_in_ptrs = (const int8_t* const*)(base + off_ptr_in); hook.n = n; hook.max_count = max_count;
     hook.nsub = nsub; hook.mb = mb; hook.d_blk0 = d_blk0; hook.d_nblk = d_nblk; hook.d_nbits = d_nbits; hook.d_bits = (uint8_t*)wsb.p; hook.st = st;
     HIP_TRY(dvbs_frontend_launch(d_work, n, max_count, d->co, d->d_bandedge, d->d_rrc, ctx->d_fd_bank, st, fa ? fa->dvbs_aux : nullptr,
-                                 fa ? fa->dvbs_ev : nullptr, nsub, fa ? &hook : nullptr));
+                                 fa ? fa->dvbs_ev : nullptr, nsub, fa ? &hook : nullptr, ctx->dvbs_bank_min));
     if (fa) {
         // the last slice's decoder run ends the Viterbi stream's work for this call
         HIP_TRY(hipEventRecord(fa->dvbs_ev[3][DVBS_FE_MAX_SLICES], fa->dvbs_aux[0]));

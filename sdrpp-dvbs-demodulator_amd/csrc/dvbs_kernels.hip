@@ -348,6 +348,12 @@ __global__ __launch_bounds__(64) void dvbs_viterbi_kernel(const int8_t* in_all, 
                 } else {
                     cc_decode_wave(depunc, 6799, ss[8], bs[8], dec, out, lane);
                     ber = reencode_ber(out, 1699, enc[3], ber_enc, depunc, 3399, 8.f, lane);
+                    // Rate 5/6: the decoder's frame is (int)(8192 * 1.66 / 2) = 6799 bits but the block advances the output by oo / 2 = 6826
+                    // or 6827 (viterbi_all.cpp:246-249, cc_decoder.cpp:304-314): the reference never writes the 27-28 bits in between, they
+                    // keep what its caller's buffer held.  Here they are ZERO -- what the oracle shows with a cleared buffer -- instead of
+                    // whatever the block's slot of the workspace held from an earlier call (found by the bank test with carriers of differing
+                    // block counts: the slot of a (stream, block) pair moves when the batch's block count changes).
+                    for (int i = 6799 + lane; i < oo / 2; i += 64) out[i] = 0;
                 }
                 n_out = oo / 2;
             } else if (rate == 2) {

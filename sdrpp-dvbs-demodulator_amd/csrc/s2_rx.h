@@ -154,7 +154,7 @@ constexpr int DVBS_FE_MAX_SLICES = 32;      // (n_sym_slice[] of the stream stat
 struct DvbsSliceHook { virtual hipError_t after_timing(int slice) = 0; virtual ~DvbsSliceHook() {} };   // called after the timing-recovery launch of every slice
 hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int max_count, DvbsLoopCoefs coefs, const cf32* d_bandedge,
                                 const float* d_rrc, const float* d_fd_bank, hipStream_t st, hipStream_t* aux = nullptr, hipEvent_t (*ev)[DVBS_FE_MAX_SLICES + 1] = nullptr, int nsub = 1,
-                                DvbsSliceHook* hook = nullptr);
+                                DvbsSliceHook* hook = nullptr, int bank_min = 1 << 30);   // bank_min: carriers from which an unsliced bank uses the many-streams-per-wave kernels
 hipError_t dvbs_costas_launch(const DvbsStreamWork* d_work, int nstreams, DvbsLoopCoefs coefs, int sub, int nsub, hipStream_t st);
 hipError_t dvbs_soft_slice_launch(const DvbsStreamWork* d_work, int nstreams, int max_count, int sub, int nsub, int* d_blk0, int* d_nblk, hipStream_t st);
 

@@ -1326,6 +1326,89 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
     if (lane == 0) { st->fll_phase = phase; st->fll_freq = freq; }
 }
 
+// The same loop for a bank that fills the GPU: FOUR STREAMS PER WAVE, one row of 16 lanes each, 4 taps and 4 running sums per lane.  A
+// wave per stream spends two thirds of its instructions on the loop's scalar part (phasor, amplitudes, frequency update), done 64 lanes
+// wide for one stream; with thousands of carriers that is what bounds the kernel (VALU issue, 4 waves per SIMD).  Here the scalar part
+// serves four streams at once.  The sums still move one TAP up per sample -- inside a lane from register to register, from a lane's last
+// register to its neighbour's first (DPP row_shr:1: rows do not mix) -- so every output accumulates its 65 terms in tap order as before
+// and the bits are the wave-per-stream kernel's; the finished sum leaves lane 15 of the row, which computes the error and hands it to
+// its row (ds_swizzle).  Whole call at once (a bank is not time-sliced).
+constexpr int FLL4_SPW = 4, FLL4_TPL = 4;
+__global__ __launch_bounds__(64) void dvbs_fll4_kernel(const DvbsStreamWork* __restrict__ work, int nstreams, DvbsLoopCoefs co,
+                                                       const cf32* __restrict__ bandedge) {
+    __shared__ cf32 ytile[FLL4_SPW][64];
+    __shared__ cf32 xtile[FLL4_SPW][64];
+    const int lane = threadIdx.x, row = lane >> 4, j = lane & 15;
+    const int s = blockIdx.x * FLL4_SPW + row;
+    const bool act = s < nstreams;
+    const DvbsStreamWork w = work[act ? s : blockIdx.x * FLL4_SPW];
+    DvbsStreamState* st = w.st;
+    const int n = act ? w.count : 0, T = co.ntaps, H = T - 1;       // T == 65 (checked on the host)
+    cf32 tl[FLL4_TPL], th[FLL4_TPL], al[FLL4_TPL], ah[FLL4_TPL];
+#pragma unroll
+    for (int q = 0; q < FLL4_TPL; ++q) { tl[q] = bandedge[FLL4_TPL * j + q]; th[q] = bandedge[T + FLL4_TPL * j + q]; }
+    const cf32 tl_last = bandedge[T - 1], th_last = bandedge[2 * T - 1];
+    float phase = st->fll_phase, freq = st->fll_freq;
+    // running sums from the delay line: tap position p = 4 j + q holds, for output 63 - p of the new data, the terms of taps 0..p
+#pragma unroll
+    for (int q = 0; q < FLL4_TPL; ++q) {
+        const int p = FLL4_TPL * j + q;
+        cf32 a{0.f, 0.f}, b{0.f, 0.f};
+        for (int jt = 0; jt <= p; ++jt) {
+            const cf32 xs = st->fll_hist[H - 1 - p + jt];
+            a = cadd(a, cmul(xs, bandedge[jt]));
+            b = cadd(b, cmul(xs, bandedge[T + jt]));
+        }
+        al[q] = a; ah[q] = b;
+    }
+    int nmax = n;
+    nmax = max(nmax, __shfl_xor(nmax, 16));
+    nmax = max(nmax, __shfl_xor(nmax, 32));
+    for (int base = 0; base < nmax; base += 64) {
+        const int m = min(64, n - base), mmax = min(64, nmax - base);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const int i = j + 16 * t; if (i < m) ytile[row][i] = w.buf_a[base + i]; }
+        __syncthreads();
+        for (int k = 0; k < mmax; ++k) {
+            if (k < m) {                                     // (whole rows: the DPP shifts and the swizzle stay inside a row)
+                const cf32 x = cmul(ytile[row][k], phasor_hw(-phase));
+                // this sample's two outputs: the sum leaving the row's last tap position + newest sample * tap 64 (lane 15 of the row)
+                const cf32 lo = cadd(al[FLL4_TPL - 1], cmul(x, tl_last)), hi = cadd(ah[FLL4_TPL - 1], cmul(x, th_last));
+                float err = fast_amplitude(hi) - fast_amplitude(lo);
+                err = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, err), 0x1F0));   // lane (l & 16) | 15 of each 32
+                freq += co.fll_beta * err;
+                freq = clamp_med3(freq, co.fll_min_freq, co.fll_max_freq);
+                phase += freq;
+                pcl_wrap_pi(phase);
+                if (j == 0) xtile[row][k] = x;
+                cf32 sl, sh;
+                sl.re = DPP_F(al[FLL4_TPL - 1].re, 0x111); sl.im = DPP_F(al[FLL4_TPL - 1].im, 0x111);     // row_shr:1, 0 into the row's lane 0
+                sh.re = DPP_F(ah[FLL4_TPL - 1].re, 0x111); sh.im = DPP_F(ah[FLL4_TPL - 1].im, 0x111);
+#pragma unroll
+                for (int q = FLL4_TPL - 1; q > 0; --q) { al[q] = cadd(al[q - 1], cmul(x, tl[q])); ah[q] = cadd(ah[q - 1], cmul(x, th[q])); }
+                al[0] = cadd(sl, cmul(x, tl[0]));
+                ah[0] = cadd(sh, cmul(x, th[0]));
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const int i = j + 16 * t; if (i < m) w.buf_b[base + i] = xtile[row][i]; }
+    }
+    __syncthreads();
+    // new delay line = last H samples of [old delay line ++ rotated samples of this call] (read everything, then write)
+    cf32 nh[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = j + 16 * t, p = n - H + i;
+        nh[t] = (act && i < H) ? (p >= 0 ? w.buf_b[p] : st->fll_hist[H + p]) : cf32{0.f, 0.f};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { const int i = j + 16 * t; if (act && i < H) st->fll_hist[i] = nh[t]; }
+    if (act && j == 0) { st->fll_phase = phase; st->fll_freq = freq; }
+}
+
 // RRC FIR at the input rate (SDR++ filter::FIR, taps accumulated in order); grid (x: sample tiles, y: stream); in = buf_b, out = buf_a
 __global__ __launch_bounds__(256) void dvbs_rrc_kernel(const DvbsStreamWork* __restrict__ work, const float* __restrict__ taps_g, int ntaps, int sub, int nsub) {
     __shared__ float taps[RRC_MAX_TAPS];
@@ -1631,7 +1714,7 @@ hipError_t s2_fifo_compact_launch(const S2StreamWork* d_work, int nstreams, cons
 // stage instead of the sum (116 -> 53 ms per 131 k samples).  Three streams + the caller's: HIP's default of 4 hardware queues is enough.  A
 // bank that fills the GPU anyway (nsub = 1) runs the stages back to back on `st`.  ev: 4 rows of nsub + 1 events.
 hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int max_count, DvbsLoopCoefs coefs, const cf32* d_bandedge,
-                                const float* d_rrc, const float* d_fd_bank, hipStream_t st, hipStream_t* aux, hipEvent_t (*ev)[DVBS_FE_MAX_SLICES + 1], int nsub, DvbsSliceHook* hook) {
+                                const float* d_rrc, const float* d_fd_bank, hipStream_t st, hipStream_t* aux, hipEvent_t (*ev)[DVBS_FE_MAX_SLICES + 1], int nsub, DvbsSliceHook* hook, int bank_min) {
     const dim3 ga((nstreams + 63) / 64);
     const bool sliced = nsub > 1 && aux && ev;
     if (!sliced) nsub = 1;
@@ -1649,7 +1732,8 @@ hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int 
     }
     for (int c = 0; c < nsub; ++c) {
         if (sliced && (e = hipStreamWaitEvent(s1, ev[0][c], 0)) != hipSuccess) return e;
-        hipLaunchKernelGGL(dvbs_fll_kernel, dim3(nstreams), dim3(64), 0, s1, d_work, coefs, d_bandedge, c, nsub);
+        if (!sliced && nstreams >= bank_min) hipLaunchKernelGGL(dvbs_fll4_kernel, dim3((nstreams + FLL4_SPW - 1) / FLL4_SPW), dim3(64), 0, s1, d_work, nstreams, coefs, d_bandedge);
+        else hipLaunchKernelGGL(dvbs_fll_kernel, dim3(nstreams), dim3(64), 0, s1, d_work, coefs, d_bandedge, c, nsub);
         hipLaunchKernelGGL(dvbs_rrc_kernel, dim3(gx, nstreams), dim3(256), 0, s1, d_work, d_rrc, coefs.ntaps, c, nsub);
         hipLaunchKernelGGL(dvbs_rrc_state_kernel, dim3(nstreams), dim3(128), 0, s1, d_work, coefs.ntaps, c, nsub);
         if (sliced) { if ((e = hipEventRecord(ev[2][c], s1)) != hipSuccess) return e; if ((e = hipStreamWaitEvent(st, ev[2][c], 0)) != hipSuccess) return e; }

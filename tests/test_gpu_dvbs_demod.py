@@ -121,6 +121,45 @@ def test_dvbs_bank_batch_equals_single(engine, pkg):
     bank.close()
 
 
+def test_dvbs_bank_kernels_equal_the_wave_per_stream_kernels(engine, pkg):
+    """a bank of more than 256 carriers runs the FLL (and the timing recovery) with several streams per wave; forced here for 6 carriers of
+    differing lengths (DVBS2GPU_DVBS_BANK_MIN=1, one time slice): decoded bits, symbols and loop state must equal the wave-per-stream path's
+    (which the tests above compare with the oracle), call by call"""
+    import os
+    import torch
+    S = 6
+    iqs = [od.dvbs_iq(r % 5, 12288, seed=60 + r, esn0_db=11.0, cfo=(r - 2) * 6e-4, timing=0.13 * r, phase0=0.2 * r)[0] for r in range(S)]
+    counts = [[24576, 20001, 24576, 777, 16384, 9000], [1000, 24576, 63, 24576, 130, 24576], [24576, 4575, 24576, 24576, 8192, 15576]]
+    single = [pkg.DvbsDemodBank(engine, 1, max_samples=24576) for _ in range(S)]
+    old = {k: os.environ.get(k) for k in ('DVBS2GPU_DVBS_BANK_MIN', 'DVBS2GPU_DVBS_FE_SLICES')}
+    try:
+        os.environ['DVBS2GPU_DVBS_BANK_MIN'] = '1'
+        os.environ['DVBS2GPU_DVBS_FE_SLICES'] = '1'
+        e2 = pkg.Engine(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    bank = pkg.DvbsDemodBank(e2, S, max_samples=24576)
+    pos = [0] * S
+    for rep in range(3):
+        tin = [torch.from_numpy(iqs[i][pos[i]:pos[i] + counts[rep][i]]).cuda() for i in range(S)]
+        tout = [torch.zeros(4 * 8192 + 24576, dtype=torch.uint8, device='cuda') for _ in range(S)]
+        nb = bank.process_batch(tin, tout)
+        for i in range(S):
+            ref = single[i].process(iqs[i][pos[i]:pos[i] + counts[rep][i]])
+            pos[i] += tin[i].numel()
+            assert np.array_equal(bank.symbols(i).view(np.uint32), single[i].symbols().view(np.uint32)), (rep, i)
+            assert np.array_equal(bank.loop_state(i).view(np.uint32), single[i].loop_state().view(np.uint32)), (rep, i)
+            assert nb[i] == ref.size and np.array_equal(tout[i][:nb[i]].cpu().numpy(), ref), (rep, i)
+    for b in single:
+        b.close()
+    bank.close()
+    e2.close()
+
+
 def test_time_sliced_dvbs_front_end_changes_nothing(engine, pkg):
     """small banks run AGC / FLL + RRC / timing recovery / Costas + soft FIFO + Viterbi as time-sliced stages on three streams (every stage keeps
     its state in the stream record); 1 slice (what a GPU-filling bank uses), 3, 8, the maximum 32 and the default 24 must give the same symbols,
