@@ -158,7 +158,6 @@ void dvbs2gpu_dvbs_demod_destroy(dvbs2gpu_dvbs_demod* d) {
     delete d;
 }
 
-constexpr int DVBS_SLICE_MAX_STREAMS = 256;   // above this the wave-per-stream stages fill the GPU on their own
 
 int dvbs2gpu_dvbs_demod_process_batch(dvbs2gpu_dvbs_demod* d, const float* const* d_iq, const int* counts, uint8_t* const* d_bits, int cap,
                                       int* out_counts) {
@@ -197,10 +196,12 @@ int dvbs2gpu_dvbs_demod_process_batch(dvbs2gpu_dvbs_demod* d, const float* const
     int* d_cnt = (int*)(base + off_cnt);
     int* d_nbits = (int*)(base + off_nbits);
     int* d_blk0 = (int*)(base + off_blk0);
-    // few carriers: the serial stages time-sliced over their own streams (s2_rx_kernels.hip, dvbs_frontend_launch): AGC, FLL, RRC, timing
-    // recovery + Costas, and -- behind every timing-recovery slice -- the slice's soft FIFO append and the Viterbi decoding of the blocks it
-    // completed; a bank that fills the GPU runs the stages back to back
-    const int nsub = n <= DVBS_SLICE_MAX_STREAMS ? ctx->dvbs_fe_slices : 1;
+    // The serial stages time-sliced over their own streams (s2_rx_kernels.hip, dvbs_frontend_launch): AGC, FLL + RRC, timing recovery, and --
+    // behind every timing-recovery slice -- the slice's Costas loop, soft FIFO append and the Viterbi decoding of the blocks it completed.
+    // One carrier then costs its slowest stage instead of the sum; a bank of thousands gains too (4096 carriers: 206 -> 146 ms per call),
+    // because its lane-per-stream and four-streams-per-wave stages (AGC, Costas, FLL) are latency chains that leave the SIMDs to the
+    // wave-per-stream ones (timing recovery, Viterbi, RRC).
+    const int nsub = ctx->dvbs_fe_slices;
     dvbs2gpu_ctx::FeAux* fa = nullptr;
     if (nsub > 1) {
         std::lock_guard<std::mutex> l(ctx->mtx);

@@ -1332,18 +1332,21 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
 // serves four streams at once.  The sums still move one TAP up per sample -- inside a lane from register to register, from a lane's last
 // register to its neighbour's first (DPP row_shr:1: rows do not mix) -- so every output accumulates its 65 terms in tap order as before
 // and the bits are the wave-per-stream kernel's; the finished sum leaves lane 15 of the row, which computes the error and hands it to
-// its row (ds_swizzle).  Whole call at once (a bank is not time-sliced).
+// its row (ds_swizzle).
 constexpr int FLL4_SPW = 4, FLL4_TPL = 4;
 __global__ __launch_bounds__(64) void dvbs_fll4_kernel(const DvbsStreamWork* __restrict__ work, int nstreams, DvbsLoopCoefs co,
-                                                       const cf32* __restrict__ bandedge) {
+                                                       const cf32* __restrict__ bandedge, int sub, int nsub) {
     __shared__ cf32 ytile[FLL4_SPW][64];
     __shared__ cf32 xtile[FLL4_SPW][64];
     const int lane = threadIdx.x, row = lane >> 4, j = lane & 15;
     const int s = blockIdx.x * FLL4_SPW + row;
     const bool act = s < nstreams;
-    const DvbsStreamWork w = work[act ? s : blockIdx.x * FLL4_SPW];
+    DvbsStreamWork w = work[act ? s : blockIdx.x * FLL4_SPW];
     DvbsStreamState* st = w.st;
-    const int n = act ? w.count : 0, T = co.ntaps, H = T - 1;       // T == 65 (checked on the host)
+    int lo, hi;
+    fe_sub_range(w.count, sub, nsub, lo, hi);                       // time slice of the call (dvbs_frontend_launch)
+    w.buf_a += lo; w.buf_b += lo;
+    const int n = act ? hi - lo : 0, T = co.ntaps, H = T - 1;       // T == 65 (checked on the host)
     cf32 tl[FLL4_TPL], th[FLL4_TPL], al[FLL4_TPL], ah[FLL4_TPL];
 #pragma unroll
     for (int q = 0; q < FLL4_TPL; ++q) { tl[q] = bandedge[FLL4_TPL * j + q]; th[q] = bandedge[T + FLL4_TPL * j + q]; }
@@ -1707,12 +1710,13 @@ hipError_t s2_fifo_compact_launch(const S2StreamWork* d_work, int nstreams, cons
     hipLaunchKernelGGL(s2_fifo_compact_kernel, dim3(16, nstreams), dim3(256), 0, st, d_work, d_cur_fill);
     return hipGetLastError();
 }
-// The serial stages of the DVB-S receiver -- AGC (lane = stream), band-edge FLL, RRC, timing recovery + Costas (a wave per stream each), and the
-// Viterbi decoder behind them -- keep their state in the stream record, so a call's samples can go through in `nsub` time slices with the stages
-// on three streams: aux[0] runs the AGC slices ahead and later the soft FIFO + Viterbi slices (the hook), aux[1] the FLL and RRC slices, `st`
-// the timing recovery; events between them.  Slice c of a stage runs beside slice c+1 of the stage before it, and ONE carrier costs the slowest
-// stage instead of the sum (116 -> 53 ms per 131 k samples).  Three streams + the caller's: HIP's default of 4 hardware queues is enough.  A
-// bank that fills the GPU anyway (nsub = 1) runs the stages back to back on `st`.  ev: 4 rows of nsub + 1 events.
+// The serial stages of the DVB-S receiver -- AGC and Costas (lane = stream), band-edge FLL (a wave per stream, or four streams per wave from
+// `bank_min` carriers), RRC, timing recovery (a wave per stream) and the Viterbi decoder behind them -- keep their state in the stream record,
+// so a call's samples can go through in `nsub` time slices with the stages on three streams: aux[0] runs the AGC slices ahead and later the
+// Costas + soft FIFO + Viterbi slices (the hook), aux[1] the FLL and RRC slices, `st` the timing recovery; events between them.  Slice c of a
+// stage runs beside slice c+1 of the stage before it: ONE carrier costs the slowest stage instead of the sum (116 -> 39 ms per 131 k samples),
+// and in a bank the latency-bound stages (few waves) hide beside the ones that fill the SIMDs.  Three streams + the caller's: HIP's default of
+// 4 hardware queues is enough.  nsub = 1: the stages back to back on `st`.  ev: 4 rows of nsub + 1 events.
 hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int max_count, DvbsLoopCoefs coefs, const cf32* d_bandedge,
                                 const float* d_rrc, const float* d_fd_bank, hipStream_t st, hipStream_t* aux, hipEvent_t (*ev)[DVBS_FE_MAX_SLICES + 1], int nsub, DvbsSliceHook* hook, int bank_min) {
     const dim3 ga((nstreams + 63) / 64);
@@ -1732,7 +1736,7 @@ hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int 
     }
     for (int c = 0; c < nsub; ++c) {
         if (sliced && (e = hipStreamWaitEvent(s1, ev[0][c], 0)) != hipSuccess) return e;
-        if (!sliced && nstreams >= bank_min) hipLaunchKernelGGL(dvbs_fll4_kernel, dim3((nstreams + FLL4_SPW - 1) / FLL4_SPW), dim3(64), 0, s1, d_work, nstreams, coefs, d_bandedge);
+        if (nstreams >= bank_min) hipLaunchKernelGGL(dvbs_fll4_kernel, dim3((nstreams + FLL4_SPW - 1) / FLL4_SPW), dim3(64), 0, s1, d_work, nstreams, coefs, d_bandedge, c, nsub);
         else hipLaunchKernelGGL(dvbs_fll_kernel, dim3(nstreams), dim3(64), 0, s1, d_work, coefs, d_bandedge, c, nsub);
         hipLaunchKernelGGL(dvbs_rrc_kernel, dim3(gx, nstreams), dim3(256), 0, s1, d_work, d_rrc, coefs.ntaps, c, nsub);
         hipLaunchKernelGGL(dvbs_rrc_state_kernel, dim3(nstreams), dim3(128), 0, s1, d_work, coefs.ntaps, c, nsub);

@@ -121,9 +121,10 @@ def test_dvbs_bank_batch_equals_single(engine, pkg):
     bank.close()
 
 
-def test_dvbs_bank_kernels_equal_the_wave_per_stream_kernels(engine, pkg):
-    """a bank of more than 256 carriers runs the FLL (and the timing recovery) with several streams per wave; forced here for 6 carriers of
-    differing lengths (DVBS2GPU_DVBS_BANK_MIN=1, one time slice): decoded bits, symbols and loop state must equal the wave-per-stream path's
+@pytest.mark.parametrize('slices', ['1', '3'])
+def test_dvbs_bank_kernels_equal_the_wave_per_stream_kernels(engine, pkg, slices):
+    """a bank of more than 256 carriers runs the FLL with several streams per wave; forced here for 6 carriers of differing lengths
+    (DVBS2GPU_DVBS_BANK_MIN=1), in one time slice and in three: decoded bits, symbols and loop state must equal the wave-per-stream path's
     (which the tests above compare with the oracle), call by call"""
     import os
     import torch
@@ -134,7 +135,7 @@ def test_dvbs_bank_kernels_equal_the_wave_per_stream_kernels(engine, pkg):
     old = {k: os.environ.get(k) for k in ('DVBS2GPU_DVBS_BANK_MIN', 'DVBS2GPU_DVBS_FE_SLICES')}
     try:
         os.environ['DVBS2GPU_DVBS_BANK_MIN'] = '1'
-        os.environ['DVBS2GPU_DVBS_FE_SLICES'] = '1'
+        os.environ['DVBS2GPU_DVBS_FE_SLICES'] = slices
         e2 = pkg.Engine(0)
     finally:
         for k, v in old.items():
