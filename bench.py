@@ -339,7 +339,7 @@ def secondary_dvbs(eng, pkg, dev):
         bank.process_batch(tin, tout)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        reps = 2
+        reps = 2 if S > 64 else 5
         for _ in range(reps):
             bank.process_batch(tin, tout)
         torch.cuda.synchronize()
@@ -633,8 +633,8 @@ def main():
         if world == 1 and not args.no_secondary:
             sec = []
             try:
-                sec.append(secondary_s2(eng, pkg, dev, '2: DVB-S2 QPSK 1/2 normal FECFRAME (MODCOD 4), same channel conditions, Es/N0 8 dB', 4, 3, 0, 0, 8.0, 4096, 4, 3))
-                sec.append(secondary_s2(eng, pkg, dev, '5 stand-in: DVB-S2 32APSK 8/9 SHORT FECFRAME + pilots (MODCOD 27; 9/10 short does not exist), Es/N0 20 dB', 27, 9, 1, 1, 20.0, 2048, 16, 3))
+                sec.append(secondary_s2(eng, pkg, dev, '2: DVB-S2 QPSK 1/2 normal FECFRAME (MODCOD 4), same channel conditions, Es/N0 8 dB', 4, 3, 0, 0, 8.0, 4096, 4, 8))
+                sec.append(secondary_s2(eng, pkg, dev, '5 stand-in: DVB-S2 32APSK 8/9 SHORT FECFRAME + pilots (MODCOD 27; 9/10 short does not exist), Es/N0 20 dB', 27, 9, 1, 1, 20.0, 2048, 16, 8))
                 sec.append(secondary_dvbs(eng, pkg, dev))
                 sec.append(small_batch(eng, pkg, dev, 64, 1))
                 sec.append(small_batch(eng, pkg, dev, 1, 4))
