@@ -1333,29 +1333,31 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
 // register to its neighbour's first (DPP row_shr:1: rows do not mix) -- so every output accumulates its 65 terms in tap order as before
 // and the bits are the wave-per-stream kernel's; the finished sum leaves lane 15 of the row, which computes the error and hands it to
 // its row (ds_swizzle).
-constexpr int FLL4_SPW = 4, FLL4_TPL = 4;
+// SPW = 4: a row of 16 lanes per stream (DPP row_shr:1 stays inside it); SPW = 2: 32 lanes per stream (wave_shr:1, lane 32 cleared by hand).
+template <int SPW>
 __global__ __launch_bounds__(64) void dvbs_fll4_kernel(const DvbsStreamWork* __restrict__ work, int nstreams, DvbsLoopCoefs co,
                                                        const cf32* __restrict__ bandedge, int sub, int nsub) {
-    __shared__ cf32 ytile[FLL4_SPW][64];
-    __shared__ cf32 xtile[FLL4_SPW][64];
-    const int lane = threadIdx.x, row = lane >> 4, j = lane & 15;
-    const int s = blockIdx.x * FLL4_SPW + row;
+    constexpr int LPS = 64 / SPW, TPL = 64 / LPS, NLD = 64 / LPS;      // lanes per stream, taps per lane, tile samples a lane moves
+    __shared__ cf32 ytile[SPW][64];
+    __shared__ cf32 xtile[SPW][64];
+    const int lane = threadIdx.x, row = lane / LPS, j = lane % LPS;
+    const int s = blockIdx.x * SPW + row;
     const bool act = s < nstreams;
-    DvbsStreamWork w = work[act ? s : blockIdx.x * FLL4_SPW];
+    DvbsStreamWork w = work[act ? s : blockIdx.x * SPW];
     DvbsStreamState* st = w.st;
     int lo, hi;
     fe_sub_range(w.count, sub, nsub, lo, hi);                       // time slice of the call (dvbs_frontend_launch)
     w.buf_a += lo; w.buf_b += lo;
     const int n = act ? hi - lo : 0, T = co.ntaps, H = T - 1;       // T == 65 (checked on the host)
-    cf32 tl[FLL4_TPL], th[FLL4_TPL], al[FLL4_TPL], ah[FLL4_TPL];
+    cf32 tl[TPL], th[TPL], al[TPL], ah[TPL];
 #pragma unroll
-    for (int q = 0; q < FLL4_TPL; ++q) { tl[q] = bandedge[FLL4_TPL * j + q]; th[q] = bandedge[T + FLL4_TPL * j + q]; }
+    for (int q = 0; q < TPL; ++q) { tl[q] = bandedge[TPL * j + q]; th[q] = bandedge[T + TPL * j + q]; }
     const cf32 tl_last = bandedge[T - 1], th_last = bandedge[2 * T - 1];
     float phase = st->fll_phase, freq = st->fll_freq;
-    // running sums from the delay line: tap position p = 4 j + q holds, for output 63 - p of the new data, the terms of taps 0..p
+    // running sums from the delay line: tap position p = TPL j + q holds, for output 63 - p of the new data, the terms of taps 0..p
 #pragma unroll
-    for (int q = 0; q < FLL4_TPL; ++q) {
-        const int p = FLL4_TPL * j + q;
+    for (int q = 0; q < TPL; ++q) {
+        const int p = TPL * j + q;
         cf32 a{0.f, 0.f}, b{0.f, 0.f};
         for (int jt = 0; jt <= p; ++jt) {
             const cf32 xs = st->fll_hist[H - 1 - p + jt];
@@ -1365,50 +1367,58 @@ __global__ __launch_bounds__(64) void dvbs_fll4_kernel(const DvbsStreamWork* __r
         al[q] = a; ah[q] = b;
     }
     int nmax = n;
-    nmax = max(nmax, __shfl_xor(nmax, 16));
-    nmax = max(nmax, __shfl_xor(nmax, 32));
+#pragma unroll
+    for (int o = LPS; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+    // the finished sum leaves the stream's last lane: its error goes to the whole group (ds_swizzle: lane (l & ~(LPS - 1)) | (LPS - 1) of each 32)
+    constexpr int SWZ = ((32 - 1) & ~(LPS - 1)) | ((LPS - 1) << 5);
     for (int base = 0; base < nmax; base += 64) {
         const int m = min(64, n - base), mmax = min(64, nmax - base);
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { const int i = j + 16 * t; if (i < m) ytile[row][i] = w.buf_a[base + i]; }
+        for (int t = 0; t < NLD; ++t) { const int i = j + LPS * t; if (i < m) ytile[row][i] = w.buf_a[base + i]; }
         __syncthreads();
         for (int k = 0; k < mmax; ++k) {
-            if (k < m) {                                     // (whole rows: the DPP shifts and the swizzle stay inside a row)
+            if (k < m) {                                     // (whole lane groups: the shifts and the swizzle stay inside a stream)
                 const cf32 x = cmul(ytile[row][k], phasor_hw(-phase));
-                // this sample's two outputs: the sum leaving the row's last tap position + newest sample * tap 64 (lane 15 of the row)
-                const cf32 lo = cadd(al[FLL4_TPL - 1], cmul(x, tl_last)), hi = cadd(ah[FLL4_TPL - 1], cmul(x, th_last));
+                // this sample's two outputs: the sum leaving the last tap position + newest sample * tap 64 (the stream's last lane)
+                const cf32 lo = cadd(al[TPL - 1], cmul(x, tl_last)), hi = cadd(ah[TPL - 1], cmul(x, th_last));
                 float err = fast_amplitude(hi) - fast_amplitude(lo);
-                err = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, err), 0x1F0));   // lane (l & 16) | 15 of each 32
+                err = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, err), SWZ));
                 freq += co.fll_beta * err;
                 freq = clamp_med3(freq, co.fll_min_freq, co.fll_max_freq);
                 phase += freq;
                 pcl_wrap_pi(phase);
                 if (j == 0) xtile[row][k] = x;
                 cf32 sl, sh;
-                sl.re = DPP_F(al[FLL4_TPL - 1].re, 0x111); sl.im = DPP_F(al[FLL4_TPL - 1].im, 0x111);     // row_shr:1, 0 into the row's lane 0
-                sh.re = DPP_F(ah[FLL4_TPL - 1].re, 0x111); sh.im = DPP_F(ah[FLL4_TPL - 1].im, 0x111);
+                if constexpr (LPS == 16) {                   // row_shr:1, 0 into the row's lane 0
+                    sl.re = DPP_F(al[TPL - 1].re, 0x111); sl.im = DPP_F(al[TPL - 1].im, 0x111);
+                    sh.re = DPP_F(ah[TPL - 1].re, 0x111); sh.im = DPP_F(ah[TPL - 1].im, 0x111);
+                } else {                                     // wave_shr:1 (0 into lane 0), and 0 into the first lane of the other streams
+                    sl.re = DPP_F(al[TPL - 1].re, 0x138); sl.im = DPP_F(al[TPL - 1].im, 0x138);
+                    sh.re = DPP_F(ah[TPL - 1].re, 0x138); sh.im = DPP_F(ah[TPL - 1].im, 0x138);
+                    if (j == 0) { sl = cf32{0.f, 0.f}; sh = cf32{0.f, 0.f}; }
+                }
 #pragma unroll
-                for (int q = FLL4_TPL - 1; q > 0; --q) { al[q] = cadd(al[q - 1], cmul(x, tl[q])); ah[q] = cadd(ah[q - 1], cmul(x, th[q])); }
+                for (int q = TPL - 1; q > 0; --q) { al[q] = cadd(al[q - 1], cmul(x, tl[q])); ah[q] = cadd(ah[q - 1], cmul(x, th[q])); }
                 al[0] = cadd(sl, cmul(x, tl[0]));
                 ah[0] = cadd(sh, cmul(x, th[0]));
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { const int i = j + 16 * t; if (i < m) w.buf_b[base + i] = xtile[row][i]; }
+        for (int t = 0; t < NLD; ++t) { const int i = j + LPS * t; if (i < m) w.buf_b[base + i] = xtile[row][i]; }
     }
     __syncthreads();
     // new delay line = last H samples of [old delay line ++ rotated samples of this call] (read everything, then write)
-    cf32 nh[4];
+    cf32 nh[NLD];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int i = j + 16 * t, p = n - H + i;
+    for (int t = 0; t < NLD; ++t) {
+        const int i = j + LPS * t, p = n - H + i;
         nh[t] = (act && i < H) ? (p >= 0 ? w.buf_b[p] : st->fll_hist[H + p]) : cf32{0.f, 0.f};
     }
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { const int i = j + 16 * t; if (act && i < H) st->fll_hist[i] = nh[t]; }
+    for (int t = 0; t < NLD; ++t) { const int i = j + LPS * t; if (act && i < H) st->fll_hist[i] = nh[t]; }
     if (act && j == 0) { st->fll_phase = phase; st->fll_freq = freq; }
 }
 
@@ -1736,7 +1746,8 @@ hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int 
     }
     for (int c = 0; c < nsub; ++c) {
         if (sliced && (e = hipStreamWaitEvent(s1, ev[0][c], 0)) != hipSuccess) return e;
-        if (nstreams >= bank_min) hipLaunchKernelGGL(dvbs_fll4_kernel, dim3((nstreams + FLL4_SPW - 1) / FLL4_SPW), dim3(64), 0, s1, d_work, nstreams, coefs, d_bandedge, c, nsub);
+        // (two streams per wave, dvbs_fll4_kernel<2>: same bits, 9 % slower at 4096 carriers, 15 % at 8192)
+        if (nstreams >= bank_min) hipLaunchKernelGGL(dvbs_fll4_kernel<4>, dim3((nstreams + 3) / 4), dim3(64), 0, s1, d_work, nstreams, coefs, d_bandedge, c, nsub);
         else hipLaunchKernelGGL(dvbs_fll_kernel, dim3(nstreams), dim3(64), 0, s1, d_work, coefs, d_bandedge, c, nsub);
         hipLaunchKernelGGL(dvbs_rrc_kernel, dim3(gx, nstreams), dim3(256), 0, s1, d_work, d_rrc, coefs.ntaps, c, nsub);
         hipLaunchKernelGGL(dvbs_rrc_state_kernel, dim3(nstreams), dim3(128), 0, s1, d_work, coefs.ntaps, c, nsub);
