@@ -334,7 +334,7 @@ struct PendingFec {
 
 // development aid: DVBS2GPU_HOST_TIMING=1 prints where the HOST spends a call (ms since entry at each mark)
 // AGC/NCO + timing recovery of a batch, time-sliced over the caller's stream and its auxiliary stream (ctx.h FeAux, created on first use)
-static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work, int n, const S2LoopCoefs& co, hipStream_t st) {
+static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work, int n, const S2LoopCoefs& co, hipStream_t st, const S2PostStages* post = nullptr) {
     int nsub = ctx->fe_slices;
     if (nsub > S2_FE_MAX_SLICES) nsub = S2_FE_MAX_SLICES;
     S2LoopCoefs cc = co;
@@ -346,11 +346,13 @@ static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work,
         if (!fa->aux) {
             hipError_t e = hipStreamCreateWithFlags(&fa->aux, hipStreamNonBlocking);
             if (e != hipSuccess) return e;
-            for (int i = 0; i <= S2_FE_MAX_SLICES; ++i)
+            for (int i = 0; i <= S2_FE_MAX_SLICES; ++i) {
                 if ((e = hipEventCreateWithFlags(&fa->ev[i], hipEventDisableTiming)) != hipSuccess) return e;
+                if ((e = hipEventCreateWithFlags(&fa->ev2[i], hipEventDisableTiming)) != hipSuccess) return e;
+            }
         }
     }
-    return s2_frontend_launch(d_work, n, cc, ctx->d_gardner_bank, st, fa ? fa->aux : nullptr, fa ? fa->ev : nullptr, nsub);
+    return s2_frontend_launch(d_work, n, cc, ctx->d_gardner_bank, st, fa ? fa->aux : nullptr, fa ? fa->ev : nullptr, nsub, post, fa ? fa->ev2 : nullptr);
 }
 
 struct HostMarks {
@@ -400,20 +402,49 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     float* d_nco = (float*)(d_nsym + n);                                                          // [n]
     int* d_curfill = (int*)(d_nco + n);                                                           // [2n]
     HIP_TRY(hipMemcpyAsync(d_work, work.data(), sizeof(S2StreamWork) * n, hipMemcpyHostToDevice, st));
-    if (!pre_nsym) {
-        // (with pre_nsym the MODCOD-independent stages already ran for the whole batch: frontend_prepass)
-        { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st)); }
-        { StageSpan sp(ctx->timers, ST_RRC, st); HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st)); }
-    }
     // ---- 3: PL sync.  The 2-state realign machine of S2PLSyncBlock runs on the device, one workgroup per stream walking its windows
-    // in order (s2_ccm_walk_kernel); the host only pools the frame tables it gets back (ONE synchronisation for stages 1-3).
+    // in order (s2_ccm_walk_kernel); the host only pools the frame tables it gets back (ONE synchronisation for stages 1-3, or 1-4).
     int maxf = 0;
     for (int i = 0; i < n; ++i) maxf = std::max(maxf, dm[i]->fifo_cap / raw + 2);
     Workspace& ws_win = W[1];
     if ((rc = ws_win.ensure(sizeof(S2VcmFound) * (size_t)n * maxf + sizeof(int) * 4 * n + 64))) return rc;
     S2VcmFound* d_found = (S2VcmFound*)ws_win.p;
     int* d_counts = (int*)(d_found + (size_t)n * maxf);
-    { StageSpan sp(ctx->timers, ST_PLSYNC, st); HIP_TRY(s2_ccm_walk_launch(d_work, n, raw, maxf, d_found, d_counts, st)); }
+    // Stage pipeline (calls of one configuration): RRC, walk and the frame loops run behind every timing-recovery slice on the auxiliary stream
+    // (s2_frontend_launch); a stream's frames stay in its maxf slots of the PLL-output / statistics arrays until the host has pooled the tables.
+    // Not while the decoder of the previous call is the critical path anyway (pipelined mode, the balancer has taken the timing loop's priority
+    // share to its minimum): there the stages back to back leave the decoder more of the SIMDs (headline: 390 vs 394 ms per step).
+    const bool staged = !pre_nsym && ctx->stage_pipeline && !(pipelined && ctx->g_prio_auto && ctx->g_prio_duty <= ctx->stage_pipeline_min_duty);
+    Workspace& ws_pll = W[3];
+    Workspace& ws_slot = W[7];
+    std::vector<S2FrameStats> slot_stats;
+    if (staged) {
+        const size_t nslot = (size_t)n * maxf;
+        if ((rc = ws_pll.ensure(nslot * raw * sizeof(cf32)))) return rc;
+        if ((rc = ws_slot.ensure(sizeof(S2FrameStats) * nslot + 64))) return rc;
+        struct Spans : S2SliceSpans {
+            StageTimers* T; std::unique_ptr<StageSpan> sp[4];
+            void begin(int stage, hipStream_t s) override { sp[stage].reset(new StageSpan(*T, stage == 1 ? ST_RRC : (stage == 2 ? ST_PLSYNC : ST_LOOPS), s)); }
+            void end(int stage, hipStream_t) override { sp[stage].reset(); }
+        } spans;
+        spans.T = &ctx->timers;
+        // how often the frame loops run inside the call: about once per frame a stream gets per call (a launch costs its longest stream's chain,
+        // 11 ms per frame, however few streams have a frame ready)
+        int launches = std::min(S2_FE_MAX_SLICES, std::max(1, (max_count / 2) / raw));
+        if (ctx->stage_pipeline_launches > 0) launches = ctx->stage_pipeline_launches;
+        S2PostStages post{d_taps, d0->cfg.rrc_taps, max_count + max_count / 32 + 8, raw, maxf, d_found, d_counts, ctx->pl, CT->dev, d0->pls_code,
+                          mp.slots, mp.pilots, mp.pilot_blocks, (cf32*)ws_pll.p, (S2FrameStats*)ws_slot.p, ctx->timers.on ? &spans : nullptr, launches};
+        { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st, &post)); }
+        slot_stats.resize(nslot);
+        HIP_TRY(hipMemcpyAsync(slot_stats.data(), ws_slot.p, sizeof(S2FrameStats) * nslot, hipMemcpyDeviceToHost, st));
+    } else {
+        if (!pre_nsym) {
+            // (with pre_nsym the MODCOD-independent stages already ran for the whole batch: frontend_prepass)
+            { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st)); }
+            { StageSpan sp(ctx->timers, ST_RRC, st); HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st)); }
+        }
+        { StageSpan sp(ctx->timers, ST_PLSYNC, st); HIP_TRY(s2_ccm_walk_launch(d_work, n, raw, maxf, d_found, d_counts, st)); }
+    }
     std::vector<S2VcmFound> found((size_t)n * maxf);
     std::vector<int> cnts(4 * n);
     HIP_TRY(hipMemcpyAsync(cnts.data(), d_counts, sizeof(int) * 4 * n, hipMemcpyDeviceToHost, st));
@@ -436,11 +467,15 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     hm.mark("plsync_done");
     // ---- 4..6 on the pooled frames
     std::vector<S2FrameRef> frames;
-    std::vector<int> first(n + 1, 0);
+    std::vector<int> first(n + 1, 0), fslot;
     for (int i = 0; i < n; ++i) {
         first[i] = (int)frames.size();
         const cf32* base = dm[i]->d_fifo[dm[i]->fifo_cur];
-        for (int s : frame_start[i]) { frames.push_back(S2FrameRef{base + s, i, 0}); dm[i]->frame_ptrs.push_back(base + s); dm[i]->frame_pos.push_back(dm[i]->sym_base + s); }
+        int k = 0;
+        for (int s : frame_start[i]) {
+            frames.push_back(S2FrameRef{base + s, i, 0}); dm[i]->frame_ptrs.push_back(base + s); dm[i]->frame_pos.push_back(dm[i]->sym_base + s);
+            fslot.push_back(i * maxf + k++);
+        }
     }
     first[n] = (int)frames.size();
     const int nf = (int)frames.size();
@@ -449,14 +484,14 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     uint8_t* d_bb = nullptr;
     if (nf > 0) {
         Workspace& ws_fr = W[2];
-        if ((rc = ws_fr.ensure(sizeof(S2FrameRef) * nf + sizeof(S2FrameStats) * nf + sizeof(int32_t) * 2 * nf + 64))) return rc;
+        if ((rc = ws_fr.ensure(sizeof(S2FrameRef) * nf + sizeof(S2FrameStats) * nf + sizeof(int32_t) * 3 * nf + 64))) return rc;
         S2FrameRef* d_frames = (S2FrameRef*)ws_fr.p;
         S2FrameStats* d_stats = (S2FrameStats*)(d_frames + nf);
         int32_t* d_trials = (int32_t*)(d_stats + nf);
         int32_t* d_corr = d_trials + nf;
+        int* d_slot = (int*)(d_corr + nf);
         int* d_first = (int*)((char*)ws_work.p + sizeof(S2StreamWork) * n);
         const int par = ctx->fec_parity[slot];
-        Workspace &ws_pll = W[3];
         Workspace &ws_llr = pipelined ? ctx->ws_fecbuf[slot][par][0] : W[4];
         Workspace &ws_bb = pipelined ? ctx->ws_fecbuf[slot][par][1] : W[5];
         if (pipelined) {
@@ -468,7 +503,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             HIP_TRY(hipMemcpyAsync(wj.p, frames.data(), sizeof(S2FrameRef) * nf, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync((char*)wj.p + sizeof(S2FrameRef) * nf, first.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, st));
         }
-        if ((rc = ws_pll.ensure((size_t)nf * raw * sizeof(cf32)))) return rc;
+        if (!staged && (rc = ws_pll.ensure((size_t)nf * raw * sizeof(cf32)))) return rc;
         if ((rc = ws_llr.ensure((size_t)nf * N))) return rc;
         if ((rc = ws_bb.ensure((size_t)nf * kb))) return rc;
         cf32* d_pll = (cf32*)ws_pll.p;
@@ -476,12 +511,15 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         d_bb = (uint8_t*)ws_bb.p;
         HIP_TRY(hipMemcpyAsync(d_frames, frames.data(), sizeof(S2FrameRef) * nf, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(d_first, first.data(), sizeof(int) * (n + 1), hipMemcpyHostToDevice, st));
-        {
+        if (staged) {
+            HIP_TRY(hipMemcpyAsync(d_slot, fslot.data(), sizeof(int) * nf, hipMemcpyHostToDevice, st));
+            for (int f = 0; f < nf; ++f) hstats[f] = slot_stats[fslot[f]];
+        } else {
             StageSpan sp(ctx->timers, ST_LOOPS, st);
             HIP_TRY(s2_frame_loops_launch(d_work, n, d_frames, d_first, d0->co, ctx->pl, CT->dev, d0->pls_code, mp.slots, mp.pilots,
                                           mp.pilot_blocks, raw, d_pll, d_stats, st));
         }
-        { StageSpan sp(ctx->timers, ST_DEMAP, st); HIP_TRY(s2_demap_launch(CT->dev, mp.rate, mp.shortframe, mp.slots, mp.pilots, raw, d_pll, nf, d_llr, N, st)); }
+        { StageSpan sp(ctx->timers, ST_DEMAP, st); HIP_TRY(s2_demap_launch(CT->dev, mp.rate, mp.shortframe, mp.slots, mp.pilots, raw, d_pll, nf, d_llr, N, st, staged ? d_slot : nullptr)); }
         const int force = d0->cfg.force_ldpc_iters > 0;
         const int mt = force ? d0->cfg.force_ldpc_iters : d0->cfg.max_ldpc_trials;
         // keep a copy of the demapper output for the tap before LDPC consumes it? LDPC does not modify d_llr.
@@ -492,10 +530,10 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         } else {
             HIP_TRY(hipEventRecord(ev_llr, st));
         }
-        HIP_TRY(hipMemcpyAsync(hstats.data(), d_stats, sizeof(S2FrameStats) * nf, hipMemcpyDeviceToHost, st));
+        if (!staged) HIP_TRY(hipMemcpyAsync(hstats.data(), d_stats, sizeof(S2FrameStats) * nf, hipMemcpyDeviceToHost, st));
         for (int i = 0; i < n; ++i) {
             int cnt = first[i + 1] - first[i];
-            dm[i]->tap_pll = d_pll + (size_t)first[i] * raw;
+            dm[i]->tap_pll = d_pll + (size_t)(staged ? (size_t)i * maxf : first[i]) * raw;
             dm[i]->tap_llr = d_llr + (size_t)first[i] * N;
             int bytes = cnt * kb;
             if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }

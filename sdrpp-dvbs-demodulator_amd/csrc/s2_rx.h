@@ -29,6 +29,12 @@ struct S2StreamState {
     int vcm_synced;   // ACM/VCM framing: locked to a frame start?
     int pl_pending;   // S2PLSyncBlock state 1 (dvbs2_pl_sync.cpp:145-164): offset of the realigned frame inside the window kept at the FIFO head
     float pl_last_bm; // S2PLSyncBlock::best_match of the last correlation
+    float nco_agc;    // nco_freq as the NCO of the CURRENT call uses it (the frame loops of a call's early time slices already move nco_freq
+                      // while its later AGC / NCO slices run; the reference applies the FED's feedback from the next process() call on)
+    // stage pipeline of a call (s2_frontend_launch with post stages): per time slice what the timing recovery / the RRC decimator have
+    // produced so far, where the PL-sync walk stands and how many of its frames the frame loops have been through
+    int n_fe_slice[8], n_sym_slice[8];
+    int walk_cur, walk_nf, loops_done;
 };
 
 // loop coefficients shared by all streams of one configuration
@@ -161,9 +167,21 @@ hipError_t dvbs_soft_slice_launch(const DvbsStreamWork* d_work, int nstreams, in
 hipError_t dvbs_soft_count_launch(const DvbsStreamWork* d_work, int nstreams, int* d_nblocks, hipStream_t st);
 hipError_t dvbs_soft_compact_launch(const DvbsStreamWork* d_work, int nstreams, hipStream_t st);
 
+constexpr int S2_FE_MAX_SLICES = 8;      // (n_fe_slice[] / n_sym_slice[] of the stream state)
+// What runs behind every timing-recovery slice when the whole CCM front half of a call is pipelined (s2_frontend_launch): RRC + decimation of the
+// slice's samples into the PL-sync FIFO, the PL-sync walk over the symbols that are in, the frame loops over the frames the walk has found so
+// far.  Frame k of stream s lives in SLOT s * maxf + k of d_found / d_pllout / d_stats (the host pools them after the call's one read-back).
+struct S2SliceSpans { virtual void begin(int stage, hipStream_t s) = 0; virtual void end(int stage, hipStream_t s) = 0; virtual ~S2SliceSpans() {} };
+struct S2PostStages {
+    const float* d_taps; int ntaps, max_count;                              // RRC + /2
+    int raw, maxf; S2VcmFound* d_found; int* d_counts;                      // PL-sync walk
+    S2PlTablesDev tabs; S2ConstelDev con; int pls_code, slots, pilots, pilot_blocks; cf32* d_pllout; S2FrameStats* d_stats;   // frame loops
+    S2SliceSpans* spans;                                                    // per-stage timers (optional)
+    int loops_launches;                                                     // the frame loops run behind this many of the slices, evenly spaced, the last one included (every
+                                                                            // launch costs its longest stream's chain: it only pays with about a frame per stream and launch)
+};
 hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCoefs coefs, const float* d_bank, hipStream_t st, hipStream_t aux,
-                              hipEvent_t* ev, int nsub);
-constexpr int S2_FE_MAX_SLICES = 8;
+                              hipEvent_t* ev, int nsub, const S2PostStages* post = nullptr, hipEvent_t* ev2 = nullptr);
 hipError_t s2_rrc_decim_launch(const S2StreamWork* d_work, int nstreams, int max_count, const float* d_taps, int ntaps, hipStream_t st);
 // per-stream frame loops: frames of stream s are d_frames[first[s] .. first[s+1])
 hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const S2FrameRef* d_frames, const int* d_first,
@@ -191,6 +209,6 @@ hipError_t s2_vcm_scatter_launch(const int* d_idx, int count, int kb, const uint
 hipError_t s2_deinterleave_launch(int constel, int rate, int bits, int N, const int8_t* d_in, int nframes, int8_t* d_out, hipStream_t st);
 hipError_t math_eval_launch(int func, int n, const float* a, const float* b, float* o0, float* o1, hipStream_t st);
 hipError_t s2_demap_launch(S2ConstelDev con, int rate, int shortframe, int slots, int pilots, int plframe, const cf32* d_pllout,
-                           int nframes, int8_t* d_llr, int N, hipStream_t st);
+                           int nframes, int8_t* d_llr, int N, hipStream_t st, const int* d_slot = nullptr);   // d_slot: frame f's symbols lie in slot d_slot[f] of d_pllout
 
 }  // namespace s2

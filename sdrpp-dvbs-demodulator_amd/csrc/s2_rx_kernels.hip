@@ -149,7 +149,7 @@ struct AgcS2Traits {                     // FastAGC gain + FreqShift phase recur
     struct Regs { float gain, nph, nfr; };
     static __device__ __forceinline__ const cf32* in_ptr(const Work& w) { return w.in; }
     static __device__ __forceinline__ cf32* out_ptr(const Work& w) { return w.fe_out + fe_scratch_offset(w.count); }
-    static __device__ __forceinline__ Regs load(const Work& w) { return Regs{w.st->agc_gain, w.st->nco_phase, w.st->nco_freq}; }
+    static __device__ __forceinline__ Regs load(const Work& w) { return Regs{w.st->agc_gain, w.st->nco_phase, w.st->nco_agc}; }
     static __device__ __forceinline__ void store(const Work& w, const Regs& r) { w.st->agc_gain = r.gain; w.st->nco_phase = r.nph; }
     static __device__ __forceinline__ cf32 step(Regs& r, cf32 x, const Coefs& co) {
         const cf32 res{r.gain, r.nph};
@@ -370,25 +370,30 @@ __global__ __launch_bounds__(64) void s2_gardner_kernel(const S2StreamWork* __re
         if (c == 0) {
             st->g_phase = pcl.phase; st->g_freq = pcl.freq; st->g_offset = offset - n; st->g_spsctr = spsctr;
             st->n_fe_out = outCount;
+            st->n_fe_slice[sub & (S2_FE_MAX_SLICES - 1)] = outCount;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ RRC + /2
 // grid (x: symbol tiles, y: stream).  Only the samples the decimator keeps are filtered.
-__global__ __launch_bounds__(256) void s2_rrc_decim_kernel(const S2StreamWork* __restrict__ work, const float* __restrict__ taps_g, int ntaps) {
+// sub / nsub: only the symbols whose windows the timing recovery's slice `sub` completed (the decimator phase and the delay line are
+// the call's: they change in s2_rrc_state_kernel, after the last slice); nsub == 1: the whole call
+__global__ __launch_bounds__(256) void s2_rrc_decim_kernel(const S2StreamWork* __restrict__ work, const float* __restrict__ taps_g, int ntaps, int sub, int nsub) {
     // a block = 256 consecutive kept symbols of one stream; their 2*256 + ntaps - 2 input samples go through LDS once (each is
     // used by up to (ntaps+1)/2 outputs: reading them from L2 per output cost 46 GB per step and competed with the LDPC messages)
     __shared__ float taps[RRC_MAX_TAPS];
     __shared__ float sre[2 * 256 + RRC_MAX_TAPS], sim[2 * 256 + RRC_MAX_TAPS];
     for (int i = threadIdx.x; i < ntaps; i += 256) taps[i] = taps_g[i];
     const S2StreamWork w = work[blockIdx.y];
-    const S2StreamState* st = w.st;
-    const int n = st->n_fe_out;
+    S2StreamState* st = w.st;
+    const int n = nsub > 1 ? st->n_fe_slice[sub] : st->n_fe_out, n_before = (nsub > 1 && sub) ? st->n_fe_slice[sub - 1] : 0;
     const int first = st->cr_samp ? 0 : 1;            // first kept index (module_dvbs2_demod.cpp:231-239)
     const int nsym = n > first ? (n - first + 1) / 2 : 0;
+    const int sym_before = n_before > first ? (n_before - first + 1) / 2 : 0;
     const int H = ntaps - 1;
-    for (int m0 = blockIdx.x * 256; m0 < nsym; m0 += gridDim.x * 256) {
+    if (nsub > 1 && blockIdx.x == 0 && threadIdx.x == 0) st->n_sym_slice[sub] = nsym;
+    for (int m0 = sym_before + blockIdx.x * 256; m0 < nsym; m0 += gridDim.x * 256) {
         const int i0 = 2 * m0 + first;                // index of the block's first window in [history(H) ++ fe_out]
         const int cnt = min(256, nsym - m0);
         const int need = 2 * (cnt - 1) + ntaps;
@@ -526,7 +531,9 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
                                                             const S2FrameRef* __restrict__ frames, const int* __restrict__ first,
                                                             S2LoopCoefs co, S2PlTablesDev T, S2ConstelDev C, int pls_code, int slots,
                                                             int pilots, int pilot_blocks, int plframe, cf32* __restrict__ pllout,
-                                                            S2FrameStats* __restrict__ stats) {
+                                                            S2FrameStats* __restrict__ stats, const S2VcmFound* __restrict__ found, int maxf) {
+    // found != nullptr (stage pipeline): no pooled frame table -- frame k of stream s is slot s * maxf + k of found / pllout / stats, and
+    // this launch goes through the frames the PL-sync walk has found (walk_nf) beyond those an earlier slice's launch did (loops_done)
     static_assert(2 * FL_TILE >= 90 && 2 * FL_TILE >= 88 && FL_TILE >= 36, "input + output tile hold the 90 header symbols; the output tile alone the 88 FED terms");
     __shared__ cf32 tiles[FL_SPW][2 * FL_TILE]; // per stream: [input tile | output tile]
     __shared__ uint8_t rnt[FL_TILE];
@@ -545,7 +552,8 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
     float nco_freq = st->nco_freq;
     const float PI_F = 3.14159265358979323846f;
     const cf32* __restrict__ plsc = T.plsc + (size_t)pls_code * 64;
-    const int f0 = first[sc], nf = act ? first[sc + 1] - f0 : 0;
+    const int done = found ? st->loops_done : 0;
+    const int f0 = found ? sc * maxf + done : first[sc], nf = !act ? 0 : (found ? st->walk_nf - done : first[sc + 1] - f0);
     __builtin_amdgcn_s_setprio(FL_PRIO);       // latency-critical serial loops (see agc_pc_kernel)
     int nfmax = nf;
 #pragma unroll
@@ -558,7 +566,7 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
         const int f = fact ? fown : fdon;
         const PclDev pll_in = pll, hdr_in = hdr;
         const float nco_in = nco_freq;
-        const cf32* __restrict__ fr = frames[f].sym;
+        const cf32* __restrict__ fr = found ? work[f / maxf].fifo + found[f].offset : frames[f].sym;
         cf32* __restrict__ out = pllout + (size_t)f * plframe;
         // ---- coarse frequency error detector (dvbs2_fed.h): terms in parallel, summed in the reference's order
         #pragma unroll 1
@@ -730,6 +738,7 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
         st->pll_phase = pll.phase; st->pll_freq = pll.freq;
         st->hdr_phase = hdr.phase; st->hdr_freq = hdr.freq;
         st->nco_freq = nco_freq;
+        if (found) st->loops_done = done + nf;
     }
 }
 
@@ -744,9 +753,9 @@ __device__ __forceinline__ int deint_pos(int constel, int rate, int bits, int ro
 // grid (x: symbol tiles, y: frame).  LUT fetch + bit de-interleave fused: LLR c of payload symbol j goes to
 // column c (8PSK 3/5: columns reversed), QPSK just swaps the pair.
 __global__ __launch_bounds__(256) void s2_demap_kernel(S2ConstelDev C, int rate, int slots, int pilots, int plframe,
-                                                       const cf32* __restrict__ pllout, int8_t* __restrict__ llr, int N) {
+                                                       const cf32* __restrict__ pllout, int8_t* __restrict__ llr, int N, const int* __restrict__ slot) {
     const int f = blockIdx.y;
-    const cf32* __restrict__ fr = pllout + (size_t)f * plframe;
+    const cf32* __restrict__ fr = pllout + (size_t)(slot ? slot[f] : f) * plframe;      // (stage pipeline: the loops wrote frame f to its stream's slot)
     int8_t* __restrict__ out = llr + (size_t)f * N;
     const int nsym = slots * 90;
     const int bits = C.bits;
@@ -782,8 +791,11 @@ __global__ __launch_bounds__(256) void s2_deinterleave_kernel(int constel, int r
 // window[pos:] plus `pos` more symbols -- taken if they are in, else the window stays at the FIFO head and the stream waits in state 1
 // (pl_pending) for the next call.  A frame carries the best_match of the correlation that placed it (the reference's member
 // variable).  Per stream out: the frames' FIFO offsets, consumed symbols, symbols available, symbols this call added.
+// sub / nsub: the walk of a call in time slices (stage pipeline): slice `sub` sees the symbols the RRC slices 0..sub have appended and resumes
+// where slice sub - 1 stopped (walk_cur / walk_nf in the stream state); the frames come out as in one walk over the whole call, because a window
+// is only ever looked at once it is complete and a realigned frame that is not all in yet waits (pl_pending) exactly as it does between calls.
 __global__ __launch_bounds__(256) void s2_ccm_walk_kernel(const S2StreamWork* __restrict__ work, int raw, int maxf, S2VcmFound* __restrict__ found,
-                                                          int* __restrict__ counts) {
+                                                          int* __restrict__ counts, int sub, int nsub) {
     __shared__ cf32 d[256 + 96];
     __shared__ float r_val[256];
     __shared__ int r_idx[256];
@@ -791,20 +803,20 @@ __global__ __launch_bounds__(256) void s2_ccm_walk_kernel(const S2StreamWork* __
     const S2StreamWork w = work[s];
     S2StreamState* st = w.st;
     const cf32* __restrict__ fifo = w.fifo;
-    const int nsym = st->n_sym;
+    const int nsym = nsub > 1 ? st->n_sym_slice[sub] : st->n_sym;
     const int avail = w.fifo_fill + nsym;
-    int pend = st->pl_pending, cur = 0, nf = 0;
+    int pend = st->pl_pending, cur = (nsub > 1 && sub) ? st->walk_cur : 0, nf = (nsub > 1 && sub) ? st->walk_nf : 0;
     float lastbm = st->pl_last_bm;
     const uint32_t dsof = 0x18d2e82u ^ (0x18d2e82u >> 1);
     const unsigned long long SCR = 0x719d83c953422dfaull;
     const unsigned long long dscr = SCR ^ (SCR >> 1);
     const int noff = raw - 90;
     bool waiting = false;
-    if (pend > 0) {
-        if (avail >= raw + pend) {
-            if (tid == 0) found[(size_t)s * maxf + nf] = S2VcmFound{pend, 0, lastbm, 0};
+    if (pend > 0) {                 // (the window the realigned frame starts in lies at `cur`: the FIFO head at the start of a call)
+        if (avail >= cur + raw + pend) {
+            if (tid == 0) found[(size_t)s * maxf + nf] = S2VcmFound{cur + pend, 0, lastbm, 0};
             ++nf;
-            cur = raw + pend;
+            cur += raw + pend;
             pend = 0;
         } else {
             waiting = true;
@@ -875,6 +887,8 @@ __global__ __launch_bounds__(256) void s2_ccm_walk_kernel(const S2StreamWork* __
     }
     if (tid == 0) {
         st->pl_pending = pend; st->pl_last_bm = lastbm;
+        st->walk_cur = cur; st->walk_nf = nf;
+        if (sub == 0) st->loops_done = 0;
         counts[4 * s] = nf; counts[4 * s + 1] = cur; counts[4 * s + 2] = avail; counts[4 * s + 3] = nsym;
     }
 }
@@ -1206,7 +1220,11 @@ __global__ __launch_bounds__(256) void s2_vcm_scatter_kernel(const int* __restri
 // ------------------------------------------------------------------------------------------------ call tails
 __global__ void s2_collect_kernel(const S2StreamWork* __restrict__ work, int nstreams, int* __restrict__ nsym, float* __restrict__ nco) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < nstreams) { nsym[s] = work[s].st->n_sym; nco[s] = work[s].st->nco_freq; }
+    if (s < nstreams) {
+        S2StreamState* st = work[s].st;
+        nsym[s] = st->n_sym; nco[s] = st->nco_freq;
+        st->nco_agc = st->nco_freq;              // the FED's feedback of this call's frames steers the NCO from the next call on
+    }
 }
 __global__ __launch_bounds__(256) void s2_scatter_out_kernel(const S2StreamWork* __restrict__ work, const S2FrameRef* __restrict__ frames,
                                                              const int* __restrict__ first, int kb, const uint8_t* __restrict__ bb) {
@@ -1786,22 +1804,66 @@ hipError_t dvbs_soft_compact_launch(const DvbsStreamWork* d_work, int nstreams, 
 // per wave, few waves) run on `aux` one slice ahead of the timing loop (8 streams per wave) on `st`, which waits for each slice's event.
 // Both are latency chains that leave most of the GPU idle, so side by side they cost the longer of the two instead of the sum.
 // ev: nsub + 1 events (the last one orders `aux` behind what `st` holds when the call starts).  nsub <= 1 or no aux stream: one slice on st.
+//
+// With `post` (CCM calls of one configuration) the rest of the front half joins the pipeline: behind every timing-recovery slice the auxiliary
+// stream -- the AGC slices stay two ahead of the timing loop, then it is free -- appends the slice's symbols to the PL-sync FIFO (RRC + /2),
+// walks the windows that are complete and runs the frame loops (FED, PLL, PLHDR: the call's other long latency chain) over the frames found
+// so far, while the timing loop works on the next slice.  No host in between: frames stay in per-stream slots (S2PostStages), the host reads
+// the frame tables once, after the last slice.  ev2: nsub + 1 more events (timing recovery of slice c done; the last: post stages done).
+static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const S2PostStages& p, int c, int nsub, hipStream_t s) {
+    int gx = ((p.max_count / nsub) / 2 + 2 + 255) / 256;
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    if (p.spans) p.spans->begin(1, s);
+    hipLaunchKernelGGL(s2_rrc_decim_kernel, dim3(gx, nstreams), dim3(256), 0, s, d_work, p.d_taps, p.ntaps, c, nsub);
+    if (c == nsub - 1) hipLaunchKernelGGL(s2_rrc_state_kernel, dim3(nstreams), dim3(128), 0, s, d_work, p.ntaps);
+    if (p.spans) { p.spans->end(1, s); p.spans->begin(2, s); }
+    hipLaunchKernelGGL(s2_ccm_walk_kernel, dim3(nstreams), dim3(256), 0, s, d_work, p.raw, p.maxf, p.d_found, p.d_counts, c, nsub);
+    if (p.spans) p.spans->end(2, s);
+    const int L = p.loops_launches < 1 ? 1 : (p.loops_launches > nsub ? nsub : p.loops_launches);
+    if ((c + 1) * L / nsub > c * L / nsub) {
+        if (p.spans) p.spans->begin(3, s);
+        hipLaunchKernelGGL(s2_frame_loops_kernel, dim3((nstreams + FL_SPW - 1) / FL_SPW), dim3(64), 0, s, d_work, nstreams, (const S2FrameRef*)nullptr,
+                           (const int*)nullptr, coefs, p.tabs, p.con, p.pls_code, p.slots, p.pilots, p.pilot_blocks, p.raw, p.d_pllout, p.d_stats,
+                           (const S2VcmFound*)p.d_found, p.maxf);
+        if (p.spans) p.spans->end(3, s);
+    }
+    return hipGetLastError();
+}
 hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCoefs coefs, const float* d_bank, hipStream_t st, hipStream_t aux,
-                              hipEvent_t* ev, int nsub) {
+                              hipEvent_t* ev, int nsub, const S2PostStages* post, hipEvent_t* ev2) {
     const dim3 ga((nstreams + 63) / 64), gg((nstreams + G_SPW - 1) / G_SPW);
-    if (nsub <= 1 || !aux || !ev) {
+    if (nsub <= 1 || !aux || !ev || (post && !ev2)) {
         hipLaunchKernelGGL(agc_pc_kernel<AgcS2Traits>, ga, dim3(128), 0, st, d_work, nstreams, coefs, 0, 1);
         hipLaunchKernelGGL(s2_gardner_kernel, gg, dim3(64), 0, st, d_work, nstreams, coefs, d_bank, 0, 1);
+        if (post) return post_stages_launch(d_work, nstreams, coefs, *post, 0, 1, st);
         return hipGetLastError();
     }
     hipError_t e;
     if ((e = hipEventRecord(ev[nsub], st)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(aux, ev[nsub], 0)) != hipSuccess) return e;
+    int agc_next = 0;
+    auto agc_upto = [&](int k) -> hipError_t {
+        for (; agc_next <= k && agc_next < nsub; ++agc_next) {
+            hipLaunchKernelGGL(agc_pc_kernel<AgcS2Traits>, ga, dim3(128), 0, aux, d_work, nstreams, coefs, agc_next, nsub);
+            hipError_t e2 = hipEventRecord(ev[agc_next], aux);
+            if (e2 != hipSuccess) return e2;
+        }
+        return hipSuccess;
+    };
     for (int c = 0; c < nsub; ++c) {
-        hipLaunchKernelGGL(agc_pc_kernel<AgcS2Traits>, ga, dim3(128), 0, aux, d_work, nstreams, coefs, c, nsub);
-        if ((e = hipEventRecord(ev[c], aux)) != hipSuccess) return e;
+        if ((e = agc_upto(post ? c + 1 : c)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(st, ev[c], 0)) != hipSuccess) return e;
         hipLaunchKernelGGL(s2_gardner_kernel, gg, dim3(64), 0, st, d_work, nstreams, coefs, d_bank, c, nsub);
+        if (post) {
+            if ((e = hipEventRecord(ev2[c], st)) != hipSuccess) return e;
+            if ((e = agc_upto(c + 2)) != hipSuccess) return e;              // (the AGC stays ahead of the timing loop: its next slices go in before this slice's post stages)
+            if ((e = hipStreamWaitEvent(aux, ev2[c], 0)) != hipSuccess) return e;
+            if ((e = post_stages_launch(d_work, nstreams, coefs, *post, c, nsub, aux)) != hipSuccess) return e;
+        }
+    }
+    if (post) {
+        if ((e = hipEventRecord(ev2[nsub], aux)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(st, ev2[nsub], 0)) != hipSuccess) return e;
     }
     return hipGetLastError();
 }
@@ -1809,7 +1871,7 @@ hipError_t s2_rrc_decim_launch(const S2StreamWork* d_work, int nstreams, int max
     int gx = (max_count / 2 + 2 + 255) / 256;
     if (gx < 1) gx = 1;
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(s2_rrc_decim_kernel, dim3(gx, nstreams), dim3(256), 0, st, d_work, d_taps, ntaps);
+    hipLaunchKernelGGL(s2_rrc_decim_kernel, dim3(gx, nstreams), dim3(256), 0, st, d_work, d_taps, ntaps, 0, 1);
     hipLaunchKernelGGL(s2_rrc_state_kernel, dim3(nstreams), dim3(128), 0, st, d_work, ntaps);
     return hipGetLastError();
 }
@@ -1817,11 +1879,11 @@ hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const
                                  S2LoopCoefs coefs, S2PlTablesDev tabs, S2ConstelDev con, int pls_code, int slots, int pilots,
                                  int pilot_blocks, int plframe, cf32* d_pllout, S2FrameStats* d_stats, hipStream_t st) {
     hipLaunchKernelGGL(s2_frame_loops_kernel, dim3((nstreams + FL_SPW - 1) / FL_SPW), dim3(64), 0, st, d_work, nstreams, d_frames, d_first, coefs,
-                       tabs, con, pls_code, slots, pilots, pilot_blocks, plframe, d_pllout, d_stats);
+                       tabs, con, pls_code, slots, pilots, pilot_blocks, plframe, d_pllout, d_stats, (const S2VcmFound*)nullptr, 0);
     return hipGetLastError();
 }
 hipError_t s2_ccm_walk_launch(const S2StreamWork* d_work, int nstreams, int raw, int maxf, S2VcmFound* d_found, int* d_counts, hipStream_t st) {
-    hipLaunchKernelGGL(s2_ccm_walk_kernel, dim3(nstreams), dim3(256), 0, st, d_work, raw, maxf, d_found, d_counts);
+    hipLaunchKernelGGL(s2_ccm_walk_kernel, dim3(nstreams), dim3(256), 0, st, d_work, raw, maxf, d_found, d_counts, 0, 1);
     return hipGetLastError();
 }
 hipError_t s2_vcm_walk_launch(const S2StreamWork* d_work, int nstreams, S2PlTablesDev tabs, const S2VcmMod* d_mods, float sof_threshold, int maxf,
@@ -1853,10 +1915,10 @@ hipError_t s2_deinterleave_launch(int constel, int rate, int bits, int N, const 
     return hipGetLastError();
 }
 hipError_t s2_demap_launch(S2ConstelDev con, int rate, int shortframe, int slots, int pilots, int plframe, const cf32* d_pllout,
-                           int nframes, int8_t* d_llr, int N, hipStream_t st) {
+                           int nframes, int8_t* d_llr, int N, hipStream_t st, const int* d_slot) {
     (void)shortframe;
     int gx = (slots * 90 + 255) / 256;
-    hipLaunchKernelGGL(s2_demap_kernel, dim3(gx, nframes), dim3(256), 0, st, con, rate, slots, pilots, plframe, d_pllout, d_llr, N);
+    hipLaunchKernelGGL(s2_demap_kernel, dim3(gx, nframes), dim3(256), 0, st, con, rate, slots, pilots, plframe, d_pllout, d_llr, N, d_slot);
     return hipGetLastError();
 }
 

@@ -604,7 +604,7 @@ def test_soft_plsc_and_pilot_aided_modes_equal_oracle(engine, modcod, short, pil
 def test_time_sliced_front_end_changes_nothing(engine, pkg):
     """the AGC/NCO and timing-recovery stages keep their state in the stream record, so running a call's samples as 1, 4 (default) or 8
     time slices -- the AGC of slice c+1 beside the Gardner loop of slice c on an auxiliary stream -- must give the same bytes, call by call
-    (DVBS2GPU_FE_SLICES is read when a context is created)"""
+    (the DVBS2GPU_* switches are read when a context is created)"""
     import os, torch
     modcod, S = 14, 6
     iqs = []
@@ -630,18 +630,27 @@ def test_time_sliced_front_end_changes_nothing(engine, pkg):
 
     ref = run(engine)
     assert sum(x.size for x in ref[0] + ref[2] + ref[4]) > 0
-    old = os.environ.get('DVBS2GPU_FE_SLICES')
+    # ... and so do the later stages: with the stage pipeline (default) the RRC decimator, the PL-sync walk and the frame loops run behind
+    # every timing-recovery slice, frames in per-stream slots; without it (DVBS2GPU_STAGE_PIPELINE=0) after the last slice on frames the host
+    # pooled; DVBS2GPU_STAGE_LOOPS fixes how many of the slices are followed by a frame-loop launch
+    names = ('DVBS2GPU_FE_SLICES', 'DVBS2GPU_STAGE_PIPELINE', 'DVBS2GPU_STAGE_LOOPS')
+    old = {k: os.environ.get(k) for k in names}
     try:
-        for k in ('1', '8'):
-            os.environ['DVBS2GPU_FE_SLICES'] = k
+        for env in ({'DVBS2GPU_FE_SLICES': '1'}, {'DVBS2GPU_FE_SLICES': '8'}, {'DVBS2GPU_STAGE_PIPELINE': '0'},
+                    {'DVBS2GPU_STAGE_PIPELINE': '0', 'DVBS2GPU_FE_SLICES': '1'}, {'DVBS2GPU_STAGE_LOOPS': '4'},
+                    {'DVBS2GPU_STAGE_LOOPS': '3', 'DVBS2GPU_FE_SLICES': '8'}, {'DVBS2GPU_STAGE_LOOPS': '1'}):
+            for k in names:
+                os.environ.pop(k, None)
+            os.environ.update(env)
             e2 = pkg.Engine(0)
             got = run(e2)
             e2.close()
             for a, b in zip(ref, got):
                 for x, y in zip(a, b):
-                    assert np.array_equal(x, y)
+                    assert np.array_equal(x, y), env
     finally:
-        if old is None:
-            os.environ.pop('DVBS2GPU_FE_SLICES', None)
-        else:
-            os.environ['DVBS2GPU_FE_SLICES'] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
