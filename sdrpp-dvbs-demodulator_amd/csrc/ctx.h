@@ -143,6 +143,7 @@ struct dvbs2gpu_ctx {
     std::map<hipStream_t, FeAux> fe_aux;
     int stage_pipeline_launches = 0;          // DVBS2GPU_STAGE_LOOPS: frame-loop launches per call (0 = chosen per call, s2_demod.hip)
     int stage_pipeline_min_duty = 0;          // DVBS2GPU_STAGE_MIN_DUTY: pipelined mode uses the stage pipeline only above this balancer setting (-1: always)
+    unsigned stage_calls = 0;
     int stage_pipeline = 1;                   // DVBS2GPU_STAGE_PIPELINE: RRC, PL-sync walk and frame loops of a CCM call behind every timing-recovery slice (0: after the last one, frames pooled by the host first)
     int fe_slices = 4;                        // DVBS2GPU_FE_SLICES (1 = both stages back to back on the caller's stream)
     // balance of the two streams of the pipelined mode (s2_demod.hip): share of the timing loop's tiles that run one priority level up

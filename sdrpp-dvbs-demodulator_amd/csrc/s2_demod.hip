@@ -414,7 +414,9 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     // (s2_frontend_launch); a stream's frames stay in its maxf slots of the PLL-output / statistics arrays until the host has pooled the tables.
     // Not while the decoder of the previous call is the critical path anyway (pipelined mode, the balancer has taken the timing loop's priority
     // share to its minimum): there the stages back to back leave the decoder more of the SIMDs (headline: 390 vs 394 ms per step).
-    const bool staged = !pre_nsym && ctx->stage_pipeline && !(pipelined && ctx->g_prio_auto && ctx->g_prio_duty <= ctx->stage_pipeline_min_duty);
+    // (stage_pipeline == 2, for the tests: every other call, whatever the mode -- the two flows leave a stream in the same state)
+    const bool staged = !pre_nsym && (ctx->stage_pipeline == 2 ? (ctx->stage_calls++ & 1) != 0 :
+        ctx->stage_pipeline && !(pipelined && ctx->g_prio_auto && ctx->g_prio_duty <= ctx->stage_pipeline_min_duty));
     Workspace& ws_pll = W[3];
     Workspace& ws_slot = W[7];
     std::vector<S2FrameStats> slot_stats;

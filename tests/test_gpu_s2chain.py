@@ -262,6 +262,61 @@ def test_mixed_modcod_batch_matches_single(engine):
         d.close()
 
 
+def test_pipelined_mode_with_and_without_the_stage_pipeline(engine, pkg):
+    """throughput mode: a call runs its RRC / PL sync / frame loops either behind the timing-recovery slices (stage pipeline) or after the
+    last one, as the balancer sees fit -- so the flow may change from call to call.  Always, never and every other call
+    (DVBS2GPU_STAGE_PIPELINE=2) must deliver the same bytes and statistics, call by call"""
+    import os, torch
+    S, calls = 5, 6
+    iqs = [orc.transmit(13, 0, 1, nframes=2 * calls, seed=940 + s, esn0_db=13.0, cfo=7e-4, timing=0.1 * s, phase0=0.2, lead_symbols=100 + 41 * s)[0] for s in range(S)]
+    kb = pkg.modcod_info(13, False, True)['kbch'] // 8
+    chunk = min(i.size for i in iqs) // calls
+
+    def run(eng):
+        cfg = eng.default_cfg(13, False, True)
+        demods = [eng.demod(cfg, max_samples=chunk) for _ in range(S)]
+        tout = [torch.zeros(6 * kb, dtype=torch.uint8, device='cuda') for _ in range(S)]
+        eng.set_pipelined(True)
+        outs = []
+        try:
+            for c in range(calls + 1):
+                tin = [torch.from_numpy(np.ascontiguousarray(iqs[s][c * chunk:(c + 1) * chunk])).cuda() if c < calls
+                       else torch.empty(0, dtype=torch.complex64, device='cuda') for s in range(S)]
+                nb = eng.process_batch(demods, tin, tout)
+                outs.append(([tout[s][:nb[s]].cpu().numpy().copy() for s in range(S)],
+                             [[(x.ldpc_trials, x.bch_corrections, x.detected_modcod, x.coarse_freq_err, x.pl_sync_best_match) for x in d.stats()] for d in demods],
+                             [d.nco_freq() for d in demods]))
+        finally:
+            eng.set_pipelined(False)
+            for d in demods:
+                d.close()
+        return outs
+
+    names = ('DVBS2GPU_STAGE_PIPELINE', 'DVBS2GPU_STAGE_MIN_DUTY')
+    old = {k: os.environ.get(k) for k in names}
+    res = []
+    try:
+        for env in ({'DVBS2GPU_STAGE_PIPELINE': '0'}, {'DVBS2GPU_STAGE_MIN_DUTY': '-1'}, {'DVBS2GPU_STAGE_PIPELINE': '2'}):
+            for k in names:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            e2 = pkg.Engine(0)
+            res.append(run(e2))
+            e2.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert sum(len(x) for c in res[0] for x in c[0]) >= S * (2 * calls - 4) * kb
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            for x, y in zip(a[0], b[0]):
+                assert np.array_equal(x, y)
+            assert a[1] == b[1] and a[2] == b[2]
+
+
 def test_pipelined_full_load_every_stream_bit_exact(engine, pkg):
     """Throughput mode at the bench's load (2048 streams, 8PSK 3/4 normal frames, 50 forced LDPC iterations): the decoder of call k
     shares the CUs with the front-end kernels of call k+1 for several multi-frame rounds per workgroup.  Every byte every stream delivers
