@@ -511,6 +511,7 @@ def main():
     ap.add_argument('--streams', type=int, default=4096, help='transponder streams per GPU')
     ap.add_argument('--frames', type=int, default=8, help='PLFRAMEs per stream per step')
     ap.add_argument('--distinct', type=int, default=DISTINCT, help='distinct signal blocks (every stream gets a private, shifted copy)')
+    ap.add_argument('--mixed-frames', type=int, default=1, help='config mixed64: PLFRAMEs per sub-stream per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip configs 2, 5, D and the mixed-MODCOD batch')
     ap.add_argument('--no-pipeline', action='store_true', help='run the FEC inside the call that produced the frames (no overlap with the next front end)')
@@ -552,7 +553,7 @@ def main():
         torch.cuda.synchronize()
 
     if args.config == 'mixed64':
-        res = mixed64(eng, pkg, dev, dd, args.steps, args.warmup)
+        res = mixed64(eng, pkg, dev, dd, args.steps, args.warmup, F=args.mixed_frames)
         if rank == 0:
             line = {'metric': 'Msymbols/s demod+FEC, 64 mixed-MODCOD DVB-S2 transponders @50 LDPC iters (BASELINE config 4)', 'value': res['value'],
                     'unit': 'Msymbols/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': res['ms_per_step'],
@@ -644,7 +645,7 @@ def main():
     if not args.no_secondary:
         # BASELINE config 4 runs on every world size (strong scaling; at N = 1 it is the one-GPU number)
         try:
-            m64 = mixed64(eng, pkg, dev, dd, 4, 1)
+            m64 = mixed64(eng, pkg, dev, dd, 10, 1, F=args.mixed_frames)
         except Exception as e:
             m64 = {'error': repr(e)}
         if rank == 0:
