@@ -1296,8 +1296,6 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
         al = cadd(al, cmul(xs, bandedge[jt]));
         ah = cadd(ah, cmul(xs, bandedge[T + jt]));
     }
-    cf32 last_x[1];
-    (void)last_x;
     for (int base = 0; base < n; base += 64) {
         const int m = min(64, n - base);
         __syncthreads();
@@ -1389,6 +1387,7 @@ __global__ __launch_bounds__(64) void dvbs_fll4_kernel(const DvbsStreamWork* __r
     for (int o = LPS; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o));
     // the finished sum leaves the stream's last lane: its error goes to the whole group (ds_swizzle: lane (l & ~(LPS - 1)) | (LPS - 1) of each 32)
     constexpr int SWZ = ((32 - 1) & ~(LPS - 1)) | ((LPS - 1) << 5);
+    __builtin_amdgcn_s_setprio(FE_PRIO);       // the bank's longest latency chain: ahead of the kernels that fill the SIMDs beside it
     for (int base = 0; base < nmax; base += 64) {
         const int m = min(64, n - base), mmax = min(64, nmax - base);
         __syncthreads();
