@@ -327,7 +327,9 @@ int dvbs2gpu_dvbs_demod_create(dvbs2gpu_ctx* ctx, const dvbs2gpu_dvbs_cfg* cfg, 
 int dvbs2gpu_dvbs_demod_reset(dvbs2gpu_dvbs_demod* d);                        /* DVBSDemod::reset + a fresh Viterbi_DVBS */
 void dvbs2gpu_dvbs_demod_destroy(dvbs2gpu_dvbs_demod* d);
 /* DVBSDemod::process (module_dvbs_demod.cpp:78-81) for a bank with nstreams == 1: host buffers, returns the number of decoded
- * bits written to h_bits (one per byte) or a negative error.  Synchronous. */
+ * bits written to h_bits (one per byte) or a negative error.  Synchronous.  Rate 5/6 only: of the 6826-6827 bits a Viterbi block
+ * advances the output by, the reference's decoder writes 6799 (viterbi_all.cpp:246-249, cc_decoder.cpp:304-314) and leaves the rest
+ * of its caller's buffer as it was; here those 27-28 bits are written as 0. */
 int dvbs2gpu_dvbs_demod_process(dvbs2gpu_dvbs_demod* d, int count, const float* h_iq, uint8_t* h_bits, int cap);
 /* All streams of the bank in one go: d_iq[i] DEVICE pointers to counts[i] complex samples, d_bits[i] DEVICE buffers of cap
  * bytes; out_counts[i] (host) = bits written for stream i.  Synchronous. */
