@@ -227,6 +227,7 @@ int dvbs2gpu_create(int device, dvbs2gpu_ctx** out) {
     if (const char* v = getenv("DVBS2GPU_DVBS_BANK_MIN")) { int k = atoi(v); if (k >= 1) c->dvbs_bank_min = k; }
     if (const char* v = getenv("DVBS2GPU_DVBS_FE_SLICES")) { int k = atoi(v); if (k >= 1 && k <= s2::DVBS_FE_MAX_SLICES) c->dvbs_fe_slices = k; }
     if (const char* v = getenv("DVBS2GPU_STAGE_PIPELINE")) c->stage_pipeline = atoi(v);
+    if (const char* v = getenv("DVBS2GPU_STAGE_POST_STREAM")) c->stage_post_stream = atoi(v) != 0;
     if (const char* v = getenv("DVBS2GPU_STAGE_LOOPS")) c->stage_pipeline_launches = atoi(v);
     if (const char* v = getenv("DVBS2GPU_STAGE_MIN_DUTY")) c->stage_pipeline_min_duty = atoi(v);
     if (const char* v = getenv("DVBS2GPU_FE_SLICES")) { int k = atoi(v); if (k >= 1 && k <= s2::S2_FE_MAX_SLICES) c->fe_slices = k; }   // (A/B switch)
@@ -272,6 +273,7 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
         if (kv.second.aux) (void)hipStreamDestroy(kv.second.aux);
         for (hipEvent_t e : kv.second.ev) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : kv.second.ev2) if (e) (void)hipEventDestroy(e);
+        if (kv.second.aux2) (void)hipStreamDestroy(kv.second.aux2);
         for (hipStream_t a : kv.second.dvbs_aux) if (a) (void)hipStreamDestroy(a);
         for (auto& row : kv.second.dvbs_ev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
     }

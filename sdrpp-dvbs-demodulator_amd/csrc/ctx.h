@@ -139,13 +139,14 @@ struct dvbs2gpu_ctx {
     hipEvent_t ev_llr_grp[MAX_PIPE_GROUPS] = {};
     std::mutex fec_mtx;                                   // FEC jobs are enqueued whole, one at a time (shared FEC workspaces, one stream)
     // time-sliced front end (s2_rx_kernels.hip, s2_frontend_launch): per main stream one auxiliary stream + the slice events
-    struct FeAux { hipStream_t aux = nullptr; hipEvent_t ev[9] = {}, ev2[9] = {}; hipStream_t dvbs_aux[4] = {}; hipEvent_t dvbs_ev[4][s2::DVBS_FE_MAX_SLICES + 1] = {}; };   // (dvbs_*: the DVB-S receiver's stage streams: AGC, FLL, RRC, soft FIFO + Viterbi)
+    struct FeAux { hipStream_t aux = nullptr, aux2 = nullptr; hipEvent_t ev[9] = {}, ev2[9] = {}; hipStream_t dvbs_aux[4] = {}; hipEvent_t dvbs_ev[4][s2::DVBS_FE_MAX_SLICES + 1] = {}; };   // (dvbs_*: the DVB-S receiver's stage streams: AGC, FLL, RRC, soft FIFO + Viterbi)
     std::map<hipStream_t, FeAux> fe_aux;
     int stage_pipeline_launches = 0;          // DVBS2GPU_STAGE_LOOPS: frame-loop launches per call (0 = chosen per call, s2_demod.hip)
     int stage_pipeline_min_duty = 0;          // DVBS2GPU_STAGE_MIN_DUTY: pipelined mode uses the stage pipeline only above this balancer setting (-1: always)
+    int stage_post_stream = 1;                // DVBS2GPU_STAGE_POST_STREAM: synchronous mode runs the post stages on a stream of their own (0: on the AGC's)
     unsigned stage_calls = 0;
     int stage_pipeline = 1;                   // DVBS2GPU_STAGE_PIPELINE: RRC, PL-sync walk and frame loops of a CCM call behind every timing-recovery slice (0: after the last one, frames pooled by the host first)
-    int fe_slices = 4;                        // DVBS2GPU_FE_SLICES (1 = both stages back to back on the caller's stream)
+    int fe_slices = 0;                        // DVBS2GPU_FE_SLICES (0 = by mode: 4 pipelined, 8 synchronous; 1 = both stages back to back on the caller's stream)
     // balance of the two streams of the pipelined mode (s2_demod.hip): share of the timing loop's tiles that run one priority level up
     int g_prio_duty = 0, g_prio_trend = 0;
     bool g_prio_auto = true;                  // DVBS2GPU_G_PRIO_DUTY fixes the value

@@ -334,8 +334,9 @@ struct PendingFec {
 
 // development aid: DVBS2GPU_HOST_TIMING=1 prints where the HOST spends a call (ms since entry at each mark)
 // AGC/NCO + timing recovery of a batch, time-sliced over the caller's stream and its auxiliary stream (ctx.h FeAux, created on first use)
-static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work, int n, const S2LoopCoefs& co, hipStream_t st, const S2PostStages* post = nullptr) {
-    int nsub = ctx->fe_slices;
+static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work, int n, const S2LoopCoefs& co, hipStream_t st, const S2PostStages* post = nullptr,
+                                  bool own_post_stream = false) {
+    int nsub = ctx->fe_slices > 0 ? ctx->fe_slices : (ctx->pipeline_fec ? 4 : 8);      // (measured: beside the decoder of the previous call 4, alone 8)
     if (nsub > S2_FE_MAX_SLICES) nsub = S2_FE_MAX_SLICES;
     S2LoopCoefs cc = co;
     cc.g_prio_duty = ctx->pipeline_fec ? ctx->g_prio_duty : 0;
@@ -352,7 +353,13 @@ static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work,
             }
         }
     }
-    return s2_frontend_launch(d_work, n, cc, ctx->d_gardner_bank, st, fa ? fa->aux : nullptr, fa ? fa->ev : nullptr, nsub, post, fa ? fa->ev2 : nullptr);
+    if (fa && post && own_post_stream && !fa->aux2) {
+        std::lock_guard<std::mutex> l(ctx->mtx);
+        hipError_t e = hipStreamCreateWithFlags(&fa->aux2, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    return s2_frontend_launch(d_work, n, cc, ctx->d_gardner_bank, st, fa ? fa->aux : nullptr, fa ? fa->ev : nullptr, nsub, post, fa ? fa->ev2 : nullptr,
+                              fa && own_post_stream ? fa->aux2 : nullptr);
 }
 
 struct HostMarks {
@@ -436,7 +443,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         if (ctx->stage_pipeline_launches > 0) launches = ctx->stage_pipeline_launches;
         S2PostStages post{d_taps, d0->cfg.rrc_taps, max_count + max_count / 32 + 8, raw, maxf, d_found, d_counts, ctx->pl, CT->dev, d0->pls_code,
                           mp.slots, mp.pilots, mp.pilot_blocks, (cf32*)ws_pll.p, (S2FrameStats*)ws_slot.p, ctx->timers.on ? &spans : nullptr, launches};
-        { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st, &post)); }
+        { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st, &post, !pipelined && ctx->stage_post_stream)); }
         slot_stats.resize(nslot);
         HIP_TRY(hipMemcpyAsync(slot_stats.data(), ws_slot.p, sizeof(S2FrameStats) * nslot, hipMemcpyDeviceToHost, st));
     } else {

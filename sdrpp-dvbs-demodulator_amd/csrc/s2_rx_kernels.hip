@@ -1829,8 +1829,12 @@ static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, c
     return hipGetLastError();
 }
 hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCoefs coefs, const float* d_bank, hipStream_t st, hipStream_t aux,
-                              hipEvent_t* ev, int nsub, const S2PostStages* post, hipEvent_t* ev2) {
+                              hipEvent_t* ev, int nsub, const S2PostStages* post, hipEvent_t* ev2, hipStream_t post_stream) {
+    // post_stream: a stream of their own for the post stages (synchronous mode: the FEC stream's hardware queue is free) -- on `aux` the
+    // frame loops queue behind the AGC slices, and for a few streams that queue is the longest (AGC 4 x 7 + loops 4 x 10 ms against 47 ms of
+    // timing recovery per 4-frame call)
     const dim3 ga((nstreams + 63) / 64), gg((nstreams + G_SPW - 1) / G_SPW);
+    hipStream_t ps = post_stream ? post_stream : aux;
     if (nsub <= 1 || !aux || !ev || (post && !ev2)) {
         hipLaunchKernelGGL(agc_pc_kernel<AgcS2Traits>, ga, dim3(128), 0, st, d_work, nstreams, coefs, 0, 1);
         hipLaunchKernelGGL(s2_gardner_kernel, gg, dim3(64), 0, st, d_work, nstreams, coefs, d_bank, 0, 1);
@@ -1856,12 +1860,12 @@ hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCo
         if (post) {
             if ((e = hipEventRecord(ev2[c], st)) != hipSuccess) return e;
             if ((e = agc_upto(c + 2)) != hipSuccess) return e;              // (the AGC stays ahead of the timing loop: its next slices go in before this slice's post stages)
-            if ((e = hipStreamWaitEvent(aux, ev2[c], 0)) != hipSuccess) return e;
-            if ((e = post_stages_launch(d_work, nstreams, coefs, *post, c, nsub, aux)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(ps, ev2[c], 0)) != hipSuccess) return e;
+            if ((e = post_stages_launch(d_work, nstreams, coefs, *post, c, nsub, ps)) != hipSuccess) return e;
         }
     }
     if (post) {
-        if ((e = hipEventRecord(ev2[nsub], aux)) != hipSuccess) return e;
+        if ((e = hipEventRecord(ev2[nsub], ps)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(st, ev2[nsub], 0)) != hipSuccess) return e;
     }
     return hipGetLastError();
