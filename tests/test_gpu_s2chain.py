@@ -687,13 +687,15 @@ def test_time_sliced_front_end_changes_nothing(engine, pkg):
     assert sum(x.size for x in ref[0] + ref[2] + ref[4]) > 0
     # ... and so do the later stages: with the stage pipeline (default) the RRC decimator, the PL-sync walk and the frame loops run behind
     # every timing-recovery slice, frames in per-stream slots; without it (DVBS2GPU_STAGE_PIPELINE=0) after the last slice on frames the host
-    # pooled; DVBS2GPU_STAGE_LOOPS fixes how many of the slices are followed by a frame-loop launch
-    names = ('DVBS2GPU_FE_SLICES', 'DVBS2GPU_STAGE_PIPELINE', 'DVBS2GPU_STAGE_LOOPS')
+    # pooled; DVBS2GPU_STAGE_LOOPS fixes how many of the slices are followed by a frame-loop launch; DVBS2GPU_STAGE_POST_STREAM=0 keeps
+    # them on the AGC's stream instead of a third one
+    names = ('DVBS2GPU_FE_SLICES', 'DVBS2GPU_STAGE_PIPELINE', 'DVBS2GPU_STAGE_LOOPS', 'DVBS2GPU_STAGE_POST_STREAM')
     old = {k: os.environ.get(k) for k in names}
     try:
         for env in ({'DVBS2GPU_FE_SLICES': '1'}, {'DVBS2GPU_FE_SLICES': '8'}, {'DVBS2GPU_STAGE_PIPELINE': '0'},
                     {'DVBS2GPU_STAGE_PIPELINE': '0', 'DVBS2GPU_FE_SLICES': '1'}, {'DVBS2GPU_STAGE_LOOPS': '4'},
-                    {'DVBS2GPU_STAGE_LOOPS': '3', 'DVBS2GPU_FE_SLICES': '8'}, {'DVBS2GPU_STAGE_LOOPS': '1'}):
+                    {'DVBS2GPU_STAGE_LOOPS': '3', 'DVBS2GPU_FE_SLICES': '8'}, {'DVBS2GPU_STAGE_LOOPS': '1'},
+                    {'DVBS2GPU_STAGE_POST_STREAM': '0', 'DVBS2GPU_FE_SLICES': '4'}, {'DVBS2GPU_FE_SLICES': '4'}):
             for k in names:
                 os.environ.pop(k, None)
             os.environ.update(env)
