@@ -227,7 +227,7 @@ int dvbs2gpu_create(int device, dvbs2gpu_ctx** out) {
     if (const char* v = getenv("DVBS2GPU_DVBS_BANK_MIN")) { int k = atoi(v); if (k >= 1) c->dvbs_bank_min = k; }
     if (const char* v = getenv("DVBS2GPU_DVBS_FE_SLICES")) { int k = atoi(v); if (k >= 1 && k <= s2::DVBS_FE_MAX_SLICES) c->dvbs_fe_slices = k; }
     if (const char* v = getenv("DVBS2GPU_STAGE_PIPELINE")) c->stage_pipeline = atoi(v);
-    if (const char* v = getenv("DVBS2GPU_STAGE_POST_STREAM")) c->stage_post_stream = atoi(v) != 0;
+    if (const char* v = getenv("DVBS2GPU_STAGE_POST_STREAM")) c->stage_post_stream = atoi(v);   // (2: in the pipelined mode too)
     if (const char* v = getenv("DVBS2GPU_STAGE_LOOPS")) c->stage_pipeline_launches = atoi(v);
     if (const char* v = getenv("DVBS2GPU_STAGE_MIN_DUTY")) c->stage_pipeline_min_duty = atoi(v);
     if (const char* v = getenv("DVBS2GPU_FE_SLICES")) { int k = atoi(v); if (k >= 1 && k <= s2::S2_FE_MAX_SLICES) c->fe_slices = k; }   // (A/B switch)
