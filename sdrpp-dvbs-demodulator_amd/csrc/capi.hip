@@ -225,6 +225,7 @@ int dvbs2gpu_create(int device, dvbs2gpu_ctx** out) {
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* v = getenv("DVBS2GPU_G_PRIO_DUTY")) { int k = atoi(v); if (k >= 0 && k <= 8) { c->g_prio_duty = k; c->g_prio_auto = false; } }
     if (const char* v = getenv("DVBS2GPU_DVBS_BANK_MIN")) { int k = atoi(v); if (k >= 1) c->dvbs_bank_min = k; }
+    if (const char* v = getenv("DVBS2GPU_DVBS_AGC_STREAM")) c->dvbs_agc_stream = atoi(v) != 0;
     if (const char* v = getenv("DVBS2GPU_DVBS_FE_SLICES")) { int k = atoi(v); if (k >= 1 && k <= s2::DVBS_FE_MAX_SLICES) c->dvbs_fe_slices = k; }
     if (const char* v = getenv("DVBS2GPU_STAGE_PIPELINE")) c->stage_pipeline = atoi(v);
     if (const char* v = getenv("DVBS2GPU_STAGE_POST_STREAM")) c->stage_post_stream = atoi(v);   // (2: in the pipelined mode too)

@@ -151,6 +151,7 @@ struct dvbs2gpu_ctx {
     int g_prio_duty = 0, g_prio_trend = 0;
     bool g_prio_auto = true;                  // DVBS2GPU_G_PRIO_DUTY fixes the value
     int dvbs_bank_min = 1280;                 // DVBS2GPU_DVBS_BANK_MIN: carriers from which a bank uses the four-streams-per-wave FLL (measured crossover; tests: 1)
+    int dvbs_agc_stream = 1;                  // DVBS2GPU_DVBS_AGC_STREAM: the AGC slices of a bank below dvbs_bank_min carriers on a third auxiliary stream (0: on the Viterbi stream)
     int dvbs_fe_slices = 24;                 // DVBS2GPU_DVBS_FE_SLICES: time slices of a DVB-S call (dvbs_demod.hip)
     // DVB-S front end (dvbs_demod.hip)
     float* d_fd_bank = nullptr;               // COMPLEX_FD interpolator bank, 256 x 256

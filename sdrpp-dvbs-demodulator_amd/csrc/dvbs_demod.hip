@@ -207,7 +207,7 @@ int dvbs2gpu_dvbs_demod_process_batch(dvbs2gpu_dvbs_demod* d, const float* const
         std::lock_guard<std::mutex> l(ctx->mtx);
         fa = &ctx->fe_aux[st];
         if (!fa->dvbs_aux[0]) {
-            for (int a = 0; a < 2; ++a) HIP_TRY(hipStreamCreateWithFlags(&fa->dvbs_aux[a], hipStreamNonBlocking));
+            for (int a = 0; a < (ctx->dvbs_agc_stream ? 3 : 2); ++a) HIP_TRY(hipStreamCreateWithFlags(&fa->dvbs_aux[a], hipStreamNonBlocking));
             for (int a = 0; a < 4; ++a)
                 for (int i = 0; i <= DVBS_FE_MAX_SLICES; ++i) HIP_TRY(hipEventCreateWithFlags(&fa->dvbs_ev[a][i], hipEventDisableTiming));
         }
@@ -230,7 +230,9 @@ int dvbs2gpu_dvbs_demod_process_batch(dvbs2gpu_dvbs_demod* d, const float* const
     } hook;
     hook.d = d; hook.fa = fa; hook.d_work = d_work; hook.d_in_ptrs = (const int8_t* const*)(base + off_ptr_in); hook.n = n; hook.max_count = max_count;
     hook.nsub = nsub; hook.mb = mb; hook.d_blk0 = d_blk0; hook.d_nblk = d_nblk; hook.d_nbits = d_nbits; hook.d_bits = (uint8_t*)wsb.p; hook.st = st;
-    HIP_TRY(dvbs_frontend_launch(d_work, n, max_count, d->co, d->d_bandedge, d->d_rrc, ctx->d_fd_bank, st, fa ? fa->dvbs_aux : nullptr,
+    // (a few carriers: the AGC slices on a stream of their own -- one carrier 39.4 -> 36.7 ms per call; a bank keeps them ahead on the Viterbi stream)
+    hipStream_t aux3[3] = {fa ? fa->dvbs_aux[0] : nullptr, fa ? fa->dvbs_aux[1] : nullptr, fa && n < ctx->dvbs_bank_min ? fa->dvbs_aux[2] : nullptr};
+    HIP_TRY(dvbs_frontend_launch(d_work, n, max_count, d->co, d->d_bandedge, d->d_rrc, ctx->d_fd_bank, st, fa ? aux3 : nullptr,
                                  fa ? fa->dvbs_ev : nullptr, nsub, fa ? &hook : nullptr, ctx->dvbs_bank_min));
     if (fa) {
         // the last slice's decoder run ends the Viterbi stream's work for this call

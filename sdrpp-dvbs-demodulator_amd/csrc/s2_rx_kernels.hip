@@ -1752,7 +1752,7 @@ hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int 
     int gx = (max_count / nsub + 1 + 255) / 256;
     gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
     hipError_t e;
-    hipStream_t s0 = sliced ? aux[0] : st, s1 = sliced ? aux[1] : st;
+    hipStream_t s0 = sliced ? (aux[2] ? aux[2] : aux[0]) : st, s1 = sliced ? aux[1] : st;       // (aux[2], optional: the AGC slices on a stream of their own)
     if (sliced) {
         if ((e = hipEventRecord(ev[0][nsub], st)) != hipSuccess) return e;          // the slices start behind what `st` holds now
         if ((e = hipStreamWaitEvent(s0, ev[0][nsub], 0)) != hipSuccess) return e;
