@@ -505,7 +505,7 @@ def pkg_distribute(pkg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=40, help='timed steps (the timed region is bracketed by full synchronisations, so it holds one pipeline fill + drain: K calls cost about K + 1 step times)')
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', default='headline', choices=['headline', 'mixed64'])
     ap.add_argument('--streams', type=int, default=4096, help='transponder streams per GPU')
