@@ -183,21 +183,27 @@ def test_time_sliced_dvbs_front_end_changes_nothing(engine, pkg):
 
     ref = run(engine)
     assert sum(x.size for x in ref[1::3]) > 20000
-    old = os.environ.get('DVBS2GPU_DVBS_FE_SLICES')
+    names = ('DVBS2GPU_DVBS_FE_SLICES', 'DVBS2GPU_DVBS_AGC_STREAM')
+    old = {k: os.environ.get(k) for k in names}
     try:
-        for k in ('1', '3', '8', '32'):
-            os.environ['DVBS2GPU_DVBS_FE_SLICES'] = k
+        # (DVBS2GPU_DVBS_AGC_STREAM=0: the AGC slices on the Viterbi stream instead of a stream of their own)
+        for env in ({'DVBS2GPU_DVBS_FE_SLICES': '1'}, {'DVBS2GPU_DVBS_FE_SLICES': '3'}, {'DVBS2GPU_DVBS_FE_SLICES': '8'},
+                    {'DVBS2GPU_DVBS_FE_SLICES': '32'}, {'DVBS2GPU_DVBS_AGC_STREAM': '0'}, {'DVBS2GPU_DVBS_AGC_STREAM': '0', 'DVBS2GPU_DVBS_FE_SLICES': '5'}):
+            for k in names:
+                os.environ.pop(k, None)
+            os.environ.update(env)
             e2 = pkg.Engine(0)
             got = run(e2)
             e2.close()
             assert len(got) == len(ref)
             for a, b in zip(ref, got):
-                assert np.array_equal(a, b)
+                assert np.array_equal(a, b), env
     finally:
-        if old is None:
-            os.environ.pop('DVBS2GPU_DVBS_FE_SLICES', None)
-        else:
-            os.environ['DVBS2GPU_DVBS_FE_SLICES'] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def test_dvbs_demod_error_codes(engine, pkg):
