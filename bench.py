@@ -400,7 +400,7 @@ MIXED_RATE = {4: 3, 6: 5, 7: 6, 11: 10, 12: 4, 13: 5, 14: 6, 15: 8}
 def mixed64(eng, pkg, dev, dd, steps, warmup, nt=64, sub=64, F=1):
     """BASELINE config 4: `nt` transponders cycling over 8 QPSK / 8PSK MODCODs (normal frames, 50 forced iterations), each carried as
     `sub` concurrently processed sub-streams (the sections one fast transponder is cut into for a GPU whose per-stream loops are serial;
-    nt x sub = 4096 streams, the shape of tools/mixed_bench.py at N = 1).  STRONG scaling: the transponder list is fixed and sharded
+    nt x sub = 4096 streams).  STRONG scaling: the transponder list is fixed and sharded
     over the ranks (MODCOD-grouped, weighted); rank 0 owns table + configuration and broadcasts them; after every step the BBFRAMEs
     and per-frame statistics are gathered to the egress rank 0, which reassembles them in transponder order and checks every frame."""
     import torch
