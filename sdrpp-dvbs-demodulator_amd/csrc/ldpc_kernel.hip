@@ -182,6 +182,9 @@ __device__ __forceinline__ uint32_t lds_offset(const int8_t* p) { return (uint32
 // MI355X runs with SRAM ECC, where a d16 load ZEROES the other half instead of preserving it, so the two halves land in
 // two registers and one v_or joins them (still 1 VALU op per pair instead of 2 sign extensions + a byte permute).
 // Issue only; lds_pairs_wait() below orders the results.
+#ifndef LDPC_LEVEL_PREFETCH_KIND
+#define LDPC_LEVEL_PREFETCH_KIND 2   // per-level layers from this kind on fetch all their shared posteriors up front (2 = also the general form: +2-3 % on the codes with more than 8 shared links per row; 3 = only the <= 4 / <= 8-link forms; A/B switch)
+#endif
 #ifndef LDPC_EXP
 #define LDPC_EXP 0   // development switches for TIMING experiments (results wrong): 1 no message records, 2 no posterior stores, 4 no posterior loads
 #endif
@@ -592,14 +595,14 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                     // (the <= 4 / <= 8-link variants fetch all their shared posteriors up front: one LDS round trip per level instead
                     // of one per late link behind the per-link branches)
                     int xs[MAXC];
-                    if constexpr (KIND >= 3) {
+                    if constexpr (KIND >= LDPC_LEVEL_PREFETCH_KIND) {
 #pragma unroll
                         for (int k = 0; k < MAXC; ++k) xs[k] = (int)LDS_I8(addr[k]);
                     }
 #pragma unroll
                     for (int k = 0; k < MAXC; ++k) {
                         if (k < nc && ((late_l >> k) & 1)) {
-                            int v = clamp8((KIND >= 3 ? xs[k] : (int)LDS_I8(addr[k])) - rec_byte<REC>(rec_in, k));
+                            int v = clamp8((KIND >= LDPC_LEVEL_PREFETCH_KIND ? xs[k] : (int)LDS_I8(addr[k])) - rec_byte<REC>(rec_in, k));
                             int m = mag_of(v);
                             LINK_SET(k, v, m);
                             ROW_ACCUM(v, m);
