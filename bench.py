@@ -517,6 +517,18 @@ def main():
     ap.add_argument('--no-pipeline', action='store_true', help='run the FEC inside the call that produced the frames (no overlap with the next front end)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` on its own: start N ranks (one per GPU) as CHILD processes of this one, which has not touched the
+        # GPU (nothing imported torch or the library yet; a process that has must never exec), and pass their exit code on
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(('127.0.0.1', 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     import torch
     import __graft_entry__ as g
     pkg = g.load_package()
@@ -524,6 +536,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or run `python bench.py --gpus N` and let it start them)' % (args.gpus, world))
     dist = None
     backend = 'nccl'
     if world > 1:

@@ -116,9 +116,13 @@ class Distributor:
             out[idx] = payload
             cnt[idx] = counts
             return out, cnt
-        nmax = torch.tensor([len(local_ids)], dtype=torch.int64, device=self.device)
+        # one all-reduce agrees on the row count AND the row width: a rank without local units may have passed an empty / 1-D payload
+        nmax = torch.tensor([len(local_ids), width], dtype=torch.int64, device=self.device)
         self.dist.all_reduce(nmax, op=self.dist.ReduceOp.MAX)
-        nmax = int(nmax.item())
+        nmax, wmax = int(nmax[0].item()), int(nmax[1].item())
+        if len(local_ids) and width != wmax:
+            raise ValueError('gather_units: payload rows are %d bytes wide here, %d on another rank' % (width, wmax))
+        width = wmax
         pad = torch.zeros((nmax, width), dtype=torch.uint8, device=self.device)
         meta = torch.full((nmax, 2), -1, dtype=torch.int32, device=self.device)
         k = len(local_ids)
