@@ -11,7 +11,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdvbs2gpu.so')
+# DVBS2GPU_LIB: development aid (tools/ab.sh runs the bench against a variant build under /tmp without touching the in-tree library)
+LIB_PATH = os.environ.get('DVBS2GPU_LIB') or os.path.join(_HERE, 'libdvbs2gpu.so')
 
 ERR_ARG, ERR_MODCOD, ERR_HIP, ERR_NODEVICE, ERR_CAPACITY = -1, -2, -3, -4, -5
 ERR_NAMES = {-1: 'ERR_ARG', -2: 'ERR_MODCOD', -3: 'ERR_HIP', -4: 'ERR_NODEVICE', -5: 'ERR_CAPACITY'}

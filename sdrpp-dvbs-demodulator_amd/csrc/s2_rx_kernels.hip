@@ -20,6 +20,7 @@
 // data-parallel over symbols.  All of these are small next to the LDPC stage (~1.3 kflop and ~24 B per symbol).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "s2_rx.h"
 #include "../../include/dvbs2gpu_math.h"
 #include "s2_params.h"
@@ -43,6 +44,7 @@ __device__ __forceinline__ __attribute__((address_space(1))) T* as_global(T* p) 
 }
 
 typedef float __attribute__((ext_vector_type(2))) f32x2;
+typedef float __attribute__((ext_vector_type(4))) f32x4;
 __device__ __forceinline__ cf32 ldg(const cf32* p) {
     const f32x2 v = *as_global(reinterpret_cast<const f32x2*>(p));
     return cf32{v.x, v.y};
@@ -372,6 +374,423 @@ __global__ __launch_bounds__(64) void s2_gardner_kernel(const S2StreamWork* __re
             st->n_fe_out = outCount;
             st->n_fe_slice[sub & (S2_FE_MAX_SLICES - 1)] = outCount;
         }
+    }
+}
+
+// ---- timing recovery, second form: the serial chain holds only what the recurrence needs ------------------------------------
+// Of the reference loop's two outputs per symbol only the on-symbol one feeds the loop (gardner.cpp:100-131: the error of the
+// other is 0, so PCL::advance(0) moves the phase by the loop frequency alone), and an output VALUE never feeds anything: the chain is
+// "interpolate three arms at the on-symbol instant -> error -> advance; advance once more".  So the RESOLVER wave (8 lanes per stream,
+// 8 streams, as above) walks symbol by symbol -- on-symbol output, then its follower without any interpolation -- and leaves one word
+// (window slot, polyphase arm) per output in an LDS list; a PRODUCER wave of the same workgroup computes every output value from that
+// list one period later (the same 8-tap dot product in the reference's accumulation order, lane = output: coalesced stores instead of
+// a predicated store inside the chain), and stages the next samples (FastAGC scaling + FreqShift rotation).  Per symbol the chain is
+// ~125 instructions of one wave instead of ~230.  Streams of a wave start a period aligned on an on-symbol output (one single step
+// at the start of a slice where the state says otherwise); the last three sample positions of a slice go through single steps, so a
+// slice ends in exactly the state the reference's loop has after the same samples.
+// Samples live in a ring of 4 periods per stream and component (slot = buffer index mod ring; the first 8 slots are mirrored behind the
+// ring so that an 8-sample window never wraps): period t is resolved while t+1 is being staged and the values of t-1 are produced.
+#ifndef G2_TILE_N
+#define G2_TILE_N 16
+#endif
+constexpr int G2_TILE = G2_TILE_N;            // samples per stream and period
+constexpr int G2_RING = 4 * G2_TILE;
+constexpr int G2_PITCH = G2_RING + 8 + 1;     // ring + mirror of its first 8 slots; odd pitch
+constexpr int G2_LIST = G2_TILE + 8;          // outputs of a stream per period: <= (G2_TILE + 3) / 0.96 (list entries beyond are refused by the loop bounds)
+constexpr int G2_SPT = (G_SPW * G2_TILE) / 64; // samples each producer lane stages per period
+
+__device__ __forceinline__ void lds_only_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__global__ __launch_bounds__(128) void s2_gardner2_kernel(const S2StreamWork* __restrict__ work, int nstreams, S2LoopCoefs co,
+                                                         const float* __restrict__ bank_g, int sub, int nsub) {
+    __shared__ __attribute__((aligned(16))) float bank[GARDNER_PHASES * GARDNER_TAPS];
+    __shared__ float ring[G_SPW * 2 * G2_PITCH];        // [stream][re/im][slot]
+    __shared__ uint32_t list[2][G_SPW][G2_LIST];        // per period parity: slot << 7 | arm of every output, in output order
+    __shared__ int s_cnt[2][G_SPW], s_ostart[2][G_SPW];
+    __shared__ const cf32* s_in[G_SPW];
+    __shared__ const cf32* s_gp[G_SPW];
+    __shared__ cf32* s_out[G_SPW];
+    __shared__ int s_n[G_SPW];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 3, r = lane & 7, arm = r >> 1, c = r & 1;
+    const int s0 = blockIdx.x * G_SPW, s = s0 + g;
+    const bool act = s < nstreams;
+    for (int i = threadIdx.x; i < GARDNER_PHASES * GARDNER_TAPS; i += 128) bank[i] = bank_g[i];
+    S2StreamWork w = work[act ? s : 0];
+    int lo, hi;
+    fe_sub_range(act ? w.count : 0, sub, nsub, lo, hi);
+    const int n = hi - lo;
+    S2StreamState* st = w.st;
+    float* row = &ring[(g * 2 + c) * G2_PITCH];
+    if (wave == 0) {
+        if (r == 0) { s_in[g] = w.in + lo; s_gp[g] = w.fe_out + fe_scratch_offset(w.count) + lo; s_out[g] = w.fe_out; s_n[g] = n; }
+        if (arm == 0)
+            for (int k = 0; k < GARDNER_TAPS - 1; ++k) { const float h = c ? st->g_hist[k].im : st->g_hist[k].re; row[k] = h; row[G2_RING + k] = h; }
+    }
+    int nmax = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+    const int ntiles = (nmax + G2_TILE - 1) / G2_TILE;
+    __syncthreads();
+
+    if (wave == 1) {
+        // ================= producer: staging + output values
+        cf32 px[G2_SPT], pg[G2_SPT];
+        const int si = lane % G2_TILE, sj0 = lane / G2_TILE;          // sample of the period, first stream of this lane
+        constexpr int SSTEP = 64 / G2_TILE;                            // stream stride between a lane's samples
+        auto issue = [&](int t) {
+#pragma unroll
+            for (int q = 0; q < G2_SPT; ++q) {
+                const int sj = sj0 + SSTEP * q, idx = t * G2_TILE + si;
+                if (idx < s_n[sj]) { px[q] = ldg(s_in[sj] + idx); pg[q] = ldg(s_gp[sj] + idx); }
+            }
+        };
+        auto commit = [&](int t) {
+#pragma unroll
+            for (int q = 0; q < G2_SPT; ++q) {
+                const int sj = sj0 + SSTEP * q, idx = t * G2_TILE + si;
+                if (idx < s_n[sj]) {
+                    const cf32 z = cmul(cscale(px[q], pg[q].re), phasor_fast(-pg[q].im));   // FastAGC scaling, FreqShift rotation
+                    const int slot = (idx + GARDNER_TAPS - 1) & (G2_RING - 1);
+                    float* rr = &ring[(sj * 2) * G2_PITCH + slot];
+                    rr[0] = z.re; rr[G2_PITCH] = z.im;
+                    if (slot < 8) { rr[G2_RING] = z.re; rr[G2_PITCH + G2_RING] = z.im; }
+                }
+            }
+        };
+        // values of the outputs the resolver listed in period p: two streams per pass (lanes 0..31 / 32..63), lane = output
+        auto produce = [&](int p) {
+            const int half = lane >> 5, li = lane & 31;
+#pragma unroll 1
+            for (int sp = 0; sp < G_SPW; sp += 2) {
+                const int sj = sp + half;
+                const int cnt = s_cnt[p & 1][sj];
+                if (li < cnt) {
+                    const uint32_t u = list[p & 1][sj][li];
+                    const float* xr = &ring[(sj * 2) * G2_PITCH + (u >> 7)];
+                    const float* t = &bank[(u & 127u) * 8];
+                    float ar = 0.f, ai = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { ar += xr[k] * t[k]; ai += xr[G2_PITCH + k] * t[k]; }
+                    stg(s_out[sj] + s_ostart[p & 1][sj] + li, cf32{ar, ai});
+                }
+            }
+        };
+        if (ntiles > 0) { issue(0); commit(0); }
+        if (ntiles > 1) issue(1);
+        lds_only_barrier();
+        for (int t = 0; t < ntiles; ++t) {
+            if (t + 1 < ntiles) commit(t + 1);
+            if (t + 2 < ntiles) issue(t + 2);
+            if (t >= 1) produce(t - 1);
+            lds_only_barrier();
+        }
+        if (ntiles > 0) produce(ntiles - 1);
+        return;
+    }
+
+    // ================= resolver
+    PclDev pcl{co.g_alpha, co.g_beta, st->g_phase, st->g_freq, co.g_min_freq, co.g_max_freq};
+    int offset = st->g_offset, spsctr = st->g_spsctr, outCount = sub ? st->n_fe_out : 0;   // (later slices append to the call's output)
+    int cnt = 0;
+    uint32_t* lp = nullptr;
+    // on-symbol output: interpolate at phase-1 / phase / phase+1, error, advance (gardner.cpp:100-140)
+    auto err_step = [&]() {
+        int phase = (int)floorf(pcl.phase * 128.0f);
+        phase = phase < 0 ? 0 : (phase > 127 ? 127 : phase);
+        int my = phase;
+        if (arm == 0) my = phase > 0 ? phase - 1 : 0;
+        if (arm == 2) my = phase < 127 ? phase + 1 : 127;
+        const int slot = offset & (G2_RING - 1);
+        const float* xw = row + slot;
+        const float* t = &bank[my * 8];
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += xw[k] * t[k];
+        lp[cnt++] = ((uint32_t)slot << 7) | (uint32_t)phase;
+        const float xm = DPP_F(acc, 0x112), xp = DPP_F(acc, 0x102), xo = acc;   // row_shr:2 = the phase-1 arm, row_shl:2 = the phase+1 arm
+        float d = (xp - xm) * 0.5f;
+        if (__any(phase == 0 || phase == 127)) d = fsel(phase == 0, xp - xo, fsel(phase == 127, xo - xm, d));   // (one-sided at the ends of the bank: rare)
+        const float e = (xo > 0 ? 1.0f : -1.0f) * d;                 // valid in lanes r = 2 (re half), 3 (im half)
+        const float eo = DPP_F(e, 0xB1);                             // quad_perm [1,0,3,2]: the other half
+        const float er = -(e + eo);
+        const float eq = DPP_F(er, 0xAA);                            // quad_perm [2,2,2,2]
+        const float eh = DPP_F(eq, 0x114);                           // row_shr:4
+        float error = r < 4 ? eq : eh;
+        error = clamp_med3(error, -1.0f, 1.0f);
+        pcl.advance(error);
+        const float delta = floorf(pcl.phase);
+        offset = (int)((float)offset + delta);
+        pcl.phase -= delta;
+    };
+    // the other output of the symbol: error 0 (gardner.cpp:132-134)
+    auto off_step = [&]() {
+        int phase = (int)floorf(pcl.phase * 128.0f);
+        phase = phase < 0 ? 0 : (phase > 127 ? 127 : phase);
+        lp[cnt++] = ((uint32_t)(offset & (G2_RING - 1)) << 7) | (uint32_t)phase;
+        pcl.advance(0.0f);
+        const float delta = floorf(pcl.phase);
+        offset = (int)((float)offset + delta);
+        pcl.phase -= delta;
+    };
+    lds_only_barrier();                       // period 0 is staged
+    __builtin_amdgcn_s_setprio(G_PRIO);       // latency-critical serial loop (see agc_pc_kernel)
+    for (int t = 0; t < ntiles; ++t) {
+        if ((((unsigned)t * G2_TILE / G_TILE) & 7u) < (unsigned)(co.g_prio_duty + G_PRIO_DUTY)) __builtin_amdgcn_s_setprio(G_PRIO + 1); else __builtin_amdgcn_s_setprio(G_PRIO);
+        const int base = t * G2_TILE;
+        const int lim = min(base + G2_TILE, n);            // outputs with offset < lim have their window staged
+        lp = &list[t & 1][g][0];
+        cnt = 0;
+        const int ostart = outCount;
+        // (the trip counts are bounded by the list: a poisoned loop state -- NaN input -- can neither hang the GPU nor overrun it)
+        if (spsctr == 1 && offset < lim) { off_step(); spsctr = 0; }     // (only where a slice starts between the two outputs of a symbol)
+        while (__any(spsctr == 0 && offset < lim - 3 && cnt < G2_LIST - 2)) {
+            if (spsctr == 0 && offset < lim - 3 && cnt < G2_LIST - 2) { err_step(); off_step(); }
+        }
+        if (base + G2_TILE >= n) {
+            // the stream's last period of this slice: the remaining positions one output at a time
+            while (__any(offset < n && cnt < G2_LIST)) {
+                if (offset < n && cnt < G2_LIST) {
+                    if (spsctr == 0) err_step(); else off_step();
+                    spsctr ^= 1;
+                }
+            }
+        }
+        outCount += cnt;
+        if (r == 0) { s_cnt[t & 1][g] = cnt; s_ostart[t & 1][g] = ostart; }
+        lds_only_barrier();
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (act && arm == 0) {
+        for (int k = 0; k < GARDNER_TAPS - 1; ++k) {
+            const float h = row[(n + k) & (G2_RING - 1)];
+            if (c) st->g_hist[k].im = h; else st->g_hist[k].re = h;
+        }
+        if (c == 0) {
+            st->g_phase = pcl.phase; st->g_freq = pcl.freq; st->g_offset = offset - n; st->g_spsctr = spsctr;
+            st->n_fe_out = outCount;
+            st->n_fe_slice[sub & (S2_FE_MAX_SLICES - 1)] = outCount;
+        }
+    }
+}
+
+// ---- timing recovery, third form: LANE = STREAM ---------------------------------------------------------------------------
+// With the LDPC decoder of the previous call on the same SIMDs a step is bound by the instructions ALL resident waves issue, not by the
+// length of one chain -- and in the 8-lanes-per-stream forms above every wave instruction serves 8 streams.  Here a lane owns a stream
+// outright (64 streams per wave, like agc_pc_kernel): the resolver wave reads its stream's window from a small per-stream LDS ring
+// (nine samples per symbol: the on-symbol output's window and, one sample on, its follower's), interpolates the three arms of the
+// on-symbol output and the one arm of the follower in packed fp32 (re and im in one instruction, the reference's accumulation order)
+// and stores the values itself; a second wave feeds the ring (FastAGC scaling + FreqShift rotation of the next 8 samples per stream).
+// ~135 vector instructions per symbol for 64 streams instead of ~230 for 8: the timing recovery all but vanishes from the step's issue
+// budget, and one stream's chain is shorter as well.  Periods, pairing of the two outputs of a symbol and the single steps at the end
+// of a slice as in s2_gardner2_kernel.
+#ifndef GB_T_N
+#define GB_T_N 4
+#endif
+#ifndef GB_PRIO
+#define GB_PRIO 2
+#endif
+constexpr int GB_T = GB_T_N;                 // samples per stream and period
+static_assert(64 % GB_T == 0, "the feeder's lane = (stream, sample) layout needs a period that divides 64");
+// ring slots per stream: period t is resolved (reaching back 2 deferred positions + the 7 of the delay line) while t+1 is fed -- and not a
+// slot more: LDS is what decides whether this workgroup finds room beside a resident two-frame LDPC workgroup (136 KB; LDS is handed out
+// in contiguous pieces, tools/ubench/lds_fit.hip: whatever small workgroups were resident when the decoder's were placed leave holes of
+// their own size, and a kernel whose workgroup fits nowhere waits for the decoder to END).  Slot = buffer index mod GB_RING, kept as a
+// running counter per lane (no power of two needed).
+constexpr int GB_RING = 2 * GB_T + 9;
+constexpr int GB_PITCH = (GB_RING + 7) | 1;  // + mirror of the first 7 slots (a window never wraps); odd: the 8-byte accesses of 32 lanes hit 64 different banks
+__device__ __forceinline__ int gb_wrap(int slot) { return (int)min((unsigned)slot, (unsigned)(slot - GB_RING)); }   // slot in [0, 2 * GB_RING)
+
+__global__ __launch_bounds__(128) void s2_gardner_bank_kernel(const S2StreamWork* __restrict__ work, int nstreams, S2LoopCoefs co,
+                                                             const float* __restrict__ bank_g, int sub, int nsub) {
+    __shared__ __attribute__((aligned(16))) float bank[GARDNER_PHASES * GARDNER_TAPS];
+    __shared__ __attribute__((aligned(8))) f32x2 ring[64 * GB_PITCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 64 + lane;
+    const bool act = s < nstreams;
+    for (int i = threadIdx.x; i < GARDNER_PHASES * GARDNER_TAPS; i += 128) bank[i] = bank_g[i];
+    const S2StreamWork w = work[act ? s : 0];
+    int lo, hi;
+    fe_sub_range(act ? w.count : 0, sub, nsub, lo, hi);
+    const int n = hi - lo;
+    S2StreamState* st = w.st;
+    f32x2* row = &ring[lane * GB_PITCH];
+    if (wave == 0)
+        for (int k = 0; k < GARDNER_TAPS - 1; ++k) {     // the delay line = buffer indices 0..6 = slots 0..6 (and their mirror)
+            const cf32 h = st->g_hist[k];
+            row[k] = f32x2{h.re, h.im}; row[GB_RING + k] = f32x2{h.re, h.im};
+        }
+    int nmax = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+    const int ntiles = (nmax + GB_T - 1) / GB_T;
+    __syncthreads();
+
+    if (wave == 1) {
+        // ================= feeder: the samples of period t+1 go into the ring while period t is resolved.  Lane = (stream % SPI, sample):
+        // one load instruction fetches the period's samples (contiguous bytes) of SPI streams; all loads of a period are issued
+        // back to back a period ahead (unconditional, clamped indices: a load behind a branch is waited for on the spot)
+        constexpr int SPI = 64 / GB_T;                  // streams per load instruction
+        constexpr int NQ = 64 / SPI;                    // load instructions per array and period
+        const int sub_s = lane / GB_T, smp = lane % GB_T;
+        // the pointers and sample counts of this lane's NQ streams, fetched once from the lanes that own them (a stream without samples
+        // in this slice may come with a null input pointer: the clamped loads then read the tap table)
+        const cf32* my_in = n > 0 ? w.in + lo : reinterpret_cast<const cf32*>(bank_g);
+        const cf32* my_gp = n > 0 ? w.fe_out + fe_scratch_offset(w.count) + lo : reinterpret_cast<const cf32*>(bank_g);
+        const cf32* q_in[NQ];
+        const cf32* q_gp[NQ];
+        int q_n[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int sj = SPI * q + sub_s;
+            q_in[q] = (const cf32*)__shfl((unsigned long long)my_in, sj);
+            q_gp[q] = (const cf32*)__shfl((unsigned long long)my_gp, sj);
+            q_n[q] = __shfl(n, sj);
+        }
+        cf32 px[NQ], pg[NQ];
+        auto issue = [&](int t) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int idx = min(t * GB_T + smp, max(q_n[q] - 1, 0));
+                px[q] = ldg(q_in[q] + idx); pg[q] = ldg(q_gp[q] + idx);
+            }
+        };
+        int slot_t = GARDNER_TAPS - 1 + smp;            // slot of this lane's sample of period t (buffer index = sample index + 7)
+        auto commit = [&](int t) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int sj = SPI * q + sub_s, idx = t * GB_T + smp;
+                if (idx < q_n[q]) {
+                    const cf32 z = cmul(cscale(px[q], pg[q].re), phasor_fast(-pg[q].im));   // FastAGC scaling, FreqShift rotation
+                    f32x2* rr = &ring[sj * GB_PITCH + slot_t];
+                    rr[0] = f32x2{z.re, z.im};
+                    if (slot_t < 7) rr[GB_RING] = f32x2{z.re, z.im};
+                }
+            }
+            slot_t = gb_wrap(slot_t + GB_T);
+        };
+        __builtin_amdgcn_s_setprio(GB_PRIO);
+        slot_t = gb_wrap(slot_t);
+        if (ntiles > 0) { issue(0); commit(0); }
+        if (ntiles > 1) issue(1);
+        lds_only_barrier();
+        for (int t = 0; t < ntiles; ++t) {
+            if (t + 1 < ntiles) commit(t + 1);
+            if (t + 2 < ntiles) issue(t + 2);
+            lds_only_barrier();
+        }
+        return;
+    }
+
+    // ================= resolver
+    PclDev pcl{co.g_alpha, co.g_beta, st->g_phase, st->g_freq, co.g_min_freq, co.g_max_freq};
+    int offset = st->g_offset, spsctr = st->g_spsctr, outCount = sub ? st->n_fe_out : 0;   // (later slices append to the call's output)
+    int slot = offset % GB_RING;                          // slot of buffer index `offset`, moved along with it
+    cf32* outp = w.fe_out;
+    // re and im of one arm: acc += x[k] * t[k] in tap order, every operation rounded (gardner.cpp / SDR++ polyphase dot product)
+    auto dot_arm = [&](const f32x2* x, const float* t) {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(t), t1 = *reinterpret_cast<const f32x4*>(t + 4);
+        f32x2 acc = f32x2{0.f, 0.f};
+        acc += x[0] * t0.x; acc += x[1] * t0.y; acc += x[2] * t0.z; acc += x[3] * t0.w;
+        acc += x[4] * t1.x; acc += x[5] * t1.y; acc += x[6] * t1.z; acc += x[7] * t1.w;
+        return acc;
+    };
+    auto arm_of = [&]() {
+        const int phase = (int)floorf(pcl.phase * 128.0f);
+        return phase < 0 ? 0 : (phase > 127 ? 127 : phase);
+    };
+    auto put = [&](f32x2 v) {
+        *as_global(reinterpret_cast<f32x2*>(outp + outCount)) = v;
+        ++outCount;
+    };
+    auto finish = [&](float error) {
+        pcl.advance(error);
+        const float delta = floorf(pcl.phase);
+        const int o1 = (int)((float)offset + delta);
+        slot = gb_wrap(slot + (o1 - offset));             // (a step moves 0, 1 or 2 samples on)
+        offset = o1;
+        pcl.phase -= delta;
+    };
+    // on-symbol output from the window x[0..7]: arms phase-1 / phase / phase+1, error, advance (gardner.cpp:100-140)
+    auto err_step = [&](const f32x2* x) {
+        const int phase = arm_of();
+        const int base_arm = min(max(phase - 1, 0), GARDNER_PHASES - 3);       // three consecutive arms that hold what the phase needs
+        const float* t = &bank[base_arm * 8];
+        const f32x2 a = dot_arm(x, t), b = dot_arm(x, t + 8), c = dot_arm(x, t + 16);
+        f32x2 xo = b, d = (c - a) * 0.5f;
+        if (__any(phase == 0 || phase == GARDNER_PHASES - 1)) {                // one-sided at the ends of the bank (rare)
+            if (phase == 0) { xo = a; d = b - a; }
+            if (phase == GARDNER_PHASES - 1) { xo = c; d = c - b; }
+        }
+        put(xo);
+        const float error = -(((xo.x > 0 ? 1.0f : -1.0f) * d.x) + ((xo.y > 0 ? 1.0f : -1.0f) * d.y));
+        finish(clamp_med3(error, -1.0f, 1.0f));
+    };
+    // the other output of the symbol: error 0 (gardner.cpp:132-134)
+    auto off_step = [&](const f32x2* x) {
+        put(dot_arm(x, &bank[arm_of() * 8]));
+        finish(0.0f);
+    };
+    lds_only_barrier();                       // period 0 is in the ring
+    __builtin_amdgcn_s_setprio(GB_PRIO);      // 64 waves in all: they keep their latency against the decoder's waves (like agc_pc_kernel)
+    for (int t = 0; t < ntiles; ++t) {
+        const int base = t * GB_T;
+        const int lim = min(base + GB_T, n);              // outputs with offset < lim have their whole window in
+        const bool last = base + GB_T >= n;               // this stream's last period of the slice
+        // single steps: a slice that starts between the two outputs of a symbol, and (below) the last positions of a slice
+        if (__any(spsctr == 1 && offset < lim)) {
+            if (spsctr == 1 && offset < lim) {
+                f32x2 x[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[k] = row[slot + k];
+                off_step(x);
+                spsctr = 0;
+            }
+        }
+        // whole symbols: the follower lies at most two samples on (|freq - 1| <= 0.05, |alpha * error| << 1), so it is in as well
+        for (int guard = 0; guard < 2 * GB_T && __any(spsctr == 0 && offset < lim - 2); ++guard) {     // (bounded: a poisoned loop state -- NaN input -- must not hang the GPU)
+            if (spsctr == 0 && offset < lim - 2) {
+                f32x2 x[9];
+                const f32x2* xr = row + slot;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[k] = xr[k];
+                x[8] = row[gb_wrap(slot + 8)];            // (the mirror holds 7 slots: the ninth sample by its own slot)
+                const int o0 = offset;
+                err_step(x);
+                if (__all(offset == o0 + 1)) {
+                    off_step(x + 1);                      // (nearly always: the follower's window is the same registers, one sample on)
+                } else {
+                    f32x2 y[8];
+                    const f32x2* yr = row + slot;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) y[k] = yr[k];
+                    off_step(y);
+                }
+            }
+        }
+        if (__any(last && offset < n)) {
+            for (int guard = 0; guard < 8 && __any(last && offset < n); ++guard) {
+                if (last && offset < n) {
+                    f32x2 x[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) x[k] = row[slot + k];
+                    if (spsctr == 0) err_step(x); else off_step(x);
+                    spsctr ^= 1;
+                }
+            }
+        }
+        lds_only_barrier();
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (act) {
+        const int sn = n % GB_RING;
+        for (int k = 0; k < GARDNER_TAPS - 1; ++k) { const f32x2 h = row[gb_wrap(sn + k)]; st->g_hist[k] = cf32{h.x, h.y}; }
+        st->g_phase = pcl.phase; st->g_freq = pcl.freq; st->g_offset = offset - n; st->g_spsctr = spsctr;
+        st->n_fe_out = outCount;
+        st->n_fe_slice[sub & (S2_FE_MAX_SLICES - 1)] = outCount;
     }
 }
 
@@ -1828,6 +2247,26 @@ static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, c
     }
     return hipGetLastError();
 }
+// Three forms of the timing recovery, all bit-identical (tests/test_gpu_s2chain.py runs every one): 1 = one wave, 8 lanes per stream
+// (s2_gardner_kernel); 2 = resolver + producer waves, 8 lanes per stream (s2_gardner2_kernel: the shortest chain per stream -- what a small
+// bank needs); 3 = lane per stream (s2_gardner_bank_kernel: the fewest instructions in all).  Default: form 2 below S2_GARDNER_BANK_MIN
+// streams, form 1 from there on; DVBS2GPU_GARDNER_FORM=1|2|3 in the environment forces one (development aid / the parity tests).
+#ifndef S2_GARDNER_BANK_MIN
+#define S2_GARDNER_BANK_MIN 512
+#endif
+static int gardner_form(int nstreams) {
+    static const int forced = [] { const char* e = getenv("DVBS2GPU_GARDNER_FORM"); return e ? atoi(e) : 0; }();
+    if (forced >= 1 && forced <= 3) return forced;
+    return nstreams < S2_GARDNER_BANK_MIN ? 2 : 1;
+}
+static void gardner_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const float* d_bank, hipStream_t st, int c, int nsub) {
+    switch (gardner_form(nstreams)) {
+        case 3: hipLaunchKernelGGL(s2_gardner_bank_kernel, dim3((nstreams + 63) / 64), dim3(128), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
+        case 2: hipLaunchKernelGGL(s2_gardner2_kernel, dim3((nstreams + G_SPW - 1) / G_SPW), dim3(128), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
+        default: hipLaunchKernelGGL(s2_gardner_kernel, dim3((nstreams + G_SPW - 1) / G_SPW), dim3(64), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
+    }
+}
+#define GARDNER_LAUNCH(c_, n_) gardner_launch(d_work, nstreams, coefs, d_bank, st, (c_), (n_))
 hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCoefs coefs, const float* d_bank, hipStream_t st, hipStream_t aux,
                               hipEvent_t* ev, int nsub, const S2PostStages* post, hipEvent_t* ev2, hipStream_t post_stream) {
     // post_stream: a stream of their own for the post stages (synchronous mode: the FEC stream's hardware queue is free) -- on `aux` the
@@ -1837,7 +2276,7 @@ hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCo
     hipStream_t ps = post_stream ? post_stream : aux;
     if (nsub <= 1 || !aux || !ev || (post && !ev2)) {
         hipLaunchKernelGGL(agc_pc_kernel<AgcS2Traits>, ga, dim3(128), 0, st, d_work, nstreams, coefs, 0, 1);
-        hipLaunchKernelGGL(s2_gardner_kernel, gg, dim3(64), 0, st, d_work, nstreams, coefs, d_bank, 0, 1);
+        GARDNER_LAUNCH(0, 1);
         if (post) return post_stages_launch(d_work, nstreams, coefs, *post, 0, 1, st);
         return hipGetLastError();
     }
@@ -1856,7 +2295,7 @@ hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCo
     for (int c = 0; c < nsub; ++c) {
         if ((e = agc_upto(post ? c + 1 : c)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(st, ev[c], 0)) != hipSuccess) return e;
-        hipLaunchKernelGGL(s2_gardner_kernel, gg, dim3(64), 0, st, d_work, nstreams, coefs, d_bank, c, nsub);
+        GARDNER_LAUNCH(c, nsub);
         if (post) {
             if ((e = hipEventRecord(ev2[c], st)) != hipSuccess) return e;
             if ((e = agc_upto(c + 2)) != hipSuccess) return e;              // (the AGC stays ahead of the timing loop: its next slices go in before this slice's post stages)
