@@ -54,6 +54,17 @@ int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
         if ((rc = upload(P.ents, &D.d_ents))) return rc;
         if ((rc = upload(P.rows, &D.d_rows))) return rc;
         D.blocks_per_cu = ldpc_blocks_per_cu(P.max_deg, D.irregular, P.N);
+        if (P.N <= 16200) {
+            // short frames also get the wave-per-frame plan; which decoder serves the code: ldpc_wave_default() (measured per code),
+            // DVBS2GPU_LDPC_WAVE=0|1 in the environment forces one (development aid / the parity tests run both)
+            const LdpcWavePlan W = build_ldpc_wave_plan(P);
+            D.wave_lw = W.lw; D.wave_nsteps = W.nsteps; D.wave_nl_min = W.nl_min; D.wave_absent_base = W.absent_base;
+            if ((rc = upload(W.lanec, &D.d_wave_lanec))) return rc;
+            if ((rc = upload(W.steps, &D.d_wave_steps))) return rc;
+            if ((rc = upload(W.step_layer, &D.d_wave_step_layer))) return rc;
+            const char* e = getenv("DVBS2GPU_LDPC_WAVE");
+            D.use_wave = e ? atoi(e) != 0 : ldpc_wave_default(code_index);
+        }
         it = ctx->ldpc.emplace(code_index, D).first;
     }
     *out = &it->second;
@@ -164,6 +175,29 @@ static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, 
     LdpcDeviceCode* C;
     int rc = get_ldpc(ctx, f.code_index, &C);
     if (rc) return rc;
+    if (C->use_wave) {
+        // wave-per-frame decoder: one 64-thread workgroup per frame slot, as many as the LDS of the device holds at once
+        const size_t lds = ldpc_wave_lds_bytes(*C);
+        int per_cu = (int)((size_t)(160 * 1024 - LDPC_WAVE_LDS_RESERVE) / lds);
+        per_cu = per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu);
+        int grid = ctx->num_cus * per_cu;
+        if (grid > nframes) grid = nframes;
+        size_t need = (size_t)grid * ldpc_wave_msg_bytes_per_frame(*C);
+        need = (need + 255) & ~(size_t)255;
+        const size_t sgn_bytes = (size_t)grid * ldpc_sign_ws_bytes_per_slot();
+        if ((rc = ctx->ws_msg.ensure(need + 256 + sgn_bytes))) return rc;
+        if (!d_trials) {
+            if ((rc = ctx->ws_misc.ensure((size_t)nframes * 2 * sizeof(int32_t)))) return rc;
+            d_trials = (int32_t*)ctx->ws_misc.p;
+        }
+        if (!d_hard) {
+            if ((rc = ctx->ws_hard.ensure((size_t)nframes * (f.K / 8)))) return rc;
+            d_hard = (uint8_t*)ctx->ws_hard.p; hard_stride = f.K / 8;
+        }
+        HIP_TRY(ldpc_wave_decode_launch(*C, d_llr, nframes, max_trials, force, d_hard, hard_stride, d_post, d_trials, (uint8_t*)ctx->ws_msg.p, grid, st,
+                                        (unsigned int*)((char*)ctx->ws_msg.p + need), (uint32_t*)((char*)ctx->ws_msg.p + need + 256)));
+        return 0;
+    }
     // workgroups hold 2 frame slots, or 1 for batches smaller than the device (ldpc_kernel.hip)
     const int fpb = ldpc_frames_per_block(nframes, ctx->num_cus);
     int grid = ctx->num_cus * C->blocks_per_cu;

@@ -10,6 +10,7 @@
 #include "../../include/dvbs2gpu.h"
 #include "s2_params.h"
 #include "ldpc_plan.h"
+#include "ldpc_wave_plan.h"
 #include "kernels.h"
 #include "s2_rx.h"
 

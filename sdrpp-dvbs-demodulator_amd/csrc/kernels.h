@@ -15,6 +15,12 @@ struct LdpcDeviceCode {
     uint32_t* d_ents = nullptr;
     uint32_t* d_rows = nullptr;
     int blocks_per_cu = 1;
+    // wave-per-frame form (ldpc_wave_plan.h / ldpc_wave_kernel.hip), built for short frames
+    int wave_lw = 0, wave_nsteps = 0, wave_nl_min = 0, wave_absent_base = 0;
+    uint32_t* d_wave_lanec = nullptr;
+    uint16_t* d_wave_steps = nullptr;
+    uint16_t* d_wave_step_layer = nullptr;
+    bool use_wave = false;          // which of the two decoders a batch of this code goes to
 };
 
 int ldpc_blocks_per_cu(int max_deg, int irregular, int N);
@@ -23,6 +29,10 @@ hipError_t ldpc_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nf
                               uint8_t* hard, int hard_stride, int8_t* post, int32_t* trials, uint32_t* msg_ws, int grid,
                               int fpb, hipStream_t stream, unsigned int* work_ctr, uint32_t* sgn_ws);
 size_t ldpc_sign_ws_bytes_per_slot();
+size_t ldpc_wave_msg_bytes_per_frame(const LdpcDeviceCode& C);
+size_t ldpc_wave_lds_bytes(const LdpcDeviceCode& C);
+hipError_t ldpc_wave_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nframes, int max_trials, int force, uint8_t* hard, int hard_stride,
+                                   int8_t* post, int32_t* trials, uint8_t* msg_ws, int grid, hipStream_t stream, unsigned int* work_ctr, uint32_t* sgn_ws);
 
 // Device-resident tables of one BCH family (GF(2^m), t).
 struct BchDeviceCode {
