@@ -61,7 +61,7 @@ int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
             D.wave_lw = W.lw; D.wave_nsteps = W.nsteps; D.wave_nl_min = W.nl_min; D.wave_absent_base = W.absent_base;
             if ((rc = upload(W.lanec, &D.d_wave_lanec))) return rc;
             if ((rc = upload(W.steps, &D.d_wave_steps))) return rc;
-            if ((rc = upload(W.step_layer, &D.d_wave_step_layer))) return rc;
+            if ((rc = upload(W.layer_end, &D.d_wave_layer_end))) return rc;
             const char* e = getenv("DVBS2GPU_LDPC_WAVE");
             D.use_wave = e ? atoi(e) != 0 : ldpc_wave_default(code_index);
         }

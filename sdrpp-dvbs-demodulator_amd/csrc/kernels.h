@@ -19,7 +19,7 @@ struct LdpcDeviceCode {
     int wave_lw = 0, wave_nsteps = 0, wave_nl_min = 0, wave_absent_base = 0;
     uint32_t* d_wave_lanec = nullptr;
     uint16_t* d_wave_steps = nullptr;
-    uint16_t* d_wave_step_layer = nullptr;
+    uint32_t* d_wave_layer_end = nullptr;
     bool use_wave = false;          // which of the two decoders a batch of this code goes to
 };
 

@@ -18,6 +18,8 @@
 
 namespace s2 {
 
+// The code tables are separate `const T* __restrict__` kernel parameters (not struct members): hipcc then proves them invariant and
+// fetches the wave-uniform entries with scalar loads.
 struct LdpcWaveArgs {
     const int8_t* llr;          // [nframes][N]
     uint8_t* hard;              // [nframes][hard_stride]
@@ -26,21 +28,48 @@ struct LdpcWaveArgs {
     uint8_t* msg_ws;            // [gridDim.x][R * 8 * element bytes]
     uint32_t* sgn_ws;           // [gridDim.x][SGN_WS_DWORDS]
     unsigned int* work_ctr;
-    const uint32_t* lanec;      // ldpc_wave_plan.h
-    const uint16_t* steps;
-    const uint16_t* step_layer;
-    const uint32_t* ents;       // the lane-per-row plan's table (syndrome-check part)
-    int nframes, N, K, R, q, nsteps, nl_min, absent_base, synd_base, max_trials, force, hard_stride;
+    int nframes, N, K, R, q, nsteps, absent_base, synd_base, max_deg, max_trials, force, hard_stride;
 };
 
 #define WQUAD(x_, ctrl) __builtin_amdgcn_update_dpp(0, (x_), (ctrl), 0xf, 0xf, true)
+// one v_med3_i32 (left to itself the compiler narrows these clamps to 16-bit saturating arithmetic: two shifts in, one out)
+__device__ __forceinline__ int wmed3(int x, int lo, int hi) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi)); return r; }
 
 template <int LW> struct WaveElem { typedef uint32_t type; };
 template <> struct WaveElem<1> { typedef uint8_t type; };
 template <> struct WaveElem<2> { typedef uint16_t type; };
 
-template <int LW, int MAXDEG_SYND>
-__global__ __launch_bounds__(64) void ldpc_wave_kernel(LdpcWaveArgs A) {
+// LDPCDecoder::bad on the packed sign vectors (ldpc_dev_common.h), one wave, few registers: the windows of four links at a time
+__device__ __forceinline__ bool wave_syndromes_bad(int q, int max_deg, const uint32_t* __restrict__ tab, const uint32_t* __restrict__ S, int lane) {
+    const int ntask = q * 6;
+    bool bad = false;
+    for (int t = lane; t < ntask; t += 64) {
+        unsigned long long acc = 0;
+        for (int k0 = 0; k0 < max_deg + 2; k0 += 4) {
+            uint32_t e[4], d0[4], d1[4], d2[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) e[i] = (k0 + i < max_deg + 2) ? tab[(k0 + i) * ntask + t] : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const uint32_t* __restrict__ p = S + (e[i] & 0xffffu); d0[i] = p[0]; d1[i] = p[1]; d2[i] = p[2]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t sh = (e[i] >> 16) & 31u;
+                uint32_t lo = __builtin_amdgcn_alignbit(d1[i], d0[i], sh), hi = __builtin_amdgcn_alignbit(d2[i], d1[i], sh);
+                lo &= ~((e[i] >> 30) & 1u);
+                const uint32_t m = (uint32_t)((int)e[i] >> 31);
+                acc ^= ((unsigned long long)(hi & m) << 32) | (lo & m);
+            }
+        }
+        if (t - 6 * (t / 6) == 5) acc &= (1ull << 40) - 1;
+        bad |= acc != 0;
+    }
+    return bad;
+}
+
+// LW link slots per lane; slots kk >= ABS_FROM may be absent in some layer (tail of an irregular code, or 8 * LW > the row degree)
+template <int LW, int ABS_FROM>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ldpc_wave_kernel(const uint32_t* __restrict__ lanec, const uint16_t* __restrict__ steps,
+                                                                                        const uint32_t* __restrict__ layer_end, const uint32_t* __restrict__ ents, LdpcWaveArgs A) {
     extern __shared__ __attribute__((aligned(16))) int8_t wpost[];
     typedef typename WaveElem<LW>::type elem_t;
     constexpr int U = LDPC_WAVE_CHUNK;
@@ -48,9 +77,12 @@ __global__ __launch_bounds__(64) void ldpc_wave_kernel(LdpcWaveArgs A) {
     const int lane = threadIdx.x, l8 = lane & 7, g = lane >> 3;
     const int N = A.N, K = A.K, R = A.R, q = A.q;
     int8_t* __restrict__ post = wpost;
-    elem_t* __restrict__ msg = reinterpret_cast<elem_t*>(A.msg_ws) + (size_t)blockIdx.x * (size_t)R * 8;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) int8_t*)post;
+    elem_t* __restrict__ msg = reinterpret_cast<elem_t*>(A.msg_ws) + (size_t)blockIdx.x * (size_t)R * 8 + l8;
     uint32_t* __restrict__ sgn = A.sgn_ws + (size_t)blockIdx.x * SGN_WS_DWORDS;
-    const int dummy = N + l8;                     // a byte behind the frame (the LDS piece is padded): where absent link slots write
+    const uint32_t dummy = lbase + (uint32_t)(N + l8);        // a byte behind the frame (the LDS piece is padded): where absent link slots read and write
+    const uint16_t* __restrict__ mysteps = steps + g;
+    typedef __attribute__((address_space(3))) int8_t lds_i8;
 
     int f = blockIdx.x;
     while (f < A.nframes) {
@@ -71,90 +103,95 @@ __global__ __launch_bounds__(64) void ldpc_wave_kernel(LdpcWaveArgs A) {
                 const uint32_t z = sign_pack(post, N, reinterpret_cast<uint8_t*>(sgn), lane, 64);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                const bool bad = z != 0 || syndromes_bad<MAXDEG_SYND>(q, A.synd_base, A.ents, sgn, lane, 64);
+                const bool bad = z != 0 || wave_syndromes_bad(q, A.max_deg, ents + A.synd_base, sgn, lane);
                 const bool any = __ballot(bad) != 0;
                 if (A.force) { ret = any ? -1 : A.max_trials; done = true; }
                 else if (!any) { ret = it; done = true; }
                 else if (it == A.max_trials) { ret = -1; done = true; }
             }
             if (done) break;
-            // ---- one layered sweep (LDPCDecoder::update)
+            // ---- one layered sweep (LDPCDecoder::update): layer by layer, a layer's steps in chunks of U; step list and message elements
+            // travel a chunk ahead (the list is padded with empty chunks, so the fetches need no bound test)
             const bool first = (it == 0);
-            int cur_layer = -1;
-            uint32_t thr[LW], cA[LW], cB[LW], absm = 0;
-            // step list and message elements travel a chunk ahead
-            uint32_t jn[U], jm[U];
-            uint32_t rn[U];
+            uint32_t jn[U], jm[U], rn[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) { jn[u] = A.steps[u * 8 + g]; jm[u] = A.steps[(U + u) * 8 + g]; }
+            for (int u = 0; u < U; ++u) { jn[u] = mysteps[u * 8]; jm[u] = mysteps[(U + u) * 8]; }
+            // (message elements are fetched unconditionally -- a load behind a branch is waited for on the spot --: empty slots read row R-1,
+            // the first sweep reads the workspace as it is and ignores it)
 #pragma unroll
-            for (int u = 0; u < U; ++u) rn[u] = (!first && jn[u] != LDPC_WAVE_NOROW) ? (uint32_t)msg[(size_t)jn[u] * 8 + l8] : 0u;
-            for (int s0 = 0; s0 < A.nsteps; s0 += U) {
-                uint32_t jq[U], rq[U];
+            for (int u = 0; u < U; ++u) { const uint32_t e = (uint32_t)msg[(size_t)min(jn[u], (uint32_t)(R - 1)) * 8]; rn[u] = first ? 0u : e; }
+            int chunk = 0;
+            for (int layer = 0; layer < q; ++layer) {
+                uint32_t thr[LW], cA[LW], cB[LW], absm = 0;
 #pragma unroll
-                for (int u = 0; u < U; ++u) jq[u] = A.steps[(s0 + 2 * U + u) * 8 + g];
-#pragma unroll
-                for (int u = 0; u < U; ++u) rq[u] = (!first && jm[u] != LDPC_WAVE_NOROW) ? (uint32_t)msg[(size_t)jm[u] * 8 + l8] : 0u;
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int layer = (int)A.step_layer[s0 + u];          // wave-uniform
-                    if (layer != cur_layer) {
-                        cur_layer = layer;
-#pragma unroll
-                        for (int kk = 0; kk < LW; ++kk) {
-                            const uint32_t c = A.lanec[((size_t)layer * 8 + l8) * LW + kk];
-                            thr[kk] = c & 0xffffu; cA[kk] = c >> 16; cB[kk] = (c >> 16) - 360u;
-                        }
-                        absm = A.lanec[A.absent_base + layer * 8 + l8];
-                    }
-                    const bool valid = jn[u] != LDPC_WAVE_NOROW;
-                    const uint32_t rowid = valid ? jn[u] : (uint32_t)(360 * layer);
-                    const int j = (int)rowid - 360 * layer;
-                    const uint32_t rec = rn[u];
-                    int a[LW], v[LW], mg[LW];
-#pragma unroll
-                    for (int kk = 0; kk < LW; ++kk) {
-                        a[kk] = j + (int)((uint32_t)j >= thr[kk] ? cB[kk] : cA[kk]);
-                        if ((kk + 1) * 8 > A.nl_min && ((absm >> kk) & 1u)) a[kk] = dummy;                 // (uniform test first: only tail slots can be absent)
-                    }
-                    if (layer == 0 && l8 == 1 && j == 0) a[0] = dummy;                                     // row 0 of layer 0 has no previous parity bit
-                    int x[LW];
-#pragma unroll
-                    for (int kk = 0; kk < LW; ++kk) x[kk] = post[a[kk]];
-                    int min0 = 255, min1 = 255, sx = 0;
-#pragma unroll
-                    for (int kk = 0; kk < LW; ++kk) {
-                        const int m = (int)__builtin_amdgcn_sbfe((int)rec, 8 * kk, 8);
-                        int vv = clamp8(x[kk] - m);
-                        int gg = mag_of(vv);
-                        if ((kk + 1) * 8 > A.nl_min && ((absm >> kk) & 1u)) { vv = 0; gg = 127; }
-                        if (kk == 0 && layer == 0 && l8 == 1 && j == 0) { vv = 0; gg = 127; }
-                        v[kk] = vv; mg[kk] = gg;
-                        min1 = min(min1, max(min0, gg));
-                        min0 = min(min0, gg);
-                        sx ^= vv;
-                    }
-                    // the row's totals over its 8 lanes: two smallest magnitudes (with multiplicity) and the sign
-#define WJOIN(ctrl) do { const int o0 = WQUAD(min0, ctrl), o1 = WQUAD(min1, ctrl); min1 = min(max(min0, o0), min(min1, o1)); min0 = min(min0, o0); sx ^= WQUAD(sx, ctrl); } while (0)
-                    WJOIN(0xB1);             // quad_perm [1,0,3,2]
-                    WJOIN(0x4E);             // quad_perm [2,3,0,1]
-                    WJOIN(0x141);            // row_half_mirror: the other quad of the 8-lane group
-#undef WJOIN
-                    uint32_t ro = 0;
-                    if (valid) {
-#pragma unroll
-                        for (int kk = 0; kk < LW; ++kk) {
-                            const int other = (mg[kk] == min0) ? min1 : min0;
-                            const int neg = (sx ^ v[kk]) >> 31;
-                            const int nm = med3i((other ^ neg) - neg, -32, 31);
-                            post[a[kk]] = (int8_t)clamp8(v[kk] + nm);
-                            ro |= ((uint32_t)nm & 0xffu) << (8 * kk);
-                        }
-                        msg[(size_t)rowid * 8 + l8] = (elem_t)ro;
-                    }
+                for (int kk = 0; kk < LW; ++kk) {
+                    const uint32_t c = lanec[((size_t)layer * 8 + l8) * LW + kk];
+                    thr[kk] = c & 0xffffu; cA[kk] = lbase + (c >> 16); cB[kk] = cA[kk] - 360u;
                 }
+                if (ABS_FROM < LW) absm = lanec[A.absent_base + layer * 8 + l8];
+                const int cend = (int)layer_end[layer];
+                const uint32_t row0 = (uint32_t)(360 * layer);
+                const bool l0fix = (layer == 0) && l8 == 1;              // row 0 of layer 0 has no previous parity bit (slot 1)
+                for (; chunk < cend; ++chunk) {
+                    uint32_t jq[U], rq[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) { jn[u] = jm[u]; jm[u] = jq[u]; rn[u] = rq[u]; }
+                    for (int u = 0; u < U; ++u) jq[u] = mysteps[((chunk + 2) * U + u) * 8];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { const uint32_t e = (uint32_t)msg[(size_t)min(jm[u], (uint32_t)(R - 1)) * 8]; rq[u] = first ? 0u : e; }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const bool valid = jn[u] != LDPC_WAVE_NOROW;
+                        const uint32_t rowid = valid ? jn[u] : row0;
+                        const uint32_t j = rowid - row0;
+                        const uint32_t rec = rn[u];
+                        uint32_t a[LW];
+                        bool ab[LW];
+#pragma unroll
+                        for (int kk = 0; kk < LW; ++kk) {
+                            a[kk] = j + (j >= thr[kk] ? cB[kk] : cA[kk]);
+                            ab[kk] = kk >= ABS_FROM && ((absm >> kk) & 1u);
+                            if (kk == 0) ab[kk] = ab[kk] || (l0fix && j == 0);
+                            if (kk >= ABS_FROM || kk == 0) a[kk] = ab[kk] ? dummy : a[kk];
+                        }
+                        int x[LW];
+#pragma unroll
+                        for (int kk = 0; kk < LW; ++kk) x[kk] = *(lds_i8*)(uintptr_t)a[kk];
+                        int v[LW], mg[LW];
+                        int min0 = 255, min1 = 255, sx = 0;
+#pragma unroll
+                        for (int kk = 0; kk < LW; ++kk) {
+                            const int m = (int)__builtin_amdgcn_sbfe((int)rec, 8 * kk, 8);
+                            int vv = wmed3(x[kk] - m, -128, 127);
+                            int gg = mag_of(vv);
+                            if (kk >= ABS_FROM || kk == 0) { vv = ab[kk] ? 0 : vv; gg = ab[kk] ? 127 : gg; }
+                            v[kk] = vv; mg[kk] = gg;
+                            if (kk == 0) min0 = gg;
+                            else if (kk == 1) { min1 = max(min0, gg); min0 = min(min0, gg); }
+                            else { min1 = min(min1, max(min0, gg)); min0 = min(min0, gg); }
+                            sx ^= vv;
+                        }
+                        // the row's totals over its 8 lanes: two smallest magnitudes (with multiplicity) and the sign
+#define WJOIN(ctrl) do { const int o0 = WQUAD(min0, ctrl), o1 = WQUAD(min1, ctrl); min1 = min(max(min0, o0), min(min1, o1)); min0 = min(min0, o0); sx ^= WQUAD(sx, ctrl); } while (0)
+                        WJOIN(0xB1);             // quad_perm [1,0,3,2]
+                        WJOIN(0x4E);             // quad_perm [2,3,0,1]
+                        WJOIN(0x141);            // row_half_mirror: the other quad of the 8-lane group
+#undef WJOIN
+                        if (valid) {
+                            uint32_t ro = 0;
+#pragma unroll
+                            for (int kk = 0; kk < LW; ++kk) {
+                                const int other = (mg[kk] == min0) ? min1 : min0;
+                                const int neg = (sx ^ v[kk]) >> 31;
+                                const int nm = wmed3((other ^ neg) - neg, -32, 31);
+                                *(lds_i8*)(uintptr_t)a[kk] = (int8_t)wmed3(v[kk] + nm, -128, 127);
+                                ro |= ((uint32_t)nm & 0xffu) << (8 * kk);
+                            }
+                            msg[(size_t)rowid * 8] = (elem_t)ro;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { jn[u] = jm[u]; jm[u] = jq[u]; rn[u] = rq[u]; }
+                }
             }
             ++it;
         }
@@ -190,12 +227,12 @@ __global__ __launch_bounds__(64) void ldpc_wave_kernel(LdpcWaveArgs A) {
     }
 }
 
-template <int LW, int MAXDEG_SYND>
-static hipError_t launch_wave(const LdpcWaveArgs& A, int grid, size_t lds, hipStream_t stream) {
-    auto kern = ldpc_wave_kernel<LW, MAXDEG_SYND>;
+template <int LW, int ABS_FROM>
+static hipError_t launch_wave(const LdpcDeviceCode& C, const LdpcWaveArgs& A, int grid, size_t lds, hipStream_t stream) {
+    auto kern = ldpc_wave_kernel<LW, ABS_FROM>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, A);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, stream, C.d_wave_lanec, C.d_wave_steps, C.d_wave_layer_end, C.d_ents, A);
     return hipGetLastError();
 }
 
@@ -209,20 +246,19 @@ hipError_t ldpc_wave_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, i
                                    int8_t* post, int32_t* trials, uint8_t* msg_ws, int grid, hipStream_t stream, unsigned int* work_ctr, uint32_t* sgn_ws) {
     LdpcWaveArgs A;
     A.llr = llr; A.hard = hard; A.post = post; A.trials = trials; A.msg_ws = msg_ws; A.sgn_ws = sgn_ws; A.work_ctr = work_ctr;
-    A.lanec = C.d_wave_lanec; A.steps = C.d_wave_steps; A.step_layer = C.d_wave_step_layer; A.ents = C.d_ents;
-    A.nframes = nframes; A.N = C.N; A.K = C.K; A.R = C.R; A.q = C.q; A.nsteps = C.wave_nsteps; A.nl_min = C.wave_nl_min;
-    A.absent_base = C.wave_absent_base; A.synd_base = C.synd_base; A.max_trials = max_trials; A.force = force; A.hard_stride = hard_stride;
+    A.nframes = nframes; A.N = C.N; A.K = C.K; A.R = C.R; A.q = C.q; A.nsteps = C.wave_nsteps;
+    A.absent_base = C.wave_absent_base; A.synd_base = C.synd_base; A.max_deg = C.max_deg; A.max_trials = max_trials; A.force = force; A.hard_stride = hard_stride;
     if (work_ctr) {
         hipError_t e = hipMemsetAsync(work_ctr, 0, sizeof(unsigned int), stream);
         if (e != hipSuccess) return e;
     }
     const size_t lds = ldpc_wave_lds_bytes(C);
-    // (the syndrome check is instantiated per table width, like the lane-per-row kernels)
-#define WAVE_CASE(LW_, MD_) if (C.wave_lw == LW_ && C.max_deg == MD_) return launch_wave<LW_, MD_>(A, grid, lds, stream)
-    WAVE_CASE(1, 2); WAVE_CASE(1, 3); WAVE_CASE(1, 4); WAVE_CASE(1, 5);
-    WAVE_CASE(2, 8); WAVE_CASE(2, 9); WAVE_CASE(2, 11); WAVE_CASE(2, 12);
-    WAVE_CASE(3, 16); WAVE_CASE(3, 17); WAVE_CASE(3, 20);
-    WAVE_CASE(4, 25); WAVE_CASE(4, 28);
+    const int abs_from = C.wave_nl_min / 8;         // first slot index kk that holds a link slot >= the smallest row degree
+#define WAVE_CASE(LW_, AF_) if (C.wave_lw == LW_ && abs_from == AF_) return launch_wave<LW_, AF_>(C, A, grid, lds, stream)
+    WAVE_CASE(1, 0); WAVE_CASE(1, 1);
+    WAVE_CASE(2, 0); WAVE_CASE(2, 1); WAVE_CASE(2, 2);
+    WAVE_CASE(3, 0); WAVE_CASE(3, 1); WAVE_CASE(3, 2); WAVE_CASE(3, 3);
+    WAVE_CASE(4, 1); WAVE_CASE(4, 2); WAVE_CASE(4, 3); WAVE_CASE(4, 4);
 #undef WAVE_CASE
     return hipErrorInvalidValue;
 }

@@ -19,7 +19,9 @@ constexpr int LDPC_WAVE_CHUNK = 4;          // steps per prefetch chunk (ldpc_wa
 constexpr uint16_t LDPC_WAVE_NOROW = 0xffffu;
 constexpr int LDPC_WAVE_LDS_RESERVE = 28 * 1024;   // LDS per CU left to the front-end kernels that run beside the decoder in the pipelined mode
 // which codes (index into QC_CODES) go to the wave-per-frame decoder unless DVBS2GPU_LDPC_WAVE says otherwise (per-code timings: DESIGN.md)
-inline bool ldpc_wave_default(int code_index) { return code_index == 20; }   // C10 (rate 8/9 short)
+// MI355X, 16384 frames x 50 forced iterations, lane-per-row vs wave-per-frame: 3/5 short 141 vs 119 ms, 4/5 short 65 vs 61, 5/6 short 155 vs 60,
+// 8/9 short 106 vs 48; the other six short codes (few links per row, few levels) stay with the lane-per-row decoder (1/4: 53 vs 305 ms)
+inline bool ldpc_wave_default(int code_index) { return code_index == 15 || code_index == 18 || code_index == 19 || code_index == 20; }
 
 struct LdpcWavePlan {
     int lw = 0;                             // link slots per lane, ceil((max_deg + 2) / 8)
@@ -27,8 +29,8 @@ struct LdpcWavePlan {
     int nsteps = 0;                         // steps per sweep, a multiple of LDPC_WAVE_CHUNK (+ 2 empty chunks behind the list for the prefetch)
     std::vector<uint32_t> lanec;            // [q][8 lanes][lw] thr | cA << 16: lane reads byte (j >= thr ? cA - 360 : cA) + j of the posterior array; then [q][8] absent masks (bit kk)
     int absent_base = 0;
-    std::vector<uint16_t> steps;            // [nsteps + 2 chunks][8] row ids (360 * layer + j), LDPC_WAVE_NOROW = empty slot
-    std::vector<uint16_t> step_layer;       // [nsteps + 2 chunks] layer of each step
+    std::vector<uint16_t> steps;            // [nsteps + 2 chunks][8] row ids (360 * layer + j), LDPC_WAVE_NOROW = empty slot; a layer's steps are padded to whole chunks
+    std::vector<uint32_t> layer_end;        // [q] chunk index at which layer i's steps end
 };
 
 inline LdpcWavePlan build_ldpc_wave_plan(const LdpcPlan& P) {
@@ -63,21 +65,20 @@ inline LdpcWavePlan build_ldpc_wave_plan(const LdpcPlan& P) {
     }
     W.absent_base = (int)W.lanec.size();
     W.lanec.insert(W.lanec.end(), absent.begin(), absent.end());
-    // steps: per layer the rows level by level, eight per step
+    // steps: per layer the rows level by level, eight per step; every layer ends on a chunk boundary
     for (int i = 0; i < q; ++i) {
         const LdpcLayerDesc& L = P.layers[i];
         const int depth = (int)(L.depth_nc & 0xffffu);
         std::vector<std::vector<int>> by_level(depth + 1);
         for (int j = 0; j < 360; ++j) by_level[depth > 1 ? (int)(P.rows[L.row_off + j] & 0xffu) : 1].push_back(j);
         for (int lv = 1; lv <= depth; ++lv)
-            for (size_t o = 0; o < by_level[lv].size(); o += 8) {
+            for (size_t o = 0; o < by_level[lv].size(); o += 8)
                 for (size_t t = 0; t < 8; ++t) W.steps.push_back(o + t < by_level[lv].size() ? (uint16_t)(360 * i + by_level[lv][o + t]) : LDPC_WAVE_NOROW);
-                W.step_layer.push_back((uint16_t)i);
-            }
+        while ((W.steps.size() / 8) % LDPC_WAVE_CHUNK) W.steps.insert(W.steps.end(), 8, LDPC_WAVE_NOROW);
+        W.layer_end.push_back((uint32_t)(W.steps.size() / 8 / LDPC_WAVE_CHUNK));
     }
-    while (W.step_layer.size() % LDPC_WAVE_CHUNK) { W.steps.insert(W.steps.end(), 8, LDPC_WAVE_NOROW); W.step_layer.push_back((uint16_t)(q - 1)); }
-    W.nsteps = (int)W.step_layer.size();
-    for (int t = 0; t < 2 * LDPC_WAVE_CHUNK; ++t) { W.steps.insert(W.steps.end(), 8, LDPC_WAVE_NOROW); W.step_layer.push_back((uint16_t)(q - 1)); }
+    W.nsteps = (int)(W.steps.size() / 8);
+    W.steps.insert(W.steps.end(), 8 * 2 * LDPC_WAVE_CHUNK, LDPC_WAVE_NOROW);
     return W;
 }
 
