@@ -179,7 +179,9 @@ typedef struct dvbs2gpu_demod_cfg {
      *              of the reference's hard decisions compared on 60 bits (dvbs2_plhdr_demod.cpp:45-58,69-79).
      * pilot_aided  SURVEY 8(f) rank 4.  The known symbols (PL header, pilot blocks) give the PLL a block phase estimate that is
      *              applied at the end of each block, on top of the reference's decision-directed loop (dvbs2_pll.cpp:34-86): no
-     *              rotational false locks. */
+     *              rotational false locks.  Pilot symbols then also drive the loop with the data-aided error phase(descrambled x
+     *              conj((1+j)/sqrt2)) at full gain; with 0 they use the reference's error, decision-directed on the sign-sliced
+     *              QPSK point and divided by 10 (dvbs2_pll.cpp:58). */
     int32_t acm_vcm, soft_plsc, pilot_aided;
 } dvbs2gpu_demod_cfg;
 
@@ -390,7 +392,9 @@ int dvbs2gpu_dvbs_tail_get_tap(dvbs2gpu_dvbs_tail* t, int stream, int which, voi
  * 8) 204-byte packets supplied by the caller as stream 0's de-interleaved frames -- DVBSReedSolomon::decode and
  * DVBSScrambling::descramble without the deframer and the de-interleaver in front.  skip_rs != 0: the packets are taken as decoded
  * (descrambler alone).  HOST pointers; returns the TS bytes written to h_ts (188 per packet); taps 1-3 above then hold the
- * corrected packets, the decoder status and the error counts.  Advances stream 0's dispersal / last-message state. */
+ * corrected packets, the decoder status and the error counts.  Advances stream 0's dispersal / last-message state and overwrites the
+ * handle's de-interleaved packets, status and frame counts: TEST HOOK, to be called on a handle of its own, never on one that is
+ * receiving (calls are serialised per context like every other entry point). */
 int dvbs2gpu_dvbs_tail_rs_stage(dvbs2gpu_dvbs_tail* t, const uint8_t* h_packets, int npackets, int skip_rs, uint8_t* h_ts, int cap);
 /* Stage entry (parity tests): the de-puncturers and the soft rotation that run inside the Viterbi kernel, on HOST buffers.
  *   mode 0  Depunc23 / Depunc56 ::depunc_static (depunc.h:16-38,108-137), period 3 / 6, h_state4[1] = shift

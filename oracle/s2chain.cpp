@@ -513,9 +513,15 @@ void S2Rx::pll(const cf* in, cf* out, const FrameCtx& fc) {   // dvbs2_pll.cpp:3
             if (!is_pilot) {
                 constel.soft_lut(tmp_val, nullptr, &error);
             } else {
-                const cf pr = cmul(descr, cf{0.707f, -0.707f});
-                error = cphase(pr);   // data-aided on the known (1+j)/sqrt2 pilot
-                acc = cadd(acc, pr);
+                if (cfg.pilot_aided) {
+                    const cf pr = cmul(descr, cf{0.707f, -0.707f});
+                    error = cphase(pr);   // own extension: data-aided on the known (1+j)/sqrt2 pilot
+                    acc = cadd(acc, pr);
+                } else {
+                    // dvbs2_pll.cpp:58: decision-directed on the sign-sliced QPSK point, a tenth of the gain
+                    const cf pt{descr.re > 0 ? 0.707f : -0.707f, descr.im > 0 ? 0.707f : -0.707f};
+                    error = cphase(cmul(descr, cconj(pt))) / 10.0f;
+                }
                 if (i == next_pilot + 35) { ++pb; next_pilot = pb < mp.pilot_blocks ? pilot_start(pb) : -1; block_end = true; }
             }
             out[i] = descr;

@@ -270,6 +270,7 @@ int dvbs2gpu_dvbs_tail_get_stats(dvbs2gpu_dvbs_tail* t, int stream, int32_t* h_o
 /* taps of the last process_batch / rs_stage call of one stream (see include/dvbs2gpu.h) */
 int dvbs2gpu_dvbs_tail_get_tap(dvbs2gpu_dvbs_tail* t, int stream, int which, void* h_dst, int cap) {
     if (!t || stream < 0 || stream >= t->nstreams || which < 0 || which > 3 || cap < 0) return DVBS2GPU_ERR_ARG;
+    CallGuard guard(t->ctx);
     HIP_TRY(hipSetDevice(t->ctx->device));
     int nf = 0;
     HIP_TRY(hipMemcpy(&nf, t->d_nframes + stream, sizeof(int), hipMemcpyDeviceToHost));
@@ -286,7 +287,11 @@ int dvbs2gpu_dvbs_tail_get_tap(dvbs2gpu_dvbs_tail* t, int stream, int which, voi
 }
 int dvbs2gpu_dvbs_tail_rs_stage(dvbs2gpu_dvbs_tail* t, const uint8_t* h_packets, int npackets, int skip_rs, uint8_t* h_ts, int cap) {
     if (!t || !h_packets || npackets <= 0 || npackets % 8 || npackets > t->max_frames * 8 || !h_ts || cap < 0) return DVBS2GPU_ERR_ARG;
+    // TEST HOOK ON A DEDICATED HANDLE (include/dvbs2gpu.h): it overwrites the handle's de-interleaved packets, status and frame counts and advances
+    // stream 0's energy-dispersal phase and last RS message -- never call it on a tail that is receiving
+    CallGuard guard(t->ctx);
     HIP_TRY(hipSetDevice(t->ctx->device));
+    HIP_TRY(hipDeviceSynchronize());            // (the engine's streams are non-blocking: null-stream copies do not order themselves behind them)
     const int n = t->nstreams, nf = npackets / 8;
     std::vector<int> nfr(n, 0);
     nfr[0] = nf;
@@ -314,6 +319,7 @@ int dvbs2gpu_dvbs_tail_rs_stage(dvbs2gpu_dvbs_tail* t, const uint8_t* h_packets,
 int dvbs2gpu_dvbs_depuncture(dvbs2gpu_ctx* ctx, int period, int mode, const uint8_t* h_in, int size, uint8_t* h_out, int out_cap, int32_t* h_state4) {
     if (!ctx || !h_in || !h_out || !h_state4 || size <= 0 || mode < 0 || mode > 2 || (mode != 2 && period != 3 && period != 6)) return DVBS2GPU_ERR_ARG;
     if (out_cap < 2 * size + 2) return DVBS2GPU_ERR_CAPACITY;
+    CallGuard guard(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     uint8_t* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, (size_t)size + out_cap + 64));

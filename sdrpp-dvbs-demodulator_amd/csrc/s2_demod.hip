@@ -951,6 +951,7 @@ int dvbs2gpu_demod_create(dvbs2gpu_ctx* ctx, const dvbs2gpu_demod_cfg* cfg, int 
     d->ctx = ctx; d->cfg = *cfg; d->max_samples = max_samples;
     int rc = demod_configure(d.get());
     if (rc) return rc;
+    CallGuard guard(ctx);               // (one context may serve several blocks on several host threads: whole calls are serialised, ctx.h)
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMalloc((void**)&d->d_state, sizeof(S2StreamState)));
     HIP_TRY(hipMalloc((void**)&d->d_fe, fe_capacity(max_samples) * sizeof(cf32)));
@@ -973,12 +974,16 @@ void dvbs2gpu_demod_destroy(dvbs2gpu_demod* d) {
 
 int dvbs2gpu_demod_reset(dvbs2gpu_demod* d) {
     if (!d) return DVBS2GPU_ERR_ARG;
+    CallGuard guard(d->ctx);
     HIP_TRY(hipSetDevice(d->ctx->device));
+    // the engine's streams are non-blocking: a null-stream copy does not order itself behind what another handle's call still has in flight
+    HIP_TRY(hipDeviceSynchronize());
     return demod_reset_state(d);
 }
 
 int dvbs2gpu_demod_set_params(dvbs2gpu_demod* d, int modcod, int shortframes, int pilots, float sof_threshold, int max_ldpc_trials) {
     if (!d) return DVBS2GPU_ERR_ARG;
+    CallGuard guard(d->ctx);
     dvbs2gpu_demod_cfg saved = d->cfg;
     d->cfg.modcod = modcod; d->cfg.shortframes = shortframes; d->cfg.pilots = pilots;
     d->cfg.sof_threshold = sof_threshold; d->cfg.max_ldpc_trials = max_ldpc_trials;
@@ -987,10 +992,15 @@ int dvbs2gpu_demod_set_params(dvbs2gpu_demod* d, int modcod, int shortframes, in
     // setDemodParams restarts the PL sync buffer (dvbs2_pl_sync.cpp:51-79); loops keep running
     d->sym_base += d->fifo_fill;      // (the dropped symbols still count on the stream's symbol axis)
     d->fifo_fill = 0;
-    {   // PL-sync state back to 0 on the device as well
-        int zero_state[2] = {0, 0};
+    {   // the whole PL-sync sub-state back to 0 on the device as well: pending realign + last best_match, and where the sliced walk / frame loops stood
         HIP_TRY(hipSetDevice(d->ctx->device));
-        HIP_TRY(hipMemcpy((char*)d->d_state + offsetof(S2StreamState, pl_pending), zero_state, sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipDeviceSynchronize());            // (non-blocking streams: see dvbs2gpu_demod_reset)
+        const int zero_pl[2] = {0, 0};              // pl_pending, pl_last_bm (0.0f)
+        const int zero_walk[3] = {0, 0, 0};         // walk_cur, walk_nf, loops_done
+        static_assert(offsetof(S2StreamState, pl_last_bm) == offsetof(S2StreamState, pl_pending) + sizeof(int), "pl_pending and pl_last_bm are cleared together");
+        static_assert(offsetof(S2StreamState, loops_done) == offsetof(S2StreamState, walk_cur) + 2 * sizeof(int), "walk_cur, walk_nf, loops_done are cleared together");
+        HIP_TRY(hipMemcpy((char*)d->d_state + offsetof(S2StreamState, pl_pending), zero_pl, sizeof(zero_pl), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy((char*)d->d_state + offsetof(S2StreamState, walk_cur), zero_walk, sizeof(zero_walk), hipMemcpyHostToDevice));
     }
     return 0;
 }

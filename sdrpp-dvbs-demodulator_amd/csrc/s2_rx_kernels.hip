@@ -1057,9 +1057,16 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
                         if (C.bits != 5) error = C.lut_err[lut_index(tmp_val.re) * 256 + lut_index(tmp_val.im)];
                         else error = soft_phase_err_group<FL_LPS>((lds_cf32*)reinterpret_cast<const float*>(s_pts), C.states, C.amp, C.prescale, tmp_val, gl);
                     } else {
-                        const cf32 pr = cmul(descr, cf32{0.707f, -0.707f});
-                        error = cphase(pr);
-                        if (co.pilot_aided) pacc = cadd(pacc, pr);
+                        if (co.pilot_aided) {
+                            // own extension: data-aided on the known (1+j)/sqrt2 pilot, and the block estimate below
+                            const cf32 pr = cmul(descr, cf32{0.707f, -0.707f});
+                            error = cphase(pr);
+                            pacc = cadd(pacc, pr);
+                        } else {
+                            // the reference's pilot error: decision-directed on the sign-sliced QPSK point, a tenth of the gain (dvbs2_pll.cpp:58)
+                            const cf32 pt{descr.re > 0 ? 0.707f : -0.707f, descr.im > 0 ? 0.707f : -0.707f};
+                            error = cphase(cmul(descr, cconj(pt))) / 10.0f;
+                        }
                         if (i == next_pilot + 35) { ++pb; next_pilot = pb < pilot_blocks ? pilot_start(pb) : -1; block_end = true; }
                     }
                     o = descr;
@@ -1545,9 +1552,16 @@ __global__ __launch_bounds__(64) void s2_vcm_loops_kernel(const S2StreamWork* __
                         if (cbits != 5) error = C->lut_err[lut_index(tmp_val.re) * 256 + lut_index(tmp_val.im)];
                         else error = soft_phase_err_group<64>((lds_cf32*)reinterpret_cast<const float*>(v_pts), C->states, C->amp, C->prescale, tmp_val, lane);
                     } else {
-                        const cf32 pr = cmul(descr, cf32{0.707f, -0.707f});
-                        error = cphase(pr);
-                        if (co.pilot_aided) pacc = cadd(pacc, pr);
+                        if (co.pilot_aided) {
+                            // own extension: data-aided on the known (1+j)/sqrt2 pilot, and the block estimate below
+                            const cf32 pr = cmul(descr, cf32{0.707f, -0.707f});
+                            error = cphase(pr);
+                            pacc = cadd(pacc, pr);
+                        } else {
+                            // the reference's pilot error: decision-directed on the sign-sliced QPSK point, a tenth of the gain (dvbs2_pll.cpp:58)
+                            const cf32 pt{descr.re > 0 ? 0.707f : -0.707f, descr.im > 0 ? 0.707f : -0.707f};
+                            error = cphase(cmul(descr, cconj(pt))) / 10.0f;
+                        }
                         if (i == next_pilot + 35) { ++pb; next_pilot = pb < pilot_blocks ? pilot_start(pb) : -1; block_end = true; }
                     }
                     o = descr;
@@ -2254,13 +2268,15 @@ static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, c
 #ifndef S2_GARDNER_BANK_MIN
 #define S2_GARDNER_BANK_MIN 512
 #endif
-static int gardner_form(int nstreams) {
+static int gardner_form(int nstreams, int prio_duty) {
     static const int forced = [] { const char* e = getenv("DVBS2GPU_GARDNER_FORM"); return e ? atoi(e) : 0; }();
     if (forced >= 1 && forced <= 3) return forced;
-    return nstreams < S2_GARDNER_BANK_MIN ? 2 : 1;
+    // a big bank beside the decoder of the previous call: the one-wave form disturbs the decoder least; once the balancer of the pipelined
+    // mode (s2_demod.hip) has found the FRONT END to be the critical path (it raises the timing loop's priority share), the shorter chain wins
+    return (nstreams < S2_GARDNER_BANK_MIN || prio_duty >= 2) ? 2 : 1;
 }
 static void gardner_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const float* d_bank, hipStream_t st, int c, int nsub) {
-    switch (gardner_form(nstreams)) {
+    switch (gardner_form(nstreams, coefs.g_prio_duty)) {
         case 3: hipLaunchKernelGGL(s2_gardner_bank_kernel, dim3((nstreams + 63) / 64), dim3(128), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
         case 2: hipLaunchKernelGGL(s2_gardner2_kernel, dim3((nstreams + G_SPW - 1) / G_SPW), dim3(128), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
         default: hipLaunchKernelGGL(s2_gardner_kernel, dim3((nstreams + G_SPW - 1) / G_SPW), dim3(64), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
