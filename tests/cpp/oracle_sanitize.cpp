@@ -51,7 +51,7 @@ static void fec_roundtrips() {
 static void s2_chain(int modcod, int sh, int pil, double esn0, int chunk) {
     using namespace orc;
     TxCfg t{};
-    t.modcod = modcod; t.shortframes = sh; t.pilots = pil; t.nframes = modcod == 27 ? 12 : 6;   // (32APSK + pilots: the reference's pilot error -- a tenth of the loop gain -- acquires later) t.seed = 5 + modcod; t.esn0_db = esn0; t.cfo = 1e-3; t.timing = 0.3;
+    t.modcod = modcod; t.shortframes = sh; t.pilots = pil; t.nframes = modcod == 27 ? 12 : 6 /* 32APSK + pilots acquires late */; t.seed = 5 + modcod; t.esn0_db = esn0; t.cfo = 1e-3; t.timing = 0.3;
     t.phase0 = 0.2; t.lead_symbols = 333; t.circular = 0; t.nsamples = 0;
     std::vector<uint8_t> bb;
     std::vector<cf> iq = s2_transmit(t, &bb);
