@@ -324,44 +324,81 @@ def secondary_s2(eng, pkg, dev, name, modcod, rate, short, pilots, esn0_db, S, F
 
 
 def secondary_dvbs(eng, pkg, dev):
-    """BASELINE config D / 1: DVB-S QPSK 1/2, IQ -> decoded bits -> TS packets.  GPU: a bank of 4096 carriers and ONE carrier; CPU:
-    the oracle restatement of DVBSDemod::process on one thread (config 1's number, kind "port": SDR++/VOLK are not available)."""
+    """BASELINE config D / 1: DVB-S QPSK 1/2, IQ -> TS PACKETS (DVBSDemod::process, module_dvbs_demod.cpp:78-117: QPSK_ALT front end, soft
+    slicer, self-locking Viterbi, TS deframer, Forney de-interleaver, RS(204,188), energy dispersal).  GPU: a bank of 4096 carriers and ONE
+    carrier, receiver bank + tail bank, a continuous signal in calls of 65 536 symbols; CPU (config 1): the oracle restatement of the same
+    chain on one thread (kind "port": SDR++ / VOLK are not available; the tail stages are pinned against the reference's own sources)."""
     import torch
     import orc_dvbs as od
-    nsym = 65536
-    iq, _ = od.dvbs_iq(0, nsym, seed=1, esn0_db=12.0, cfo=1e-3, timing=0.3)
-    out = {'config': 'D: DVB-S QPSK 1/2, 2 sps, IQ -> Viterbi output (receiver bank, dvbs2gpu_dvbs_demod_*)'}
+    import orc_dvbs_tail as ot
+    npk, chunk_sym = 320, 65536
+    obits, ts = ot.dvbs_outer_tx(npk, seed=5)
+    enc = od.cc_encode(obits)
+    nsym = enc.size // 2
+    iq = np.zeros(2 * nsym, np.complex64)
+    od.LF().orc_dvbs_modulate(od.P(np.ascontiguousarray(enc)), nsym, 12.0, 1e-3, 0.3, 0.2, 7, od.P(iq))
+    sent = {bytes(p) for p in ts}
+    ncalls = nsym // chunk_sym
+    out = {'config': 'D / 1: DVB-S QPSK 1/2, 2 sps, IQ -> TS packets (receiver bank dvbs2gpu_dvbs_demod_* + tail bank dvbs2gpu_dvbs_tail_*), continuous signal of %d symbols in calls of %d' % (ncalls * chunk_sym, chunk_sym)}
+    d_iq = torch.from_numpy(iq).to(dev)
     for S in (4096, 1):
-        bank = pkg.DvbsDemodBank(eng, S, max_samples=iq.size)
-        d_iq = torch.from_numpy(iq).to(dev)
-        tin = [d_iq for _ in range(S)]
-        tout = [torch.zeros(iq.size + 4 * 8192, dtype=torch.uint8, device=dev) for _ in range(S)]
-        bank.process_batch(tin, tout)
+        bank = pkg.DvbsDemodBank(eng, S, max_samples=2 * chunk_sym)
+        tail = pkg.DvbsTailBank(eng, S, max_bits=chunk_sym + 4 * 8192)
+        bits = torch.zeros((S, 2 * chunk_sym + 4 * 8192), dtype=torch.uint8, device=dev)
+        tso = torch.zeros((S, (chunk_sym // 1632 + 3) * 8 * 188), dtype=torch.uint8, device=dev)
+        tbits, tts = [bits[i] for i in range(S)], [tso[i] for i in range(S)]
+        got, hit = 0, 0
+
+        def call(c, check):
+            nonlocal got, hit
+            part = d_iq[2 * c * chunk_sym:2 * (c + 1) * chunk_sym]
+            nb = bank.process_batch([part for _ in range(S)], tbits)
+            nts = tail.process_batch([tbits[i][:nb[i]] for i in range(S)], tts)
+            if check:
+                for i in (0, S - 1):
+                    pk = tso[i, :nts[i]].cpu().numpy().reshape(-1, 188)
+                    got += len(pk); hit += sum(bytes(x) in sent for x in pk)
+        call(0, False)                       # acquisition (FLL, timing, Viterbi lock search, deframer) outside the timed calls
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        reps = 2 if S > 64 else 5
-        for _ in range(reps):
-            bank.process_batch(tin, tout)
+        for c in range(1, ncalls):
+            call(c, False)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
+        dt = time.perf_counter() - t0
+        bank.reset(); tail.reset()
+        for c in range(ncalls):              # the same signal once more, untimed, with the TS packets of two carriers checked
+            call(c, True)
         st = bank.stats()[0]
-        out['bank_%d_msym_s' % S] = round(S * nsym / dt / 1e6, 2)
+        out['bank_%d_msym_s' % S] = round(S * (ncalls - 1) * chunk_sym / dt / 1e6, 2)
         out['bank_%d_locked' % S] = bool(st.state == 1 and st.rate == 0)
-        bank.close()
-    # CPU (config 1): front end + slicer + Viterbi of the oracle, one stream, one thread, bounded sample
+        out['bank_%d_ts_packets_checked' % S] = got
+        out['bank_%d_ts_packets_equal_to_transmitted' % S] = hit
+        bank.close(); tail.close()
+        del bits, tso
+        torch.cuda.empty_cache()
+    # CPU (config 1): the whole chain of the oracle, one stream, one thread, bounded sample
+    from test_gpu_dvbs_tail import OracleTail
     rx, o = od.OracleQpskAlt(), od.L()
-    sl, vit = od.VP(o.orc_dvbs_slicer_create()), od.OracleViterbi()
+    sl, vit, otail = od.VP(o.orc_dvbs_slicer_create()), od.OracleViterbi(), OracleTail()
     t0 = time.perf_counter()
-    done = 0
-    while time.perf_counter() - t0 < 4.0:
-        sy = np.ascontiguousarray(rx.process(iq))
+    done = pk_cpu = hit_cpu = 0
+    for c in range(ncalls):
+        sy = np.ascontiguousarray(rx.process(iq[2 * c * chunk_sym:2 * (c + 1) * chunk_sym]))
         soft = np.zeros(2 * sy.size + 8192, np.int8)
         n = o.orc_dvbs_slicer_process(sl, sy.size, od.P(sy), od.P(soft))
+        bl = []
         if n:
-            vit.work(soft[:n].reshape(-1, 8192))
-        done += nsym
+            eb, en, es = vit.work(soft[:n].reshape(-1, 8192))
+            bl = [eb[b, :en[b]] for b in range(len(en))]
+        tsb, nf = otail.process(np.concatenate(bl) if bl else np.zeros(0, np.uint8))
+        pk = tsb.reshape(-1, 188)
+        pk_cpu += len(pk); hit_cpu += sum(bytes(x) in sent for x in pk)
+        done += chunk_sym
+        if time.perf_counter() - t0 > 6.0:
+            break
     out['cpu_config1_msym_s'] = round(done / (time.perf_counter() - t0) / 1e6, 3)
-    out['cpu_config1_note'] = 'oracle restatement of DVBSDemod::process up to the Viterbi output, ONE stream on ONE host thread (kind "port")'
+    out['cpu_config1_ts_packets'] = [pk_cpu, hit_cpu]
+    out['cpu_config1_note'] = 'BASELINE config 1: oracle restatement of DVBSDemod::process, IQ -> TS packets, ONE stream on ONE host thread (kind "port"); [packets delivered, equal to transmitted ones]'
     return out
 
 
@@ -384,10 +421,10 @@ def small_batch(eng, pkg, dev, S=64, F=1):
     st = eng.stage_times()
     acc = run.check(nb)
     run.close()
-    dev_ms = sum(v[0] for v in st.values()) / reps
     return {'config': 'small batch: %d transponders x %d PLFRAME per call, 8PSK 3/4 normal, synchronous mode, LDPC with early exit' % (S, F),
             'ms_per_call': round(dt * 1e3, 3), 'msym_s_total': round(S * F * run.sym / dt / 1e6, 2), 'msym_s_per_stream': round(F * run.sym / dt / 1e6, 3),
-            'stage_ms_per_call': {k: round(v[0] / reps, 3) for k, v in st.items()}, 'host_and_gaps_ms_per_call': round(dt * 1e3 - dev_ms, 3),
+            'stage_ms_per_call': {k: round(v[0] / reps, 3) for k, v in st.items()},
+            'stage_note': 'per-stage device times overlap (the stages of a call run pipelined on several HIP streams): they do not add up to ms_per_call',
             'frames_delivered': acc['delivered'], 'frames_equal_to_transmitted': acc['equal']}
 
 
@@ -486,8 +523,10 @@ def mixed64(eng, pkg, dev, dd, steps, warmup, nt=64, sub=64, F=1):
     eng.set_pipelined(False)
     for d in demods:
         d.close()
-    res = {'config': '4: %d transponders, MODCODs %s cycled, normal frames, %d sub-streams each, %d PLFRAME(s) per stream per step, 50 forced LDPC iterations'
-                     % (nt, MIXED_MODCODS, cfg['sub'], cfg['frames']),
+    what = ('4 as named: %d transponders (one stream each), MODCODs %s cycled' % (nt, MIXED_MODCODS) if cfg['sub'] == 1 else
+            '4, GPU-sized: %d streams in %d MODCOD groups (%d transponders with MODCODs %s cycled, each carried as %d concurrently processed sub-streams)'
+            % (nt * cfg['sub'], len(MIXED_MODCODS), nt, MIXED_MODCODS, cfg['sub']))
+    res = {'config': what + ', normal frames, %d PLFRAME(s) per stream per step, 50 forced LDPC iterations' % cfg['frames'],
            'value': round(total_sym_per_step * steps / dt / 1e6, 1), 'unit': 'Msymbols/s', 'scaling': 'strong', 'n_gpus': dd.world,
            'ms_per_step': round(dt / steps * 1e3, 2), 'transponders_per_rank': [len(a) for a in assign],
            'modcods_per_rank': [sorted({table[i]['modcod'] for i in a}) for a in assign],
@@ -664,6 +703,13 @@ def main():
             m64 = {'error': repr(e)}
         if rank == 0:
             line['mixed64'] = m64
+        # ... and BASELINE config 4 as it is named: 64 transponders, one stream each (4 PLFRAMEs per transponder and step)
+        try:
+            m64l = mixed64(eng, pkg, dev, dd, 10, 1, sub=1, F=4)
+        except Exception as e:
+            m64l = {'error': repr(e)}
+        if rank == 0:
+            line['config4_64_transponders'] = m64l
     if rank == 0:
         print(json.dumps(line))
     if dist is not None:

@@ -145,6 +145,7 @@ int orc_s2rx_tap(void* h, int which, void* dst) {
     return -1;
 }
 float orc_s2rx_nco_freq(void* h) { return ((S2Rx*)h)->nco_freq(); }
+float orc_s2rx_agc_gain(void* h) { return ((S2Rx*)h)->agc_gain_now(); }   // (tools/sensitivity.py: level at the AGC output = gain x input rms)
 
 // stage-level entry points on a receiver object (state carried inside it)
 void orc_s2rx_agc(void* h, int n, const float* in, float* out) { ((S2Rx*)h)->agc(n, (const cf*)in, (cf*)out); }

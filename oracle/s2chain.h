@@ -117,6 +117,7 @@ public:
     std::vector<int8_t> dbg_llr;        // deinterleaved LLRs per frame
     std::vector<FrameStats> dbg_stats;
     float nco_freq() const { return nco_freq_; }
+    float agc_gain_now() const { return agc_gain; }
     s2::ModcodParams mp;
     // what a frame is processed with: CCM = the configured MODCOD, ACM/VCM = the MODCOD its PLS code names
     struct FrameCtx { s2::ModcodParams mp; int pls_code; const Constellation* constel; const LdpcCode* ldpc; const BchCode* bch; bool dummy; };

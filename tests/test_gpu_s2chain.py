@@ -76,6 +76,12 @@ CASES = [
     (27, 1, 1, 15.0, 12, 6007, 0, 50),      # BASELINE config 5 stand-in: 32APSK 8/9 short + pilots at threshold - 1 dB: every frame
                                             # runs into the iteration limit (max-iter stress)
     (27, 1, 1, 30.0, 12, 6007, 4, 50),      # ... and the same chain decoding
+    # the lowest Es/N0 at which at least half the frames decode once the loops have settled (tools/sensitivity.py, DESIGN.md section 6:
+    # the restated receiver -- the reference's distance-metric LUT demapper with its halving clamp -- stands 3 to 6 dB off the codes'
+    # thresholds): equality with the oracle where frames DO decode, not only where none does
+    (4, 0, 0, 7.0, 12, 40001, 5, 50),
+    (14, 0, 0, 11.0, 24, 30011, 8, 50),
+    (27, 1, 1, 17.5, 24, 6007, 8, 50),
 ]
 
 
