@@ -323,7 +323,10 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
             }
             s16x2 v = sat_sub2(X, rec_pair<REC>(rec_in, 2 * p));                     // int8 saturation by the 16-bit clamp
             const s16x2 av = pmax2(v, sat_sub2(splat2(0), v));
-            s16x2 g = pmin2(__builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, av), (u16x2){256, 256})), q8(126));   // mag_of
+            // mag_of: |v| - 1 clamped at 0.  No upper clamp: |v| <= 127 + 255/256 here, so the high byte -- all that is ever consumed -- is <= 126;
+            // the low byte is 0xff instead of 0 only where |v| saturated, i.e. at magnitude 126, the largest there is: min / max / equality
+            // against other halves can then only confuse 126 with 126 (and a row whose smallest magnitude is 126 has its second smallest there too)
+            s16x2 g = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, av), (u16x2){256, 256}));
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int k = 2 * p + h;
