@@ -16,6 +16,31 @@ __device__ __forceinline__ int mag_of(int in) {
 }
 
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// ---- packed int16 helpers: two links per VALU instruction (v_pk_*_i16), the int8 saturation rules emulated in 16 bits
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 splat2(int v) { return s16x2{(short)v, (short)v}; }
+__device__ __forceinline__ s16x2 pmin2(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s16x2 pmax2(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ s16x2 pclamp2(s16x2 v, int lo, int hi) { return pmin2(pmax2(v, splat2(lo)), splat2(hi)); }
+__device__ __forceinline__ uint32_t bits2(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ s16x2 from_bits2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+// The packed row arithmetic works on values scaled by 256 ("Q8": the int8 quantity sits in the HIGH byte of each 16-bit half):
+// the 16-bit saturating add/subtract of the hardware (v_pk_add_i16 / v_pk_sub_i16 with clamp) then IS the int8 saturation of the
+// reference's SIMD lanes, and message bytes drop into place with one v_perm, no sign extension.  Only the high byte of a half
+// is ever consumed (a positive saturation leaves 0xff below it).  Magnitude sentinel ("no link"): 127 (real ones are <= 126).
+constexpr int Q8_NONE = 127 << 8;
+__device__ __forceinline__ s16x2 q8(int v) { return s16x2{(short)(v << 8), (short)(v << 8)}; }
+__device__ __forceinline__ s16x2 sat_sub2(s16x2 a, s16x2 b) { return __builtin_elementwise_sub_sat(a, b); }
+__device__ __forceinline__ s16x2 sat_add2(s16x2 a, s16x2 b) { return __builtin_elementwise_add_sat(a, b); }
+// message bytes k, k+1 (k even) of a record into the high bytes of the two halves: one v_perm
+__device__ __forceinline__ s16x2 rec_pair_dw(uint32_t w, int k) {
+    return from_bits2((k & 2) ? __builtin_amdgcn_perm(0u, w, 0x030c020cu) : __builtin_amdgcn_perm(0u, w, 0x010c000cu));
+}
+template <int REC>
+__device__ __forceinline__ s16x2 rec_pair(const uint32_t (&rec)[REC], int k) { return rec_pair_dw(rec[k >> 2], k); }
+
+
 // LDPCDecoder::bad (layered_decoder.hh:28-45): true if any row is unsatisfied.  A row is bad when the sign product of its links'
 // posteriors is negative or when one of them is 0.  Every posterior belongs to at least one row (each parity bit to its own row), so the
 // second condition over all rows is "some posterior of the frame is 0": a dword scan shared by the slot's 384 threads.  The first one is

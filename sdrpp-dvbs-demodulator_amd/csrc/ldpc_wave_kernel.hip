@@ -129,6 +129,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ld
                     thr[kk] = c & 0xffffu; cA[kk] = lbase + (c >> 16); cB[kk] = cA[kk] - 360u;
                 }
                 if (ABS_FROM < LW) absm = lanec[A.absent_base + layer * 8 + l8];
+                uint32_t vkeep[(LW + 1) / 2], gnone[(LW + 1) / 2];       // packed form: per pair of slots, what an absent slot is masked with
+#pragma unroll
+                for (int p = 0; p < (LW + 1) / 2; ++p) {
+                    vkeep[p] = 0xffffffffu; gnone[p] = 0u;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        if (2 * p + h < LW && ((absm >> (2 * p + h)) & 1u)) { vkeep[p] &= ~(0xffffu << (16 * h)); gnone[p] |= (uint32_t)Q8_NONE << (16 * h); }
+                }
                 const int cend = (int)layer_end[layer];
                 const uint32_t row0 = (uint32_t)(360 * layer);
                 const bool l0fix = (layer == 0) && l8 == 1;              // row 0 of layer 0 has no previous parity bit (slot 1)
@@ -156,8 +164,58 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ld
                         int x[LW];
 #pragma unroll
                         for (int kk = 0; kk < LW; ++kk) x[kk] = *(lds_i8*)(uintptr_t)a[kk];
-                        int v[LW], mg[LW];
                         int min0 = 255, min1 = 255, sx = 0;
+#define WJOIN(ctrl) do { const int o0 = WQUAD(min0, ctrl), o1 = WQUAD(min1, ctrl); min1 = min(max(min0, o0), min(min1, o1)); min0 = min(min0, o0); sx ^= WQUAD(sx, ctrl); } while (0)
+                        if constexpr ((LW & 1) == 0) {
+                            // ---- two link slots per packed int16 register ("Q8": the int8 value in the high byte of each half; the 16-bit saturating
+                            // add / subtract then IS the int8 saturation of the reference's SIMD lanes -- ldpc_dev_common.h, as in the lane-per-row kernel)
+                            constexpr int NPW = LW / 2;
+                            s16x2 V[NPW], G[NPW], MIN0 = splat2(Q8_NONE), MIN1 = splat2(Q8_NONE);
+                            uint32_t SX = 0;
+#pragma unroll
+                            for (int p = 0; p < NPW; ++p) {
+                                const s16x2 X = from_bits2(__builtin_amdgcn_perm((uint32_t)x[2 * p + 1], (uint32_t)x[2 * p], 0x040c000cu));
+                                s16x2 v = sat_sub2(X, rec_pair_dw(rec, 2 * p));
+                                const s16x2 av = pmax2(v, sat_sub2(splat2(0), v));
+                                s16x2 g = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, av), (u16x2){256, 256}));   // mag_of (high byte)
+                                // absent slots (tail of the row, or the missing previous parity bit of row 0 in layer 0): value 0, magnitude "none" (>= 127)
+                                if (2 * p + 1 >= ABS_FROM) { v = from_bits2(bits2(v) & vkeep[p]); g = from_bits2(bits2(g) | gnone[p]); }
+                                if (p == 0 && layer == 0) { const bool z = l0fix && j == 0; v = from_bits2(bits2(v) & (z ? 0xffff0000u : 0xffffffffu)); g = from_bits2(bits2(g) | (z ? (uint32_t)Q8_NONE : 0u)); }
+                                V[p] = v; G[p] = g;
+                                if (p == 0) MIN0 = g;
+                                else if (p == 1) { MIN1 = pmax2(MIN0, g); MIN0 = pmin2(MIN0, g); }
+                                else { MIN1 = pmin2(MIN1, pmax2(MIN0, g)); MIN0 = pmin2(MIN0, g); }
+                                SX ^= bits2(v);
+                            }
+                            const int a0 = MIN0[0] >> 8, b0 = MIN0[1] >> 8, a1 = MIN1[0] >> 8, b1 = MIN1[1] >> 8;
+                            min0 = min(a0, b0);
+                            min1 = min(max(a0, b0), min(a1, b1));
+                            sx = (int)(short)(SX ^ (SX >> 16));
+                            WJOIN(0xB1);             // quad_perm [1,0,3,2]
+                            WJOIN(0x4E);             // quad_perm [2,3,0,1]
+                            WJOIN(0x141);            // row_half_mirror: the other quad of the 8-lane group
+                            if (valid) {
+                                const int min0c = min(min0, 32), min1c = min(min1, 32);
+                                const s16x2 MIN0B = q8(min0), MIN1CB = q8(min1c), NDB = q8(min0c - min1c);
+                                const uint32_t SXB = ((uint32_t)sx & 0xffffu) * 0x10001u;
+                                s16x2 NM[2] = {splat2(0), splat2(0)};
+#pragma unroll
+                                for (int p = 0; p < NPW; ++p) {
+                                    // other = (mag == min0) ? min1 : min0  ==  min1 + (mag != min0) * (min0 - min1), limited to 32 once per row
+                                    const s16x2 ne = pmin2(G[p] - MIN0B, splat2(1));
+                                    const s16x2 other = ne * NDB + MIN1CB;
+                                    const s16x2 neg = from_bits2(SXB ^ bits2(V[p])) >> 15;
+                                    const s16x2 nm = pmin2(from_bits2(bits2(other) ^ bits2(neg)) - neg, q8(31));
+                                    const uint32_t pn = bits2(sat_add2(V[p], nm)) >> 8;          // new posteriors at bits 7:0 and 23:16
+                                    *(lds_i8*)(uintptr_t)a[2 * p] = (int8_t)pn;
+                                    *(lds_i8*)(uintptr_t)a[2 * p + 1] = (int8_t)(pn >> 16);
+                                    NM[p] = nm;
+                                }
+                                const uint32_t ro = __builtin_amdgcn_perm(bits2(NM[1]), bits2(NM[0]), 0x07050301u);     // the four high bytes
+                                msg[(size_t)rowid * 8] = (elem_t)ro;
+                            }
+                        } else {
+                        int v[LW], mg[LW];
 #pragma unroll
                         for (int kk = 0; kk < LW; ++kk) {
                             const int m = (int)__builtin_amdgcn_sbfe((int)rec, 8 * kk, 8);
@@ -171,11 +229,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ld
                             sx ^= vv;
                         }
                         // the row's totals over its 8 lanes: two smallest magnitudes (with multiplicity) and the sign
-#define WJOIN(ctrl) do { const int o0 = WQUAD(min0, ctrl), o1 = WQUAD(min1, ctrl); min1 = min(max(min0, o0), min(min1, o1)); min0 = min(min0, o0); sx ^= WQUAD(sx, ctrl); } while (0)
                         WJOIN(0xB1);             // quad_perm [1,0,3,2]
                         WJOIN(0x4E);             // quad_perm [2,3,0,1]
                         WJOIN(0x141);            // row_half_mirror: the other quad of the 8-lane group
-#undef WJOIN
                         if (valid) {
                             uint32_t ro = 0;
 #pragma unroll
@@ -188,6 +244,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ld
                             }
                             msg[(size_t)rowid * 8] = (elem_t)ro;
                         }
+                        }
+#undef WJOIN
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) { jn[u] = jm[u]; jm[u] = jq[u]; rn[u] = rq[u]; }
