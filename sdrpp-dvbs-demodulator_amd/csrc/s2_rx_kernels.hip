@@ -936,11 +936,23 @@ __device__ __attribute__((noinline)) float soft_phase_err_group(lds_cf32* __rest
         const float dist = camp(csub(sample, p));
         if (dist < bd) { bd = dist; bi = i; }                 // strict: the lowest index among this lane's equals stays
     }
+    if constexpr (GSZ == 8) {
+        // the (distance, index) minimum over the 8 lanes of the group by DPP exchanges (quad, quad, the other quad mirrored): a shuffle
+        // through the LDS crossbar costs a round trip per step, and this sits in the per-symbol chain of the PLL
+#define PE_JOIN(ctrl) do { const float od = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, bd), (ctrl), 0xf, 0xf, false)); \
+                           const int oi = __builtin_amdgcn_update_dpp(0, bi, (ctrl), 0xf, 0xf, false); \
+                           if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; } } while (0)
+        PE_JOIN(0xB1);      // quad_perm [1,0,3,2]
+        PE_JOIN(0x4E);      // quad_perm [2,3,0,1]
+        PE_JOIN(0x141);     // row_half_mirror
+#undef PE_JOIN
+    } else {
 #pragma unroll
-    for (int o = GSZ / 2; o > 0; o >>= 1) {
-        const float od = __shfl_xor(bd, o);
-        const int oi = __shfl_xor(bi, o);
-        if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+        for (int o = GSZ / 2; o > 0; o >>= 1) {
+            const float od = __shfl_xor(bd, o);
+            const int oi = __shfl_xor(bi, o);
+            if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+        }
     }
     cf32 closest{0.f, 0.f};
     if (bi < 64) closest = cf32{pts[2 * bi], pts[2 * bi + 1]};
