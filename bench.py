@@ -56,6 +56,15 @@ WORKLOAD = ('DVB-S2 8PSK 3/4 normal FECFRAME (MODCOD 14), pilots off, 27.5 Msym/
             'clock error ~10 ppm, Es/N0 %.0f dB, 50 forced LDPC iterations, IQ in -> BBFRAMEs out' % ESN0_DB)
 
 
+def ldpc_source_hash():
+    """identifies the decoder build a set of PMC figures belongs to (tools/collect_profiles.py stores it with them)"""
+    import hashlib
+    h = hashlib.sha256()
+    for n in ('ldpc_kernel.hip', 'ldpc_plan.h', 'ldpc_dev_common.h'):
+        h.update(open(os.path.join(ROOT, 'sdrpp-dvbs-demodulator_amd', 'csrc', n), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def make_block(modcod, short, pilots, frames, seed, esn0_db, cfo=CFO, ppm=PPM):
     """one periodic IQ block from the repo's transmitter (oracle/s2chain.cpp, bench/test infrastructure): `frames` PLFRAMEs, resampled so
     that the sampling clock is ~ppm off, carrier offset rounded so that the block repeats seamlessly.  -> (iq, bbframes)"""
@@ -551,6 +560,7 @@ def main():
     ap.add_argument('--frames', type=int, default=8, help='PLFRAMEs per stream per step')
     ap.add_argument('--distinct', type=int, default=DISTINCT, help='distinct signal blocks (every stream gets a private, shifted copy)')
     ap.add_argument('--mixed-frames', type=int, default=1, help='config mixed64: PLFRAMEs per sub-stream per step')
+    ap.add_argument('--mixed-sub', type=int, default=64, help='config mixed64: sub-streams per transponder (1 = BASELINE config 4 as named: 64 streams)')
     ap.add_argument('--workload', default='', help='development aid: MODCOD,short,pilots,Es/N0,rate instead of the headline workload (e.g. 27,1,1,20,9 = the config 5 stand-in); the line then is NOT the headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip configs 2, 5, D and the mixed-MODCOD batch')
@@ -607,7 +617,7 @@ def main():
         torch.cuda.synchronize()
 
     if args.config == 'mixed64':
-        res = mixed64(eng, pkg, dev, dd, args.steps, args.warmup, F=args.mixed_frames)
+        res = mixed64(eng, pkg, dev, dd, args.steps, args.warmup, sub=args.mixed_sub, F=args.mixed_frames)
         if rank == 0:
             line = {'metric': 'Msymbols/s demod+FEC, 64 mixed-MODCOD DVB-S2 transponders @50 LDPC iters (BASELINE config 4)', 'value': res['value'],
                     'unit': 'Msymbols/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': res['ms_per_step'],
@@ -646,14 +656,18 @@ def main():
     in_step_frames = l_frames / max(l_n, 1)
     achieved = bytes_per_frame * in_step_frames / (in_step_ms * 1e-3) / 1e9 if l_n else None
     achieved_alone = bytes_per_frame * nfr / (k['forced'] * 1e-3) / 1e9
-    traffic, traffic_note, issue, wcf = None, None, None, None
-    tp = os.path.join(ROOT, 'profiles', 'r02_ldpc_traffic.json')
-    if os.path.exists(tp):
-        tj = json.load(open(tp))
+    # PMC figures need rocprofv3 passes of their own (tools/profile_run.sh): the newest committed set is quoted, with a flag when the decoder
+    # sources have changed since it was taken
+    traffic, traffic_note, issue, wcf, traffic_current = None, None, None, None, None
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_ldpc_traffic.json')))
+    if cands:
+        tj = json.load(open(cands[-1]))
         traffic = tj.get('traffic_bytes_per_frame', 0) * in_step_frames or None     # (measured on a 4096-frame launch; the kernel's traffic is per frame)
         traffic_note = tj.get('source')
         issue = tj.get('valu_issue_fraction')
         wcf = tj.get('wave_cycles_fraction')
+        traffic_current = tj.get('kernel_source_sha16') == ldpc_source_hash()
 
     if rank == 0:
         value = world * S * F * args.steps * sym / dt / 1e6
@@ -679,7 +693,7 @@ def main():
                          'kernel_ms_in_step': round(in_step_ms, 4), 'frames_per_launch': int(in_step_frames),
                          'kernel_ms_alone': round(k['forced'], 4), 'achieved_alone': round(achieved_alone, 1), 'frac_alone': round(achieved_alone / HBM_PEAK_GBS, 4),
                          'kernel_ms_alone_normal_mode_same_iterations': round(k['normal'], 4) if k['normal_all_ran'] else None,
-                         'traffic': traffic, 'traffic_unit': 'bytes per launch (fabric-side FETCH_SIZE x2 + WRITE_SIZE, per frame x frames of the launch)', 'traffic_source': traffic_note,
+                         'traffic': traffic, 'traffic_taken_from_this_build': traffic_current, 'traffic_unit': 'bytes per launch (fabric-side FETCH_SIZE x2 + WRITE_SIZE, per frame x frames of the launch)', 'traffic_source': traffic_note,
                          'valu_issue_fraction': issue, 'wave_cycles_fraction': wcf,
                          'algorithmic_bytes_per_frame': bytes_per_frame, 'algorithmic_bytes_per_launch': int(bytes_per_frame * in_step_frames),
                          'ldpc_share_of_step': round(in_step_ms * l_n / (dt * 1e3), 3),

@@ -1006,6 +1006,10 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
     const int done = found ? st->loops_done : 0;
     const int f0 = found ? sc * maxf + done : first[sc], nf = !act ? 0 : (found ? st->walk_nf - done : first[sc + 1] - f0);
     __builtin_amdgcn_s_setprio(FL_PRIO);       // latency-critical serial loops (see agc_pc_kernel)
+    // the phase-error table's address lives in vector registers for the whole kernel (as a kernel argument it was re-fetched from the argument
+    // segment -- a scalar-cache round trip -- in front of every symbol's lookup)
+    const float* lut_err_v = C.lut_err;
+    asm volatile("" : "+v"(lut_err_v));
     int nfmax = nf;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nfmax = max(nfmax, __shfl_xor(nfmax, o));
@@ -1076,6 +1080,29 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
             if (lane < m) rnt[lane] = (uint8_t)prn;
             __syncthreads();
             if (base + FL_TILE < plframe) fetch(base + FL_TILE);
+            // A tile of payload symbols only (no header, no pilot symbol: all but a handful of the frame's tiles) takes the short loop: rotate, phase
+            // error, advance -- the Gold-sequence rotation of the OUTPUT (descrambling acts on the rotated symbol and feeds nothing back into
+            // the loop) is left to the lanes that copy the tile out.  Everything else goes through the general loop below.
+            const bool plain = base >= 90 && !(next_pilot >= 0 && next_pilot < base + m && next_pilot + 36 > base);
+            if (plain) {
+                if (C.bits != 5) {
+                    for (int k = 0; k < m; ++k) {
+                        const cf32 tmp_val = cmul(tl[k], phasor_fast(-pll.phase));
+                        const float error = lut_err_v[lut_index(tmp_val.re) * 256 + lut_index(tmp_val.im)];
+                        if (gl == 0) ot[k] = tmp_val;
+                        pll.advance(error);
+                        pll.wrap_pi_once();
+                    }
+                } else {
+                    for (int k = 0; k < m; ++k) {
+                        const cf32 tmp_val = cmul(tl[k], phasor_fast(-pll.phase));
+                        const float error = soft_phase_err_group<FL_LPS>((lds_cf32*)reinterpret_cast<const float*>(s_pts), C.states, C.amp, C.prescale, tmp_val, gl);
+                        if (gl == 0) ot[k] = tmp_val;
+                        pll.advance(error);
+                        pll.wrap_pi_once();
+                    }
+                }
+            } else
             for (int k = 0; k < m; ++k) {
                 const int i = base + k;
                 cf32 tmp_val = cmul(tl[k], phasor_fast(-pll.phase));
@@ -1125,7 +1152,7 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
             __syncthreads();
             if (fact)
                 for (int i = gl; i < m; i += FL_LPS)
-                    if (base + i >= 90) out[base + i] = ot[i];
+                    if (base + i >= 90) out[base + i] = plain ? pl_descramble(ot[i], rnt[i]) : ot[i];
         }
         // ---- PL header demod (dvbs2_plhdr_demod.cpp:33-67)
         // (the 90 header symbols are staged now, over the input + output tiles the PLL loop is through with)

@@ -7,7 +7,9 @@
   <tag>_ldpc_traffic.json          fabric traffic and VALU issue fraction derived from them (read by bench.py)"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
+sys.path.insert(0, ROOT)
+from bench import ldpc_source_hash
 F, P = os.path.join(ROOT, 'gpurun_out', 'fin_' + tag), os.path.join(ROOT, 'profiles')
 rd = lambda n: open(os.path.join(F, n)).read()
 open(os.path.join(P, tag + '_bench.json'), 'w').write(rd('bench.json'))
@@ -26,6 +28,7 @@ traffic = (2 * fetch + write) * 1024
 cus, simds, clk = 256, 4, 2.4e9
 t = {
     'kernel': 'ldpc_decode_kernel<12,4,false>',
+    'kernel_source_sha16': ldpc_source_hash(),     # bench.py flags these figures as stale when the decoder sources have changed since
     'launch': {'rate': '3/4 normal', 'frames': frames, 'iterations': iters, 'forced': True, 'kernel_ms': round(ms, 3)},
     'source': 'profiles/%s_ldpc_pmc.txt (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc SQ_* in separate passes, tools/pmc_ldpc.py); gfx950: FETCH_SIZE tallies '
               '128-B read requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE taken as is; both count fabric-side requests, Infinity-Cache hits '
@@ -39,9 +42,8 @@ t = {
     # where a wave's resident cycles go (SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES, both in quad-cycles; fourth PMC pass)
     'wave_cycles_fraction': {k: round(get(c) / get('SQ_WAVE_CYCLES'), 4) for k, c in (('valu', 'SQ_ACTIVE_INST_VALU'), ('scalar', 'SQ_ACTIVE_INST_SCA'),
                              ('lds', 'SQ_ACTIVE_INST_LDS'), ('misc', 'SQ_ACTIVE_INST_MISC'), ('waiting_for_lds', 'SQ_WAIT_INST_LDS'))},
-    'reading': 'a wave executes an instruction in ~30 % of its resident cycles: one wave issues at most one VALU instruction per 4.5-5.5 cycles whatever shares its SIMD '
-               '(tools/ubench/valu_cu.hip: 4 waves per SIMD run at the single-wave rate), so the decoder is bound by the length of the per-wave instruction streams between '
-               'barriers and by its serial sections, not by SIMD throughput or memory',
+    'reading': 'a wave executes an instruction in ~30 % of its resident cycles; the decoder is bound by the length of the per-wave instruction streams between barriers '
+               'and by its serial sections, not by memory (DESIGN.md section 5)',
 }
 json.dump(t, open(os.path.join(P, tag + '_ldpc_traffic.json'), 'w'), indent=2)
 print(json.dumps(t, indent=1))

@@ -2,7 +2,7 @@
 # The round's evidence run on the GPU box (gpurun -- bash tools/profile_run.sh r02): bench line, kernel trace of the pipelined bench,
 # four separate PMC passes over ONE forced LDPC launch (the bench's dominant kernel).  Outputs under gpurun_out/fin_<tag>/;
 # tools/collect_profiles.py <tag> turns them into the committed summaries under profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/fin_$TAG
 rm -rf $O; mkdir -p $O
