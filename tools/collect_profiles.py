@@ -46,4 +46,8 @@ t = {
                'and by its serial sections, not by memory (DESIGN.md section 5)',
 }
 json.dump(t, open(os.path.join(P, tag + '_ldpc_traffic.json'), 'w'), indent=2)
+wrows = [l.rstrip() for p in ('w1', 'w2', 'w3') if os.path.exists(os.path.join(F, p + '.csv')) for l in open(os.path.join(F, p + '.csv')) if 'ldpc_wave_kernel' in l]
+if wrows:
+    open(os.path.join(P, tag + '_ldpc_wave_pmc.txt'), 'w').write('\n'.join(['# %s: the wave-per-frame decoder (ldpc_wave_kernel<4,3>) on rate 8/9 short, 16384 frames x 50 forced iterations: tools/pmc_ldpc.py 9 1, FRAMES=16384 ITERS=50' % tag,
+        '# separate passes: --pmc SQ_* | --pmc FETCH_SIZE | --pmc WRITE_SIZE (values summed over XCDs; FETCH/WRITE_SIZE unit = KB; gfx950: FETCH_SIZE counts 128-B requests at 64 B)'] + wrows) + '\n')
 print(json.dumps(t, indent=1))

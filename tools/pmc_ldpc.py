@@ -8,8 +8,9 @@ import __graft_entry__ as g
 pkg = g.load_package()
 eng = pkg.Engine(0)
 rate = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+short = bool(int(sys.argv[2])) if len(sys.argv) > 2 else False
 F = int(os.environ.get('FRAMES', '512'))
-fi = pkg.fec_info(rate, False)
+fi = pkg.fec_info(rate, short)
 llr = torch.randint(-30, 31, (F, fi['ldpc_n']), dtype=torch.int8, device='cuda')
-eng.ldpc_decode(llr, rate, False, max_trials=int(os.environ.get('ITERS', '20')), force=True)
+eng.ldpc_decode(llr, rate, short, max_trials=int(os.environ.get('ITERS', '20')), force=True)
 torch.cuda.synchronize()
