@@ -53,6 +53,7 @@ int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
         if ((rc = upload(P.layers, &D.d_layers))) return rc;
         if ((rc = upload(P.ents, &D.d_ents))) return rc;
         if ((rc = upload(P.rows, &D.d_rows))) return rc;
+        if (!P.atab.empty() && (rc = upload(P.atab, &D.d_atab))) return rc;
         D.blocks_per_cu = ldpc_blocks_per_cu(P.max_deg, D.irregular, P.N);
         if (P.N <= 16200) {
             // short frames also get the wave-per-frame plan; which decoder serves the code: ldpc_wave_default() (measured per code),

@@ -14,6 +14,7 @@ struct LdpcDeviceCode {
     LdpcLayerDesc* d_layers = nullptr;
     uint32_t* d_ents = nullptr;
     uint32_t* d_rows = nullptr;
+    uint32_t* d_atab = nullptr;     // per-row link addresses (regular codes up to degree 12, ldpc_plan.h); null otherwise
     int blocks_per_cu = 1;
     // wave-per-frame form (ldpc_wave_plan.h / ldpc_wave_kernel.hip), built for short frames
     int wave_lw = 0, wave_nsteps = 0, wave_nl_min = 0, wave_absent_base = 0;

@@ -77,6 +77,28 @@ struct LdpcKernelArgs {
 #define PROF_ADD(slot, t0, t1) do { } while (0)
 #endif
 
+#ifndef LDPC_ADDR_TABLE
+#define LDPC_ADDR_TABLE 1   // regular codes of degree 2, 8 and 12 (ldpc_plan.h: ldpc_atab_degree): the LDS addresses of a row's links come from a per-code table [layer][row][pair] (two 16-bit
+                            // addresses per word, fetched a layer ahead like the message record) instead of four packed VALU operations per pair:
+                            // the kernel is bound by VALU issue (60 % alone, more with the front end beside it), vector memory instructions are free there
+#endif
+// (measured per kernel, 4096 frames x 50 iterations: degree 12 (3/4) 44.1 -> 42.5 ms, degree 8 (2/3) 42.1 -> 39.6, degree 2 (1/4) 38.0 -> 36.1; the
+// kernels of degree 3, 4, 5 and 9 -- many short layers: the fetch a layer ahead no longer hides behind the layer -- LOSE 8-23 % and keep the arithmetic)
+template <int MAXDEG, bool IRREG> constexpr bool ldpc_use_atab() { return LDPC_ADDR_TABLE && !IRREG && ldpc_atab_degree(MAXDEG); }
+// a row's words of the address table: NPI pairs, stored with a stride of LDPC_ATAB_STRIDE(NPI) words so that one or two aligned vector loads fetch them
+__device__ __forceinline__ constexpr int ldpc_atab_stride(int npi) { return npi <= 1 ? 1 : npi <= 2 ? 2 : npi <= 4 ? 4 : 8; }
+template <int NPI, int NPW>
+__device__ __forceinline__ void atab_load(uint32_t (&pw)[NPW], const uint32_t* __restrict__ p) {
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (NPI <= 1) { w[0] = p[0]; }
+    else if constexpr (NPI <= 2) { const uint2 v = *reinterpret_cast<const uint2*>(p); w[0] = v.x; w[1] = v.y; }
+    else {
+        const uint4 v = *reinterpret_cast<const uint4*>(p); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        if constexpr (NPI > 4) { const uint4 u = *reinterpret_cast<const uint4*>(p + 4); w[4] = u.x; w[5] = u.y; w[6] = u.z; w[7] = u.w; }
+    }
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) pw[2 * i] = w[i];
+}
 #ifndef LDPC_WPE4_MAXDEG
 #define LDPC_WPE4_MAXDEG 28    // kernels up to this degree are held to 128 VGPRs (4 waves per SIMD: room for a front-end wave beside three decoder waves)
 #endif
@@ -258,10 +280,15 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
             bool absent[2] = {false, false};     // uniform (table) absence; the missing previous parity bit of row 0 is per lane
             uint32_t la[2] = {lbase, lbase};
             if (2 * p < MAXDEG) {
-                // both table links of the pair at once: (j + sp) mod 360 + 360*r in packed uint16 (pair table, ldpc_plan.h)
-                u16x2 T = __builtin_bit_cast(u16x2, JJ) + __builtin_bit_cast(u16x2, pw[2 * p]);
-                T = __builtin_elementwise_min(T, (u16x2)(T - (u16x2){360, 360}));
-                const uint32_t AD = __builtin_bit_cast(uint32_t, (u16x2)(T + __builtin_bit_cast(u16x2, pw[2 * p + 1])));
+                uint32_t AD;
+                if constexpr (ldpc_use_atab<MAXDEG, IRREG>()) {
+                    AD = pw[2 * p];          // this row's two addresses, straight from the code's address table (ldpc_plan.h)
+                } else {
+                    // both table links of the pair at once: (j + sp) mod 360 + 360*r in packed uint16 (pair table, ldpc_plan.h)
+                    u16x2 T = __builtin_bit_cast(u16x2, JJ) + __builtin_bit_cast(u16x2, pw[2 * p]);
+                    T = __builtin_elementwise_min(T, (u16x2)(T - (u16x2){360, 360}));
+                    AD = __builtin_bit_cast(uint32_t, (u16x2)(T + __builtin_bit_cast(u16x2, pw[2 * p + 1])));
+                }
                 la[0] = lbase + (AD & 0xffffu);
                 la[1] = lbase + (AD >> 16);
             }
@@ -656,7 +683,7 @@ constexpr int LDPC_TPS = 384;        // threads per slot
 
 template <int MAXDEG, int REC, bool IRREG, int LDPC_FPB>
 __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_per_eu(MAXDEG <= LDPC_WPE4_MAXDEG ? 4 : 3))) void ldpc_decode_kernel(const LdpcLayerDesc* __restrict__ layers, const uint32_t* __restrict__ ents,
-                                                                               const uint32_t* __restrict__ rows, LdpcKernelArgs A) {
+                                                                               const uint32_t* __restrict__ rows, const uint32_t* __restrict__ atab, LdpcKernelArgs A) {
     extern __shared__ __attribute__((aligned(16))) int8_t post_all[];
     __shared__ int s_flag[LDPC_FPB][8];
     __shared__ int s_done[LDPC_FPB];
@@ -732,8 +759,14 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
             // latency is then off the path between a layer barrier and the first LDS read
             constexpr int NPW = 2 * ((MAXDEG + 1) / 2);
             constexpr bool PW_AHEAD = MAXDEG <= 12;   // (wider tables do not fit the scalar registers twice: measured 14 % slower for degree 28)
+            constexpr bool ATAB = ldpc_use_atab<MAXDEG, IRREG>();
+            constexpr int NPI = (MAXDEG + 1) / 2;     // pairs of table links = words per row of the address table
             uint32_t pw_next[NPW];
-            if constexpr (PW_AHEAD) {
+            if constexpr (ATAB) {
+#pragma unroll
+                for (int i = 0; i < NPW; ++i) pw_next[i] = 0;
+                if (active) atab_load<NPI>(pw_next, atab + (size_t)j * ldpc_atab_stride(NPI));      // layer 0
+            } else if constexpr (PW_AHEAD) {
 #pragma unroll
                 for (int i = 0; i < NPW; ++i) pw_next[i] = ents[A.pent_base + i];
             }
@@ -747,13 +780,15 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
                 const LdpcLayerDesc L = Lnext;
                 uint32_t pw[NPW];
 #pragma unroll
-                for (int i = 0; i < NPW; ++i) pw[i] = PW_AHEAD ? pw_next[i] : ents[A.pent_base + layer * NPW + i];
+                for (int i = 0; i < NPW; ++i) pw[i] = (ATAB || PW_AHEAD) ? pw_next[i] : ents[A.pent_base + layer * NPW + i];
                 const uint32_t rw = rw_next;
                 uint32_t* rp = msg + ((size_t)layer * 360 + j) * REC;
                 if (layer + 1 < q) {
                     Lnext = Lnext2;
                     Lnext2 = layers[layer + 2 < q ? layer + 2 : q - 1];
-                    if constexpr (PW_AHEAD) {
+                    if constexpr (ATAB) {
+                        if (active) atab_load<NPI>(pw_next, atab + ((size_t)(layer + 1) * LDPC_TPS + j) * ldpc_atab_stride(NPI));
+                    } else if constexpr (PW_AHEAD) {
 #pragma unroll
                         for (int i = 0; i < NPW; ++i) pw_next[i] = ents[A.pent_base + (layer + 1) * NPW + i];
                     }
@@ -780,7 +815,10 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
                 asm volatile("" : "+v"(rw_next));
                 // (the same for the scalar prefetches: claimed at the end of the layer, their wait does not open the next one)
                 asm volatile("" : "+s"(Lnext2.ent_off), "+s"(Lnext2.deg), "+s"(Lnext2.depth_nc), "+s"(Lnext2.row_off));
-                if constexpr (PW_AHEAD) {
+                if constexpr (ATAB) {
+#pragma unroll
+                    for (int i = 0; i < NPI; ++i) asm volatile("" : "+v"(pw_next[2 * i]));
+                } else if constexpr (PW_AHEAD) {
 #pragma unroll
                     for (int i = 0; i < NPW; ++i) asm volatile("" : "+s"(pw_next[i]));
                 }
@@ -841,12 +879,12 @@ static hipError_t launch_ldpc(const LdpcDeviceCode& C, const LdpcKernelArgs& A, 
         auto kern = ldpc_decode_kernel<MAXDEG, REC, IRREG, 1>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(LDPC_TPS), lds, stream, C.d_layers, C.d_ents, C.d_rows, A);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(LDPC_TPS), lds, stream, C.d_layers, C.d_ents, C.d_rows, C.d_atab, A);
     } else {
         auto kern = ldpc_decode_kernel<MAXDEG, REC, IRREG, 2>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * LDPC_TPS), lds, stream, C.d_layers, C.d_ents, C.d_rows, A);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * LDPC_TPS), lds, stream, C.d_layers, C.d_ents, C.d_rows, C.d_atab, A);
     }
     return hipGetLastError();
 }

@@ -45,6 +45,9 @@ constexpr int LDPC_MAX_CONFLICT_LINKS = 12;
 #endif
 constexpr uint32_t LDPC_WALK_MARK = 0xfffeu;   // chain-step field of a quad-walk layer
 
+// which kernels (by maximum row degree, regular codes only) take their link addresses from the address table (ldpc_kernel.hip: LDPC_ADDR_TABLE)
+constexpr bool ldpc_atab_degree(int max_deg) { return max_deg == 2 || max_deg == 8 || max_deg == 12; }
+
 struct LdpcPlan {
     int code_index = -1;
     int N = 0, K = 0, R = 0, q = 0, max_deg = 0, min_deg = 0, edges = 0;
@@ -56,6 +59,8 @@ struct LdpcPlan {
     int pent_base = 0;            // pair table: per layer (max_deg+1)/2 pairs x 2 words {spA | spB<<16, 360*rA | 360*rB<<16}
     std::vector<uint32_t> rows;
     int synd_base = 0;            // syndrome-check table (in ents[]): [max_deg + 2][q * 6] words, one per (link, layer, 64-row word), see below
+    std::vector<uint32_t> atab;   // address table [q][384 rows][(max_deg + 1) / 2, padded to 1 / 2 / 4 / 8 words]: byte offsets of the row's two links of a pair inside the posterior array,
+                                  // a0 | a1 << 16 with a = 360 r + (j + sp) mod 360 (regular codes of the degrees ldpc_atab_degree names; ldpc_kernel.hip, LDPC_ADDR_TABLE)
 };
 
 inline LdpcPlan build_ldpc_plan(int code_index) {
@@ -212,6 +217,20 @@ inline LdpcPlan build_ldpc_plan(int code_index) {
                 }
                 P.ents.push_back(e);
             }
+    }
+    if (ldpc_atab_degree(P.max_deg) && P.min_deg == P.max_deg) {
+        const int npi = (P.max_deg + 1) / 2;
+        const int stride = npi <= 1 ? 1 : npi <= 2 ? 2 : npi <= 4 ? 4 : 8;      // (ldpc_kernel.hip: ldpc_atab_stride)
+        P.atab.assign((size_t)d.q * 384 * stride, 0);
+        for (int i = 0; i < d.q; ++i) {
+            const LdpcLayerDesc& L = P.layers[i];
+            for (int j = 0; j < 360; ++j)
+                for (int k = 0; k < P.max_deg; ++k) {
+                    const uint32_t e = P.ents[L.ent_off + k];
+                    const uint32_t a = 360u * (e >> 16) + ((uint32_t)j + (e & 0xffffu)) % 360u;
+                    P.atab[((size_t)i * 384 + j) * stride + k / 2] |= a << (16 * (k & 1));
+                }
+        }
     }
     return P;
 }
