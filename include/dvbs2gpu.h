@@ -85,6 +85,14 @@ int dvbs2gpu_ldpc_plan_info(dvbs2gpu_ctx* ctx, int rate, int shortframes, int32_
  * counts3 = {layers, link entries, per-row words}.  layers4: 4 uint32 per layer {first entry, degree,
  * depth | nc<<16, first row word}; ents: sp | r<<16; rows: level | late<<8 | early<<20 (ldpc_plan.h). */
 int dvbs2gpu_ldpc_plan_dump(int rate, int shortframes, uint32_t* layers4, uint32_t* ents, uint32_t* rows, int32_t* counts3);
+/* The same for the wave-per-frame decoder's plan (csrc/ldpc_wave_plan.h) and for the lane-per-row decoder's address table
+ * (csrc/ldpc_plan.h; regular codes of degree 2, 8, 12, else empty).  NULL arrays: counts only.
+ * counts6 = {link slots per lane LW, smallest row degree incl. parity links, steps per sweep, index of the absent masks inside
+ * lanec, words in lanec, entries in steps}; lanec: [q][8][LW] thr | cA << 16, then [q][8] absent masks; steps: [..][8] row ids
+ * (360 * layer + j, 0xffff = empty slot); layer_end: [q] chunk (4 steps) index at which a layer's steps end.
+ * counts2 = {words in the table, words per row}; table: [q][384][words per row], two 16-bit byte offsets per word. */
+int dvbs2gpu_ldpc_wave_plan_dump(int rate, int shortframes, uint32_t* lanec, uint16_t* steps, uint32_t* layer_end, int32_t* counts6);
+int dvbs2gpu_ldpc_addr_table_dump(int rate, int shortframes, uint32_t* table, int32_t* counts2);
 
 /* replaces BBFrameBCH::decode (bbframe_bch.cpp:380-405).  d_frames [nframes][K/8] corrected in place;
  * d_corrections [nframes] int32: #bits corrected, 0 clean, -1 uncorrectable (frame left untouched). */

@@ -69,6 +69,8 @@ PROTOTYPES = {
     'dvbs2gpu_fec_info_get': (_i, [_i, _i, C.POINTER(ModcodInfo)]),
     'dvbs2gpu_ldpc_plan_dump': (_i, [_i, _i, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
     'dvbs2gpu_ldpc_plan_info': (_i, [_vp, _i, _i, C.POINTER(C.c_int32)]),
+    'dvbs2gpu_ldpc_wave_plan_dump': (_i, [_i, _i, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
+    'dvbs2gpu_ldpc_addr_table_dump': (_i, [_i, _i, _vp, C.POINTER(C.c_int32)]),
     'dvbs2gpu_ldpc_decode_batch': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'dvbs2gpu_bch_decode_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
     'dvbs2gpu_bb_descramble_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),

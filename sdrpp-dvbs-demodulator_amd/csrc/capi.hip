@@ -397,6 +397,30 @@ int dvbs2gpu_ldpc_plan_dump(int rate, int shortframes, uint32_t* layers4, uint32
     return 0;
 }
 
+int dvbs2gpu_ldpc_wave_plan_dump(int rate, int shortframes, uint32_t* lanec, uint16_t* steps, uint32_t* layer_end, int32_t* counts6) {
+    FecParams f;
+    if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
+    if (!counts6) return DVBS2GPU_ERR_ARG;
+    const LdpcPlan P = build_ldpc_plan(f.code_index);
+    const LdpcWavePlan W = build_ldpc_wave_plan(P);
+    counts6[0] = W.lw; counts6[1] = W.nl_min; counts6[2] = W.nsteps; counts6[3] = W.absent_base; counts6[4] = (int32_t)W.lanec.size(); counts6[5] = (int32_t)W.steps.size();
+    if (lanec) memcpy(lanec, W.lanec.data(), W.lanec.size() * sizeof(uint32_t));
+    if (steps) memcpy(steps, W.steps.data(), W.steps.size() * sizeof(uint16_t));
+    if (layer_end) memcpy(layer_end, W.layer_end.data(), W.layer_end.size() * sizeof(uint32_t));
+    return 0;
+}
+
+int dvbs2gpu_ldpc_addr_table_dump(int rate, int shortframes, uint32_t* table, int32_t* counts2) {
+    FecParams f;
+    if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
+    if (!counts2) return DVBS2GPU_ERR_ARG;
+    const LdpcPlan P = build_ldpc_plan(f.code_index);
+    const int npi = (P.max_deg + 1) / 2;
+    counts2[0] = (int32_t)P.atab.size(); counts2[1] = npi <= 1 ? 1 : npi <= 2 ? 2 : npi <= 4 ? 4 : 8;
+    if (table && !P.atab.empty()) memcpy(table, P.atab.data(), P.atab.size() * sizeof(uint32_t));
+    return 0;
+}
+
 int dvbs2gpu_ldpc_plan_info(dvbs2gpu_ctx* ctx, int rate, int shortframes, int32_t* out8) {
     if (!ctx || !out8) return DVBS2GPU_ERR_ARG;
     FecParams f;

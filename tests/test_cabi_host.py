@@ -209,3 +209,103 @@ def test_dvbs_segment_join_rule(pkg):
     assert _find_join(pkg, tail, seg[:6999])[0] == -1
     lib = pkg.load_library()
     assert lib.dvbs2gpu_dvbs_segrx_find_join(None, 10, None, 10, None) == pkg.ERR_ARG
+
+
+def _reference_rows(rate, short):
+    """the reference's expansion of the code (oracle): per row the information-bit positions, in its sequential row order"""
+    p = orc.fec_params(rate, short)
+    R = p['N'] - p['K']
+    lib_o = orc.lib()
+    lib_o.orc_ldpc_rows.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    cnl = lib_o.orc_ldpc_rows(rate, short, None, None)
+    pos = np.zeros((R, cnl), np.uint16)
+    cn = np.zeros(R, np.uint8)
+    lib_o.orc_ldpc_rows(rate, short, pos.ctypes.data, cn.ctypes.data)
+    return p, R, pos, cn
+
+
+@pytest.mark.parametrize('rate,short', [c for c in orc.ALL_CODES if c[1]])
+def test_ldpc_wave_plan_keeps_the_reference_row_order(pkg, rate, short):
+    """wave-per-frame decoder (csrc/ldpc_wave_plan.h): every row of a sweep sits in exactly one step, layers in order; the lane constants
+    address exactly the reference's bits (own parity, previous parity, information links); rows of one step share no bit, and of two rows
+    of a layer that share a bit the one the reference processes first sits in an EARLIER step"""
+    lib = pkg.load_library()
+    cnt = (C.c_int32 * 6)()
+    assert lib.dvbs2gpu_ldpc_wave_plan_dump(rate, short, None, None, None, cnt) == 0
+    lw, nl_min, nsteps, absent_base, nlanec, nst = list(cnt)
+    p, R, pos, cn = _reference_rows(rate, short)
+    q, K = R // 360, p['K']
+    lanec = np.zeros(nlanec, np.uint32); steps = np.zeros(nst, np.uint16); layer_end = np.zeros(q, np.uint32)
+    assert lib.dvbs2gpu_ldpc_wave_plan_dump(rate, short, lanec.ctypes.data, steps.ctypes.data, layer_end.ctypes.data, cnt) == 0
+    assert nsteps % 4 == 0 and nst == (nsteps + 8) * 8 and np.all(steps[nsteps * 8:] == 0xffff)
+    st = steps[:nsteps * 8].reshape(nsteps, 8).astype(np.int64)
+    seen = np.zeros(R, np.int64)
+    step_of = np.full(R, -1, np.int64)
+    lo = 0
+    for i in range(q):
+        hi = int(layer_end[i]) * 4
+        blk = st[lo:hi]
+        rows = blk[blk != 0xffff]
+        assert np.all(rows // 360 == i)                                   # a layer's steps hold that layer's rows only
+        np.add.at(seen, rows, 1)
+        for s_ in range(lo, hi):
+            for rr in st[s_][st[s_] != 0xffff]:
+                step_of[rr] = s_
+        lo = hi
+    assert lo == nsteps and np.all(seen == 1)
+    # the bits every (row, slot) touches
+    absent = lanec[absent_base:absent_base + q * 8].reshape(q, 8)
+    c = lanec[:q * 8 * lw].reshape(q, 8, lw)
+    thr, cA = (c & 0xffff).astype(np.int64), (c >> 16).astype(np.int64)
+    assert nl_min == int(cn.min()) + 2
+    for i in range(q):
+        deg = int(cn[360 * i])
+        touch = {}                                                          # bit -> rows of this layer
+        for j in range(360):
+            got = []
+            for l8 in range(8):
+                for kk in range(lw):
+                    k = 8 * kk + l8
+                    ab = (absent[i, l8] >> kk) & 1
+                    assert ab == (k >= deg + 2)
+                    if ab:
+                        continue
+                    a = j + (cA[i, l8, kk] - 360 if j >= thr[i, l8, kk] else cA[i, l8, kk])
+                    if k == 0:
+                        assert a == K + 360 * i + j
+                    elif k == 1:
+                        if i == 0 and j == 0:
+                            continue                                        # (masked in the kernel: row 0 of layer 0 has no previous parity bit)
+                        assert a == (K + 360 * (i - 1) + j if i else K + 360 * (q - 1) + j - 1)
+                    else:
+                        got.append(a)
+            assert sorted(got) == sorted(int(x) for x in pos[360 * i + j, :deg])
+            for b in got:
+                touch.setdefault(b, []).append(j)
+        for b, lst in touch.items():
+            for a_, b_ in zip(lst, lst[1:]):                                # ascending row index = the reference's order
+                assert step_of[360 * i + a_] < step_of[360 * i + b_]
+
+
+@pytest.mark.parametrize('rate,short', orc.ALL_CODES)
+def test_ldpc_address_table_holds_the_links_of_every_row(pkg, rate, short):
+    """lane-per-row decoder: the per-code address table (regular codes of degree 2, 8, 12) names, per layer and row, exactly the reference's bits"""
+    lib = pkg.load_library()
+    cnt = (C.c_int32 * 2)()
+    assert lib.dvbs2gpu_ldpc_addr_table_dump(rate, short, None, cnt) == 0
+    n, stride = list(cnt)
+    p, R, pos, cn = _reference_rows(rate, short)
+    q = R // 360
+    deg = int(cn.max())
+    if n == 0:
+        assert deg not in (2, 8, 12) or int(cn.min()) != deg
+        return
+    assert int(cn.min()) == deg and n == q * 384 * stride
+    tab = np.zeros(n, np.uint32)
+    assert lib.dvbs2gpu_ldpc_addr_table_dump(rate, short, tab.ctypes.data, cnt) == 0
+    tab = tab.reshape(q, 384, stride)
+    npi = (deg + 1) // 2
+    a = np.stack([(tab[:, :360, k // 2] >> (16 * (k & 1))) & 0xffff for k in range(deg)], axis=-1).astype(np.int64)     # [layer][row][link]
+    want = pos[:, :deg].astype(np.int64).reshape(q, 360, deg)
+    assert np.array_equal(np.sort(a, axis=-1), np.sort(want, axis=-1))
+    assert np.all(tab[:, 360:, :] == 0) and np.all(tab[:, :, npi:] == 0)
