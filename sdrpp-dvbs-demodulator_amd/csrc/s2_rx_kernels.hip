@@ -45,27 +45,13 @@ __device__ __forceinline__ __attribute__((address_space(1))) T* as_global(T* p) 
 
 typedef float __attribute__((ext_vector_type(2))) f32x2;
 typedef float __attribute__((ext_vector_type(4))) f32x4;
-// FE_NT: the front end's sample streams (IQ in, per-sample scratch, timing-recovery output: ~57 GB per headline step, each byte touched once
-// or twice) as non-temporal accesses, so that they do not push the LDPC decoder's message records (132 MB live, re-read every iteration)
-// out of the Infinity Cache in the pipelined mode
-#ifndef FE_NT
-#define FE_NT 0
-#endif
+// (tried in round 3: these sample streams -- IQ in, per-sample scratch, timing-recovery output, ~57 GB per headline step -- as non-temporal
+// accesses, so that they would not push the LDPC decoder's message records out of the Infinity Cache in the pipelined mode: no measurable change)
 __device__ __forceinline__ cf32 ldg(const cf32* p) {
-#if FE_NT
-    const f32x2 v = __builtin_nontemporal_load(as_global(reinterpret_cast<const f32x2*>(p)));
-#else
     const f32x2 v = *as_global(reinterpret_cast<const f32x2*>(p));
-#endif
     return cf32{v.x, v.y};
 }
-__device__ __forceinline__ void stg(cf32* p, cf32 v) {
-#if FE_NT
-    __builtin_nontemporal_store(f32x2{v.re, v.im}, as_global(reinterpret_cast<f32x2*>(p)));
-#else
-    *as_global(reinterpret_cast<f32x2*>(p)) = f32x2{v.re, v.im};
-#endif
-}
+__device__ __forceinline__ void stg(cf32* p, cf32 v) { *as_global(reinterpret_cast<f32x2*>(p)) = f32x2{v.re, v.im}; }
 
 // branch-free select (the compiler turns short float ternaries of the serial loops into exec-mask branches otherwise)
 __device__ __forceinline__ float fsel(bool c, float a, float b) {
@@ -352,11 +338,7 @@ __global__ __launch_bounds__(64) void s2_gardner_kernel(const S2StreamWork* __re
                 for (int k = 0; k < 8; ++k) acc += xw[k] * t[k];
                 // arm-1 lanes (r = 2: re, 3: im) collect the neighbours' arms: row_shr:2 = lane-2 (phase-1), row_shl:2 = lane+2 (phase+1)
                 const float xm = DPP_F(acc, 0x112), xp = DPP_F(acc, 0x102), xo = acc;
-#if FE_NT
-                if (arm == 1) __builtin_nontemporal_store(xo, &outc[2 * outCount]);
-#else
                 if (arm == 1) outc[2 * outCount] = xo;
-#endif
                 ++outCount;
                 // straight-line on purpose (streams of one wave differ in spsctr): the error of the off-symbol outputs is masked to 0
                 const float d = fsel(phase == 0, xp - xo, fsel(phase == 127, xo - xm, (xp - xm) * 0.5f));
