@@ -6,9 +6,9 @@
  * the device's OCML and the hardware v_sin_f32 all differ by an ULP here and there), and the receiver's loops are
  * sign-directed / LUT-quantised, so one ULP in a phasor becomes a different polyphase arm or LUT cell a few samples
  * later.  A bit-exact GPU engine therefore needs ONE definition that host and device evaluate identically.  This header
- * is that definition: straight-line IEEE-754 binary32/binary64 arithmetic (+, -, *, /, conversions, comparisons; no fused
- * multiply-add -- every translation unit that includes it is compiled with -ffp-contract=off), so gfx950 and x86-64
- * produce the same bits.  The device kernels (csrc/s2_rx_kernels.hip), the host-side table builders of the library and
+ * is that definition: straight-line IEEE-754 binary32/binary64 arithmetic (+, -, *, /, conversions, comparisons, and -- in sincosf_det
+ * only, written out as fmaf -- the correctly rounded fused multiply-add; nothing is contracted implicitly: every translation unit that
+ * includes it is compiled with -ffp-contract=off), so gfx950 and x86-64 produce the same bits.  The device kernels (csrc/s2_rx_kernels.hip), the host-side table builders of the library and
  * the CPU oracle (oracle/s2chain.cpp, oracle/dvbs_fe.cpp) all call these functions and nothing else for these values.
  *
  * Accuracy (checked in tests/test_det_math.py against the host libm in double): sincos <= 2 ULP for |x| <= 64,
@@ -34,25 +34,28 @@ DVBS2M_HD double d_from_bits(uint64_t u) { return __builtin_bit_cast(double, u);
 DVBS2M_HD uint64_t d_to_bits(double d) { return __builtin_bit_cast(uint64_t, d); }
 DVBS2M_HD float f_from_bits(uint32_t u) { return __builtin_bit_cast(float, u); }
 
-/* sin and cos of x, |x| up to a few thousand (the loops here keep |x| <= 2 pi; the band-edge taps go to ~70 rad):
- * three-term Cody-Waite reduction to [-pi/4, pi/4] around an even multiple of pi/4, then the classic single-precision
- * minimax polynomials.  sincos(0) = (0, 1) exactly. */
+/* sin and cos of x, |x| up to a few thousand (the loops here keep |x| <= 2 pi; the band-edge taps go to ~70 rad).
+ * Round 3 form: x = j pi/2 + r with j = rint(x 2/pi) and a two-term Cody-Waite reduction in fused multiply-adds (the products j * hi,
+ * j * lo enter the sums unrounded), the classic single-precision minimax polynomials on |r| <= pi/4 in Horner form with fused
+ * multiply-adds, quadrant fix-ups on the sign bits.  fmaf is ONE correctly rounded operation on both sides (v_fma_f32 on gfx950, vfmadd /
+ * glibc's exact fmaf on x86-64), so host and device still agree bit for bit; what it buys is the length of the serial per-symbol chains
+ * this sits in (PLL, PLHDR, Costas, FLL): ~27 device instructions instead of ~46 for the separately rounded three-term form of rounds
+ * 1-2.  sincos(0) = (0, 1) exactly.  Accuracy unchanged (tests/test_det_math.py: |error| < 2.5 * 2^-24 for |x| <= 70). */
 DVBS2M_HD void sincosf_det(float x, float* sn_out, float* cs_out) {
-    const float ax = f_abs(x);
-    int j = (int)(ax * 1.27323954473516f);
-    j = (j + 1) & ~1;
-    const float y = (float)j;
-    const float r = ((ax - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    const float j = __builtin_rintf(x * 0.636619772367581343f);
+    float r = __builtin_fmaf(j, -1.57079637050628662109375f, x);            /* pi/2 = hi + lo, hi = the nearest binary32 */
+    r = __builtin_fmaf(j, 4.37113900018624283e-8f, r);                      /* -lo */
     const float z = r * r;
-    const float ps = r + r * z * ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f);
-    const float pc = (1.0f - 0.5f * z) + z * z * ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f);
-    const int q = (j >> 1) & 3;
-    float sn = (q & 1) ? pc : ps, cs = (q & 1) ? ps : pc;
-    if (q == 1 || q == 2) cs = -cs;
-    if (q >= 2) sn = -sn;
-    if (x < 0.f) sn = -sn;
-    *sn_out = sn;
-    *cs_out = cs;
+    const float ps = __builtin_fmaf(r * z, __builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), r);
+    const float pc = __builtin_fmaf(z * z, __builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f),
+                                    __builtin_fmaf(-0.5f, z, 1.0f));
+    const int ji = (int)j;
+    const bool swap = (ji & 1) != 0;
+    const uint32_t s1 = (uint32_t)ji << 30;                                 /* bit 31 = bit 1 of j, bit 30 = bit 0 of j */
+    const uint32_t sflip = s1 & 0x80000000u;                                /* sin changes sign in quadrants 2, 3 */
+    const uint32_t cflip = (s1 + (s1 << 1)) & 0x80000000u;                  /* cos in quadrants 1, 2: bit 1 ^ bit 0 (no carry into bit 31) */
+    *sn_out = f_from_bits(__builtin_bit_cast(uint32_t, swap ? pc : ps) ^ sflip);
+    *cs_out = f_from_bits(__builtin_bit_cast(uint32_t, swap ? ps : pc) ^ cflip);
 }
 
 /* atan2(y, x) in (-pi, pi]: a = min/max of the magnitudes; beyond tan(pi/8) the identity

@@ -80,16 +80,21 @@ CASES = [
     # the restated receiver -- the reference's distance-metric LUT demapper with its halving clamp -- stands 3 to 6 dB off the codes'
     # thresholds): equality with the oracle where frames DO decode, not only where none does
     (4, 0, 0, 7.0, 12, 40001, 5, 50),
-    (14, 0, 0, 11.0, 24, 30011, 8, 50),
-    (27, 1, 1, 17.5, 24, 6007, 8, 50),
+    (14, 0, 0, 11.0, 24, 30011, 8, 50, 3),
+    # ... and a signal (noise seed 14) on which this receiver settles on a wrong 8PSK rotation and delivers 23 frames of which none is a
+    # transmitted one -- about one stream in eleven does at this Es/N0 (bench: fraction_equal_to_transmitted); which streams do depends
+    # on the last bit of a phasor (with the separately rounded sin/cos of rounds 1-2 this very signal decoded): equality through a false lock
+    (14, 0, 0, 11.0, 24, 30011, 0, 50),
+    (27, 1, 1, 17.5, 24, 6007, 4, 50),      # (the loops take ~18 short frames to settle on 32APSK: the last 5 decode)
 ]
+CASES = [c if len(c) == 9 else c + (c[0],) for c in CASES]      # last field: seed of payload + noise (default: the MODCOD number)
 
 
-@pytest.mark.parametrize('modcod,short,pilots,esn0,nframes,chunk,min_good,trials', CASES)
-def test_demod_end_to_end_vs_oracle(engine, modcod, short, pilots, esn0, nframes, chunk, min_good, trials):
+@pytest.mark.parametrize('modcod,short,pilots,esn0,nframes,chunk,min_good,trials,seed', CASES)
+def test_demod_end_to_end_vs_oracle(engine, modcod, short, pilots, esn0, nframes, chunk, min_good, trials, seed):
     """IQ with carrier offset 1e-3 rad/sample, timing offset 0.3 samples and a phase offset through both receivers in
     chunks: every tap and every output byte of every call must be EQUAL"""
-    iq, bb, _ = orc.transmit(modcod, short, pilots, nframes=nframes, seed=modcod, esn0_db=esn0, cfo=1e-3, timing=0.3, phase0=0.1,
+    iq, bb, _ = orc.transmit(modcod, short, pilots, nframes=nframes, seed=seed, esn0_db=esn0, cfo=1e-3, timing=0.3, phase0=0.1,
                              lead_symbols=700)
     rx = orc.OracleRx(orc.default_cfg(modcod, short, pilots, max_ldpc_trials=trials))
     dm = engine.demod(engine.default_cfg(modcod, bool(short), bool(pilots), max_ldpc_trials=trials), max_samples=max(chunk, 4096))

@@ -14,7 +14,7 @@ info = pkg.modcod_info(B.MODCOD, bool(B.SHORT), bool(B.PILOTS))
 kb = info['kbch'] // 8
 sym = info['plframe_symbols']
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
-for S in (1, 8, 64, 512):
+for S in [int(x) for x in os.environ.get('STREAMS', '1,8,64,512').split(',')]:
     run = B.S2Run(eng, pkg, torch.device('cuda', 0), B.MODCOD, B.SHORT, B.PILOTS, 14.0, S, F, 4, seed=0)
     for _ in range(B.PREROLL_FRAMES // F + 2):
         run.step()
