@@ -164,8 +164,12 @@ struct AgcS2Traits {                     // FastAGC gain + FreqShift phase recur
         r.gain = r.gain > 10e6f ? 10e6f : r.gain;
         // FreqShift phase accumulator (common/dsp/demod/freq_shift.cpp)
         r.nph += r.nfr;
-        while ((double)r.nph > 6.283185307179586) r.nph = (float)((double)r.nph - 6.283185307179586);
-        while ((double)r.nph < -6.283185307179586) r.nph = (float)((double)r.nph + 6.283185307179586);
+        // (a binary32 value exceeds the double 2 pi exactly when it reaches the first binary32 above it: one float compare per sample, the
+        //  double-precision wrap of the reference only when it acts -- once per 2 pi / |freq| samples)
+        if (__any(__builtin_fabsf(r.nph) >= 6.2831854820251465f)) {
+            while ((double)r.nph > 6.283185307179586) r.nph = (float)((double)r.nph - 6.283185307179586);
+            while ((double)r.nph < -6.283185307179586) r.nph = (float)((double)r.nph + 6.283185307179586);
+        }
         return res;
     }
 };
@@ -242,9 +246,21 @@ __global__ __launch_bounds__(128) void agc_pc_kernel(const typename TR::Work* __
         if (wave == 0) {
             cf32(*B)[AG_T + 1] = buf[t & 1];
             const int m = min(AG_T, n - t * AG_T);
+            if (__all(m == AG_T || m <= 0)) {
+                // whole tiles (all but a stream's last): the tile's samples fetched up front, no predicate inside the chain; streams that
+                // are through (or absent) run along on stale data and get their state back
+                const typename TR::Regs keep = regs;
+                cf32 x[AG_T];
+#pragma unroll
+                for (int i = 0; i < AG_T; ++i) x[i] = B[lane][i];
+#pragma unroll
+                for (int i = 0; i < AG_T; ++i) B[lane][i] = TR::step(regs, x[i], co);
+                if (m <= 0) regs = keep;
+            } else {
 #pragma unroll 4
-            for (int i = 0; i < AG_T; ++i)
-                if (i < m) B[lane][i] = TR::step(regs, B[lane][i], co);
+                for (int i = 0; i < AG_T; ++i)
+                    if (i < m) B[lane][i] = TR::step(regs, B[lane][i], co);
+            }
         } else {
             if (t >= 1) store_tile(t - 1, buf[(t - 1) & 1]);
             if (t + 1 < ntiles) load_tile(t + 1, buf[(t + 1) & 1]);
