@@ -292,6 +292,10 @@ int demod_configure(dvbs2gpu_demod* d) {
     // the Gardner loop (omega = 1 sample per output, module_dvbs2_demod.cpp:49) emits at most count / (1 - omega_rel_limit) samples; the
     // timing-recovery scratch (count + count/16 + 128) and the symbol FIFO are sized for a limit of a few percent (main.cpp:73: 0.02)
     if (!(c.omega_rel_limit >= 0.f) || !(c.omega_rel_limit <= 0.05f)) { last_error() = "omega_rel_limit must be within [0, 0.05]"; return DVBS2GPU_ERR_ARG; }
+    // (the kernels evaluate PCL::advance(0) as "freq unchanged" -- exact for finite gains only)
+    if (!std::isfinite(c.clock_mu_gain) || !std::isfinite(c.clock_omega_gain) || !std::isfinite(c.agc_rate) || !std::isfinite(c.loop_bw) || !std::isfinite(c.fll_bw)) {
+        last_error() = "loop gains must be finite"; return DVBS2GPU_ERR_ARG;
+    }
     S2LoopCoefs& co = d->co;
     co.agc_rate = c.agc_rate;
     co.g_alpha = c.clock_mu_gain; co.g_beta = c.clock_omega_gain;

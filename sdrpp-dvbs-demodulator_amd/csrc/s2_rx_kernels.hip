@@ -166,7 +166,7 @@ struct AgcS2Traits {                     // FastAGC gain + FreqShift phase recur
         r.nph += r.nfr;
         // (a binary32 value exceeds the double 2 pi exactly when it reaches the first binary32 above it: one float compare per sample, the
         //  double-precision wrap of the reference only when it acts -- once per 2 pi / |freq| samples)
-        if (__any(__builtin_fabsf(r.nph) >= 6.2831854820251465f)) {
+        if (__builtin_expect(__any(__builtin_fabsf(r.nph) >= 6.2831854820251465f), 0)) {
             while ((double)r.nph > 6.283185307179586) r.nph = (float)((double)r.nph - 6.283185307179586);
             while ((double)r.nph < -6.283185307179586) r.nph = (float)((double)r.nph + 6.283185307179586);
         }
@@ -812,6 +812,279 @@ __global__ __launch_bounds__(128) void s2_gardner_bank_kernel(const S2StreamWork
     }
 }
 
+// ---- timing recovery, fourth form: CANDIDATE TABLES for small banks -------------------------------------------------------
+// A small bank is bound by the length of ONE stream's chain, and ~100 of the ~135 instructions per symbol of the forms above are the
+// four 8-tap dot products.  Which interpolants the loop will ask for is almost known in advance: an on-symbol output sits at a sample
+// offset of the current period, and the polyphase arm moves by alpha * error + (freq - 1) ~ 0.05 arms per symbol.  So two helper waves
+// compute, for the period AFTER the one being resolved, the interpolant of EVERY sample offset of that period with the 8 arms around the
+// arm the resolver last reported -- the same dot product in the same order as everywhere else, hence the same bits -- into an LDS table.
+// The resolver wave (lane = stream) is left with: arm -> three table fetches -> sign error -> advance -> floor, and, as in the second
+// form, one 16-bit word (ring slot, arm) per output in an LDS list; it stores nothing itself.  A fetch off the table (the arm ran away,
+// the ends of the tap bank) falls back to the dot products themselves, so no result ever depends on the prediction.  The output values
+// come from the list one period later (helper wave 2: lane = output, the dot product again -- coalesced stores).
+// Workgroup = resolver (GC_CS lanes used) + wave 1 (stages the samples: FastAGC scaling + FreqShift rotation; arms 0..3 of the tables)
+// + wave 2 (arms 4..7; output values).  Periods, single steps at the ends of a slice and the state hand-over as in the other forms.
+constexpr int GC_T = 16;                      // samples per stream and period
+constexpr int GC_CS = 4;                      // streams per workgroup (64 = GC_CS * GC_T: one staged sample per lane of wave 1)
+constexpr int GC_RING = 8 * GC_T;             // ring slots per stream: t-1 (its outputs' values), t (resolved), t+1 (tables), t+2 (staged), slack
+constexpr int GC_PITCH = GC_RING + 8;         // + mirror of the first 8 slots: a window never wraps
+constexpr int GC_NR = GC_T + 4;               // table rows: offsets base-4 .. base+T-1 of the period
+constexpr int GC_WN = 8;                      // arms per row: (reported arm - 3) .. (reported arm + 4), kept inside 0 .. 127
+constexpr int GC_LIST = GC_T + 8;             // outputs of a stream per period (bounded by the loops below)
+static_assert(GC_CS * GC_T == 64 && GC_RING == 128, "stager layout; a list word holds slot << 7 | arm in 14 bits");
+
+__global__ __launch_bounds__(192) void s2_gardner_cand_kernel(const S2StreamWork* __restrict__ work, int nstreams, S2LoopCoefs co,
+                                                             const float* __restrict__ bank_g, int sub, int nsub) {
+    __shared__ __attribute__((aligned(16))) float bank[GARDNER_PHASES * GARDNER_TAPS];
+    __shared__ __attribute__((aligned(8))) f32x2 ring[GC_CS * GC_PITCH];
+    __shared__ __attribute__((aligned(8))) f32x2 tab[2][GC_CS][GC_NR][GC_WN];
+    __shared__ __attribute__((aligned(4))) uint16_t list[2][GC_CS][GC_LIST];
+    __shared__ int tab_alo[2][GC_CS], s_pred[2][GC_CS], s_cnt[2][GC_CS], s_ostart[2][GC_CS];
+    __shared__ const cf32* s_in[GC_CS];
+    __shared__ const cf32* s_gp[GC_CS];
+    __shared__ cf32* s_out[GC_CS];
+    __shared__ int s_n[GC_CS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < GARDNER_PHASES * GARDNER_TAPS; i += 192) bank[i] = bank_g[i];
+    const int s = blockIdx.x * GC_CS + lane;
+    const bool mine = lane < GC_CS, act = mine && s < nstreams;
+    const S2StreamWork w = work[act ? s : 0];
+    int lo, hi;
+    fe_sub_range(act ? w.count : 0, sub, nsub, lo, hi);
+    const int n = hi - lo;
+    S2StreamState* st = w.st;
+    auto arm_of_phase = [](float ph) {
+        // (truncation instead of floor: the same arm for every phase once clamped -- negative products end at 0 either way)
+        const int a = (int)(ph * 128.0f);
+        return a < 0 ? 0 : (a > 127 ? 127 : a);
+    };
+    if (wave == 0 && mine) {
+        s_in[lane] = n > 0 ? w.in + lo : reinterpret_cast<const cf32*>(bank_g);
+        s_gp[lane] = n > 0 ? w.fe_out + fe_scratch_offset(w.count) + lo : reinterpret_cast<const cf32*>(bank_g);
+        s_out[lane] = w.fe_out;
+        s_n[lane] = n;
+        const int a0 = act ? arm_of_phase(st->g_phase) : 0;
+        s_pred[0][lane] = a0; s_pred[1][lane] = a0;
+        s_cnt[0][lane] = 0; s_cnt[1][lane] = 0;
+        if (act) {
+            f32x2* row = &ring[lane * GC_PITCH];
+            for (int k = 0; k < GARDNER_TAPS - 1; ++k) { const cf32 h = st->g_hist[k]; row[k] = f32x2{h.re, h.im}; row[GC_RING + k] = f32x2{h.re, h.im}; }
+        }
+    }
+    __syncthreads();
+    int nmax = 0;
+#pragma unroll
+    for (int j = 0; j < GC_CS; ++j) nmax = max(nmax, s_n[j]);
+    const int ntiles = (nmax + GC_T - 1) / GC_T;
+    // re and im of one arm: acc += x[k] * t[k] in tap order, every operation rounded (gardner.cpp / SDR++ polyphase dot product)
+    auto dot_arm = [&](const f32x2* x, const float* t) {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(t), t1 = *reinterpret_cast<const f32x4*>(t + 4);
+        f32x2 acc = f32x2{0.f, 0.f};
+        acc += x[0] * t0.x; acc += x[1] * t0.y; acc += x[2] * t0.z; acc += x[3] * t0.w;
+        acc += x[4] * t1.x; acc += x[5] * t1.y; acc += x[6] * t1.z; acc += x[7] * t1.w;
+        return acc;
+    };
+
+    if (wave >= 1) {
+        // ================= helper waves
+        const int sj = lane >> 4, smp = lane & 15, half = wave - 1;
+        const cf32* q_in = s_in[sj];
+        const cf32* q_gp = s_gp[sj];
+        cf32* q_out = s_out[sj];
+        const int q_n = s_n[sj];
+        cf32 px, pg;
+        auto issue = [&](int t) {
+            const int idx = min(t * GC_T + smp, max(q_n - 1, 0));
+            px = ldg(q_in + idx); pg = ldg(q_gp + idx);
+        };
+        auto commit = [&](int t) {
+            const int idx = t * GC_T + smp;
+            if (idx < q_n) {
+                const cf32 z = cmul(cscale(px, pg.re), phasor_fast(-pg.im));   // FastAGC scaling, FreqShift rotation
+                const int slot = (idx + GARDNER_TAPS - 1) & (GC_RING - 1);
+                f32x2* rr = &ring[sj * GC_PITCH + slot];
+                rr[0] = f32x2{z.re, z.im};
+                if (slot < 8) rr[GC_RING] = f32x2{z.re, z.im};
+            }
+        };
+        // the table of period t.  Lane = (stream, q): row q with this wave's four arms, then one (row, arm) of the rows 16..19
+        auto cand_row = [&](int t, int a_lo, int r, int j_first, int j_count) {
+            const int o = t * GC_T - 4 + r;                                   // the row's sample offset
+            if (o >= 0) {
+                const f32x2* xr = &ring[sj * GC_PITCH + (o & (GC_RING - 1))];
+                f32x2 x[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = xr[i];
+#pragma unroll
+                for (int j = 0; j < GC_WN / 2; ++j)
+                    if (j < j_count) tab[t & 1][sj][r][j_first + j] = dot_arm(x, &bank[(a_lo + j_first + j) * 8]);
+            }
+        };
+        auto candidates = [&](int t, int pred) {
+            const int a_lo = min(max(pred - 3, 0), GARDNER_PHASES - GC_WN);   // (no wrap: beside the ends of the bank the resolver computes itself)
+            if (smp == 0 && half == 0) tab_alo[t & 1][sj] = a_lo;
+            cand_row(t, a_lo, smp, half * (GC_WN / 2), GC_WN / 2);
+            cand_row(t, a_lo, GC_T + (smp >> 2), half * (GC_WN / 2) + (smp & 3), 1);
+        };
+        static_assert(GC_NR == GC_T + 4 && GC_WN == 8, "row / arm split of the helper waves");
+        // values of the outputs the resolver listed in period p: lane = (stream, output), two passes
+        auto produce = [&](int p) {
+            const int cnt = s_cnt[p & 1][sj], ostart = s_ostart[p & 1][sj];
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int li = smp + 16 * pass;
+                if (li < cnt) {
+                    const uint32_t u = list[p & 1][sj][li];
+                    const f32x2* xr = &ring[sj * GC_PITCH + ((u >> 7) & (GC_RING - 1))];
+                    f32x2 x[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[i] = xr[i];
+                    const f32x2 v = dot_arm(x, &bank[(u & 127u) * 8]);
+                    stg(q_out + ostart + li, cf32{v.x, v.y});
+                }
+            }
+        };
+        static_assert(GC_LIST <= 32, "two passes of 16 outputs");
+        if (half == 0) {
+            if (ntiles > 0) { issue(0); commit(0); }
+            if (ntiles > 1) { issue(1); commit(1); }
+            if (ntiles > 2) issue(2);
+        }
+        lds_only_barrier();                   // (period 0 is in the ring for both helper waves)
+        if (ntiles > 0) candidates(0, s_pred[1][sj]);
+        lds_only_barrier();
+        for (int t = 0; t < ntiles; ++t) {
+            if (half == 0) {
+                if (t + 2 < ntiles) commit(t + 2);
+                if (t + 3 < ntiles) issue(t + 3);
+            }
+            if (t + 1 < ntiles) candidates(t + 1, s_pred[(t + 1) & 1][sj]);   // (what the resolver reported at the end of period t-1)
+            if (half == 1 && t >= 1) produce(t - 1);
+            lds_only_barrier();
+        }
+        if (half == 1 && ntiles > 0) produce(ntiles - 1);
+        return;
+    }
+
+    // ================= resolver (lane = stream)
+    PclDev pcl{co.g_alpha, co.g_beta, st->g_phase, st->g_freq, co.g_min_freq, co.g_max_freq};
+    asm volatile("" : "+v"(pcl.maxFreq));         // (v_med3_f32 takes one scalar operand: the other bound stays in a vector register)
+    int offset = st->g_offset, spsctr = st->g_spsctr, outCount = sub ? st->n_fe_out : 0;   // (later slices append to the call's output)
+    const f32x2* row = &ring[(mine ? lane : 0) * GC_PITCH];
+    const f32x2* const tab0 = &tab[0][0][0][0];
+    uint16_t* const list0 = &list[0][0][0];
+    int tbi = 0, lbi = 0, a_lo = 0, rowbase = 0;     // the period's table: tab0 + tbi (arms a_lo .. a_lo + 7, rows from offset rowbase), list: list0 + lbi
+    int cnt = 0;
+    auto arm_of = [&]() { return arm_of_phase(pcl.phase); };
+    auto note = [&](int phase) {                     // the output at (offset, phase) joins the period's list
+        list0[lbi + cnt] = (uint16_t)((offset << 7) | phase);       // (bits 14, 15: stray offset bits, masked by the reader)
+        ++cnt;
+    };
+    auto finish = [&](float error) {
+        pcl.advance(error);
+        const float delta = floorf(pcl.phase);
+        offset = (int)((float)offset + delta);
+        pcl.phase -= delta;
+    };
+    // PCL::advance(0): freq + beta * 0 and freq + alpha * 0 are freq itself for finite gains (configuration refuses others) and a loop
+    // frequency that is not -0 (it lies within [1 - limit, 1 + limit] or is a NaN, which stays one)
+    auto finish0 = [&]() {
+        pcl.freq = clamp_med3(pcl.freq, pcl.minFreq, pcl.maxFreq);
+        pcl.phase += pcl.freq;
+        const float delta = floorf(pcl.phase);
+        offset = (int)((float)offset + delta);
+        pcl.phase -= delta;
+    };
+    // the dot products themselves (off the table, and the single steps at the ends of a slice): as in s2_gardner_bank_kernel
+    auto err_direct = [&](int phase, f32x2& xo, f32x2& d) {
+        const int base_arm = min(max(phase - 1, 0), GARDNER_PHASES - 3);       // three consecutive arms that hold what the phase needs
+        const f32x2* xr = row + (offset & (GC_RING - 1));
+        f32x2 x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = xr[k];
+        const float* t = &bank[base_arm * 8];
+        const f32x2 a = dot_arm(x, t), b = dot_arm(x, t + 8), c = dot_arm(x, t + 16);
+        xo = b; d = (c - a) * 0.5f;
+        if (phase == 0) { xo = a; d = b - a; }                                  // one-sided at the ends of the bank
+        if (phase == GARDNER_PHASES - 1) { xo = c; d = c - b; }
+    };
+    auto err_finish = [&](f32x2 xo, f32x2 d) {
+        // -((xo.re > 0 ? 1 : -1) * d.re + (xo.im > 0 ? 1 : -1) * d.im): a product with +-1 is the operand or its negation
+        const float e = (xo.x > 0 ? d.x : -d.x) + (xo.y > 0 ? d.y : -d.y);
+        finish(clamp_med3(-e, -1.0f, 1.0f));
+    };
+    // one whole symbol: on-symbol output (error, advance), then its follower (error 0)
+    auto symbol = [&]() {
+        const int phase = arm_of();
+        const int r = offset - rowbase;                    // (within the table's rows: checked once per period, see below)
+        const unsigned j0 = (unsigned)(phase - 1 - a_lo);
+        f32x2 xo, d;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(j0 > (unsigned)(GC_WN - 3)) == 0, 1)) {      // every active stream on its table
+            const f32x2* e = tab0 + tbi + r * GC_WN + (int)j0;
+            const f32x2 a = e[0], c = e[2];
+            xo = e[1]; d = (c - a) * 0.5f;                 // (a_lo >= 0 and a_lo + 7 <= 127: phase is neither 0 nor 127 here)
+        } else {
+            err_direct(phase, xo, d);
+        }
+        note(phase);
+        err_finish(xo, d);
+        note(arm_of());
+        finish0();
+    };
+    lds_only_barrier();
+    lds_only_barrier();                       // periods 0 and 1 are in the ring, the table of period 0 is made
+    __builtin_amdgcn_s_setprio(GB_PRIO);
+    for (int t = 0; t < ntiles; ++t) {
+        const int base = t * GC_T;
+        const int lim = min(base + GC_T, n);              // outputs with offset < lim have their whole window in
+        const bool last = base + GC_T >= n;               // this stream's last period of the slice
+        a_lo = tab_alo[t & 1][mine ? lane : 0];
+        tbi = ((t & 1) * GC_CS + (mine ? lane : 0)) * (GC_NR * GC_WN);
+        lbi = ((t & 1) * GC_CS + (mine ? lane : 0)) * GC_LIST;
+        rowbase = base - 4;
+        cnt = 0;
+        // rows: a whole symbol starts at base - 4 <= offset < lim - 2 <= base + T - 2 -- the upper bound is the loop's own condition, the
+        // lower one holds because a period ends at offset >= lim - 2; should it not (a period cut short by the list bound: poisoned state),
+        // this period's arms are declared off the table
+        if (offset < rowbase) a_lo = -1000;
+        if (mine) {
+            const int ostart = outCount;
+            if (spsctr == 1 && offset < lim) { note(arm_of()); finish0(); spsctr = 0; }     // (a slice that starts between the two outputs of a symbol)
+            // (trip counts bounded by the list: a poisoned loop state -- NaN input -- can neither hang the GPU nor overrun it)
+            if (spsctr == 0)
+                for (int guard = 0; guard < (GC_LIST - 4) / 2; ++guard) {
+                    const bool go = offset < lim - 2;
+                    if (__builtin_amdgcn_ballot_w64(go) == 0) break;
+                    if (go) symbol();
+                }
+            if (last)
+                for (int guard = 0; guard < 8 && offset < n && cnt < GC_LIST; ++guard) {
+                    const int phase = arm_of();
+                    note(phase);
+                    if (spsctr == 0) {
+                        f32x2 xo, d;
+                        err_direct(phase, xo, d);
+                        err_finish(xo, d);
+                    } else {
+                        finish0();
+                    }
+                    spsctr ^= 1;
+                }
+            outCount += cnt;
+            s_cnt[t & 1][lane] = cnt; s_ostart[t & 1][lane] = ostart;
+            s_pred[t & 1][lane] = arm_of();
+        }
+        lds_only_barrier();
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (act) {
+        for (int k = 0; k < GARDNER_TAPS - 1; ++k) { const f32x2 h = row[(n + k) & (GC_RING - 1)]; st->g_hist[k] = cf32{h.x, h.y}; }
+        st->g_phase = pcl.phase; st->g_freq = pcl.freq; st->g_offset = offset - n; st->g_spsctr = spsctr;
+        st->n_fe_out = outCount;
+        st->n_fe_slice[sub & (S2_FE_MAX_SLICES - 1)] = outCount;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ RRC + /2
 // grid (x: symbol tiles, y: stream).  Only the samples the decimator keeps are filtered.
 // sub / nsub: only the symbols whose windows the timing recovery's slice `sub` completed (the decimator phase and the delay line are
@@ -897,7 +1170,7 @@ __device__ __forceinline__ int lut_cell(float re, float im) {
     const float yr = __builtin_fmaf(re, K, 128.0f), yi = __builtin_fmaf(im, K, 128.0f);
     const float dr = yr - __builtin_rintf(yr), di = yi - __builtin_rintf(yi);
     int xr, xi;
-    if (__builtin_fabsf(dr) < 2.5e-4f || __builtin_fabsf(di) < 2.5e-4f) {
+    if (__builtin_expect(__builtin_fabsf(dr) < 2.5e-4f || __builtin_fabsf(di) < 2.5e-4f, 0)) {
         xr = lut_index(re); xi = lut_index(im);
     } else {
         xr = (int)yr; xi = (int)yi;                    // (NaN -> 0, +-inf saturate: what the double form gives after its clamp)
@@ -2335,22 +2608,29 @@ static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, c
     }
     return hipGetLastError();
 }
-// Three forms of the timing recovery, all bit-identical (tests/test_gpu_s2chain.py runs every one): 1 = one wave, 8 lanes per stream
-// (s2_gardner_kernel); 2 = resolver + producer waves, 8 lanes per stream (s2_gardner2_kernel: the shortest chain per stream -- what a small
-// bank needs); 3 = lane per stream (s2_gardner_bank_kernel: the fewest instructions in all).  Default: form 2 below S2_GARDNER_BANK_MIN
-// streams, form 1 from there on; DVBS2GPU_GARDNER_FORM=1|2|3 in the environment forces one (development aid / the parity tests).
+// Four forms of the timing recovery, all bit-identical (tests/test_gpu_gardner_forms.py runs every one): 1 = one wave, 8 lanes per stream
+// (s2_gardner_kernel); 2 = resolver + producer waves, 8 lanes per stream (s2_gardner2_kernel); 3 = lane per stream (s2_gardner_bank_kernel:
+// the fewest instructions in all); 4 = candidate tables (s2_gardner_cand_kernel: the shortest chain per stream -- what a small bank
+// needs: one stream 3.68 -> 2.5 ms per 21 690-sample slice against form 2, no gain from 64 streams on).  Default: form 4 below
+// S2_GARDNER_CAND_MAX streams, form 2 below S2_GARDNER_BANK_MIN, form 1 from there on; DVBS2GPU_GARDNER_FORM=1|2|3|4 in the environment
+// forces one (development aid / the parity tests).
 #ifndef S2_GARDNER_BANK_MIN
 #define S2_GARDNER_BANK_MIN 512
 #endif
+#ifndef S2_GARDNER_CAND_MAX
+#define S2_GARDNER_CAND_MAX 64
+#endif
 static int gardner_form(int nstreams, int prio_duty) {
     static const int forced = [] { const char* e = getenv("DVBS2GPU_GARDNER_FORM"); return e ? atoi(e) : 0; }();
-    if (forced >= 1 && forced <= 3) return forced;
+    if (forced >= 1 && forced <= 4) return forced;
+    if (nstreams < S2_GARDNER_CAND_MAX) return 4;
     // a big bank beside the decoder of the previous call: the one-wave form disturbs the decoder least; once the balancer of the pipelined
     // mode (s2_demod.hip) has found the FRONT END to be the critical path (it raises the timing loop's priority share), the shorter chain wins
     return (nstreams < S2_GARDNER_BANK_MIN || prio_duty >= 2) ? 2 : 1;
 }
 static void gardner_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const float* d_bank, hipStream_t st, int c, int nsub) {
     switch (gardner_form(nstreams, coefs.g_prio_duty)) {
+        case 4: hipLaunchKernelGGL(s2_gardner_cand_kernel, dim3((nstreams + GC_CS - 1) / GC_CS), dim3(192), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
         case 3: hipLaunchKernelGGL(s2_gardner_bank_kernel, dim3((nstreams + 63) / 64), dim3(128), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
         case 2: hipLaunchKernelGGL(s2_gardner2_kernel, dim3((nstreams + G_SPW - 1) / G_SPW), dim3(128), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
         default: hipLaunchKernelGGL(s2_gardner_kernel, dim3((nstreams + G_SPW - 1) / G_SPW), dim3(64), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('form', [1, 2, 3])
+@pytest.mark.parametrize('form', [1, 2, 3, 4])
 def test_chain_is_bit_identical_with_every_timing_recovery_form(form):
     env = dict(os.environ, DVBS2GPU_GARDNER_FORM=str(form))
     sel = 'front_end_is_bit_identical or time_sliced_front_end or (demod_end_to_end_vs_oracle and (4-1-0 or 6-1-1 or 14-1-0))'
