@@ -1169,12 +1169,11 @@ __device__ __forceinline__ int lut_cell(float re, float im) {
     const float K = 170.66666666666666f;
     const float yr = __builtin_fmaf(re, K, 128.0f), yi = __builtin_fmaf(im, K, 128.0f);
     const float dr = yr - __builtin_rintf(yr), di = yi - __builtin_rintf(yi);
-    int xr, xi;
-    if (__builtin_expect(__builtin_fabsf(dr) < 2.5e-4f || __builtin_fabsf(di) < 2.5e-4f, 0)) {
-        xr = lut_index(re); xi = lut_index(im);
-    } else {
-        xr = (int)yr; xi = (int)yi;                    // (NaN -> 0, +-inf saturate: what the double form gives after its clamp)
-        xr = max(0, min(255, xr)); xi = max(0, min(255, xi));
+    int xr = (int)yr, xi = (int)yi;                    // (NaN -> 0, +-inf saturate: what the double form gives after its clamp)
+    xr = max(0, min(255, xr)); xi = max(0, min(255, xi));
+    const bool near = __builtin_fabsf(dr) < 2.5e-4f || __builtin_fabsf(di) < 2.5e-4f;
+    if (__builtin_expect(__any(near), 0)) {             // (uniform branch, its body out of line: a taken branch costs ~28 cycles here)
+        if (near) { xr = lut_index(re); xi = lut_index(im); }
     }
     return xr * 256 + xi;
 }
@@ -1255,6 +1254,9 @@ __device__ __attribute__((noinline)) float soft_phase_err_group(lds_cf32* __rest
 // takes issue slots from the LDPC decoder that shares the SIMDs in the pipelined mode (16 lanes per stream: 28 ms beside it,
 // LDPC 74 ms).  Groups whose stream has fewer frames in this call shadow a frame of another group (same code path, nothing
 // stored, state restored afterwards).
+// (tried in round 3 for small banks: the PLL's phase-error table folded onto one quadrant -- 8PSK's table is bit for bit invariant under
+// 90-degree turns -- and kept in LDS, 66 KB: no gain.  The lookups of one stream mostly hit the CU's vector L1 (~130 cycles, tools/ubench/
+// chase.hip), and the fold's index arithmetic costs what the LDS fetch saves: 459 against 463 cycles per symbol in the plain PLL loop.)
 #ifndef FL_LPS_N
 #define FL_LPS_N 8
 #endif
