@@ -210,23 +210,26 @@ __global__ __launch_bounds__(128) void agc_pc_kernel(const typename TR::Work* __
     fe_sub_range(act ? w.count : 0, sub, nsub, lo, hi);
     const int n = hi - lo;
     typename TR::Regs regs = TR::load(w);
-    if (wave == 0) { s_in[lane] = TR::in_ptr(w) + lo; s_out[lane] = TR::out_ptr(w) + lo; s_n[lane] = n; }
+    // (a stream without samples in this slice may come with a null input pointer: the movers' clamped loads then read the work table)
+    if (wave == 0) { s_in[lane] = n > 0 ? TR::in_ptr(w) + lo : reinterpret_cast<const cf32*>(work); s_out[lane] = TR::out_ptr(w) + lo; s_n[lane] = n; }
     int nmax = n;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
     const int ntiles = (nmax + AG_T - 1) / AG_T;
     __syncthreads();
-    // tile movers (wave 1): each instruction moves 64/AG_T rows of a tile, AG_T*8 contiguous bytes per row
+    // tile movers (wave 1): each instruction moves 64/AG_T rows of a tile, AG_T*8 contiguous bytes per row.  The loads of a tile are issued
+    // a whole period before their values go to LDS (unconditional, clamped indices: a load behind a branch is waited for on the spot), so
+    // the memory latency of a 64-stream tile never enters a period -- with it inside, the mover, not the chains, set the pace of a full wave
+    // of streams (160 ns per sample against 100 for a single stream)
     const int half = lane / AG_T, col = lane % AG_T;
     constexpr int RPI = 64 / AG_T;        // rows per load/store instruction
     constexpr int NQ = 64 / RPI;          // instructions per tile
-    auto load_tile = [&](int t, cf32 (*B)[AG_T + 1]) {
-        cf32 v[NQ];
+    cf32 v[NQ];                           // (pointers and counts stay in LDS: this kernel has to fit into 128 registers, see s2_frame_loops_kernel)
+    auto issue = [&](int t) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int row = RPI * q + half, idx = t * AG_T + col;
-            v[q] = idx < s_n[row] ? ldg(s_in[row] + idx) : cf32{0.f, 0.f};
-        }
+        for (int q = 0; q < NQ; ++q) v[q] = ldg(s_in[RPI * q + half] + min(t * AG_T + col, max(s_n[RPI * q + half] - 1, 0)));
+    };
+    auto commit = [&](cf32 (*B)[AG_T + 1]) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) B[RPI * q + half][col] = v[q];
     };
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(128) void agc_pc_kernel(const typename TR::Work* __
             if (idx < s_n[row]) stg(s_out[row] + idx, B[row][col]);
         }
     };
-    if (wave == 1 && ntiles > 0) load_tile(0, buf[0]);
+    if (wave == 1 && ntiles > 0) { issue(0); commit(buf[0]); if (ntiles > 1) issue(1); }
     __syncthreads();
     // the serial chains are latency-critical and issue little: win the issue arbitration against throughput kernels (the LDPC
     // decoder of the previous call shares the SIMDs in the pipelined mode)
@@ -262,8 +265,9 @@ __global__ __launch_bounds__(128) void agc_pc_kernel(const typename TR::Work* __
                     if (i < m) B[lane][i] = TR::step(regs, B[lane][i], co);
             }
         } else {
-            if (t >= 1) store_tile(t - 1, buf[(t - 1) & 1]);
-            if (t + 1 < ntiles) load_tile(t + 1, buf[(t + 1) & 1]);
+            if (t >= 1) store_tile(t - 1, buf[(t - 1) & 1]);          // (out of the buffer tile t+1 goes into next)
+            if (t + 1 < ntiles) commit(buf[(t + 1) & 1]);
+            if (t + 2 < ntiles) issue(t + 2);
         }
         __syncthreads();
     }
@@ -828,7 +832,9 @@ constexpr int GC_T = 16;                      // samples per stream and period
 constexpr int GC_CS = 4;                      // streams per workgroup (64 = GC_CS * GC_T: one staged sample per lane of wave 1)
 constexpr int GC_RING = 8 * GC_T;             // ring slots per stream: t-1 (its outputs' values), t (resolved), t+1 (tables), t+2 (staged), slack
 constexpr int GC_PITCH = GC_RING + 8;         // + mirror of the first 8 slots: a window never wraps
-constexpr int GC_NR = GC_T + 4;               // table rows: offsets base-4 .. base+T-1 of the period
+constexpr int GC_LB = 2;                      // a period's whole symbols start at offsets >= base - GC_LB (the period before ended at >= lim - 2)
+constexpr int GC_NR = GC_T + GC_LB;           // table rows: offsets base-2 .. base+T-1 of the period (with 4 more rows the workgroup's LDS would
+                                              // exceed the AGC kernel's 18.7 KB: beside a resident decoder workgroup it fits where that one fits)
 constexpr int GC_WN = 8;                      // arms per row: (reported arm - 3) .. (reported arm + 4), kept inside 0 .. 127
 constexpr int GC_LIST = GC_T + 8;             // outputs of a stream per period (bounded by the loops below)
 static_assert(GC_CS * GC_T == 64 && GC_RING == 128, "stager layout; a list word holds slot << 7 | arm in 14 bits");
@@ -907,10 +913,10 @@ __global__ __launch_bounds__(192) void s2_gardner_cand_kernel(const S2StreamWork
                 if (slot < 8) rr[GC_RING] = f32x2{z.re, z.im};
             }
         };
-        // the table of period t.  Lane = (stream, q): row q with this wave's four arms, then one (row, arm) of the rows 16..19
+        // the table of period t.  Lane = (stream, q): row q with this wave's four arms, then (q < 8) one (row, arm) of the rows 16, 17
         auto cand_row = [&](int t, int a_lo, int r, int j_first, int j_count) {
-            const int o = t * GC_T - 4 + r;                                   // the row's sample offset
-            if (o >= 0) {
+            const int o = t * GC_T - GC_LB + r;                               // the row's sample offset
+            if (o >= 0 && r < GC_NR) {
                 const f32x2* xr = &ring[sj * GC_PITCH + (o & (GC_RING - 1))];
                 f32x2 x[8];
 #pragma unroll
@@ -924,9 +930,9 @@ __global__ __launch_bounds__(192) void s2_gardner_cand_kernel(const S2StreamWork
             const int a_lo = min(max(pred - 3, 0), GARDNER_PHASES - GC_WN);   // (no wrap: beside the ends of the bank the resolver computes itself)
             if (smp == 0 && half == 0) tab_alo[t & 1][sj] = a_lo;
             cand_row(t, a_lo, smp, half * (GC_WN / 2), GC_WN / 2);
-            cand_row(t, a_lo, GC_T + (smp >> 2), half * (GC_WN / 2) + (smp & 3), 1);
+            cand_row(t, a_lo, GC_T + (smp >> 2), half * (GC_WN / 2) + (smp & 3), 1);       // (rows >= GC_NR: nothing)
         };
-        static_assert(GC_NR == GC_T + 4 && GC_WN == 8, "row / arm split of the helper waves");
+        static_assert(GC_NR == GC_T + 2 && GC_WN == 8, "row / arm split of the helper waves");
         // values of the outputs the resolver listed in period p: lane = (stream, output), two passes
         auto produce = [&](int p) {
             const int cnt = s_cnt[p & 1][sj], ostart = s_ostart[p & 1][sj];
@@ -1041,9 +1047,9 @@ __global__ __launch_bounds__(192) void s2_gardner_cand_kernel(const S2StreamWork
         a_lo = tab_alo[t & 1][mine ? lane : 0];
         tbi = ((t & 1) * GC_CS + (mine ? lane : 0)) * (GC_NR * GC_WN);
         lbi = ((t & 1) * GC_CS + (mine ? lane : 0)) * GC_LIST;
-        rowbase = base - 4;
+        rowbase = base - GC_LB;
         cnt = 0;
-        // rows: a whole symbol starts at base - 4 <= offset < lim - 2 <= base + T - 2 -- the upper bound is the loop's own condition, the
+        // rows: a whole symbol starts at base - 2 <= offset < lim - 2 <= base + T - 2 -- the upper bound is the loop's own condition, the
         // lower one holds because a period ends at offset >= lim - 2; should it not (a period cut short by the list bound: poisoned state),
         // this period's arms are declared off the table
         if (offset < rowbase) a_lo = -1000;
@@ -2613,19 +2619,19 @@ static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, c
 // Four forms of the timing recovery, all bit-identical (tests/test_gpu_gardner_forms.py runs every one): 1 = one wave, 8 lanes per stream
 // (s2_gardner_kernel); 2 = resolver + producer waves, 8 lanes per stream (s2_gardner2_kernel); 3 = lane per stream (s2_gardner_bank_kernel:
 // the fewest instructions in all); 4 = candidate tables (s2_gardner_cand_kernel: the shortest chain per stream -- what a small bank
-// needs: one stream 3.68 -> 2.5 ms per 21 690-sample slice against form 2, no gain from 64 streams on).  Default: form 4 below
-// S2_GARDNER_CAND_MAX streams, form 2 below S2_GARDNER_BANK_MIN, form 1 from there on; DVBS2GPU_GARDNER_FORM=1|2|3|4 in the environment
+// needs: one stream 3.68 -> 2.5 ms per 21 690-sample slice against form 2; 64 streams x 1 frame 18.6 -> 16.7 ms per call, 256 x 4 frames
+// 50.3 -> 47.2).  Default: form 4 up to S2_GARDNER_CAND_MAX streams, form 2 below S2_GARDNER_BANK_MIN, form 1 from there on; DVBS2GPU_GARDNER_FORM=1|2|3|4 in the environment
 // forces one (development aid / the parity tests).
 #ifndef S2_GARDNER_BANK_MIN
 #define S2_GARDNER_BANK_MIN 512
 #endif
 #ifndef S2_GARDNER_CAND_MAX
-#define S2_GARDNER_CAND_MAX 64
+#define S2_GARDNER_CAND_MAX 256
 #endif
 static int gardner_form(int nstreams, int prio_duty) {
     static const int forced = [] { const char* e = getenv("DVBS2GPU_GARDNER_FORM"); return e ? atoi(e) : 0; }();
     if (forced >= 1 && forced <= 4) return forced;
-    if (nstreams < S2_GARDNER_CAND_MAX) return 4;
+    if (nstreams <= S2_GARDNER_CAND_MAX) return 4;
     // a big bank beside the decoder of the previous call: the one-wave form disturbs the decoder least; once the balancer of the pipelined
     // mode (s2_demod.hip) has found the FRONT END to be the critical path (it raises the timing loop's priority share), the shorter chain wins
     return (nstreams < S2_GARDNER_BANK_MIN || prio_duty >= 2) ? 2 : 1;
