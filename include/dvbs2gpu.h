@@ -171,7 +171,8 @@ typedef struct dvbs2gpu_demod_cfg {
     float agc_rate, rrc_alpha;
     int32_t rrc_taps;
     float loop_bw, fll_bw;
-    float clock_omega_gain, clock_mu_gain, omega_rel_limit;
+    float clock_omega_gain, clock_mu_gain, omega_rel_limit;   /* gains, agc_rate and the bandwidths must be finite (DVBS2GPU_ERR_ARG otherwise):
+                                          * the timing-recovery kernels evaluate PCL::advance(0) as "frequency unchanged" */
     int32_t modcod, shortframes, pilots;
     float sof_threshold;                 /* stored, unused in CCM mode -- as in the reference (dvbs2_pl_sync.cpp:140-142); ACM/VCM mode:
                                           * minimum SOF quality of a frame start */
