@@ -143,7 +143,9 @@ struct dvbs2gpu_ctx {
     struct FeAux { hipStream_t aux = nullptr, aux2 = nullptr; hipEvent_t ev[9] = {}, ev2[9] = {}; hipStream_t dvbs_aux[4] = {}; hipEvent_t dvbs_ev[4][s2::DVBS_FE_MAX_SLICES + 1] = {}; };   // (dvbs_*: the DVB-S receiver's stage streams: AGC, FLL, RRC, soft FIFO + Viterbi)
     std::map<hipStream_t, FeAux> fe_aux;
     int stage_pipeline_launches = 0;          // DVBS2GPU_STAGE_LOOPS: frame-loop launches per call (0 = chosen per call, s2_demod.hip)
-    int stage_pipeline_min_duty = 0;          // DVBS2GPU_STAGE_MIN_DUTY: pipelined mode uses the stage pipeline only above this balancer setting (-1: always)
+    int stage_pipeline_min_duty = 2;          // DVBS2GPU_STAGE_MIN_DUTY: pipelined mode uses the stage pipeline only above this balancer setting (-1: always).
+                                              // 2: with the frame loops at the decoder's base priority the two streams of a headline step are 6 ms apart, a stray
+                                              // verdict of the balancer must not tip the step into the other flow (which costs it 3 %)
     int stage_post_stream = 1;                // DVBS2GPU_STAGE_POST_STREAM: synchronous mode runs the post stages on a stream of their own (0: on the AGC's)
     unsigned stage_calls = 0;
     int stage_pipeline = 1;                   // DVBS2GPU_STAGE_PIPELINE: RRC, PL-sync walk and frame loops of a CCM call behind every timing-recovery slice (0: after the last one, frames pooled by the host first)

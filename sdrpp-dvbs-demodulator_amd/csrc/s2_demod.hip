@@ -529,7 +529,9 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             for (int f = 0; f < nf; ++f) hstats[f] = slot_stats[fslot[f]];
         } else {
             StageSpan sp(ctx->timers, ST_LOOPS, st);
-            HIP_TRY(s2_frame_loops_launch(d_work, n, d_frames, d_first, d0->co, ctx->pl, CT->dev, d0->pls_code, mp.slots, mp.pilots,
+            S2LoopCoefs lc = d0->co;
+            lc.g_prio_duty = pipelined ? ctx->g_prio_duty : 0;      // (scheduling only: the loops' wave priority, see the kernel)
+            HIP_TRY(s2_frame_loops_launch(d_work, n, d_frames, d_first, lc, ctx->pl, CT->dev, d0->pls_code, mp.slots, mp.pilots,
                                           mp.pilot_blocks, raw, d_pll, d_stats, st));
         }
         { StageSpan sp(ctx->timers, ST_DEMAP, st); HIP_TRY(s2_demap_launch(CT->dev, mp.rate, mp.shortframe, mp.slots, mp.pilots, raw, d_pll, nf, d_llr, N, st, staged ? d_slot : nullptr)); }

@@ -1301,7 +1301,11 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
     const cf32* __restrict__ plsc = T.plsc + (size_t)pls_code * 64;
     const int done = found ? st->loops_done : 0;
     const int f0 = found ? sc * maxf + done : first[sc], nf = !act ? 0 : (found ? st->walk_nf - done : first[sc + 1] - f0);
-    __builtin_amdgcn_s_setprio(FL_PRIO);       // latency-critical serial loops (see agc_pc_kernel)
+    // Wave priority: FL_PRIO (the serial loops' latency first) only where the balancer of the pipelined mode has found the FRONT END to be the
+    // critical path (s2_demod.hip: g_prio_duty >= 2).  Beside a decoder that IS the critical path the loops run at the decoder's own base
+    // priority: they take 88 instead of 60 ms per headline step -- there is slack for that on their stream -- and the decoder launch 342
+    // instead of 352 (2 020 against 1 966 Msym/s).  At priority 1 nothing changes: what counts is being level with the decoder's parallel phases.
+    if (co.g_prio_duty >= 2) __builtin_amdgcn_s_setprio(FL_PRIO); else __builtin_amdgcn_s_setprio(0);
     // the phase-error table's address lives in vector registers for the whole kernel (as a kernel argument it was re-fetched from the argument
     // segment -- a scalar-cache round trip -- in front of every symbol's lookup)
     const float* lut_err_v = C.lut_err;
