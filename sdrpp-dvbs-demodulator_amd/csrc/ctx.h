@@ -133,7 +133,7 @@ struct dvbs2gpu_ctx {
     void* pending_fec[MAX_PIPE_GROUPS] = {};              // s2::PendingFec*
     s2::Workspace ws_fecbuf[MAX_PIPE_GROUPS][2][3];       // per parity: LLRs | BBFRAMEs | frame refs + first[] + trials + corrections
     int fec_parity[MAX_PIPE_GROUPS] = {};
-    hipEvent_t ev_fec[MAX_PIPE_GROUPS] = {};
+    hipEvent_t ev_fec[MAX_PIPE_GROUPS][2] = {};   // end of a group's FEC job, per job parity (the next job is enqueued before the previous one is delivered)
     // several groups of one pipelined batch run their MODCOD-dependent stages side by side (one host thread and HIP stream each)
     s2::Workspace ws_grp[MAX_PIPE_GROUPS][8];
     hipStream_t grp_stream[MAX_PIPE_GROUPS] = {};

@@ -334,6 +334,7 @@ struct PendingFec {
     const uint8_t* d_bb = nullptr;
     const int32_t* d_trials = nullptr;
     const int32_t* d_corr = nullptr;
+    hipEvent_t done = nullptr;          // recorded on the FEC stream behind the job
 };
 
 // development aid: DVBS2GPU_HOST_TIMING=1 prints where the HOST spends a call (ms since entry at each mark)
@@ -592,7 +593,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     for (int i = 0; i < n; ++i) out_bytes[i] = 0;
     // results of a finished (or finishing) job -> the caller's output buffers and the per-frame stats of its streams
     auto deliver = [&](PendingFec* job) -> int {
-        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_fec[slot], 0));
+        HIP_TRY(hipStreamWaitEvent(st, job->done, 0));
         Workspace& wo = W[6];
         int rc2;
         if ((rc2 = wo.ensure(sizeof(uint8_t*) * n))) return rc2;
@@ -627,6 +628,40 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             last_error() = "pipelined mode needs the same streams in the same order on every call";
             return DVBS2GPU_ERR_ARG;
         }
+    }
+    // This call's job goes onto the FEC stream BEFORE the previous call's job is delivered: the stream then runs decoder launch after decoder
+    // launch with no host in between (delivered first, a headline step left the FEC stream idle for ~5 ms: the scatter, its copies and the
+    // synchronisation of the delivery).  The two jobs use the two halves of the double-buffered FEC workspaces and an event each.
+    std::unique_ptr<PendingFec> started;
+    if (nf > 0) {
+        const int par = ctx->fec_parity[slot];
+        Workspace& wj = ctx->ws_fecbuf[slot][par][2];
+        S2FrameRef* j_frames = (S2FrameRef*)wj.p;
+        int* j_first = (int*)((char*)wj.p + sizeof(S2FrameRef) * nf);
+        int32_t* j_trials = (int32_t*)((char*)wj.p + sizeof(S2FrameRef) * nf + sizeof(int) * (n + 1));
+        int32_t* j_corr = j_trials + nf;
+        auto job = std::make_unique<PendingFec>();
+        job->n = n; job->nf = nf; job->kb = kb;
+        job->dm.assign(dm, dm + n);
+        job->first = first; job->hstats = hstats; job->frame_bm = frame_bm;
+        job->d_frames = j_frames; job->d_first = j_first; job->d_bb = (const uint8_t*)ctx->ws_fecbuf[slot][par][1].p;
+        job->d_trials = j_trials; job->d_corr = j_corr;
+        const int force = d0->cfg.force_ldpc_iters > 0;
+        const int mt = force ? d0->cfg.force_ldpc_iters : d0->cfg.max_ldpc_trials;
+        {
+            std::lock_guard<std::mutex> fl(ctx->fec_mtx);
+            HIP_TRY(hipStreamWaitEvent(sf, ev_llr, 0));
+            if ((rc = fec_run(ctx, mp.fec, (const int8_t*)ctx->ws_fecbuf[slot][par][0].p, nf, mt, force, (uint8_t*)ctx->ws_fecbuf[slot][par][1].p, j_trials, j_corr, sf)))
+                return rc;
+            if (!ctx->ev_fec[slot][par]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fec[slot][par], hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(ctx->ev_fec[slot][par], sf));
+            job->done = ctx->ev_fec[slot][par];
+        }
+        ctx->fec_parity[slot] ^= 1;
+        hm.mark("fec_enqueued");
+        started = std::move(job);
+    }
+    if (prev) {
         const auto t_d0 = std::chrono::steady_clock::now();
         if ((rc = deliver(prev))) return rc;      // FEC of the previous call (ran during this call's front end)
         hm.mark("prev_delivered");
@@ -648,36 +683,12 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     } else {
         for (int i = 0; i < n; ++i) dm[i]->stats.clear();
     }
-    if (nf > 0) {
-        const int par = ctx->fec_parity[slot];
-        Workspace& wj = ctx->ws_fecbuf[slot][par][2];
-        S2FrameRef* j_frames = (S2FrameRef*)wj.p;
-        int* j_first = (int*)((char*)wj.p + sizeof(S2FrameRef) * nf);
-        int32_t* j_trials = (int32_t*)((char*)wj.p + sizeof(S2FrameRef) * nf + sizeof(int) * (n + 1));
-        int32_t* j_corr = j_trials + nf;
-        auto job = std::make_unique<PendingFec>();
-        job->n = n; job->nf = nf; job->kb = kb;
-        job->dm.assign(dm, dm + n);
-        job->first = first; job->hstats = hstats; job->frame_bm = frame_bm;
-        job->d_frames = j_frames; job->d_first = j_first; job->d_bb = (const uint8_t*)ctx->ws_fecbuf[slot][par][1].p;
-        job->d_trials = j_trials; job->d_corr = j_corr;
-        const int force = d0->cfg.force_ldpc_iters > 0;
-        const int mt = force ? d0->cfg.force_ldpc_iters : d0->cfg.max_ldpc_trials;
-        {
-            std::lock_guard<std::mutex> fl(ctx->fec_mtx);
-            HIP_TRY(hipStreamWaitEvent(sf, ev_llr, 0));
-            if ((rc = fec_run(ctx, mp.fec, (const int8_t*)ctx->ws_fecbuf[slot][par][0].p, nf, mt, force, (uint8_t*)ctx->ws_fecbuf[slot][par][1].p, j_trials, j_corr, sf)))
-                return rc;
-            if (!ctx->ev_fec[slot]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fec[slot], hipEventDisableTiming));
-            HIP_TRY(hipEventRecord(ctx->ev_fec[slot], sf));
-        }
-        ctx->fec_parity[slot] ^= 1;
-        hm.mark("fec_enqueued");
+    if (started) {
         if (deliver_now) {
             // synchronous call with several groups side by side: the job is collected by the call that started it
-            if ((rc = deliver(job.get()))) return rc;
+            if ((rc = deliver(started.get()))) return rc;
         } else {
-            ctx->pending_fec[slot] = job.release();
+            ctx->pending_fec[slot] = started.release();
         }
     }
     return 0;
