@@ -131,7 +131,8 @@ int dvbs2gpu_deinterleave_batch(dvbs2gpu_ctx* ctx, int modcod, int shortframes, 
  * freq_shift.cpp:6, dvbs2_pll.cpp:39,50-75, dvbs2_plhdr_demod.cpp:35, fll.cpp:137, constellation.cpp:226,250,259).  This
  * entry point evaluates those definitions element-wise on the GPU so that a test can compare them bit for bit with the
  * host evaluation of the same header.  func: 0 sincos(a) -> out0 = sin, out1 = cos; 1 atan2(a, b) -> out0; 2 exp(a);
- * 3 log(a); 4 the LLR clamp of constellation.cpp:263-270 (as float).  Device pointers, n elements. */
+ * 3 log(a); 4 the LLR clamp of constellation.cpp:263-270 (as float); 5 the LUT cell of the sample (a, b) = re_index * 256 + im_index
+ * (constellation.cpp:295-301; the kernels' binary32 fast path with the double form as its guard).  Device pointers, n elements. */
 int dvbs2gpu_math_eval(dvbs2gpu_ctx* ctx, int func, int n, const float* d_a, const float* d_b, float* d_out0, float* d_out1,
                        void* stream);
 

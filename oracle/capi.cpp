@@ -188,6 +188,7 @@ void orc_math_eval(int func, int n, const float* a, const float* b, float* o0, f
             case 1: o0[i] = dvbs2m::atan2f_det(a[i], b[i]); break;
             case 2: o0[i] = dvbs2m::expf_det(a[i]); break;
             case 3: o0[i] = dvbs2m::logf_det(a[i]); break;
+            case 5: o0[i] = (float)(Constellation::lut_index(a[i]) * 256 + Constellation::lut_index(b[i])); break;   // constellation.cpp:295-301, in double
             default: o0[i] = (float)dvbs2m::llr_clamp_det(a[i]); break;
         }
     }

@@ -1291,9 +1291,9 @@ int dvbs2gpu_deinterleave_batch(dvbs2gpu_ctx* ctx, int modcod, int shortframes, 
 }
 
 int dvbs2gpu_math_eval(dvbs2gpu_ctx* ctx, int func, int n, const float* d_a, const float* d_b, float* d_out0, float* d_out1, void* stream) {
-    if (!ctx || n < 0 || func < 0 || func > 4) return DVBS2GPU_ERR_ARG;
+    if (!ctx || n < 0 || func < 0 || func > 5) return DVBS2GPU_ERR_ARG;
     if (n == 0) return 0;
-    if (!d_a || !d_out0 || (func == 1 && !d_b) || (func == 0 && !d_out1)) return DVBS2GPU_ERR_ARG;
+    if (!d_a || !d_out0 || ((func == 1 || func == 5) && !d_b) || (func == 0 && !d_out1)) return DVBS2GPU_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(math_eval_launch(func, n, d_a, d_b, d_out0, d_out1, (hipStream_t)stream));
     return 0;

@@ -1165,6 +1165,9 @@ __device__ __forceinline__ int lut_index(float v) {   // constellation.cpp:295-3
     const double y = (double)v * 170.66666666666666 + 128.0;
     int x = (int)y;
     if (__builtin_fabs(y - __builtin_rint(y)) < 1e-9) x = (int)(((double)v / 1.5) * 256 + 128);
+    // (a value beyond the int range -- |v| > 1.2e7, +inf -- converts to INT_MIN on x86-64 and ends at cell 0 there; the device's conversion
+    //  saturates: the x86 outcome is the reference's, tests/test_det_math.py)
+    if (!(y < 2147483648.0)) x = 0;
     return x < 0 ? 0 : (x > 255 ? 255 : x);
 }
 // Both table indices of a sample at once, as re_index * 256 + im_index.  The binary32 product-sum y32 = fma(v, 256/1.5, 128) is within
@@ -1177,7 +1180,7 @@ __device__ __forceinline__ int lut_cell(float re, float im) {
     const float dr = yr - __builtin_rintf(yr), di = yi - __builtin_rintf(yi);
     int xr = (int)yr, xi = (int)yi;                    // (NaN -> 0, +-inf saturate: what the double form gives after its clamp)
     xr = max(0, min(255, xr)); xi = max(0, min(255, xi));
-    const bool near = __builtin_fabsf(dr) < 2.5e-4f || __builtin_fabsf(di) < 2.5e-4f;
+    const bool near = !(__builtin_fabsf(dr) >= 2.5e-4f && __builtin_fabsf(di) >= 2.5e-4f);      // (NaN differences -- infinite or NaN samples -- count as near)
     if (__builtin_expect(__any(near), 0)) {             // (uniform branch, its body out of line: a taken branch costs ~28 cycles here)
         if (near) { xr = lut_index(re); xi = lut_index(im); }
     }
@@ -2502,6 +2505,7 @@ __global__ __launch_bounds__(256) void math_eval_kernel(int func, int n, const f
         case 1: o0[i] = dvbs2m::atan2f_det(a[i], b[i]); break;
         case 2: o0[i] = dvbs2m::expf_det(a[i]); break;
         case 3: o0[i] = dvbs2m::logf_det(a[i]); break;
+        case 5: o0[i] = (float)lut_cell(a[i], b[i]); break;       // the loops' and the demapper's table cell (binary32 fast path + double form)
         default: o0[i] = (float)dvbs2m::llr_clamp_det(a[i]); break;
     }
 }

@@ -101,3 +101,18 @@ def test_device_evaluates_the_same_bits(engine):
     same(2, I['exp'])
     same(3, I['log'])
     same(4, I['clamp'])
+    # the LUT cell index: the kernels take it from ONE binary32 product-sum and fall back to the reference's double expression only within
+    # 2.5e-4 of an integer -- equal to the double expression for every input, the cell boundaries and their float neighbours included
+    edges = (np.arange(-300, 300, dtype=np.float64) * 1.5 / 256).astype(np.float32)
+    near = np.concatenate([edges, np.nextafter(edges, np.float32(10)), np.nextafter(edges, np.float32(-10)),
+                           (edges.astype(np.float64) + rng.uniform(-3e-6, 3e-6, edges.size)).astype(np.float32)])
+    re = np.concatenate([rng.uniform(-0.8, 0.8, 2000000).astype(np.float32), near, rng.permutation(near),
+                         np.float32([np.inf, -np.inf, np.nan, 1e30, -1e30, 0.0, -0.0, 0.75, -0.75])])
+    im = np.concatenate([rng.uniform(-0.8, 0.8, 2000000).astype(np.float32), rng.permutation(near), near,
+                         np.float32([0.1, 0.2, 0.3, np.nan, np.inf, -0.0, 0.0, -0.75, 0.75])])
+    same(5, re, im)
+    h0, _ = orc.math_eval(5, re, im)
+    fin = np.isfinite(re) & np.isfinite(im)
+    xi = np.clip(np.trunc(np.clip(re[fin].astype(np.float64) / 1.5 * 256 + 128, -1e9, 1e9)), 0, 255)
+    yi = np.clip(np.trunc(np.clip(im[fin].astype(np.float64) / 1.5 * 256 + 128, -1e9, 1e9)), 0, 255)
+    assert np.array_equal(h0[fin].astype(np.int64), (xi * 256 + yi).astype(np.int64))
