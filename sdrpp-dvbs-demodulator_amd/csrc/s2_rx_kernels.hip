@@ -839,8 +839,10 @@ constexpr int GC_WN = 8;                      // arms per row: (reported arm - 3
 constexpr int GC_LIST = GC_T + 8;             // outputs of a stream per period (bounded by the loops below)
 static_assert(GC_CS * GC_T == 64 && GC_RING == 128, "stager layout; a list word holds slot << 7 | arm in 14 bits");
 
+// pred_skew: added to the reported arm before the table's window is laid around it -- 0 in production; the tests skew the prediction so
+// that the resolver leaves its tables (partly, or with every symbol) and has to get the same bits from the fall-back path
 __global__ __launch_bounds__(192) void s2_gardner_cand_kernel(const S2StreamWork* __restrict__ work, int nstreams, S2LoopCoefs co,
-                                                             const float* __restrict__ bank_g, int sub, int nsub) {
+                                                             const float* __restrict__ bank_g, int sub, int nsub, int pred_skew) {
     __shared__ __attribute__((aligned(16))) float bank[GARDNER_PHASES * GARDNER_TAPS];
     __shared__ __attribute__((aligned(8))) f32x2 ring[GC_CS * GC_PITCH];
     __shared__ __attribute__((aligned(8))) f32x2 tab[2][GC_CS][GC_NR][GC_WN];
@@ -927,7 +929,7 @@ __global__ __launch_bounds__(192) void s2_gardner_cand_kernel(const S2StreamWork
             }
         };
         auto candidates = [&](int t, int pred) {
-            const int a_lo = min(max(pred - 3, 0), GARDNER_PHASES - GC_WN);   // (no wrap: beside the ends of the bank the resolver computes itself)
+            const int a_lo = min(max(pred + pred_skew - 3, 0), GARDNER_PHASES - GC_WN);   // (no wrap: beside the ends of the bank the resolver computes itself)
             if (smp == 0 && half == 0) tab_alo[t & 1][sj] = a_lo;
             cand_row(t, a_lo, smp, half * (GC_WN / 2), GC_WN / 2);
             cand_row(t, a_lo, GC_T + (smp >> 2), half * (GC_WN / 2) + (smp & 3), 1);       // (rows >= GC_NR: nothing)
@@ -2646,7 +2648,11 @@ static int gardner_form(int nstreams, int prio_duty) {
 }
 static void gardner_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const float* d_bank, hipStream_t st, int c, int nsub) {
     switch (gardner_form(nstreams, coefs.g_prio_duty)) {
-        case 4: hipLaunchKernelGGL(s2_gardner_cand_kernel, dim3((nstreams + GC_CS - 1) / GC_CS), dim3(192), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
+        case 4: {
+            static const int skew = [] { const char* e = getenv("DVBS2GPU_GARDNER_CAND_SKEW"); return e ? atoi(e) : 0; }();     // (tests only)
+            hipLaunchKernelGGL(s2_gardner_cand_kernel, dim3((nstreams + GC_CS - 1) / GC_CS), dim3(192), 0, st, d_work, nstreams, coefs, d_bank, c, nsub, skew);
+            break;
+        }
         case 3: hipLaunchKernelGGL(s2_gardner_bank_kernel, dim3((nstreams + 63) / 64), dim3(128), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
         case 2: hipLaunchKernelGGL(s2_gardner2_kernel, dim3((nstreams + G_SPW - 1) / G_SPW), dim3(128), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
         default: hipLaunchKernelGGL(s2_gardner_kernel, dim3((nstreams + G_SPW - 1) / G_SPW), dim3(64), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
