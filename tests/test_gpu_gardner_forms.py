@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize('form', [1, 2, 3, 4])
 def test_chain_is_bit_identical_with_every_timing_recovery_form(form):
     env = dict(os.environ, DVBS2GPU_GARDNER_FORM=str(form))
-    sel = 'front_end_is_bit_identical or time_sliced_front_end or (demod_end_to_end_vs_oracle and (4-1-0 or 6-1-1 or 14-1-0))'
+    sel = 'front_end_is_bit_identical or time_sliced_front_end or tiny_and_empty or (demod_end_to_end_vs_oracle and (4-1-0 or 6-1-1 or 14-1-0))'
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_s2chain.py'), '-m', 'gpu', '-x', '-q', '-k', sel],
                        env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
@@ -27,7 +27,7 @@ def test_candidate_tables_fall_back_to_the_dot_products_bit_exactly(skew):
     by 4 arms the resolver is at the edge of the table and leaves it whenever the arm drifts, with 40 it computes EVERY symbol itself --
     the chain must come out bit-identical either way"""
     env = dict(os.environ, DVBS2GPU_GARDNER_FORM='4', DVBS2GPU_GARDNER_CAND_SKEW=str(skew))
-    sel = 'front_end_is_bit_identical or time_sliced_front_end or (demod_end_to_end_vs_oracle and (4-1-0 or 14-1-0))'
+    sel = 'front_end_is_bit_identical or time_sliced_front_end or tiny_and_empty or (demod_end_to_end_vs_oracle and (4-1-0 or 14-1-0))'
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_s2chain.py'), '-m', 'gpu', '-x', '-q', '-k', sel],
                        env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -131,6 +131,34 @@ def test_demod_end_to_end_vs_oracle(engine, modcod, short, pilots, esn0, nframes
     dm.close()
 
 
+@pytest.mark.gpu
+def test_tiny_and_empty_calls_equal_oracle(engine):
+    """calls of 0 .. 40 samples (time slices without a sample, periods of the timing recovery with fewer samples than a tile, calls that
+    end between the two outputs of a symbol), then ordinary ones: every tap and every output equal to the oracle's, call by call"""
+    modcod, short, pilots = 4, 1, 0
+    iq, bb, _ = orc.transmit(modcod, short, pilots, nframes=4, seed=91, esn0_db=12.0, cfo=1e-3, timing=0.3, phase0=0.1, lead_symbols=150)
+    rx = orc.OracleRx(orc.default_cfg(modcod, short, pilots, max_ldpc_trials=16))
+    dm = engine.demod(engine.default_cfg(modcod, True, False, max_ldpc_trials=16), max_samples=8192)
+    rng = np.random.default_rng(5)
+    cuts = [0]
+    while cuts[-1] < 2500:
+        cuts.append(cuts[-1] + int(rng.choice([0, 1, 2, 3, 5, 8, 15, 16, 17, 31, 33, 40])))
+    while cuts[-1] < iq.size:
+        cuts.append(min(iq.size, cuts[-1] + 7001))
+    good = 0
+    for ncall, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        part = iq[a:b]
+        o = rx.process(part)
+        g = dm.process(part)
+        for t in range(4):
+            assert same_bits(rx.tap(t), dm.tap(t)), ('tap', t, 'call', ncall, 'samples', b - a)
+        assert o.shape == g.shape and np.array_equal(o, g), ('BBFRAMEs', ncall)
+        assert np.float32(dm.nco_freq()).view(np.uint32) == np.float32(rx.L.orc_s2rx_nco_freq(rx.h)).view(np.uint32)
+        good += g.shape[0]
+    assert good >= 2
+    dm.close()
+
+
 @pytest.mark.parametrize('chunk', [3001, 777, 65536])
 def test_front_end_is_bit_identical_without_nco_feedback(engine, chunk):
     """fll_bw = 0 keeps the NCO at frequency 0: AGC, Gardner, RRC, decimator and PL sync alone, call by call, for any
