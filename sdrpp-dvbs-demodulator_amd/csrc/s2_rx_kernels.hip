@@ -132,6 +132,14 @@ __device__ __forceinline__ cf32 phasor_hw(float x) { return phasor(x); }
 #ifndef FE_PRIO
 #define FE_PRIO 2   // wave priority of the serial front-end loops (A/B switch; the decoder's parallel phases run at 0, its serial ones at 3)
 #endif
+// a uniform value stored by every lane (1) or by lane 0 behind a predicate (0): the predicate costs the single-carrier chains a taken branch
+// per sample (A/B switches)
+#ifndef FD_STORE_ALL
+#define FD_STORE_ALL 0      // (the timing recovery of a 4096-carrier bank: 128 against 133 ms per call with the predicate; one carrier is paced by the FLL)
+#endif
+#ifndef FLL_STORE_ALL
+#define FLL_STORE_ALL 1
+#endif
 constexpr int G_TILE = 64;     // samples per stream per staging tile
 constexpr int G_SPW = 8;       // streams per wave (8 lanes each)
 constexpr int G_PITCH = G_TILE + 9;   // 7 history + tile, odd pitch spreads the rows over the LDS banks
@@ -1402,7 +1410,7 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
                     for (int k = 0; k < m; ++k) {
                         const cf32 tmp_val = cmul(tl[k], phasor_fast(-pll.phase));
                         const float error = soft_phase_err_group<FL_LPS>((lds_cf32*)reinterpret_cast<const float*>(s_pts), C.states, C.amp, C.prescale, tmp_val, gl);
-                        if (gl == 0) ot[k] = tmp_val;
+                        ot[k] = tmp_val;
                         pll.advance(error);
                         pll.wrap_pi_once();
                     }
@@ -1441,7 +1449,7 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
                     block_end = i == 89;
                     o = cf32{0.f, 0.f};   // header symbols come from the PLHDR demod below
                 }
-                if (gl == 0) ot[k] = o;
+                ot[k] = o;                                // (the same value in every lane of the group)
                 pll.advance(error);
                 pll.wrap_pi_once();
                 if (co.pilot_aided && block_end) {
@@ -1936,7 +1944,7 @@ __global__ __launch_bounds__(64) void s2_vcm_loops_kernel(const S2StreamWork* __
                     block_end = i == 89;
                     o = cf32{0.f, 0.f};
                 }
-                if (lane == 0) otile[k] = o;
+                otile[k] = o;                             // (uniform value)
                 pll.advance(error);
                 pll.wrap_pi_once();
                 if (co.pilot_aided && block_end) {
@@ -2113,7 +2121,7 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
             freq = clamp_med3(freq, co.fll_min_freq, co.fll_max_freq);
             phase += freq;
             pcl_wrap_pi(phase);
-            if (lane == 0) xtile[k] = x;
+            if (FLL_STORE_ALL || lane == 0) xtile[k] = x;
             // systolic step: sums move one lane up, lane 0 starts the sum of output m + 64
             cf32 sl, sh;
             sl.re = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, al.re), 0x138, 0xf, 0xf, false));
@@ -2373,10 +2381,9 @@ __global__ __launch_bounds__(64) void dvbs_fd_kernel(const DvbsStreamWork* __res
             // the interpolated sample and, for the derivative of the signal, its neighbours in phase (complex_fd.cpp:103-120)
             cf32 outVal, fT1, fT_1;
             fd_dot3_wave(x, brow + (phase - wlo) * FD_TAPS, brow + (pp - wlo) * FD_TAPS, brow + (pm - wlo) * FD_TAPS, lane, outVal, fT1, fT_1);
-            cf32 dfdt;
-            if (phase == 0) dfdt = csub(fT1, outVal);
-            else if (phase == FD_PHASES - 1) dfdt = csub(outVal, fT_1);
-            else dfdt = cscale(csub(fT1, fT_1), 0.5f);
+            cf32 dfdt = cscale(csub(fT1, fT_1), 0.5f);
+            if (__builtin_expect(phase == 0 || phase == FD_PHASES - 1, 0))         // (one-sided at the ends of the bank: rare, out of line)
+                dfdt = phase == 0 ? csub(fT1, outVal) : csub(outVal, fT_1);
             float error = spsctr == 0 ? ((outVal.re * dfdt.re) + (outVal.im * dfdt.im)) : 0.f;
             spsctr++;
             if (spsctr >= 1) spsctr = 0;                 // outSps = 1 (qpsk_alt.cpp:22)
@@ -2385,7 +2392,7 @@ __global__ __launch_bounds__(64) void dvbs_fd_kernel(const DvbsStreamWork* __res
             const float delta = floorf(pcl.phase);
             offset = (int)((float)offset + delta);       // `offset += delta` with an int offset and a float delta
             pcl.phase -= delta;
-            if (lane == 0) ostage[nout] = outVal;       // (the Costas loop has its own kernel, below)
+            if (FD_STORE_ALL || lane == 0) ostage[nout] = outVal;       // (the Costas loop has its own kernel, below)
             ++nout;
         }
         __syncthreads();
