@@ -150,20 +150,21 @@ int get_prbs(dvbs2gpu_ctx* ctx) {
 
 namespace s2 {
 static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, int nframes, int max_trials, int force,
-                    uint8_t* d_hard, int hard_stride, int8_t* d_post, int32_t* d_trials, hipStream_t st);
-static int bch_run(dvbs2gpu_ctx* ctx, const FecParams& f, uint8_t* d_frames, int nframes, int32_t* d_corr, hipStream_t st);
+                    uint8_t* d_hard, int hard_stride, int8_t* d_post, int32_t* d_trials, hipStream_t st, FecWs& W);
+static int bch_run(dvbs2gpu_ctx* ctx, const FecParams& f, uint8_t* d_frames, int nframes, int32_t* d_corr, hipStream_t st, FecWs& W);
 
 int fec_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, int nframes, int max_trials, int force, uint8_t* d_bbframes,
-            int32_t* d_trials, int32_t* d_corr, hipStream_t st) {
+            int32_t* d_trials, int32_t* d_corr, hipStream_t st, FecWs* ws) {
+    FecWs& W = ws ? *ws : ctx->fws;
     int rc;
-    if ((rc = ctx->ws_hard.ensure((size_t)nframes * (f.K / 8)))) return rc;
-    uint8_t* hard = (uint8_t*)ctx->ws_hard.p;
+    if ((rc = W.hard.ensure((size_t)nframes * (f.K / 8)))) return rc;
+    uint8_t* hard = (uint8_t*)W.hard.p;
     {
         StageSpan sp(ctx->timers, ST_LDPC, st, nframes);
-        if ((rc = ldpc_run(ctx, f, d_llr, nframes, max_trials, force, hard, f.K / 8, nullptr, d_trials, st))) return rc;
+        if ((rc = ldpc_run(ctx, f, d_llr, nframes, max_trials, force, hard, f.K / 8, nullptr, d_trials, st, W))) return rc;
     }
     StageSpan sp(ctx->timers, ST_BCH, st, nframes);
-    if ((rc = bch_run(ctx, f, hard, nframes, d_corr, st))) return rc;
+    if ((rc = bch_run(ctx, f, hard, nframes, d_corr, st, W))) return rc;
     if ((rc = get_prbs(ctx))) return rc;
     HIP_TRY(bb_descramble_launch(hard, f.K / 8, ctx->d_prbs, f.kbch / 8, nframes, d_bbframes, st));
     return 0;
@@ -172,7 +173,7 @@ int fec_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, int nfra
 
 namespace s2 {
 static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, int nframes, int max_trials, int force,
-                    uint8_t* d_hard, int hard_stride, int8_t* d_post, int32_t* d_trials, hipStream_t st) {
+                    uint8_t* d_hard, int hard_stride, int8_t* d_post, int32_t* d_trials, hipStream_t st, FecWs& W) {
     LdpcDeviceCode* C;
     int rc = get_ldpc(ctx, f.code_index, &C);
     if (rc) return rc;
@@ -186,17 +187,17 @@ static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, 
         size_t need = (size_t)grid * ldpc_wave_msg_bytes_per_frame(*C);
         need = (need + 255) & ~(size_t)255;
         const size_t sgn_bytes = (size_t)grid * ldpc_sign_ws_bytes_per_slot();
-        if ((rc = ctx->ws_msg.ensure(need + 256 + sgn_bytes))) return rc;
+        if ((rc = W.msg.ensure(need + 256 + sgn_bytes))) return rc;
         if (!d_trials) {
-            if ((rc = ctx->ws_misc.ensure((size_t)nframes * 2 * sizeof(int32_t)))) return rc;
-            d_trials = (int32_t*)ctx->ws_misc.p;
+            if ((rc = W.misc.ensure((size_t)nframes * 2 * sizeof(int32_t)))) return rc;
+            d_trials = (int32_t*)W.misc.p;
         }
         if (!d_hard) {
-            if ((rc = ctx->ws_hard.ensure((size_t)nframes * (f.K / 8)))) return rc;
-            d_hard = (uint8_t*)ctx->ws_hard.p; hard_stride = f.K / 8;
+            if ((rc = W.hard.ensure((size_t)nframes * (f.K / 8)))) return rc;
+            d_hard = (uint8_t*)W.hard.p; hard_stride = f.K / 8;
         }
-        HIP_TRY(ldpc_wave_decode_launch(*C, d_llr, nframes, max_trials, force, d_hard, hard_stride, d_post, d_trials, (uint8_t*)ctx->ws_msg.p, grid, st,
-                                        (unsigned int*)((char*)ctx->ws_msg.p + need), (uint32_t*)((char*)ctx->ws_msg.p + need + 256)));
+        HIP_TRY(ldpc_wave_decode_launch(*C, d_llr, nframes, max_trials, force, d_hard, hard_stride, d_post, d_trials, (uint8_t*)W.msg.p, grid, st,
+                                        (unsigned int*)((char*)W.msg.p + need), (uint32_t*)((char*)W.msg.p + need + 256)));
         return 0;
     }
     // workgroups hold 2 frame slots, or 1 for batches smaller than the device (ldpc_kernel.hip)
@@ -206,30 +207,30 @@ static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, 
     size_t need = (size_t)grid * fpb * C->R * C->rec_dwords * sizeof(uint32_t);
     need = (need + 255) & ~(size_t)255;
     const size_t sgn_bytes = (size_t)grid * fpb * ldpc_sign_ws_bytes_per_slot();   // bit-packed signs for the syndrome check
-    if ((rc = ctx->ws_msg.ensure(need + 256 + sgn_bytes))) return rc;   // + the dynamic work counter + the sign scratch
+    if ((rc = W.msg.ensure(need + 256 + sgn_bytes))) return rc;   // + the dynamic work counter + the sign scratch
     if (!d_trials) {
-        if ((rc = ctx->ws_misc.ensure((size_t)nframes * 2 * sizeof(int32_t)))) return rc;
-        d_trials = (int32_t*)ctx->ws_misc.p;
+        if ((rc = W.misc.ensure((size_t)nframes * 2 * sizeof(int32_t)))) return rc;
+        d_trials = (int32_t*)W.misc.p;
     }
     if (!d_hard) {
-        if ((rc = ctx->ws_hard.ensure((size_t)nframes * (f.K / 8)))) return rc;
-        d_hard = (uint8_t*)ctx->ws_hard.p; hard_stride = f.K / 8;
+        if ((rc = W.hard.ensure((size_t)nframes * (f.K / 8)))) return rc;
+        d_hard = (uint8_t*)W.hard.p; hard_stride = f.K / 8;
     }
     HIP_TRY(ldpc_decode_launch(*C, d_llr, nframes, max_trials, force, d_hard, hard_stride, d_post, d_trials,
-                               (uint32_t*)ctx->ws_msg.p, grid, fpb, st, (unsigned int*)((char*)ctx->ws_msg.p + need),
-                               (uint32_t*)((char*)ctx->ws_msg.p + need + 256)));
+                               (uint32_t*)W.msg.p, grid, fpb, st, (unsigned int*)((char*)W.msg.p + need),
+                               (uint32_t*)((char*)W.msg.p + need + 256)));
     return 0;
 }
 }  // namespace s2
 
 namespace s2 {
-static int bch_run(dvbs2gpu_ctx* ctx, const FecParams& f, uint8_t* d_frames, int nframes, int32_t* d_corr, hipStream_t st) {
+static int bch_run(dvbs2gpu_ctx* ctx, const FecParams& f, uint8_t* d_frames, int nframes, int32_t* d_corr, hipStream_t st, FecWs& W) {
     BchDeviceCode* B;
     // GF(2^16): t = 8 and 10 use the first 2t syndromes of the same field; tables depend on (m, t) only via t rows
     int rc = get_bch(ctx, f.bch_m, f.bch_t, &B);
     if (rc) return rc;
-    if ((rc = ctx->ws_syn.ensure((size_t)nframes * 32 * sizeof(uint16_t)))) return rc;
-    uint16_t* syn = (uint16_t*)ctx->ws_syn.p;
+    if ((rc = W.syn.ensure((size_t)nframes * 32 * sizeof(uint16_t)))) return rc;
+    uint16_t* syn = (uint16_t*)W.syn.p;
     HIP_TRY(bch_syndromes_launch(*B, d_frames, f.K / 8, f.K, nframes, syn, st));
     HIP_TRY(bch_correct_launch(*B, d_frames, f.K / 8, f.K, f.kbch, nframes, syn, d_corr, st));
     return 0;
@@ -304,7 +305,7 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
     if (ctx->ev_ws) (void)hipEventDestroy(ctx->ev_ws);
     for (auto& sp : ctx->timers.pending) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : ctx->timers.pool) (void)hipEventDestroy(e);
-    ctx->ws_msg.release(); ctx->ws_hard.release(); ctx->ws_syn.release(); ctx->ws_misc.release();
+    ctx->fws.release();
     for (auto& kv : ctx->fe_aux) {
         if (kv.second.aux) (void)hipStreamDestroy(kv.second.aux);
         for (hipEvent_t e : kv.second.ev) if (e) (void)hipEventDestroy(e);
@@ -320,6 +321,8 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
         for (int k = 0; k < 2; ++k) if (ctx->ev_fec[g][k]) (void)hipEventDestroy(ctx->ev_fec[g][k]);
         if (ctx->ev_llr_grp[g]) (void)hipEventDestroy(ctx->ev_llr_grp[g]);
         if (ctx->grp_stream[g]) (void)hipStreamDestroy(ctx->grp_stream[g]);
+        if (ctx->fec_stream_grp[g]) (void)hipStreamDestroy(ctx->fec_stream_grp[g]);
+        ctx->fws_grp[g].release();
         for (auto& w : ctx->ws_grp[g]) w.release();
         for (auto& par : ctx->ws_fecbuf[g]) for (auto& w : par) w.release();
     }
@@ -448,7 +451,7 @@ int dvbs2gpu_ldpc_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, con
     if (rc) return rc;
     {
         StageSpan sp(ctx->timers, ST_LDPC, (hipStream_t)stream, nframes);
-        rc = ldpc_run(ctx, f, d_llr, nframes, max_trials, force, d_hard, f.K / 8, d_post, d_trials, (hipStream_t)stream);
+        rc = ldpc_run(ctx, f, d_llr, nframes, max_trials, force, d_hard, f.K / 8, d_post, d_trials, (hipStream_t)stream, ctx->fws);
     }
     int rc2 = ws_release(ctx, (hipStream_t)stream);
     return rc ? rc : rc2;
@@ -466,7 +469,7 @@ int dvbs2gpu_bch_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, uint
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = stage_enter(ctx, (hipStream_t)stream);
     if (rc) return rc;
-    rc = bch_run(ctx, f, d_frames, nframes, d_corrections, (hipStream_t)stream);
+    rc = bch_run(ctx, f, d_frames, nframes, d_corrections, (hipStream_t)stream, ctx->fws);
     int rc2 = ws_release(ctx, (hipStream_t)stream);
     return rc ? rc : rc2;
 }
@@ -496,7 +499,7 @@ int dvbs2gpu_fec_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, cons
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = stage_enter(ctx, (hipStream_t)stream);
     if (rc) return rc;
-    rc = fec_run(ctx, f, d_llr, nframes, max_trials, force, d_bbframes, d_trials, d_corrections, (hipStream_t)stream);
+    rc = fec_run(ctx, f, d_llr, nframes, max_trials, force, d_bbframes, d_trials, d_corrections, (hipStream_t)stream, nullptr);
     int rc2 = ws_release(ctx, (hipStream_t)stream);
     return rc ? rc : rc2;
 }

@@ -83,6 +83,9 @@ struct StageSpan {
     }
 };
 
+// the FEC stage's scratch buffers: one set per context, and one per configuration group for jobs that run side by side (s2_demod.hip)
+struct FecWs { Workspace msg, hard, syn, misc; void release() { msg.release(); hard.release(); syn.release(); misc.release(); } };
+
 struct ConstelTables {          // device tables of one constellation (type, gamma1, gamma2)
     S2ConstelDev dev;
     int8_t* d_bits = nullptr;
@@ -109,7 +112,7 @@ struct dvbs2gpu_ctx {
     std::map<int, s2::LdpcDeviceCode> ldpc;   // by code_index
     std::map<int, s2::BchDeviceCode> bch;     // by m*100 + t
     uint8_t* d_prbs = nullptr;                // BB scrambler sequence, 8100 bytes
-    s2::Workspace ws_msg, ws_hard, ws_syn, ws_misc;
+    s2::FecWs fws;                            // LDPC message records (+ work counter, sign scratch), hard decisions, BCH syndromes, trial counts
     // receive-chain tables (s2_demod.hip)
     float* d_gardner_bank = nullptr;
     s2::S2PlTablesDev pl{};
@@ -138,7 +141,11 @@ struct dvbs2gpu_ctx {
     s2::Workspace ws_grp[MAX_PIPE_GROUPS][8];
     hipStream_t grp_stream[MAX_PIPE_GROUPS] = {};
     hipEvent_t ev_llr_grp[MAX_PIPE_GROUPS] = {};
-    std::mutex fec_mtx;                                   // FEC jobs are enqueued whole, one at a time (shared FEC workspaces, one stream)
+    std::mutex fec_mtx;                                   // FEC jobs on the shared stream are enqueued whole, one at a time (shared FEC workspaces)
+    // FEC jobs too small to fill the device (a group of a 64-transponder batch: a handful of decoder workgroups, 4-6 ms of latency each) run
+    // SIDE BY SIDE instead: a FEC stream and a set of FEC workspaces per group
+    hipStream_t fec_stream_grp[MAX_PIPE_GROUPS] = {};
+    s2::FecWs fws_grp[MAX_PIPE_GROUPS];
     // time-sliced front end (s2_rx_kernels.hip, s2_frontend_launch): per main stream one auxiliary stream + the slice events
     struct FeAux { hipStream_t aux = nullptr, aux2 = nullptr; hipEvent_t ev[9] = {}, ev2[9] = {}; hipStream_t dvbs_aux[4] = {}; hipEvent_t dvbs_ev[4][s2::DVBS_FE_MAX_SLICES + 1] = {}; };   // (dvbs_*: the DVB-S receiver's stage streams: AGC, FLL, RRC, soft FIFO + Viterbi)
     std::map<hipStream_t, FeAux> fe_aux;
@@ -168,7 +175,7 @@ struct CallGuard {
     std::unique_lock<std::recursive_mutex> l;
     explicit CallGuard(dvbs2gpu_ctx* ctx) : l(ctx->call_mtx) {}
 };
-int ws_acquire(dvbs2gpu_ctx* ctx, hipStream_t st);   // before enqueuing work that uses ws_msg / ws_hard / ws_syn / ws_misc on `st`
+int ws_acquire(dvbs2gpu_ctx* ctx, hipStream_t st);   // before enqueuing work that uses the context's FEC workspaces (ctx->fws) on `st`
 int ws_release(dvbs2gpu_ctx* ctx, hipStream_t st);   // after it
 int ws_quiesce(dvbs2gpu_ctx* ctx);                   // host-side wait for the last asynchronous user (synchronous entry points)
 bool fec_jobs_pending(dvbs2gpu_ctx* ctx);
@@ -181,5 +188,5 @@ std::vector<float> make_rrc_taps(int count, double beta, double Ts);
 int get_rrc(dvbs2gpu_ctx* ctx, int ntaps, float alpha, double Ts, float** out);
 void critically_damped(float bw, float* alpha, float* beta);
 int fec_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, int nframes, int max_trials, int force, uint8_t* d_bbframes,
-            int32_t* d_trials, int32_t* d_corr, hipStream_t st);
+            int32_t* d_trials, int32_t* d_corr, hipStream_t st, FecWs* ws = nullptr);     // ws: the FEC workspaces to use (null: the context's own set)
 }  // namespace s2

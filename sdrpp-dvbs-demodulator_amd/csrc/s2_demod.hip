@@ -648,8 +648,25 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         job->d_trials = j_trials; job->d_corr = j_corr;
         const int force = d0->cfg.force_ldpc_iters > 0;
         const int mt = force ? d0->cfg.force_ldpc_iters : d0->cfg.max_ldpc_trials;
-        {
+        // A group's job that cannot fill the device (fewer decoder workgroups than half the CUs: the groups of a 64-transponder batch -- a
+        // handful of workgroups and 4-6 ms of decoder LATENCY each) runs beside the other groups' jobs, on the group's own FEC stream with the
+        // group's own FEC workspaces; big jobs queue up on the shared stream as before (two persistent decoders would only take turns)
+        const bool beside = own_ws && nf <= ctx->num_cus && !getenv("DVBS2GPU_FEC_JOBS_IN_LINE");
+        if (beside) {
+            if (!ctx->fec_stream_grp[slot]) HIP_TRY(hipStreamCreateWithFlags(&ctx->fec_stream_grp[slot], hipStreamNonBlocking));
+            hipStream_t sg = ctx->fec_stream_grp[slot];
+            HIP_TRY(hipStreamWaitEvent(sg, ev_llr, 0));
+            if ((rc = fec_run(ctx, mp.fec, (const int8_t*)ctx->ws_fecbuf[slot][par][0].p, nf, mt, force, (uint8_t*)ctx->ws_fecbuf[slot][par][1].p, j_trials, j_corr, sg,
+                              &ctx->fws_grp[slot])))
+                return rc;
+            if (!ctx->ev_fec[slot][par]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fec[slot][par], hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(ctx->ev_fec[slot][par], sg));
+            job->done = ctx->ev_fec[slot][par];
+        } else {
             std::lock_guard<std::mutex> fl(ctx->fec_mtx);
+            // (a job of this group that ran on the group's own stream last time must be through before the shared workspaces' turn: its
+            //  results are delivered by now or about to be -- the delivery waits on its event -- so this is an ordering formality)
+            if (own_ws && ctx->fec_stream_grp[slot]) HIP_TRY(hipStreamSynchronize(ctx->fec_stream_grp[slot]));
             HIP_TRY(hipStreamWaitEvent(sf, ev_llr, 0));
             if ((rc = fec_run(ctx, mp.fec, (const int8_t*)ctx->ws_fecbuf[slot][par][0].p, nf, mt, force, (uint8_t*)ctx->ws_fecbuf[slot][par][1].p, j_trials, j_corr, sf)))
                 return rc;
@@ -1036,6 +1053,7 @@ int dvbs2gpu_set_pipelined(dvbs2gpu_ctx* ctx, int on) {
     if (!on && ctx->fec_stream) {
         // frames of the last pipelined call that nobody collected are dropped (collect them with a zero-count call first)
         HIP_TRY(hipStreamSynchronize(ctx->fec_stream));
+        for (hipStream_t sg : ctx->fec_stream_grp) if (sg) HIP_TRY(hipStreamSynchronize(sg));
         for (auto& pj : ctx->pending_fec) { delete (PendingFec*)pj; pj = nullptr; }
     }
     ctx->pipeline_fec = on ? 1 : 0;
