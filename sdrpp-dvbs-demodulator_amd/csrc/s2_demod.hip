@@ -341,7 +341,8 @@ struct PendingFec {
 // AGC/NCO + timing recovery of a batch, time-sliced over the caller's stream and its auxiliary stream (ctx.h FeAux, created on first use)
 static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work, int n, const S2LoopCoefs& co, hipStream_t st, const S2PostStages* post = nullptr,
                                   bool own_post_stream = false) {
-    int nsub = ctx->fe_slices > 0 ? ctx->fe_slices : (ctx->pipeline_fec ? 4 : 8);      // (measured: beside the decoder of the previous call 4, alone 8)
+    // (measured: beside the decoder of the previous call 4, alone 8; a small bank is a latency chain in either mode: the shorter pipeline fill wins)
+    int nsub = ctx->fe_slices > 0 ? ctx->fe_slices : (ctx->pipeline_fec && n > 256 ? 4 : 8);
     if (nsub > S2_FE_MAX_SLICES) nsub = S2_FE_MAX_SLICES;
     S2LoopCoefs cc = co;
     cc.g_prio_duty = ctx->pipeline_fec ? ctx->g_prio_duty : 0;
