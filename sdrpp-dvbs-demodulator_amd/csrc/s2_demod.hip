@@ -284,6 +284,8 @@ struct dvbs2gpu_demod {
 
 namespace {
 
+constexpr int S2_SMALL_BANK = 256;       // streams up to which a batch is treated as a set of latency chains (stage pipeline always, groups of a mixed batch on their own)
+
 int demod_configure(dvbs2gpu_demod* d) {
     const dvbs2gpu_demod_cfg& c = d->cfg;
     if (!modcod_params(c.modcod, c.shortframes, c.pilots, &d->mp)) { last_error() = "unsupported MODCOD"; return DVBS2GPU_ERR_MODCOD; }
@@ -428,8 +430,9 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     // Not while the decoder of the previous call is the critical path anyway (pipelined mode, the balancer has taken the timing loop's priority
     // share to its minimum): there the stages back to back leave the decoder more of the SIMDs (headline: 390 vs 394 ms per step).
     // (stage_pipeline == 2, for the tests: every other call, whatever the mode -- the two flows leave a stream in the same state)
+    // (a small bank is a set of latency chains whatever the mode: always staged)
     const bool staged = !pre_nsym && (ctx->stage_pipeline == 2 ? (ctx->stage_calls++ & 1) != 0 :
-        ctx->stage_pipeline && !(pipelined && ctx->g_prio_auto && ctx->g_prio_duty <= ctx->stage_pipeline_min_duty));
+        ctx->stage_pipeline && (n <= S2_SMALL_BANK || !(pipelined && ctx->g_prio_auto && ctx->g_prio_duty <= ctx->stage_pipeline_min_duty)));
     Workspace& ws_pll = W[3];
     Workspace& ws_slot = W[7];
     std::vector<S2FrameStats> slot_stats;
@@ -1106,8 +1109,12 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
     if (pipe && (int)groups.size() > dvbs2gpu_ctx::MAX_PIPE_GROUPS) { last_error() = "pipelined mode handles at most 16 configuration groups per batch"; return DVBS2GPU_ERR_ARG; }
     hipStream_t st = pipe ? ctx->fe_stream : nullptr;
     // several groups with one front end: the MODCOD-independent stages run once for the whole batch
+    // (tried in round 3 for small mixed batches -- 64 transponders in 8 groups: every group running its WHOLE chain by itself, side by side, each
+    // with the stage pipeline inside.  8 groups x 4 streams do not get a hardware queue each (9 queues in all with GPU_MAX_HW_QUEUES=12): the
+    // groups' kernels queue up behind each other, 130 ms per step against 80 with the shared pass.  DVBS2GPU_MIXED_ALONE=1 selects it.)
     std::vector<int> pre_nsym;
-    bool merged = groups.size() > 1;
+    const bool small_mixed = groups.size() > 1 && n <= S2_SMALL_BANK && (int)groups.size() <= dvbs2gpu_ctx::MAX_PIPE_GROUPS && getenv("DVBS2GPU_MIXED_ALONE");
+    bool merged = groups.size() > 1 && !small_mixed;
     for (int i = 1; merged && i < n; ++i) merged = same_frontend(demods[0], demods[i]);
     if (merged) {
         int rc = frontend_prepass(ctx, demods, n, (const cf32* const*)d_iq, counts, d_out, st, &pre_nsym);
@@ -1123,7 +1130,7 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
     };
     std::list<GroupJob> jobs;
     // (synchronous calls collect each group's FEC job before they return)
-    const bool side_by_side = merged && (int)groups.size() <= dvbs2gpu_ctx::MAX_PIPE_GROUPS;
+    const bool side_by_side = (merged || small_mixed) && (int)groups.size() <= dvbs2gpu_ctx::MAX_PIPE_GROUPS;
     int group_no = 0;
     for (const std::vector<int>& idx : groups) {
         std::vector<dvbs2gpu_demod*> g;
@@ -1159,22 +1166,22 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
         for (GroupJob& J : jobs) {
             if (&J == &jobs.back()) break;            // (the last group runs on the calling thread, below)
             try {
-                th.emplace_back([&J, ctx, out_cap, pipe]() {
+                th.emplace_back([&J, ctx, out_cap, pipe, merged]() {
                     if (hipSetDevice(ctx->device) != hipSuccess) { J.rc = DVBS2GPU_ERR_HIP; J.err = "hipSetDevice"; return; }
                     J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
-                                         ctx->grp_stream[J.slot], true, J.slot, J.gn.data(), true, !pipe);
+                                         ctx->grp_stream[J.slot], true, J.slot, merged ? J.gn.data() : nullptr, true, !pipe);
                     if (J.rc) J.err = last_error();
                 });
             } catch (...) {                           // no thread to be had: run the group here (no exception leaves the C ABI)
                 J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
-                                     ctx->grp_stream[J.slot], true, J.slot, J.gn.data(), true, !pipe);
+                                     ctx->grp_stream[J.slot], true, J.slot, merged ? J.gn.data() : nullptr, true, !pipe);
                 if (J.rc) J.err = last_error();
             }
         }
         {
             GroupJob& J = jobs.back();
             J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
-                                 ctx->grp_stream[J.slot], true, J.slot, J.gn.data(), true, !pipe);
+                                 ctx->grp_stream[J.slot], true, J.slot, merged ? J.gn.data() : nullptr, true, !pipe);
             if (J.rc) J.err = last_error();
         }
         for (auto& t : th) t.join();
