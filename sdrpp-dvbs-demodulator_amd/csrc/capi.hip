@@ -321,7 +321,6 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
         for (int k = 0; k < 2; ++k) if (ctx->ev_fec[g][k]) (void)hipEventDestroy(ctx->ev_fec[g][k]);
         if (ctx->ev_llr_grp[g]) (void)hipEventDestroy(ctx->ev_llr_grp[g]);
         if (ctx->grp_stream[g]) (void)hipStreamDestroy(ctx->grp_stream[g]);
-        if (ctx->fec_stream_grp[g]) (void)hipStreamDestroy(ctx->fec_stream_grp[g]);
         ctx->fws_grp[g].release();
         for (auto& w : ctx->ws_grp[g]) w.release();
         for (auto& par : ctx->ws_fecbuf[g]) for (auto& w : par) w.release();

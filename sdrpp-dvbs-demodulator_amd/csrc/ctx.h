@@ -143,8 +143,7 @@ struct dvbs2gpu_ctx {
     hipEvent_t ev_llr_grp[MAX_PIPE_GROUPS] = {};
     std::mutex fec_mtx;                                   // FEC jobs on the shared stream are enqueued whole, one at a time (shared FEC workspaces)
     // FEC jobs too small to fill the device (a group of a 64-transponder batch: a handful of decoder workgroups, 4-6 ms of latency each) run
-    // SIDE BY SIDE instead: a FEC stream and a set of FEC workspaces per group
-    hipStream_t fec_stream_grp[MAX_PIPE_GROUPS] = {};
+    // SIDE BY SIDE instead: on the group's own stream (grp_stream) with a set of FEC workspaces per group
     s2::FecWs fws_grp[MAX_PIPE_GROUPS];
     // time-sliced front end (s2_rx_kernels.hip, s2_frontend_launch): per main stream one auxiliary stream + the slice events
     struct FeAux { hipStream_t aux = nullptr, aux2 = nullptr; hipEvent_t ev[9] = {}, ev2[9] = {}; hipStream_t dvbs_aux[4] = {}; hipEvent_t dvbs_ev[4][s2::DVBS_FE_MAX_SLICES + 1] = {}; };   // (dvbs_*: the DVB-S receiver's stage streams: AGC, FLL, RRC, soft FIFO + Viterbi)

@@ -637,6 +637,15 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     // launch with no host in between (delivered first, a headline step left the FEC stream idle for ~5 ms: the scatter, its copies and the
     // synchronisation of the delivery).  The two jobs use the two halves of the double-buffered FEC workspaces and an event each.
     std::unique_ptr<PendingFec> started;
+    // (a small job that runs on the group's own stream -- see below -- goes behind the previous job's delivery instead: that delivery ends with a
+    //  synchronisation of this very stream)
+    const bool beside = own_ws && st && nf <= ctx->num_cus && !getenv("DVBS2GPU_FEC_JOBS_IN_LINE");
+    bool prev_delivered = false;
+    if (beside && prev) {
+        if ((rc = deliver(prev))) return rc;
+        hm.mark("prev_delivered");
+        prev_delivered = true;
+    }
     if (nf > 0) {
         const int par = ctx->fec_parity[slot];
         Workspace& wj = ctx->ws_fecbuf[slot][par][2];
@@ -653,24 +662,19 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         const int force = d0->cfg.force_ldpc_iters > 0;
         const int mt = force ? d0->cfg.force_ldpc_iters : d0->cfg.max_ldpc_trials;
         // A group's job that cannot fill the device (fewer decoder workgroups than half the CUs: the groups of a 64-transponder batch -- a
-        // handful of workgroups and 4-6 ms of decoder LATENCY each) runs beside the other groups' jobs, on the group's own FEC stream with the
-        // group's own FEC workspaces; big jobs queue up on the shared stream as before (two persistent decoders would only take turns)
-        const bool beside = own_ws && nf <= ctx->num_cus && !getenv("DVBS2GPU_FEC_JOBS_IN_LINE");
+        // handful of workgroups and 4-6 ms of decoder LATENCY each) runs beside the other groups' jobs: on the GROUP's stream, behind its
+        // demapper, with the group's own FEC workspaces (the group's next call enqueues its stages a whole front-end pass later, so nothing
+        // waits behind the job; more streams would only share the few hardware queues).  Big jobs queue up on the shared FEC stream as
+        // before (two persistent decoders would only take turns).
         if (beside) {
-            if (!ctx->fec_stream_grp[slot]) HIP_TRY(hipStreamCreateWithFlags(&ctx->fec_stream_grp[slot], hipStreamNonBlocking));
-            hipStream_t sg = ctx->fec_stream_grp[slot];
-            HIP_TRY(hipStreamWaitEvent(sg, ev_llr, 0));
-            if ((rc = fec_run(ctx, mp.fec, (const int8_t*)ctx->ws_fecbuf[slot][par][0].p, nf, mt, force, (uint8_t*)ctx->ws_fecbuf[slot][par][1].p, j_trials, j_corr, sg,
+            if ((rc = fec_run(ctx, mp.fec, (const int8_t*)ctx->ws_fecbuf[slot][par][0].p, nf, mt, force, (uint8_t*)ctx->ws_fecbuf[slot][par][1].p, j_trials, j_corr, st,
                               &ctx->fws_grp[slot])))
                 return rc;
             if (!ctx->ev_fec[slot][par]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fec[slot][par], hipEventDisableTiming));
-            HIP_TRY(hipEventRecord(ctx->ev_fec[slot][par], sg));
+            HIP_TRY(hipEventRecord(ctx->ev_fec[slot][par], st));
             job->done = ctx->ev_fec[slot][par];
         } else {
             std::lock_guard<std::mutex> fl(ctx->fec_mtx);
-            // (a job of this group that ran on the group's own stream last time must be through before the shared workspaces' turn: its
-            //  results are delivered by now or about to be -- the delivery waits on its event -- so this is an ordering formality)
-            if (own_ws && ctx->fec_stream_grp[slot]) HIP_TRY(hipStreamSynchronize(ctx->fec_stream_grp[slot]));
             HIP_TRY(hipStreamWaitEvent(sf, ev_llr, 0));
             if ((rc = fec_run(ctx, mp.fec, (const int8_t*)ctx->ws_fecbuf[slot][par][0].p, nf, mt, force, (uint8_t*)ctx->ws_fecbuf[slot][par][1].p, j_trials, j_corr, sf)))
                 return rc;
@@ -682,7 +686,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         hm.mark("fec_enqueued");
         started = std::move(job);
     }
-    if (prev) {
+    if (prev && !prev_delivered) {
         const auto t_d0 = std::chrono::steady_clock::now();
         if ((rc = deliver(prev))) return rc;      // FEC of the previous call (ran during this call's front end)
         hm.mark("prev_delivered");
@@ -701,7 +705,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
                 ctx->g_prio_trend = verdict;
             }
         }
-    } else {
+    } else if (!prev) {
         for (int i = 0; i < n; ++i) dm[i]->stats.clear();
     }
     if (started) {
@@ -1057,7 +1061,7 @@ int dvbs2gpu_set_pipelined(dvbs2gpu_ctx* ctx, int on) {
     if (!on && ctx->fec_stream) {
         // frames of the last pipelined call that nobody collected are dropped (collect them with a zero-count call first)
         HIP_TRY(hipStreamSynchronize(ctx->fec_stream));
-        for (hipStream_t sg : ctx->fec_stream_grp) if (sg) HIP_TRY(hipStreamSynchronize(sg));
+        for (hipStream_t sg : ctx->grp_stream) if (sg) HIP_TRY(hipStreamSynchronize(sg));      // (small jobs of mixed batches run on their group's stream)
         for (auto& pj : ctx->pending_fec) { delete (PendingFec*)pj; pj = nullptr; }
     }
     ctx->pipeline_fec = on ? 1 : 0;
@@ -1158,6 +1162,26 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
         // the MODCOD-dependent stages (PL sync, frame loops, demapper, FEC hand-over, delivery) of the groups are independent and
         // latency-bound: one host thread and HIP stream per group (the pre-pass above has completed; every group ends synchronised)
         if (!ctx->fec_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->fec_stream, hipStreamNonBlocking));
+        // The groups' streams only run side by side while each has a hardware queue to itself (HIP maps streams onto GPU_MAX_HW_QUEUES
+        // queues -- 4 by default -- and a stream created when all are taken shares one: 64 x 4 PLFRAMEs cost 75 ms per step with a queue per
+        // group, 110 with four queues).  Auxiliary streams other flows of this context left behind (time-sliced front ends on other main
+        // streams, the DVB-S receiver's stage streams) are idle now -- one call at a time per context -- and given back first.
+        bool need_streams = false;
+        for (GroupJob& J : jobs) need_streams = need_streams || !ctx->grp_stream[J.slot];
+        if (need_streams) {
+            std::lock_guard<std::mutex> l(ctx->mtx);
+            for (auto it = ctx->fe_aux.begin(); it != ctx->fe_aux.end();) {
+                if (it->first == st) { ++it; continue; }
+                dvbs2gpu_ctx::FeAux& a = it->second;
+                if (a.aux) (void)hipStreamDestroy(a.aux);
+                if (a.aux2) (void)hipStreamDestroy(a.aux2);
+                for (hipEvent_t e : a.ev) if (e) (void)hipEventDestroy(e);
+                for (hipEvent_t e : a.ev2) if (e) (void)hipEventDestroy(e);
+                for (hipStream_t d : a.dvbs_aux) if (d) (void)hipStreamDestroy(d);
+                for (auto& row : a.dvbs_ev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
+                it = ctx->fe_aux.erase(it);
+            }
+        }
         for (GroupJob& J : jobs) {
             if (!ctx->grp_stream[J.slot]) HIP_TRY(hipStreamCreateWithFlags(&ctx->grp_stream[J.slot], hipStreamNonBlocking));
             if (!ctx->ev_llr_grp[J.slot]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_llr_grp[J.slot], hipEventDisableTiming));
