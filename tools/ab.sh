@@ -3,7 +3,7 @@
 # is compiled and linked under /tmp (the in-tree library and objects are never touched) and loaded through DVBS2GPU_LIB.
 #   gpurun -- bash tools/ab.sh s2_rx_kernels "-DGB_PRIO=0" "-DGB_PRIO=1 -DGB_T_N=8"        (STEPS=6 BENCH_ARGS="..." optional)
 #   MODE=ldpc: time the LDPC kernel alone (tools/ldpc_sweep.py, RATES=...) instead of the bench; MODE=cmd CMD="...": any command
-set -e
+set -e  # (a variant that does not compile ends the run)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.."; pwd)}
 SRC=$R/sdrpp-dvbs-demodulator_amd/csrc
 F=$1; shift
