@@ -1281,6 +1281,10 @@ __device__ __attribute__((noinline)) float soft_phase_err_group(lds_cf32* __rest
 #endif
 constexpr int FL_LPS = FL_LPS_N;
 constexpr int FL_SPW = 64 / FL_LPS;
+#ifndef FL_SMALL_BANK
+#define FL_SMALL_BANK 64
+#endif
+static inline int frame_loops_spw(int nstreams) { return nstreams <= FL_SMALL_BANK ? 1 : FL_SPW; }      // streams per workgroup of s2_frame_loops_kernel
 constexpr int FL_TILE = 46;          // PLL symbols staged per round (>= 36: the FED reuses the tile for a pilot block; input + output
                                      // tile together hold the 90 header symbols for the PLHDR loop and the 88 FED terms); small: THREE
                                      // workgroups have to fit into the 24 KB of LDS an LDPC workgroup leaves free -- a mixed batch launches
@@ -1291,7 +1295,9 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
                                                             const S2FrameRef* __restrict__ frames, const int* __restrict__ first,
                                                             S2LoopCoefs co, S2PlTablesDev T, S2ConstelDev C, int pls_code, int slots,
                                                             int pilots, int pilot_blocks, int plframe, cf32* __restrict__ pllout,
-                                                            S2FrameStats* __restrict__ stats, const S2VcmFound* __restrict__ found, int maxf) {
+                                                            S2FrameStats* __restrict__ stats, const S2VcmFound* __restrict__ found, int maxf, int spw) {
+    // spw: streams per workgroup, 1 .. FL_SPW.  A small bank gets a workgroup (and with it a CU's vector L1 for its phase-error table lookups)
+    // per stream: 64 streams x 1 frame 6.1 -> 5.x ms; the lane groups without a stream shadow the others' code path as usual
     // found != nullptr (stage pipeline): no pooled frame table -- frame k of stream s is slot s * maxf + k of found / pllout / stats, and
     // this launch goes through the frames the PL-sync walk has found (walk_nf) beyond those an earlier slice's launch did (loops_done)
     static_assert(2 * FL_TILE >= 90 && 2 * FL_TILE >= 88 && FL_TILE >= 36, "input + output tile hold the 90 header symbols; the output tile alone the 88 FED terms");
@@ -1303,8 +1309,8 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
     cf32* const tl = &tiles[g][0];                      // input tile (also a 36-symbol pilot block for the FED; with the output tile: the 90 header symbols)
     cf32* const ot = &tiles[g][FL_TILE];                // output tile
     float* const fd = reinterpret_cast<float*>(ot);     // FED terms live in the (then unused) output tile
-    const int s0 = blockIdx.x * FL_SPW, s = s0 + g;
-    const bool act = s < nstreams;
+    const int s0 = blockIdx.x * spw, s = s0 + g;
+    const bool act = g < spw && s < nstreams;
     const int sc = act ? s : s0;
     S2StreamState* st = work[sc].st;
     PclDev pll{co.pll_alpha, co.pll_beta, st->pll_phase, st->pll_freq, co.pll_min_freq, co.pll_max_freq};
@@ -2626,9 +2632,10 @@ static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, c
     const int L = p.loops_launches < 1 ? 1 : (p.loops_launches > nsub ? nsub : p.loops_launches);
     if ((c + 1) * L / nsub > c * L / nsub) {
         if (p.spans) p.spans->begin(3, s);
-        hipLaunchKernelGGL(s2_frame_loops_kernel, dim3((nstreams + FL_SPW - 1) / FL_SPW), dim3(64), 0, s, d_work, nstreams, (const S2FrameRef*)nullptr,
+        const int spw = frame_loops_spw(nstreams);
+        hipLaunchKernelGGL(s2_frame_loops_kernel, dim3((nstreams + spw - 1) / spw), dim3(64), 0, s, d_work, nstreams, (const S2FrameRef*)nullptr,
                            (const int*)nullptr, coefs, p.tabs, p.con, p.pls_code, p.slots, p.pilots, p.pilot_blocks, p.raw, p.d_pllout, p.d_stats,
-                           (const S2VcmFound*)p.d_found, p.maxf);
+                           (const S2VcmFound*)p.d_found, p.maxf, spw);
         if (p.spans) p.spans->end(3, s);
     }
     return hipGetLastError();
@@ -2719,8 +2726,9 @@ hipError_t s2_rrc_decim_launch(const S2StreamWork* d_work, int nstreams, int max
 hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const S2FrameRef* d_frames, const int* d_first,
                                  S2LoopCoefs coefs, S2PlTablesDev tabs, S2ConstelDev con, int pls_code, int slots, int pilots,
                                  int pilot_blocks, int plframe, cf32* d_pllout, S2FrameStats* d_stats, hipStream_t st) {
-    hipLaunchKernelGGL(s2_frame_loops_kernel, dim3((nstreams + FL_SPW - 1) / FL_SPW), dim3(64), 0, st, d_work, nstreams, d_frames, d_first, coefs,
-                       tabs, con, pls_code, slots, pilots, pilot_blocks, plframe, d_pllout, d_stats, (const S2VcmFound*)nullptr, 0);
+    const int spw = frame_loops_spw(nstreams);
+    hipLaunchKernelGGL(s2_frame_loops_kernel, dim3((nstreams + spw - 1) / spw), dim3(64), 0, st, d_work, nstreams, d_frames, d_first, coefs,
+                       tabs, con, pls_code, slots, pilots, pilot_blocks, plframe, d_pllout, d_stats, (const S2VcmFound*)nullptr, 0, spw);
     return hipGetLastError();
 }
 hipError_t s2_ccm_walk_launch(const S2StreamWork* d_work, int nstreams, int raw, int maxf, S2VcmFound* d_found, int* d_counts, hipStream_t st) {
