@@ -146,7 +146,7 @@ struct dvbs2gpu_ctx {
     // SIDE BY SIDE instead: on the group's own stream (grp_stream) with a set of FEC workspaces per group
     s2::FecWs fws_grp[MAX_PIPE_GROUPS];
     // time-sliced front end (s2_rx_kernels.hip, s2_frontend_launch): per main stream one auxiliary stream + the slice events
-    struct FeAux { hipStream_t aux = nullptr, aux2 = nullptr; hipEvent_t ev[9] = {}, ev2[9] = {}; hipStream_t dvbs_aux[4] = {}; hipEvent_t dvbs_ev[4][s2::DVBS_FE_MAX_SLICES + 1] = {}; };   // (dvbs_*: the DVB-S receiver's stage streams: AGC, FLL, RRC, soft FIFO + Viterbi)
+    struct FeAux { hipStream_t aux = nullptr, aux2 = nullptr; hipEvent_t ev[s2::S2_FE_MAX_SLICES + 1] = {}, ev2[s2::S2_FE_MAX_SLICES + 1] = {}; hipStream_t dvbs_aux[4] = {}; hipEvent_t dvbs_ev[4][s2::DVBS_FE_MAX_SLICES + 1] = {}; };   // (dvbs_*: the DVB-S receiver's stage streams: AGC, FLL, RRC, soft FIFO + Viterbi)
     std::map<hipStream_t, FeAux> fe_aux;
     int stage_pipeline_launches = 0;          // DVBS2GPU_STAGE_LOOPS: frame-loop launches per call (0 = chosen per call, s2_demod.hip)
     int stage_pipeline_min_duty = 2;          // DVBS2GPU_STAGE_MIN_DUTY: pipelined mode uses the stage pipeline only above this balancer setting (-1: always).
