@@ -342,11 +342,12 @@ struct PendingFec {
 // development aid: DVBS2GPU_HOST_TIMING=1 prints where the HOST spends a call (ms since entry at each mark)
 // AGC/NCO + timing recovery of a batch, time-sliced over the caller's stream and its auxiliary stream (ctx.h FeAux, created on first use)
 static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work, int n, const S2LoopCoefs& co, hipStream_t st, const S2PostStages* post = nullptr,
-                                  bool own_post_stream = false) {
+                                  bool own_post_stream = false, int* nsub_out = nullptr) {
     // (measured: beside the decoder of the previous call 4, alone 8; a small bank is a latency chain in either mode: the shorter pipeline fill wins)
     // (banks up to 256 streams: 16 -- one 8PSK stream 32.4 -> 31.6 ms per 4-frame call, 64 x 1 frame 16.1 -> 15.7)
     int nsub = ctx->fe_slices > 0 ? ctx->fe_slices : (n <= 256 ? 16 : (ctx->pipeline_fec ? 4 : 8));
     if (nsub > S2_FE_MAX_SLICES) nsub = S2_FE_MAX_SLICES;
+    if (nsub_out) *nsub_out = nsub > 1 ? nsub : 1;
     S2LoopCoefs cc = co;
     cc.g_prio_duty = ctx->pipeline_fec ? ctx->g_prio_duty : 0;
     dvbs2gpu_ctx::FeAux* fa = nullptr;
@@ -383,8 +384,12 @@ struct HostMarks {
     ~HostMarks() { if (on) fprintf(stderr, "[dvbs2gpu host]%s\n", line.c_str()); }
 };
 
+// a shared front-end pass of a mixed batch that is still running: slice c (AGC, timing recovery, RRC) is through when ev[c] has happened
+struct PreSlices { const hipEvent_t* ev; int nsub; };
+
 int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts,
-                  uint8_t* const* d_out, int out_cap, int* out_bytes, hipStream_t st, bool pipelined, int slot, const int* pre_nsym, bool own_ws, bool deliver_now) {
+                  uint8_t* const* d_out, int out_cap, int* out_bytes, hipStream_t st, bool pipelined, int slot, const int* pre_nsym, bool own_ws, bool deliver_now,
+                  const PreSlices* pre = nullptr) {
     HostMarks hm;
     const auto t_entry = std::chrono::steady_clock::now();
     dvbs2gpu_demod* d0 = dm[0];
@@ -432,7 +437,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     // share to its minimum): there the stages back to back leave the decoder more of the SIMDs (headline: 390 vs 394 ms per step).
     // (stage_pipeline == 2, for the tests: every other call, whatever the mode -- the two flows leave a stream in the same state)
     // (a small bank is a set of latency chains whatever the mode: always staged)
-    const bool staged = !pre_nsym && (ctx->stage_pipeline == 2 ? (ctx->stage_calls++ & 1) != 0 :
+    const bool staged = pre ? true : !pre_nsym && (ctx->stage_pipeline == 2 ? (ctx->stage_calls++ & 1) != 0 :
         ctx->stage_pipeline && (n <= S2_SMALL_BANK || !(pipelined && ctx->g_prio_auto && ctx->g_prio_duty <= ctx->stage_pipeline_min_duty)));
     Workspace& ws_pll = W[3];
     Workspace& ws_slot = W[7];
@@ -453,6 +458,17 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         if (ctx->stage_pipeline_launches > 0) launches = ctx->stage_pipeline_launches;
         S2PostStages post{d_taps, d0->cfg.rrc_taps, max_count + max_count / 32 + 8, raw, maxf, d_found, d_counts, ctx->pl, CT->dev, d0->pls_code,
                           mp.slots, mp.pilots, mp.pilot_blocks, (cf32*)ws_pll.p, (S2FrameStats*)ws_slot.p, ctx->timers.on ? &spans : nullptr, launches};
+        if (pre) {
+            // the shared pass (frontend_prepass) is running on its own streams: this group's PL-sync walk and frame loops go behind every one of
+            // its slices, on the group's stream
+            post.parts = 2;
+            S2LoopCoefs lc = d0->co;
+            lc.g_prio_duty = pipelined ? ctx->g_prio_duty : 0;
+            for (int c = 0; c < pre->nsub; ++c) {
+                HIP_TRY(hipStreamWaitEvent(st, pre->ev[c], 0));
+                HIP_TRY(s2_post_stages_launch(d_work, n, lc, post, c, pre->nsub, st));
+            }
+        } else
         { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st, &post, ctx->stage_post_stream == 2 || (!pipelined && ctx->stage_post_stream))); }
         slot_stats.resize(nslot);
         HIP_TRY(hipMemcpyAsync(slot_stats.data(), ws_slot.p, sizeof(S2FrameStats) * nslot, hipMemcpyDeviceToHost, st));
@@ -930,8 +946,10 @@ int process_vcm_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const
 // AGC, NCO, Gardner, RRC + decimation do not depend on the MODCOD: for a batch of several configuration groups whose loop
 // coefficients and matched filter agree they run ONCE over all streams (these kernels are latency-bound: eight groups of 512
 // streams cost eight times one group of 4096).  Leaves the symbols in the streams' FIFOs exactly as process_group would.
+// slices != nullptr: the pass is left RUNNING -- its RRC stage goes behind every timing-recovery slice and ctx->ev_pre[c] marks slice c;
+// the groups hang their own stages on those events (process_group with `pre`) and the call ends when they have
 int frontend_prepass(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts, uint8_t* const* d_out,
-                     hipStream_t st, std::vector<int>* nsym_out) {
+                     hipStream_t st, std::vector<int>* nsym_out, PreSlices* slices = nullptr) {
     int rc;
     if ((rc = get_rx_tables(ctx))) return rc;
     dvbs2gpu_demod* d0 = dm[0];
@@ -953,6 +971,18 @@ int frontend_prepass(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const 
     int* d_nsym = (int*)((char*)ws.p + sizeof(S2StreamWork) * n);
     float* d_nco = (float*)(d_nsym + n);
     HIP_TRY(hipMemcpyAsync(d_work, work.data(), sizeof(S2StreamWork) * n, hipMemcpyHostToDevice, st));
+    if (slices) {
+        for (hipEvent_t& e : ctx->ev_pre) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        S2PostStages post{};
+        post.d_taps = d_taps; post.ntaps = d0->cfg.rrc_taps; post.max_count = max_count + max_count / 32 + 8;
+        post.parts = 1; post.slice_done = ctx->ev_pre; post.loops_launches = 1;
+        int nsub = 1;
+        // (the work table is copied from pageable memory: staged by the runtime before hipMemcpyAsync returns)
+        { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st, &post, false, &nsub)); }
+        slices->ev = ctx->ev_pre; slices->nsub = nsub;
+        nsym_out->assign(n, 0);
+        return 0;
+    }
     { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st)); }
     { StageSpan sp(ctx->timers, ST_RRC, st); HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st)); }
     nsym_out->assign(n, 0);
@@ -1121,8 +1151,12 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
     const bool small_mixed = groups.size() > 1 && n <= S2_SMALL_BANK && (int)groups.size() <= dvbs2gpu_ctx::MAX_PIPE_GROUPS && getenv("DVBS2GPU_MIXED_ALONE");
     bool merged = groups.size() > 1 && !small_mixed;
     for (int i = 1; merged && i < n; ++i) merged = same_frontend(demods[0], demods[i]);
+    // a small merged batch: the pass stays running and every group's walk + frame loops follow it slice by slice; a GPU-filling batch gains
+    // nothing from it (its loops fill the device whenever they run)
+    PreSlices pre_slices{nullptr, 0};
+    const bool pre_async = merged && n <= S2_SMALL_BANK && (int)groups.size() <= dvbs2gpu_ctx::MAX_PIPE_GROUPS && ctx->stage_pipeline == 1 && !getenv("DVBS2GPU_MIXED_PREPASS_SYNC");
     if (merged) {
-        int rc = frontend_prepass(ctx, demods, n, (const cf32* const*)d_iq, counts, d_out, st, &pre_nsym);
+        int rc = frontend_prepass(ctx, demods, n, (const cf32* const*)d_iq, counts, d_out, st, &pre_nsym, pre_async ? &pre_slices : nullptr);
         if (rc) return rc;
     }
     struct GroupJob {
@@ -1191,22 +1225,22 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
         for (GroupJob& J : jobs) {
             if (&J == &jobs.back()) break;            // (the last group runs on the calling thread, below)
             try {
-                th.emplace_back([&J, ctx, out_cap, pipe, merged]() {
+                th.emplace_back([&J, ctx, out_cap, pipe, merged, pre_async, &pre_slices]() {
                     if (hipSetDevice(ctx->device) != hipSuccess) { J.rc = DVBS2GPU_ERR_HIP; J.err = "hipSetDevice"; return; }
                     J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
-                                         ctx->grp_stream[J.slot], true, J.slot, merged ? J.gn.data() : nullptr, true, !pipe);
+                                         ctx->grp_stream[J.slot], true, J.slot, (merged && !pre_async) ? J.gn.data() : nullptr, true, !pipe, pre_async ? &pre_slices : nullptr);
                     if (J.rc) J.err = last_error();
                 });
             } catch (...) {                           // no thread to be had: run the group here (no exception leaves the C ABI)
                 J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
-                                     ctx->grp_stream[J.slot], true, J.slot, merged ? J.gn.data() : nullptr, true, !pipe);
+                                     ctx->grp_stream[J.slot], true, J.slot, (merged && !pre_async) ? J.gn.data() : nullptr, true, !pipe, pre_async ? &pre_slices : nullptr);
                 if (J.rc) J.err = last_error();
             }
         }
         {
             GroupJob& J = jobs.back();
             J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
-                                 ctx->grp_stream[J.slot], true, J.slot, merged ? J.gn.data() : nullptr, true, !pipe);
+                                 ctx->grp_stream[J.slot], true, J.slot, (merged && !pre_async) ? J.gn.data() : nullptr, true, !pipe, pre_async ? &pre_slices : nullptr);
             if (J.rc) J.err = last_error();
         }
         for (auto& t : th) t.join();

@@ -2621,24 +2621,33 @@ hipError_t dvbs_soft_compact_launch(const DvbsStreamWork* d_work, int nstreams, 
 // so far, while the timing loop works on the next slice.  No host in between: frames stay in per-stream slots (S2PostStages), the host reads
 // the frame tables once, after the last slice.  ev2: nsub + 1 more events (timing recovery of slice c done; the last: post stages done).
 static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const S2PostStages& p, int c, int nsub, hipStream_t s) {
-    int gx = ((p.max_count / nsub) / 2 + 2 + 255) / 256;
-    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
-    if (p.spans) p.spans->begin(1, s);
-    hipLaunchKernelGGL(s2_rrc_decim_kernel, dim3(gx, nstreams), dim3(256), 0, s, d_work, p.d_taps, p.ntaps, c, nsub);
-    if (c == nsub - 1) hipLaunchKernelGGL(s2_rrc_state_kernel, dim3(nstreams), dim3(128), 0, s, d_work, p.ntaps);
-    if (p.spans) { p.spans->end(1, s); p.spans->begin(2, s); }
-    hipLaunchKernelGGL(s2_ccm_walk_kernel, dim3(nstreams), dim3(256), 0, s, d_work, p.raw, p.maxf, p.d_found, p.d_counts, c, nsub);
-    if (p.spans) p.spans->end(2, s);
-    const int L = p.loops_launches < 1 ? 1 : (p.loops_launches > nsub ? nsub : p.loops_launches);
-    if ((c + 1) * L / nsub > c * L / nsub) {
-        if (p.spans) p.spans->begin(3, s);
-        const int spw = frame_loops_spw(nstreams);
-        hipLaunchKernelGGL(s2_frame_loops_kernel, dim3((nstreams + spw - 1) / spw), dim3(64), 0, s, d_work, nstreams, (const S2FrameRef*)nullptr,
-                           (const int*)nullptr, coefs, p.tabs, p.con, p.pls_code, p.slots, p.pilots, p.pilot_blocks, p.raw, p.d_pllout, p.d_stats,
-                           (const S2VcmFound*)p.d_found, p.maxf, spw);
-        if (p.spans) p.spans->end(3, s);
+    if (p.parts & 1) {
+        int gx = ((p.max_count / nsub) / 2 + 2 + 255) / 256;
+        gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+        if (p.spans) p.spans->begin(1, s);
+        hipLaunchKernelGGL(s2_rrc_decim_kernel, dim3(gx, nstreams), dim3(256), 0, s, d_work, p.d_taps, p.ntaps, c, nsub);
+        if (c == nsub - 1) hipLaunchKernelGGL(s2_rrc_state_kernel, dim3(nstreams), dim3(128), 0, s, d_work, p.ntaps);
+        if (p.spans) p.spans->end(1, s);
     }
+    if (p.parts & 2) {
+        if (p.spans) p.spans->begin(2, s);
+        hipLaunchKernelGGL(s2_ccm_walk_kernel, dim3(nstreams), dim3(256), 0, s, d_work, p.raw, p.maxf, p.d_found, p.d_counts, c, nsub);
+        if (p.spans) p.spans->end(2, s);
+        const int L = p.loops_launches < 1 ? 1 : (p.loops_launches > nsub ? nsub : p.loops_launches);
+        if ((c + 1) * L / nsub > c * L / nsub) {
+            if (p.spans) p.spans->begin(3, s);
+            const int spw = frame_loops_spw(nstreams);
+            hipLaunchKernelGGL(s2_frame_loops_kernel, dim3((nstreams + spw - 1) / spw), dim3(64), 0, s, d_work, nstreams, (const S2FrameRef*)nullptr,
+                               (const int*)nullptr, coefs, p.tabs, p.con, p.pls_code, p.slots, p.pilots, p.pilot_blocks, p.raw, p.d_pllout, p.d_stats,
+                               (const S2VcmFound*)p.d_found, p.maxf, spw);
+            if (p.spans) p.spans->end(3, s);
+        }
+    }
+    if (p.slice_done) { hipError_t e = hipEventRecord(p.slice_done[c], s); if (e != hipSuccess) return e; }
     return hipGetLastError();
+}
+hipError_t s2_post_stages_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const S2PostStages& p, int c, int nsub, hipStream_t s) {
+    return post_stages_launch(d_work, nstreams, coefs, p, c, nsub, s);
 }
 // Four forms of the timing recovery, all bit-identical (tests/test_gpu_gardner_forms.py runs every one): 1 = one wave, 8 lanes per stream
 // (s2_gardner_kernel); 2 = resolver + producer waves, 8 lanes per stream (s2_gardner2_kernel); 3 = lane per stream (s2_gardner_bank_kernel:
