@@ -1154,7 +1154,8 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
     // a small merged batch: the pass stays running and every group's walk + frame loops follow it slice by slice; a GPU-filling batch gains
     // nothing from it (its loops fill the device whenever they run)
     PreSlices pre_slices{nullptr, 0};
-    const bool pre_async = merged && n <= S2_SMALL_BANK && (int)groups.size() <= dvbs2gpu_ctx::MAX_PIPE_GROUPS && ctx->stage_pipeline == 1 && !getenv("DVBS2GPU_MIXED_PREPASS_SYNC");
+    static const int pre_async_max = [] { const char* e = getenv("DVBS2GPU_MIXED_PREPASS_ASYNC_MAX"); return e ? atoi(e) : S2_SMALL_BANK; }();     // (0: never)
+    const bool pre_async = merged && n <= pre_async_max && (int)groups.size() <= dvbs2gpu_ctx::MAX_PIPE_GROUPS && ctx->stage_pipeline == 1;
     if (merged) {
         int rc = frontend_prepass(ctx, demods, n, (const cf32* const*)d_iq, counts, d_out, st, &pre_nsym, pre_async ? &pre_slices : nullptr);
         if (rc) return rc;
