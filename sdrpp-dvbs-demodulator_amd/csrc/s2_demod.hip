@@ -266,6 +266,7 @@ struct dvbs2gpu_demod {
     cf32* d_in = nullptr;        // staging for the host-pointer entry point
     cf32* d_fe = nullptr;        // timing-recovery output + scratch
     cf32* d_fifo[2] = {nullptr, nullptr};
+    cf32* d_spec = nullptr;                  // PLL output of the window the frame loops are ahead of the PL sync in (small banks; allocated on first use)
     uint8_t* d_out = nullptr;    // staging for the host-pointer entry point
     int fifo_cap = 0, fifo_cur = 0, fifo_fill = 0;
     // (the PL-sync state machine's state -- pending realign offset, last best_match -- lives in the device-side S2StreamState)
@@ -405,14 +406,19 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     if ((rc = get_rrc(ctx, d0->cfg.rrc_taps, d0->cfg.rrc_alpha, d0->cfg.samplerate / d0->cfg.symbolrate, &d_taps))) return rc;
 
     // ---- 1,2: front end + RRC
+    // small banks (a workgroup per stream in the frame loops): the loops run behind EVERY slice and ahead of the PL sync (s2_frame_loops_kernel);
+    // the window they are ahead in keeps its PLL output in a buffer of the stream's own (one PLFRAME of the longest kind)
+    static const bool loops_ahead_on = [] { const char* e = getenv("DVBS2GPU_LOOPS_AHEAD"); return !e || atoi(e) != 0; }();
+    const bool loops_ahead = loops_ahead_on && n <= 64 && !d0->cfg.pilot_aided && ctx->stage_pipeline_launches <= 0;
     std::vector<S2StreamWork> work(n);
     int max_count = 0;
     for (int i = 0; i < n; ++i) {
         dvbs2gpu_demod* d = dm[i];
         if (counts[i] < 0 || counts[i] > d->max_samples) { last_error() = "count exceeds max_samples"; return DVBS2GPU_ERR_ARG; }
+        if (loops_ahead && !d->d_spec) HIP_TRY(hipMalloc((void**)&d->d_spec, sizeof(cf32) * 33282));
         work[i].in = d_iq[i]; work[i].count = counts[i]; work[i].fe_out = d->d_fe;
         work[i].fifo = d->d_fifo[d->fifo_cur]; work[i].fifo_fill = d->fifo_fill; work[i].st = d->d_state;
-        work[i].fifo_next = d->d_fifo[d->fifo_cur ^ 1]; work[i].out = d_out[i];
+        work[i].fifo_next = d->d_fifo[d->fifo_cur ^ 1]; work[i].out = d_out[i]; work[i].spec_out = d->d_spec;
         max_count = std::max(max_count, counts[i]);
         d->stats.clear(); d->frame_ptrs.clear(); d->frame_pos.clear();
     }
@@ -458,6 +464,13 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         if (ctx->stage_pipeline_launches > 0) launches = ctx->stage_pipeline_launches;
         S2PostStages post{d_taps, d0->cfg.rrc_taps, max_count + max_count / 32 + 8, raw, maxf, d_found, d_counts, ctx->pl, CT->dev, d0->pls_code,
                           mp.slots, mp.pilots, mp.pilot_blocks, (cf32*)ws_pll.p, (S2FrameStats*)ws_slot.p, ctx->timers.on ? &spans : nullptr, launches};
+        if (loops_ahead) {
+            // behind (nearly) every slice -- but a launch wants a few thousand symbols per stream to chew on: a bank of 64 spends 0.4 ms per
+            // launch on top of its symbols
+            static const int sym_per_launch = [] { const char* e = getenv("DVBS2GPU_LOOPS_AHEAD_SYMBOLS"); return e ? atoi(e) : 2700; }();
+            post.spec = 1;
+            post.loops_launches = std::min(S2_FE_MAX_SLICES, std::max(launches, (max_count / 2) / std::max(sym_per_launch, 1)));
+        }
         if (pre) {
             // the shared pass (frontend_prepass) is running on its own streams: this group's PL-sync walk and frame loops go behind every one of
             // its slices, on the group's stream
@@ -793,7 +806,7 @@ int process_vcm_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const
         if (counts[i] < 0 || counts[i] > d->max_samples) { last_error() = "count exceeds max_samples"; return DVBS2GPU_ERR_ARG; }
         work[i].in = d_iq[i]; work[i].count = counts[i]; work[i].fe_out = d->d_fe;
         work[i].fifo = d->d_fifo[d->fifo_cur]; work[i].fifo_fill = d->fifo_fill; work[i].st = d->d_state;
-        work[i].fifo_next = d->d_fifo[d->fifo_cur ^ 1]; work[i].out = d_out[i];
+        work[i].fifo_next = d->d_fifo[d->fifo_cur ^ 1]; work[i].out = d_out[i]; work[i].spec_out = d->d_spec;
         max_count = std::max(max_count, counts[i]);
         maxf = std::max(maxf, d->fifo_cap / VCM_DUMMY_PLFRAME + 2);
         d->stats.clear(); d->frame_ptrs.clear(); d->frame_pos.clear(); d->frame_len.clear();
@@ -962,7 +975,7 @@ int frontend_prepass(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const 
         if (counts[i] < 0 || counts[i] > d->max_samples) { last_error() = "count exceeds max_samples"; return DVBS2GPU_ERR_ARG; }
         work[i].in = d_iq[i]; work[i].count = counts[i]; work[i].fe_out = d->d_fe;
         work[i].fifo = d->d_fifo[d->fifo_cur]; work[i].fifo_fill = d->fifo_fill; work[i].st = d->d_state;
-        work[i].fifo_next = d->d_fifo[d->fifo_cur ^ 1]; work[i].out = d_out[i];
+        work[i].fifo_next = d->d_fifo[d->fifo_cur ^ 1]; work[i].out = d_out[i]; work[i].spec_out = d->d_spec;
         max_count = std::max(max_count, counts[i]);
     }
     Workspace& ws = ctx->ws_rx[7];
@@ -1042,6 +1055,7 @@ void dvbs2gpu_demod_destroy(dvbs2gpu_demod* d) {
     (void)hipDeviceSynchronize();
     (void)hipFree(d->d_state); if (d->d_in) (void)hipFree(d->d_in); (void)hipFree(d->d_fe);
     (void)hipFree(d->d_fifo[0]); (void)hipFree(d->d_fifo[1]); if (d->d_out) (void)hipFree(d->d_out);
+    if (d->d_spec) (void)hipFree(d->d_spec);
     delete d;
 }
 
@@ -1072,6 +1086,17 @@ int dvbs2gpu_demod_set_params(dvbs2gpu_demod* d, int modcod, int shortframes, in
         const int zero_walk[3] = {0, 0, 0};         // walk_cur, walk_nf, loops_done
         static_assert(offsetof(S2StreamState, pl_last_bm) == offsetof(S2StreamState, pl_pending) + sizeof(int), "pl_pending and pl_last_bm are cleared together");
         static_assert(offsetof(S2StreamState, loops_done) == offsetof(S2StreamState, walk_cur) + 2 * sizeof(int), "walk_cur, walk_nf, loops_done are cleared together");
+        {   // frame loops that ran ahead of the PL sync (s2_frame_loops_kernel): back to the loop state at that window's start -- the window is gone
+            S2StreamState hs;
+            HIP_TRY(hipMemcpy(&hs, d->d_state, sizeof(hs), hipMemcpyDeviceToHost));
+            if (hs.spec_on) {
+                const float back[2] = {hs.spec_phase0, hs.spec_freq0};
+                static_assert(offsetof(S2StreamState, pll_freq) == offsetof(S2StreamState, pll_phase) + sizeof(float), "pll_phase, pll_freq are restored together");
+                HIP_TRY(hipMemcpy((char*)d->d_state + offsetof(S2StreamState, pll_phase), back, sizeof(back), hipMemcpyHostToDevice));
+                const int off = 0;
+                HIP_TRY(hipMemcpy((char*)d->d_state + offsetof(S2StreamState, spec_on), &off, sizeof(off), hipMemcpyHostToDevice));
+            }
+        }
         HIP_TRY(hipMemcpy((char*)d->d_state + offsetof(S2StreamState, pl_pending), zero_pl, sizeof(zero_pl), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy((char*)d->d_state + offsetof(S2StreamState, walk_cur), zero_walk, sizeof(zero_walk), hipMemcpyHostToDevice));
     }

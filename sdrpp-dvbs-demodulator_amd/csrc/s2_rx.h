@@ -35,6 +35,13 @@ struct S2StreamState {
     // produced so far, where the PL-sync walk stands and how many of its frames the frame loops have been through
     int n_fe_slice[16], n_sym_slice[16];    // [S2_FE_MAX_SLICES]
     int walk_cur, walk_nf, loops_done;
+    // frame loops ahead of the PL sync (s2_frame_loops_kernel, spec): the walk leaves how many symbols the FIFO holds (walk_avail); the loops
+    // may have run the PLL over the first spec_tiles tiles of the window at FIFO offset spec_off that is not a confirmed frame yet -- their
+    // state then IS ahead (pll_phase / pll_freq), and spec_phase0 / spec_freq0 hold what it was at that window's start (restored when the
+    // window turns out not to be the next frame, or when frame loops that do not know about it come next).  It carries over from call to
+    // call: the window's symbols stay in the FIFO, the PLL's output for them in S2StreamWork::spec_out
+    int walk_avail, spec_on, spec_off, spec_tiles, spec_carried;     // (spec_carried: tiles of that window done in EARLIER calls -- only those have to come out of spec_out)
+    float spec_phase0, spec_freq0;
 };
 
 // loop coefficients shared by all streams of one configuration
@@ -59,6 +66,7 @@ struct S2StreamWork {
     S2StreamState* st;
     cf32* fifo_next;         // spare FIFO buffer (receives the unconsumed tail at the end of the call)
     uint8_t* out;            // BBFRAME output of this stream
+    cf32* spec_out;          // PLL output of the window the frame loops are ahead of the PL sync in (one PLFRAME; null: no such loops for this stream)
 };
 
 // one aligned PLFRAME found by PL sync
@@ -181,6 +189,7 @@ struct S2PostStages {
                                                                             // launch costs its longest stream's chain: it only pays with about a frame per stream and launch)
     // mixed batches (s2_demod.hip): the shared front-end pass runs part 1 (RRC) for ALL streams behind every slice and records slice_done[c];
     // every configuration group then runs part 2 (walk + frame loops) for ITS streams behind that event on its own stream
+    int spec = 0;                                                           // frame loops ahead of the PL sync (small banks, see S2StreamState)
     int parts = 3;                                                          // 1: RRC + /2, 2: PL-sync walk + frame loops
     hipEvent_t* slice_done = nullptr;                                       // [nsub] or null
 };

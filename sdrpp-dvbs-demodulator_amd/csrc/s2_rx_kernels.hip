@@ -1291,6 +1291,9 @@ constexpr int FL_TILE = 46;          // PLL symbols staged per round (>= 36: the
                                      // one kernel per configuration group, and with two 11.7 KB workgroups per CU plus a stray third the
                                      // decoder workgroup of that CU could not start before the frame loops had finished (pipelined mode)
 
+// SPEC: with the loops ahead of the PL sync (below) compiled in -- small banks only: the plain instantiation has to stay within 128 registers
+// (it shares its SIMDs with three decoder waves in the pipelined mode), and the extra state costs it 14
+template <bool SPEC>
 __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* __restrict__ work, int nstreams,
                                                             const S2FrameRef* __restrict__ frames, const int* __restrict__ first,
                                                             S2LoopCoefs co, S2PlTablesDev T, S2ConstelDev C, int pls_code, int slots,
@@ -1320,6 +1323,37 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
     const cf32* __restrict__ plsc = T.plsc + (size_t)pls_code * 64;
     const int done = found ? st->loops_done : 0;
     const int f0 = found ? sc * maxf + done : first[sc], nf = !act ? 0 : (found ? st->walk_nf - done : first[sc + 1] - f0);
+    // ---- AHEAD OF THE PL SYNC (spec; one stream per workgroup, stage pipeline).  A frame only exists once the PL sync has seen its whole
+    // window -- until then a call of F frames has its frame loops waiting for symbols F - 1 times and working off a whole frame after the
+    // last symbol has arrived.  In lock the next window IS the next frame, so this kernel (launched behind every time slice) runs the PLL
+    // over the whole tiles of the window the FIFO holds so far, into the slot the frame will get; FED, PLHDR demod and statistics wait for
+    // the confirmation.  The loop state saved at the window's start comes back if the walk decides otherwise, and at the next call.
+    const int n_tiles = (plframe + FL_TILE - 1) / FL_TILE;
+    const bool spec_on_here = SPEC && found && spw == 1 && !co.pilot_aided && work[sc].spec_out != nullptr;
+    bool resume = false, sp_go = false, sp_keep = false;
+    int sp_t0 = 0, sp_t1 = 0, sp_so = 0, sp_tiles = 0, sp_slot = 0, sp_carried = 0;
+    float sp_ph0 = 0.f, sp_fr0 = 0.f;
+    if (spec_on_here && act) {
+        const int on = st->spec_on, off = st->spec_off;
+        sp_tiles = st->spec_tiles; sp_ph0 = st->spec_phase0; sp_fr0 = st->spec_freq0; sp_carried = st->spec_carried;
+        sp_so = st->walk_cur + st->pl_pending;
+        sp_slot = st->walk_nf;
+        bool cont = false;
+        if (on) {
+            if (nf > 0) { if (found[f0].offset == off) resume = true; else { pll.phase = sp_ph0; pll.freq = sp_fr0; } }
+            else if (sp_so == off) cont = true;
+            else { pll.phase = sp_ph0; pll.freq = sp_fr0; }
+        }
+        sp_t0 = cont ? sp_tiles : 0;
+        sp_t1 = min((st->walk_avail - sp_so) / FL_TILE, n_tiles - 1);          // whole tiles, and never the frame's last one
+        sp_go = sp_slot < maxf && sp_t1 > sp_t0;
+        sp_keep = cont && !sp_go;                                              // nothing new to do: the speculation stands as it is
+    } else if (!SPEC && act && st->spec_on) {
+        // loops that do not run ahead (another bank size, the frames pooled by the host): what earlier ones did is given up
+        pll.phase = st->spec_phase0; pll.freq = st->spec_freq0;
+    }
+    const bool sp_drop = !spec_on_here && act && st->spec_on;
+    if (SPEC && sp_drop) { pll.phase = st->spec_phase0; pll.freq = st->spec_freq0; }
     // Wave priority: FL_PRIO (the serial loops' latency first) only where the balancer of the pipelined mode has found the FRONT END to be the
     // critical path (s2_demod.hip: g_prio_duty >= 2).  Beside a decoder that IS the critical path the loops run at the decoder's own base
     // priority: they take 88 instead of 60 ms per headline step -- there is slack for that on their stream -- and the decoder launch 342
@@ -1332,47 +1366,40 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
     int nfmax = nf;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nfmax = max(nfmax, __shfl_xor(nfmax, o));
-    for (int ff = 0; ff < nfmax; ++ff) {
-        const bool fact = ff < nf;
-        const int fown = f0 + ff;
+    for (int ff = 0; ff < nfmax + (SPEC ? 1 : 0); ++ff) {
+        const bool spec_pass = SPEC && ff == nfmax;         // (after the confirmed frames: the window that is not one yet)
+        if (spec_pass && !__any(sp_go)) break;
+        const bool fact = spec_pass ? sp_go : ff < nf;
+        const int fown = spec_pass ? sc * maxf + sp_slot : f0 + ff;
         const int donor = __ffsll((unsigned long long)__ballot(fact)) - 1;
         const int fdon = __shfl(fown, donor);
         const int f = fact ? fown : fdon;
+        // tiles of this pass: all of them for a confirmed frame (from where the speculation stood, if this is its window), the whole tiles
+        // at hand for the unconfirmed window -- uniform over the wave (with speculation a workgroup has ONE stream: the donor's values)
+        const int t0 = SPEC ? __shfl(spec_pass ? sp_t0 : ((ff == 0 && resume) ? sp_tiles : 0), donor) : 0;
+        const int t1 = SPEC ? __shfl(spec_pass ? sp_t1 : n_tiles, donor) : n_tiles;
+        const bool fin = !spec_pass;
+        const int foff = SPEC ? __shfl(sp_so, donor) : 0;
+        if (spec_pass && fact && t0 == 0) { sp_ph0 = pll.phase; sp_fr0 = pll.freq; sp_carried = 0; }
         const PclDev pll_in = pll, hdr_in = hdr;
         const float nco_in = nco_freq;
-        const cf32* __restrict__ fr = found ? work[f / maxf].fifo + found[f].offset : frames[f].sym;
+        const cf32* __restrict__ fr = found ? work[f / maxf].fifo + (spec_pass ? foff : found[f].offset) : frames[f].sym;
+        // (the unconfirmed window's output goes into the slot the frame will get AND into the stream's own buffer, which outlives the call: a
+        //  frame that continues from tiles done in earlier calls first gets those out of there -- all 64 lanes copy, the workgroup has one stream)
         cf32* __restrict__ out = pllout + (size_t)f * plframe;
-        // ---- coarse frequency error detector (dvbs2_fed.h): terms in parallel, summed in the reference's order
-        #pragma unroll 1
-        for (int i = gl; i < 88; i += FL_LPS) {
-            cf32 r2 = (i + 2) < 26 ? T.sof[i + 2] : plsc[i + 2 - 26];
-            cf32 r0 = i < 26 ? T.sof[i] : plsc[i - 26];
-            fd[i] = cmul(cmul(cmul(fr[i + 2], cconj(r2)), cconj(fr[i])), r0).im;
+        cf32* __restrict__ keep = spec_pass ? work[f / maxf].spec_out : nullptr;
+        if (SPEC && fin && t0 > 0) {
+            const int carried = min(__shfl(sp_carried, donor), t0);
+            const cf32* __restrict__ so = work[f / maxf].spec_out;
+            for (int i = 90 + lane; i < carried * FL_TILE; i += 64) out[i] = so[i];
         }
-        __syncthreads();
-        float err = 0.f, symcnt = 90 - 2;
-        for (int i = 0; i < 88; ++i) err += fd[i];
-        if (pilots) {
-            const cf32 p{0.707f, 0.707f};
-            for (int b = 0; b < pilot_blocks; ++b) {
-                int start = pilot_start(b);
-                __syncthreads();
-                for (int i = gl; i < 36; i += FL_LPS) tl[i] = pl_descramble(fr[start + i], T.rn[start - 90 + i]);
-                __syncthreads();
-                for (int i = gl; i < 36; i += FL_LPS)
-                    if (i >= 2) fd[i] = cmul(cmul(cmul(tl[i], cconj(p)), cconj(tl[i - 2])), p).im;
-                __syncthreads();
-                for (int i = 2; i < 36; ++i) err += fd[i];
-                symcnt += 36 - 2;
-            }
-        }
-        float est = err / symcnt;
-        if (fabsf(est) < 0.02) nco_freq = nco_freq + est * (co.fll_bw / 100.0f);
-        else nco_freq = nco_freq + est * co.fll_bw;
-        if (nco_freq > 0.3f * PI_F) nco_freq = 0.3f * PI_F;
-        if (nco_freq < -0.3f * PI_F) nco_freq = -0.3f * PI_F;
         // ---- PLL (dvbs2_pll.cpp:34-86), 64-symbol tiles
-        int next_pilot = (pilots && pilot_blocks > 0) ? pilot_start(0) : -1, pb = 0;
+        const int b0 = t0 * FL_TILE, b1 = fin ? plframe : t1 * FL_TILE;
+        int next_pilot = -1, pb = 0;
+        if (pilots && pilot_blocks > 0) {                   // (the pilot block at or ahead of the first symbol: a pass may start inside the frame)
+            while (pb < pilot_blocks && pilot_start(pb) + 36 <= b0) ++pb;
+            next_pilot = pb < pilot_blocks ? pilot_start(pb) : -1;
+        }
         cf32 pacc{0.f, 0.f};
         // the next tile's symbols and Gold-sequence values are fetched into registers while the serial loop runs on the current one
         constexpr int NPF = (FL_TILE + FL_LPS - 1) / FL_LPS;
@@ -1387,8 +1414,8 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
             const int gi = base + lane;
             prn = (lane < FL_TILE && gi < plframe && gi >= 90) ? T.rn[gi - 90] : 0;
         };
-        fetch(0);
-        for (int base = 0; base < plframe; base += FL_TILE) {
+        fetch(b0);
+        for (int base = b0; base < b1; base += FL_TILE) {
             const int m = min(FL_TILE, plframe - base);
             __syncthreads();
 #pragma unroll
@@ -1398,7 +1425,7 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
             }
             if (lane < m) rnt[lane] = (uint8_t)prn;
             __syncthreads();
-            if (base + FL_TILE < plframe) fetch(base + FL_TILE);
+            if (base + FL_TILE < b1) fetch(base + FL_TILE);
             // A tile of payload symbols only (no header, no pilot symbol: all but a handful of the frame's tiles) takes the short loop: rotate, phase
             // error, advance -- the Gold-sequence rotation of the OUTPUT (descrambling acts on the rotated symbol and feeds nothing back into
             // the loop) is left to the lanes that copy the tile out.  Everything else goes through the general loop below.
@@ -1471,8 +1498,43 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
             __syncthreads();
             if (fact)
                 for (int i = gl; i < m; i += FL_LPS)
-                    if (base + i >= 90) out[base + i] = plain ? pl_descramble(ot[i], rnt[i]) : ot[i];
+                    if (base + i >= 90) {
+                        const cf32 v = plain ? pl_descramble(ot[i], rnt[i]) : ot[i];
+                        out[base + i] = v;
+                        if (SPEC && keep) keep[base + i] = v;
+                    }
         }
+        if (fin) {
+        __syncthreads();
+        // ---- coarse frequency error detector (dvbs2_fed.h): terms in parallel, summed in the reference's order
+        #pragma unroll 1
+        for (int i = gl; i < 88; i += FL_LPS) {
+            cf32 r2 = (i + 2) < 26 ? T.sof[i + 2] : plsc[i + 2 - 26];
+            cf32 r0 = i < 26 ? T.sof[i] : plsc[i - 26];
+            fd[i] = cmul(cmul(cmul(fr[i + 2], cconj(r2)), cconj(fr[i])), r0).im;
+        }
+        __syncthreads();
+        float err = 0.f, symcnt = 90 - 2;
+        for (int i = 0; i < 88; ++i) err += fd[i];
+        if (pilots) {
+            const cf32 p{0.707f, 0.707f};
+            for (int b = 0; b < pilot_blocks; ++b) {
+                int start = pilot_start(b);
+                __syncthreads();
+                for (int i = gl; i < 36; i += FL_LPS) tl[i] = pl_descramble(fr[start + i], T.rn[start - 90 + i]);
+                __syncthreads();
+                for (int i = gl; i < 36; i += FL_LPS)
+                    if (i >= 2) fd[i] = cmul(cmul(cmul(tl[i], cconj(p)), cconj(tl[i - 2])), p).im;
+                __syncthreads();
+                for (int i = 2; i < 36; ++i) err += fd[i];
+                symcnt += 36 - 2;
+            }
+        }
+        float est = err / symcnt;
+        if (fabsf(est) < 0.02) nco_freq = nco_freq + est * (co.fll_bw / 100.0f);
+        else nco_freq = nco_freq + est * co.fll_bw;
+        if (nco_freq > 0.3f * PI_F) nco_freq = 0.3f * PI_F;
+        if (nco_freq < -0.3f * PI_F) nco_freq = -0.3f * PI_F;
         // ---- PL header demod (dvbs2_plhdr_demod.cpp:33-67)
         // (the 90 header symbols are staged now, over the input + output tiles the PLL loop is through with)
         __syncthreads();
@@ -1535,6 +1597,7 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
             stt.fed_err = est;
             stats[f] = stt;
         }
+        }   // fin
         if (!fact) { pll = pll_in; hdr = hdr_in; nco_freq = nco_in; }
         __syncthreads();
     }
@@ -1543,6 +1606,11 @@ __global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* 
         st->hdr_phase = hdr.phase; st->hdr_freq = hdr.freq;
         st->nco_freq = nco_freq;
         if (found) st->loops_done = done + nf;
+        if (spec_on_here) {
+            if (sp_go) { st->spec_on = 1; st->spec_off = sp_so; st->spec_tiles = sp_t1; st->spec_phase0 = sp_ph0; st->spec_freq0 = sp_fr0; st->spec_carried = sp_carried; }
+            else if (!sp_keep) st->spec_on = 0;
+        }
+        if (sp_drop) st->spec_on = 0;
     }
 }
 
@@ -1611,6 +1679,8 @@ __global__ __launch_bounds__(256) void s2_ccm_walk_kernel(const S2StreamWork* __
     const int avail = w.fifo_fill + nsym;
     int pend = st->pl_pending, cur = (nsub > 1 && sub) ? st->walk_cur : 0, nf = (nsub > 1 && sub) ? st->walk_nf : 0;
     float lastbm = st->pl_last_bm;
+    // a window the frame loops of the previous call were ahead in: the FIFO has lost the walk_cur symbols in front of it since
+    if (sub == 0 && tid == 0 && st->spec_on) { st->spec_off -= st->walk_cur; st->spec_carried = st->spec_tiles; }
     const uint32_t dsof = 0x18d2e82u ^ (0x18d2e82u >> 1);
     const unsigned long long SCR = 0x719d83c953422dfaull;
     const unsigned long long dscr = SCR ^ (SCR >> 1);
@@ -1691,7 +1761,7 @@ __global__ __launch_bounds__(256) void s2_ccm_walk_kernel(const S2StreamWork* __
     }
     if (tid == 0) {
         st->pl_pending = pend; st->pl_last_bm = lastbm;
-        st->walk_cur = cur; st->walk_nf = nf;
+        st->walk_cur = cur; st->walk_nf = nf; st->walk_avail = avail;
         if (sub == 0) st->loops_done = 0;
         counts[4 * s] = nf; counts[4 * s + 1] = cur; counts[4 * s + 2] = avail; counts[4 * s + 3] = nsym;
     }
@@ -2637,7 +2707,12 @@ static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, c
         if ((c + 1) * L / nsub > c * L / nsub) {
             if (p.spans) p.spans->begin(3, s);
             const int spw = frame_loops_spw(nstreams);
-            hipLaunchKernelGGL(s2_frame_loops_kernel, dim3((nstreams + spw - 1) / spw), dim3(64), 0, s, d_work, nstreams, (const S2FrameRef*)nullptr,
+            if (p.spec && spw == 1)
+                hipLaunchKernelGGL(s2_frame_loops_kernel<true>, dim3(nstreams), dim3(64), 0, s, d_work, nstreams, (const S2FrameRef*)nullptr,
+                                   (const int*)nullptr, coefs, p.tabs, p.con, p.pls_code, p.slots, p.pilots, p.pilot_blocks, p.raw, p.d_pllout, p.d_stats,
+                                   (const S2VcmFound*)p.d_found, p.maxf, spw);
+            else
+            hipLaunchKernelGGL(s2_frame_loops_kernel<false>, dim3((nstreams + spw - 1) / spw), dim3(64), 0, s, d_work, nstreams, (const S2FrameRef*)nullptr,
                                (const int*)nullptr, coefs, p.tabs, p.con, p.pls_code, p.slots, p.pilots, p.pilot_blocks, p.raw, p.d_pllout, p.d_stats,
                                (const S2VcmFound*)p.d_found, p.maxf, spw);
             if (p.spans) p.spans->end(3, s);
@@ -2736,7 +2811,7 @@ hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const
                                  S2LoopCoefs coefs, S2PlTablesDev tabs, S2ConstelDev con, int pls_code, int slots, int pilots,
                                  int pilot_blocks, int plframe, cf32* d_pllout, S2FrameStats* d_stats, hipStream_t st) {
     const int spw = frame_loops_spw(nstreams);
-    hipLaunchKernelGGL(s2_frame_loops_kernel, dim3((nstreams + spw - 1) / spw), dim3(64), 0, st, d_work, nstreams, d_frames, d_first, coefs,
+    hipLaunchKernelGGL(s2_frame_loops_kernel<false>, dim3((nstreams + spw - 1) / spw), dim3(64), 0, st, d_work, nstreams, d_frames, d_first, coefs,
                        tabs, con, pls_code, slots, pilots, pilot_blocks, plframe, d_pllout, d_stats, (const S2VcmFound*)nullptr, 0, spw);
     return hipGetLastError();
 }
