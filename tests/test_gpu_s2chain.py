@@ -132,6 +132,33 @@ def test_demod_end_to_end_vs_oracle(engine, modcod, short, pilots, esn0, nframes
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('cut', [2 * 5000 + 1, 2 * 16233])
+def test_realignment_in_mid_stream_equals_oracle(engine, cut):
+    """the transmission loses `cut` samples in mid-stream: the PL sync finds its next window misaligned and realigns (dvbs2_pl_sync.cpp:145-164)
+    -- with the frame loops of a small bank running AHEAD of the PL sync this is where what they did on the window that turned out not to be
+    a frame has to be given up.  Every tap and every output equal to the oracle's, call by call, across the break"""
+    modcod, short, pilots = 14, 1, 0
+    iq, bb, _ = orc.transmit(modcod, short, pilots, nframes=14, seed=33, esn0_db=16.0, cfo=1e-3, timing=0.3, phase0=0.1, lead_symbols=211)
+    half = (iq.size // 2) | 1
+    iq = np.concatenate([iq[:half], iq[half + cut:]])
+    rx = orc.OracleRx(orc.default_cfg(modcod, short, pilots, max_ldpc_trials=16))
+    dm = engine.demod(engine.default_cfg(modcod, True, False, max_ldpc_trials=16), max_samples=16384)
+    good = 0
+    sent = {bytes(b) for b in bb}
+    for ncall, a in enumerate(range(0, iq.size, 9001)):
+        part = iq[a:a + 9001]
+        o = rx.process(part)
+        g = dm.process(part)
+        for t in range(4):
+            assert same_bits(rx.tap(t), dm.tap(t)), ('tap', t, 'call', ncall)
+        assert o.shape == g.shape and np.array_equal(o, g), ('BBFRAMEs', ncall)
+        assert np.float32(dm.nco_freq()).view(np.uint32) == np.float32(rx.L.orc_s2rx_nco_freq(rx.h)).view(np.uint32)
+        good += sum(bytes(x) in sent for x in g)
+    assert good >= 3, good          # (the frames before the break; after it the reference receiver needs many frames to settle again)
+    dm.close()
+
+
+@pytest.mark.gpu
 def test_tiny_and_empty_calls_equal_oracle(engine):
     """calls of 0 .. 40 samples (time slices without a sample, periods of the timing recovery with fewer samples than a tile, calls that
     end between the two outputs of a symbol), then ordinary ones: every tap and every output equal to the oracle's, call by call"""
