@@ -33,7 +33,7 @@ struct S2StreamState {
                       // while its later AGC / NCO slices run; the reference applies the FED's feedback from the next process() call on)
     // stage pipeline of a call (s2_frontend_launch with post stages): per time slice what the timing recovery / the RRC decimator have
     // produced so far, where the PL-sync walk stands and how many of its frames the frame loops have been through
-    int n_fe_slice[16], n_sym_slice[16];    // [S2_FE_MAX_SLICES]
+    int n_fe_slice[32], n_sym_slice[32];    // [S2_FE_MAX_SLICES]
     int walk_cur, walk_nf, loops_done;
     // frame loops ahead of the PL sync (s2_frame_loops_kernel, spec): the walk leaves how many symbols the FIFO holds (walk_avail); the loops
     // may have run the PLL over the first spec_tiles tiles of the window at FIFO offset spec_off that is not a confirmed frame yet -- their
@@ -175,7 +175,7 @@ hipError_t dvbs_soft_slice_launch(const DvbsStreamWork* d_work, int nstreams, in
 hipError_t dvbs_soft_count_launch(const DvbsStreamWork* d_work, int nstreams, int* d_nblocks, hipStream_t st);
 hipError_t dvbs_soft_compact_launch(const DvbsStreamWork* d_work, int nstreams, hipStream_t st);
 
-constexpr int S2_FE_MAX_SLICES = 16;     // (n_fe_slice[] / n_sym_slice[] of the stream state; a power of two)
+constexpr int S2_FE_MAX_SLICES = 32;     // (n_fe_slice[] / n_sym_slice[] of the stream state; a power of two)
 // What runs behind every timing-recovery slice when the whole CCM front half of a call is pipelined (s2_frontend_launch): RRC + decimation of the
 // slice's samples into the PL-sync FIFO, the PL-sync walk over the symbols that are in, the frame loops over the frames the walk has found so
 // far.  Frame k of stream s lives in SLOT s * maxf + k of d_found / d_pllout / d_stats (the host pools them after the call's one read-back).
