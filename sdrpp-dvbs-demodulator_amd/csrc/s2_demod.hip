@@ -409,7 +409,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     // small banks (a workgroup per stream in the frame loops): the loops run behind EVERY slice and ahead of the PL sync (s2_frame_loops_kernel);
     // the window they are ahead in keeps its PLL output in a buffer of the stream's own (one PLFRAME of the longest kind)
     static const bool loops_ahead_on = [] { const char* e = getenv("DVBS2GPU_LOOPS_AHEAD"); return !e || atoi(e) != 0; }();
-    const bool loops_ahead = loops_ahead_on && n <= 64 && !d0->cfg.pilot_aided && ctx->stage_pipeline_launches <= 0;
+    const bool loops_ahead = loops_ahead_on && n <= S2_SMALL_BANK && !d0->cfg.pilot_aided && ctx->stage_pipeline_launches <= 0;     // (S2_SMALL_BANK = FL_SMALL_BANK of the kernels)
     std::vector<S2StreamWork> work(n);
     int max_count = 0;
     for (int i = 0; i < n; ++i) {

@@ -1282,9 +1282,9 @@ __device__ __attribute__((noinline)) float soft_phase_err_group(lds_cf32* __rest
 constexpr int FL_LPS = FL_LPS_N;
 constexpr int FL_SPW = 64 / FL_LPS;
 #ifndef FL_SMALL_BANK
-#define FL_SMALL_BANK 64
+#define FL_SMALL_BANK 256
 #endif
-static inline int frame_loops_spw(int nstreams) { return nstreams <= FL_SMALL_BANK ? 1 : FL_SPW; }      // streams per workgroup of s2_frame_loops_kernel
+static inline int frame_loops_spw(int nstreams) { return nstreams <= FL_SMALL_BANK ? 1 : FL_SPW; }      // streams per workgroup of s2_frame_loops_kernel (a CU each up to 256 streams)
 constexpr int FL_TILE = 46;          // PLL symbols staged per round (>= 36: the FED reuses the tile for a pilot block; input + output
                                      // tile together hold the 90 header symbols for the PLHDR loop and the 88 FED terms); small: THREE
                                      // workgroups have to fit into the 24 KB of LDS an LDPC workgroup leaves free -- a mixed batch launches
@@ -1294,7 +1294,7 @@ constexpr int FL_TILE = 46;          // PLL symbols staged per round (>= 36: the
 // SPEC: with the loops ahead of the PL sync (below) compiled in -- small banks only: the plain instantiation has to stay within 128 registers
 // (it shares its SIMDs with three decoder waves in the pipelined mode), and the extra state costs it 14
 template <bool SPEC>
-__global__ __launch_bounds__(64) void s2_frame_loops_kernel(const S2StreamWork* __restrict__ work, int nstreams,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void s2_frame_loops_kernel(const S2StreamWork* __restrict__ work, int nstreams,
                                                             const S2FrameRef* __restrict__ frames, const int* __restrict__ first,
                                                             S2LoopCoefs co, S2PlTablesDev T, S2ConstelDev C, int pls_code, int slots,
                                                             int pilots, int pilot_blocks, int plframe, cf32* __restrict__ pllout,
