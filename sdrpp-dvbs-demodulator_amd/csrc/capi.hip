@@ -293,6 +293,7 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
     if (ctx->pl.rn) (void)hipFree((void*)ctx->pl.rn);
     for (auto& kv : ctx->constel) {
         if (kv.second.d_bits) (void)hipFree(kv.second.d_bits);
+        if (kv.second.d_bits4) (void)hipFree(kv.second.d_bits4);
         if (kv.second.d_err) (void)hipFree(kv.second.d_err);
         if (kv.second.d_pts) (void)hipFree(kv.second.d_pts);
     }

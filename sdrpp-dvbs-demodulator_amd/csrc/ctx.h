@@ -89,6 +89,7 @@ struct FecWs { Workspace msg, hard, syn, misc; void release() { msg.release(); h
 struct ConstelTables {          // device tables of one constellation (type, gamma1, gamma2)
     S2ConstelDev dev;
     int8_t* d_bits = nullptr;
+    uint32_t* d_bits4 = nullptr;
     float* d_err = nullptr;
     cf32* d_pts = nullptr;
 };

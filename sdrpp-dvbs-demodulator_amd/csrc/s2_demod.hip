@@ -205,7 +205,7 @@ int get_constel(dvbs2gpu_ctx* ctx, const ModcodParams& mp, ConstelTables** out) 
             if (rcp) return rcp;
             T.dev.pts_g = T.d_pts;
         }
-        T.dev.lut_bits = nullptr; T.dev.lut_err = nullptr;
+        T.dev.lut_bits = nullptr; T.dev.lut_err = nullptr; T.dev.lut_bits4 = nullptr;
         if (H.bits != 5) {   // make_lut(256), constellation.cpp:272-291 -- built on the host with the shared math definitions, uploaded
             std::vector<int8_t> lb((size_t)65536 * H.bits);
             std::vector<float> le(65536);
@@ -218,6 +218,12 @@ int get_constel(dvbs2gpu_ctx* ctx, const ModcodParams& mp, ConstelTables** out) 
             if ((rc = upload(lb, &T.d_bits))) return rc;
             if ((rc = upload(le, &T.d_err))) return rc;
             T.dev.lut_bits = T.d_bits; T.dev.lut_err = T.d_err;
+            // the same soft values, one word per cell (the demapper fetches a cell with one load)
+            std::vector<uint32_t> lb4(65536, 0u);
+            for (size_t cell = 0; cell < 65536; ++cell)
+                for (int c = 0; c < H.bits; ++c) lb4[cell] |= (uint32_t)(uint8_t)lb[cell * H.bits + c] << (8 * c);
+            if ((rc = upload(lb4, &T.d_bits4))) return rc;
+            T.dev.lut_bits4 = T.d_bits4;
         }
         it = ctx->constel.emplace(key, T).first;
     }

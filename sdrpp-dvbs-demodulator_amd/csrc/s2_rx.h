@@ -90,6 +90,7 @@ struct S2ConstelDev {
     float amp, sca, prescale;
     const int8_t* lut_bits;    // [256][256][bits]   (null for 32APSK)
     const float* lut_err;      // [256][256]
+    const uint32_t* lut_bits4; // [256][256]: the cell's `bits` soft values as bytes 0..bits-1 of one word (bits <= 4; null for 32APSK)
     cf32 pts[32];
     const cf32* pts_g;         // the same points in global memory
 };

@@ -20,9 +20,12 @@ def same_bits(a, b):
     return np.array_equal(a, b)
 
 
-@pytest.mark.parametrize('modcod,short,pilots', [(4, 1, 0), (14, 1, 0), (12, 1, 0), (19, 1, 0), (6, 1, 1), (14, 1, 1)])
+@pytest.mark.parametrize('modcod,short,pilots', [(4, 1, 0), (14, 1, 0), (12, 1, 0), (19, 1, 0), (6, 1, 1), (14, 1, 1),
+                                                 (19, 0, 0), (12, 0, 1), (4, 0, 1), (21, 0, 1)])
 def test_demap_bit_exact(engine, modcod, short, pilots):
-    """LUT demap + de-interleave on arbitrary symbols: exact (same LUT, same double index math)."""
+    """LUT demap + de-interleave on arbitrary symbols: exact (same LUT, same double index math).  QPSK, 8PSK (3/5: columns reversed) and
+    16APSK normal frames take the four-symbols-per-lane form, 16APSK short frames (columns of 4050 bytes) and symbols at an address that is
+    not a multiple of 16 the byte form"""
     import torch
     mp = orc.modcod_params(modcod, short, pilots)
     rng = np.random.default_rng(modcod)
@@ -37,6 +40,11 @@ def test_demap_bit_exact(engine, modcod, short, pilots):
     got = engine.demap(torch.from_numpy(fr).cuda(), modcod, bool(short), bool(pilots))
     torch.cuda.synchronize()
     assert np.array_equal(got.cpu().numpy(), want)
+    # the same frames one sample further into a buffer (8 bytes off the 16-byte grid)
+    buf = torch.zeros(F * mp['plframe'] + 1, dtype=torch.complex64, device='cuda')
+    buf[1:] = torch.from_numpy(fr).cuda().reshape(-1)
+    got2 = engine.demap(buf[1:].reshape(F, mp['plframe']), modcod, bool(short), bool(pilots))
+    assert np.array_equal(got2.cpu().numpy(), want)
 
 
 @pytest.mark.parametrize('modcod,short,pilots', [(27, 1, 1), (24, 0, 0), (28, 0, 1)])
