@@ -42,7 +42,8 @@ struct GfDev {
 };
 
 __global__ __launch_bounds__(256) void bch_syndromes_kernel(BchDeviceCode C, const uint8_t* __restrict__ frames, int frame_stride,
-                                                            int nbch, int nframes, uint16_t* __restrict__ syn_out) {
+                                                            int nbch, int nframes, uint16_t* __restrict__ syn_out, int32_t* __restrict__ todo,
+                                                            int32_t* __restrict__ corrections) {
     __shared__ uint16_t tab[12 * 3 * 256];
     __shared__ uint16_t red[4][12];
     __shared__ uint16_t sfin[32];
@@ -92,6 +93,9 @@ __global__ __launch_bounds__(256) void bch_syndromes_kernel(BchDeviceCode C, con
             if (nz)   // clean frame: the even syndromes are squares of zeros
                 for (int k = 1; k <= t; ++k) sfin[2 * k - 1] = G.vmul(sfin[k - 1], sfin[k - 1]);                  // S_2k = S_k^2
             sfin[31] = nz ? 1 : 0;                                                                                 // "needs correction" flag
+            // a frame with a syndrome joins the correction kernel's work list, a clean one is done
+            if (nz) todo[2 + atomicAdd(&todo[0], 1)] = f;
+            else if (corrections) corrections[f] = 0;
         }
         __syncthreads();
         if (tid < 32) syn_out[(size_t)f * 32 + tid] = sfin[tid];
@@ -104,8 +108,9 @@ __device__ __forceinline__ void xor_be_bit(uint8_t* buf, int pos) { buf[pos / 8]
 constexpr int BCH_CT = 256;         // threads of a correction workgroup
 constexpr int BCH_MAXDEG = 24;      // a locator found from 2t <= 24 syndromes has degree <= 24
 __global__ __launch_bounds__(BCH_CT) void bch_correct_kernel(BchDeviceCode C, uint8_t* __restrict__ frames, int frame_stride, int nbch,
-                                                             int kbch, int nframes, const uint16_t* __restrict__ syn_in,
+                                                             int kbch, int nframes, const uint16_t* __restrict__ syn_in, int32_t* __restrict__ todo,
                                                              int32_t* __restrict__ corrections) {
+    __shared__ int s_item;
     __shared__ uint16_t s_loc[32];      // locator
     __shared__ uint16_t s_pos[32];      // locations
     __shared__ int s_deg, s_count, s_state;
@@ -116,14 +121,18 @@ __global__ __launch_bounds__(BCH_CT) void bch_correct_kernel(BchDeviceCode C, ui
     GfDev G{C.d_log, C.d_exp, C.N};
     const int NR = 2 * C.t;
     const int lane = threadIdx.x;
-    for (int f = blockIdx.x; f < nframes; f += gridDim.x) {
+    // the frames with a syndrome, one by one off the list the syndrome kernel left (work counter in todo[1]): how many there are and where they sit is the
+    // channel's business, and a frame costs a few hundred microseconds of dependent lookups -- a fixed frame-to-workgroup map ends with its unluckiest workgroup
+    const int ntodo = todo[0];
+    while (true) {
+        if (lane == 0) s_item = atomicAdd(&todo[1], 1);
+        __syncthreads();
+        const int item = s_item;
+        __syncthreads();
+        if (item >= ntodo) break;
+        const int f = todo[2 + item];
         const uint16_t* __restrict__ syn = syn_in + (size_t)f * 32;
         // state: 0 = clean, 1 = need Chien, 2 = locations ready, -1 = failed
-        // fast path: the syndrome kernel left a flag; a clean frame costs one load
-        if (syn[31] == 0) {
-            if (lane == 0 && corrections) corrections[f] = 0;
-            continue;
-        }
         // Berlekamp-Massey (reed_solomon_error_correction.hh:226-276, count = 0) with the polynomials in LDS and the inner loops --
         // discrepancy, T = C + d x^m B, B = C / d -- spread over the threads (the serial form with per-thread arrays lived in scratch
         // memory: thousands of dependent memory round trips per frame)
@@ -329,15 +338,17 @@ __global__ __launch_bounds__(256) void bb_descramble_kernel(const uint8_t* __res
 }
 
 hipError_t bch_syndromes_launch(const BchDeviceCode& C, const uint8_t* frames, int frame_stride, int nbch, int nframes,
-                                uint16_t* syn, hipStream_t stream) {
+                                uint16_t* syn, int32_t* todo, int32_t* corrections, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(todo, 0, 2 * sizeof(int32_t), stream);
+    if (e != hipSuccess) return e;
     int grid = nframes < 4096 ? nframes : 4096;
-    hipLaunchKernelGGL(bch_syndromes_kernel, dim3(grid), dim3(256), 0, stream, C, frames, frame_stride, nbch, nframes, syn);
+    hipLaunchKernelGGL(bch_syndromes_kernel, dim3(grid), dim3(256), 0, stream, C, frames, frame_stride, nbch, nframes, syn, todo, corrections);
     return hipGetLastError();
 }
 hipError_t bch_correct_launch(const BchDeviceCode& C, uint8_t* frames, int frame_stride, int nbch, int kbch, int nframes,
-                              const uint16_t* syn, int32_t* corrections, hipStream_t stream) {
-    int grid = nframes < 2048 ? nframes : 2048;
-    hipLaunchKernelGGL(bch_correct_kernel, dim3(grid), dim3(BCH_CT), 0, stream, C, frames, frame_stride, nbch, kbch, nframes, syn, corrections);
+                              const uint16_t* syn, int32_t* todo, int32_t* corrections, hipStream_t stream) {
+    int grid = nframes < 2048 ? nframes : 2048;      // (as many workgroups as the device holds at once, 25 KB of LDS each; the idle ones leave at their first look at the list)
+    hipLaunchKernelGGL(bch_correct_kernel, dim3(grid), dim3(BCH_CT), 0, stream, C, frames, frame_stride, nbch, kbch, nframes, syn, todo, corrections);
     return hipGetLastError();
 }
 hipError_t bb_descramble_launch(const uint8_t* frames, int frame_stride, const uint8_t* prbs, int out_bytes, int nframes,

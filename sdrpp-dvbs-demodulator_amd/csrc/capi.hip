@@ -229,10 +229,11 @@ static int bch_run(dvbs2gpu_ctx* ctx, const FecParams& f, uint8_t* d_frames, int
     // GF(2^16): t = 8 and 10 use the first 2t syndromes of the same field; tables depend on (m, t) only via t rows
     int rc = get_bch(ctx, f.bch_m, f.bch_t, &B);
     if (rc) return rc;
-    if ((rc = W.syn.ensure((size_t)nframes * 32 * sizeof(uint16_t)))) return rc;
+    if ((rc = W.syn.ensure((size_t)nframes * 32 * sizeof(uint16_t) + (size_t)(nframes + 2) * sizeof(int32_t)))) return rc;
     uint16_t* syn = (uint16_t*)W.syn.p;
-    HIP_TRY(bch_syndromes_launch(*B, d_frames, f.K / 8, f.K, nframes, syn, st));
-    HIP_TRY(bch_correct_launch(*B, d_frames, f.K / 8, f.K, f.kbch, nframes, syn, d_corr, st));
+    int32_t* todo = (int32_t*)(syn + (size_t)nframes * 32);      // counters + list of the frames that need the correction kernel
+    HIP_TRY(bch_syndromes_launch(*B, d_frames, f.K / 8, f.K, nframes, syn, todo, d_corr, st));
+    HIP_TRY(bch_correct_launch(*B, d_frames, f.K / 8, f.K, f.kbch, nframes, syn, todo, d_corr, st));
     return 0;
 }
 }  // namespace s2

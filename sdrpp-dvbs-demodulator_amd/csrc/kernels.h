@@ -45,10 +45,13 @@ struct BchDeviceCode {
     uint16_t* d_syn_tab = nullptr; // [t][3][256] byte-Horner tables for the odd syndromes
 };
 
+// `todo` = int32 [2 + nframes]: {frames with a non-zero syndrome, the correction kernel's work counter} (zeroed by bch_syndromes_launch) and the list
+// of those frames: the correction kernel's workgroups take them one by one -- a frame that needs correcting costs a few hundred microseconds of
+// dependent table lookups, a clean one nothing, and which are which is the channel's business
 hipError_t bch_syndromes_launch(const BchDeviceCode& C, const uint8_t* frames, int frame_stride, int nbch, int nframes,
-                                uint16_t* syn /*[nframes][32]*/, hipStream_t stream);
+                                uint16_t* syn /*[nframes][32]*/, int32_t* todo, int32_t* corrections, hipStream_t stream);
 hipError_t bch_correct_launch(const BchDeviceCode& C, uint8_t* frames, int frame_stride, int nbch, int kbch, int nframes,
-                              const uint16_t* syn, int32_t* corrections, hipStream_t stream);
+                              const uint16_t* syn, int32_t* todo, int32_t* corrections, hipStream_t stream);
 hipError_t bb_descramble_launch(const uint8_t* frames, int frame_stride, const uint8_t* prbs, int out_bytes, int nframes,
                                 uint8_t* out, hipStream_t stream);
 
