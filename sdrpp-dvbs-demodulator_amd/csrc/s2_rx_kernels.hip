@@ -634,21 +634,24 @@ constexpr int GB_RING = 2 * GB_T + 9;
 constexpr int GB_PITCH = (GB_RING + 7) | 1;  // + mirror of the first 7 slots (a window never wraps); odd: the 8-byte accesses of 32 lanes hit 64 different banks
 __device__ __forceinline__ int gb_wrap(int slot) { return (int)min((unsigned)slot, (unsigned)(slot - GB_RING)); }   // slot in [0, 2 * GB_RING)
 
+// SPB = streams per workgroup: 64 (a full wave), or 16 -- lanes 16..63 of the resolver idle, but a bank of 4096 streams then is 256 workgroups, one per
+// compute unit, and a workgroup's ring is 4.6 KB instead of 16.9
+template <int SPB>
 __global__ __launch_bounds__(128) void s2_gardner_bank_kernel(const S2StreamWork* __restrict__ work, int nstreams, S2LoopCoefs co,
                                                              const float* __restrict__ bank_g, int sub, int nsub) {
     __shared__ __attribute__((aligned(16))) float bank[GARDNER_PHASES * GARDNER_TAPS];
-    __shared__ __attribute__((aligned(8))) f32x2 ring[64 * GB_PITCH];
+    __shared__ __attribute__((aligned(8))) f32x2 ring[SPB * GB_PITCH];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 64 + lane;
-    const bool act = s < nstreams;
+    const int s = blockIdx.x * SPB + lane;
+    const bool act = lane < SPB && s < nstreams;
     for (int i = threadIdx.x; i < GARDNER_PHASES * GARDNER_TAPS; i += 128) bank[i] = bank_g[i];
     const S2StreamWork w = work[act ? s : 0];
     int lo, hi;
     fe_sub_range(act ? w.count : 0, sub, nsub, lo, hi);
     const int n = hi - lo;
     S2StreamState* st = w.st;
-    f32x2* row = &ring[lane * GB_PITCH];
-    if (wave == 0)
+    f32x2* row = &ring[(lane % SPB) * GB_PITCH];
+    if (wave == 0 && lane < SPB)
         for (int k = 0; k < GARDNER_TAPS - 1; ++k) {     // the delay line = buffer indices 0..6 = slots 0..6 (and their mirror)
             const cf32 h = st->g_hist[k];
             row[k] = f32x2{h.re, h.im}; row[GB_RING + k] = f32x2{h.re, h.im};
@@ -664,7 +667,8 @@ __global__ __launch_bounds__(128) void s2_gardner_bank_kernel(const S2StreamWork
         // one load instruction fetches the period's samples (contiguous bytes) of SPI streams; all loads of a period are issued
         // back to back a period ahead (unconditional, clamped indices: a load behind a branch is waited for on the spot)
         constexpr int SPI = 64 / GB_T;                  // streams per load instruction
-        constexpr int NQ = 64 / SPI;                    // load instructions per array and period
+        static_assert(SPB % SPI == 0, "a load instruction serves whole groups of streams");
+        constexpr int NQ = SPB / SPI;                   // load instructions per array and period
         const int sub_s = lane / GB_T, smp = lane % GB_T;
         // the pointers and sample counts of this lane's NQ streams, fetched once from the lanes that own them (a stream without samples
         // in this slice may come with a null input pointer: the clamped loads then read the tap table)
@@ -2759,10 +2763,21 @@ hipError_t s2_post_stages_launch(const S2StreamWork* d_work, int nstreams, const
 // (s2_gardner_kernel); 2 = resolver + producer waves, 8 lanes per stream (s2_gardner2_kernel); 3 = lane per stream (s2_gardner_bank_kernel:
 // the fewest instructions in all); 4 = candidate tables (s2_gardner_cand_kernel: the shortest chain per stream -- what a small bank
 // needs: one stream 3.68 -> 2.5 ms per 21 690-sample slice against form 2; 64 streams x 1 frame 18.6 -> 16.7 ms per call, 256 x 4 frames
-// 50.3 -> 47.2).  Default: form 4 up to S2_GARDNER_CAND_MAX streams, form 2 below S2_GARDNER_BANK_MIN, form 1 from there on; DVBS2GPU_GARDNER_FORM=1|2|3|4 in the environment
-// forces one (development aid / the parity tests).
+// 50.3 -> 47.2).  Who wins where (round 4, MI355X, ms per step, front end | decoder in the step | step):
+//   4096 streams x 8 frames 8PSK 3/4 (decoder critical):  form 1  185 | 342 | 363     form 2  147 | 345 | 363     form 3  102 | 366 | 386
+//   4096 streams x 8 frames QPSK 1/2 (front end critical): form 1  283 | 337 | 465     form 2  297 | 356 | 410     form 3  146 | 365 | 396
+//   1024 streams x 4 frames 8PSK 3/4:                      form 1   71 |  48 |  76     form 2   60 |  49 |  65     form 3   65 |  51 |  71
+//    384 streams x 4 frames:                               form 1   65 |  19 |  67     form 2   52 |  18 |  54     form 3   58 |  19 |  60     form 4  51 | 19 | 53
+// Form 3 runs with 16 streams per workgroup (256 workgroups for 4096 streams: one per compute unit; DVBS2GPU_GARDNER_BANK_SPB=64: a full wave of
+// streams, 64 workgroups): it halves the timing recovery of a big bank and costs the co-resident decoder 20-25 ms per step, so it is taken only once
+// the balancer has found the front end to be the critical path.  Default: form 4 up to S2_GARDNER_CAND_MAX streams; form 2 below S2_GARDNER_BANK_MIN
+// and, up to S2_GARDNER_LANE_MIN streams, wherever the front end is critical; form 3 from S2_GARDNER_LANE_MIN streams on when the front end is critical;
+// form 1 for big banks beside a decoder that is.  DVBS2GPU_GARDNER_FORM=1|2|3|4 in the environment forces one (development aid / the parity tests).
 #ifndef S2_GARDNER_BANK_MIN
 #define S2_GARDNER_BANK_MIN 512
+#endif
+#ifndef S2_GARDNER_LANE_MIN
+#define S2_GARDNER_LANE_MIN 2048
 #endif
 #ifndef S2_GARDNER_CAND_MAX
 #define S2_GARDNER_CAND_MAX 256
@@ -2771,9 +2786,11 @@ static int gardner_form(int nstreams, int prio_duty) {
     static const int forced = [] { const char* e = getenv("DVBS2GPU_GARDNER_FORM"); return e ? atoi(e) : 0; }();
     if (forced >= 1 && forced <= 4) return forced;
     if (nstreams <= S2_GARDNER_CAND_MAX) return 4;
+    if (nstreams < S2_GARDNER_BANK_MIN) return 2;
     // a big bank beside the decoder of the previous call: the one-wave form disturbs the decoder least; once the balancer of the pipelined
-    // mode (s2_demod.hip) has found the FRONT END to be the critical path (it raises the timing loop's priority share), the shorter chain wins
-    return (nstreams < S2_GARDNER_BANK_MIN || prio_duty >= 2) ? 2 : 1;
+    // mode (s2_demod.hip) has found the FRONT END to be the critical path (it raises the timing loop's priority share), the shorter forms win
+    if (prio_duty < 2) return 1;
+    return nstreams >= S2_GARDNER_LANE_MIN ? 3 : 2;
 }
 static void gardner_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const float* d_bank, hipStream_t st, int c, int nsub) {
     switch (gardner_form(nstreams, coefs.g_prio_duty)) {
@@ -2782,7 +2799,12 @@ static void gardner_launch(const S2StreamWork* d_work, int nstreams, const S2Loo
             hipLaunchKernelGGL(s2_gardner_cand_kernel, dim3((nstreams + GC_CS - 1) / GC_CS), dim3(192), 0, st, d_work, nstreams, coefs, d_bank, c, nsub, skew);
             break;
         }
-        case 3: hipLaunchKernelGGL(s2_gardner_bank_kernel, dim3((nstreams + 63) / 64), dim3(128), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
+        case 3: {
+            static const int spb = [] { const char* e = getenv("DVBS2GPU_GARDNER_BANK_SPB"); return e ? atoi(e) : 16; }();
+            if (spb == 64) hipLaunchKernelGGL(s2_gardner_bank_kernel<64>, dim3((nstreams + 63) / 64), dim3(128), 0, st, d_work, nstreams, coefs, d_bank, c, nsub);
+            else hipLaunchKernelGGL(s2_gardner_bank_kernel<16>, dim3((nstreams + 15) / 16), dim3(128), 0, st, d_work, nstreams, coefs, d_bank, c, nsub);
+            break;
+        }
         case 2: hipLaunchKernelGGL(s2_gardner2_kernel, dim3((nstreams + G_SPW - 1) / G_SPW), dim3(128), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
         default: hipLaunchKernelGGL(s2_gardner_kernel, dim3((nstreams + G_SPW - 1) / G_SPW), dim3(64), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
     }

@@ -1,5 +1,6 @@
-"""The three forms of the timing-recovery kernel (csrc/s2_rx_kernels.hip: one wave with 8 lanes per stream, resolver + producer waves,
-lane per stream) are selected by bank size; every one must be bit-identical to the oracle.  The form is fixed per process
+"""The four forms of the timing-recovery kernel (csrc/s2_rx_kernels.hip: one wave with 8 lanes per stream, resolver + producer waves,
+lane per stream with 16 or 64 streams per workgroup, candidate tables) are selected by bank size and by which stream of the pipelined
+step is critical; every one must be bit-identical to the oracle.  The form is fixed per process
 (DVBS2GPU_GARDNER_FORM is read once), so each runs the chain tests that exercise the front end in a child process."""
 import os
 import subprocess
@@ -11,9 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('form', [1, 2, 3, 4])
-def test_chain_is_bit_identical_with_every_timing_recovery_form(form):
+@pytest.mark.parametrize('form,spb', [(1, None), (2, None), (3, '16'), (3, '64'), (4, None)])
+def test_chain_is_bit_identical_with_every_timing_recovery_form(form, spb):
     env = dict(os.environ, DVBS2GPU_GARDNER_FORM=str(form))
+    if spb:
+        env['DVBS2GPU_GARDNER_BANK_SPB'] = spb
     sel = 'front_end_is_bit_identical or time_sliced_front_end or tiny_and_empty or (demod_end_to_end_vs_oracle and (4-1-0 or 6-1-1 or 14-1-0))'
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_s2chain.py'), '-m', 'gpu', '-x', '-q', '-k', sel],
                        env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
