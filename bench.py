@@ -313,9 +313,9 @@ def cpu_baseline(block_iq, budget_s=12.0):
 
 
 # ------------------------------------------------------------------------------------------------ secondary configurations
-def secondary_s2(eng, pkg, dev, name, modcod, rate, short, pilots, esn0_db, S, F, steps):
+def secondary_s2(eng, pkg, dev, name, modcod, rate, short, pilots, esn0_db, S, F, steps, iters=ITERS, force=True):
     import torch
-    run = S2Run(eng, pkg, dev, modcod, short, pilots, esn0_db, S, F, DISTINCT, seed=50 + modcod)
+    run = S2Run(eng, pkg, dev, modcod, short, pilots, esn0_db, S, F, DISTINCT, seed=50 + modcod, iters=iters, force=force)
 
     def barrier():
         torch.cuda.synchronize()
@@ -326,6 +326,15 @@ def secondary_s2(eng, pkg, dev, name, modcod, rate, short, pilots, esn0_db, S, F
     dt, stages, acc = time_steps(run, steps, 8, barrier, True)
     k = ldpc_alone(eng, run.info, rate, short, S * F, dev)
     bpf = ITERS * 4 * run.info['ldpc_edges'] + run.info['ldpc_n'] + run.info['kbch'] // 8
+    if not force:
+        # the plugin's own mode (main.cpp:65: 16 trials, layered_decoder.hh:127: `while (bad() && --trials >= 0)`): the decoder's work depends on the
+        # channel, so the decoder-alone figures (50 forced iterations on noise) do not belong to this line
+        run.close()
+        torch.cuda.empty_cache()
+        return {'config': name, 'value': round(S * F * steps * run.sym / dt / 1e6, 1), 'unit': 'Msymbols/s', 'ms_per_step': round(dt / steps * 1e3, 2),
+                'streams': S, 'frames_per_stream_per_step': F, 'esn0_db': esn0_db, 'max_ldpc_trials': iters, 'early_exit': True,
+                'frames_delivered': acc['delivered'], 'frames_equal_to_transmitted': acc['equal'],
+                'stage_ms_per_step': {name: round(v[0] / steps, 2) for name, v in stages.items()}}
     out = {'config': name, 'value': round(S * F * steps * run.sym / dt / 1e6, 1), 'unit': 'Msymbols/s', 'ms_per_step': round(dt / steps * 1e3, 2),
            'streams': S, 'frames_per_stream_per_step': F, 'esn0_db': esn0_db, 'frames_delivered': acc['delivered'],
            'frames_equal_to_transmitted': acc['equal'], 'stage_ms_per_step': {name: round(v[0] / steps, 2) for name, v in stages.items()},
@@ -390,7 +399,7 @@ def secondary_dvbs(eng, pkg, dev):
         del bits, tso
         torch.cuda.empty_cache()
     # CPU (config 1): the whole chain of the oracle, one stream, one thread, bounded sample
-    from test_gpu_dvbs_tail import OracleTail
+    from orc_dvbs_tail import OracleTail
     rx, o = od.OracleQpskAlt(), od.L()
     sl, vit, otail = od.VP(o.orc_dvbs_slicer_create()), od.OracleViterbi(), OracleTail()
     t0 = time.perf_counter()
@@ -563,7 +572,7 @@ def pkg_distribute(pkg):
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--gpus', type=int, default=int(os.environ.get('WORLD_SIZE', '1')), help='ranks = GPUs of this node (default: WORLD_SIZE when a launcher set it, else 1)')
     ap.add_argument('--steps', type=int, default=40, help='timed steps (the timed region is bracketed by full synchronisations, so it holds one pipeline fill + drain: K calls cost about K + 1 step times)')
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', default='headline', choices=['headline', 'mixed64'])
@@ -718,6 +727,9 @@ def main():
         if world == 1 and not args.no_secondary:
             sec = []
             try:
+                sec.append(secondary_s2(eng, pkg, dev, 'headline workload in the PLUGIN\'s mode: 8PSK 3/4 normal FECFRAME, Es/N0 %.0f dB, max_ldpc_trials 16 with early exit '
+                                        '(reference src/main.cpp:65, layered_decoder.hh:127), syndrome check before every iteration' % ESN0_DB, MODCOD, RATE, SHORT, PILOTS, ESN0_DB,
+                                        S, F, 8, iters=16, force=False))
                 sec.append(secondary_s2(eng, pkg, dev, '2: DVB-S2 QPSK 1/2 normal FECFRAME (MODCOD 4), same channel conditions, Es/N0 8 dB', 4, 3, 0, 0, 8.0, 4096, 4, 8))
                 sec.append(secondary_s2(eng, pkg, dev, '5 stand-in: DVB-S2 32APSK 8/9 SHORT FECFRAME + pilots (MODCOD 27; 9/10 short does not exist), Es/N0 20 dB', 27, 9, 1, 1, 20.0, 2048, 16, 8))
                 sec.append(secondary_dvbs(eng, pkg, dev))

@@ -41,6 +41,12 @@ static int stage_enter(dvbs2gpu_ctx* ctx, hipStream_t st) {
     return ws_acquire(ctx, st);
 }
 
+// every device table of one code (hipFree(nullptr) is a no-op)
+void free_ldpc_code(LdpcDeviceCode& D) {
+    (void)hipFree(D.d_layers); (void)hipFree(D.d_ents); (void)hipFree(D.d_rows); (void)hipFree(D.d_atab);
+    (void)hipFree(D.d_wave_lanec); (void)hipFree(D.d_wave_steps); (void)hipFree(D.d_wave_layer_end);
+    D.d_layers = nullptr; D.d_ents = D.d_rows = D.d_atab = D.d_wave_lanec = D.d_wave_layer_end = nullptr; D.d_wave_steps = nullptr;
+}
 int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
     std::lock_guard<std::mutex> l(ctx->mtx);
     auto it = ctx->ldpc.find(code_index);
@@ -50,19 +56,20 @@ int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
         D.code_index = code_index;
         D.N = P.N; D.K = P.K; D.R = P.R; D.q = P.q; D.max_deg = P.max_deg; D.irregular = (P.min_deg != P.max_deg); D.rec_dwords = P.rec_dwords; D.edges = P.edges; D.pent_base = P.pent_base; D.synd_base = P.synd_base;
         int rc;
-        if ((rc = upload(P.layers, &D.d_layers))) return rc;
-        if ((rc = upload(P.ents, &D.d_ents))) return rc;
-        if ((rc = upload(P.rows, &D.d_rows))) return rc;
-        if (!P.atab.empty() && (rc = upload(P.atab, &D.d_atab))) return rc;
+        auto fail = [&D](int e) { free_ldpc_code(D); return e; };      // (a failed upload gives the earlier ones back)
+        if ((rc = upload(P.layers, &D.d_layers))) return fail(rc);
+        if ((rc = upload(P.ents, &D.d_ents))) return fail(rc);
+        if ((rc = upload(P.rows, &D.d_rows))) return fail(rc);
+        if (!P.atab.empty() && (rc = upload(P.atab, &D.d_atab))) return fail(rc);
         D.blocks_per_cu = ldpc_blocks_per_cu(P.max_deg, D.irregular, P.N);
         if (P.N <= 16200) {
             // short frames also get the wave-per-frame plan; which decoder serves the code: ldpc_wave_default() (measured per code),
             // DVBS2GPU_LDPC_WAVE=0|1 in the environment forces one (development aid / the parity tests run both)
             const LdpcWavePlan W = build_ldpc_wave_plan(P);
             D.wave_lw = W.lw; D.wave_nsteps = W.nsteps; D.wave_nl_min = W.nl_min; D.wave_absent_base = W.absent_base;
-            if ((rc = upload(W.lanec, &D.d_wave_lanec))) return rc;
-            if ((rc = upload(W.steps, &D.d_wave_steps))) return rc;
-            if ((rc = upload(W.layer_end, &D.d_wave_layer_end))) return rc;
+            if ((rc = upload(W.lanec, &D.d_wave_lanec))) return fail(rc);
+            if ((rc = upload(W.steps, &D.d_wave_steps))) return fail(rc);
+            if ((rc = upload(W.layer_end, &D.d_wave_layer_end))) return fail(rc);
             const char* e = getenv("DVBS2GPU_LDPC_WAVE");
             D.use_wave = e ? atoi(e) != 0 : ldpc_wave_default(code_index);
         }
@@ -279,9 +286,7 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    for (auto& kv : ctx->ldpc) {
-        (void)hipFree(kv.second.d_layers); (void)hipFree(kv.second.d_ents); (void)hipFree(kv.second.d_rows);
-    }
+    for (auto& kv : ctx->ldpc) free_ldpc_code(kv.second);
     for (auto& kv : ctx->bch) {
         (void)hipFree(kv.second.d_log); (void)hipFree(kv.second.d_exp); (void)hipFree(kv.second.d_imap); (void)hipFree(kv.second.d_syn_tab);
     }

@@ -848,7 +848,7 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
                 b = __builtin_bswap64(__brevll(b));
                 if (lane == 0) {
                     int nbytes = min(8, (K - base) / 8);
-                    if (nbytes == 8) *reinterpret_cast<uint2*>(hd + base / 8) = make_uint2((uint32_t)b, (uint32_t)(b >> 32));
+                    if (nbytes == 8 && ((uintptr_t)(hd + base / 8) & 7u) == 0) *reinterpret_cast<uint2*>(hd + base / 8) = make_uint2((uint32_t)b, (uint32_t)(b >> 32));   // (a caller's stride need not be a multiple of 8)
                     else for (int n = 0; n < nbytes; ++n) hd[base / 8 + n] = (uint8_t)(b >> (8 * n));
                 }
             }

@@ -264,7 +264,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ld
             b = __builtin_bswap64(__brevll(b));
             if (lane == 0) {
                 const int nbytes = min(8, (K - base) / 8);
-                if (nbytes == 8) *reinterpret_cast<uint2*>(hd + base / 8) = make_uint2((uint32_t)b, (uint32_t)(b >> 32));
+                // (K / 8 is odd for three of the codes this decoder serves, and a caller's stride need not be a multiple of 8: the 8-byte store only where it is aligned)
+                if (nbytes == 8 && ((uintptr_t)(hd + base / 8) & 7u) == 0) *reinterpret_cast<uint2*>(hd + base / 8) = make_uint2((uint32_t)b, (uint32_t)(b >> 32));
                 else for (int n = 0; n < nbytes; ++n) hd[base / 8 + n] = (uint8_t)(b >> (8 * n));
             }
         }

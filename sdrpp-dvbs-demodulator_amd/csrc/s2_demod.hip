@@ -724,7 +724,13 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     }
     if (prev && !prev_delivered) {
         const auto t_d0 = std::chrono::steady_clock::now();
-        if ((rc = deliver(prev))) return rc;      // FEC of the previous call (ran during this call's front end)
+        if ((rc = deliver(prev))) {               // FEC of the previous call (ran during this call's front end)
+            // this call's job is already on the device: it stays parked for the next call (or reset) to collect -- dropping it here would free
+            // buffers its kernels are still using and lose the call's frames behind the previous job's error
+            if (started && !deliver_now) ctx->pending_fec[slot] = started.release();
+            else if (started) (void)hipDeviceSynchronize();     // (a job that would have been collected by this very call: let it end before its buffers go)
+            return rc;
+        }
         hm.mark("prev_delivered");
         // Balance of the two streams: did this call have to wait for the previous call's FEC job (the decoder is the critical path: the timing
         // loop should yield more) or was the job long done (the front end is: it should yield less)?  One step of the priority duty per two

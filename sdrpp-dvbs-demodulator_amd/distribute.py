@@ -116,12 +116,15 @@ class Distributor:
             out[idx] = payload
             cnt[idx] = counts
             return out, cnt
-        # one all-reduce agrees on the row count AND the row width: a rank without local units may have passed an empty / 1-D payload
-        nmax = torch.tensor([len(local_ids), width], dtype=torch.int64, device=self.device)
+        # one all-reduce agrees on the row count AND the row width: a rank without local units may have passed an empty / 1-D payload.  The
+        # verdict on the widths is COLLECTIVE (the smallest width of a rank that has rows travels as a negated maximum): every rank raises, or
+        # none -- a rank that raised alone would leave the others waiting in the gathers below
+        big = 1 << 40
+        nmax = torch.tensor([len(local_ids), width, -(width if len(local_ids) else big)], dtype=torch.int64, device=self.device)
         self.dist.all_reduce(nmax, op=self.dist.ReduceOp.MAX)
-        nmax, wmax = int(nmax[0].item()), int(nmax[1].item())
-        if len(local_ids) and width != wmax:
-            raise ValueError('gather_units: payload rows are %d bytes wide here, %d on another rank' % (width, wmax))
+        nmax, wmax, wmin = int(nmax[0].item()), int(nmax[1].item()), -int(nmax[2].item())
+        if wmin != big and wmin != wmax:
+            raise ValueError('gather_units: payload rows are %d bytes wide on one rank and %d on another (%d here)' % (wmin, wmax, width))
         width = wmax
         pad = torch.zeros((nmax, width), dtype=torch.uint8, device=self.device)
         meta = torch.full((nmax, 2), -1, dtype=torch.int32, device=self.device)

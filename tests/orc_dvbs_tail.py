@@ -5,6 +5,7 @@ import ctypes as C
 import numpy as np
 from orc import lib, ref
 from orc_dvbs import P, VP
+import orc_dvbs as _od
 
 _b = False
 
@@ -114,3 +115,32 @@ def dvbs_outer_tx(npackets, seed):
     inter, _ = forney_interleave(coded.reshape(-1))
     bits = np.unpackbits(inter)
     return bits, ts
+
+
+class OracleTail:
+    """DVBSDemod::process after vit.process, frame k at stride 1632 (SURVEY Q5)"""
+
+    def __init__(self):
+        self.o, self.ol = L(), _od.L()
+        self.hd, self.hf = VP(self.o.orc_tsdef_create()), VP(self.ol.orc_forney_create())
+        self.hr, self.hs = VP(self.o.orc_dvbsrs_create()), VP(self.o.orc_dvbsdescr_create())
+        self.last_rs = [0] * 8
+        self.errs = np.zeros(2, np.int32)
+
+    def process(self, bits):
+        bits = np.ascontiguousarray(bits, np.uint8)
+        frames = np.zeros(1632 * (bits.size // 13056 + 4), np.uint8)
+        nf = self.o.orc_tsdef_work(self.hd, P(bits), bits.size, P(frames), P(self.errs)) if bits.size else 0
+        out = []
+        for k in range(nf):
+            f = np.ascontiguousarray(frames[1632 * k:1632 * (k + 1)])
+            d = np.zeros(1632, np.uint8)
+            self.ol.orc_forney_deinterleave(self.hf, P(f), P(d))
+            for i in range(8):
+                pkt = np.ascontiguousarray(d[204 * i:204 * (i + 1)])
+                self.last_rs[i] = self.o.orc_dvbsrs_decode(self.hr, P(pkt))
+                d[204 * i:204 * i + 188] = pkt[:188]
+            self.o.orc_dvbsdescr_work(self.hs, P(d))
+            for i in range(8):
+                out.append(d[204 * i:204 * i + 188].copy())
+        return (np.concatenate(out) if out else np.zeros(0, np.uint8)), nf

@@ -73,6 +73,14 @@ def _worker(rank, world, port, q):
     st_out, _ = dd.gather_units(mine, st_payload, torch.full((len(mine),), 8 * FRAMES, dtype=torch.int32), len(table))
     tmax = dd.max_over_ranks(len(mine))
     dd.barrier()
+    # an argument error on ONE rank (rows of a different width) must surface on EVERY rank, before anybody enters the gathers
+    try:
+        dd.gather_units([rank], torch.zeros((1, 5 if rank == 1 else 4), dtype=torch.uint8), torch.tensor([1], dtype=torch.int32), 2)
+        raised = False
+    except ValueError:
+        raised = True
+    dd.barrier()
+    q.put(('raised', rank, raised))
     if rank == 0:
         q.put((assign, out.numpy(), cnt.numpy(), st_out.numpy().view(np.int32), tmax))
     dist.destroy_process_group()
@@ -88,8 +96,10 @@ def test_two_ranks_broadcast_assign_gather_reassemble():
     port = _free_port()
     ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in ps]
-    assign, out, cnt, st, tmax = q.get(timeout=180)
+    got = [q.get(timeout=180) for _ in range(world + 1)]
     [p.join(60) for p in ps]
+    assert sorted(x[1:] for x in got if x[0] == 'raised') == [(0, True), (1, True)]      # the width mismatch was reported by both ranks
+    assign, out, cnt, st, tmax = [x for x in got if x[0] != 'raised'][0]
     assert all(p.exitcode == 0 for p in ps)
     # every unit exactly once, balanced to within one unit (9 equal-weight units of three codes on two ranks: a code group is split
     # only because the balance demands it; test_assignment_helpers shows the exclusive case)
@@ -126,6 +136,18 @@ def test_assignment_helpers(pkg):
             for i in idx:
                 owner.setdefault(table[i]['modcod'], set()).add(r)
         assert all(len(v) == 1 for v in owner.values()), (world, owner)
+        loads = [sum(table[i]['weight'] for i in idx) for idx in a]
+        assert max(loads) <= 1.25 * (sum(loads) / world), (world, loads)
+    # the table bench.py --config mixed64 really builds (weights = LDPC edges x iterations + 40 x PLFRAME symbols of each MODCOD)
+    import bench
+    table = []
+    for t in range(64):
+        m = bench.MIXED_MODCODS[t % len(bench.MIXED_MODCODS)]
+        info = pkg.modcod_info(m, False, False)
+        table.append(dict(id=t, modcod=m, weight=float(info['ldpc_edges']) * bench.ITERS + 40.0 * info['plframe_symbols']))
+    for world in (2, 4, 8):
+        a = D.assign_transponders(table, world)
+        assert sorted(sum(a, [])) == list(range(64))
         loads = [sum(table[i]['weight'] for i in idx) for idx in a]
         assert max(loads) <= 1.25 * (sum(loads) / world), (world, loads)
     # more ranks than MODCOD groups: groups are split, every rank gets work
