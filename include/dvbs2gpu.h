@@ -222,9 +222,13 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
 /* Throughput mode for dvbs2gpu_demod_process_batch: with `on` != 0 the FEC (LDPC, BCH, descrambler) of call k runs on its own
  * HIP stream while call k+1 runs the front end, PL sync and frame loops of the next samples; the BBFRAMEs (and stats) of call
  * k are delivered by call k+1 into ITS output buffers (the reference delivers frames late as well: it holds them until 16 have
- * queued, module_dvbs2_demod.cpp:343-347).  Needs the same streams in the same order on every call; streams of different
- * configurations may share the batch (one FEC job per configuration group and call, at most 16 groups).  A call with all
- * counts 0 collects the last frames; switching the mode off drops uncollected ones. */
+ * queued, module_dvbs2_demod.cpp:343-347).  The streams of a batch may change from call to call (transponders come and go, in any
+ * order): a job is collected into the buffers of those of ITS streams that are part of the collecting call; a stream that joins has
+ * nothing pending; the frames of a stream that is absent from the call after its own are dropped (pass it with count 0 once more
+ * to collect them).  Streams of different configurations may share the batch (one FEC job per configuration group and call, at
+ * most 16 groups); ACM/VCM streams too (one job per LDPC code present in the call, BBFRAMEs of differing size: per-frame sizes in
+ * dvbs2gpu_frame_stats.bbframe_bytes).  A call with all counts 0 collects the last frames; switching the mode off drops
+ * uncollected ones. */
 int dvbs2gpu_set_pipelined(dvbs2gpu_ctx* ctx, int on);
 
 /* Stats of the frames completed by the last process call of this handle (the public fields the GUI polls,

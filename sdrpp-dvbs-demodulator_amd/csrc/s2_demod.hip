@@ -16,6 +16,7 @@
 #include "ctx.h"
 #include "../../include/dvbs2gpu_math.h"
 #include <list>
+#include <unordered_map>
 #include <thread>
 #include <cmath>
 #include <algorithm>
@@ -306,6 +307,7 @@ int demod_configure(dvbs2gpu_demod* d) {
         last_error() = "loop gains must be finite"; return DVBS2GPU_ERR_ARG;
     }
     S2LoopCoefs& co = d->co;
+    co.g_prio_duty = 0; co.g_lane_form = 0;       // (scheduling hints: set per call by the pipelined mode's balancer)
     co.agc_rate = c.agc_rate;
     co.g_alpha = c.clock_mu_gain; co.g_beta = c.clock_omega_gain;
     co.g_min_freq = (float)(1.0 * (1.0 - c.omega_rel_limit)); co.g_max_freq = (float)(1.0 * (1.0 + c.omega_rel_limit));
@@ -332,19 +334,110 @@ int demod_reset_state(dvbs2gpu_demod* d) {
 
 // Runs one group of streams that share (modcod, shortframes, pilots) and loop coefficients.
 // FEC job launched by one pipelined call and delivered by the next
+// The FEC job of a pipelined call, collected by the next call (or by a later one, or dropped when the mode is switched off).
+// CCM groups: one job = one LDPC code, frames stream-major, every BBFRAME kb bytes.  ACM/VCM groups: one part per LDPC code present in the
+// call (frames of a part = pooled frame indices idx[]), BBFRAMEs of different sizes at per-frame byte offsets inside their stream's output.
 struct PendingFec {
     int n = 0, nf = 0, kb = 0;
-    std::vector<dvbs2gpu_demod*> dm;
-    std::vector<int> first;
-    std::vector<S2FrameStats> hstats;
+    std::vector<dvbs2gpu_demod*> dm;    // the streams of the call that started the job (its stream indices are positions in this list)
+    std::vector<int> first;             // [n + 1] pooled frames per stream
+    std::vector<S2FrameStats> hstats;   // [nf]
     std::vector<std::vector<float>> frame_bm;
     const S2FrameRef* d_frames = nullptr;
     const int* d_first = nullptr;
     const uint8_t* d_bb = nullptr;
-    const int32_t* d_trials = nullptr;
+    const int32_t* d_trials = nullptr;  // CCM: [nf]; ACM/VCM: per part trials[cnt] ++ corrections[cnt] at part.to
     const int32_t* d_corr = nullptr;
+    // ACM/VCM
+    struct Part { int kb, cnt; const uint8_t* d_bb; const int* d_idx; size_t to; };
+    bool vcm = false;
+    std::vector<Part> parts;
+    std::vector<int> frame_off;         // [nf] byte offset of the frame's BBFRAME inside its stream's output, -1: none (dummy PLFRAME)
+    std::vector<int> frame_tr, frame_co;   // [nf] index of the frame's trial count / correction count in the job's result array, -1: none
+    std::vector<int> stream_bytes;      // [n]
+    uint8_t** d_dst = nullptr;          // [nf] device table of the frames' destinations, filled by the delivery
+    size_t n_results = 0;               // int32 words in d_trials (ACM/VCM)
     hipEvent_t done = nullptr;          // recorded on the FEC stream behind the job
 };
+
+// the streams of the whole batch a pipelined call works on: a job is collected into the buffers of whichever of ITS streams are part of this batch
+// -- in any order, in any configuration group; frames of a stream that has left are dropped (collect them with a zero-count call before it leaves)
+struct BatchMap {
+    std::unordered_map<const dvbs2gpu_demod*, int> pos;
+    uint8_t* const* d_out = nullptr;
+    int* out_bytes = nullptr;
+    int out_cap = 0;
+};
+
+// results of a finished (or finishing) job -> the callers' output buffers and the per-frame stats of its streams.  `wo`: a scratch workspace of the caller's
+static int deliver_job(dvbs2gpu_ctx* ctx, PendingFec* job, hipStream_t st, Workspace& wo, const BatchMap& bm) {
+    HIP_TRY(hipStreamWaitEvent(st, job->done, 0));
+    int rc2;
+    std::vector<int> where(job->n, -1);
+    for (int i = 0; i < job->n; ++i) {
+        auto it = bm.pos.find(job->dm[i]);
+        if (it != bm.pos.end()) where[i] = it->second;
+    }
+    std::vector<int32_t> res;
+    if (!job->vcm) {
+        std::vector<uint8_t*> outs(job->n, nullptr);
+        for (int i = 0; i < job->n; ++i) {
+            if (where[i] < 0) continue;
+            const int bytes = (job->first[i + 1] - job->first[i]) * job->kb;
+            if (bytes > bm.out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
+            outs[i] = bm.d_out[where[i]];
+            bm.out_bytes[where[i]] = bytes;
+        }
+        if ((rc2 = wo.ensure(sizeof(uint8_t*) * job->n))) return rc2;
+        HIP_TRY(hipMemcpyAsync(wo.p, outs.data(), sizeof(uint8_t*) * job->n, hipMemcpyHostToDevice, st));
+        res.resize(2 * (size_t)job->nf);
+        HIP_TRY(hipMemcpyAsync(res.data(), job->d_trials, sizeof(int32_t) * job->nf, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(res.data() + job->nf, job->d_corr, sizeof(int32_t) * job->nf, hipMemcpyDeviceToHost, st));
+        { StageSpan sp(ctx->timers, ST_DELIVER, st); HIP_TRY(s2_scatter_out2_launch((uint8_t* const*)wo.p, job->d_frames, job->d_first, job->nf, job->kb, job->d_bb, st)); }
+        HIP_TRY(hipStreamSynchronize(st));      // (also: `outs` was copied from pageable memory)
+        for (int i = 0; i < job->n; ++i) {
+            if (where[i] < 0) continue;
+            dvbs2gpu_demod* d = job->dm[i];
+            d->stats.clear();
+            for (int f = job->first[i]; f < job->first[i + 1]; ++f) {
+                S2FrameStats s = job->hstats[f];
+                s.best_match = job->frame_bm[i][f - job->first[i]];
+                s.ldpc_trials = res[f]; s.bch_corr = res[job->nf + f]; s.bbframe_bytes = job->kb;
+                d->stats.push_back(s);
+            }
+        }
+        return 0;
+    }
+    // ACM/VCM: per-frame destinations
+    std::vector<uint8_t*> dst(job->nf, nullptr);
+    for (int i = 0; i < job->n; ++i) {
+        if (where[i] < 0) continue;
+        if (job->stream_bytes[i] > bm.out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
+        bm.out_bytes[where[i]] = job->stream_bytes[i];
+        for (int f = job->first[i]; f < job->first[i + 1]; ++f)
+            if (job->frame_off[f] >= 0) dst[f] = bm.d_out[where[i]] + job->frame_off[f];
+    }
+    if (job->nf) HIP_TRY(hipMemcpyAsync(job->d_dst, dst.data(), sizeof(uint8_t*) * job->nf, hipMemcpyHostToDevice, st));
+    res.resize(job->n_results);
+    if (job->n_results) HIP_TRY(hipMemcpyAsync(res.data(), job->d_trials, sizeof(int32_t) * job->n_results, hipMemcpyDeviceToHost, st));
+    for (const PendingFec::Part& P : job->parts) {
+        StageSpan sp(ctx->timers, ST_DELIVER, st);
+        HIP_TRY(s2_vcm_scatter_launch(P.d_idx, P.cnt, P.kb, P.d_bb, job->d_dst, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < job->n; ++i) {
+        if (where[i] < 0) continue;
+        dvbs2gpu_demod* d = job->dm[i];
+        d->stats.clear();
+        for (int f = job->first[i]; f < job->first[i + 1]; ++f) {
+            S2FrameStats s = job->hstats[f];
+            s.ldpc_trials = job->frame_tr[f] >= 0 ? res[job->frame_tr[f]] : 0;
+            s.bch_corr = job->frame_co[f] >= 0 ? res[job->frame_co[f]] : 0;
+            d->stats.push_back(s);
+        }
+    }
+    return 0;
+}
 
 // development aid: DVBS2GPU_HOST_TIMING=1 prints where the HOST spends a call (ms since entry at each mark)
 // AGC/NCO + timing recovery of a batch, time-sliced over the caller's stream and its auxiliary stream (ctx.h FeAux, created on first use)
@@ -357,6 +450,8 @@ static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work,
     if (nsub_out) *nsub_out = nsub > 1 ? nsub : 1;
     S2LoopCoefs cc = co;
     cc.g_prio_duty = ctx->pipeline_fec ? ctx->g_prio_duty : 0;
+    if (cc.g_prio_duty >= 3) ctx->g_lane_form = true; else if (cc.g_prio_duty == 0) ctx->g_lane_form = false;
+    cc.g_lane_form = ctx->g_lane_form ? 1 : 0;
     dvbs2gpu_ctx::FeAux* fa = nullptr;
     if (nsub > 1) {
         std::lock_guard<std::mutex> l(ctx->mtx);
@@ -396,7 +491,7 @@ struct PreSlices { const hipEvent_t* ev; int nsub; };
 
 int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts,
                   uint8_t* const* d_out, int out_cap, int* out_bytes, hipStream_t st, bool pipelined, int slot, const int* pre_nsym, bool own_ws, bool deliver_now,
-                  const PreSlices* pre = nullptr) {
+                  const PreSlices* pre = nullptr, const BatchMap* bm = nullptr) {
     HostMarks hm;
     const auto t_entry = std::chrono::steady_clock::now();
     dvbs2gpu_demod* d0 = dm[0];
@@ -426,7 +521,8 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         work[i].fifo = d->d_fifo[d->fifo_cur]; work[i].fifo_fill = d->fifo_fill; work[i].st = d->d_state;
         work[i].fifo_next = d->d_fifo[d->fifo_cur ^ 1]; work[i].out = d_out[i]; work[i].spec_out = d->d_spec;
         max_count = std::max(max_count, counts[i]);
-        d->stats.clear(); d->frame_ptrs.clear(); d->frame_pos.clear();
+        if (!pipelined) d->stats.clear();        // (pipelined: dvbs2gpu_demod_process_batch has cleared them -- another group's thread may be delivering this stream's frames)
+        d->frame_ptrs.clear(); d->frame_pos.clear();
     }
     Workspace& ws_work = W[0];
     if ((rc = ws_work.ensure(sizeof(S2StreamWork) * n + sizeof(int) * (n + 1) + sizeof(int) * 4 * n + 64))) return rc;
@@ -630,45 +726,17 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     // Jobs of all groups run in order on the FEC stream; each is followed by its own event, and the delivery (scatter into the
     // caller's buffers) runs on the front-end stream behind that event, so it never queues behind a later group's decoder.
     hipStream_t sf = ctx->fec_stream;
-    for (int i = 0; i < n; ++i) out_bytes[i] = 0;
-    // results of a finished (or finishing) job -> the caller's output buffers and the per-frame stats of its streams
-    auto deliver = [&](PendingFec* job) -> int {
-        HIP_TRY(hipStreamWaitEvent(st, job->done, 0));
-        Workspace& wo = W[6];
-        int rc2;
-        if ((rc2 = wo.ensure(sizeof(uint8_t*) * n))) return rc2;
-        HIP_TRY(hipMemcpyAsync(wo.p, d_out, sizeof(uint8_t*) * n, hipMemcpyHostToDevice, st));
-        std::vector<int32_t> ptr(job->nf), pco(job->nf);
-        HIP_TRY(hipMemcpyAsync(ptr.data(), job->d_trials, sizeof(int32_t) * job->nf, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(pco.data(), job->d_corr, sizeof(int32_t) * job->nf, hipMemcpyDeviceToHost, st));
-        for (int i = 0; i < n; ++i) {
-            int bytes = (job->first[i + 1] - job->first[i]) * job->kb;
-            if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
-            out_bytes[i] = bytes;
-        }
-        { StageSpan sp(ctx->timers, ST_DELIVER, st); HIP_TRY(s2_scatter_out2_launch((uint8_t* const*)wo.p, job->d_frames, job->d_first, job->nf, job->kb, job->d_bb, st)); }
-        HIP_TRY(hipStreamSynchronize(st));
-        for (int i = 0; i < n; ++i) {
-            dm[i]->stats.clear();
-            for (int f = job->first[i]; f < job->first[i + 1]; ++f) {
-                S2FrameStats s = job->hstats[f];
-                s.best_match = job->frame_bm[i][f - job->first[i]];
-                s.ldpc_trials = ptr[f]; s.bch_corr = pco[f]; s.bbframe_bytes = job->kb;
-                dm[i]->stats.push_back(s);
-            }
-        }
-        return 0;
-    };
+    // (out_bytes of a pipelined call are written by the deliveries alone, through the batch map: the job a slot holds may belong to other streams of the batch)
+    BatchMap bm_local;
+    if (!bm) {
+        for (int i = 0; i < n; ++i) { bm_local.pos[dm[i]] = i; out_bytes[i] = 0; dm[i]->stats.clear(); }
+        bm_local.d_out = d_out; bm_local.out_bytes = out_bytes; bm_local.out_cap = out_cap;
+        bm = &bm_local;
+    }
+    auto deliver = [&](PendingFec* job) -> int { return deliver_job(ctx, job, st, W[6], *bm); };
     PendingFec* prev = (PendingFec*)ctx->pending_fec[slot];
     ctx->pending_fec[slot] = nullptr;
     std::unique_ptr<PendingFec> prev_guard(prev);
-    if (prev) {
-        if (prev->n != n || memcmp(prev->dm.data(), dm, sizeof(dvbs2gpu_demod*) * n) != 0) {
-            HIP_TRY(hipStreamSynchronize(sf));
-            last_error() = "pipelined mode needs the same streams in the same order on every call";
-            return DVBS2GPU_ERR_ARG;
-        }
-    }
     // This call's job goes onto the FEC stream BEFORE the previous call's job is delivered: the stream then runs decoder launch after decoder
     // launch with no host in between (delivered first, a headline step left the FEC stream idle for ~5 ms: the scatter, its copies and the
     // synchronisation of the delivery).  The two jobs use the two halves of the double-buffered FEC workspaces and an event each.
@@ -747,8 +815,6 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
                 ctx->g_prio_trend = verdict;
             }
         }
-    } else if (!prev) {
-        for (int i = 0; i < n; ++i) dm[i]->stats.clear();
     }
     if (started) {
         if (deliver_now) {
@@ -804,7 +870,7 @@ int get_vcm_tables(dvbs2gpu_ctx* ctx) {
 // pooling, grouping by LDPC code] -> per-frame-MODCOD loops + demapper -> one FEC job per code present -> BBFRAMEs of differing size
 // into the streams' output buffers in frame order.
 int process_vcm_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts, uint8_t* const* d_out,
-                      int out_cap, int* out_bytes, hipStream_t st) {
+                      int out_cap, int* out_bytes, hipStream_t st, bool pipelined = false, int slot = 0, const BatchMap* bm = nullptr) {
     dvbs2gpu_demod* d0 = dm[0];
     int rc;
     if ((rc = get_rx_tables(ctx)) || (rc = get_vcm_tables(ctx))) return rc;
@@ -821,7 +887,8 @@ int process_vcm_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const
         work[i].fifo_next = d->d_fifo[d->fifo_cur ^ 1]; work[i].out = d_out[i]; work[i].spec_out = d->d_spec;
         max_count = std::max(max_count, counts[i]);
         maxf = std::max(maxf, d->fifo_cap / VCM_DUMMY_PLFRAME + 2);
-        d->stats.clear(); d->frame_ptrs.clear(); d->frame_pos.clear(); d->frame_len.clear();
+        if (!pipelined) d->stats.clear();
+        d->frame_ptrs.clear(); d->frame_pos.clear(); d->frame_len.clear();
         d->tap_pll = nullptr; d->tap_llr = nullptr; d->tap_pll_count = 0; d->tap_llr_count = 0;
     }
     if ((rc = W[0].ensure(sizeof(S2StreamWork) * n + sizeof(int) * (n + 1) + sizeof(int) * 8 * n + sizeof(float) * n + 64))) return rc;
@@ -846,6 +913,7 @@ int process_vcm_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const
     std::vector<S2VcmFrame> frames;
     std::vector<int> first(n + 1, 0);
     std::vector<uint8_t*> dst;                     // per pooled frame: where its BBFRAME goes
+    std::vector<int> frame_off, stream_bytes(n, 0);   // (pipelined: the same as offsets -- the buffers are those of the call that collects the job)
     std::map<int, std::vector<int>> groups;        // PLS-independent FEC identity (code index * 2 + frame size is implied by the index) -> pooled frame indices
     std::map<int, int> group_pls;                  // a PLS code of the group (its FEC parameters)
     long long pll_off = 0, llr_off = 0;
@@ -870,21 +938,25 @@ int process_vcm_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const
                 group_pls[M.code_index] = F.pls;
                 if (obytes + M.kb > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
                 dst.push_back(d_out[i] + obytes);
+                frame_off.push_back(obytes);
                 obytes += M.kb;
                 pll_off += M.plframe; llr_off += M.N;
                 d->tap_pll_count += M.plframe; d->tap_llr_count += M.N;
             } else {
                 dst.push_back(nullptr);
+                frame_off.push_back(-1);
             }
             d->frame_ptrs.push_back(fr.sym); d->frame_len.push_back(M.plframe); d->frame_pos.push_back(d->sym_base + F.offset);
             frames.push_back(fr);
         }
-        out_bytes[i] = obytes;
+        stream_bytes[i] = obytes;
+        if (!pipelined) out_bytes[i] = obytes;
     }
     first[n] = (int)frames.size();
     const int nf = (int)frames.size();
     std::vector<S2FrameStats> hstats(nf);
     std::vector<int32_t> trials(nf, 0), corr(nf, 0);
+    std::unique_ptr<PendingFec> job_started;
     if (nf > 0) {
         if ((rc = W[2].ensure(sizeof(S2VcmFrame) * nf + sizeof(S2FrameStats) * nf + sizeof(uint8_t*) * nf + sizeof(int) * nf + 64))) return rc;
         S2VcmFrame* d_frames = (S2VcmFrame*)W[2].p;
@@ -913,30 +985,79 @@ int process_vcm_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const
             const FecParams& f = ctx->h_vcm_fec[group_pls[kv.first]];
             llr_need += (size_t)kv.second.size() * f.N; bb_need += (size_t)kv.second.size() * (f.kbch / 8 + 8);
         }
-        if ((rc = W[5].ensure(llr_need + 64)) || (rc = W[6].ensure(bb_need + 64)) || (rc = W[7].ensure(sizeof(int32_t) * 2 * all_idx.size() + 64))) return rc;
+        // pipelined: the job's buffers are the slot's double-buffered FEC workspaces (the next call reuses ws_vcm while the job runs):
+        // LLR groups | BBFRAME groups | results (trials ++ corrections per part) + the parts' frame index lists + the destination table
+        const int par = pipelined ? ctx->fec_parity[slot] : 0;
+        Workspace& ws_gl = pipelined ? ctx->ws_fecbuf[slot][par][0] : W[5];
+        Workspace& ws_gb = pipelined ? ctx->ws_fecbuf[slot][par][1] : W[6];
+        Workspace& ws_gt = pipelined ? ctx->ws_fecbuf[slot][par][2] : W[7];
+        const size_t nall = all_idx.size();
+        const size_t res_bytes = (sizeof(int32_t) * 2 * nall + 63) & ~(size_t)63, idx_bytes = (sizeof(int) * nall + 63) & ~(size_t)63;
+        if ((rc = ws_gl.ensure(llr_need + 64)) || (rc = ws_gb.ensure(bb_need + 64)) || (rc = ws_gt.ensure(res_bytes + idx_bytes + sizeof(uint8_t*) * nf + 64))) return rc;
+        int* j_idx = (int*)((char*)ws_gt.p + res_bytes);
+        if (pipelined) {
+            HIP_TRY(hipMemcpyAsync(j_idx, all_idx.data(), sizeof(int) * nall, hipMemcpyHostToDevice, st));
+            if (!ctx->ev_llr) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_llr, hipEventDisableTiming));
+        }
         size_t lo = 0, bo = 0, to = 0;
         struct Out { int code; size_t to; int cnt; };
         std::vector<Out> outs;
+        std::vector<PendingFec::Part> parts;
+        struct Run { FecParams f; int8_t* llr; int cnt; uint8_t* bb; int32_t* tr; };
+        std::vector<Run> runs;
         for (auto& kv : groups) {
             const FecParams& f = ctx->h_vcm_fec[group_pls[kv.first]];
             const int cnt = (int)kv.second.size(), kb = f.kbch / 8;
-            int8_t* g_llr = (int8_t*)W[5].p + lo;
-            uint8_t* g_bb = (uint8_t*)W[6].p + bo;
-            int32_t* g_tr = (int32_t*)W[7].p + to;
+            int8_t* g_llr = (int8_t*)ws_gl.p + lo;
+            uint8_t* g_bb = (uint8_t*)ws_gb.p + bo;
+            int32_t* g_tr = (int32_t*)ws_gt.p + to;
             HIP_TRY(s2_vcm_gather_launch(d_frames, d_idx + off_idx, cnt, f.N, d_llr, g_llr, st));
-            if ((rc = fec_run(ctx, f, g_llr, cnt, mt, force, g_bb, g_tr, g_tr + cnt, st))) return rc;
-            // the group's index list, re-based onto the per-frame destination table
-            { StageSpan sp(ctx->timers, ST_DELIVER, st); HIP_TRY(s2_vcm_scatter_launch(d_idx + off_idx, cnt, kb, g_bb, d_dst, st)); }
+            if (!pipelined) {
+                if ((rc = fec_run(ctx, f, g_llr, cnt, mt, force, g_bb, g_tr, g_tr + cnt, st))) return rc;
+                // the group's index list, re-based onto the per-frame destination table
+                { StageSpan sp(ctx->timers, ST_DELIVER, st); HIP_TRY(s2_vcm_scatter_launch(d_idx + off_idx, cnt, kb, g_bb, d_dst, st)); }
+            } else {
+                runs.push_back(Run{f, g_llr, cnt, g_bb, g_tr});
+                parts.push_back(PendingFec::Part{kb, cnt, g_bb, j_idx + off_idx, to});
+            }
             outs.push_back(Out{kv.first, to, cnt});
             off_idx += cnt; lo += (size_t)cnt * f.N; bo += (size_t)cnt * kb; bo = (bo + 7) & ~(size_t)7; to += 2 * (size_t)cnt;
         }
+        if (pipelined) {
+            // the decoders of this call's codes go onto the FEC stream, behind the gathers; the call that follows collects them
+            hipStream_t sf = ctx->fec_stream;
+            HIP_TRY(hipEventRecord(ctx->ev_llr, st));
+            {
+                std::lock_guard<std::mutex> fl(ctx->fec_mtx);
+                HIP_TRY(hipStreamWaitEvent(sf, ctx->ev_llr, 0));
+                for (const Run& r : runs)
+                    if ((rc = fec_run(ctx, r.f, r.llr, r.cnt, mt, force, r.bb, r.tr, r.tr + r.cnt, sf))) return rc;
+                if (!ctx->ev_fec[slot][par]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fec[slot][par], hipEventDisableTiming));
+                HIP_TRY(hipEventRecord(ctx->ev_fec[slot][par], sf));
+            }
+            ctx->fec_parity[slot] ^= 1;
+            HIP_TRY(hipMemcpyAsync(hstats.data(), d_stats, sizeof(S2FrameStats) * nf, hipMemcpyDeviceToHost, st));
+            job_started.reset(new PendingFec());
+            PendingFec& J = *job_started;
+            J.vcm = true; J.n = n; J.nf = nf; J.dm.assign(dm, dm + n); J.first = first;
+            J.parts = std::move(parts); J.frame_off = frame_off; J.stream_bytes = stream_bytes;
+            J.frame_tr.assign(nf, -1); J.frame_co.assign(nf, -1);
+            for (const Out& o : outs) {
+                const std::vector<int>& idx = groups[o.code];
+                for (int k = 0; k < o.cnt; ++k) { J.frame_tr[idx[k]] = (int)(o.to + k); J.frame_co[idx[k]] = (int)(o.to + o.cnt + k); }
+            }
+            J.d_trials = (const int32_t*)ws_gt.p; J.n_results = 2 * nall;
+            J.d_dst = (uint8_t**)((char*)ws_gt.p + res_bytes + idx_bytes);
+            J.done = ctx->ev_fec[slot][par];
+        } else {
         std::vector<int32_t> tc(2 * all_idx.size());
-        HIP_TRY(hipMemcpyAsync(tc.data(), W[7].p, sizeof(int32_t) * tc.size(), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(tc.data(), ws_gt.p, sizeof(int32_t) * tc.size(), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(hstats.data(), d_stats, sizeof(S2FrameStats) * nf, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (const Out& o : outs) {
             const std::vector<int>& idx = groups[o.code];
             for (int k = 0; k < o.cnt; ++k) { trials[idx[k]] = tc[o.to + k]; corr[idx[k]] = tc[o.to + o.cnt + k]; }
+        }
         }
         for (int i = 0; i < n; ++i)
             if (first[i + 1] > first[i]) {
@@ -954,6 +1075,21 @@ int process_vcm_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const
     HIP_TRY(s2_collect_launch(d_work, n, d_nsym, d_nco, st));
     HIP_TRY(hipMemcpyAsync(nco.data(), d_nco, sizeof(float) * n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (pipelined) {
+        for (int i = 0; i < n; ++i) {
+            dvbs2gpu_demod* d = dm[i];
+            const int cur = cnts[4 * i + 1];
+            if (cur > 0) { d->fifo_fill -= cur; d->fifo_cur ^= 1; d->sym_base += cur; }
+            d->nco_freq_host = nco[i];
+        }
+        // the job of the previous call of this slot is collected AFTER this call's job has gone onto the FEC stream (process_group does the same)
+        PendingFec* prev = (PendingFec*)ctx->pending_fec[slot];
+        ctx->pending_fec[slot] = nullptr;
+        std::unique_ptr<PendingFec> prev_guard(prev);
+        if (job_started) { job_started->hstats = hstats; ctx->pending_fec[slot] = job_started.release(); }
+        if (prev && (rc = deliver_job(ctx, prev, st, W[8], *bm))) return rc;
+        return 0;
+    }
     for (int i = 0; i < n; ++i) {
         dvbs2gpu_demod* d = dm[i];
         const int cur = cnts[4 * i + 1];
@@ -1162,24 +1298,48 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
     const bool pipe = ctx->pipeline_fec != 0;
     bool any_vcm = false;
     for (int i = 0; i < n; ++i) any_vcm = any_vcm || demods[i]->cfg.acm_vcm != 0;
+    if (pipe && (int)groups.size() > dvbs2gpu_ctx::MAX_PIPE_GROUPS) { last_error() = "pipelined mode handles at most 16 configuration groups per batch"; return DVBS2GPU_ERR_ARG; }
+    hipStream_t st = pipe ? ctx->fe_stream : nullptr;
+    // pipelined: every job is collected through this map -- the streams of a batch may come and go and change places between calls
+    BatchMap bmap;
+    if (pipe) {
+        for (int i = 0; i < n; ++i) {
+            if (!bmap.pos.emplace(demods[i], i).second) { last_error() = "a stream appears twice in the batch"; return DVBS2GPU_ERR_ARG; }
+            out_bytes[i] = 0;
+            demods[i]->stats.clear();
+        }
+        bmap.d_out = d_out; bmap.out_bytes = out_bytes; bmap.out_cap = out_cap;
+    }
+    // jobs left in slots this call has no group for (the batch has fewer configuration groups than the one before): collected at the end of the call
+    auto collect_leftovers = [&](int first_free_slot) -> int {
+        for (int sl = first_free_slot; sl < dvbs2gpu_ctx::MAX_PIPE_GROUPS; ++sl) {
+            PendingFec* job = (PendingFec*)ctx->pending_fec[sl];
+            if (!job) continue;
+            ctx->pending_fec[sl] = nullptr;
+            std::unique_ptr<PendingFec> guard(job);
+            int rc = deliver_job(ctx, job, st, ctx->ws_rx[6], bmap);
+            if (rc) return rc;
+        }
+        return 0;
+    };
     if (any_vcm) {
-        // ACM/VCM streams: group after group, synchronous (the FEC of a call depends on what its framing finds)
-        if (pipe) { last_error() = "ACM/VCM streams run in the synchronous mode (dvbs2gpu_set_pipelined(ctx, 0))"; return DVBS2GPU_ERR_ARG; }
+        // ACM/VCM streams: group after group (the FEC jobs of a call depend on what its framing finds: one per LDPC code present); pipelined: the
+        // jobs run on the FEC stream beside the next call's front end and are collected by that call, like those of the CCM groups
+        int slot = 0;
         for (const std::vector<int>& idx : groups) {
             std::vector<dvbs2gpu_demod*> g;
             std::vector<const cf32*> gi;
             std::vector<int> gc, gb(idx.size());
             std::vector<uint8_t*> go;
             for (int k : idx) { g.push_back(demods[k]); gi.push_back((const cf32*)d_iq[k]); gc.push_back(counts[k]); go.push_back(d_out[k]); }
-            int rc = g[0]->cfg.acm_vcm ? process_vcm_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), nullptr)
-                                       : process_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), nullptr, false, 0, nullptr, false, false);
+            int rc = g[0]->cfg.acm_vcm ? process_vcm_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), st, pipe, slot, pipe ? &bmap : nullptr)
+                                       : process_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), st, pipe, slot, nullptr, false, false, nullptr, pipe ? &bmap : nullptr);
             if (rc) return rc;
-            for (size_t k = 0; k < idx.size(); ++k) out_bytes[idx[k]] = gb[k];
+            if (!pipe) for (size_t k = 0; k < idx.size(); ++k) out_bytes[idx[k]] = gb[k];
+            ++slot;
         }
-        return 0;
+        return pipe ? collect_leftovers(slot) : 0;
     }
-    if (pipe && (int)groups.size() > dvbs2gpu_ctx::MAX_PIPE_GROUPS) { last_error() = "pipelined mode handles at most 16 configuration groups per batch"; return DVBS2GPU_ERR_ARG; }
-    hipStream_t st = pipe ? ctx->fe_stream : nullptr;
     // several groups with one front end: the MODCOD-independent stages run once for the whole batch
     // (tried in round 3 for small mixed batches -- 64 transponders in 8 groups: every group running its WHOLE chain by itself, side by side, each
     // with the stage pipeline inside.  8 groups x 4 streams do not get a hardware queue each (9 queues in all with GPU_MAX_HW_QUEUES=12): the
@@ -1226,9 +1386,9 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
             continue;
         }
         int rc = process_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), st, pipe, pipe ? group_no : 0,
-                               merged ? gn.data() : nullptr, false, false);
+                               merged ? gn.data() : nullptr, false, false, nullptr, pipe ? &bmap : nullptr);
         if (rc) return rc;
-        for (size_t k = 0; k < idx.size(); ++k) out_bytes[idx[k]] = gb[k];
+        if (!pipe) for (size_t k = 0; k < idx.size(); ++k) out_bytes[idx[k]] = gb[k];
         ++group_no;
     }
     if (side_by_side) {
@@ -1263,31 +1423,31 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
         for (GroupJob& J : jobs) {
             if (&J == &jobs.back()) break;            // (the last group runs on the calling thread, below)
             try {
-                th.emplace_back([&J, ctx, out_cap, pipe, merged, pre_async, &pre_slices]() {
+                th.emplace_back([&J, ctx, out_cap, pipe, merged, pre_async, &pre_slices, &bmap]() {
                     if (hipSetDevice(ctx->device) != hipSuccess) { J.rc = DVBS2GPU_ERR_HIP; J.err = "hipSetDevice"; return; }
                     J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
-                                         ctx->grp_stream[J.slot], true, J.slot, (merged && !pre_async) ? J.gn.data() : nullptr, true, !pipe, pre_async ? &pre_slices : nullptr);
+                                         ctx->grp_stream[J.slot], true, J.slot, (merged && !pre_async) ? J.gn.data() : nullptr, true, !pipe, pre_async ? &pre_slices : nullptr, pipe ? &bmap : nullptr);
                     if (J.rc) J.err = last_error();
                 });
             } catch (...) {                           // no thread to be had: run the group here (no exception leaves the C ABI)
                 J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
-                                     ctx->grp_stream[J.slot], true, J.slot, (merged && !pre_async) ? J.gn.data() : nullptr, true, !pipe, pre_async ? &pre_slices : nullptr);
+                                     ctx->grp_stream[J.slot], true, J.slot, (merged && !pre_async) ? J.gn.data() : nullptr, true, !pipe, pre_async ? &pre_slices : nullptr, pipe ? &bmap : nullptr);
                 if (J.rc) J.err = last_error();
             }
         }
         {
             GroupJob& J = jobs.back();
             J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
-                                 ctx->grp_stream[J.slot], true, J.slot, (merged && !pre_async) ? J.gn.data() : nullptr, true, !pipe, pre_async ? &pre_slices : nullptr);
+                                 ctx->grp_stream[J.slot], true, J.slot, (merged && !pre_async) ? J.gn.data() : nullptr, true, !pipe, pre_async ? &pre_slices : nullptr, pipe ? &bmap : nullptr);
             if (J.rc) J.err = last_error();
         }
         for (auto& t : th) t.join();
         for (GroupJob& J : jobs) {
             if (J.rc) { last_error() = J.err; return J.rc; }
-            for (size_t k = 0; k < J.idx.size(); ++k) out_bytes[J.idx[k]] = J.gb[k];
+            if (!pipe) for (size_t k = 0; k < J.idx.size(); ++k) out_bytes[J.idx[k]] = J.gb[k];
         }
     }
-    return 0;
+    return pipe ? collect_leftovers(group_no) : 0;
 }
 
 int dvbs2gpu_demod_process(dvbs2gpu_demod* d, int count, const float* h_iq, uint8_t* h_out, int out_cap) {

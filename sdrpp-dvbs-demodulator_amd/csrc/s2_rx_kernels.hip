@@ -2130,6 +2130,7 @@ __global__ __launch_bounds__(256) void s2_vcm_gather_kernel(const S2VcmFrame* __
 __global__ __launch_bounds__(256) void s2_vcm_scatter_kernel(const int* __restrict__ idx, int kb, const uint8_t* __restrict__ bb, uint8_t* const* __restrict__ dst) {
     const uint8_t* __restrict__ src = bb + (size_t)blockIdx.x * kb;
     uint8_t* __restrict__ d = dst[idx[blockIdx.x]];
+    if (!d) return;                                 // (pipelined mode: the frame's stream has left the batch)
     for (int i = threadIdx.x; i < kb; i += 256) d[i] = src[i];
 }
 
@@ -2155,6 +2156,7 @@ __global__ __launch_bounds__(256) void s2_scatter_out2_kernel(uint8_t* const* __
                                                               const int* __restrict__ first, int kb, const uint8_t* __restrict__ bb) {
     const int f = blockIdx.x;
     const int s = frames[f].stream;
+    if (!outs[s]) return;                           // (pipelined mode: the stream is not part of the call that collects this job -- its frames are dropped)
     uint8_t* __restrict__ dst = outs[s] + (size_t)(f - first[s]) * kb;
     const uint8_t* __restrict__ src = bb + (size_t)f * kb;
     for (int i = threadIdx.x; i < kb; i += 256) dst[i] = src[i];
@@ -2782,18 +2784,18 @@ hipError_t s2_post_stages_launch(const S2StreamWork* d_work, int nstreams, const
 #ifndef S2_GARDNER_CAND_MAX
 #define S2_GARDNER_CAND_MAX 256
 #endif
-static int gardner_form(int nstreams, int prio_duty) {
+static int gardner_form(int nstreams, int prio_duty, int lane_form) {
     static const int forced = [] { const char* e = getenv("DVBS2GPU_GARDNER_FORM"); return e ? atoi(e) : 0; }();
     if (forced >= 1 && forced <= 4) return forced;
     if (nstreams <= S2_GARDNER_CAND_MAX) return 4;
     if (nstreams < S2_GARDNER_BANK_MIN) return 2;
     // a big bank beside the decoder of the previous call: the one-wave form disturbs the decoder least; once the balancer of the pipelined
     // mode (s2_demod.hip) has found the FRONT END to be the critical path (it raises the timing loop's priority share), the shorter forms win
-    if (prio_duty < 2) return 1;
-    return nstreams >= S2_GARDNER_LANE_MIN ? 3 : 2;
+    if (nstreams >= S2_GARDNER_LANE_MIN) return lane_form ? 3 : 1;       // (the balancer switches with hysteresis: ctx.h g_lane_form)
+    return prio_duty < 2 ? 1 : 2;
 }
 static void gardner_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const float* d_bank, hipStream_t st, int c, int nsub) {
-    switch (gardner_form(nstreams, coefs.g_prio_duty)) {
+    switch (gardner_form(nstreams, coefs.g_prio_duty, coefs.g_lane_form)) {
         case 4: {
             static const int skew = [] { const char* e = getenv("DVBS2GPU_GARDNER_CAND_SKEW"); return e ? atoi(e) : 0; }();     // (tests only)
             hipLaunchKernelGGL(s2_gardner_cand_kernel, dim3((nstreams + GC_CS - 1) / GC_CS), dim3(192), 0, st, d_work, nstreams, coefs, d_bank, c, nsub, skew);

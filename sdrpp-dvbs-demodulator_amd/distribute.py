@@ -159,6 +159,16 @@ class Distributor:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def all_over_ranks(self, x):
+        """every rank's value of a scalar, in rank order (one all-gather): per-rank step times next to the per-rank loads"""
+        import torch
+        if self.dist is None:
+            return [float(x)]
+        t = torch.tensor([float(x)], dtype=torch.float64, device=self.device)
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(v.item()) for v in out]
+
     def barrier(self):
         if self.dist is not None:
             self.dist.barrier()

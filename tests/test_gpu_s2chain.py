@@ -672,7 +672,7 @@ def test_acm_vcm_stream_cycling_modcods_equals_oracle(engine, esn0, cfo, chunk):
 
 
 def test_acm_vcm_batch_of_streams_and_error_paths(engine, pkg):
-    """several ACM/VCM streams and a CCM stream in one process_batch call == each on its own handle; the pipelined mode refuses ACM/VCM"""
+    """several ACM/VCM streams and a CCM stream in one process_batch call == each on its own handle"""
     import torch
     lists = [VCM_PLS, [(6 << 2) | 2, (14 << 2) | 2], [(13 << 2) | 2 | 1, 0, (4 << 2)]]
     iqs, ref, dms = [], [], []
@@ -695,15 +695,101 @@ def test_acm_vcm_batch_of_streams_and_error_paths(engine, pkg):
     for s in range(len(iqs)):
         assert nb[s] == ref[s].size and np.array_equal(tout[s][:nb[s]].cpu().numpy(), ref[s]), s
     assert sum(nb) > 20000
-    engine.set_pipelined(True)
-    try:
-        with pytest.raises(pkg.Dvbs2GpuError) as e:
-            engine.process_batch(dms, tin, tout)
-        assert e.value.code == pkg.ERR_ARG
-    finally:
-        engine.set_pipelined(False)
     for d in dms:
         d.close()
+
+
+def test_acm_vcm_streams_in_the_pipelined_mode_equal_synchronous_one_call_later(engine, pkg):
+    """throughput mode with ACM/VCM streams (one FEC job per LDPC code present in a call, on the FEC stream beside the next call's front end) and a
+    CCM stream in the same batch: BBFRAMEs of differing size, their order and the per-frame stats equal the synchronous mode's, one call later"""
+    import torch
+    lists = [VCM_PLS, [(6 << 2) | 2, (14 << 2) | 2], [(13 << 2) | 2 | 1, 0, (4 << 2)]]
+    iqs = []
+    for k, pl in enumerate(lists):
+        iq, _ = orc.transmit_vcm(pl, 16, seed=20 + k, esn0_db=25.0, cfo=2e-4 * k, timing=0.1 * k, lead_symbols=300)
+        iqs.append(iq)
+    iq, _, _ = orc.transmit(14, 1, 0, nframes=6, seed=31, esn0_db=25.0, lead_symbols=200)
+    iqs.append(iq)
+    calls = 3
+    cap = max(i.size for i in iqs) // 2 + 100000
+
+    def run(pipelined):
+        dms = [engine.demod(engine.default_cfg(4, True, False, acm_vcm=1), max_samples=i.size) for i in iqs[:3]]
+        dms.append(engine.demod(engine.default_cfg(14, True, False), max_samples=iqs[3].size))
+        tout = [torch.zeros(cap, dtype=torch.uint8, device='cuda') for _ in iqs]
+        engine.set_pipelined(pipelined)
+        outs = []
+        try:
+            for c in range(calls + (1 if pipelined else 0)):
+                tin = []
+                for x in iqs:
+                    n = (x.size // calls) & ~1
+                    part = x[c * n:(c + 1) * n] if c < calls - 1 else (x[c * n:] if c == calls - 1 else x[:0])
+                    tin.append(torch.from_numpy(np.ascontiguousarray(part)).cuda() if part.size else torch.empty(0, dtype=torch.complex64, device='cuda'))
+                nb = engine.process_batch(dms, tin, tout)
+                outs.append(([tout[i][:nb[i]].cpu().numpy().copy() for i in range(len(iqs))],
+                             [[(x.ldpc_trials, x.bch_corrections, x.detected_modcod, x.detected_shortframes, x.bbframe_bytes) for x in d.stats()] for d in dms]))
+        finally:
+            engine.set_pipelined(False)
+            for d in dms:
+                d.close()
+        return outs
+
+    sync, pipe = run(False), run(True)
+    assert all(x.size == 0 for x in pipe[0][0]) and all(len(x) == 0 for x in pipe[0][1])
+    total = 0
+    for c in range(calls):
+        for i in range(len(iqs)):
+            assert np.array_equal(pipe[c + 1][0][i], sync[c][0][i]), (c, i)
+            assert pipe[c + 1][1][i] == sync[c][1][i], (c, i)
+            total += sync[c][0][i].size
+    assert total > 20000
+
+
+def test_pipelined_batch_whose_streams_come_and_go(engine, pkg):
+    """throughput mode with a stream set that changes from call to call: a stream that joins starts with nothing pending, the streams that stay get the
+    frames of the previous call whatever their new position in the batch, a stream that is absent from the call after its own loses that call's
+    frames (the output buffers are the collecting call's) and nothing else"""
+    import torch
+    S, calls = 5, 5
+    iqs = [orc.transmit(11, 0, 0, nframes=calls, seed=700 + s, esn0_db=12.0, cfo=1e-3, timing=0.25, phase0=0.3)[0] for s in range(S)]
+    kb = pkg.modcod_info(11, False, False)['kbch'] // 8
+    chunk = iqs[0].size // calls
+    cfg = engine.default_cfg(11, False, False)
+    schedule = [[0, 1, 2, 3], [1, 2, 3, 4], [3, 4, 1, 2], [0, 1, 2, 3, 4], [4, 0]]
+
+    def run(pipelined):
+        demods = [engine.demod(cfg, max_samples=chunk) for _ in range(S)]
+        tout = [torch.zeros(4 * kb, dtype=torch.uint8, device='cuda') for _ in range(S)]
+        fed = [0] * S                                  # chunks a stream has consumed so far
+        engine.set_pipelined(pipelined)
+        outs = []
+        try:
+            for who in schedule + ([[0, 1, 2, 3, 4]] if pipelined else []):
+                last = len(outs) >= len(schedule)
+                tin = []
+                for s in who:
+                    tin.append(torch.empty(0, dtype=torch.complex64, device='cuda') if last else torch.from_numpy(iqs[s][fed[s] * chunk:(fed[s] + 1) * chunk]).cuda())
+                    fed[s] += 0 if last else 1
+                nb = engine.process_batch([demods[s] for s in who], tin, [tout[s] for s in who])
+                outs.append({s: (tout[s][:nb[k]].cpu().numpy().copy(), [(x.ldpc_trials, x.bch_corrections) for x in demods[s].stats()]) for k, s in enumerate(who)})
+        finally:
+            engine.set_pipelined(False)
+            for d in demods:
+                d.close()
+        return outs
+
+    sync, pipe = run(False), run(True)
+    full = schedule + [[0, 1, 2, 3, 4]]
+    frames = 0
+    for c in range(1, len(full)):
+        for s in full[c]:
+            if s in full[c - 1]:
+                assert np.array_equal(pipe[c][s][0], sync[c - 1][s][0]) and pipe[c][s][1] == sync[c - 1][s][1], (c, s)
+                frames += len(sync[c - 1][s][1])
+            else:
+                assert pipe[c][s][0].size == 0 and pipe[c][s][1] == [], (c, s)      # joined in this call: nothing pending
+    assert all(v[0].size == 0 for v in pipe[0].values()) and frames >= 8
 
 
 @pytest.mark.parametrize('modcod,short,pilots,esn0,flags', [(14, 1, 1, 12.0, dict(pilot_aided=1)), (27, 1, 1, 18.0, dict(pilot_aided=1, soft_plsc=1)),
