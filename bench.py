@@ -457,6 +457,58 @@ def small_batch(eng, pkg, dev, S=64, F=1):
             'frames_delivered': acc['delivered'], 'frames_equal_to_transmitted': acc['equal']}
 
 
+def secondary_vcm(eng, pkg, dev, S=64, frames_per_call=8, calls=10, distinct=4):
+    """ACM/VCM in the throughput mode: `S` streams whose PLFRAMEs cycle over QPSK / 8PSK / 16APSK / 32APSK MODCODs, normal and short
+    frames, with and without pilots, and a dummy PLFRAME (the reference only REPORTS the PLS code, dvbs2_plhdr_demod.cpp:43-64, and its GUI reconfigures:
+    main.cpp:375-408; here the framing follows every frame's code).  Continuous signals fed in calls of ~`frames_per_call` cycles' worth of samples, 16 LDPC
+    trials with early exit, one FEC job per LDPC code present in a call, collected by the next call."""
+    import torch
+    import orc
+    pls = [(4 << 2) | 2, (14 << 2) | 2, (6 << 2) | 2 | 1, 0, (19 << 2) | 2, (27 << 2) | 2 | 1, 13 << 2, (12 << 2) | 2]
+    nfr = len(pls) * frames_per_call * (calls + 3) // 8 * 8 // len(pls) * len(pls)
+    sigs, sent = [], []
+    for b in range(distinct):
+        iq, bbs = orc.transmit_vcm(pls, nfr, seed=4000 + b, esn0_db=30.0, cfo=1e-4, timing=0.2, phase0=0.3, lead_symbols=500 + 1000 * b)
+        sigs.append(torch.from_numpy(iq).to(dev))
+        sent.append({bytes(x) for x in bbs if x is not None})
+    nsym_total = (sigs[0].numel() // 2)
+    chunk = (min(x.numel() for x in sigs) // (calls + 2)) & ~1
+    cfg = eng.default_cfg(4, True, False, acm_vcm=1, max_ldpc_trials=16)
+    dms = [eng.demod(cfg, max_samples=chunk) for _ in range(S)]
+    cap = chunk // 2 + 100000
+    out = torch.zeros((S, cap), dtype=torch.uint8, device=dev)
+    tout = [out[i] for i in range(S)]
+    eng.set_pipelined(True)
+    try:
+        def call(c):
+            return eng.process_batch(dms, [sigs[i % distinct][c * chunk:(c + 1) * chunk] for i in range(S)], tout)
+        call(0); call(1)                                    # acquisition outside the timed calls
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nb = None
+        for c in range(2, calls + 2):
+            nb = call(c)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # the frames the last timed call delivered, streams 0 and S - 1, against the transmitted BBFRAMEs (sizes from the per-frame stats)
+        got = hit = 0
+        for i in (0, S - 1):
+            buf, pos = out[i, :nb[i]].cpu().numpy(), 0
+            for st in dms[i].stats():
+                if st.bbframe_bytes:
+                    got += 1; hit += bytes(buf[pos:pos + st.bbframe_bytes]) in sent[i % distinct]
+                    pos += st.bbframe_bytes
+        eng.process_batch(dms, [torch.empty(0, dtype=torch.complex64, device=dev) for _ in dms], tout)
+    finally:
+        eng.set_pipelined(False)
+        for d in dms:
+            d.close()
+    return {'config': 'ACM/VCM, throughput mode: %d streams, PLFRAMEs cycling over PLS codes %s (QPSK..32APSK, normal + short, +- pilots, a dummy PLFRAME), Es/N0 30 dB, carrier offset 1e-4 rad/sample (the reference PLL loses the 16APSK / 32APSK frames of such a cycle from ~2e-4 on), '
+                      '16 LDPC trials with early exit, calls of %d samples per stream' % (S, pls, chunk),
+            'value': round(S * calls * (chunk // 2) / dt / 1e6, 2), 'unit': 'Msymbols/s', 'ms_per_call': round(dt / calls * 1e3, 2), 'streams': S,
+            'msym_s_per_stream': round(calls * (chunk // 2) / dt / 1e6, 3), 'frames_checked_last_call': got, 'frames_equal_to_transmitted': hit}
+
+
 # ------------------------------------------------------------------------------------------------ config 4: 64 mixed transponders
 MIXED_MODCODS = [4, 6, 7, 11, 12, 13, 14, 15]
 MIXED_ESN0 = {4: 8.0, 6: 10.0, 7: 11.0, 11: 14.0, 12: 12.0, 13: 13.0, 14: 14.0, 15: 16.0}
@@ -747,6 +799,7 @@ def main():
                 sec.append(secondary_dvbs(eng, pkg, dev))
                 sec.append(small_batch(eng, pkg, dev, 64, 1))
                 sec.append(small_batch(eng, pkg, dev, 1, 4))
+                sec.append(secondary_vcm(eng, pkg, dev))
             except Exception as e:          # a secondary line must not take the headline down
                 sec.append({'error': repr(e)})
             line['secondary'] = sec
