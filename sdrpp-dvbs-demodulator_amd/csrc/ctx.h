@@ -126,6 +126,9 @@ struct dvbs2gpu_ctx {
     std::vector<s2::S2VcmMod> h_vcm_mods;
     std::vector<s2::FecParams> h_vcm_fec;     // by PLS code
     s2::Workspace ws_vcm[12];
+    // mixed CCM batches through one launch per stage (s2_demod.hip, process_mixed): per-call scratch, and per FEC side stream and job parity the event behind its jobs
+    s2::Workspace ws_mix[12];
+    hipEvent_t ev_mix[8][2] = {};
     // pipelined FEC (s2_demod.hip): with pipeline_fec set, dvbs2gpu_demod_process_batch runs the FEC of call k on fec_stream
     // while call k+1's front end runs on fe_stream; BBFRAMEs of call k are delivered by call k+1
     int pipeline_fec = 0;

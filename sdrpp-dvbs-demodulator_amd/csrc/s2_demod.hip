@@ -17,6 +17,7 @@
 #include "../../include/dvbs2gpu_math.h"
 #include <list>
 #include <unordered_map>
+#include <tuple>
 #include <thread>
 #include <cmath>
 #include <algorithm>
@@ -358,6 +359,7 @@ struct PendingFec {
     uint8_t** d_dst = nullptr;          // [nf] device table of the frames' destinations, filled by the delivery
     size_t n_results = 0;               // int32 words in d_trials (ACM/VCM)
     hipEvent_t done = nullptr;          // recorded on the FEC stream behind the job
+    std::vector<hipEvent_t> done_more;  // (a job whose parts ran on several streams: one event per stream)
 };
 
 // the streams of the whole batch a pipelined call works on: a job is collected into the buffers of whichever of ITS streams are part of this batch
@@ -371,7 +373,8 @@ struct BatchMap {
 
 // results of a finished (or finishing) job -> the callers' output buffers and the per-frame stats of its streams.  `wo`: a scratch workspace of the caller's
 static int deliver_job(dvbs2gpu_ctx* ctx, PendingFec* job, hipStream_t st, Workspace& wo, const BatchMap& bm) {
-    HIP_TRY(hipStreamWaitEvent(st, job->done, 0));
+    if (job->done) HIP_TRY(hipStreamWaitEvent(st, job->done, 0));
+    for (hipEvent_t e : job->done_more) HIP_TRY(hipStreamWaitEvent(st, e, 0));
     int rc2;
     std::vector<int> where(job->n, -1);
     for (int i = 0; i < job->n; ++i) {
@@ -1104,6 +1107,215 @@ int process_vcm_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------- mixed CCM batches, one launch per stage
+// A batch of up to S2_SMALL_BANK streams with DIFFERENT MODCODs (BASELINE config 4 as named: 64 transponders in 8 groups) and one front-end
+// configuration.  Round 3 ran the MODCOD-dependent stages per configuration group -- a host thread and a HIP stream (a hardware queue) per group
+// behind a shared front-end pass.  Here the whole call is ONE stage pipeline: AGC / timing recovery / RRC are MODCOD-independent anyway, and the
+// PL-sync walk, the frame loops (ahead of the PL sync, as for a small bank of one configuration) and the demapper take what they otherwise get as
+// kernel arguments from a per-stream table (S2StreamCfgDev).  The FEC stays one job per LDPC code -- a handful of decoder workgroups each, a few
+// milliseconds of latency: they run side by side on up to MIX_FEC_STREAMS side streams -- and the BBFRAMEs go out through the per-frame
+// destination table of the ACM/VCM jobs.  No host thread per group; the streams: the caller's, the front end's two auxiliary ones, the side streams.
+constexpr int MIX_FEC_STREAMS = 4;
+int process_mixed(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts, uint8_t* const* d_out,
+                  int out_cap, int* out_bytes, hipStream_t st, bool pipelined, const BatchMap* bm) {
+    dvbs2gpu_demod* d0 = dm[0];
+    Workspace* const W = ctx->ws_mix;
+    int rc;
+    if ((rc = get_rx_tables(ctx))) return rc;
+    float* d_taps;
+    if ((rc = get_rrc(ctx, d0->cfg.rrc_taps, d0->cfg.rrc_alpha, d0->cfg.samplerate / d0->cfg.symbolrate, &d_taps))) return rc;
+    static const bool loops_ahead_on = [] { const char* e = getenv("DVBS2GPU_LOOPS_AHEAD"); return !e || atoi(e) != 0; }();
+    const bool loops_ahead = loops_ahead_on && !d0->cfg.pilot_aided && ctx->stage_pipeline_launches <= 0;
+    std::vector<S2StreamWork> work(n);
+    std::vector<S2StreamCfgDev> cfgs(n);
+    int max_count = 0, maxf = 0, raw_max = 0, raw_min = 1 << 30, max_slots = 0;
+    for (int i = 0; i < n; ++i) {
+        dvbs2gpu_demod* d = dm[i];
+        const ModcodParams& mp = d->mp;
+        if (counts[i] < 0 || counts[i] > d->max_samples) { last_error() = "count exceeds max_samples"; return DVBS2GPU_ERR_ARG; }
+        if (loops_ahead && !d->d_spec) HIP_TRY(hipMalloc((void**)&d->d_spec, sizeof(cf32) * 33282));
+        ConstelTables* CT;
+        if ((rc = get_constel(ctx, mp, &CT))) return rc;
+        work[i].in = d_iq[i]; work[i].count = counts[i]; work[i].fe_out = d->d_fe;
+        work[i].fifo = d->d_fifo[d->fifo_cur]; work[i].fifo_fill = d->fifo_fill; work[i].st = d->d_state;
+        work[i].fifo_next = d->d_fifo[d->fifo_cur ^ 1]; work[i].out = d_out[i]; work[i].spec_out = d->d_spec;
+        S2StreamCfgDev& q = cfgs[i];
+        q.con = CT->dev; q.pls_code = d->pls_code; q.slots = mp.slots; q.pilots = mp.pilots; q.pilot_blocks = mp.pilot_blocks; q.plframe = mp.plframe;
+        q.rate = mp.rate; q.N = mp.fec.N;
+        max_count = std::max(max_count, counts[i]);
+        maxf = std::max(maxf, d->fifo_cap / mp.plframe + 2);
+        raw_max = std::max(raw_max, mp.plframe); raw_min = std::min(raw_min, mp.plframe); max_slots = std::max(max_slots, mp.slots);
+        if (!pipelined) d->stats.clear();
+        d->frame_ptrs.clear(); d->frame_pos.clear();
+    }
+    if ((rc = W[0].ensure(sizeof(S2StreamWork) * n + sizeof(S2StreamCfgDev) * n + sizeof(int) * 4 * n + sizeof(float) * n + 256))) return rc;
+    S2StreamWork* d_work = (S2StreamWork*)W[0].p;
+    S2StreamCfgDev* d_cfgs = (S2StreamCfgDev*)(d_work + n);
+    int* d_nsym = (int*)(d_cfgs + n);              // [n]
+    float* d_nco = (float*)(d_nsym + n);           // [n]
+    int* d_curfill = (int*)(d_nco + n);            // [2n]
+    HIP_TRY(hipMemcpyAsync(d_work, work.data(), sizeof(S2StreamWork) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_cfgs, cfgs.data(), sizeof(S2StreamCfgDev) * n, hipMemcpyHostToDevice, st));
+    const size_t nslot = (size_t)n * maxf;
+    if ((rc = W[1].ensure(sizeof(S2VcmFound) * nslot + sizeof(int) * 4 * n + 64))) return rc;
+    S2VcmFound* d_found = (S2VcmFound*)W[1].p;
+    int* d_counts = (int*)(d_found + nslot);
+    if ((rc = W[3].ensure(nslot * raw_max * sizeof(cf32)))) return rc;
+    if ((rc = W[7].ensure(sizeof(S2FrameStats) * nslot + 64))) return rc;
+    cf32* d_pll = (cf32*)W[3].p;
+    // ---- front half: the stage pipeline of a small bank, every stage one launch per slice for ALL configurations
+    {
+        struct Spans : S2SliceSpans {
+            StageTimers* T; std::unique_ptr<StageSpan> sp[4];
+            void begin(int stage, hipStream_t s) override { sp[stage].reset(new StageSpan(*T, stage == 1 ? ST_RRC : (stage == 2 ? ST_PLSYNC : ST_LOOPS), s)); }
+            void end(int stage, hipStream_t) override { sp[stage].reset(); }
+        } spans;
+        spans.T = &ctx->timers;
+        int launches = std::min(S2_FE_MAX_SLICES, std::max(1, (max_count / 2) / raw_min));
+        if (ctx->stage_pipeline_launches > 0) launches = ctx->stage_pipeline_launches;
+        S2PostStages post{d_taps, d0->cfg.rrc_taps, max_count + max_count / 32 + 8, raw_max, maxf, d_found, d_counts, ctx->pl, S2ConstelDev{}, 0,
+                          0, 0, 0, d_pll, (S2FrameStats*)W[7].p, ctx->timers.on ? &spans : nullptr, launches};
+        post.cfgs = d_cfgs;
+        if (loops_ahead) {
+            static const int sym_per_launch = [] { const char* e = getenv("DVBS2GPU_LOOPS_AHEAD_SYMBOLS"); return e ? atoi(e) : 2700; }();
+            post.spec = 1;
+            post.loops_launches = std::min(S2_FE_MAX_SLICES, std::max(launches, (max_count / 2) / std::max(sym_per_launch, 1)));
+        }
+        StageSpan sp(ctx->timers, ST_FRONTEND, st);
+        // (the post stages on a stream of their own in either mode: on the AGC's stream every slice's frame loops queue in front of the AGC slice the
+        //  timing recovery waits for next -- 4.3 instead of 2.4 ms per slice)
+        HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st, &post, true));
+    }
+    std::vector<S2FrameStats> slot_stats(nslot);
+    std::vector<S2VcmFound> found(nslot);
+    std::vector<int> cnts(4 * n);
+    HIP_TRY(hipMemcpyAsync(slot_stats.data(), W[7].p, sizeof(S2FrameStats) * nslot, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(cnts.data(), d_counts, sizeof(int) * 4 * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(found.data(), d_found, sizeof(S2VcmFound) * nslot, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // ---- pool the frames (stream-major), one FEC part per (LDPC code, iteration setting)
+    struct PartH { FecParams f; int mt, force; std::vector<int> frames; size_t lo = 0, bo = 0, to = 0; };
+    std::vector<PartH> parts;
+    std::map<std::tuple<int, int, int>, int> part_of;
+    std::vector<int> first(n + 1, 0), fslot, frame_off, cur(n, 0), stream_bytes(n, 0);
+    std::vector<S2FrameStats> hstats;
+    for (int i = 0; i < n; ++i) {
+        dvbs2gpu_demod* d = dm[i];
+        const int nfi = cnts[4 * i], kb = d->mp.fec.kbch / 8;
+        d->tap_sym_off = d->fifo_fill; d->tap_sym_cnt = cnts[4 * i + 3]; d->tap_fifo = d->fifo_cur;
+        d->fifo_fill = cnts[4 * i + 2];
+        if (d->fifo_fill > d->fifo_cap) { last_error() = "symbol FIFO overflow"; return DVBS2GPU_ERR_CAPACITY; }
+        cur[i] = cnts[4 * i + 1];
+        first[i] = (int)fslot.size();
+        if (nfi * kb > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
+        const int force = d->cfg.force_ldpc_iters > 0, mt = force ? d->cfg.force_ldpc_iters : d->cfg.max_ldpc_trials;
+        const auto key = std::make_tuple(d->mp.fec.code_index, mt, force);
+        auto it = part_of.find(key);
+        if (it == part_of.end()) { it = part_of.emplace(key, (int)parts.size()).first; parts.push_back(PartH{d->mp.fec, mt, force, {}}); }
+        const cf32* base = d->d_fifo[d->fifo_cur];
+        for (int k = 0; k < nfi; ++k) {
+            const S2VcmFound& F = found[(size_t)i * maxf + k];
+            d->frame_ptrs.push_back(base + F.offset); d->frame_pos.push_back(d->sym_base + F.offset);
+            S2FrameStats s = slot_stats[(size_t)i * maxf + k];
+            s.best_match = F.sofq; s.bbframe_bytes = kb;
+            hstats.push_back(s);
+            frame_off.push_back(k * kb);
+            parts[it->second].frames.push_back((int)fslot.size());
+            fslot.push_back(i * maxf + k);
+        }
+        stream_bytes[i] = nfi * kb;
+        d->tap_pll = d_pll + (size_t)i * maxf * raw_max;
+        d->tap_llr = nullptr;
+    }
+    first[n] = (int)fslot.size();
+    const int nf = (int)fslot.size();
+    std::unique_ptr<PendingFec> job;
+    if (nf > 0) {
+        const int par = pipelined ? ctx->fec_parity[0] : 0;
+        Workspace& ws_gl = pipelined ? ctx->ws_fecbuf[0][par][0] : W[4];
+        Workspace& ws_gb = pipelined ? ctx->ws_fecbuf[0][par][1] : W[5];
+        Workspace& ws_gt = pipelined ? ctx->ws_fecbuf[0][par][2] : W[6];
+        size_t lo = 0, bo = 0, to = 0;
+        for (PartH& P : parts) {
+            P.lo = lo; P.bo = bo; P.to = to;
+            lo += (size_t)P.frames.size() * P.f.N; bo += ((size_t)P.frames.size() * (P.f.kbch / 8) + 63) & ~(size_t)63; to += 2 * P.frames.size();
+        }
+        const size_t res_bytes = (sizeof(int32_t) * to + 63) & ~(size_t)63, idx_bytes = (sizeof(int) * nf + 63) & ~(size_t)63;
+        if ((rc = ws_gl.ensure(lo + 64)) || (rc = ws_gb.ensure(bo + 64)) || (rc = ws_gt.ensure(res_bytes + idx_bytes + sizeof(uint8_t*) * nf + 64))) return rc;
+        if ((rc = W[2].ensure(sizeof(int) * nf + sizeof(int8_t*) * nf + 64))) return rc;
+        int8_t** d_llr_of = (int8_t**)W[2].p;
+        int* d_slot = (int*)(d_llr_of + nf);
+        int* j_idx = (int*)((char*)ws_gt.p + res_bytes);
+        std::vector<int8_t*> llr_of(nf);
+        std::vector<int> all_idx;
+        for (const PartH& P : parts)
+            for (size_t k = 0; k < P.frames.size(); ++k) { llr_of[P.frames[k]] = (int8_t*)ws_gl.p + P.lo + k * P.f.N; all_idx.push_back(P.frames[k]); }
+        for (int i = 0; i < n; ++i)
+            if (first[i + 1] > first[i]) dm[i]->tap_llr = llr_of[first[i]];      // (a stream's frames are consecutive inside its part)
+        HIP_TRY(hipMemcpyAsync(d_llr_of, llr_of.data(), sizeof(int8_t*) * nf, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_slot, fslot.data(), sizeof(int) * nf, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(j_idx, all_idx.data(), sizeof(int) * nf, hipMemcpyHostToDevice, st));
+        { StageSpan sp(ctx->timers, ST_DEMAP, st); HIP_TRY(s2_demap_mixed_launch(d_cfgs, max_slots, maxf, raw_max, d_pll, nf, d_llr_of, st, d_slot)); }
+        if (!ctx->ev_llr) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_llr, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ctx->ev_llr, st));
+        // the FEC jobs, side by side
+        job.reset(new PendingFec());
+        PendingFec& J = *job;
+        J.vcm = true; J.n = n; J.nf = nf; J.dm.assign(dm, dm + n); J.first = first; J.hstats = hstats;
+        J.frame_off = frame_off; J.stream_bytes = stream_bytes;
+        J.frame_tr.assign(nf, -1); J.frame_co.assign(nf, -1);
+        J.d_trials = (const int32_t*)ws_gt.p; J.n_results = to;
+        J.d_dst = (uint8_t**)((char*)ws_gt.p + res_bytes + idx_bytes);
+        static const int side_max = [] { const char* e = getenv("DVBS2GPU_MIX_FEC_STREAMS"); const int k = e ? atoi(e) : MIX_FEC_STREAMS; return k < 1 ? 1 : (k > 8 ? 8 : k); }();
+        const int nside = std::min<int>((int)parts.size(), side_max);
+        size_t off_idx = 0;
+        for (size_t pi = 0; pi < parts.size(); ++pi) {
+            const PartH& P = parts[pi];
+            const int k = (int)(pi % nside), cnt = (int)P.frames.size();
+            if (!ctx->grp_stream[k]) HIP_TRY(hipStreamCreateWithFlags(&ctx->grp_stream[k], hipStreamNonBlocking));
+            hipStream_t sk = ctx->grp_stream[k];
+            if ((int)pi < nside) HIP_TRY(hipStreamWaitEvent(sk, ctx->ev_llr, 0));
+            int32_t* g_tr = (int32_t*)ws_gt.p + P.to;
+            uint8_t* g_bb = (uint8_t*)ws_gb.p + P.bo;
+            if ((rc = fec_run(ctx, P.f, (const int8_t*)ws_gl.p + P.lo, cnt, P.mt, P.force, g_bb, g_tr, g_tr + cnt, sk, &ctx->fws_grp[k]))) return rc;
+            J.parts.push_back(PendingFec::Part{P.f.kbch / 8, cnt, g_bb, j_idx + off_idx, P.to});
+            for (int q = 0; q < cnt; ++q) { J.frame_tr[P.frames[q]] = (int)(P.to + q); J.frame_co[P.frames[q]] = (int)(P.to + cnt + q); }
+            off_idx += cnt;
+        }
+        for (int k = 0; k < nside; ++k) {
+            if (!ctx->ev_mix[k][par]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_mix[k][par], hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(ctx->ev_mix[k][par], ctx->grp_stream[k]));
+            J.done_more.push_back(ctx->ev_mix[k][par]);
+        }
+        if (pipelined) ctx->fec_parity[0] ^= 1;
+    }
+    // ---- FIFO remainder to the spare buffer, NCO frequency for the getter
+    std::vector<int> curfill(2 * n);
+    for (int i = 0; i < n; ++i) { curfill[2 * i] = cur[i]; curfill[2 * i + 1] = dm[i]->fifo_fill; }
+    HIP_TRY(hipMemcpyAsync(d_curfill, curfill.data(), sizeof(int) * 2 * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(s2_fifo_compact_launch(d_work, n, d_curfill, st));
+    std::vector<float> nco(n);
+    HIP_TRY(s2_collect_launch(d_work, n, d_nsym, d_nco, st));
+    HIP_TRY(hipMemcpyAsync(nco.data(), d_nco, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < n; ++i) {
+        dvbs2gpu_demod* d = dm[i];
+        if (cur[i] > 0) { d->fifo_fill -= cur[i]; d->fifo_cur ^= 1; d->sym_base += cur[i]; }
+        d->nco_freq_host = nco[i];
+    }
+    BatchMap bm_local;
+    if (!bm) {
+        for (int i = 0; i < n; ++i) { bm_local.pos[dm[i]] = i; out_bytes[i] = 0; dm[i]->stats.clear(); }
+        bm_local.d_out = d_out; bm_local.out_bytes = out_bytes; bm_local.out_cap = out_cap;
+        bm = &bm_local;
+    }
+    if (!pipelined) return job ? deliver_job(ctx, job.get(), st, W[8], *bm) : 0;
+    PendingFec* prev = (PendingFec*)ctx->pending_fec[0];
+    ctx->pending_fec[0] = job.release();
+    std::unique_ptr<PendingFec> prev_guard(prev);
+    return prev ? deliver_job(ctx, prev, st, W[8], *bm) : 0;
+}
+
 // AGC, NCO, Gardner, RRC + decimation do not depend on the MODCOD: for a batch of several configuration groups whose loop
 // coefficients and matched filter agree they run ONCE over all streams (these kernels are latency-bound: eight groups of 512
 // streams cost eight times one group of 4096).  Leaves the symbols in the streams' FIFOs exactly as process_group would.
@@ -1339,6 +1551,22 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
             ++slot;
         }
         return pipe ? collect_leftovers(slot) : 0;
+    }
+    // a small mixed batch with one front-end and loop configuration: ONE stage pipeline for all MODCODs (process_mixed); DVBS2GPU_MIXED_GROUPS=1
+    // keeps round 3's flow (a host thread and a HIP stream per configuration group behind a shared front-end pass), which bigger mixed batches use
+    if (groups.size() > 1 && n <= S2_SMALL_BANK && ctx->stage_pipeline == 1) {
+        static const bool by_groups = getenv("DVBS2GPU_MIXED_GROUPS") != nullptr;
+        bool one = !by_groups;
+        for (int i = 1; one && i < n; ++i) {
+            const S2LoopCoefs &x = demods[0]->co, &y = demods[i]->co;
+            one = same_frontend(demods[0], demods[i]) && x.pll_alpha == y.pll_alpha && x.pll_beta == y.pll_beta && x.hdr_alpha == y.hdr_alpha && x.hdr_beta == y.hdr_beta &&
+                  x.soft_plsc == y.soft_plsc && x.pilot_aided == y.pilot_aided;
+        }
+        if (one) {
+            int rc = process_mixed(ctx, demods, n, (const cf32* const*)d_iq, counts, d_out, out_cap, out_bytes, st, pipe, pipe ? &bmap : nullptr);
+            if (rc) return rc;
+            return pipe ? collect_leftovers(1) : 0;
+        }
     }
     // several groups with one front end: the MODCOD-independent stages run once for the whole batch
     // (tried in round 3 for small mixed batches -- 64 transponders in 8 groups: every group running its WHOLE chain by itself, side by side, each

@@ -96,6 +96,15 @@ struct S2ConstelDev {
     const cf32* pts_g;         // the same points in global memory
 };
 
+// Mixed CCM batches (streams of DIFFERENT MODCODs in one call): ONE launch per stage serves all configurations -- what the MODCOD-dependent
+// kernels (PL-sync walk, frame loops, demapper) otherwise get as kernel arguments comes from a per-stream table in device memory.  A workgroup's
+// streams share a configuration (the walk and the small-bank frame loops have one stream per workgroup), so the values stay scalar.
+struct S2StreamCfgDev {
+    S2ConstelDev con;
+    int pls_code, slots, pilots, pilot_blocks, plframe;
+    int rate, N;             // demapper
+};
+
 // ---- ACM/VCM mode (include/dvbs2gpu.h, acm_vcm): every frame carries its own MODCOD
 constexpr int VCM_ACQ_WINDOW = 33282;        // acquisition search span = the longest PLFRAME (QPSK normal with pilots)
 constexpr float VCM_MIN_RATIO = 0.5f;        // PLS decodes below this correlation ratio count as "no header here"
@@ -192,6 +201,7 @@ struct S2PostStages {
     // mixed batches (s2_demod.hip): the shared front-end pass runs part 1 (RRC) for ALL streams behind every slice and records slice_done[c];
     // every configuration group then runs part 2 (walk + frame loops) for ITS streams behind that event on its own stream
     int spec = 0;                                                           // frame loops ahead of the PL sync (small banks, see S2StreamState)
+    const S2StreamCfgDev* cfgs = nullptr;                                   // mixed batch: per-stream configuration (then `raw` is the slot stride = the longest PLFRAME of the batch)
     int parts = 3;                                                          // 1: RRC + /2, 2: PL-sync walk + frame loops
     hipEvent_t* slice_done = nullptr;                                       // [nsub] or null
 };
@@ -226,5 +236,8 @@ hipError_t s2_deinterleave_launch(int constel, int rate, int bits, int N, const 
 hipError_t math_eval_launch(int func, int n, const float* a, const float* b, float* o0, float* o1, hipStream_t st);
 hipError_t s2_demap_launch(S2ConstelDev con, int rate, int shortframe, int slots, int pilots, int plframe, const cf32* d_pllout,
                            int nframes, int8_t* d_llr, int N, hipStream_t st, const int* d_slot = nullptr);   // d_slot: frame f's symbols lie in slot d_slot[f] of d_pllout
+// mixed batch: frame f belongs to stream d_slot[f] / maxf (its configuration: cfgs), its symbols lie in slot d_slot[f] (stride slot_stride), its LLRs go to d_llr_of[f]
+hipError_t s2_demap_mixed_launch(const S2StreamCfgDev* cfgs, int max_slots, int maxf, int slot_stride, const cf32* d_pllout, int nframes,
+                                 int8_t* const* d_llr_of, hipStream_t st, const int* d_slot);
 
 }  // namespace s2

@@ -1302,12 +1302,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                                                             const S2FrameRef* __restrict__ frames, const int* __restrict__ first,
                                                             S2LoopCoefs co, S2PlTablesDev T, S2ConstelDev C, int pls_code, int slots,
                                                             int pilots, int pilot_blocks, int plframe, cf32* __restrict__ pllout,
-                                                            S2FrameStats* __restrict__ stats, const S2VcmFound* __restrict__ found, int maxf, int spw) {
+                                                            S2FrameStats* __restrict__ stats, const S2VcmFound* __restrict__ found, int maxf, int spw,
+                                                            const S2StreamCfgDev* __restrict__ cfgs) {
     // spw: streams per workgroup, 1 .. FL_SPW.  A small bank gets a workgroup (and with it a CU's vector L1 for its phase-error table lookups)
     // per stream: 64 streams x 1 frame 6.1 -> 5.x ms; the lane groups without a stream shadow the others' code path as usual
     // found != nullptr (stage pipeline): no pooled frame table -- frame k of stream s is slot s * maxf + k of found / pllout / stats, and
     // this launch goes through the frames the PL-sync walk has found (walk_nf) beyond those an earlier slice's launch did (loops_done)
     static_assert(2 * FL_TILE >= 90 && 2 * FL_TILE >= 88 && FL_TILE >= 36, "input + output tile hold the 90 header symbols; the output tile alone the 88 FED terms");
+    // mixed batch: this workgroup's streams share the configuration of its first one (s2_demod.hip sees to that); `plframe` as passed is then the
+    // stride of the PLL-output slots (the longest PLFRAME of the batch)
+    const int slot_stride = plframe;
+    if (cfgs) {
+        const S2StreamCfgDev* __restrict__ q = cfgs + min((int)blockIdx.x * spw, nstreams - 1);
+        C = q->con; pls_code = q->pls_code; slots = q->slots; pilots = q->pilots; pilot_blocks = q->pilot_blocks; plframe = q->plframe;
+    }
     __shared__ cf32 tiles[FL_SPW][2 * FL_TILE]; // per stream: [input tile | output tile]
     __shared__ uint8_t rnt[FL_TILE];
     __shared__ cf32 s_pts[32];                 // constellation points for the 32APSK phase-error search (the other constellations use the LUT)
@@ -1390,7 +1398,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const cf32* __restrict__ fr = found ? work[f / maxf].fifo + (spec_pass ? foff : found[f].offset) : frames[f].sym;
         // (the unconfirmed window's output goes into the slot the frame will get AND into the stream's own buffer, which outlives the call: a
         //  frame that continues from tiles done in earlier calls first gets those out of there -- all 64 lanes copy, the workgroup has one stream)
-        cf32* __restrict__ out = pllout + (size_t)f * plframe;
+        cf32* __restrict__ out = pllout + (size_t)f * slot_stride;
         cf32* __restrict__ keep = spec_pass ? work[f / maxf].spec_out : nullptr;
         if (SPEC && fin && t0 > 0) {
             const int carried = min(__shfl(sp_carried, donor), t0);
@@ -1632,10 +1640,17 @@ __device__ __forceinline__ int deint_pos(int constel, int rate, int bits, int ro
 // loads, one table word per symbol (lut_bits4), one 32-bit store per bit column; the byte form (three byte loads and three byte stores per symbol)
 // ran at 1.1 TB/s of its 7.8 GB per 32 768 frames.
 __global__ __launch_bounds__(256) void s2_demap_kernel(S2ConstelDev C, int rate, int slots, int pilots, int plframe,
-                                                       const cf32* __restrict__ pllout, int8_t* __restrict__ llr, int N, const int* __restrict__ slot) {
+                                                       const cf32* __restrict__ pllout, int8_t* __restrict__ llr, int N, const int* __restrict__ slot,
+                                                       const S2StreamCfgDev* __restrict__ cfgs, int maxf, int8_t* const* __restrict__ llr_of) {
     const int f = blockIdx.y;
     const cf32* __restrict__ fr = pllout + (size_t)(slot ? slot[f] : f) * plframe;      // (stage pipeline: the loops wrote frame f to its stream's slot)
     int8_t* __restrict__ out = llr + (size_t)f * N;
+    if (cfgs) {
+        // mixed batch: the frame's configuration is its stream's (slot = stream * maxf + k; `plframe` as passed = the slot stride), its LLRs go where the table says
+        const S2StreamCfgDev* __restrict__ q = cfgs + slot[f] / maxf;
+        C = q->con; rate = q->rate; slots = q->slots; pilots = q->pilots; N = q->N;
+        out = llr_of[f];
+    }
     const int nsym = slots * 90;
     const int bits = C.bits;
     const int rows = N / bits;
@@ -1702,11 +1717,12 @@ __global__ __launch_bounds__(256) void s2_deinterleave_kernel(int constel, int r
 // where slice sub - 1 stopped (walk_cur / walk_nf in the stream state); the frames come out as in one walk over the whole call, because a window
 // is only ever looked at once it is complete and a realigned frame that is not all in yet waits (pl_pending) exactly as it does between calls.
 __global__ __launch_bounds__(256) void s2_ccm_walk_kernel(const S2StreamWork* __restrict__ work, int raw, int maxf, S2VcmFound* __restrict__ found,
-                                                          int* __restrict__ counts, int sub, int nsub) {
+                                                          int* __restrict__ counts, int sub, int nsub, const S2StreamCfgDev* __restrict__ cfgs) {
     __shared__ cf32 d[256 + 96];
     __shared__ float r_val[256];
     __shared__ int r_idx[256];
     const int s = blockIdx.x, tid = threadIdx.x;
+    if (cfgs) raw = cfgs[s].plframe;             // mixed batch: the PLFRAME length of THIS stream's MODCOD
     const S2StreamWork w = work[s];
     S2StreamState* st = w.st;
     const cf32* __restrict__ fifo = w.fifo;
@@ -2738,7 +2754,7 @@ static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, c
     }
     if (p.parts & 2) {
         if (p.spans) p.spans->begin(2, s);
-        hipLaunchKernelGGL(s2_ccm_walk_kernel, dim3(nstreams), dim3(256), 0, s, d_work, p.raw, p.maxf, p.d_found, p.d_counts, c, nsub);
+        hipLaunchKernelGGL(s2_ccm_walk_kernel, dim3(nstreams), dim3(256), 0, s, d_work, p.raw, p.maxf, p.d_found, p.d_counts, c, nsub, p.cfgs);
         if (p.spans) p.spans->end(2, s);
         const int L = p.loops_launches < 1 ? 1 : (p.loops_launches > nsub ? nsub : p.loops_launches);
         if ((c + 1) * L / nsub > c * L / nsub) {
@@ -2747,11 +2763,11 @@ static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, c
             if (p.spec && spw == 1)
                 hipLaunchKernelGGL(s2_frame_loops_kernel<true>, dim3(nstreams), dim3(64), 0, s, d_work, nstreams, (const S2FrameRef*)nullptr,
                                    (const int*)nullptr, coefs, p.tabs, p.con, p.pls_code, p.slots, p.pilots, p.pilot_blocks, p.raw, p.d_pllout, p.d_stats,
-                                   (const S2VcmFound*)p.d_found, p.maxf, spw);
+                                   (const S2VcmFound*)p.d_found, p.maxf, spw, p.cfgs);
             else
             hipLaunchKernelGGL(s2_frame_loops_kernel<false>, dim3((nstreams + spw - 1) / spw), dim3(64), 0, s, d_work, nstreams, (const S2FrameRef*)nullptr,
                                (const int*)nullptr, coefs, p.tabs, p.con, p.pls_code, p.slots, p.pilots, p.pilot_blocks, p.raw, p.d_pllout, p.d_stats,
-                               (const S2VcmFound*)p.d_found, p.maxf, spw);
+                               (const S2VcmFound*)p.d_found, p.maxf, spw, p.cfgs);
             if (p.spans) p.spans->end(3, s);
         }
     }
@@ -2867,11 +2883,11 @@ hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const
                                  int pilot_blocks, int plframe, cf32* d_pllout, S2FrameStats* d_stats, hipStream_t st) {
     const int spw = frame_loops_spw(nstreams);
     hipLaunchKernelGGL(s2_frame_loops_kernel<false>, dim3((nstreams + spw - 1) / spw), dim3(64), 0, st, d_work, nstreams, d_frames, d_first, coefs,
-                       tabs, con, pls_code, slots, pilots, pilot_blocks, plframe, d_pllout, d_stats, (const S2VcmFound*)nullptr, 0, spw);
+                       tabs, con, pls_code, slots, pilots, pilot_blocks, plframe, d_pllout, d_stats, (const S2VcmFound*)nullptr, 0, spw, (const S2StreamCfgDev*)nullptr);
     return hipGetLastError();
 }
 hipError_t s2_ccm_walk_launch(const S2StreamWork* d_work, int nstreams, int raw, int maxf, S2VcmFound* d_found, int* d_counts, hipStream_t st) {
-    hipLaunchKernelGGL(s2_ccm_walk_kernel, dim3(nstreams), dim3(256), 0, st, d_work, raw, maxf, d_found, d_counts, 0, 1);
+    hipLaunchKernelGGL(s2_ccm_walk_kernel, dim3(nstreams), dim3(256), 0, st, d_work, raw, maxf, d_found, d_counts, 0, 1, (const S2StreamCfgDev*)nullptr);
     return hipGetLastError();
 }
 hipError_t s2_vcm_walk_launch(const S2StreamWork* d_work, int nstreams, S2PlTablesDev tabs, const S2VcmMod* d_mods, float sof_threshold, int maxf,
@@ -2912,7 +2928,16 @@ hipError_t s2_demap_launch(S2ConstelDev con, int rate, int shortframe, int slots
                       (con.bits == 2 || ((N / con.bits) & 3) == 0);
     if (!wide) con.lut_bits4 = nullptr;
     else gx = (slots * 90 / 4 + 255) / 256;
-    hipLaunchKernelGGL(s2_demap_kernel, dim3(gx, nframes), dim3(256), 0, st, con, rate, slots, pilots, plframe, d_pllout, d_llr, N, d_slot);
+    hipLaunchKernelGGL(s2_demap_kernel, dim3(gx, nframes), dim3(256), 0, st, con, rate, slots, pilots, plframe, d_pllout, d_llr, N, d_slot,
+                       (const S2StreamCfgDev*)nullptr, 0, (int8_t* const*)nullptr);
+    return hipGetLastError();
+}
+hipError_t s2_demap_mixed_launch(const S2StreamCfgDev* cfgs, int max_slots, int maxf, int slot_stride, const cf32* d_pllout, int nframes,
+                                 int8_t* const* d_llr_of, hipStream_t st, const int* d_slot) {
+    // (every buffer here is the library's own: aligned for the wide form; the kernel falls back to the byte form per configuration where a column is not a whole number of words)
+    const int gx = (max_slots * 90 / 4 + 255) / 256;
+    hipLaunchKernelGGL(s2_demap_kernel, dim3(gx, nframes), dim3(256), 0, st, S2ConstelDev{}, 0, 0, 0, slot_stride, d_pllout, (int8_t*)nullptr, 0, d_slot,
+                       cfgs, maxf, d_llr_of);
     return hipGetLastError();
 }
 
