@@ -324,7 +324,6 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
     if (ctx->fe_stream) (void)hipStreamDestroy(ctx->fe_stream);
     if (ctx->fec_stream) (void)hipStreamDestroy(ctx->fec_stream);
     if (ctx->ev_llr) (void)hipEventDestroy(ctx->ev_llr);
-    for (hipEvent_t e : ctx->ev_pre) if (e) (void)hipEventDestroy(e);
     for (int g = 0; g < dvbs2gpu_ctx::MAX_PIPE_GROUPS; ++g) {
         for (int k = 0; k < 2; ++k) if (ctx->ev_fec[g][k]) (void)hipEventDestroy(ctx->ev_fec[g][k]);
         if (ctx->ev_llr_grp[g]) (void)hipEventDestroy(ctx->ev_llr_grp[g]);

@@ -145,7 +145,6 @@ struct dvbs2gpu_ctx {
     s2::Workspace ws_grp[MAX_PIPE_GROUPS][8];
     hipStream_t grp_stream[MAX_PIPE_GROUPS] = {};
     hipEvent_t ev_llr_grp[MAX_PIPE_GROUPS] = {};
-    hipEvent_t ev_pre[s2::S2_FE_MAX_SLICES + 1] = {};     // mixed batches: slice c of the shared front-end pass (RRC included) is through
     std::mutex fec_mtx;                                   // FEC jobs on the shared stream are enqueued whole, one at a time (shared FEC workspaces)
     // FEC jobs too small to fill the device (a group of a 64-transponder batch: a handful of decoder workgroups, 4-6 ms of latency each) run
     // SIDE BY SIDE instead: on the group's own stream (grp_stream) with a set of FEC workspaces per group

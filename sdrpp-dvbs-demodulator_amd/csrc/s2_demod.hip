@@ -489,12 +489,9 @@ struct HostMarks {
     ~HostMarks() { if (on) fprintf(stderr, "[dvbs2gpu host]%s\n", line.c_str()); }
 };
 
-// a shared front-end pass of a mixed batch that is still running: slice c (AGC, timing recovery, RRC) is through when ev[c] has happened
-struct PreSlices { const hipEvent_t* ev; int nsub; };
-
 int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts,
                   uint8_t* const* d_out, int out_cap, int* out_bytes, hipStream_t st, bool pipelined, int slot, const int* pre_nsym, bool own_ws, bool deliver_now,
-                  const PreSlices* pre = nullptr, const BatchMap* bm = nullptr) {
+                  const BatchMap* bm = nullptr) {
     HostMarks hm;
     const auto t_entry = std::chrono::steady_clock::now();
     dvbs2gpu_demod* d0 = dm[0];
@@ -548,7 +545,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     // share to its minimum): there the stages back to back leave the decoder more of the SIMDs (headline: 390 vs 394 ms per step).
     // (stage_pipeline == 2, for the tests: every other call, whatever the mode -- the two flows leave a stream in the same state)
     // (a small bank is a set of latency chains whatever the mode: always staged)
-    const bool staged = pre ? true : !pre_nsym && (ctx->stage_pipeline == 2 ? (ctx->stage_calls++ & 1) != 0 :
+    const bool staged = !pre_nsym && (ctx->stage_pipeline == 2 ? (ctx->stage_calls++ & 1) != 0 :
         ctx->stage_pipeline && (n <= S2_SMALL_BANK || !(pipelined && ctx->g_prio_auto && ctx->g_prio_duty <= ctx->stage_pipeline_min_duty)));
     Workspace& ws_pll = W[3];
     Workspace& ws_slot = W[7];
@@ -576,17 +573,6 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             post.spec = 1;
             post.loops_launches = std::min(S2_FE_MAX_SLICES, std::max(launches, (max_count / 2) / std::max(sym_per_launch, 1)));
         }
-        if (pre) {
-            // the shared pass (frontend_prepass) is running on its own streams: this group's PL-sync walk and frame loops go behind every one of
-            // its slices, on the group's stream
-            post.parts = 2;
-            S2LoopCoefs lc = d0->co;
-            lc.g_prio_duty = pipelined ? ctx->g_prio_duty : 0;
-            for (int c = 0; c < pre->nsub; ++c) {
-                HIP_TRY(hipStreamWaitEvent(st, pre->ev[c], 0));
-                HIP_TRY(s2_post_stages_launch(d_work, n, lc, post, c, pre->nsub, st));
-            }
-        } else
         { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st, &post, ctx->stage_post_stream == 2 || (!pipelined && ctx->stage_post_stream))); }
         slot_stats.resize(nslot);
         HIP_TRY(hipMemcpyAsync(slot_stats.data(), ws_slot.p, sizeof(S2FrameStats) * nslot, hipMemcpyDeviceToHost, st));
@@ -1319,10 +1305,8 @@ int process_mixed(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
 // AGC, NCO, Gardner, RRC + decimation do not depend on the MODCOD: for a batch of several configuration groups whose loop
 // coefficients and matched filter agree they run ONCE over all streams (these kernels are latency-bound: eight groups of 512
 // streams cost eight times one group of 4096).  Leaves the symbols in the streams' FIFOs exactly as process_group would.
-// slices != nullptr: the pass is left RUNNING -- its RRC stage goes behind every timing-recovery slice and ctx->ev_pre[c] marks slice c;
-// the groups hang their own stages on those events (process_group with `pre`) and the call ends when they have
 int frontend_prepass(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts, uint8_t* const* d_out,
-                     hipStream_t st, std::vector<int>* nsym_out, PreSlices* slices = nullptr) {
+                     hipStream_t st, std::vector<int>* nsym_out) {
     int rc;
     if ((rc = get_rx_tables(ctx))) return rc;
     dvbs2gpu_demod* d0 = dm[0];
@@ -1344,18 +1328,6 @@ int frontend_prepass(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const 
     int* d_nsym = (int*)((char*)ws.p + sizeof(S2StreamWork) * n);
     float* d_nco = (float*)(d_nsym + n);
     HIP_TRY(hipMemcpyAsync(d_work, work.data(), sizeof(S2StreamWork) * n, hipMemcpyHostToDevice, st));
-    if (slices) {
-        for (hipEvent_t& e : ctx->ev_pre) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        S2PostStages post{};
-        post.d_taps = d_taps; post.ntaps = d0->cfg.rrc_taps; post.max_count = max_count + max_count / 32 + 8;
-        post.parts = 1; post.slice_done = ctx->ev_pre; post.loops_launches = 1;
-        int nsub = 1;
-        // (the work table is copied from pageable memory: staged by the runtime before hipMemcpyAsync returns)
-        { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st, &post, false, &nsub)); }
-        slices->ev = ctx->ev_pre; slices->nsub = nsub;
-        nsym_out->assign(n, 0);
-        return 0;
-    }
     { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st)); }
     { StageSpan sp(ctx->timers, ST_RRC, st); HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st)); }
     nsym_out->assign(n, 0);
@@ -1545,7 +1517,7 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
             std::vector<uint8_t*> go;
             for (int k : idx) { g.push_back(demods[k]); gi.push_back((const cf32*)d_iq[k]); gc.push_back(counts[k]); go.push_back(d_out[k]); }
             int rc = g[0]->cfg.acm_vcm ? process_vcm_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), st, pipe, slot, pipe ? &bmap : nullptr)
-                                       : process_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), st, pipe, slot, nullptr, false, false, nullptr, pipe ? &bmap : nullptr);
+                                       : process_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), st, pipe, slot, nullptr, false, false, pipe ? &bmap : nullptr);
             if (rc) return rc;
             if (!pipe) for (size_t k = 0; k < idx.size(); ++k) out_bytes[idx[k]] = gb[k];
             ++slot;
@@ -1568,21 +1540,13 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
             return pipe ? collect_leftovers(1) : 0;
         }
     }
-    // several groups with one front end: the MODCOD-independent stages run once for the whole batch
-    // (tried in round 3 for small mixed batches -- 64 transponders in 8 groups: every group running its WHOLE chain by itself, side by side, each
-    // with the stage pipeline inside.  8 groups x 4 streams do not get a hardware queue each (9 queues in all with GPU_MAX_HW_QUEUES=12): the
-    // groups' kernels queue up behind each other, 130 ms per step against 80 with the shared pass.  DVBS2GPU_MIXED_ALONE=1 selects it.)
+    // bigger mixed batches (and small ones whose loop settings differ): several groups with one front end -- the MODCOD-independent stages run once
+    // for the whole batch, then the groups' MODCOD-dependent stages side by side
     std::vector<int> pre_nsym;
-    const bool small_mixed = groups.size() > 1 && n <= S2_SMALL_BANK && (int)groups.size() <= dvbs2gpu_ctx::MAX_PIPE_GROUPS && getenv("DVBS2GPU_MIXED_ALONE");
-    bool merged = groups.size() > 1 && !small_mixed;
+    bool merged = groups.size() > 1;
     for (int i = 1; merged && i < n; ++i) merged = same_frontend(demods[0], demods[i]);
-    // a small merged batch: the pass stays running and every group's walk + frame loops follow it slice by slice; a GPU-filling batch gains
-    // nothing from it (its loops fill the device whenever they run)
-    PreSlices pre_slices{nullptr, 0};
-    static const int pre_async_max = [] { const char* e = getenv("DVBS2GPU_MIXED_PREPASS_ASYNC_MAX"); return e ? atoi(e) : S2_SMALL_BANK; }();     // (0: never)
-    const bool pre_async = merged && n <= pre_async_max && (int)groups.size() <= dvbs2gpu_ctx::MAX_PIPE_GROUPS && ctx->stage_pipeline == 1;
     if (merged) {
-        int rc = frontend_prepass(ctx, demods, n, (const cf32* const*)d_iq, counts, d_out, st, &pre_nsym, pre_async ? &pre_slices : nullptr);
+        int rc = frontend_prepass(ctx, demods, n, (const cf32* const*)d_iq, counts, d_out, st, &pre_nsym);
         if (rc) return rc;
     }
     struct GroupJob {
@@ -1595,7 +1559,7 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
     };
     std::list<GroupJob> jobs;
     // (synchronous calls collect each group's FEC job before they return)
-    const bool side_by_side = (merged || small_mixed) && (int)groups.size() <= dvbs2gpu_ctx::MAX_PIPE_GROUPS;
+    const bool side_by_side = merged && (int)groups.size() <= dvbs2gpu_ctx::MAX_PIPE_GROUPS;
     int group_no = 0;
     for (const std::vector<int>& idx : groups) {
         std::vector<dvbs2gpu_demod*> g;
@@ -1614,7 +1578,7 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
             continue;
         }
         int rc = process_group(ctx, g.data(), (int)g.size(), gi.data(), gc.data(), go.data(), out_cap, gb.data(), st, pipe, pipe ? group_no : 0,
-                               merged ? gn.data() : nullptr, false, false, nullptr, pipe ? &bmap : nullptr);
+                               merged ? gn.data() : nullptr, false, false, pipe ? &bmap : nullptr);
         if (rc) return rc;
         if (!pipe) for (size_t k = 0; k < idx.size(); ++k) out_bytes[idx[k]] = gb[k];
         ++group_no;
@@ -1651,22 +1615,22 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
         for (GroupJob& J : jobs) {
             if (&J == &jobs.back()) break;            // (the last group runs on the calling thread, below)
             try {
-                th.emplace_back([&J, ctx, out_cap, pipe, merged, pre_async, &pre_slices, &bmap]() {
+                th.emplace_back([&J, ctx, out_cap, pipe, merged, &bmap]() {
                     if (hipSetDevice(ctx->device) != hipSuccess) { J.rc = DVBS2GPU_ERR_HIP; J.err = "hipSetDevice"; return; }
                     J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
-                                         ctx->grp_stream[J.slot], true, J.slot, (merged && !pre_async) ? J.gn.data() : nullptr, true, !pipe, pre_async ? &pre_slices : nullptr, pipe ? &bmap : nullptr);
+                                         ctx->grp_stream[J.slot], true, J.slot, merged ? J.gn.data() : nullptr, true, !pipe, pipe ? &bmap : nullptr);
                     if (J.rc) J.err = last_error();
                 });
             } catch (...) {                           // no thread to be had: run the group here (no exception leaves the C ABI)
                 J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
-                                     ctx->grp_stream[J.slot], true, J.slot, (merged && !pre_async) ? J.gn.data() : nullptr, true, !pipe, pre_async ? &pre_slices : nullptr, pipe ? &bmap : nullptr);
+                                     ctx->grp_stream[J.slot], true, J.slot, merged ? J.gn.data() : nullptr, true, !pipe, pipe ? &bmap : nullptr);
                 if (J.rc) J.err = last_error();
             }
         }
         {
             GroupJob& J = jobs.back();
             J.rc = process_group(ctx, J.g.data(), (int)J.g.size(), J.gi.data(), J.gc.data(), J.go.data(), out_cap, J.gb.data(),
-                                 ctx->grp_stream[J.slot], true, J.slot, (merged && !pre_async) ? J.gn.data() : nullptr, true, !pipe, pre_async ? &pre_slices : nullptr, pipe ? &bmap : nullptr);
+                                 ctx->grp_stream[J.slot], true, J.slot, merged ? J.gn.data() : nullptr, true, !pipe, pipe ? &bmap : nullptr);
             if (J.rc) J.err = last_error();
         }
         for (auto& t : th) t.join();

@@ -198,12 +198,8 @@ struct S2PostStages {
     S2SliceSpans* spans;                                                    // per-stage timers (optional)
     int loops_launches;                                                     // the frame loops run behind this many of the slices, evenly spaced, the last one included (every
                                                                             // launch costs its longest stream's chain: it only pays with about a frame per stream and launch)
-    // mixed batches (s2_demod.hip): the shared front-end pass runs part 1 (RRC) for ALL streams behind every slice and records slice_done[c];
-    // every configuration group then runs part 2 (walk + frame loops) for ITS streams behind that event on its own stream
     int spec = 0;                                                           // frame loops ahead of the PL sync (small banks, see S2StreamState)
     const S2StreamCfgDev* cfgs = nullptr;                                   // mixed batch: per-stream configuration (then `raw` is the slot stride = the longest PLFRAME of the batch)
-    int parts = 3;                                                          // 1: RRC + /2, 2: PL-sync walk + frame loops
-    hipEvent_t* slice_done = nullptr;                                       // [nsub] or null
 };
 hipError_t s2_post_stages_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const S2PostStages& p, int c, int nsub, hipStream_t s);
 hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCoefs coefs, const float* d_bank, hipStream_t st, hipStream_t aux,

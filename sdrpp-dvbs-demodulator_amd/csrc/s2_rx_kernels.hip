@@ -2744,7 +2744,7 @@ hipError_t dvbs_soft_compact_launch(const DvbsStreamWork* d_work, int nstreams, 
 // so far, while the timing loop works on the next slice.  No host in between: frames stay in per-stream slots (S2PostStages), the host reads
 // the frame tables once, after the last slice.  ev2: nsub + 1 more events (timing recovery of slice c done; the last: post stages done).
 static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const S2PostStages& p, int c, int nsub, hipStream_t s) {
-    if (p.parts & 1) {
+    {
         int gx = ((p.max_count / nsub) / 2 + 2 + 255) / 256;
         gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
         if (p.spans) p.spans->begin(1, s);
@@ -2752,7 +2752,7 @@ static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, c
         if (c == nsub - 1) hipLaunchKernelGGL(s2_rrc_state_kernel, dim3(nstreams), dim3(128), 0, s, d_work, p.ntaps);
         if (p.spans) p.spans->end(1, s);
     }
-    if (p.parts & 2) {
+    {
         if (p.spans) p.spans->begin(2, s);
         hipLaunchKernelGGL(s2_ccm_walk_kernel, dim3(nstreams), dim3(256), 0, s, d_work, p.raw, p.maxf, p.d_found, p.d_counts, c, nsub, p.cfgs);
         if (p.spans) p.spans->end(2, s);
@@ -2771,7 +2771,6 @@ static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, c
             if (p.spans) p.spans->end(3, s);
         }
     }
-    if (p.slice_done) { hipError_t e = hipEventRecord(p.slice_done[c], s); if (e != hipSuccess) return e; }
     return hipGetLastError();
 }
 hipError_t s2_post_stages_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const S2PostStages& p, int c, int nsub, hipStream_t s) {
