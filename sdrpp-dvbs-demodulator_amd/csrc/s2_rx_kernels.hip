@@ -1639,13 +1639,16 @@ __device__ __forceinline__ int deint_pos(int constel, int rate, int bits, int ro
 // Wide form (the LUT constellations, whenever a column is a whole number of words): a lane takes FOUR consecutive payload symbols -- two 16-byte
 // loads, one table word per symbol (lut_bits4), one 32-bit store per bit column; the byte form (three byte loads and three byte stores per symbol)
 // ran at 1.1 TB/s of its 7.8 GB per 32 768 frames.
+// MIXED: a separate instantiation -- with the configuration a run-time choice between the arguments and a table the plain kernel lost its
+// scalar operands (headline: 4.4 -> 18.8 ms per step)
+template <bool MIXED>
 __global__ __launch_bounds__(256) void s2_demap_kernel(S2ConstelDev C, int rate, int slots, int pilots, int plframe,
                                                        const cf32* __restrict__ pllout, int8_t* __restrict__ llr, int N, const int* __restrict__ slot,
                                                        const S2StreamCfgDev* __restrict__ cfgs, int maxf, int8_t* const* __restrict__ llr_of) {
     const int f = blockIdx.y;
     const cf32* __restrict__ fr = pllout + (size_t)(slot ? slot[f] : f) * plframe;      // (stage pipeline: the loops wrote frame f to its stream's slot)
     int8_t* __restrict__ out = llr + (size_t)f * N;
-    if (cfgs) {
+    if constexpr (MIXED) {
         // mixed batch: the frame's configuration is its stream's (slot = stream * maxf + k; `plframe` as passed = the slot stride), its LLRs go where the table says
         const S2StreamCfgDev* __restrict__ q = cfgs + slot[f] / maxf;
         C = q->con; rate = q->rate; slots = q->slots; pilots = q->pilots; N = q->N;
@@ -2927,7 +2930,7 @@ hipError_t s2_demap_launch(S2ConstelDev con, int rate, int shortframe, int slots
                       (con.bits == 2 || ((N / con.bits) & 3) == 0);
     if (!wide) con.lut_bits4 = nullptr;
     else gx = (slots * 90 / 4 + 255) / 256;
-    hipLaunchKernelGGL(s2_demap_kernel, dim3(gx, nframes), dim3(256), 0, st, con, rate, slots, pilots, plframe, d_pllout, d_llr, N, d_slot,
+    hipLaunchKernelGGL(s2_demap_kernel<false>, dim3(gx, nframes), dim3(256), 0, st, con, rate, slots, pilots, plframe, d_pllout, d_llr, N, d_slot,
                        (const S2StreamCfgDev*)nullptr, 0, (int8_t* const*)nullptr);
     return hipGetLastError();
 }
@@ -2935,7 +2938,7 @@ hipError_t s2_demap_mixed_launch(const S2StreamCfgDev* cfgs, int max_slots, int 
                                  int8_t* const* d_llr_of, hipStream_t st, const int* d_slot) {
     // (every buffer here is the library's own: aligned for the wide form; the kernel falls back to the byte form per configuration where a column is not a whole number of words)
     const int gx = (max_slots * 90 / 4 + 255) / 256;
-    hipLaunchKernelGGL(s2_demap_kernel, dim3(gx, nframes), dim3(256), 0, st, S2ConstelDev{}, 0, 0, 0, slot_stride, d_pllout, (int8_t*)nullptr, 0, d_slot,
+    hipLaunchKernelGGL(s2_demap_kernel<true>, dim3(gx, nframes), dim3(256), 0, st, S2ConstelDev{}, 0, 0, 0, slot_stride, d_pllout, (int8_t*)nullptr, 0, d_slot,
                        cfgs, maxf, d_llr_of);
     return hipGetLastError();
 }
