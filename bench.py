@@ -749,7 +749,7 @@ def main():
         tj = json.load(open(cands[-1]))
         traffic = tj.get('traffic_bytes_per_frame', 0) * in_step_frames or None     # (measured on a 4096-frame launch; the kernel's traffic is per frame)
         traffic_note = tj.get('source')
-        issue = tj.get('valu_issue_fraction')
+        issue = tj.get('valu_per_simd_cycle', tj.get('valu_issue_fraction'))
         wcf = tj.get('wave_cycles_fraction')
         traffic_current = tj.get('kernel_source_sha16') == ldpc_source_hash()
 
@@ -769,7 +769,7 @@ def main():
                        'frames_out_of_sequence': acc['out_of_order'],
                        'check': 'every delivered frame of every stream, last timed step + pipeline flush, on the device (hash + full byte compare)',
                        'fec_pipelined_across_steps': pipelined},
-            'roofline': {'bound': 'per-wave instruction issue + serial-section latency (measured, see wave_cycles_fraction); the HBM figure below is NOMINAL: algorithmic bytes against the 8 TB/s peak',
+            'roofline': {'bound': 'latency of the barrier-separated phases of a layer (per-wave instruction streams, LDS round trips, serial sections; see wave_cycles_fraction); the HBM figure below is NOMINAL: algorithmic bytes against the 8 TB/s peak',
                          'kernel': 'ldpc_decode_kernel<%d,%d,%s>' % (plan['max_deg'], plan['rec_dwords'], 'true' if plan.get('irregular') else 'false'),
                          'achieved': round(achieved if achieved else achieved_alone, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round((achieved if achieved else achieved_alone) / HBM_PEAK_GBS, 4),
@@ -778,7 +778,8 @@ def main():
                          'kernel_ms_alone': round(k['forced'], 4), 'achieved_alone': round(achieved_alone, 1), 'frac_alone': round(achieved_alone / HBM_PEAK_GBS, 4),
                          'kernel_ms_alone_normal_mode_same_iterations': round(k['normal'], 4) if k['normal_all_ran'] else None,
                          'traffic': traffic, 'traffic_taken_from_this_build': traffic_current, 'traffic_unit': 'bytes per launch (fabric-side FETCH_SIZE x2 + WRITE_SIZE, per frame x frames of the launch)', 'traffic_source': traffic_note,
-                         'valu_issue_fraction': issue, 'wave_cycles_fraction': wcf,
+                         'valu_per_simd_cycle': issue, 'valu_note': 'wave64 VALU instructions per SIMD and clock over the launch (PMC); a SIMD sustains >= 0.88 with four waves (tools/ubench/valu_cu.hip)',
+                         'wave_cycles_fraction': wcf,
                          'algorithmic_bytes_per_frame': bytes_per_frame, 'algorithmic_bytes_per_launch': int(bytes_per_frame * in_step_frames),
                          'ldpc_share_of_step': round(in_step_ms * l_n / (dt * 1e3), 3),
                          'syndrome_check': 'forced mode (the headline): evaluated once, after the last iteration; normal mode: before every iteration, as in the reference (bit-vector form, see DESIGN.md)',

@@ -453,8 +453,7 @@ static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work,
     if (nsub_out) *nsub_out = nsub > 1 ? nsub : 1;
     S2LoopCoefs cc = co;
     cc.g_prio_duty = ctx->pipeline_fec ? ctx->g_prio_duty : 0;
-    if (cc.g_prio_duty >= 3) ctx->g_lane_form = true; else if (cc.g_prio_duty == 0) ctx->g_lane_form = false;
-    cc.g_lane_form = ctx->g_lane_form ? 1 : 0;
+    cc.g_lane_form = (ctx->pipeline_fec && ctx->g_lane_form) ? 1 : 0;
     dvbs2gpu_ctx::FeAux* fa = nullptr;
     if (nsub > 1) {
         std::lock_guard<std::mutex> l(ctx->mtx);
@@ -569,7 +568,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         if (loops_ahead) {
             // behind (nearly) every slice -- but a launch wants a few thousand symbols per stream to chew on: a bank of 64 spends 0.4 ms per
             // launch on top of its symbols
-            static const int sym_per_launch = [] { const char* e = getenv("DVBS2GPU_LOOPS_AHEAD_SYMBOLS"); return e ? atoi(e) : 2700; }();
+            constexpr int sym_per_launch = 2700;
             post.spec = 1;
             post.loops_launches = std::min(S2_FE_MAX_SLICES, std::max(launches, (max_count / 2) / std::max(sym_per_launch, 1)));
         }
@@ -732,7 +731,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     std::unique_ptr<PendingFec> started;
     // (a small job that runs on the group's own stream -- see below -- goes behind the previous job's delivery instead: that delivery ends with a
     //  synchronisation of this very stream)
-    const bool beside = own_ws && st && nf <= ctx->num_cus && !getenv("DVBS2GPU_FEC_JOBS_IN_LINE");
+    const bool beside = own_ws && st && nf <= ctx->num_cus;
     bool prev_delivered = false;
     if (beside && prev) {
         if ((rc = deliver(prev))) return rc;
@@ -803,6 +802,31 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             } else {
                 ctx->g_prio_trend = verdict;
             }
+            // which timing-recovery form a big bank runs (ctx.h): the call times of the two forms decide
+            if (n >= 2048) {
+                dvbs2gpu_ctx::LaneProbe& L = ctx->lane_probe;
+                if (L.n != n || std::abs(L.max_count - max_count) > max_count / 8) { L = dvbs2gpu_ctx::LaneProbe(); L.n = n; L.max_count = max_count; }
+                const int cur_form = ctx->g_lane_form ? 1 : 0;
+                if (L.since_switch++ >= 1) { L.sum[cur_form] += call_ms; L.cnt[cur_form]++; }       // (the first call after a switch is a transient)
+                ++L.since_probe;
+                constexpr int PROBE_CALLS = 4, REPROBE_AFTER = 128;
+                auto go = [&](int form) { ctx->g_lane_form = form != 0; L.since_switch = 0; L.sum[form] = 0; L.cnt[form] = 0; };
+                if (L.probing) {
+                    if (L.cnt[cur_form] >= PROBE_CALLS) {
+                        // keep the form with the shorter calls (both have fresh figures now)
+                        const int other = cur_form ^ 1;
+                        const bool stay = L.cnt[other] == 0 || L.sum[cur_form] / L.cnt[cur_form] <= L.sum[other] / L.cnt[other];
+                        L.probing = false; L.since_probe = 0;
+                        if (!stay) { ctx->g_lane_form = other != 0; L.since_switch = 0; }
+                    }
+                } else if (L.cnt[cur_form] >= PROBE_CALLS && (cur_form == 1 || ctx->g_prio_duty >= 2) && (L.cnt[cur_form ^ 1] == 0 || L.since_probe >= REPROBE_AFTER)) {
+                    // the other form has no (recent) figure: try it -- the lane form only once the front end has been found critical
+                    L.probing = true;
+                    L.sum[cur_form] = L.sum[cur_form] / L.cnt[cur_form] * PROBE_CALLS; L.cnt[cur_form] = PROBE_CALLS;     // (the mean of the form being left, as PROBE_CALLS calls)
+                    go(cur_form ^ 1);
+                }
+            }
+            if (hm.on) { char b[96]; snprintf(b, sizeof(b), " wait=%.2f call=%.1f duty=%d lane=%d", wait_ms, call_ms, ctx->g_prio_duty, (int)ctx->g_lane_form); hm.line += b; }
         }
     }
     if (started) {
@@ -1163,7 +1187,7 @@ int process_mixed(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
                           0, 0, 0, d_pll, (S2FrameStats*)W[7].p, ctx->timers.on ? &spans : nullptr, launches};
         post.cfgs = d_cfgs;
         if (loops_ahead) {
-            static const int sym_per_launch = [] { const char* e = getenv("DVBS2GPU_LOOPS_AHEAD_SYMBOLS"); return e ? atoi(e) : 2700; }();
+            constexpr int sym_per_launch = 2700;
             post.spec = 1;
             post.loops_launches = std::min(S2_FE_MAX_SLICES, std::max(launches, (max_count / 2) / std::max(sym_per_launch, 1)));
         }

@@ -36,14 +36,17 @@ t = {
     'fetch_size_kb': fetch, 'write_size_kb': write,
     'traffic_bytes_per_launch': traffic, 'traffic_bytes_per_frame': traffic / frames,
     'sq_insts_valu': valu,
-    'valu_issue_fraction': round(valu * 4 / (cus * simds * ms * 1e-3 * clk), 4),
-    'valu_issue_formula': 'SQ_INSTS_VALU x 4 cycles (a wave64 VALU instruction occupies its SIMD for 4 cycles) / (256 CUs x 4 SIMDs x kernel time x 2.4 GHz)',
+    'valu_per_simd_cycle': round(valu / (cus * simds * ms * 1e-3 * clk), 4),
+    'valu_per_simd_cycle_formula': 'SQ_INSTS_VALU / (256 CUs x 4 SIMDs x kernel time x 2.4 GHz); tools/ubench/valu_cu.hip: a wave issues one VALU instruction per 4.6 (4-byte '
+                                   'encoding) / 5.6 (8-byte) cycles whatever else runs on its SIMD, and a SIMD sustains >= 0.88 per cycle with four such waves '
+                                   '(profiles/r04_ubench_notes.txt) -- rounds 1-3 multiplied this figure by 4 and called it a utilisation; it is not one',
     'wait_fraction': round(get('SQ_WAIT_ANY') / get('SQ_WAVE_CYCLES'), 4),
     # where a wave's resident cycles go (SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES, both in quad-cycles; fourth PMC pass)
     'wave_cycles_fraction': {k: round(get(c) / get('SQ_WAVE_CYCLES'), 4) for k, c in (('valu', 'SQ_ACTIVE_INST_VALU'), ('scalar', 'SQ_ACTIVE_INST_SCA'),
                              ('lds', 'SQ_ACTIVE_INST_LDS'), ('misc', 'SQ_ACTIVE_INST_MISC'), ('waiting_for_lds', 'SQ_WAIT_INST_LDS'))},
-    'reading': 'a wave executes an instruction in ~30 % of its resident cycles; the decoder is bound by the length of the per-wave instruction streams between barriers '
-               'and by its serial sections, not by memory (DESIGN.md section 5)',
+    'reading': 'a wave executes an instruction in ~30 % of its resident cycles and a SIMD issues a vector instruction in ~15 % of its cycles: the decoder is bound by the '
+               'latency of its barrier-separated phases (per-wave instruction streams, LDS round trips at the phase boundaries, serial sections), not by memory and not '
+               'by vector throughput (DESIGN.md section 5; round 4 experiments: profiles/r04_ubench_notes.txt)',
 }
 json.dump(t, open(os.path.join(P, tag + '_ldpc_traffic.json'), 'w'), indent=2)
 wrows = [l.rstrip() for p in ('w1', 'w2', 'w3') if os.path.exists(os.path.join(F, p + '.csv')) for l in open(os.path.join(F, p + '.csv')) if 'ldpc_wave_kernel' in l]
