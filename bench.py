@@ -33,7 +33,7 @@ import time
 
 import numpy as np
 
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '12')   # mixed batches run one HIP stream per configuration group (default: 4 hardware queues)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '12')   # mixed batches drive 7+ HIP streams side by side (default: 4 hardware queues, which they would share: correct, slower)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
