@@ -99,6 +99,15 @@ __device__ __forceinline__ void atab_load(uint32_t (&pw)[NPW], const uint32_t* _
 #pragma unroll
     for (int i = 0; i < NPI; ++i) pw[2 * i] = w[i];
 }
+#ifndef LDPC_DIET
+#define LDPC_DIET 1   // two cuts in a layer's per-wave instruction stream (what a layer costs): (1) the layer-ahead fetches -- message record, address / row words --
+                      // are issued unconditionally by every lane (idle lanes with a clamped row index; the records are cleared at the start of a frame, so the first sweep needs no "is
+                      // this the first sweep" either): no exec-mask juggling and, above all, no "fetched / not fetched" merge of the registers, which cost a copy of every prefetch register
+                      // at the top AND the bottom of the layer loop (20 v_mov); (2) the parity bits' LDS addresses follow the layer by one add instead of being rebuilt from the layer number.
+#endif
+// Measured per kernel (1024 frames x 50 iterations, frames/s): degree 2 (1/4) 114 441 -> 118 196, degree 5 (1/2) 99 026 -> 102 814, degree 28 (9/10) 79 153 -> 83 527;
+// degree 8 (2/3) 102 711 -> 100 674 and degree 12 (3/4) 92 541 -> 91 892: the two kernels that sit AT the 128-register cap lose what they gain to a different allocation and keep the old form
+template <int MAXDEG, bool IRREG> constexpr bool ldpc_diet() { return LDPC_DIET && (IRREG || (MAXDEG != 8 && MAXDEG != 12)); }
 #ifndef LDPC_WPE4_MAXDEG
 #define LDPC_WPE4_MAXDEG 28    // kernels up to this degree are held to 128 VGPRs (4 waves per SIMD: room for a front-end wave beside three decoder waves)
 #endif
@@ -231,7 +240,7 @@ template <int MAXDEG, int REC, int KIND, bool IRREG>
 __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const LdpcKernelArgs& A, const uint32_t* __restrict__ ents,
                                              const uint32_t (&pw)[2 * ((MAXDEG + 1) / 2)], const LdpcLayerDesc L, uint32_t rowword, int layer, int j, bool active, bool live,
                                              const uint32_t (&rec_in)[REC], uint32_t (&rec_out)[REC],
-                                             uint32_t* __restrict__ cw, uint8_t* __restrict__ cres, const uint32_t* __restrict__ walk = nullptr, unsigned long long* t_mark_p = nullptr) {
+                                             uint32_t* __restrict__ cw, uint8_t* __restrict__ cres, uint32_t own_a, const uint32_t* __restrict__ walk = nullptr, unsigned long long* t_mark_p = nullptr) {
 #if defined(LDPC_PROF) && LDPC_PROF == 3
     unsigned long long& t_mark = *t_mark_p;
 #endif
@@ -253,9 +262,13 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
     const int nc = CONF ? (int)(L.depth_nc >> 16) : 0;
     const uint32_t level = rowword & 0xffu, late = (rowword >> 8) & 0xfffu, early = rowword >> 20;
     int min0 = 255, min1 = 255, sx = 0;
-    const int own = A.K + 360 * layer + j;
+    constexpr bool DIET = ldpc_diet<MAXDEG, IRREG>();
     const bool has_prev = (layer | j) != 0;
-    const int prev = layer ? own - 360 : A.K + 360 * (A.q - 1) + j - 1;
+    // LDS addresses of the row's own parity bit and of the previous one (a layer back; layer 0: the last layer's, a row back -- row 0 of layer 0 has none: a valid byte, masked below).
+    // DIET: own_a is kept by the caller (+ 360 per layer)
+    const uint32_t own_l = DIET ? own_a : lbase + (uint32_t)(A.K + 360 * layer + j);
+    const uint32_t prev_l = DIET ? own_a + (uint32_t)(layer ? -360 : 360 * (A.q - 1) - 1)
+                                 : lbase + (uint32_t)(has_prev ? (layer ? A.K + 360 * layer + j - 360 : A.K + 360 * (A.q - 1) + j - 1) : A.K + 360 * layer + j);
 #define LINK_IN(k) ((int)V[(k) >> 1][(k) & 1] >> 8)
 #define LINK_MG(k) ((int)G[(k) >> 1][(k) & 1] >> 8)
 #define LINK_SET(k, v, m) do { V[(k) >> 1][(k) & 1] = (short)((v) << 8); G[(k) >> 1][(k) & 1] = (short)((m) << 8); } while (0)
@@ -299,9 +312,9 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                     addr[k] = la[h];
                     if (IRREG && k >= deg) absent[h] = true;
                 } else if (k == MAXDEG) {
-                    la[h] = lbase + (uint32_t)own;
+                    la[h] = own_l;
                 } else if (k == MAXDEG + 1) {
-                    la[h] = lbase + (uint32_t)(has_prev ? prev : own);   // (row 0 of layer 0 has no previous parity bit: masked below)
+                    la[h] = prev_l;
                 } else {
                     absent[h] = true;
                 }
@@ -650,7 +663,7 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
                     if (k < MAXC && k < nc) wr = !((early >> k) & 1);
                 }
                 if (wr) {
-                    const uint32_t a = (k < MAXDEG) ? addr[k] : lbase + (uint32_t)(k == MAXDEG ? own : prev);
+                    const uint32_t a = (k < MAXDEG) ? addr[k] : (k == MAXDEG ? own_l : prev_l);
                     if (h == 0) lds_write_lo_i8(a, bits2(pn)); else lds_write_hi_i8(a, bits2(pn));
                 }
             }
@@ -714,6 +727,15 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
                 int jj = c / q, i = c - jj * q;
                 post[K + 360 * i + jj] = src[K + c];
             }
+            if constexpr (ldpc_diet<MAXDEG, IRREG>()) {
+                // the first sweep reads all-zero messages: this lane's records are cleared here, so that a sweep fetches them without asking which sweep it is
+                if (j < 360 && !(LDPC_EXP & 1)) {
+                    uint32_t z[REC];
+#pragma unroll
+                    for (int w = 0; w < REC; ++w) z[w] = 0;
+                    for (int l = 0; l < q; ++l) rec_store<REC>(z, msg + ((size_t)l * 360 + j) * REC);
+                }
+            }
         }
         lds_barrier();
 
@@ -751,7 +773,10 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
             uint32_t rec_next[REC];
 #pragma unroll
             for (int w = 0; w < REC; ++w) rec_next[w] = 0;
-            if (!first && active && !(LDPC_EXP & 1)) rec_load<REC>(rec_next, msg + (size_t)j * REC);
+            constexpr bool DIET = ldpc_diet<MAXDEG, IRREG>();
+            const int jc = min(j, 359);                                  // (the row index idle lanes fetch with)
+            if constexpr (DIET) { if (!(LDPC_EXP & 1)) rec_load<REC>(rec_next, msg + (size_t)jc * REC); }
+            else if (!first && active && !(LDPC_EXP & 1)) rec_load<REC>(rec_next, msg + (size_t)j * REC);
             // The layer descriptors travel TWO layers ahead: the one of layer + 1 decides, at the top of a layer, whether that layer's row words
             // are prefetched -- loaded only one layer ahead it was awaited right there, i.e. every layer began with a scalar-cache round trip.
             LdpcLayerDesc Lnext = layers[0], Lnext2 = layers[q > 1 ? 1 : 0];
@@ -765,13 +790,15 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
             if constexpr (ATAB) {
 #pragma unroll
                 for (int i = 0; i < NPW; ++i) pw_next[i] = 0;
-                if (active) atab_load<NPI>(pw_next, atab + (size_t)j * ldpc_atab_stride(NPI));      // layer 0
+                if (DIET || active) atab_load<NPI>(pw_next, atab + (size_t)j * ldpc_atab_stride(NPI));      // layer 0
             } else if constexpr (PW_AHEAD) {
 #pragma unroll
                 for (int i = 0; i < NPW; ++i) pw_next[i] = ents[A.pent_base + i];
             }
             uint32_t rw_next = 1;
-            if ((Lnext.depth_nc & 0xffffu) > 1 && active) rw_next = rows[Lnext.row_off + j];
+            if constexpr (DIET) rw_next = rows[Lnext.row_off + jc];      // (conflict-free layers have row_off 0: a word nobody looks at)
+            else if ((Lnext.depth_nc & 0xffffu) > 1 && active) rw_next = rows[Lnext.row_off + j];
+            uint32_t own_a = lds_offset(post) + (uint32_t)(K + j);       // LDS address of the row's own parity bit: + 360 per layer
             for (int layer = 0; layer < q; ++layer) {
                 PROF_T(t_g);
                 uint32_t rec[REC];
@@ -783,7 +810,19 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
                 for (int i = 0; i < NPW; ++i) pw[i] = (ATAB || PW_AHEAD) ? pw_next[i] : ents[A.pent_base + layer * NPW + i];
                 const uint32_t rw = rw_next;
                 uint32_t* rp = msg + ((size_t)layer * 360 + j) * REC;
-                if (layer + 1 < q) {
+                if constexpr (DIET) {
+                    const int ln = layer + 1 < q ? layer + 1 : q - 1;       // (behind the last layer: the last layer's once more -- nobody reads them)
+                    Lnext = Lnext2;
+                    Lnext2 = layers[layer + 2 < q ? layer + 2 : q - 1];
+                    if constexpr (ATAB) {
+                        atab_load<NPI>(pw_next, atab + ((size_t)ln * LDPC_TPS + j) * ldpc_atab_stride(NPI));
+                    } else if constexpr (PW_AHEAD) {
+#pragma unroll
+                        for (int i = 0; i < NPW; ++i) pw_next[i] = ents[A.pent_base + ln * NPW + i];
+                    }
+                    if (!(LDPC_EXP & 1)) rec_load<REC>(rec_next, msg + ((size_t)ln * 360 + jc) * REC);
+                    rw_next = rows[Lnext.row_off + jc];
+                } else if (layer + 1 < q) {
                     Lnext = Lnext2;
                     Lnext2 = layers[layer + 2 < q ? layer + 2 : q - 1];
                     if constexpr (ATAB) {
@@ -800,12 +839,13 @@ __global__ __launch_bounds__(LDPC_FPB * LDPC_TPS) __attribute__((amdgpu_waves_pe
                 uint32_t ro[REC];
 #pragma unroll
                 for (int w = 0; w < REC; ++w) ro[w] = 0;
-                if ((L.depth_nc & 0xffffu) == 1) layer_update<MAXDEG, REC, 0, IRREG>(post, A, ents + L.ent_off, pw, L, 1u, layer, j, active, live, rec, ro, cw, cres, nullptr, PROF_MARK_PTR);
-                else if ((L.deg >> 16) == LDPC_WALK_MARK) layer_update<MAXDEG, REC, 6, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres, rows + L.row_off + 360);
-                else if ((L.deg >> 16) > 0) layer_update<MAXDEG, REC, 1, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres, nullptr, PROF_MARK_PTR);
-                else if ((L.depth_nc >> 16) <= 4u) layer_update<MAXDEG, REC, 3, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres);
-                else if (MAXDEG > 12 && (L.depth_nc >> 16) <= 8u) layer_update<MAXDEG, REC, (MAXDEG > 12 ? 4 : 2), IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres);
-                else layer_update<MAXDEG, REC, 2, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres);
+                if ((L.depth_nc & 0xffffu) == 1) layer_update<MAXDEG, REC, 0, IRREG>(post, A, ents + L.ent_off, pw, L, 1u, layer, j, active, live, rec, ro, cw, cres, own_a, nullptr, PROF_MARK_PTR);
+                else if ((L.deg >> 16) == LDPC_WALK_MARK) layer_update<MAXDEG, REC, 6, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres, own_a, rows + L.row_off + 360);
+                else if ((L.deg >> 16) > 0) layer_update<MAXDEG, REC, 1, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres, own_a, nullptr, PROF_MARK_PTR);
+                else if ((L.depth_nc >> 16) <= 4u) layer_update<MAXDEG, REC, 3, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres, own_a);
+                else if (MAXDEG > 12 && (L.depth_nc >> 16) <= 8u) layer_update<MAXDEG, REC, (MAXDEG > 12 ? 4 : 2), IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres, own_a);
+                else layer_update<MAXDEG, REC, 2, IRREG>(post, A, ents + L.ent_off, pw, L, rw, layer, j, active, live, rec, ro, cw, cres, own_a);
+                own_a += 360u;
                 // The prefetched record / row word of the next layer are claimed HERE, in uniform control flow and before this layer's
                 // record store is issued: the compiler's wait for those loads then sits where nothing recent is in flight.  Left to
                 // itself it put an s_waitcnt vmcnt(0) behind the store (the loop-carried copy of the prefetch registers, merged over
