@@ -646,6 +646,7 @@ def main():
     ap.add_argument('--mixed-frames', type=int, default=4, help='config mixed64: PLFRAMEs per stream per step')
     ap.add_argument('--mixed-sub', type=int, default=64, help='config mixed64: independent carriers per table entry (1 = BASELINE config 4 as named: 64 streams)')
     ap.add_argument('--workload', default='', help='development aid: MODCOD,short,pilots,Es/N0,rate instead of the headline workload (e.g. 27,1,1,20,9 = the config 5 stand-in); the line then is NOT the headline')
+    ap.add_argument('--plugin-mode', action='store_true', help='development aid: the main run with max_ldpc_trials 16 and early exit (the plugin\'s mode) instead of 50 forced iterations; the line then is NOT the headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip configs 2, 5, D and the mixed-MODCOD batch')
     ap.add_argument('--no-pipeline', action='store_true', help='run the FEC inside the call that produced the frames (no overlap with the next front end)')
@@ -716,12 +717,14 @@ def main():
 
     S, F = args.streams, args.frames
     pipelined = not args.no_pipeline
+    global MODCOD, SHORT, PILOTS, ESN0_DB, RATE, WORKLOAD
     if args.workload:
-        global MODCOD, SHORT, PILOTS, ESN0_DB, RATE, WORKLOAD
         w = args.workload.split(',')
         MODCOD, SHORT, PILOTS, ESN0_DB, RATE = int(w[0]), int(w[1]), int(w[2]), float(w[3]), int(w[4])
         WORKLOAD = 'development run, NOT the headline: MODCOD %d short %d pilots %d at %.1f dB' % (MODCOD, SHORT, PILOTS, ESN0_DB)
-    run = S2Run(eng, pkg, dev, MODCOD, SHORT, PILOTS, ESN0_DB, S, F, args.distinct, seed=rank)
+    if args.plugin_mode:
+        WORKLOAD = 'development run, NOT the headline: ' + WORKLOAD + ' -- in the plugin\'s mode (16 trials, early exit)'
+    run = S2Run(eng, pkg, dev, MODCOD, SHORT, PILOTS, ESN0_DB, S, F, args.distinct, seed=rank, **(dict(iters=16, force=False) if args.plugin_mode else {}))
     dt, stages, acc = time_steps(run, args.steps, args.warmup, barrier, pipelined)
     dt = dd.max_over_ranks(dt)
     info, sym = run.info, run.sym

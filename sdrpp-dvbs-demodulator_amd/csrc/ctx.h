@@ -162,11 +162,6 @@ struct dvbs2gpu_ctx {
     int fe_slices = 0;                        // DVBS2GPU_FE_SLICES (0 = by mode: 4 pipelined, 8 synchronous; 1 = both stages back to back on the caller's stream)
     // balance of the two streams of the pipelined mode (s2_demod.hip): share of the timing loop's tiles that run one priority level up
     int g_prio_duty = 0, g_prio_trend = 0;
-    // big banks (>= 2048 streams): the lane-per-stream timing recovery halves the front end and costs the co-resident decoder 20-25 ms per step.  Whether a step
-    // gains by it is MEASURED: once the balancer has found the front end critical (duty >= 2) the other form is tried for a few calls, the form with the shorter
-    // calls stays, the other one is tried again every 128 calls (s2_demod.hip).  (A switch tied to the duty alone made a step bound by both streams flip for ever.)
-    bool g_lane_form = false;
-    struct LaneProbe { double sum[2] = {0, 0}; int cnt[2] = {0, 0}; int since_switch = 0, since_probe = 0, n = 0, max_count = 0; bool probing = false; } lane_probe;
     bool g_prio_auto = true;                  // DVBS2GPU_G_PRIO_DUTY fixes the value
     int dvbs_bank_min = 1280;                 // DVBS2GPU_DVBS_BANK_MIN: carriers from which a bank uses the four-streams-per-wave FLL (measured crossover; tests: 1)
     int dvbs_agc_stream = 1;                  // DVBS2GPU_DVBS_AGC_STREAM: the AGC slices of a bank below dvbs_bank_min carriers on a third auxiliary stream (0: on the Viterbi stream)

@@ -453,7 +453,7 @@ static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work,
     if (nsub_out) *nsub_out = nsub > 1 ? nsub : 1;
     S2LoopCoefs cc = co;
     cc.g_prio_duty = ctx->pipeline_fec ? ctx->g_prio_duty : 0;
-    cc.g_lane_form = (ctx->pipeline_fec && ctx->g_lane_form) ? 1 : 0;
+    cc.g_lane_form = 0;
     dvbs2gpu_ctx::FeAux* fa = nullptr;
     if (nsub > 1) {
         std::lock_guard<std::mutex> l(ctx->mtx);
@@ -779,6 +779,9 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         started = std::move(job);
     }
     if (prev && !prev_delivered) {
+        // (asked BEFORE the delivery: had the previous call's FEC job already ended when this call's front end was through?  The delivery itself takes
+        //  0.3-0.6 ms with the job long done -- copies, scatter, synchronisation --, which a fixed threshold on the waiting time mistook for "just in time")
+        const bool job_was_done = prev->done && hipEventQuery(prev->done) == hipSuccess;
         const auto t_d0 = std::chrono::steady_clock::now();
         if ((rc = deliver(prev))) {               // FEC of the previous call (ran during this call's front end)
             // this call's job is already on the device: it stays parked for the next call (or reset) to collect -- dropping it here would free
@@ -795,38 +798,14 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             const auto t_d1 = std::chrono::steady_clock::now();
             const double wait_ms = std::chrono::duration<double, std::milli>(t_d1 - t_d0).count();
             const double call_ms = std::chrono::duration<double, std::milli>(t_d1 - t_entry).count();
-            const int verdict = wait_ms > 1.0 + 0.02 * call_ms ? -1 : (wait_ms < 0.5 ? +1 : 0);
+            const int verdict = job_was_done ? +1 : (wait_ms > 1.0 + 0.02 * call_ms ? -1 : 0);
             if (verdict != 0 && verdict == ctx->g_prio_trend) {
                 ctx->g_prio_duty = std::min(7, std::max(0, ctx->g_prio_duty + verdict));
                 ctx->g_prio_trend = 0;
             } else {
                 ctx->g_prio_trend = verdict;
             }
-            // which timing-recovery form a big bank runs (ctx.h): the call times of the two forms decide
-            if (n >= 2048) {
-                dvbs2gpu_ctx::LaneProbe& L = ctx->lane_probe;
-                if (L.n != n || std::abs(L.max_count - max_count) > max_count / 8) { L = dvbs2gpu_ctx::LaneProbe(); L.n = n; L.max_count = max_count; }
-                const int cur_form = ctx->g_lane_form ? 1 : 0;
-                if (L.since_switch++ >= 1) { L.sum[cur_form] += call_ms; L.cnt[cur_form]++; }       // (the first call after a switch is a transient)
-                ++L.since_probe;
-                constexpr int PROBE_CALLS = 4, REPROBE_AFTER = 128;
-                auto go = [&](int form) { ctx->g_lane_form = form != 0; L.since_switch = 0; L.sum[form] = 0; L.cnt[form] = 0; };
-                if (L.probing) {
-                    if (L.cnt[cur_form] >= PROBE_CALLS) {
-                        // keep the form with the shorter calls (both have fresh figures now)
-                        const int other = cur_form ^ 1;
-                        const bool stay = L.cnt[other] == 0 || L.sum[cur_form] / L.cnt[cur_form] <= L.sum[other] / L.cnt[other];
-                        L.probing = false; L.since_probe = 0;
-                        if (!stay) { ctx->g_lane_form = other != 0; L.since_switch = 0; }
-                    }
-                } else if (L.cnt[cur_form] >= PROBE_CALLS && (cur_form == 1 || ctx->g_prio_duty >= 2) && (L.cnt[cur_form ^ 1] == 0 || L.since_probe >= REPROBE_AFTER)) {
-                    // the other form has no (recent) figure: try it -- the lane form only once the front end has been found critical
-                    L.probing = true;
-                    L.sum[cur_form] = L.sum[cur_form] / L.cnt[cur_form] * PROBE_CALLS; L.cnt[cur_form] = PROBE_CALLS;     // (the mean of the form being left, as PROBE_CALLS calls)
-                    go(cur_form ^ 1);
-                }
-            }
-            if (hm.on) { char b[96]; snprintf(b, sizeof(b), " wait=%.2f call=%.1f duty=%d lane=%d", wait_ms, call_ms, ctx->g_prio_duty, (int)ctx->g_lane_form); hm.line += b; }
+            if (hm.on) { char b[96]; snprintf(b, sizeof(b), " wait=%.2f call=%.1f duty=%d", wait_ms, call_ms, ctx->g_prio_duty); hm.line += b; }
         }
     }
     if (started) {

@@ -2789,10 +2789,12 @@ hipError_t s2_post_stages_launch(const S2StreamWork* d_work, int nstreams, const
 //   1024 streams x 4 frames 8PSK 3/4:                      form 1   71 |  48 |  76     form 2   60 |  49 |  65     form 3   65 |  51 |  71
 //    384 streams x 4 frames:                               form 1   65 |  19 |  67     form 2   52 |  18 |  54     form 3   58 |  19 |  60     form 4  51 | 19 | 53
 // Form 3 runs with 16 streams per workgroup (256 workgroups for 4096 streams: one per compute unit; DVBS2GPU_GARDNER_BANK_SPB=64: a full wave of
-// streams, 64 workgroups): it halves the timing recovery of a big bank and costs the co-resident decoder 20-25 ms per step, so it is taken only once
-// the balancer has found the front end to be the critical path.  Default: form 4 up to S2_GARDNER_CAND_MAX streams; form 2 below S2_GARDNER_BANK_MIN
-// and, up to S2_GARDNER_LANE_MIN streams, wherever the front end is critical; form 3 from S2_GARDNER_LANE_MIN streams on when the front end is critical;
-// form 1 for big banks beside a decoder that is.  DVBS2GPU_GARDNER_FORM=1|2|3|4 in the environment forces one (development aid / the parity tests).
+// streams, 64 workgroups): alone it halves the timing recovery of a big bank, but it costs the co-resident decoder 20-25 ms per step and in every
+// pipelined configuration measured form 2 ends up at least as fast (the plugin's mode: form 1 202 | form 2 174 | form 3 181 | form 4 171 ms per step;
+// QPSK 1/2: 206 | 202 | 206): it is selectable (DVBS2GPU_GARDNER_FORM=3) and tested, not chosen by default.  A round-4 attempt to choose between the forms
+// by measured call times was taken out again: it spent its probes inside the very steps it was meant to speed up.  Default: form 4 up to
+// S2_GARDNER_CAND_MAX streams; form 2 below S2_GARDNER_BANK_MIN streams and wherever the pipelined mode's balancer has found the front end critical
+// (duty >= 2); form 1 for big banks beside a decoder that is.  DVBS2GPU_GARDNER_FORM=1|2|3|4 in the environment forces one.
 #ifndef S2_GARDNER_BANK_MIN
 #define S2_GARDNER_BANK_MIN 512
 #endif
@@ -2809,7 +2811,7 @@ static int gardner_form(int nstreams, int prio_duty, int lane_form) {
     if (nstreams < S2_GARDNER_BANK_MIN) return 2;
     // a big bank beside the decoder of the previous call: the one-wave form disturbs the decoder least; once the balancer of the pipelined
     // mode (s2_demod.hip) has found the FRONT END to be the critical path (it raises the timing loop's priority share), the shorter forms win
-    if (nstreams >= S2_GARDNER_LANE_MIN) return lane_form ? 3 : 1;       // (the balancer switches with hysteresis: ctx.h g_lane_form)
+    (void)lane_form;
     return prio_duty < 2 ? 1 : 2;
 }
 static void gardner_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const float* d_bank, hipStream_t st, int c, int nsub) {
