@@ -1642,16 +1642,18 @@ __device__ __forceinline__ int deint_pos(int constel, int rate, int bits, int ro
 // MIXED: a separate instantiation -- with the configuration a run-time choice between the arguments and a table the plain kernel lost its
 // scalar operands (headline: 4.4 -> 18.8 ms per step)
 template <bool MIXED>
-__global__ __launch_bounds__(256) void s2_demap_kernel(S2ConstelDev C, int rate, int slots, int pilots, int plframe,
+__global__ __launch_bounds__(256) void s2_demap_kernel(S2ConstelDev C_arg, int rate, int slots, int pilots, int plframe,
                                                        const cf32* __restrict__ pllout, int8_t* __restrict__ llr, int N, const int* __restrict__ slot,
                                                        const S2StreamCfgDev* __restrict__ cfgs, int maxf, int8_t* const* __restrict__ llr_of) {
     const int f = blockIdx.y;
     const cf32* __restrict__ fr = pllout + (size_t)(slot ? slot[f] : f) * plframe;      // (stage pipeline: the loops wrote frame f to its stream's slot)
     int8_t* __restrict__ out = llr + (size_t)f * N;
+    // mixed batch: the frame's configuration is its stream's (slot = stream * maxf + k; `plframe` as passed = the slot stride), its LLRs go where the table says.
+    // The constellation record is read in place (a copy of its 32 points went to scratch)
+    const S2StreamCfgDev* __restrict__ q = MIXED ? cfgs + slot[f] / maxf : nullptr;
+    const S2ConstelDev& C = MIXED ? q->con : C_arg;
     if constexpr (MIXED) {
-        // mixed batch: the frame's configuration is its stream's (slot = stream * maxf + k; `plframe` as passed = the slot stride), its LLRs go where the table says
-        const S2StreamCfgDev* __restrict__ q = cfgs + slot[f] / maxf;
-        C = q->con; rate = q->rate; slots = q->slots; pilots = q->pilots; N = q->N;
+        rate = q->rate; slots = q->slots; pilots = q->pilots; N = q->N;
         out = llr_of[f];
     }
     const int nsym = slots * 90;
