@@ -1200,7 +1200,7 @@ int process_mixed(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         const int force = d->cfg.force_ldpc_iters > 0, mt = force ? d->cfg.force_ldpc_iters : d->cfg.max_ldpc_trials;
         const auto key = std::make_tuple(d->mp.fec.code_index, mt, force);
         auto it = part_of.find(key);
-        if (it == part_of.end()) { it = part_of.emplace(key, (int)parts.size()).first; parts.push_back(PartH{d->mp.fec, mt, force, {}}); }
+        if (nfi > 0 && it == part_of.end()) { it = part_of.emplace(key, (int)parts.size()).first; parts.push_back(PartH{d->mp.fec, mt, force, {}}); }     // (a part exists only with frames in it)
         const cf32* base = d->d_fifo[d->fifo_cur];
         for (int k = 0; k < nfi; ++k) {
             const S2VcmFound& F = found[(size_t)i * maxf + k];

@@ -336,6 +336,40 @@ def test_mixed_modcod_batch_matches_single(engine):
         d.close()
 
 
+def test_mixed_batch_of_all_four_constellations_with_and_without_pilots(engine):
+    """the one-launch-per-stage flow of mixed batches (process_mixed: per-stream parameter tables) with everything a table entry can differ in -- QPSK, 8PSK,
+    16APSK and 32APSK (the closest-point search instead of the error LUT, the byte form of the demapper), normal and short frames, pilots on and off,
+    several calls per stream: every stream == its own single-stream handle, call by call, bytes and per-frame statistics"""
+    import torch
+    specs = [(4, 1, 1), (14, 0, 1), (19, 1, 0), (27, 1, 1), (6, 1, 0), (21, 1, 1), (24, 1, 0), (14, 1, 0), (27, 1, 0), (11, 0, 0)]
+    calls = 3
+    iqs = []
+    for s, (modcod, short, pilots) in enumerate(specs):
+        iq, bb, _ = orc.transmit(modcod, short, pilots, nframes=6 if short else 3, seed=1700 + s, esn0_db=24.0, cfo=1.5e-4 * s, timing=0.06 * s,
+                                 phase0=0.05 * s, lead_symbols=150 + 17 * s)
+        iqs.append(iq)
+    parts = lambda x, c: np.ascontiguousarray(x[c * ((x.size // calls) & ~1):(c + 1) * ((x.size // calls) & ~1)] if c < calls - 1 else x[c * ((x.size // calls) & ~1):])
+    ref = []
+    for s, (modcod, short, pilots) in enumerate(specs):
+        d = engine.demod(engine.default_cfg(modcod, bool(short), bool(pilots)), max_samples=iqs[s].size)
+        ref.append([(np.concatenate([np.asarray(x).reshape(-1) for x in [d.process(parts(iqs[s], c))]] or [np.zeros(0, np.uint8)]),
+                     [(x.ldpc_trials, x.bch_corrections, x.detected_modcod, x.detected_pilots) for x in d.stats()]) for c in range(calls)])
+        d.close()
+    dms = [engine.demod(engine.default_cfg(m, bool(sh), bool(p)), max_samples=iqs[s].size) for s, (m, sh, p) in enumerate(specs)]
+    cap = max(d.info['kbch'] // 8 for d in dms) * 8
+    tout = [torch.zeros(cap, dtype=torch.uint8, device='cuda') for _ in specs]
+    total = 0
+    for c in range(calls):
+        nb = engine.process_batch(dms, [torch.from_numpy(parts(iqs[s], c)).cuda() for s in range(len(specs))], tout)
+        for s, d in enumerate(dms):
+            assert np.array_equal(tout[s][:nb[s]].cpu().numpy(), ref[s][c][0]), (c, s, specs[s])
+            assert [(x.ldpc_trials, x.bch_corrections, x.detected_modcod, x.detected_pilots) for x in d.stats()] == ref[s][c][1], (c, s, specs[s])
+            total += nb[s]
+    assert total > 40000
+    for d in dms:
+        d.close()
+
+
 def test_pipelined_mode_with_and_without_the_stage_pipeline(engine, pkg):
     """throughput mode: a call runs its RRC / PL sync / frame loops either behind the timing-recovery slices (stage pipeline) or after the
     last one, as the balancer sees fit -- so the flow may change from call to call.  Always, never and every other call
