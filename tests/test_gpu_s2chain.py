@@ -671,6 +671,53 @@ def test_segment_receiver_argument_checks(engine, pkg):
 VCM_PLS = [(4 << 2) | 2, (14 << 2) | 2, (6 << 2) | 2 | 1, 0, (19 << 2) | 2, (27 << 2) | 2 | 1, 13 << 2, (12 << 2) | 2]
 
 
+def test_pipelined_batches_that_change_between_mixed_and_single_configuration(engine, pkg):
+    """throughput mode, the stream set AND its shape change from call to call: a mixed batch (one launch per stage, one FEC job per LDPC code), then streams of
+    one configuration only (the plain group flow), then another mix ... -- whatever flow started a job, the next call collects it for the streams it still holds"""
+    import torch
+    specs = [(11, 0), (11, 0), (4, 1), (14, 1), (4, 1)]
+    calls = 5
+    iqs, kbs = [], []
+    for s, (m, sh) in enumerate(specs):
+        iq, bb, _ = orc.transmit(m, sh, 0, nframes=(calls + 1) * (3 if sh else 1), seed=2300 + s, esn0_db=16.0, cfo=1e-4 * s, timing=0.05 * s, phase0=0.1)
+        iqs.append(iq); kbs.append(bb.shape[1])
+    chunk = [(x.size // (calls + 1)) & ~1 for x in iqs]
+    schedule = [[0, 1, 2, 3], [0, 1], [1, 2, 4], [4, 2], [0, 1, 2, 3, 4]]
+
+    def run(pipelined):
+        dms = [engine.demod(engine.default_cfg(m, bool(sh), False), max_samples=chunk[s]) for s, (m, sh) in enumerate(specs)]
+        tout = [torch.zeros(8 * max(kbs), dtype=torch.uint8, device='cuda') for s in range(len(specs))]
+        fed = [0] * len(specs)
+        engine.set_pipelined(pipelined)
+        outs = []
+        try:
+            for who in schedule + ([[0, 1, 2, 3, 4]] if pipelined else []):
+                last = len(outs) >= len(schedule)
+                tin = []
+                for s in who:
+                    tin.append(torch.empty(0, dtype=torch.complex64, device='cuda') if last else torch.from_numpy(iqs[s][fed[s] * chunk[s]:(fed[s] + 1) * chunk[s]]).cuda())
+                    fed[s] += 0 if last else 1
+                nb = engine.process_batch([dms[s] for s in who], tin, [tout[s] for s in who])
+                outs.append({s: (tout[s][:nb[k]].cpu().numpy().copy(), [(x.ldpc_trials, x.bch_corrections, x.detected_modcod) for x in dms[s].stats()]) for k, s in enumerate(who)})
+        finally:
+            engine.set_pipelined(False)
+            for d in dms:
+                d.close()
+        return outs
+
+    sync, pipe = run(False), run(True)
+    full = schedule + [[0, 1, 2, 3, 4]]
+    frames = 0
+    for c in range(1, len(full)):
+        for s in full[c]:
+            if s in full[c - 1]:
+                assert np.array_equal(pipe[c][s][0], sync[c - 1][s][0]) and pipe[c][s][1] == sync[c - 1][s][1], (c, s)
+                frames += len(sync[c - 1][s][1])
+            else:
+                assert pipe[c][s][0].size == 0 and pipe[c][s][1] == [], (c, s)
+    assert all(v[0].size == 0 for v in pipe[0].values()) and frames >= 8
+
+
 @pytest.mark.parametrize('esn0,cfo,chunk', [(100.0, 0.0, 50000), (22.0, 1e-3, 30011), (22.0, 1e-3, 1000000)])
 def test_acm_vcm_stream_cycling_modcods_equals_oracle(engine, esn0, cfo, chunk):
     """ONE stream whose frames cycle over seven MODCODs (QPSK, 8PSK, 16APSK, 32APSK; short and normal frames; with
