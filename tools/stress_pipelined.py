@@ -2,7 +2,7 @@
 """Development aid (GPU box): randomized soak of the throughput mode.  Streams of several CCM MODCODs and ACM/VCM streams; every call takes a random subset
 in random order (so batches change between single-configuration, mixed and ACM/VCM shapes, streams come and go); the same schedule runs synchronously and
 pipelined, and what the pipelined run delivers must be what the synchronous run produced one call earlier for every stream present in both calls.
-usage: python tools/stress_pipelined.py [calls=120] [seed=1]"""
+usage: python tools/stress_pipelined.py [calls=120] [seed=1] [copies=1]   (copies > 25 reaches the big-batch flow: front-end prepass + one host thread per group)"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +14,7 @@ import __graft_entry__ as g
 
 calls = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+copies = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 pkg = g.load_package()
 eng = pkg.Engine(0)
 rng = np.random.default_rng(seed)
@@ -26,7 +27,9 @@ for s, (m, sh, p) in enumerate(ccm):
 for k, pl in enumerate(vcm_lists):
     iq, _ = orc.transmit_vcm(pl, 60, seed=6000 + k, esn0_db=28.0, cfo=1e-4, timing=0.1 * k, lead_symbols=300)
     sigs.append(iq); cfgs.append(dict(modcod=4, shortframes=True, pilots=False, acm_vcm=1)); kinds.append('vcm')
+sigs, cfgs, kinds = sigs * copies, cfgs * copies, kinds * copies
 S = len(sigs)
+dev_sig = [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in sigs[:len(sigs) // copies]]
 chunk = 40000
 schedule = []
 for c in range(calls):
@@ -50,10 +53,10 @@ def run(pipelined):
                 if flush:
                     tin.append(torch.empty(0, dtype=torch.complex64, device='cuda'))
                 else:
-                    a = pos[s] % (sigs[s].size - chunk)
+                    a = (pos[s] + 2 * (s // len(dev_sig)) * 977) % (sigs[s].size - chunk)
                     a -= a & 1
                     n = int(rng_len[ci][s])
-                    tin.append(torch.from_numpy(np.ascontiguousarray(sigs[s][a:a + n])).cuda())
+                    tin.append(dev_sig[s % len(dev_sig)][a:a + n].clone())
                     pos[s] += n
             nb = eng.process_batch([dms[s] for s in who], tin, [tout[s] for s in who])
             outs.append({s: (tout[s][:nb[k]].cpu().numpy().copy(), [(x.ldpc_trials, x.bch_corrections, x.detected_modcod, x.bbframe_bytes) for x in dms[s].stats()]) for k, s in enumerate(who)})
