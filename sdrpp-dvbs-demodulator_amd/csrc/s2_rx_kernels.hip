@@ -2194,9 +2194,11 @@ __global__ __launch_bounds__(256) void s2_fifo_compact_kernel(const S2StreamWork
 // ================================================================================================ DVB-S front end (a17)
 // demod::QPSK_ALT::process (common/dsp/demod/qpsk_alt.cpp:136-144): FastAGC -> FLL -> RRC FIR -> COMPLEX_FD -> Costas<4>,
 // then DVBSymToSoftBlock's conversion into the 8192-soft block FIFO (dvbs_syms_to_soft.cpp:24-42).
-__device__ __forceinline__ float fast_amplitude(cf32 v) {   // SDR++ complex_t::fastAmplitude
+__device__ __forceinline__ float fast_amplitude(cf32 v) {   // SDR++ complex_t::fastAmplitude: the larger of |re|, |im| plus 0.4 times the smaller one
+    // (re_abs > im_abs ? re_abs + 0.4f * im_abs : im_abs + 0.4f * re_abs, as max / min: two instructions with |.| operand modifiers instead of two
+    // ANDs, a compare, a wait state and a select -- the same value for every input that is not a NaN)
     const float re_abs = fabsf(v.re), im_abs = fabsf(v.im);
-    return re_abs > im_abs ? re_abs + 0.4f * im_abs : im_abs + 0.4f * re_abs;
+    return fmaxf(re_abs, im_abs) + 0.4f * fminf(re_abs, im_abs);
 }
 // CLAMP_PHASE with [-pi, pi] for loops whose phase moves by less than 2 pi per step (FLL: |freq| <= pi/2, Costas: pi/10 + alpha): the
 // reference's two while loops then run at most once each, and two selects give the same value without the divergent loop code
@@ -2207,6 +2209,16 @@ __device__ __forceinline__ void pcl_wrap_pi(float& phase) {
     phase = phase < -PI_F ? phase + delta : phase;
 }
 
+// complex product in THREE packed instructions -- (a.re b.re, a.re b.im), (a.im b.im, a.im b.re), then low halves subtracted and high halves added
+// (v_pk_add_f32 neg_lo) -- where the compiler builds five (two packed adds, a register move to pick one half of each).  Same roundings as cmul.
+__device__ __forceinline__ cf32 cmul_pk3(cf32 a, cf32 b) {
+    const f32x2 av{a.re, a.im}, bv{b.re, b.im};
+    f32x2 p, q, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "v"(av), "v"(bv));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(q) : "v"(av), "v"(bv));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(p), "v"(q));
+    return cf32{r.x, r.y};
+}
 // ONE WAVE PER STREAM.  loop::FLL::process (fll.cpp:135-149): every sample is rotated by the loop phase and fed to the two
 // band-edge FIRs whose amplitude difference steers the loop -- a feedback through two 65-tap complex dot products per sample.
 // The dot products run as a SYSTOLIC ARRAY over the lanes: lane k holds tap k and a running sum; each new sample x[m] adds
@@ -2215,8 +2227,9 @@ __device__ __forceinline__ void pcl_wrap_pi(float& phase) {
 // loop's serial chain.  Lanes 0..63 = taps 0..63; tap 64 is applied by all lanes to the sum leaving lane 63.
 __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __restrict__ work, DvbsLoopCoefs co,
                                                       const cf32* __restrict__ bandedge, int sub, int nsub) {
-    __shared__ cf32 ytile[64];
-    __shared__ cf32 xtile[64];
+    __shared__ cf32 tile[128];                   // [0, 64): rotated samples out (x), [64, 128): samples in (y) -- the loop below addresses both from one register
+    cf32* const xtile = tile;
+    cf32* const ytile = tile + 64;
     const int lane = threadIdx.x;
     DvbsStreamWork w = work[blockIdx.x];
     DvbsStreamState* st = w.st;
@@ -2235,36 +2248,123 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
         al = cadd(al, cmul(xs, bandedge[jt]));
         ah = cadd(ah, cmul(xs, bandedge[T + jt]));
     }
+    const f32x2 tlv{tl.re, tl.im}, thv{th.re, th.im};
+    const f32x2 tlL{__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tl_last.re))), __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tl_last.im)))};
+    const f32x2 thL{__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, th_last.re))), __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, th_last.im)))};
+    const float beta_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, co.fll_beta)));
+    const float minf_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, co.fll_min_freq)));
+    const float maxf_v = co.fll_max_freq;
     for (int base = 0; base < n; base += 64) {
         const int m = min(64, n - base);
         __syncthreads();
         if (lane < m) ytile[lane] = w.buf_a[base + lane];
         __syncthreads();
-        for (int k = 0; k < m; ++k) {
-            const cf32 x = cmul(ytile[k], phasor_hw(-phase));
-            // complete this sample's two outputs: partial sum leaving lane 63 + newest sample * last tap
-            cf32 pl, ph;
-            pl.re = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al.re), 63));
-            pl.im = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al.im), 63));
-            ph.re = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ah.re), 63));
-            ph.im = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ah.im), 63));
-            const cf32 lo = cadd(pl, cmul(x, tl_last)), hi = cadd(ph, cmul(x, th_last));
-            const float err = fast_amplitude(hi) - fast_amplitude(lo);
-            // PhaseControlLoop::advance with alpha = 0 (fll.cpp:26)
-            freq += co.fll_beta * err;
-            freq = clamp_med3(freq, co.fll_min_freq, co.fll_max_freq);
-            phase += freq;
-            pcl_wrap_pi(phase);
-            if (FLL_STORE_ALL || lane == 0) xtile[k] = x;
-            // systolic step: sums move one lane up, lane 0 starts the sum of output m + 64
-            cf32 sl, sh;
-            sl.re = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, al.re), 0x138, 0xf, 0xf, false));
-            sl.im = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, al.im), 0x138, 0xf, 0xf, false));
-            sh.re = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ah.re), 0x138, 0xf, 0xf, false));
-            sh.im = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ah.im), 0x138, 0xf, 0xf, false));
-            al = cadd(sl, cmul(x, tl));
-            ah = cadd(sh, cmul(x, th));
-        }
+        // ONE WAVE ALONE ON ITS SIMD issues one instruction per ~4.5 (4-byte encodings) to ~5.5 cycles (packed / VOP3 / literal operands), dependent or
+        // not (tools/ubench/lone_wave.hip): this loop's time is its instruction count.  The compiler's form of it was 95 instructions per sample; written
+        // out it is 69 -- a complex product as two packed multiplications and ONE packed addition with neg_lo (the compiler builds two additions and
+        // register moves), fastAmplitude as max + 0.4 min with |.| operand modifiers, the systolic shift as the DPP operand of the addition that uses it,
+        // compares through VCC (4-byte encodings, no wait states), constants in scalar registers, a carry-out loop counter.  Every operation and
+        // every rounding is the C++ form's (phasor = dvbs2m::sincosf_det(-phase), cmul, cadd, fast_amplitude, PhaseControlLoop::advance with alpha = 0, pcl_wrap_pi):
+        // the DVB-S tests compare symbols, loop state and decoded bits with the oracle.
+        uint32_t xa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) cf32*)xtile;
+        uint32_t cnt = (uint32_t)-__builtin_amdgcn_readfirstlane(m);          // counts up; the carry out of the last increment ends the loop
+        asm volatile(
+            "s_mov_b32 s40, 0xbf22f983\n\t"          // -2/pi
+            "s_mov_b32 s41, 0xbfc90fdb\n\t"          // -(pi/2 rounded to binary32)
+            "s_mov_b32 s42, 0x333bbd2e\n\t"          // -(pi/2 - that)
+            "s_mov_b32 s43, 0x80000000\n\t"
+            "s_mov_b32 s44, 0x37ccf5ce\n\t"          // polynomial coefficients (cos, sin): degree 2 ...
+            "s_mov_b32 s45, 0xb94ca1f9\n\t"
+            "v_mov_b32 v40, 0xbab6061a\n\t"          // ... degree 1 ...
+            "v_mov_b32 v41, 0x3c08839e\n\t"
+            "s_mov_b32 s46, 0x3d2aaaa5\n\t"          // ... degree 0
+            "s_mov_b32 s47, 0xbe2aaaa3\n\t"
+            "s_mov_b32 s48, 0x3ecccccd\n\t"          // 0.4f
+            "s_mov_b32 s49, 0x40490fdb\n\t"          // pi
+            "s_mov_b32 s50, 0xc0490fdb\n\t"          // -pi
+            "s_mov_b32 s51, 0x40c90fdb\n\t"          // 2 pi
+            "s_mov_b32 s52, 0xc0c90fdb\n\t"          // -2 pi
+            "1:\n\t"
+            "ds_read_b64 v[42:43], %[xa] offset:512\n\t"                                              // y
+            // phasor(-phase): j = rint(-phase 2/pi), r = fma(j, -lo, fma(j, -hi, -phase)), z = r r
+            "v_mul_f32 v44, s40, %[ph]\n\t"
+            "v_rndne_f32 v44, v44\n\t"
+            "v_cvt_i32_f32 v45, v44\n\t"
+            "v_fma_f32 v47, v44, s41, -%[ph]\n\t"
+            "v_fmac_f32 v47, s42, v44\n\t"
+            "v_mul_f32 v46, v47, v47\n\t"                                                             // v[46:47] = (z, r)
+            "v_pk_fma_f32 v[48:49], v[46:47], s[44:45], v[40:41] op_sel_hi:[0,1,1]\n\t"              // (z c2 + c1) for cos | sin
+            "v_pk_mul_f32 v[50:51], v[46:47], v[46:47] op_sel_hi:[1,0]\n\t"                           // (z z, r z)
+            "v_pk_fma_f32 v[48:49], v[48:49], v[46:47], s[46:47] op_sel_hi:[1,0,1]\n\t"              // (.. z + c0)
+            "v_fma_f32 v46, v46, -0.5, 1.0\n\t"                                                       // (1 - z/2, r)
+            "v_pk_fma_f32 v[46:47], v[50:51], v[48:49], v[46:47]\n\t"                                 // (pc, ps)
+            "v_and_b32 v48, 1, v45\n\t"
+            "v_lshlrev_b32 v49, 30, v45\n\t"
+            "v_sub_u32 v50, 0, v49\n\t"
+            "v_cmp_eq_u32 vcc, 0, v48\n\t"
+            "v_and_b32 v49, s43, v49\n\t"                                                             // sin changes sign in quadrants 2, 3
+            "v_and_b32 v50, s43, v50\n\t"                                                             // cos in quadrants 1, 2
+            "v_cndmask_b32 v51, v46, v47, vcc\n\t"                                                    // even quadrant ? ps : pc
+            "v_cndmask_b32 v46, v47, v46, vcc\n\t"                                                    // even quadrant ? pc : ps
+            "v_xor_b32 v47, v51, v49\n\t"
+            "v_xor_b32 v46, v46, v50\n\t"                                                             // v[46:47] = (cos, sin)
+            "v_readlane_b32 s54, %[alr], 63\n\t"                                                      // the sums leaving lane 63 (taps 0..63 of this sample's outputs)
+            "v_readlane_b32 s55, %[ali], 63\n\t"
+            "v_readlane_b32 s56, %[ahr], 63\n\t"
+            "v_readlane_b32 s57, %[ahi], 63\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            // x = y * phasor
+            "v_pk_mul_f32 v[48:49], v[42:43], v[46:47] op_sel_hi:[0,1]\n\t"
+            "v_pk_mul_f32 v[50:51], v[42:43], v[46:47] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+            "v_pk_add_f32 v[42:43], v[48:49], v[50:51] neg_lo:[0,1]\n\t"
+            "ds_write_b64 %[xa], v[42:43]\n\t"
+            // the two outputs: sum of taps 0..63 + x * tap 64
+            "v_pk_mul_f32 v[48:49], v[42:43], %[tlL] op_sel_hi:[0,1]\n\t"
+            "v_pk_mul_f32 v[50:51], v[42:43], %[tlL] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+            "v_pk_add_f32 v[48:49], v[48:49], v[50:51] neg_lo:[0,1]\n\t"
+            "v_pk_mul_f32 v[50:51], v[42:43], %[thL] op_sel_hi:[0,1]\n\t"
+            "v_pk_mul_f32 v[52:53], v[42:43], %[thL] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+            "v_pk_add_f32 v[50:51], v[50:51], v[52:53] neg_lo:[0,1]\n\t"
+            "v_pk_add_f32 v[48:49], v[48:49], s[54:55]\n\t"                                           // lower band edge
+            "v_pk_add_f32 v[50:51], v[50:51], s[56:57]\n\t"                                           // upper band edge
+            // err = fastAmplitude(upper) - fastAmplitude(lower)
+            "v_max_f32 v52, |v50|, |v51|\n\t"
+            "v_max_f32 v53, |v48|, |v49|\n\t"
+            "v_min_f32 v54, |v50|, |v51|\n\t"
+            "v_min_f32 v55, |v48|, |v49|\n\t"
+            "v_pk_mul_f32 v[54:55], v[54:55], s[48:49] op_sel_hi:[1,0]\n\t"
+            "v_pk_add_f32 v[52:53], v[52:53], v[54:55]\n\t"
+            "v_sub_f32 v52, v52, v53\n\t"
+            // freq += beta err, clamped; phase += freq, wrapped into [-pi, pi]
+            "v_mul_f32 v52, %[beta], v52\n\t"
+            "v_add_f32 %[fr], %[fr], v52\n\t"
+            "v_med3_f32 %[fr], %[fr], %[minf], %[maxf]\n\t"
+            "v_add_f32 %[ph], %[ph], %[fr]\n\t"
+            "v_add_f32 v52, s52, %[ph]\n\t"
+            "v_cmp_lt_f32 vcc, s49, %[ph]\n\t"
+            "v_cndmask_b32 %[ph], %[ph], v52, vcc\n\t"
+            "v_add_f32 v52, s51, %[ph]\n\t"
+            "v_cmp_gt_f32 vcc, s50, %[ph]\n\t"
+            "v_cndmask_b32 %[ph], %[ph], v52, vcc\n\t"
+            // systolic step: every lane adds x * its tap to the sum arriving from the lane below (lane 0: to zero = starts the sum of output m + 64)
+            "v_pk_mul_f32 v[48:49], v[42:43], %[tl] op_sel_hi:[0,1]\n\t"
+            "v_pk_mul_f32 v[50:51], v[42:43], %[tl] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+            "v_pk_add_f32 v[48:49], v[48:49], v[50:51] neg_lo:[0,1]\n\t"
+            "v_pk_mul_f32 v[50:51], v[42:43], %[th] op_sel_hi:[0,1]\n\t"
+            "v_pk_mul_f32 v[52:53], v[42:43], %[th] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+            "v_pk_add_f32 v[50:51], v[50:51], v[52:53] neg_lo:[0,1]\n\t"
+            "v_add_u32 %[xa], 8, %[xa]\n\t"
+            "v_add_f32_dpp %[alr], %[alr], v48 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %[ali], %[ali], v49 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %[ahr], %[ahr], v50 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %[ahi], %[ahi], v51 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "s_add_u32 %[cnt], %[cnt], 1\n\t"
+            "s_cbranch_scc0 1b\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : [ph] "+v"(phase), [fr] "+v"(freq), [alr] "+v"(al.re), [ali] "+v"(al.im), [ahr] "+v"(ah.re), [ahi] "+v"(ah.im), [xa] "+v"(xa), [cnt] "+s"(cnt)
+            : [tl] "v"(tlv), [th] "v"(thv), [tlL] "s"(tlL), [thL] "s"(thL), [beta] "s"(beta_s), [minf] "s"(minf_s), [maxf] "v"(maxf_v)
+            : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
+              "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s54", "s55", "s56", "s57", "vcc", "scc", "memory");
         __syncthreads();
         if (lane < m) w.buf_b[base + lane] = xtile[lane];
     }
