@@ -2579,6 +2579,7 @@ __global__ __launch_bounds__(64) void dvbs_fd_kernel(const DvbsStreamWork* __res
                                                             const float* __restrict__ bank, int sub, int nsub) {
     __shared__ cf32 win[FD_TILE + FD_TAPS];      // [255 history][tile]
     __shared__ cf32 ostage[FD_TILE / 2 + 72];
+    __shared__ float odump[2];                    // where the lanes that hold no part of a symbol store (the written-out loop below)
     __shared__ __attribute__((aligned(16))) float brow[FD_WROWS * FD_TAPS];   // bank rows [wlo, wlo + FD_WROWS), each lane-major: [lane][tap lane + 64 q]
     const int lane = threadIdx.x;
     DvbsStreamWork w = work[blockIdx.x];
@@ -2593,12 +2594,22 @@ __global__ __launch_bounds__(64) void dvbs_fd_kernel(const DvbsStreamWork* __res
     for (int i = lane; i < FD_TAPS - 1; i += 64) win[i] = st->fd_hist[i];
     __syncthreads();
     __builtin_amdgcn_s_setprio(FE_PRIO);               // latency-critical serial loop (see agc_pc_kernel)
+    constexpr int OCAP = FD_TILE / 2 + 72;             // symbols a tile can produce at most (samples per symbol x (1 - limit) >= 1.5, checked on the host: <= 171)
+    const uint32_t win_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) cf32*)win;
+    const uint32_t ost_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) cf32*)ostage;
+    const uint32_t brow_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)brow;
+    const uint32_t dump_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)odump;
+    const float alpha_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, co.fd_alpha)));
+    const float beta_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, co.fd_beta)));
+    const float minf_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, co.fd_min_freq)));
+    const float maxf_v = co.fd_max_freq;
     for (int base = 0; base < n; base += FD_TILE) {
         const int m = min(FD_TILE, n - base);
         for (int i = lane; i < m; i += 64) win[FD_TAPS - 1 + i] = w.buf_a[base + i];
         __syncthreads();
         int nout = 0;
-        for (int guard = 0; guard < 4 * FD_TILE && offset < base + m; ++guard) {
+        // one symbol the general way: any phase (the one-sided derivative at the ends of the bank), the row window re-centred where the phase has left it
+        auto symbol_general = [&]() {
             int phase = (int)floorf(pcl.phase * (float)FD_PHASES);
             phase = phase < 0 ? 0 : (phase > FD_PHASES - 1 ? FD_PHASES - 1 : phase);
             const int pm = phase > 0 ? phase - 1 : phase, pp = phase < FD_PHASES - 1 ? phase + 1 : phase;
@@ -2628,6 +2639,137 @@ __global__ __launch_bounds__(64) void dvbs_fd_kernel(const DvbsStreamWork* __res
             pcl.phase -= delta;
             if (FD_STORE_ALL || lane == 0) ostage[nout] = outVal;       // (the Costas loop has its own kernel, below)
             ++nout;
+        };
+        while (offset < base + m && nout < OCAP) {
+            if (spsctr == 0 && wlo >= 0) {
+                // THE FAST PATH, written out (a wave alone on its SIMD pays per instruction, tools/ubench/lone_wave.hip; the compiler's form of this loop is ~140
+                // instructions and three taken branches per symbol, this one 95): symbols whose phase row lies inside the window with both neighbours
+                // and inside the bank (1 <= phase <= 254) -- everything else leaves the loop BEFORE the symbol is touched and goes through symbol_general.
+                // Same operations, same order, same roundings as fd_dot3_wave + the loop body above: three 256-tap dot products (four taps per lane in
+                // tap order, then the lane tree: l ^ 8, + 4, + 2, + 1, rows), o in lanes 0 / 8, fT1 in 4 / 12, fT_1 in 2 / 10; the derivative, the
+                // error products and their sum stay in those lanes (DPP) and ONE v_readlane brings the error back; lanes 0 and 8 store the symbol.
+                const int wlo_u = __builtin_amdgcn_readfirstlane(wlo);               // (wave-uniform by construction; the compiler sees a vector value)
+                const int lo_ok = max(wlo_u + 1, 1), hi_ok = min(wlo_u + FD_WROWS - 2, FD_PHASES - 2);
+                const uint32_t xb = win_a + 8u * (uint32_t)(lane - base);
+                const uint32_t rb = brow_a + 16u * (uint32_t)lane - 1024u * (uint32_t)(wlo + 1);
+                uint32_t oa = (lane == 0 ? ost_a + 8u * nout : lane == 8 ? ost_a + 8u * nout + 4u : dump_a) - (lane == 0 || lane == 8 ? 8u : 0u);
+                const uint32_t incv = lane == 0 || lane == 8 ? 8u : 0u;
+                uint32_t nneg = (uint32_t)__builtin_amdgcn_readfirstlane(nout - OCAP), why = 0;
+                const int lim = __builtin_amdgcn_readfirstlane(base + m);
+                asm volatile(
+                    "s_mov_b32 s60, 0x43800000\n\t"                   // 256.0f
+                    "s_movk_i32 s61, 0xff\n\t"
+                    "1:\n\t"
+                    "v_lshl_add_u32 v88, %[off], 3, %[xb]\n\t"
+                    "ds_read2st64_b64 v[60:63], v88 offset1:1\n\t"                           // x[lane], x[lane + 64]
+                    "ds_read2st64_b64 v[64:67], v88 offset0:2 offset1:3\n\t"                 // x[lane + 128], x[lane + 192]
+                    "v_mul_f32 v89, s60, %[ph]\n\t"
+                    "v_floor_f32 v89, v89\n\t"
+                    "v_cvt_i32_f32 v89, v89\n\t"
+                    "v_med3_i32 v89, v89, 0, s61\n\t"                                        // the phase row
+                    "v_subrev_u32 v90, %[slo], v89\n\t"
+                    "v_cmp_lt_u32 vcc, %[span], v90\n\t"
+                    "s_cbranch_vccnz 3f\n\t"                                                 // outside [lo_ok, hi_ok]: the general way
+                    "v_lshl_add_u32 v91, v89, 10, %[rb]\n\t"
+                    "ds_read_b128 v[72:75], v91 offset:1024\n\t"                             // row phase
+                    "ds_read_b128 v[76:79], v91 offset:2048\n\t"                             // row phase + 1
+                    "ds_read_b128 v[68:71], v91\n\t"                                         // row phase - 1
+                    "v_cvt_f32_i32 v92, %[off]\n\t"
+                    "s_waitcnt lgkmcnt(2)\n\t"
+                    "v_pk_mul_f32 v[80:81], v[60:61], v[72:73] op_sel_hi:[1,0]\n\t"
+                    "v_pk_add_f32 v[80:81], v[80:81], 0 op_sel_hi:[1,0]\n\t"
+                    "v_pk_mul_f32 v[86:87], v[62:63], v[72:73] op_sel:[0,1]\n\t"
+                    "v_pk_add_f32 v[80:81], v[80:81], v[86:87]\n\t"
+                    "v_pk_mul_f32 v[86:87], v[64:65], v[74:75] op_sel_hi:[1,0]\n\t"
+                    "v_pk_add_f32 v[80:81], v[80:81], v[86:87]\n\t"
+                    "v_pk_mul_f32 v[86:87], v[66:67], v[74:75] op_sel:[0,1]\n\t"
+                    "v_pk_add_f32 v[80:81], v[80:81], v[86:87]\n\t"
+                    "s_waitcnt lgkmcnt(1)\n\t"
+                    "v_pk_mul_f32 v[82:83], v[60:61], v[76:77] op_sel_hi:[1,0]\n\t"
+                    "v_pk_add_f32 v[82:83], v[82:83], 0 op_sel_hi:[1,0]\n\t"
+                    "v_pk_mul_f32 v[86:87], v[62:63], v[76:77] op_sel:[0,1]\n\t"
+                    "v_pk_add_f32 v[82:83], v[82:83], v[86:87]\n\t"
+                    "v_pk_mul_f32 v[86:87], v[64:65], v[78:79] op_sel_hi:[1,0]\n\t"
+                    "v_pk_add_f32 v[82:83], v[82:83], v[86:87]\n\t"
+                    "v_pk_mul_f32 v[86:87], v[66:67], v[78:79] op_sel:[0,1]\n\t"
+                    "v_pk_add_f32 v[82:83], v[82:83], v[86:87]\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "v_pk_mul_f32 v[84:85], v[60:61], v[68:69] op_sel_hi:[1,0]\n\t"
+                    "v_pk_add_f32 v[84:85], v[84:85], 0 op_sel_hi:[1,0]\n\t"
+                    "v_pk_mul_f32 v[86:87], v[62:63], v[68:69] op_sel:[0,1]\n\t"
+                    "v_pk_add_f32 v[84:85], v[84:85], v[86:87]\n\t"
+                    "v_pk_mul_f32 v[86:87], v[64:65], v[70:71] op_sel_hi:[1,0]\n\t"
+                    "v_pk_add_f32 v[84:85], v[84:85], v[86:87]\n\t"
+                    "v_pk_mul_f32 v[86:87], v[66:67], v[70:71] op_sel:[0,1]\n\t"
+                    "v_pk_add_f32 v[84:85], v[84:85], v[86:87]\n\t"
+                    // lane tree; a register a DPP operand reads was written at least two instructions earlier
+                    "v_add_f32_dpp v80, v80, v80 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp v81, v81, v81 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp v82, v82, v82 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp v83, v83, v83 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp v84, v84, v84 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp v85, v85, v85 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_cndmask_b32_e64 v80, v80, v81, %[b3]\n\t"
+                    "v_cndmask_b32_e64 v82, v82, v83, %[b3]\n\t"
+                    "v_cndmask_b32_e64 v84, v84, v85, %[b3]\n\t"
+                    "v_add_f32_dpp v81, v80, v80 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp v83, v82, v82 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_add_f32_dpp v85, v84, v84 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_cndmask_b32_e64 v81, v81, v83, %[b2]\n\t"
+                    "v_add_u32 %[oa], %[oa], %[incv]\n\t"
+                    "v_add_f32_dpp v85, v85, v85 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "s_nop 0\n\t"
+                    "v_add_f32_dpp v81, v81, v81 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_cndmask_b32_e64 v81, v81, v85, %[b1]\n\t"
+                    "s_nop 1\n\t"
+                    "v_add_f32_dpp v81, v81, v81 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "v_mov_b32 v82, v81\n\t"
+                    "s_nop 1\n\t"
+                    "v_permlane16_swap_b32 v81, v82\n\t"
+                    "v_add_f32 v81, v81, v82\n\t"
+                    "v_mov_b32 v82, v81\n\t"
+                    "s_nop 1\n\t"
+                    "v_permlane32_swap_b32 v81, v82\n\t"
+                    "v_add_f32 v81, v81, v82\n\t"                                            // lanes 0 / 8: o, 4 / 12: fT1, 2 / 10: fT_1
+                    "ds_write_b32 %[oa], v81\n\t"
+                    "s_nop 0\n\t"
+                    "v_subrev_f32_dpp v82, v81, v81 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"     // lanes 4 / 12: fT1 - fT_1
+                    "v_mul_f32 v82, 0.5, v82\n\t"
+                    "s_nop 1\n\t"
+                    "v_mul_f32_dpp v83, v82, v81 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"        // lanes 0 / 8: o.re dfdt.re, o.im dfdt.im
+                    "s_nop 1\n\t"
+                    "v_add_f32_dpp v83, v83, v83 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                    "s_add_u32 %[nneg], %[nneg], 1\n\t"                                      // (carry out: the tile's symbol store is full)
+                    "v_readlane_b32 s62, v83, 0\n\t"
+                    "v_med3_f32 v83, s62, -1.0, 1.0\n\t"
+                    "v_mul_f32 v84, %[beta], v83\n\t"
+                    "v_add_f32 %[fr], %[fr], v84\n\t"
+                    "v_med3_f32 %[fr], %[fr], %[minf], %[maxf]\n\t"
+                    "v_mul_f32 v84, %[alpha], v83\n\t"
+                    "v_add_f32 v84, v84, %[fr]\n\t"
+                    "v_add_f32 %[ph], %[ph], v84\n\t"
+                    "v_floor_f32 v84, %[ph]\n\t"
+                    "v_add_f32 v92, v92, v84\n\t"
+                    "v_cvt_i32_f32 %[off], v92\n\t"
+                    "v_sub_f32 %[ph], %[ph], v84\n\t"
+                    "v_cmp_gt_i32 vcc, %[lim], %[off]\n\t"
+                    "s_cbranch_scc1 4f\n\t"
+                    "s_cbranch_vccnz 1b\n\t"
+                    "s_branch 4f\n\t"
+                    "3:\n\t"
+                    "s_mov_b32 %[why], 1\n\t"
+                    "4:\n\t"
+                    "s_waitcnt lgkmcnt(0)"
+                    : [ph] "+v"(pcl.phase), [fr] "+v"(pcl.freq), [off] "+v"(offset), [oa] "+v"(oa), [nneg] "+s"(nneg), [why] "+s"(why)
+                    : [xb] "v"(xb), [rb] "v"(rb), [incv] "v"(incv), [maxf] "v"(maxf_v), [slo] "s"(lo_ok), [span] "s"(hi_ok - lo_ok), [lim] "s"(lim),
+                      [alpha] "s"(alpha_s), [beta] "s"(beta_s), [minf] "s"(minf_s),
+                      [b3] "s"(0xFF00FF00FF00FF00ull), [b2] "s"(0xF0F0F0F0F0F0F0F0ull), [b1] "s"(0xCCCCCCCCCCCCCCCCull)
+                    : "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
+                      "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "s60", "s61", "s62", "vcc", "scc", "memory");
+                nout = OCAP + (int)nneg;
+                if (!why) continue;                      // (the tile is used up or its symbol store is full: the loop condition ends it)
+            }
+            symbol_general();
         }
         __syncthreads();
         for (int i = lane; i < nout; i += 64) w.sym[outCount + i] = ostage[i];
