@@ -216,7 +216,7 @@ int dvbs2gpu_dvbs_demod_process_batch(dvbs2gpu_dvbs_demod* d, const float* const
         dvbs2gpu_dvbs_demod* d; dvbs2gpu_ctx::FeAux* fa; const DvbsStreamWork* d_work; const int8_t* const* d_in_ptrs; int n, max_count, nsub, mb;
         int* d_blk0; int* d_nblk; int* d_nbits; uint8_t* d_bits; hipStream_t st;
         hipError_t after_timing(int c) override {
-            hipStream_t sv = fa->dvbs_aux[0];        // behind the AGC slices, which were all enqueued before the first timing-recovery slice
+            hipStream_t sv = fa->dvbs_aux[0];        // a bank: behind the AGC slices, which were all enqueued before the first timing-recovery slice
             hipError_t e;
             if ((e = hipEventRecord(fa->dvbs_ev[3][c], st)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(sv, fa->dvbs_ev[3][c], 0)) != hipSuccess) return e;
@@ -230,6 +230,7 @@ int dvbs2gpu_dvbs_demod_process_batch(dvbs2gpu_dvbs_demod* d, const float* const
     } hook;
     hook.d = d; hook.fa = fa; hook.d_work = d_work; hook.d_in_ptrs = (const int8_t* const*)(base + off_ptr_in); hook.n = n; hook.max_count = max_count;
     hook.nsub = nsub; hook.mb = mb; hook.d_blk0 = d_blk0; hook.d_nblk = d_nblk; hook.d_nbits = d_nbits; hook.d_bits = (uint8_t*)wsb.p; hook.st = st;
+    // (tried: the Costas slices on the AGC's stream and the decoder alone on `sv` -- AGC + Costas then carry 0.94 ms per slice beside the FLL's 0.81: nothing gained)
     // (a few carriers: the AGC slices on a stream of their own -- one carrier 39.4 -> 36.7 ms per call; a bank keeps them ahead on the Viterbi stream)
     hipStream_t aux3[3] = {fa ? fa->dvbs_aux[0] : nullptr, fa ? fa->dvbs_aux[1] : nullptr, fa && n < ctx->dvbs_bank_min ? fa->dvbs_aux[2] : nullptr};
     HIP_TRY(dvbs_frontend_launch(d_work, n, max_count, d->co, d->d_bandedge, d->d_rrc, ctx->d_fd_bank, st, fa ? aux3 : nullptr,

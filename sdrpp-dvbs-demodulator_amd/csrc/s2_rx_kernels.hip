@@ -156,6 +156,7 @@ __device__ __forceinline__ size_t fe_scratch_offset(int n) { return (size_t)n + 
 #endif
 constexpr int AG_T = AG_T_N;             // samples per stream per tile (17 KB of LDS: fits beside a resident LDPC workgroup)
 struct AgcS2Traits {                     // FastAGC gain + FreqShift phase recurrences; result = (gain, phase) per sample
+    static constexpr bool DVBS_SLICES = false;
     typedef S2StreamWork Work;
     typedef S2LoopCoefs Coefs;
     struct Regs { float gain, nph, nfr; };
@@ -182,6 +183,7 @@ struct AgcS2Traits {                     // FastAGC gain + FreqShift phase recur
     }
 };
 struct AgcDvbsTraits {                   // FastAGC only; result = scaled sample
+    static constexpr bool DVBS_SLICES = true;
     typedef DvbsStreamWork Work;
     typedef DvbsLoopCoefs Coefs;
     struct Regs { float gain; };
@@ -204,6 +206,16 @@ __device__ __forceinline__ void fe_sub_range(int n, int sub, int nsub, int& lo, 
     lo = (int)((long long)n * sub / nsub);
     hi = (int)((long long)n * (sub + 1) / nsub);
 }
+// The DVB-S receiver's slices (12 or more): the first and the last two are a quarter and a half of the others -- what a call pays beyond its slowest
+// stage is the stages before that one on the FIRST slice and the stages behind it on the LAST one (one carrier: 2.7 of 22 ms with equal slices).
+// Weights 1 2 4 4 ... 4 2 1 in quarters of a full slice; every stage derives its range from here, and the data-parallel ones stride over whatever they get.
+__device__ __forceinline__ int fe_taper_cum(int c, int nsub) { return c <= 0 ? 0 : c == 1 ? 1 : c <= nsub - 2 ? 4 * c - 5 : c == nsub - 1 ? 4 * nsub - 11 : 4 * nsub - 10; }
+__device__ __forceinline__ void fe_sub_range_dvbs(int n, int sub, int nsub, int& lo, int& hi) {
+    if (nsub < 12) { fe_sub_range(n, sub, nsub, lo, hi); return; }
+    const int total = 4 * nsub - 10;
+    lo = (int)((long long)n * fe_taper_cum(sub, nsub) / total);
+    hi = (int)((long long)n * fe_taper_cum(sub + 1, nsub) / total);
+}
 
 template <class TR>
 __global__ __launch_bounds__(128) void agc_pc_kernel(const typename TR::Work* __restrict__ work, int nstreams, typename TR::Coefs co, int sub, int nsub) {
@@ -215,7 +227,8 @@ __global__ __launch_bounds__(128) void agc_pc_kernel(const typename TR::Work* __
     const bool act = s < nstreams;
     const typename TR::Work w = work[act ? s : 0];
     int lo, hi;
-    fe_sub_range(act ? w.count : 0, sub, nsub, lo, hi);
+    if constexpr (TR::DVBS_SLICES) fe_sub_range_dvbs(act ? w.count : 0, sub, nsub, lo, hi);
+    else fe_sub_range(act ? w.count : 0, sub, nsub, lo, hi);
     const int n = hi - lo;
     typename TR::Regs regs = TR::load(w);
     // (a stream without samples in this slice may come with a null input pointer: the movers' clamped loads then read the work table)
@@ -2234,7 +2247,7 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
     DvbsStreamWork w = work[blockIdx.x];
     DvbsStreamState* st = w.st;
     int lo, hi;
-    fe_sub_range(w.count, sub, nsub, lo, hi);            // time slice of the call (dvbs_frontend_launch)
+    fe_sub_range_dvbs(w.count, sub, nsub, lo, hi);            // time slice of the call (dvbs_frontend_launch)
     w.buf_a += lo; w.buf_b += lo;
     const int n = hi - lo, T = co.ntaps, H = T - 1;     // the systolic layout needs T == 65 (checked on the host)
     const cf32 tl = bandedge[lane], th = bandedge[T + lane];
@@ -2401,7 +2414,7 @@ __global__ __launch_bounds__(64) void dvbs_fll4_kernel(const DvbsStreamWork* __r
     DvbsStreamWork w = work[act ? s : blockIdx.x * SPW];
     DvbsStreamState* st = w.st;
     int lo, hi;
-    fe_sub_range(w.count, sub, nsub, lo, hi);                       // time slice of the call (dvbs_frontend_launch)
+    fe_sub_range_dvbs(w.count, sub, nsub, lo, hi);                       // time slice of the call (dvbs_frontend_launch)
     w.buf_a += lo; w.buf_b += lo;
     const int n = act ? hi - lo : 0, T = co.ntaps, H = T - 1;       // T == 65 (checked on the host)
     cf32 tl[TPL], th[TPL], al[TPL], ah[TPL];
@@ -2486,7 +2499,7 @@ __global__ __launch_bounds__(256) void dvbs_rrc_kernel(const DvbsStreamWork* __r
     DvbsStreamWork w = work[blockIdx.y];
     const DvbsStreamState* st = w.st;
     int lo, hi;
-    fe_sub_range(w.count, sub, nsub, lo, hi);
+    fe_sub_range_dvbs(w.count, sub, nsub, lo, hi);
     w.buf_a += lo; w.buf_b += lo;
     const int n = hi - lo, H = ntaps - 1;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
@@ -2504,7 +2517,7 @@ __global__ __launch_bounds__(128) void dvbs_rrc_state_kernel(const DvbsStreamWor
     DvbsStreamWork w = work[blockIdx.x];
     DvbsStreamState* st = w.st;
     int lo, hi;
-    fe_sub_range(w.count, sub, nsub, lo, hi);
+    fe_sub_range_dvbs(w.count, sub, nsub, lo, hi);
     w.buf_b += lo;
     const int n = hi - lo, H = ntaps - 1;
     __shared__ cf32 nh[RRC_MAX_TAPS];
@@ -2585,7 +2598,7 @@ __global__ __launch_bounds__(64) void dvbs_fd_kernel(const DvbsStreamWork* __res
     DvbsStreamWork w = work[blockIdx.x];
     DvbsStreamState* st = w.st;
     int lo, hi;
-    fe_sub_range(w.count, sub, nsub, lo, hi);
+    fe_sub_range_dvbs(w.count, sub, nsub, lo, hi);
     w.buf_a += lo;
     const int n = hi - lo;
     PclDev pcl{co.fd_alpha, co.fd_beta, st->fd_phase, st->fd_freq, co.fd_min_freq, co.fd_max_freq};
@@ -2938,11 +2951,19 @@ hipError_t dvbs_frontend_launch(const DvbsStreamWork* d_work, int nstreams, int 
         if ((e = hipEventRecord(ev[0][nsub], st)) != hipSuccess) return e;          // the slices start behind what `st` holds now
         if ((e = hipStreamWaitEvent(s0, ev[0][nsub], 0)) != hipSuccess) return e;
     }
-    for (int c = 0; c < nsub; ++c) {                                                 // the AGC runs ahead (cheapest stage)
+    // The AGC runs ahead (cheapest stage).  A bank: all its slices first.  A few carriers (aux[2]): AGC_AHEAD slices ahead of the FLL, enqueued slice by
+    // slice -- the FLL's first launch then leaves the host behind four AGC launches instead of behind all of them (one carrier: 0.4 ms per call), and the
+    // AGC never holds it up.
+    constexpr int AGC_AHEAD = 4;
+    const bool agc_interleaved = sliced && aux[2];
+    auto agc_slice = [&](int c) -> hipError_t {
         hipLaunchKernelGGL(agc_pc_kernel<AgcDvbsTraits>, ga, dim3(128), 0, s0, d_work, nstreams, coefs, c, nsub);
-        if (sliced && (e = hipEventRecord(ev[0][c], s0)) != hipSuccess) return e;
-    }
+        return sliced ? hipEventRecord(ev[0][c], s0) : hipSuccess;
+    };
+    for (int c = 0; c < (agc_interleaved ? (nsub < AGC_AHEAD ? nsub : AGC_AHEAD) : nsub); ++c)
+        if ((e = agc_slice(c)) != hipSuccess) return e;
     for (int c = 0; c < nsub; ++c) {
+        if (agc_interleaved && c + AGC_AHEAD < nsub && (e = agc_slice(c + AGC_AHEAD)) != hipSuccess) return e;
         if (sliced && (e = hipStreamWaitEvent(s1, ev[0][c], 0)) != hipSuccess) return e;
         // (two streams per wave, dvbs_fll4_kernel<2>: same bits, 9 % slower at 4096 carriers, 15 % at 8192)
         if (nstreams >= bank_min) hipLaunchKernelGGL(dvbs_fll4_kernel<4>, dim3((nstreams + 3) / 4), dim3(64), 0, s1, d_work, nstreams, coefs, d_bandedge, c, nsub);
