@@ -48,59 +48,152 @@ __device__ __forceinline__ int wave_sum(int v) {
 
 // One CCDecoder::work (cc_decoder.cpp:304-314) by one wave.  src: 2*(frame+6) unsigned softs; dst: frame bits, one per byte;
 // dec: frame+6 decision words of scratch; (ss, biased) = the decoder object's chained start state.
+//
+// ROTATING STATE LAYOUT.  At step t (r = t mod 6) lane L holds the metric of state rotl6(L, r).  The new state n = ((p << 1) | bit) & 63 has
+// rotr6(n, 1) equal to p except in bit 5, so in the layout of step t + 1 the lane of n IS the lane of one predecessor (p0 = n >> 1 for even n,
+// p1 = p0 + 32 for odd n) and the other predecessor sits in the lane that differs in bit bp = 5 - r: the two fetches of a step (ds_bpermute
+// before, two LDS round trips in the step's chain) are ONE lane exchange by a constant -- DPP quad_perm / row_ror / row_shl+shr for 1, 2, 8, 4,
+// v_permlane16/32_swap for 16, 32 -- and the two lanes of a butterfly face each other.  With own = X[lane], partner = X[lane ^ 1 << bp]:
+//   A = own + metric, B = partner + (63 - metric)   (uint8 wrap-around, volk_k7_r2_generic_fixed.h:27-50: for even n (m0, m1) = (A, B), for odd n (m2, m3) = (B, A))
+//   survivor = min(A, B) either way; decision = A >= B in the even lanes, B >= A in the odd ones (two compares, combined on the scalar unit).
+// The decision word of a step is in the layout of step t + 1 (bit L = the state in lane L); the chain-back walks in the same rotating layout
+// (the predecessor of lane L is L with bit bp replaced by the decision bit), so nothing is ever permuted back.  Chunks of 60 steps = 10
+// rotations; the wave-wide minimum (renormalize, :52-68) is a DPP chain (4 row rotations, row_bcast:15, row_bcast:31, one v_readlane) whose
+// wait states are filled with the decision store and the NEXT step's branch metric.  ~27 issue slots per step instead of ~50 and two LDS
+// round trips.
+__device__ __forceinline__ int rotl6(int x, int r) { return ((x << r) | (x >> (6 - r))) & 63; }
+__device__ __forceinline__ int rotr6(int x, int r) { return ((x >> r) | (x << (6 - r))) & 63; }
+
+#define VIT_PART5 "v_mov_b32 %[T], %[X]\n\tv_mov_b32 %[Xp], %[X]\n\ts_nop 1\n\tv_permlane32_swap_b32 %[T], %[Xp]\n\tv_cndmask_b32_e64 %[Xp], %[T], %[Xp], %[e5]\n\t"
+#define VIT_PART4 "v_mov_b32 %[T], %[X]\n\tv_mov_b32 %[Xp], %[X]\n\ts_nop 1\n\tv_permlane16_swap_b32 %[T], %[Xp]\n\tv_cndmask_b32_e64 %[Xp], %[T], %[Xp], %[e4]\n\t"
+#define VIT_PART3 "v_mov_b32_dpp %[Xp], %[X] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+#define VIT_PART2 "v_mov_b32_dpp %[Xp], %[X] row_shl:4 row_mask:0xf bank_mask:0x5\n\tv_mov_b32_dpp %[Xp], %[X] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+#define VIT_PART1 "v_mov_b32_dpp %[Xp], %[X] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+#define VIT_PART0 "v_mov_b32_dpp %[Xp], %[X] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+// one step; PART: the lane exchange, E: the even-state lanes of the NEW layout (bit bp clear), BN: the branch table of the NEXT step (b0 | b1 << 8: the
+// branch metric sum 1 + (b0 ^ y0) + (b1 ^ y1) is ONE v_sad_u8 against the two softs -- b is 0 or 255, so b ^ y = |b - y|).
+// Wait states: a DPP operand must have been written at least two instructions earlier, a v_readlane source one (tools/ubench/readlane_probe.hip: read right
+// behind its write it returns the OLD value) -- filled with the decision store and the next step's metric, s_nop where nothing is left.
+#define VIT_STEP(PART, E, BN)                                                                                                            \
+    PART                                                                                                                                 \
+    "v_add_u32 %[A], %[X], %[m]\n\t"                                                                                                     \
+    "v_xad_u32 %[B], %[m], 63, %[Xp]\n\t"                                                                                                \
+    "v_cmp_ge_u32_sdwa vcc, %[A], %[B] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"                                                              \
+    "v_cmp_le_u32_sdwa s[20:21], %[A], %[B] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"                                                         \
+    "v_min_u32_sdwa %[Y], %[A], %[B] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"                            \
+    "s_and_b64 s[22:23], vcc, " E "\n\t"                                                                                                 \
+    "s_andn2_b64 s[20:21], s[20:21], " E "\n\t"                                                                                          \
+    "v_min_u32_dpp %[M], %[Y], %[Y] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                                                            \
+    "s_or_b64 s[22:23], s[22:23], s[20:21]\n\t"                                                                                          \
+    "v_writelane_b32 %[wlo], s22, m0\n\t"                                                                                                \
+    "v_min_u32_dpp %[M], %[M], %[M] row_ror:2 row_mask:0xf bank_mask:0xf\n\t"                                                            \
+    "v_writelane_b32 %[whi], s23, m0\n\t"                                                                                                \
+    "s_add_u32 m0, m0, 1\n\t"                                                                                                            \
+    "v_min_u32_dpp %[M], %[M], %[M] row_ror:4 row_mask:0xf bank_mask:0xf\n\t"                                                            \
+    "v_readlane_b32 s24, %[cur], m0\n\t"                                                                                                 \
+    "v_sad_u8 %[m], " BN ", s24, 1\n\t"                                                                                                  \
+    "v_min_u32_dpp %[M], %[M], %[M] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                                                            \
+    "v_lshrrev_b32 %[m], 3, %[m]\n\t"                                                                                                    \
+    "s_nop 0\n\t"                                                                                                                        \
+    "v_min_u32_dpp %[M], %[M], %[M] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                                                         \
+    "s_nop 1\n\t"                                                                                                                        \
+    "v_min_u32_dpp %[M], %[M], %[M] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                                                         \
+    "s_nop 0\n\t"                                                                                                                        \
+    "v_readlane_b32 s27, %[M], 63\n\t"                                                                                                   \
+    "v_subrev_u32 %[X], s27, %[Y]\n\t"                                                                                                   \
+    "s_nop 1\n\t"
+#define VIT_S0 VIT_STEP(VIT_PART5, "%[e5]", "%[b1]")
+#define VIT_S1 VIT_STEP(VIT_PART4, "%[e4]", "%[b2]")
+#define VIT_S2 VIT_STEP(VIT_PART3, "%[e3]", "%[b3]")
+#define VIT_S3 VIT_STEP(VIT_PART2, "%[e2]", "%[b4]")
+#define VIT_S4 VIT_STEP(VIT_PART1, "%[e1]", "%[b5]")
+#define VIT_S5 VIT_STEP(VIT_PART0, "%[e0]", "%[b0]")
+
 __device__ void cc_decode_wave(const uint8_t* src, int frame, int& ss, int& biased, unsigned long long* dec, uint8_t* dst, int lane) {
     const int veclen = frame + 6;
-    // branch table bits for butterfly i = lane>>1 (cc_decoder.cpp:113-125): polys 79, 109
-    const int bi = lane >> 1;
-    const int b0 = (__popc((2 * bi) & 79) & 1) ? 255 : 0, b1 = (__popc((2 * bi) & 109) & 1) ? 255 : 0;
-    const int oddmask = (lane & 1) ? 63 : 0;
-    int X = biased ? ((lane == (ss & 63)) ? 0 : 63) : 31;   // init_viterbi :159-175 / first block unbiased :177-190
-    int sy = 0;
-    if (lane < veclen) sy = src[2 * lane] | (src[2 * lane + 1] << 8);
-    for (int s0 = 0; s0 < veclen; s0 += 64) {
-        const int m = min(64, veclen - s0);
-        const int cur = sy;
-        if (s0 + 64 + lane < veclen) sy = src[2 * (s0 + 64 + lane)] | (src[2 * (s0 + 64 + lane) + 1] << 8);   // next chunk in flight
-        unsigned long long myw = 0;
-        for (int k = 0; k < m; ++k) {
-            const int y = __builtin_amdgcn_readlane(cur, k);
-            const int y0 = y & 255, y1 = y >> 8;
-            const int metric = ((1 + (b0 ^ y0) + (b1 ^ y1)) >> 1) >> 2;   // BFLY: unsigned short sum, >>1, >>2 (volk_k7_r2_generic_fixed.h:27-50)
-            const int xa = __shfl(X, bi), xb = __shfl(X, bi + 32);        // predecessors i and i + 32
-            // even state 2i: m0 = X[i]+metric, m1 = X[i+32]+(63-metric); odd state 2i+1: m2 = X[i]+(63-metric), m3 = X[i+32]+metric
-            const int ma = metric ^ oddmask;                              // 63 - m == m ^ 63 for m in 0..63
-            const int c0 = (xa + ma) & 0xff, c1 = (xb + (ma ^ 63)) & 0xff;   // unsigned char wrap
-            const bool decision = c0 >= c1;                               // (signed int)(m0 - m1) >= 0
-            const unsigned long long w = __ballot(decision);              // bit n = state n: the reference's decision_t layout
-            if (lane == k) myw = w;
-            const int Y = decision ? c1 : c0;
-            X = Y - wave_min_bcast(Y);                                    // renormalize (:52-68)
-        }
-        if (lane < m) dec[s0 + lane] = myw;
+    // branch table bits of the butterfly in this lane, per rotation: the step with old layout r puts state n = rotl6(lane, r + 1) here; butterfly n >> 1 (cc_decoder.cpp:113-125: polys 79, 109)
+    int bt[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const int bi = rotl6(lane, (r + 1) % 6) >> 1;
+        bt[r] = ((__popc((2 * bi) & 79) & 1) ? 255 : 0) | ((__popc((2 * bi) & 109) & 1) ? 255 << 8 : 0);
     }
-    // find_endstate: first minimal metric (cc_decoder.cpp:192-209)
-    const int endstate = wave_min_bcast((X << 8) | lane) & 63;
+    int X = biased ? ((lane == (ss & 63)) ? 0 : 63) : 31;   // init_viterbi :159-175 / first block unbiased :177-190 (layout 0: lane = state)
+    for (int s0 = 0; s0 < veclen; s0 += 60) {
+        const int cnt = min(60, veclen - s0);
+        int cur = 0;
+        if (lane < cnt) cur = src[2 * (s0 + lane)] | (src[2 * (s0 + lane) + 1] << 8);
+        int wlo = 0, whi = 0, tA, tB, tY, tM, tm, tXp, tT;
+        uint32_t ng = (uint32_t)__builtin_amdgcn_readfirstlane(cnt / 6), rem = (uint32_t)__builtin_amdgcn_readfirstlane(cnt % 6);
+        asm volatile(
+            "s_mov_b32 m0, 0\n\t"
+            "v_readlane_b32 s24, %[cur], m0\n\t"
+            "v_sad_u8 %[m], %[b0], s24, 1\n\t"
+            "v_lshrrev_b32 %[m], 3, %[m]\n\t"
+            "s_cmp_eq_u32 %[ng], 0\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "1:\n\t"
+            VIT_S0 VIT_S1 VIT_S2 VIT_S3 VIT_S4 VIT_S5
+            "s_sub_u32 %[ng], %[ng], 1\n\t"
+            "s_cmp_lg_u32 %[ng], 0\n\t"
+            "s_cbranch_scc1 1b\n\t"
+            "2:\n\t"
+            "s_cmp_lt_u32 %[rem], 1\n\t"
+            "s_cbranch_scc1 9f\n\t"
+            VIT_S0
+            "s_cmp_lt_u32 %[rem], 2\n\t"
+            "s_cbranch_scc1 9f\n\t"
+            VIT_S1
+            "s_cmp_lt_u32 %[rem], 3\n\t"
+            "s_cbranch_scc1 9f\n\t"
+            VIT_S2
+            "s_cmp_lt_u32 %[rem], 4\n\t"
+            "s_cbranch_scc1 9f\n\t"
+            VIT_S3
+            "s_cmp_lt_u32 %[rem], 5\n\t"
+            "s_cbranch_scc1 9f\n\t"
+            VIT_S4
+            "9:\n\t"
+            : [X] "+v"(X), [wlo] "+v"(wlo), [whi] "+v"(whi), [ng] "+s"(ng), [A] "=&v"(tA), [B] "=&v"(tB), [Y] "=&v"(tY), [M] "=&v"(tM), [m] "=&v"(tm),
+              [Xp] "=&v"(tXp), [T] "=&v"(tT)
+            : [cur] "v"(cur), [rem] "s"(rem), [b0] "v"(bt[0]), [b1] "v"(bt[1]), [b2] "v"(bt[2]), [b3] "v"(bt[3]), [b4] "v"(bt[4]), [b5] "v"(bt[5]),
+              [e0] "s"(0x5555555555555555ull), [e1] "s"(0x3333333333333333ull), [e2] "s"(0x0F0F0F0F0F0F0F0Full),
+              [e3] "s"(0x00FF00FF00FF00FFull), [e4] "s"(0x0000FFFF0000FFFFull), [e5] "s"(0x00000000FFFFFFFFull)
+            : "s20", "s21", "s22", "s23", "s24", "s27", "m0", "vcc", "scc");
+        if (lane < cnt) dec[s0 + lane] = (unsigned long long)(unsigned)wlo | ((unsigned long long)(unsigned)whi << 32);
+    }
+    // find_endstate: first minimal metric in STATE order (cc_decoder.cpp:192-209); the layout after veclen steps is veclen mod 6
+    const int rend = veclen % 6;
+    const int endstate = wave_min_bcast((X << 8) | rotl6(lane, rend)) & 63;
     __syncthreads();
-    // chainback (cc_decoder.cpp:228-276), tailsize 6, ADDSHIFT 2: uniform (scalar) walk over 64 steps held one per lane
-    unsigned es = (unsigned)endstate << 2;
-    int retval = 0;
-    for (int base = ((frame - 1) >> 6) << 6; base >= 0; base -= 64) {
-        const int cnt = min(64, frame - base);
+    // chainback (cc_decoder.cpp:228-276), tailsize 6, ADDSHIFT 2: a uniform (scalar) walk in the rotating layout.  L = the lane of the state at time
+    // t + 1; bit L of decision word t says which predecessor survived, and the predecessor's lane is L with bit 5 - t mod 6 replaced by that bit.
+    int L = rotr6(endstate, rend), retL = 0;
+    for (int cbase = ((veclen - 1) / 60) * 60; cbase >= 0; cbase -= 60) {
+        const int tlo = max(cbase, 6), thi = min(cbase + 60, veclen);          // decision words [tlo, thi) = output bits [tlo - 6, thi - 6)
+        if (thi <= tlo) continue;
         unsigned long long myw = 0;
-        if (lane < cnt) myw = dec[6 + base + lane];
+        if (lane < 60 && cbase + lane < veclen) myw = dec[cbase + lane];
         const int lo = (int)(unsigned)myw, hi = (int)(unsigned)(myw >> 32);
         unsigned long long bits = 0;
-        for (int k = cnt - 1; k >= 0; --k) {
+        int t = thi - 1;
+        auto one = [&](int k, int bp) {
             const unsigned long long w =
                 (unsigned)__builtin_amdgcn_readlane(lo, k) | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, k) << 32);
-            const unsigned kb = (unsigned)((w >> (es >> 2)) & 1ull);
-            es = (es >> 1) | (kb << 7);
+            const int kb = (int)((w >> L) & 1ull);
+            L = (L & ~(1 << bp)) | (kb << bp);
             bits |= (unsigned long long)kb << k;
-            if (base + k == frame - 6) retval = (int)es;
+            if (cbase + k == frame) retL = L;
+        };
+        for (; t >= tlo && (t + 1) % 6 != 0; --t) one(t - cbase, 5 - (t % 6));       // the partial rotation at the top of the last chunk
+        for (; t >= tlo; t -= 6) {                                                    // whole rotations: the bit positions are constants
+            const int k = t - cbase;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) one(k - q, q);                                // t - q has (t - q) mod 6 = 5 - q
         }
-        if (lane < cnt) dst[base + lane] = (uint8_t)((bits >> lane) & 1ull);
+        if (lane >= tlo - cbase && lane < thi - cbase) dst[cbase + lane - 6] = (uint8_t)((bits >> lane) & 1ull);
     }
-    ss = retval >> 2;
+    ss = rotl6(retL, frame % 6);          // the state at time `frame` (retval >> 2 of the reference's walk)
     biased = 1;
     __syncthreads();
 }
