@@ -2448,9 +2448,9 @@ __global__ __launch_bounds__(64) void dvbs_fll4_kernel(const DvbsStreamWork* __r
         __syncthreads();
         for (int k = 0; k < mmax; ++k) {
             if (k < m) {                                     // (whole lane groups: the shifts and the swizzle stay inside a stream)
-                const cf32 x = cmul(ytile[row][k], phasor_hw(-phase));
+                const cf32 x = cmul_pk3(ytile[row][k], phasor_hw(-phase));
                 // this sample's two outputs: the sum leaving the last tap position + newest sample * tap 64 (the stream's last lane)
-                const cf32 lo = cadd(al[TPL - 1], cmul(x, tl_last)), hi = cadd(ah[TPL - 1], cmul(x, th_last));
+                const cf32 lo = cadd(al[TPL - 1], cmul_pk3(x, tl_last)), hi = cadd(ah[TPL - 1], cmul_pk3(x, th_last));
                 float err = fast_amplitude(hi) - fast_amplitude(lo);
                 err = __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, err), SWZ));
                 freq += co.fll_beta * err;
@@ -2468,9 +2468,9 @@ __global__ __launch_bounds__(64) void dvbs_fll4_kernel(const DvbsStreamWork* __r
                     if (j == 0) { sl = cf32{0.f, 0.f}; sh = cf32{0.f, 0.f}; }
                 }
 #pragma unroll
-                for (int q = TPL - 1; q > 0; --q) { al[q] = cadd(al[q - 1], cmul(x, tl[q])); ah[q] = cadd(ah[q - 1], cmul(x, th[q])); }
-                al[0] = cadd(sl, cmul(x, tl[0]));
-                ah[0] = cadd(sh, cmul(x, th[0]));
+                for (int q = TPL - 1; q > 0; --q) { al[q] = cadd(al[q - 1], cmul_pk3(x, tl[q])); ah[q] = cadd(ah[q - 1], cmul_pk3(x, th[q])); }
+                al[0] = cadd(sl, cmul_pk3(x, tl[0]));
+                ah[0] = cadd(sh, cmul_pk3(x, th[0]));
             }
         }
         __syncthreads();
