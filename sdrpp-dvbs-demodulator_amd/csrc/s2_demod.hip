@@ -572,7 +572,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             post.spec = 1;
             post.loops_launches = std::min(S2_FE_MAX_SLICES, std::max(launches, (max_count / 2) / std::max(sym_per_launch, 1)));
         }
-        { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st, &post, ctx->stage_post_stream == 2 || (!pipelined && ctx->stage_post_stream))); }
+        { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st, &post, ctx->stage_post_stream == 2 || ((!pipelined || n <= S2_SMALL_BANK) && ctx->stage_post_stream))); }   // (a small bank is a set of latency chains in the throughput mode too: its post stages on the AGC's stream made one stream's 4-frame call 39.9 ms instead of 25)
         slot_stats.resize(nslot);
         HIP_TRY(hipMemcpyAsync(slot_stats.data(), ws_slot.p, sizeof(S2FrameStats) * nslot, hipMemcpyDeviceToHost, st));
     } else {
