@@ -23,7 +23,7 @@ def test_slice_matches_oracle(engine, pkg):
     assert pkg.dvbs_slice(engine, torch.zeros(0, dtype=torch.complex64, device='cuda')).numel() == 0
 
 
-@pytest.mark.parametrize('frame', [1024, 1366, 1699, 4096, 6799])
+@pytest.mark.parametrize('frame', [54, 56, 57, 59, 114, 1024, 1366, 1699, 4096, 6799])     # (frame + 6 steps in chunks of 60 = 10 rotations of the state layout: every remainder 0..5, a chunk that is exactly full)
 def test_ccdec_chained_blocks_bit_exact(engine, pkg, frame):
     import torch
     rng = np.random.default_rng(frame)

@@ -65,6 +65,34 @@ def test_fll_and_costas_active_bit_exact(engine, pkg, costas_bw):
     bank.close()
 
 
+@pytest.mark.parametrize('ppm', [1500.0, -1200.0])
+def test_timing_phase_sweeping_through_the_whole_bank_bit_exact(engine, pkg, ppm):
+    """a sampling clock that is off by ~0.1 %: the timing phase walks through all 256 rows of the interpolator bank and over its ends every few hundred
+    symbols -- the written-out per-symbol loop of dvbs_fd_kernel hands every symbol at the ends of the bank (one-sided derivative) and every re-centring
+    of its LDS row window to the general form and takes over again behind it; odd chunk sizes (tiles of 1..3 samples, an empty call) on top"""
+    iq0, _ = od.dvbs_iq(0, 30000, seed=11, esn0_db=14.0, cfo=5e-4, timing=0.1)
+    t = np.arange(int(iq0.size / (1 + ppm * 1e-6)) - 2) * (1 + ppm * 1e-6)
+    k = t.astype(np.int64)
+    f = (t - k).astype(np.float32)
+    iq = (iq0[k] * (1 - f) + iq0[k + 1] * f).astype(np.complex64)                     # (any resampler will do: both sides get the same samples)
+    chunks = [1, 2, 3, 0, 7001, 255, 256, 257, 16384, 12288]
+    chunks.append(min(16384, iq.size - sum(chunks)))
+    iq = iq[:sum(chunks)]
+    exp, rx = _oracle_chain(iq, chunks)
+    bank = pkg.DvbsDemodBank(engine, 1, max_samples=16384)
+    got, pos = [], 0
+    for c in chunks:
+        bank.process(iq[pos:pos + c])
+        got.append(bank.symbols())
+        pos += c
+    got = np.concatenate(got)
+    assert got.size == exp.size and np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    st, es = bank.loop_state(), rx.state()
+    assert np.array_equal(st.view(np.uint32), es.view(np.uint32)), (st, es)
+    assert abs(exp.size - iq.size / 2 * (1 + ppm * 1e-6)) < 64                       # the loop followed the clock: symbols out = samples / (2 / (1 + ppm))
+    bank.close()
+
+
 @pytest.mark.parametrize('rate,cfo,timing,phase0', [(0, 0.0, 0.0, 0.0), (2, 1e-3, 0.3, 0.4), (4, -5e-4, 0.6, 1.0)])
 def test_dvbs_chain_decodes_like_oracle(engine, pkg, rate, cfo, timing, phase0):
     """IQ -> decoded bits through front end, slicer and the self-locking Viterbi: equal to the oracle bit for bit, call by call"""
