@@ -2264,7 +2264,7 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
     const f32x2 tlv{tl.re, tl.im}, thv{th.re, th.im};
     const f32x2 tlL{__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tl_last.re))), __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tl_last.im)))};
     const f32x2 thL{__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, th_last.re))), __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, th_last.im)))};
-    const float beta_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, co.fll_beta)));
+    const float beta_v = co.fll_beta;
     const float minf_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, co.fll_min_freq)));
     const float maxf_v = co.fll_max_freq;
     for (int base = 0; base < n; base += 64) {
@@ -2274,7 +2274,7 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
         __syncthreads();
         // ONE WAVE ALONE ON ITS SIMD issues one instruction per ~4.5 (4-byte encodings) to ~5.5 cycles (packed / VOP3 / literal operands), dependent or
         // not (tools/ubench/lone_wave.hip): this loop's time is its instruction count.  The compiler's form of it was 95 instructions per sample; written
-        // out it is 69 -- a complex product as two packed multiplications and ONE packed addition with neg_lo (the compiler builds two additions and
+        // out it is 66 -- a complex product as two packed multiplications and ONE packed addition with neg_lo (the compiler builds two additions and
         // register moves), fastAmplitude as max + 0.4 min with |.| operand modifiers, the systolic shift as the DPP operand of the addition that uses it,
         // compares through VCC (4-byte encodings, no wait states), constants in scalar registers, a carry-out loop counter.  Every operation and
         // every rounding is the C++ form's (phasor = dvbs2m::sincosf_det(-phase), cmul, cadd, fast_amplitude, PhaseControlLoop::advance with alpha = 0, pcl_wrap_pi):
@@ -2297,6 +2297,10 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
             "s_mov_b32 s50, 0xc0490fdb\n\t"          // -pi
             "s_mov_b32 s51, 0x40c90fdb\n\t"          // 2 pi
             "s_mov_b32 s52, 0xc0c90fdb\n\t"          // -2 pi
+            "v_mov_b32 v56, %[alr]\n\t"              // the running sums in register PAIRS (packed additions below), moved back behind the loop
+            "v_mov_b32 v57, %[ali]\n\t"
+            "v_mov_b32 v58, %[ahr]\n\t"
+            "v_mov_b32 v59, %[ahi]\n\t"
             "1:\n\t"
             "ds_read_b64 v[42:43], %[xa] offset:512\n\t"                                              // y
             // phasor(-phase): j = rint(-phase 2/pi), r = fma(j, -lo, fma(j, -hi, -phase)), z = r r
@@ -2321,10 +2325,6 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
             "v_cndmask_b32 v46, v47, v46, vcc\n\t"                                                    // even quadrant ? pc : ps
             "v_xor_b32 v47, v51, v49\n\t"
             "v_xor_b32 v46, v46, v50\n\t"                                                             // v[46:47] = (cos, sin)
-            "v_readlane_b32 s54, %[alr], 63\n\t"                                                      // the sums leaving lane 63 (taps 0..63 of this sample's outputs)
-            "v_readlane_b32 s55, %[ali], 63\n\t"
-            "v_readlane_b32 s56, %[ahr], 63\n\t"
-            "v_readlane_b32 s57, %[ahi], 63\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             // x = y * phasor
             "v_pk_mul_f32 v[48:49], v[42:43], v[46:47] op_sel_hi:[0,1]\n\t"
@@ -2338,8 +2338,10 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
             "v_pk_mul_f32 v[50:51], v[42:43], %[thL] op_sel_hi:[0,1]\n\t"
             "v_pk_mul_f32 v[52:53], v[42:43], %[thL] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
             "v_pk_add_f32 v[50:51], v[50:51], v[52:53] neg_lo:[0,1]\n\t"
-            "v_pk_add_f32 v[48:49], v[48:49], s[54:55]\n\t"                                           // lower band edge
-            "v_pk_add_f32 v[50:51], v[50:51], s[56:57]\n\t"                                           // upper band edge
+            // every lane adds ITS running sums: lane 63's are the sums of taps 0..63 of this sample's outputs, so lane 63 holds the two band-edge outputs and
+            // the error, and ONE v_readlane hands the error to the wave (reading the four sums out of lane 63 first took four)
+            "v_pk_add_f32 v[48:49], v[48:49], v[56:57]\n\t"                                           // lower band edge
+            "v_pk_add_f32 v[50:51], v[50:51], v[58:59]\n\t"                                           // upper band edge
             // err = fastAmplitude(upper) - fastAmplitude(lower)
             "v_max_f32 v52, |v50|, |v51|\n\t"
             "v_max_f32 v53, |v48|, |v49|\n\t"
@@ -2348,8 +2350,16 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
             "v_pk_mul_f32 v[54:55], v[54:55], s[48:49] op_sel_hi:[1,0]\n\t"
             "v_pk_add_f32 v[52:53], v[52:53], v[54:55]\n\t"
             "v_sub_f32 v52, v52, v53\n\t"
+            // the products of the systolic step (every lane: x * its tap) stand between the v_readlane and the first use of what it read
+            "v_pk_mul_f32 v[48:49], v[42:43], %[tl] op_sel_hi:[0,1]\n\t"                              // (and behind the write of its source: read right behind it, a v_readlane returns the old value)
+            "v_readlane_b32 s54, v52, 63\n\t"
+            "v_pk_mul_f32 v[50:51], v[42:43], %[tl] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+            "v_pk_add_f32 v[48:49], v[48:49], v[50:51] neg_lo:[0,1]\n\t"
+            "v_pk_mul_f32 v[50:51], v[42:43], %[th] op_sel_hi:[0,1]\n\t"
+            "v_pk_mul_f32 v[52:53], v[42:43], %[th] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+            "v_pk_add_f32 v[50:51], v[50:51], v[52:53] neg_lo:[0,1]\n\t"
             // freq += beta err, clamped; phase += freq, wrapped into [-pi, pi]
-            "v_mul_f32 v52, %[beta], v52\n\t"
+            "v_mul_f32 v52, s54, %[beta]\n\t"
             "v_add_f32 %[fr], %[fr], v52\n\t"
             "v_med3_f32 %[fr], %[fr], %[minf], %[maxf]\n\t"
             "v_add_f32 %[ph], %[ph], %[fr]\n\t"
@@ -2359,25 +2369,23 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
             "v_add_f32 v52, s51, %[ph]\n\t"
             "v_cmp_gt_f32 vcc, s50, %[ph]\n\t"
             "v_cndmask_b32 %[ph], %[ph], v52, vcc\n\t"
-            // systolic step: every lane adds x * its tap to the sum arriving from the lane below (lane 0: to zero = starts the sum of output m + 64)
-            "v_pk_mul_f32 v[48:49], v[42:43], %[tl] op_sel_hi:[0,1]\n\t"
-            "v_pk_mul_f32 v[50:51], v[42:43], %[tl] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
-            "v_pk_add_f32 v[48:49], v[48:49], v[50:51] neg_lo:[0,1]\n\t"
-            "v_pk_mul_f32 v[50:51], v[42:43], %[th] op_sel_hi:[0,1]\n\t"
-            "v_pk_mul_f32 v[52:53], v[42:43], %[th] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
-            "v_pk_add_f32 v[50:51], v[50:51], v[52:53] neg_lo:[0,1]\n\t"
+            // systolic step: every lane adds its product to the sum arriving from the lane below (lane 0: to zero = starts the sum of output m + 64)
             "v_add_u32 %[xa], 8, %[xa]\n\t"
-            "v_add_f32_dpp %[alr], %[alr], v48 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_add_f32_dpp %[ali], %[ali], v49 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_add_f32_dpp %[ahr], %[ahr], v50 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_add_f32_dpp %[ahi], %[ahi], v51 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp v56, v56, v48 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp v57, v57, v49 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp v58, v58, v50 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp v59, v59, v51 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
             "s_add_u32 %[cnt], %[cnt], 1\n\t"
             "s_cbranch_scc0 1b\n\t"
+            "v_mov_b32 %[alr], v56\n\t"
+            "v_mov_b32 %[ali], v57\n\t"
+            "v_mov_b32 %[ahr], v58\n\t"
+            "v_mov_b32 %[ahi], v59\n\t"
             "s_waitcnt lgkmcnt(0)"
             : [ph] "+v"(phase), [fr] "+v"(freq), [alr] "+v"(al.re), [ali] "+v"(al.im), [ahr] "+v"(ah.re), [ahi] "+v"(ah.im), [xa] "+v"(xa), [cnt] "+s"(cnt)
-            : [tl] "v"(tlv), [th] "v"(thv), [tlL] "s"(tlL), [thL] "s"(thL), [beta] "s"(beta_s), [minf] "s"(minf_s), [maxf] "v"(maxf_v)
+            : [tl] "v"(tlv), [th] "v"(thv), [tlL] "s"(tlL), [thL] "s"(thL), [beta] "v"(beta_v), [minf] "s"(minf_s), [maxf] "v"(maxf_v)
             : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
-              "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s54", "s55", "s56", "s57", "vcc", "scc", "memory");
+              "v56", "v57", "v58", "v59", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s54", "vcc", "scc", "memory");
         __syncthreads();
         if (lane < m) w.buf_b[base + lane] = xtile[lane];
     }
