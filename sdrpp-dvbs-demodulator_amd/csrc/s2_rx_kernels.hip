@@ -2238,6 +2238,80 @@ __device__ __forceinline__ cf32 cmul_pk3(cf32 a, cf32 b) {
 // x[m]*t[k] to the running sum of output m+64-k and the sums move one lane up (DPP wave_shr:1), so every output accumulates its
 // terms in tap order 0..64 (the order of VOLK's generic kernel) while only the LAST term (tap 64, the newest sample) sits in the
 // loop's serial chain.  Lanes 0..63 = taps 0..63; tap 64 is applied by all lanes to the sum leaving lane 63.
+// ONE SAMPLE of the FLL loop (dvbs_fll_kernel's inline assembly; operands as named there, v40.. / s40.. as set up there), in this order:
+//   y = the sample (LDS read issued first, waited for behind the phasor)
+//   phasor(-phase) = dvbs2m::sincosf_det: j = rint(-phase 2/pi), r = fma(j, -lo, fma(j, -hi, -phase)), z = r r, both minimax polynomials in packed FMAs
+//     (v[46:47] = (cos part, sin part)), quadrant fix-ups on the sign bits -> v[46:47] = (cos, sin)
+//   x = y * phasor (two packed multiplications, one packed addition with neg_lo) -> v[42:43], stored to the output tile
+//   the two band-edge outputs of lane 63: x * tap 64 + that lane's running sums v[56:57], v[58:59] (taps 0..63); err = fastAmplitude(upper) - fastAmplitude(lower)
+//     (max + 0.4 min with |.| operand modifiers); ONE v_readlane of lane 63 hands err to the wave, with the first systolic product between its source's write and it
+//   the systolic products x * tap of every lane; freq += beta err, clamped (v_med3); phase += freq, wrapped into [-pi, pi] (compares through VCC)
+//   every lane adds its product to the sum arriving from the lane below (v_add_f32_dpp wave_shr:1, lane 0 reads zero = starts the sum of output m + 64)
+#define DVBS_FLL_SAMPLE \
+    "ds_read_b64 v[42:43], %[xa] offset:512\n\t" \
+    "v_mul_f32 v44, s40, %[ph]\n\t" \
+    "v_rndne_f32 v44, v44\n\t" \
+    "v_cvt_i32_f32 v45, v44\n\t" \
+    "v_fma_f32 v47, v44, s41, -%[ph]\n\t" \
+    "v_fmac_f32 v47, s42, v44\n\t" \
+    "v_mul_f32 v46, v47, v47\n\t" \
+    "v_pk_fma_f32 v[48:49], v[46:47], s[44:45], v[40:41] op_sel_hi:[0,1,1]\n\t" \
+    "v_pk_mul_f32 v[50:51], v[46:47], v[46:47] op_sel_hi:[1,0]\n\t" \
+    "v_pk_fma_f32 v[48:49], v[48:49], v[46:47], s[46:47] op_sel_hi:[1,0,1]\n\t" \
+    "v_fma_f32 v46, v46, -0.5, 1.0\n\t" \
+    "v_pk_fma_f32 v[46:47], v[50:51], v[48:49], v[46:47]\n\t" \
+    "v_and_b32 v48, 1, v45\n\t" \
+    "v_lshlrev_b32 v49, 30, v45\n\t" \
+    "v_sub_u32 v50, 0, v49\n\t" \
+    "v_cmp_eq_u32 vcc, 0, v48\n\t" \
+    "v_and_b32 v49, s43, v49\n\t" \
+    "v_and_b32 v50, s43, v50\n\t" \
+    "v_cndmask_b32 v51, v46, v47, vcc\n\t" \
+    "v_cndmask_b32 v46, v47, v46, vcc\n\t" \
+    "v_xor_b32 v47, v51, v49\n\t" \
+    "v_xor_b32 v46, v46, v50\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "v_pk_mul_f32 v[48:49], v[42:43], v[46:47] op_sel_hi:[0,1]\n\t" \
+    "v_pk_mul_f32 v[50:51], v[42:43], v[46:47] op_sel:[1,1] op_sel_hi:[1,0]\n\t" \
+    "v_pk_add_f32 v[42:43], v[48:49], v[50:51] neg_lo:[0,1]\n\t" \
+    "ds_write_b64 %[xa], v[42:43]\n\t" \
+    "v_pk_mul_f32 v[48:49], v[42:43], %[tlL] op_sel_hi:[0,1]\n\t" \
+    "v_pk_mul_f32 v[50:51], v[42:43], %[tlL] op_sel:[1,1] op_sel_hi:[1,0]\n\t" \
+    "v_pk_add_f32 v[48:49], v[48:49], v[50:51] neg_lo:[0,1]\n\t" \
+    "v_pk_mul_f32 v[50:51], v[42:43], %[thL] op_sel_hi:[0,1]\n\t" \
+    "v_pk_mul_f32 v[52:53], v[42:43], %[thL] op_sel:[1,1] op_sel_hi:[1,0]\n\t" \
+    "v_pk_add_f32 v[50:51], v[50:51], v[52:53] neg_lo:[0,1]\n\t" \
+    "v_pk_add_f32 v[48:49], v[48:49], v[56:57]\n\t" \
+    "v_pk_add_f32 v[50:51], v[50:51], v[58:59]\n\t" \
+    "v_max_f32 v52, |v50|, |v51|\n\t" \
+    "v_max_f32 v53, |v48|, |v49|\n\t" \
+    "v_min_f32 v54, |v50|, |v51|\n\t" \
+    "v_min_f32 v55, |v48|, |v49|\n\t" \
+    "v_pk_mul_f32 v[54:55], v[54:55], s[48:49] op_sel_hi:[1,0]\n\t" \
+    "v_pk_add_f32 v[52:53], v[52:53], v[54:55]\n\t" \
+    "v_sub_f32 v52, v52, v53\n\t" \
+    "v_pk_mul_f32 v[48:49], v[42:43], %[tl] op_sel_hi:[0,1]\n\t" \
+    "v_readlane_b32 s54, v52, 63\n\t" \
+    "v_pk_mul_f32 v[50:51], v[42:43], %[tl] op_sel:[1,1] op_sel_hi:[1,0]\n\t" \
+    "v_pk_add_f32 v[48:49], v[48:49], v[50:51] neg_lo:[0,1]\n\t" \
+    "v_pk_mul_f32 v[50:51], v[42:43], %[th] op_sel_hi:[0,1]\n\t" \
+    "v_pk_mul_f32 v[52:53], v[42:43], %[th] op_sel:[1,1] op_sel_hi:[1,0]\n\t" \
+    "v_pk_add_f32 v[50:51], v[50:51], v[52:53] neg_lo:[0,1]\n\t" \
+    "v_mul_f32 v52, s54, %[beta]\n\t" \
+    "v_add_f32 %[fr], %[fr], v52\n\t" \
+    "v_med3_f32 %[fr], %[fr], %[minf], %[maxf]\n\t" \
+    "v_add_f32 %[ph], %[ph], %[fr]\n\t" \
+    "v_add_f32 v52, s52, %[ph]\n\t" \
+    "v_cmp_lt_f32 vcc, s49, %[ph]\n\t" \
+    "v_cndmask_b32 %[ph], %[ph], v52, vcc\n\t" \
+    "v_add_f32 v52, s51, %[ph]\n\t" \
+    "v_cmp_gt_f32 vcc, s50, %[ph]\n\t" \
+    "v_cndmask_b32 %[ph], %[ph], v52, vcc\n\t" \
+    "v_add_u32 %[xa], 8, %[xa]\n\t" \
+    "v_add_f32_dpp v56, v56, v48 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp v57, v57, v49 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp v58, v58, v50 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+    "v_add_f32_dpp v59, v59, v51 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __restrict__ work, DvbsLoopCoefs co,
                                                       const cf32* __restrict__ bandedge, int sub, int nsub) {
     __shared__ cf32 tile[128];                   // [0, 64): rotated samples out (x), [64, 128): samples in (y) -- the loop below addresses both from one register
@@ -2276,11 +2350,12 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
         // not (tools/ubench/lone_wave.hip): this loop's time is its instruction count.  The compiler's form of it was 95 instructions per sample; written
         // out it is 66 -- a complex product as two packed multiplications and ONE packed addition with neg_lo (the compiler builds two additions and
         // register moves), fastAmplitude as max + 0.4 min with |.| operand modifiers, the systolic shift as the DPP operand of the addition that uses it,
-        // compares through VCC (4-byte encodings, no wait states), constants in scalar registers, a carry-out loop counter.  Every operation and
+        // compares through VCC (4-byte encodings, no wait states), constants in scalar registers, four samples per trip of the loop.  Every operation and
         // every rounding is the C++ form's (phasor = dvbs2m::sincosf_det(-phase), cmul, cadd, fast_amplitude, PhaseControlLoop::advance with alpha = 0, pcl_wrap_pi):
         // the DVB-S tests compare symbols, loop state and decoded bits with the oracle.
         uint32_t xa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) cf32*)xtile;
-        uint32_t cnt = (uint32_t)-__builtin_amdgcn_readfirstlane(m);          // counts up; the carry out of the last increment ends the loop
+        const uint32_t mu = (uint32_t)__builtin_amdgcn_readfirstlane(m), cnt = mu & 3u;
+        uint32_t n4 = mu >> 2;
         asm volatile(
             "s_mov_b32 s40, 0xbf22f983\n\t"          // -2/pi
             "s_mov_b32 s41, 0xbfc90fdb\n\t"          // -(pi/2 rounded to binary32)
@@ -2301,89 +2376,32 @@ __global__ __launch_bounds__(64) void dvbs_fll_kernel(const DvbsStreamWork* __re
             "v_mov_b32 v57, %[ali]\n\t"
             "v_mov_b32 v58, %[ahr]\n\t"
             "v_mov_b32 v59, %[ahi]\n\t"
+            // four samples per trip of the loop (a taken branch costs a lone wave ~28 cycles: tools/ubench/branch.hip), then the tile's last 0..3
+            "s_cmp_eq_u32 %[n4], 0\n\t"
+            "s_cbranch_scc1 2f\n\t"
             "1:\n\t"
-            "ds_read_b64 v[42:43], %[xa] offset:512\n\t"                                              // y
-            // phasor(-phase): j = rint(-phase 2/pi), r = fma(j, -lo, fma(j, -hi, -phase)), z = r r
-            "v_mul_f32 v44, s40, %[ph]\n\t"
-            "v_rndne_f32 v44, v44\n\t"
-            "v_cvt_i32_f32 v45, v44\n\t"
-            "v_fma_f32 v47, v44, s41, -%[ph]\n\t"
-            "v_fmac_f32 v47, s42, v44\n\t"
-            "v_mul_f32 v46, v47, v47\n\t"                                                             // v[46:47] = (z, r)
-            "v_pk_fma_f32 v[48:49], v[46:47], s[44:45], v[40:41] op_sel_hi:[0,1,1]\n\t"              // (z c2 + c1) for cos | sin
-            "v_pk_mul_f32 v[50:51], v[46:47], v[46:47] op_sel_hi:[1,0]\n\t"                           // (z z, r z)
-            "v_pk_fma_f32 v[48:49], v[48:49], v[46:47], s[46:47] op_sel_hi:[1,0,1]\n\t"              // (.. z + c0)
-            "v_fma_f32 v46, v46, -0.5, 1.0\n\t"                                                       // (1 - z/2, r)
-            "v_pk_fma_f32 v[46:47], v[50:51], v[48:49], v[46:47]\n\t"                                 // (pc, ps)
-            "v_and_b32 v48, 1, v45\n\t"
-            "v_lshlrev_b32 v49, 30, v45\n\t"
-            "v_sub_u32 v50, 0, v49\n\t"
-            "v_cmp_eq_u32 vcc, 0, v48\n\t"
-            "v_and_b32 v49, s43, v49\n\t"                                                             // sin changes sign in quadrants 2, 3
-            "v_and_b32 v50, s43, v50\n\t"                                                             // cos in quadrants 1, 2
-            "v_cndmask_b32 v51, v46, v47, vcc\n\t"                                                    // even quadrant ? ps : pc
-            "v_cndmask_b32 v46, v47, v46, vcc\n\t"                                                    // even quadrant ? pc : ps
-            "v_xor_b32 v47, v51, v49\n\t"
-            "v_xor_b32 v46, v46, v50\n\t"                                                             // v[46:47] = (cos, sin)
-            "s_waitcnt lgkmcnt(0)\n\t"
-            // x = y * phasor
-            "v_pk_mul_f32 v[48:49], v[42:43], v[46:47] op_sel_hi:[0,1]\n\t"
-            "v_pk_mul_f32 v[50:51], v[42:43], v[46:47] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
-            "v_pk_add_f32 v[42:43], v[48:49], v[50:51] neg_lo:[0,1]\n\t"
-            "ds_write_b64 %[xa], v[42:43]\n\t"
-            // the two outputs: sum of taps 0..63 + x * tap 64
-            "v_pk_mul_f32 v[48:49], v[42:43], %[tlL] op_sel_hi:[0,1]\n\t"
-            "v_pk_mul_f32 v[50:51], v[42:43], %[tlL] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
-            "v_pk_add_f32 v[48:49], v[48:49], v[50:51] neg_lo:[0,1]\n\t"
-            "v_pk_mul_f32 v[50:51], v[42:43], %[thL] op_sel_hi:[0,1]\n\t"
-            "v_pk_mul_f32 v[52:53], v[42:43], %[thL] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
-            "v_pk_add_f32 v[50:51], v[50:51], v[52:53] neg_lo:[0,1]\n\t"
-            // every lane adds ITS running sums: lane 63's are the sums of taps 0..63 of this sample's outputs, so lane 63 holds the two band-edge outputs and
-            // the error, and ONE v_readlane hands the error to the wave (reading the four sums out of lane 63 first took four)
-            "v_pk_add_f32 v[48:49], v[48:49], v[56:57]\n\t"                                           // lower band edge
-            "v_pk_add_f32 v[50:51], v[50:51], v[58:59]\n\t"                                           // upper band edge
-            // err = fastAmplitude(upper) - fastAmplitude(lower)
-            "v_max_f32 v52, |v50|, |v51|\n\t"
-            "v_max_f32 v53, |v48|, |v49|\n\t"
-            "v_min_f32 v54, |v50|, |v51|\n\t"
-            "v_min_f32 v55, |v48|, |v49|\n\t"
-            "v_pk_mul_f32 v[54:55], v[54:55], s[48:49] op_sel_hi:[1,0]\n\t"
-            "v_pk_add_f32 v[52:53], v[52:53], v[54:55]\n\t"
-            "v_sub_f32 v52, v52, v53\n\t"
-            // the products of the systolic step (every lane: x * its tap) stand between the v_readlane and the first use of what it read
-            "v_pk_mul_f32 v[48:49], v[42:43], %[tl] op_sel_hi:[0,1]\n\t"                              // (and behind the write of its source: read right behind it, a v_readlane returns the old value)
-            "v_readlane_b32 s54, v52, 63\n\t"
-            "v_pk_mul_f32 v[50:51], v[42:43], %[tl] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
-            "v_pk_add_f32 v[48:49], v[48:49], v[50:51] neg_lo:[0,1]\n\t"
-            "v_pk_mul_f32 v[50:51], v[42:43], %[th] op_sel_hi:[0,1]\n\t"
-            "v_pk_mul_f32 v[52:53], v[42:43], %[th] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
-            "v_pk_add_f32 v[50:51], v[50:51], v[52:53] neg_lo:[0,1]\n\t"
-            // freq += beta err, clamped; phase += freq, wrapped into [-pi, pi]
-            "v_mul_f32 v52, s54, %[beta]\n\t"
-            "v_add_f32 %[fr], %[fr], v52\n\t"
-            "v_med3_f32 %[fr], %[fr], %[minf], %[maxf]\n\t"
-            "v_add_f32 %[ph], %[ph], %[fr]\n\t"
-            "v_add_f32 v52, s52, %[ph]\n\t"
-            "v_cmp_lt_f32 vcc, s49, %[ph]\n\t"
-            "v_cndmask_b32 %[ph], %[ph], v52, vcc\n\t"
-            "v_add_f32 v52, s51, %[ph]\n\t"
-            "v_cmp_gt_f32 vcc, s50, %[ph]\n\t"
-            "v_cndmask_b32 %[ph], %[ph], v52, vcc\n\t"
-            // systolic step: every lane adds its product to the sum arriving from the lane below (lane 0: to zero = starts the sum of output m + 64)
-            "v_add_u32 %[xa], 8, %[xa]\n\t"
-            "v_add_f32_dpp v56, v56, v48 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_add_f32_dpp v57, v57, v49 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_add_f32_dpp v58, v58, v50 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_add_f32_dpp v59, v59, v51 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "s_add_u32 %[cnt], %[cnt], 1\n\t"
-            "s_cbranch_scc0 1b\n\t"
+            DVBS_FLL_SAMPLE DVBS_FLL_SAMPLE DVBS_FLL_SAMPLE DVBS_FLL_SAMPLE
+            "s_sub_u32 %[n4], %[n4], 1\n\t"
+            "s_cmp_lg_u32 %[n4], 0\n\t"
+            "s_cbranch_scc1 1b\n\t"
+            "2:\n\t"
+            "s_cmp_lt_u32 %[cnt], 1\n\t"
+            "s_cbranch_scc1 3f\n\t"
+            DVBS_FLL_SAMPLE
+            "s_cmp_lt_u32 %[cnt], 2\n\t"
+            "s_cbranch_scc1 3f\n\t"
+            DVBS_FLL_SAMPLE
+            "s_cmp_lt_u32 %[cnt], 3\n\t"
+            "s_cbranch_scc1 3f\n\t"
+            DVBS_FLL_SAMPLE
+            "3:\n\t"
             "v_mov_b32 %[alr], v56\n\t"
             "v_mov_b32 %[ali], v57\n\t"
             "v_mov_b32 %[ahr], v58\n\t"
             "v_mov_b32 %[ahi], v59\n\t"
             "s_waitcnt lgkmcnt(0)"
-            : [ph] "+v"(phase), [fr] "+v"(freq), [alr] "+v"(al.re), [ali] "+v"(al.im), [ahr] "+v"(ah.re), [ahi] "+v"(ah.im), [xa] "+v"(xa), [cnt] "+s"(cnt)
-            : [tl] "v"(tlv), [th] "v"(thv), [tlL] "s"(tlL), [thL] "s"(thL), [beta] "v"(beta_v), [minf] "s"(minf_s), [maxf] "v"(maxf_v)
+            : [ph] "+v"(phase), [fr] "+v"(freq), [alr] "+v"(al.re), [ali] "+v"(al.im), [ahr] "+v"(ah.re), [ahi] "+v"(ah.im), [xa] "+v"(xa), [n4] "+s"(n4)
+            : [tl] "v"(tlv), [th] "v"(thv), [tlL] "s"(tlL), [thL] "s"(thL), [beta] "v"(beta_v), [minf] "s"(minf_s), [maxf] "v"(maxf_v), [cnt] "s"(cnt)
             : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",
               "v56", "v57", "v58", "v59", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s54", "vcc", "scc", "memory");
         __syncthreads();
