@@ -126,6 +126,7 @@ __device__ void cc_decode_wave(const uint8_t* src, int frame, int& ss, int& bias
         int wlo = 0, whi = 0, tA, tB, tY, tM, tm, tXp, tT;
         uint32_t ng = (uint32_t)__builtin_amdgcn_readfirstlane(cnt / 6), rem = (uint32_t)__builtin_amdgcn_readfirstlane(cnt % 6);
         asm volatile(
+            "s_mov_b32 s26, m0\n\t"                  // (m0 = the lane the step reads its softs from and writes its decision word to; the caller's value comes back at the end)
             "s_mov_b32 m0, 0\n\t"
             "v_readlane_b32 s24, %[cur], m0\n\t"
             "v_sad_u8 %[m], %[b0], s24, 1\n\t"
@@ -154,12 +155,13 @@ __device__ void cc_decode_wave(const uint8_t* src, int frame, int& ss, int& bias
             "s_cbranch_scc1 9f\n\t"
             VIT_S4
             "9:\n\t"
+            "s_mov_b32 m0, s26\n\t"
             : [X] "+v"(X), [wlo] "+v"(wlo), [whi] "+v"(whi), [ng] "+s"(ng), [A] "=&v"(tA), [B] "=&v"(tB), [Y] "=&v"(tY), [M] "=&v"(tM), [m] "=&v"(tm),
               [Xp] "=&v"(tXp), [T] "=&v"(tT)
             : [cur] "v"(cur), [rem] "s"(rem), [b0] "v"(bt[0]), [b1] "v"(bt[1]), [b2] "v"(bt[2]), [b3] "v"(bt[3]), [b4] "v"(bt[4]), [b5] "v"(bt[5]),
               [e0] "s"(0x5555555555555555ull), [e1] "s"(0x3333333333333333ull), [e2] "s"(0x0F0F0F0F0F0F0F0Full),
               [e3] "s"(0x00FF00FF00FF00FFull), [e4] "s"(0x0000FFFF0000FFFFull), [e5] "s"(0x00000000FFFFFFFFull)
-            : "s20", "s21", "s22", "s23", "s24", "s27", "m0", "vcc", "scc");
+            : "s20", "s21", "s22", "s23", "s24", "s26", "s27", "vcc", "scc");
         if (lane < cnt) dec[s0 + lane] = (unsigned long long)(unsigned)wlo | ((unsigned long long)(unsigned)whi << 32);
     }
     // find_endstate: first minimal metric in STATE order (cc_decoder.cpp:192-209); the layout after veclen steps is veclen mod 6
