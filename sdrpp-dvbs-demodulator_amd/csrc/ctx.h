@@ -163,7 +163,7 @@ struct dvbs2gpu_ctx {
     // balance of the two streams of the pipelined mode (s2_demod.hip): share of the timing loop's tiles that run one priority level up
     int g_prio_duty = 0, g_prio_trend = 0;
     bool g_prio_auto = true;                  // DVBS2GPU_G_PRIO_DUTY fixes the value
-    int dvbs_bank_min = 1280;                 // DVBS2GPU_DVBS_BANK_MIN: carriers from which a bank uses the four-streams-per-wave FLL (measured crossover; tests: 1)
+    int dvbs_bank_min = 2048;                 // DVBS2GPU_DVBS_BANK_MIN: carriers from which a bank uses the four-streams-per-wave FLL (measured crossover with the written-out wave-per-stream loop: 2048 carriers 74.2 vs 74.8 ms, 1024: 46.2 vs 54.8, 4096: 128.8 vs 111.4; tests: 1)
     int dvbs_agc_stream = 1;                  // DVBS2GPU_DVBS_AGC_STREAM: the AGC slices of a bank below dvbs_bank_min carriers on a third auxiliary stream (0: on the Viterbi stream)
     int dvbs_fe_slices = 24;                 // DVBS2GPU_DVBS_FE_SLICES: time slices of a DVB-S call (dvbs_demod.hip)
     // DVB-S front end (dvbs_demod.hip)
