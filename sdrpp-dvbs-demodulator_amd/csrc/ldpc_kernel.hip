@@ -100,6 +100,12 @@ __device__ __forceinline__ void atab_load(uint32_t (&pw)[NPW], const uint32_t* _
     for (int i = 0; i < NPI; ++i) pw[2 * i] = w[i];
 }
 #ifndef LDPC_DIET
+#ifndef LDPC_OTHER_SUM
+#define LDPC_OTHER_SUM 1   // the other-minimum selection of the output phase as a sum minus a minimum (2 packed operations per link pair instead of 3).  Frames/s, 1024 frames x 50
+#endif                     // iterations, without -> with: normal 1/3 77 694 -> 82 151, 2/5 103 492 -> 104 048, 1/2 103 140 -> 106 015, 3/5 66 843 -> 67 977, 2/3 102 926 -> 106 170,
+                           // 4/5 80 950 -> 82 588, 5/6 73 178 -> 74 543, 8/9 97 007 -> 99 090, 9/10 83 223 -> 83 865, 1/4 118 119 -> 117 120; short 1/4 314 901 -> 335 881, the other
+                           // short codes within 1 %; the degree-12 kernel (3/4 normal, at the register cap: a different allocation eats it) 93 348 -> 90 917 -- it keeps the product form
+template <int MAXDEG, bool IRREG> constexpr bool ldpc_other_sum() { return LDPC_OTHER_SUM && MAXDEG != 12; }
 #define LDPC_DIET 1   // two cuts in a layer's per-wave instruction stream (what a layer costs): (1) the layer-ahead fetches -- message record, address / row words --
                       // are issued unconditionally by every lane (idle lanes with a clamped row index; the records are cleared at the start of a frame, so the first sweep needs no "is
                       // this the first sweep" either): no exec-mask juggling and, above all, no "fetched / not fetched" merge of the registers, which cost a copy of every prefetch register
@@ -640,14 +646,22 @@ __device__ __forceinline__ void layer_update(int8_t* __restrict__ post, const Ld
         // [-32, 31] then only needs its upper side)
         const int min0c = min(min0, 32), min1c = min(min1, 32);
         const s16x2 MIN0B = q8(min0), MIN1CB = q8(min1c), NDB = q8(min0c - min1c);
+        const s16x2 SUMCB = q8(min0c + min1c);
         const uint32_t SXB = ((uint32_t)sx & 0xffffu) * 0x10001u;
         s16x2 NM[NP + 1];
         NM[NP] = splat2(0);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             // new_msg for both links: other = (mag == min0) ? min1 : min0  ==  min1 + (mag != min0) * (min0 - min1)
-            const s16x2 ne = pmin2(G[p] - MIN0B, splat2(1));
-            const s16x2 other = ne * NDB + MIN1CB;
+            // other = (mag == min0) ? min1c : min0c -- as min1c + (mag != min0) * (min0c - min1c), or (the same value: a magnitude is the row minimum, where
+            // min(mag, min1c) = min0c, or at least the second one, where it is min1c) as min0c + min1c - min(mag, min1c)
+            s16x2 other;
+            if constexpr (ldpc_other_sum<MAXDEG, IRREG>()) {
+                other = SUMCB - pmin2(G[p], MIN1CB);
+            } else {
+                const s16x2 ne = pmin2(G[p] - MIN0B, splat2(1));
+                other = ne * NDB + MIN1CB;
+            }
             const s16x2 neg = from_bits2(SXB ^ bits2(V[p])) >> 15;                   // 0 or -1
             s16x2 nm = pmin2(from_bits2(bits2(other) ^ bits2(neg)) - neg, q8(31));
             // new posterior: 16-bit saturating add = int8 saturation; >> 8 brings the bytes to bits 7:0 / 23:16 for the stores
