@@ -16,6 +16,9 @@
 #include "kernels.h"
 #include "ldpc_dev_common.h"
 
+#ifndef LDPC_WAVE_OTHER_SUM
+#define LDPC_WAVE_OTHER_SUM 1   // the other-minimum selection as a sum minus a minimum (A/B switch; see ldpc_kernel.hip)
+#endif
 namespace s2 {
 
 // The code tables are separate `const T* __restrict__` kernel parameters (not struct members): hipcc then proves them invariant and
@@ -196,14 +199,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void ld
                             WJOIN(0x141);            // row_half_mirror: the other quad of the 8-lane group
                             if (valid) {
                                 const int min0c = min(min0, 32), min1c = min(min1, 32);
+#if LDPC_WAVE_OTHER_SUM
+                                const s16x2 MIN1CB = q8(min1c), SUMCB = q8(min0c + min1c);
+#else
                                 const s16x2 MIN0B = q8(min0), MIN1CB = q8(min1c), NDB = q8(min0c - min1c);
+#endif
                                 const uint32_t SXB = ((uint32_t)sx & 0xffffu) * 0x10001u;
                                 s16x2 NM[2] = {splat2(0), splat2(0)};
 #pragma unroll
                                 for (int p = 0; p < NPW; ++p) {
                                     // other = (mag == min0) ? min1 : min0  ==  min1 + (mag != min0) * (min0 - min1), limited to 32 once per row
+#if LDPC_WAVE_OTHER_SUM
+                                    const s16x2 other = SUMCB - pmin2(G[p], MIN1CB);      // (the same value: a magnitude is the row minimum or at least the second one; ldpc_kernel.hip)
+#else
                                     const s16x2 ne = pmin2(G[p] - MIN0B, splat2(1));
                                     const s16x2 other = ne * NDB + MIN1CB;
+#endif
                                     const s16x2 neg = from_bits2(SXB ^ bits2(V[p])) >> 15;
                                     const s16x2 nm = pmin2(from_bits2(bits2(other) ^ bits2(neg)) - neg, q8(31));
                                     const uint32_t pn = bits2(sat_add2(V[p], nm)) >> 8;          // new posteriors at bits 7:0 and 23:16
