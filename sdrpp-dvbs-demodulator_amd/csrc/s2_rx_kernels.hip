@@ -137,9 +137,6 @@ __device__ __forceinline__ cf32 phasor_hw(float x) { return phasor(x); }
 #ifndef FD_STORE_ALL
 #define FD_STORE_ALL 0      // (the timing recovery of a 4096-carrier bank: 128 against 133 ms per call with the predicate; one carrier is paced by the FLL)
 #endif
-#ifndef FLL_STORE_ALL
-#define FLL_STORE_ALL 1
-#endif
 constexpr int G_TILE = 64;     // samples per stream per staging tile
 constexpr int G_SPW = 8;       // streams per wave (8 lanes each)
 constexpr int G_PITCH = G_TILE + 9;   // 7 history + tile, odd pitch spreads the rows over the LDS banks
