@@ -1293,6 +1293,9 @@ __device__ __attribute__((noinline)) float soft_phase_err_group(lds_cf32* __rest
 #ifndef FL_LPS_N
 #define FL_LPS_N 8
 #endif
+#ifndef S2_PLL_ASM
+#define S2_PLL_ASM 1     // the PLL's payload-tile loop of s2_frame_loops_kernel written out (A/B switch)
+#endif
 constexpr int FL_LPS = FL_LPS_N;
 constexpr int FL_SPW = 64 / FL_LPS;
 #ifndef FL_SMALL_BANK
@@ -1454,6 +1457,124 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const bool plain = base >= 90 && !(next_pilot >= 0 && next_pilot < base + m && next_pilot + 36 > base);
             if (plain) {
                 if (C.bits != 5) {
+#if S2_PLL_ASM
+                    // THE SHORT LOOP WRITTEN OUT (a small bank's frame loops are one wave per CU: its time is its instruction count + the table's round trip;
+                    // tools/ubench/lone_wave.hip).  Per symbol, as in the C++ form below: tmp = tl[k] * phasor(-phase) (dvbs2m::sincosf_det; two packed
+                    // multiplications + one packed addition), the table cell of tmp (lut_cell: y = fma(v, 256/1.5, 128), truncated and clamped; a symbol with
+                    // a y within 2.5e-4 of an integer in ANY lane group leaves the loop untouched and goes through the C++ form), error = lut[cell],
+                    // ot[k] = tmp, PhaseControlLoop::advance, one wrap into [-pi, pi].  ~60 instructions instead of ~85.
+                    int k = 0;
+                    const uint64_t lut_s = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uintptr_t)lut_err_v >> 32)) << 32) |
+                                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uintptr_t)lut_err_v);
+                    const float alpha_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pll.alpha)));
+                    const float beta_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pll.beta)));
+                    const float minf_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pll.minFreq)));
+                    while (k < m) {
+                        uint32_t ta = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) cf32*)tl + 8u * (uint32_t)k;
+                        uint32_t left = (uint32_t)__builtin_amdgcn_readfirstlane(m - k), why = 0;
+                        float tj, te;
+                        int tji;
+                        asm volatile(
+                            "s_mov_b32 s60, 0xbf22f983\n\t"          // -2/pi
+                            "s_mov_b32 s61, 0xbfc90fdb\n\t"          // -(pi/2 rounded to binary32)
+                            "s_mov_b32 s62, 0x333bbd2e\n\t"          // -(pi/2 - that)
+                            "s_mov_b32 s63, 0x80000000\n\t"
+                            "s_mov_b32 s64, 0x37ccf5ce\n\t"          // polynomial coefficients (cos, sin): degree 2 ...
+                            "s_mov_b32 s65, 0xb94ca1f9\n\t"
+                            "v_mov_b32 v116, 0xbab6061a\n\t"         // ... degree 1 ...
+                            "v_mov_b32 v117, 0x3c08839e\n\t"
+                            "s_mov_b32 s66, 0x3d2aaaa5\n\t"          // ... degree 0
+                            "s_mov_b32 s67, 0xbe2aaaa3\n\t"
+                            "s_mov_b32 s68, 0x432aaaab\n\t"          // 256 / 1.5
+                            "s_mov_b32 s69, 0x432aaaab\n\t"
+                            "s_mov_b32 s70, 0x3983126f\n\t"          // 2.5e-4f
+                            "s_mov_b32 s71, 0x40490fdb\n\t"          // pi
+                            "s_mov_b32 s72, 0xc0490fdb\n\t"          // -pi
+                            "s_mov_b32 s73, 0x40c90fdb\n\t"          // 2 pi
+                            "s_mov_b32 s74, 0xc0c90fdb\n\t"          // -2 pi
+                            "s_movk_i32 s75, 0xff\n\t"
+                            "v_mov_b32 v126, 0x43000000\n\t"         // 128.0f
+                            "v_mov_b32 v127, 0x43000000\n\t"
+                            "1:\n\t"
+                            "ds_read_b64 v[118:119], %[ta]\n\t"                                                       // tl[k]
+                            "v_mul_f32 %[j], s60, %[ph]\n\t"
+                            "v_rndne_f32 %[j], %[j]\n\t"
+                            "v_cvt_i32_f32 %[ji], %[j]\n\t"
+                            "v_fma_f32 v121, %[j], s61, -%[ph]\n\t"
+                            "v_fmac_f32 v121, s62, %[j]\n\t"
+                            "v_mul_f32 v120, v121, v121\n\t"                                                          // v[120:121] = (z, r)
+                            "v_pk_fma_f32 v[122:123], v[120:121], s[64:65], v[116:117] op_sel_hi:[0,1,1]\n\t"
+                            "v_pk_mul_f32 v[124:125], v[120:121], v[120:121] op_sel_hi:[1,0]\n\t"
+                            "v_pk_fma_f32 v[122:123], v[122:123], v[120:121], s[66:67] op_sel_hi:[1,0,1]\n\t"
+                            "v_fma_f32 v120, v120, -0.5, 1.0\n\t"
+                            "v_pk_fma_f32 v[120:121], v[124:125], v[122:123], v[120:121]\n\t"                          // (pc, ps)
+                            "v_and_b32 v122, 1, %[ji]\n\t"
+                            "v_lshlrev_b32 v123, 30, %[ji]\n\t"
+                            "v_sub_u32 v124, 0, v123\n\t"
+                            "v_cmp_eq_u32 vcc, 0, v122\n\t"
+                            "v_and_b32 v123, s63, v123\n\t"
+                            "v_and_b32 v124, s63, v124\n\t"
+                            "v_cndmask_b32 v125, v120, v121, vcc\n\t"
+                            "v_cndmask_b32 v120, v121, v120, vcc\n\t"
+                            "v_xor_b32 v121, v125, v123\n\t"
+                            "v_xor_b32 v120, v120, v124\n\t"                                                          // v[120:121] = (cos, sin)
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "v_pk_mul_f32 v[122:123], v[118:119], v[120:121] op_sel_hi:[0,1]\n\t"
+                            "v_pk_mul_f32 v[124:125], v[118:119], v[120:121] op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+                            "v_pk_add_f32 v[118:119], v[122:123], v[124:125] neg_lo:[0,1]\n\t"                         // tmp_val
+                            // the table cell
+                            "v_pk_fma_f32 v[122:123], v[118:119], s[68:69], v[126:127]\n\t"                            // y = fma(v, 256/1.5, 128)
+                            "v_rndne_f32 v124, v122\n\t"
+                            "v_rndne_f32 v125, v123\n\t"
+                            "v_pk_add_f32 v[124:125], v[122:123], v[124:125] neg_lo:[0,1] neg_hi:[0,1]\n\t"            // y - rint(y)
+                            "v_cvt_i32_f32 v122, v122\n\t"
+                            "v_cvt_i32_f32 v123, v123\n\t"
+                            "v_cmp_nge_f32 vcc, |v124|, s70\n\t"
+                            "s_cbranch_vccnz 3f\n\t"
+                            "v_cmp_nge_f32 vcc, |v125|, s70\n\t"
+                            "s_cbranch_vccnz 3f\n\t"
+                            "v_med3_i32 v122, v122, 0, s75\n\t"
+                            "v_med3_i32 v123, v123, 0, s75\n\t"
+                            "v_lshl_add_u32 v122, v122, 8, v123\n\t"
+                            "v_lshlrev_b32 v122, 2, v122\n\t"
+                            "global_load_dword %[e], v122, %[lut]\n\t"
+                            "ds_write_b64 %[ta], v[118:119] offset:%[oto]\n\t"                                         // ot[k] = tmp_val
+                            "v_add_u32 %[ta], 8, %[ta]\n\t"
+                            "s_waitcnt vmcnt(0)\n\t"
+                            "v_mul_f32 v124, %[beta], %[e]\n\t"
+                            "v_add_f32 %[fr], %[fr], v124\n\t"
+                            "v_med3_f32 %[fr], %[fr], %[minf], %[maxf]\n\t"
+                            "v_mul_f32 v124, %[alpha], %[e]\n\t"
+                            "v_add_f32 v124, %[fr], v124\n\t"
+                            "v_add_f32 %[ph], %[ph], v124\n\t"
+                            "v_add_f32 v124, s74, %[ph]\n\t"
+                            "v_cmp_lt_f32 vcc, s71, %[ph]\n\t"
+                            "v_cndmask_b32 %[ph], %[ph], v124, vcc\n\t"
+                            "v_add_f32 v124, s73, %[ph]\n\t"
+                            "v_cmp_gt_f32 vcc, s72, %[ph]\n\t"
+                            "v_cndmask_b32 %[ph], %[ph], v124, vcc\n\t"
+                            "s_sub_u32 %[left], %[left], 1\n\t"
+                            "s_cmp_lg_u32 %[left], 0\n\t"
+                            "s_cbranch_scc1 1b\n\t"
+                            "s_branch 4f\n\t"
+                            "3:\n\t"
+                            "s_mov_b32 %[why], 1\n\t"
+                            "4:\n\t"
+                            "s_waitcnt lgkmcnt(0)"
+                            : [ph] "+v"(pll.phase), [fr] "+v"(pll.freq), [ta] "+v"(ta), [left] "+s"(left), [why] "+s"(why), [j] "=&v"(tj), [ji] "=&v"(tji), [e] "=&v"(te)
+                            : [alpha] "s"(alpha_s), [beta] "s"(beta_s), [minf] "s"(minf_s), [maxf] "v"(pll.maxFreq), [lut] "s"(lut_s), [oto] "n"(FL_TILE * 8)
+                            : "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127",
+                              "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "vcc", "scc", "memory");
+                        k = m - (int)left;
+                        if (!why) break;
+                        const cf32 tmp_val = cmul(tl[k], phasor_fast(-pll.phase));           // (a cell index that needs the double form)
+                        const float error = as_global(lut_err_v)[lut_cell(tmp_val.re, tmp_val.im)];
+                        ot[k] = tmp_val;
+                        pll.advance(error);
+                        pll.wrap_pi_once();
+                        ++k;
+                    }
+#else
                     for (int k = 0; k < m; ++k) {
                         const cf32 tmp_val = cmul(tl[k], phasor_fast(-pll.phase));
                         const float error = as_global(lut_err_v)[lut_cell(tmp_val.re, tmp_val.im)];
@@ -1461,6 +1582,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                         pll.advance(error);
                         pll.wrap_pi_once();
                     }
+#endif
                 } else {
                     for (int k = 0; k < m; ++k) {
                         const cf32 tmp_val = cmul(tl[k], phasor_fast(-pll.phase));
