@@ -850,6 +850,9 @@ __global__ __launch_bounds__(128) void s2_gardner_bank_kernel(const S2StreamWork
 // come from the list one period later (helper wave 2: lane = output, the dot product again -- coalesced stores).
 // Workgroup = resolver (GC_CS lanes used) + wave 1 (stages the samples: FastAGC scaling + FreqShift rotation; arms 0..3 of the tables)
 // + wave 2 (arms 4..7; output values).  Periods, single steps at the ends of a slice and the state hand-over as in the other forms.
+#ifndef S2_GCAND_ASM
+#define S2_GCAND_ASM 1    // the resolver's symbol loop of s2_gardner_cand_kernel written out (A/B switch)
+#endif
 constexpr int GC_T = 16;                      // samples per stream and period
 constexpr int GC_CS = 4;                      // streams per workgroup (64 = GC_CS * GC_T: one staged sample per lane of wave 1)
 constexpr int GC_RING = 8 * GC_T;             // ring slots per stream: t-1 (its outputs' values), t (resolved), t+1 (tables), t+2 (staged), slack
@@ -1081,12 +1084,99 @@ __global__ __launch_bounds__(192) void s2_gardner_cand_kernel(const S2StreamWork
             const int ostart = outCount;
             if (spsctr == 1 && offset < lim) { note(arm_of()); finish0(); spsctr = 0; }     // (a slice that starts between the two outputs of a symbol)
             // (trip counts bounded by the list: a poisoned loop state -- NaN input -- can neither hang the GPU nor overrun it)
-            if (spsctr == 0)
-                for (int guard = 0; guard < (GC_LIST - 4) / 2; ++guard) {
+            if (spsctr == 0) {
+                int guard = 0;
+#if S2_GCAND_ASM
+                // THE SYMBOL LOOP WRITTEN OUT (the resolver is one wave per CU: its time is its instruction count + the table's LDS round trip + its taken
+                // branches; tools/ubench/lone_wave.hip): ~52 instructions and one taken branch per symbol instead of ~68 and three.  Every stream (lane) still
+                // inside the period takes symbol after symbol off its table -- arm -> three table fetches -> sign error -> advance -> floor; follower:
+                // arm -> advance by the loop frequency -> floor; two list words -- with the operations and roundings of symbol() below.  A stream that has
+                // finished the period drops out of EXEC; an arm off the table (ballot, as below) leaves the loop BEFORE that symbol is touched, and the
+                // C++ loop underneath finishes the period the general way with what is left of the trip budget.
+                {
+                    const uint32_t tab_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) f32x2*)tab0;
+                    const uint32_t list_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint16_t*)list0;
+                    const uint32_t tadr = tab_a + 8u * (uint32_t)tbi - 64u * (uint32_t)rowbase;          // + 64 offset + 8 (arm - 1 - a_lo): the entry of arm - 1
+                    uint32_t la = list_a + 2u * (uint32_t)(lbi + cnt);
+                    const int alo1 = a_lo + 1;
+                    uint32_t budget = (GC_LIST - 4) / 2;
+                    const int lim2 = lim - 2;                       // (per stream: a slice ends where the stream's samples end)
+                    const float alpha_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pcl.alpha)));
+                    const float beta_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pcl.beta)));
+                    const float minf_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pcl.minFreq)));
+                    asm volatile(
+                        "s_mov_b64 s[80:81], exec\n\t"
+                        "s_mov_b32 s82, 0x43000000\n\t"                                            // 128.0f
+                        "s_movk_i32 s83, 0x7f\n\t"
+                        "1:\n\t"
+                        "v_cmp_lt_i32 vcc, %[off], %[lim2]\n\t"                                    // this stream's next symbol starts inside the period
+                        "s_and_b64 exec, exec, vcc\n\t"
+                        "s_cbranch_execz 4f\n\t"
+                        "v_mul_f32 v100, s82, %[ph]\n\t"
+                        "v_cvt_i32_f32 v100, v100\n\t"
+                        "v_med3_i32 v100, v100, 0, s83\n\t"                                        // the arm
+                        "v_sub_u32 v101, v100, %[alo1]\n\t"
+                        "v_cmp_lt_u32 vcc, 5, v101\n\t"                                            // arm - 1 .. arm + 1 not all on the table (GC_WN - 3)
+                        "s_cbranch_vccnz 4f\n\t"
+                        "v_lshl_add_u32 v102, %[off], 6, %[tadr]\n\t"
+                        "v_lshl_add_u32 v102, v101, 3, v102\n\t"
+                        "ds_read2_b64 v[104:107], v102 offset1:2\n\t"                              // arm - 1, arm + 1
+                        "ds_read_b64 v[108:109], v102 offset:8\n\t"                                // arm
+                        "v_lshl_or_b32 v103, %[off], 7, v100\n\t"
+                        "ds_write_b16 %[la], v103\n\t"                                            // list: (offset, arm) of the on-symbol output
+                        "s_waitcnt lgkmcnt(1)\n\t"
+                        "v_pk_add_f32 v[104:105], v[106:107], v[104:105] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                        "v_pk_mul_f32 v[104:105], v[104:105], 0.5 op_sel_hi:[1,0]\n\t"            // d
+                        "v_cmp_lt_f32 vcc, 0, v108\n\t"
+                        "v_cndmask_b32_e64 v106, -v104, v104, vcc\n\t"
+                        "v_cmp_lt_f32 vcc, 0, v109\n\t"
+                        "v_cndmask_b32_e64 v107, -v105, v105, vcc\n\t"
+                        "v_add_f32 v106, v106, v107\n\t"
+                        "v_med3_f32 v106, -v106, -1.0, 1.0\n\t"                                   // error
+                        "v_mul_f32 v107, %[beta], v106\n\t"
+                        "v_add_f32 %[fr], %[fr], v107\n\t"
+                        "v_med3_f32 %[fr], %[fr], %[minf], %[maxf]\n\t"
+                        "v_mul_f32 v107, %[alpha], v106\n\t"
+                        "v_add_f32 v107, %[fr], v107\n\t"
+                        "v_add_f32 %[ph], %[ph], v107\n\t"
+                        "v_floor_f32 v107, %[ph]\n\t"
+                        "v_cvt_f32_i32 v106, %[off]\n\t"
+                        "v_sub_f32 %[ph], %[ph], v107\n\t"
+                        "v_add_f32 v106, v106, v107\n\t"
+                        "v_cvt_i32_f32 %[off], v106\n\t"
+                        // the follower: its list word, then the advance by the loop frequency alone
+                        "v_mul_f32 v100, s82, %[ph]\n\t"
+                        "v_cvt_i32_f32 v100, v100\n\t"
+                        "v_med3_i32 v100, v100, 0, s83\n\t"
+                        "v_lshl_or_b32 v103, %[off], 7, v100\n\t"
+                        "ds_write_b16 %[la], v103 offset:2\n\t"
+                        "v_add_u32 %[la], 4, %[la]\n\t"
+                        "v_med3_f32 %[fr], %[fr], %[minf], %[maxf]\n\t"
+                        "v_add_f32 %[ph], %[ph], %[fr]\n\t"
+                        "v_floor_f32 v107, %[ph]\n\t"
+                        "v_cvt_f32_i32 v106, %[off]\n\t"
+                        "v_sub_f32 %[ph], %[ph], v107\n\t"
+                        "v_add_f32 v106, v106, v107\n\t"
+                        "v_cvt_i32_f32 %[off], v106\n\t"
+                        "s_sub_u32 %[bud], %[bud], 1\n\t"
+                        "s_cmp_lg_u32 %[bud], 0\n\t"
+                        "s_cbranch_scc1 1b\n\t"
+                        "4:\n\t"
+                        "s_mov_b64 exec, s[80:81]\n\t"
+                        "s_waitcnt lgkmcnt(0)"
+                        : [ph] "+v"(pcl.phase), [fr] "+v"(pcl.freq), [off] "+v"(offset), [la] "+v"(la), [bud] "+s"(budget)
+                        : [tadr] "v"(tadr), [alo1] "v"(alo1), [lim2] "v"(lim2), [alpha] "s"(alpha_s), [beta] "s"(beta_s), [minf] "s"(minf_s), [maxf] "v"(pcl.maxFreq)
+                        : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "s80", "s81", "s82", "s83", "vcc", "scc", "memory");
+                    cnt = (int)((la - list_a) >> 1) - lbi;
+                    guard = (GC_LIST - 4) / 2 - (int)budget;
+                }
+#endif
+                for (; guard < (GC_LIST - 4) / 2; ++guard) {
                     const bool go = offset < lim - 2;
                     if (__builtin_amdgcn_ballot_w64(go) == 0) break;
                     if (go) symbol();
                 }
+            }
             if (last)
                 for (int guard = 0; guard < 8 && offset < n && cnt < GC_LIST; ++guard) {
                     const int phase = arm_of();
