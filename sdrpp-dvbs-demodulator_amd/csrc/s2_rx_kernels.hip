@@ -430,6 +430,12 @@ __global__ __launch_bounds__(64) void s2_gardner_kernel(const S2StreamWork* __re
 // slice ends in exactly the state the reference's loop has after the same samples.
 // Samples live in a ring of 4 periods per stream and component (slot = buffer index mod ring; the first 8 slots are mirrored behind the
 // ring so that an 8-sample window never wraps): period t is resolved while t+1 is being staged and the values of t-1 are produced.
+#ifndef G2_EXP
+#define G2_EXP 0          // development switches for TIMING experiments (results wrong): 1 no output values, 2 no staging
+#endif
+#ifndef S2_G2_ASM
+#define S2_G2_ASM 1       // the resolver's symbol loop of s2_gardner2_kernel written out (A/B switch)
+#endif
 #ifndef G2_TILE_N
 #define G2_TILE_N 16
 #endif
@@ -523,12 +529,12 @@ __global__ __launch_bounds__(128) void s2_gardner2_kernel(const S2StreamWork* __
         if (ntiles > 1) issue(1);
         lds_only_barrier();
         for (int t = 0; t < ntiles; ++t) {
-            if (t + 1 < ntiles) commit(t + 1);
+            if (!(G2_EXP & 2) && t + 1 < ntiles) commit(t + 1);
             if (t + 2 < ntiles) issue(t + 2);
-            if (t >= 1) produce(t - 1);
+            if (!(G2_EXP & 1) && t >= 1) produce(t - 1);
             lds_only_barrier();
         }
-        if (ntiles > 0) produce(ntiles - 1);
+        if (!(G2_EXP & 1) && ntiles > 0) produce(ntiles - 1);
         return;
     }
 
@@ -587,6 +593,134 @@ __global__ __launch_bounds__(128) void s2_gardner2_kernel(const S2StreamWork* __
         const int ostart = outCount;
         // (the trip counts are bounded by the list: a poisoned loop state -- NaN input -- can neither hang the GPU nor overrun it)
         if (spsctr == 1 && offset < lim) { off_step(); spsctr = 0; }     // (only where a slice starts between the two outputs of a symbol)
+#if S2_G2_ASM
+        // THE SYMBOL LOOP WRITTEN OUT (the 4096-stream bank is 512 of these resolver waves: fewer than the GPU has SIMDs -- a wave's time is its instruction count,
+        // its LDS round trips and its taken branches; tools/ubench/lone_wave.hip): ~90 instructions and one taken branch per symbol where the compiler's form of
+        // err_step() + off_step() has ~140 and four.  Same operations, same order, same roundings: the arm, this lane's 8-tap dot product (products and sums
+        // rounded one by one, from 0), the neighbours' arms by DPP, the sign error of the re and im halves, their negated sum handed to the stream's 8 lanes
+        // (quad_perm, row_shr:4), clamp, PhaseControlLoop::advance, floor; the follower's list word and its advance by the loop frequency alone (advance(0): freq
+        // + beta * 0 and freq + alpha * 0 are freq itself for finite gains and a loop frequency that is not -0, as in the candidate-table form).  A stream whose
+        // condition no longer holds drops out of EXEC; a phase at the ends of the bank (one-sided derivative) leaves the loop BEFORE the symbol is touched and the
+        // C++ loop underneath takes over.
+        {
+            static_assert(G2_RING == 64, "the written-out loop masks the slot with 63");
+            const uint32_t rowa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)row;
+            const uint32_t banka = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)bank;
+            const uint32_t lista = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)lp;
+            uint32_t lpa = lista + 4u * (uint32_t)cnt;
+            const uint32_t lpa_lim = lista + 4u * (uint32_t)(G2_LIST - 2);
+            const int lim3 = lim - 3;
+            const int d_arm = arm == 0 ? -1 : (arm == 2 ? 1 : 0);
+            const uint64_t inmask = __builtin_amdgcn_ballot_w64(spsctr == 0);
+            const float alpha_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pcl.alpha)));
+            const float beta_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pcl.beta)));
+            const float minf_s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pcl.minFreq)));
+            const float maxf_v = pcl.maxFreq;
+            asm volatile(
+                "s_mov_b64 s[80:81], exec\n\t"
+                "s_and_b64 exec, exec, %[inmask]\n\t"
+                "s_mov_b32 s82, 0x43000000\n\t"                                            // 128.0f
+                "s_movk_i32 s83, 0x7f\n\t"
+                "s_movk_i32 s84, 0x7d\n\t"                                                 // 125
+                "1:\n\t"
+                "v_cmp_lt_i32 vcc, %[off], %[lim3]\n\t"
+                "v_cmp_lt_u32 s[86:87], %[lpa], %[lpalim]\n\t"
+                "s_and_b64 vcc, vcc, s[86:87]\n\t"
+                "s_and_b64 exec, exec, vcc\n\t"
+                "s_cbranch_execz 4f\n\t"
+                "v_mul_f32 v100, s82, %[ph]\n\t"
+                "v_floor_f32 v100, v100\n\t"
+                "v_cvt_i32_f32 v100, v100\n\t"
+                "v_med3_i32 v100, v100, 0, s83\n\t"                                        // phase
+                "v_add_u32 v101, -1, v100\n\t"
+                "v_cmp_lt_u32 vcc, s84, v101\n\t"                                          // phase 0 or 127: the one-sided derivative, the general way
+                "s_cbranch_vccnz 4f\n\t"
+                "v_add_u32 v101, v100, %[darm]\n\t"
+                "v_med3_i32 v101, v101, 0, s83\n\t"                                        // this lane's arm
+                "v_and_b32 v102, 63, %[off]\n\t"                                           // slot
+                "v_lshl_add_u32 v103, v102, 2, %[rowa]\n\t"
+                "v_lshl_add_u32 v101, v101, 5, %[banka]\n\t"
+                "ds_read_b128 v[104:107], v101\n\t"
+                "ds_read_b128 v[108:111], v101 offset:16\n\t"
+                "ds_read2_b32 v[112:113], v103 offset1:1\n\t"
+                "ds_read2_b32 v[114:115], v103 offset0:2 offset1:3\n\t"
+                "ds_read2_b32 v[116:117], v103 offset0:4 offset1:5\n\t"
+                "ds_read2_b32 v[118:119], v103 offset0:6 offset1:7\n\t"
+                "v_lshl_or_b32 v102, v102, 7, v100\n\t"
+                "ds_write_b32 %[lpa], v102\n\t"                                            // list: (slot, phase) of the on-symbol output
+                "s_waitcnt lgkmcnt(4)\n\t"
+                "v_mul_f32 v120, v112, v104\n\t"
+                "v_add_f32 v120, 0, v120\n\t"
+                "v_mul_f32 v121, v113, v105\n\t"
+                "v_add_f32 v120, v120, v121\n\t"
+                "s_waitcnt lgkmcnt(3)\n\t"
+                "v_mul_f32 v121, v114, v106\n\t"
+                "v_add_f32 v120, v120, v121\n\t"
+                "v_mul_f32 v121, v115, v107\n\t"
+                "v_add_f32 v120, v120, v121\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mul_f32 v121, v116, v108\n\t"
+                "v_add_f32 v120, v120, v121\n\t"
+                "v_mul_f32 v121, v117, v109\n\t"
+                "v_add_f32 v120, v120, v121\n\t"
+                "s_waitcnt lgkmcnt(1)\n\t"
+                "v_mul_f32 v121, v118, v110\n\t"
+                "v_add_f32 v120, v120, v121\n\t"
+                "v_mul_f32 v121, v119, v111\n\t"
+                "v_add_f32 v120, v120, v121\n\t"                                           // acc = this lane's interpolant (arm x re / im)
+                "v_cvt_f32_i32 v122, %[off]\n\t"
+                "s_nop 0\n\t"
+                "v_mov_b32_dpp v121, v120 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          // xm: the phase - 1 arm
+                "v_sub_f32_dpp v121, v120, v121 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"    // xp - xm
+                "v_mul_f32 v121, 0.5, v121\n\t"
+                "v_cmp_lt_f32 vcc, 0, v120\n\t"
+                "v_cndmask_b32_e64 v121, -v121, v121, vcc\n\t"                             // (xo > 0 ? 1 : -1) * d, valid in the lanes of arm 1
+                "s_nop 1\n\t"
+                "v_add_f32_dpp v121, v121, v121 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   // re half + im half
+                "s_nop 1\n\t"
+                "v_mov_b32_dpp v123, v121 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "s_nop 1\n\t"
+                "v_mov_b32_dpp v121, v123 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_cndmask_b32_e64 v121, v121, v123, %[lo4]\n\t"
+                "v_med3_f32 v121, -v121, -1.0, 1.0\n\t"                                    // error = clamp(-(e_re + e_im))
+                "v_mul_f32 v123, %[beta], v121\n\t"
+                "v_add_f32 %[fr], %[fr], v123\n\t"
+                "v_med3_f32 %[fr], %[fr], %[minf], %[maxf]\n\t"
+                "v_mul_f32 v123, %[alpha], v121\n\t"
+                "v_add_f32 v123, %[fr], v123\n\t"
+                "v_add_f32 %[ph], %[ph], v123\n\t"
+                "v_floor_f32 v123, %[ph]\n\t"
+                "v_sub_f32 %[ph], %[ph], v123\n\t"
+                "v_add_f32 v122, v122, v123\n\t"
+                "v_cvt_i32_f32 %[off], v122\n\t"
+                // the follower
+                "v_mul_f32 v100, s82, %[ph]\n\t"
+                "v_floor_f32 v100, v100\n\t"
+                "v_cvt_i32_f32 v100, v100\n\t"
+                "v_med3_i32 v100, v100, 0, s83\n\t"
+                "v_and_b32 v102, 63, %[off]\n\t"
+                "v_lshl_or_b32 v102, v102, 7, v100\n\t"
+                "ds_write_b32 %[lpa], v102 offset:4\n\t"
+                "v_add_u32 %[lpa], 8, %[lpa]\n\t"
+                "v_med3_f32 %[fr], %[fr], %[minf], %[maxf]\n\t"
+                "v_add_f32 %[ph], %[ph], %[fr]\n\t"
+                "v_floor_f32 v123, %[ph]\n\t"
+                "v_cvt_f32_i32 v122, %[off]\n\t"
+                "v_sub_f32 %[ph], %[ph], v123\n\t"
+                "v_add_f32 v122, v122, v123\n\t"
+                "v_cvt_i32_f32 %[off], v122\n\t"
+                "s_branch 1b\n\t"
+                "4:\n\t"
+                "s_mov_b64 exec, s[80:81]\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : [ph] "+v"(pcl.phase), [fr] "+v"(pcl.freq), [off] "+v"(offset), [lpa] "+v"(lpa)
+                : [lim3] "v"(lim3), [lpalim] "v"(lpa_lim), [darm] "v"(d_arm), [rowa] "v"(rowa), [banka] "v"(banka), [inmask] "s"(inmask),
+                  [alpha] "s"(alpha_s), [beta] "s"(beta_s), [minf] "s"(minf_s), [maxf] "v"(maxf_v), [lo4] "s"(0x0F0F0F0F0F0F0F0Full)
+                : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117",
+                  "v118", "v119", "v120", "v121", "v122", "v123", "s80", "s81", "s82", "s83", "s84", "s86", "s87", "vcc", "scc", "memory");
+            cnt = (int)((lpa - lista) >> 2);
+        }
+#endif
         while (__any(spsctr == 0 && offset < lim - 3 && cnt < G2_LIST - 2)) {
             if (spsctr == 0 && offset < lim - 3 && cnt < G2_LIST - 2) { err_step(); off_step(); }
         }
