@@ -572,7 +572,9 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             post.spec = 1;
             post.loops_launches = std::min(S2_FE_MAX_SLICES, std::max(launches, (max_count / 2) / std::max(sym_per_launch, 1)));
         }
-        { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st, &post, ctx->stage_post_stream == 2 || ((!pipelined || n <= S2_SMALL_BANK) && ctx->stage_post_stream))); }   // (a small bank is a set of latency chains in the throughput mode too: its post stages on the AGC's stream made one stream's 4-frame call 39.9 ms instead of 25)
+        { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st, &post, ctx->stage_post_stream == 2 || ((!pipelined || n <= S2_SMALL_BANK || (ctx->g_prio_auto && ctx->g_prio_duty >= 4)) && ctx->stage_post_stream))); }   // (a small bank is a set of latency chains in the throughput mode too: its post stages on the AGC's stream made one stream's 4-frame call 39.9 ms instead of 25;
+        //  a big bank whose FRONT END the balancer has found critical -- priority share 4 or more: the plugin's mode, QPSK -- likewise: AGC + RRC + walk + frame loops on one
+        //  stream were 127 ms of launches per 140 ms step; beside a decoder that is the critical path the shared stream stays: headline 347 vs 361 ms per step)
         slot_stats.resize(nslot);
         HIP_TRY(hipMemcpyAsync(slot_stats.data(), ws_slot.p, sizeof(S2FrameStats) * nslot, hipMemcpyDeviceToHost, st));
     } else {
