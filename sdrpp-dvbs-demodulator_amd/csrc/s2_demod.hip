@@ -448,7 +448,10 @@ static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work,
                                   bool own_post_stream = false, int* nsub_out = nullptr) {
     // (measured: beside the decoder of the previous call 4, alone 8; a small bank is a latency chain in either mode: the shorter pipeline fill wins)
     // (banks up to 256 streams: 16 -- one 8PSK stream 32.4 -> 31.6 ms per 4-frame call, 64 x 1 frame 16.1 -> 15.7)
-    int nsub = ctx->fe_slices > 0 ? ctx->fe_slices : (n <= 8 ? 32 : (n <= 256 ? 16 : (ctx->pipeline_fec ? 4 : 8)));    // (a handful of streams: 32 -- 28.7 -> 27.9 ms per 4-frame call)
+    // (a big bank in the throughput mode whose FRONT END the balancer has found critical -- priority share 4 or more -- is sliced like a synchronous call: plugin's mode 139.9 -> 137.4 ms,
+    //  config 2 187 -> 182; 6 or 12 slices cut the frames of a step unevenly: 162 ms)
+    const bool fe_critical = ctx->pipeline_fec && ctx->g_prio_auto && ctx->g_prio_duty >= 4;
+    int nsub = ctx->fe_slices > 0 ? ctx->fe_slices : (n <= 8 ? 32 : (n <= 256 ? 16 : (ctx->pipeline_fec && !fe_critical ? 4 : 8)));    // (a handful of streams: 32 -- 28.7 -> 27.9 ms per 4-frame call)
     if (nsub > S2_FE_MAX_SLICES) nsub = S2_FE_MAX_SLICES;
     if (nsub_out) *nsub_out = nsub > 1 ? nsub : 1;
     S2LoopCoefs cc = co;
