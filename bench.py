@@ -797,8 +797,8 @@ def main():
         if world == 1 and not args.no_secondary:
             sec = []
             try:
-                # the small synchronous calls first: a small bank is a set of latency chains on three or four HIP streams, and a process that has created many
-                # streams by then (the DVB-S banks, the mixed batches' side streams) has them share hardware queues (1 x 4: 28.5 instead of 25.2 ms per call)
+                # the small synchronous calls first: a small bank is a set of latency chains of a handful of waves, and late in this run -- after minutes of the
+                # full-load configurations -- the same calls take ~10 % longer (1 x 4: 28.5 instead of 25.2 ms; 24 hardware queues change nothing: clocks?)
                 sec.append(small_batch(eng, pkg, dev, 64, 1))
                 sec.append(small_batch(eng, pkg, dev, 1, 4))
                 sec.append(secondary_s2(eng, pkg, dev, 'headline workload in the PLUGIN\'s mode: 8PSK 3/4 normal FECFRAME, Es/N0 %.0f dB, max_ldpc_trials 16 with early exit '
