@@ -45,6 +45,8 @@ static int stage_enter(dvbs2gpu_ctx* ctx, hipStream_t st) {
 void free_ldpc_code(LdpcDeviceCode& D) {
     (void)hipFree(D.d_layers); (void)hipFree(D.d_ents); (void)hipFree(D.d_rows); (void)hipFree(D.d_atab);
     (void)hipFree(D.d_wave_lanec); (void)hipFree(D.d_wave_steps); (void)hipFree(D.d_wave_layer_end);
+    (void)hipFree(D.d_split_layers); (void)hipFree(D.d_split_rows); (void)hipFree(D.d_split_atab);
+    D.d_split_layers = nullptr; D.d_split_rows = D.d_split_atab = nullptr;
     D.d_layers = nullptr; D.d_ents = D.d_rows = D.d_atab = D.d_wave_lanec = D.d_wave_layer_end = nullptr; D.d_wave_steps = nullptr;
 }
 int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
@@ -62,6 +64,20 @@ int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
         if ((rc = upload(P.rows, &D.d_rows))) return fail(rc);
         if (!P.atab.empty() && (rc = upload(P.atab, &D.d_atab))) return fail(rc);
         D.blocks_per_cu = ldpc_blocks_per_cu(P.max_deg, D.irregular, P.N);
+        if (P.N > 16200 && ldpc_split_supported(P.max_deg)) {
+            // normal frames of the codes the half-row decoder takes (ldpc_split_plan.h); DVBS2GPU_LDPC_SPLIT=0 keeps the lane-per-row decoder
+            // (development aid / the parity tests run both)
+            const LdpcSplitPlan SP = build_ldpc_split_plan(P);
+            const char* e = getenv("DVBS2GPU_LDPC_SPLIT");
+            if (SP.ok && !(e && atoi(e) == 0)) {
+                if ((rc = upload(SP.layers, &D.d_split_layers))) return fail(rc);
+                if ((rc = upload(SP.rows, &D.d_split_rows))) return fail(rc);
+                if ((rc = upload(SP.atab, &D.d_split_atab))) return fail(rc);
+                D.split_rec_dwords = SP.rec_dwords;
+                D.split_blocks_per_cu = ldpc_split_blocks_per_cu(P.max_deg, P.N);
+                D.use_split = true;
+            }
+        }
         if (P.N <= 16200) {
             // short frames also get the wave-per-frame plan; which decoder serves the code: ldpc_wave_default() (measured per code),
             // DVBS2GPU_LDPC_WAVE=0|1 in the environment forces one (development aid / the parity tests run both)
@@ -205,6 +221,27 @@ static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, 
         }
         HIP_TRY(ldpc_wave_decode_launch(*C, d_llr, nframes, max_trials, force, d_hard, hard_stride, d_post, d_trials, (uint8_t*)W.msg.p, grid, st,
                                         (unsigned int*)((char*)W.msg.p + need), (uint32_t*)((char*)W.msg.p + need + 256)));
+        return 0;
+    }
+    if (C->use_split) {
+        // half-row decoder: one frame per workgroup, frames beyond the first wave of workgroups claimed through the work counter
+        int grid = ctx->num_cus * C->split_blocks_per_cu;
+        if (grid > nframes) grid = nframes;
+        size_t need = (size_t)grid * ldpc_split_msg_bytes_per_block(*C);
+        need = (need + 255) & ~(size_t)255;
+        const size_t sgn_bytes = (size_t)grid * ldpc_sign_ws_bytes_per_slot();
+        if ((rc = W.msg.ensure(need + 256 + sgn_bytes))) return rc;
+        if (!d_trials) {
+            if ((rc = W.misc.ensure((size_t)nframes * 2 * sizeof(int32_t)))) return rc;
+            d_trials = (int32_t*)W.misc.p;
+        }
+        if (!d_hard) {
+            if ((rc = W.hard.ensure((size_t)nframes * (f.K / 8)))) return rc;
+            d_hard = (uint8_t*)W.hard.p; hard_stride = f.K / 8;
+        }
+        if (nframes > 0)
+            HIP_TRY(ldpc_split_decode_launch(*C, d_llr, nframes, max_trials, force, d_hard, hard_stride, d_post, d_trials, (uint32_t*)W.msg.p, grid, st,
+                                             (unsigned int*)((char*)W.msg.p + need), (uint32_t*)((char*)W.msg.p + need + 256)));
         return 0;
     }
     // workgroups hold 2 frame slots, or 1 for batches smaller than the device (ldpc_kernel.hip)

@@ -11,6 +11,7 @@
 #include "s2_params.h"
 #include "ldpc_plan.h"
 #include "ldpc_wave_plan.h"
+#include "ldpc_split_plan.h"
 #include "kernels.h"
 #include "s2_rx.h"
 

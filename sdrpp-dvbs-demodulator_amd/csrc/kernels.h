@@ -22,6 +22,12 @@ struct LdpcDeviceCode {
     uint16_t* d_wave_steps = nullptr;
     uint32_t* d_wave_layer_end = nullptr;
     bool use_wave = false;          // which of the two decoders a batch of this code goes to
+    // half-row form (ldpc_split_plan.h / ldpc_split_kernel.hip): two lanes per row, one frame per workgroup
+    LdpcLayerDesc* d_split_layers = nullptr;
+    uint32_t* d_split_rows = nullptr;
+    uint32_t* d_split_atab = nullptr;
+    int split_rec_dwords = 0, split_blocks_per_cu = 1;
+    bool use_split = false;
 };
 
 int ldpc_blocks_per_cu(int max_deg, int irregular, int N);
@@ -30,6 +36,11 @@ hipError_t ldpc_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nf
                               uint8_t* hard, int hard_stride, int8_t* post, int32_t* trials, uint32_t* msg_ws, int grid,
                               int fpb, hipStream_t stream, unsigned int* work_ctr, uint32_t* sgn_ws);
 size_t ldpc_sign_ws_bytes_per_slot();
+bool ldpc_split_supported(int max_deg);
+int ldpc_split_blocks_per_cu(int max_deg, int N);
+size_t ldpc_split_msg_bytes_per_block(const LdpcDeviceCode& C);
+hipError_t ldpc_split_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nframes, int max_trials, int force, uint8_t* hard, int hard_stride,
+                                    int8_t* post, int32_t* trials, uint32_t* msg_ws, int grid, hipStream_t stream, unsigned int* work_ctr, uint32_t* sgn_ws);
 size_t ldpc_wave_msg_bytes_per_frame(const LdpcDeviceCode& C);
 size_t ldpc_wave_lds_bytes(const LdpcDeviceCode& C);
 hipError_t ldpc_wave_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nframes, int max_trials, int force, uint8_t* hard, int hard_stride,
