@@ -71,6 +71,7 @@ PROTOTYPES = {
     'dvbs2gpu_ldpc_plan_info': (_i, [_vp, _i, _i, C.POINTER(C.c_int32)]),
     'dvbs2gpu_ldpc_wave_plan_dump': (_i, [_i, _i, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
     'dvbs2gpu_ldpc_addr_table_dump': (_i, [_i, _i, _vp, C.POINTER(C.c_int32)]),
+    'dvbs2gpu_ldpc_split_plan_dump': (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
     'dvbs2gpu_ldpc_decode_batch': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'dvbs2gpu_bch_decode_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
     'dvbs2gpu_bb_descramble_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
@@ -178,6 +179,27 @@ def fec_info(rate, shortframes=False):
     return info.as_dict()
 
 
+def ldpc_split_plan(rate, shortframes=False, pack_max_depth=-1):
+    """Host-only: the half-row LDPC decoder's plan (csrc/ldpc_split_plan.h) as numpy arrays; None for codes that decoder does not take."""
+    import numpy as np
+    lib = load_library()
+    cnt = (C.c_int32 * 6)()
+    rc = lib.dvbs2gpu_ldpc_split_plan_dump(int(rate), int(bool(shortframes)), int(pack_max_depth), None, None, None, None, cnt)
+    if rc != 0:
+        raise Dvbs2GpuError(rc, lib.dvbs2gpu_last_error().decode())
+    npl, npw, hs, rec_total, nwords, rec_dw = list(cnt)
+    if npl == 0:
+        return None
+    layers = np.zeros((npl, 4), np.uint32); table = np.zeros(nwords, np.uint32)
+    row_of = np.zeros((npl, 384), np.int32); layer_of = np.zeros(npl, np.int32)
+    rc = lib.dvbs2gpu_ldpc_split_plan_dump(int(rate), int(bool(shortframes)), int(pack_max_depth), layers.ctypes.data, table.ctypes.data, row_of.ctypes.data, layer_of.ctypes.data, cnt)
+    if rc != 0:
+        raise Dvbs2GpuError(rc, lib.dvbs2gpu_last_error().decode())
+    return {'npl': npl, 'npw': npw, 'hs': hs, 'rec_total': rec_total, 'rec_dwords': rec_dw, 'kind': (layers[:, 0] & 0xff).astype(int), 'nw': ((layers[:, 0] >> 8) & 0xff).astype(int),
+            'nc': ((layers[:, 0] >> 16) & 15).astype(int), 'noprev': ((layers[:, 0] >> 20) & 1).astype(int), 'aux': layers[:, 1].astype(int), 'rec_off': layers[:, 2].astype(int),
+            'ent_off': layers[:, 3].astype(int), 'table': table.reshape(npl, 768, npw), 'row_of': row_of, 'layer': layer_of}
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -220,6 +242,9 @@ class Engine:
         self._check(self.lib.dvbs2gpu_ldpc_plan_info(self.h, int(rate), int(bool(shortframes)), out))
         keys = ['layers', 'max_deg', 'rec_dwords', 'sum_depth', 'blocks_per_cu', 'cus', 'edges', 'conflict_layers']
         return dict(zip(keys, list(out)))
+
+    def ldpc_split_plan(self, rate, shortframes=False):
+        return ldpc_split_plan(rate, shortframes)
 
     # ---- FEC stages --------------------------------------------------------------------------------
     def ldpc_decode(self, llr, rate, shortframes=False, max_trials=25, force=False, want_post=False):

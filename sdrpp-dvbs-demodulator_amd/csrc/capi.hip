@@ -45,8 +45,8 @@ static int stage_enter(dvbs2gpu_ctx* ctx, hipStream_t st) {
 void free_ldpc_code(LdpcDeviceCode& D) {
     (void)hipFree(D.d_layers); (void)hipFree(D.d_ents); (void)hipFree(D.d_rows); (void)hipFree(D.d_atab);
     (void)hipFree(D.d_wave_lanec); (void)hipFree(D.d_wave_steps); (void)hipFree(D.d_wave_layer_end);
-    (void)hipFree(D.d_split_layers); (void)hipFree(D.d_split_rows); (void)hipFree(D.d_split_atab);
-    D.d_split_layers = nullptr; D.d_split_rows = D.d_split_atab = nullptr;
+    (void)hipFree(D.d_split_layers); (void)hipFree(D.d_split_atab);
+    D.d_split_layers = nullptr; D.d_split_atab = nullptr;
     D.d_layers = nullptr; D.d_ents = D.d_rows = D.d_atab = D.d_wave_lanec = D.d_wave_layer_end = nullptr; D.d_wave_steps = nullptr;
 }
 int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
@@ -71,9 +71,8 @@ int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
             const char* e = getenv("DVBS2GPU_LDPC_SPLIT");
             if (SP.ok && !(e && atoi(e) == 0)) {
                 if ((rc = upload(SP.layers, &D.d_split_layers))) return fail(rc);
-                if ((rc = upload(SP.rows, &D.d_split_rows))) return fail(rc);
                 if ((rc = upload(SP.atab, &D.d_split_atab))) return fail(rc);
-                D.split_rec_dwords = SP.rec_dwords;
+                D.split_npl = (int)SP.layers.size(); D.split_rec_total = SP.rec_total;
                 D.split_blocks_per_cu = ldpc_split_blocks_per_cu(P.max_deg, P.N);
                 D.use_split = true;
             }
@@ -464,6 +463,21 @@ int dvbs2gpu_ldpc_addr_table_dump(int rate, int shortframes, uint32_t* table, in
     const int npi = (P.max_deg + 1) / 2;
     counts2[0] = (int32_t)P.atab.size(); counts2[1] = npi <= 1 ? 1 : npi <= 2 ? 2 : npi <= 4 ? 4 : 8;
     if (table && !P.atab.empty()) memcpy(table, P.atab.data(), P.atab.size() * sizeof(uint32_t));
+    return 0;
+}
+
+int dvbs2gpu_ldpc_split_plan_dump(int rate, int shortframes, int pack_max_depth, uint32_t* layers4, uint32_t* table, int32_t* row_of, int32_t* layer_of, int32_t* counts6) {
+    FecParams f;
+    if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
+    if (!counts6) return DVBS2GPU_ERR_ARG;
+    const LdpcPlan P = build_ldpc_plan(f.code_index);
+    const LdpcSplitPlan S = pack_max_depth < 0 ? build_ldpc_split_plan(P) : build_ldpc_split_plan(P, pack_max_depth);
+    counts6[0] = S.ok ? (int32_t)S.layers.size() : 0; counts6[1] = S.npw; counts6[2] = S.hs; counts6[3] = S.rec_total; counts6[4] = (int32_t)S.atab.size(); counts6[5] = S.rec_dwords;
+    if (!S.ok) return 0;
+    if (layers4) memcpy(layers4, S.layers.data(), S.layers.size() * sizeof(LdpcSplitLayer));
+    if (table) memcpy(table, S.atab.data(), S.atab.size() * sizeof(uint32_t));
+    if (row_of) for (size_t i = 0; i < S.row_of.size(); ++i) row_of[i] = S.row_of[i];
+    if (layer_of) for (size_t i = 0; i < S.layer_of.size(); ++i) layer_of[i] = S.layer_of[i];
     return 0;
 }
 

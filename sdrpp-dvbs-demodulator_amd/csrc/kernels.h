@@ -23,10 +23,9 @@ struct LdpcDeviceCode {
     uint32_t* d_wave_layer_end = nullptr;
     bool use_wave = false;          // which of the two decoders a batch of this code goes to
     // half-row form (ldpc_split_plan.h / ldpc_split_kernel.hip): two lanes per row, one frame per workgroup
-    LdpcLayerDesc* d_split_layers = nullptr;
-    uint32_t* d_split_rows = nullptr;
+    struct LdpcSplitLayer* d_split_layers = nullptr;
     uint32_t* d_split_atab = nullptr;
-    int split_rec_dwords = 0, split_blocks_per_cu = 1;
+    int split_npl = 0, split_rec_total = 0, split_blocks_per_cu = 1;
     bool use_split = false;
 };
 

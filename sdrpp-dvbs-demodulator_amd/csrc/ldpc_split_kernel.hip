@@ -3,17 +3,19 @@
 // Replaces BBFrameLDPC::decode (reference src/demod/dvbs2/codings/bbframe_ldpc.cpp:123-139) and the library under it
 // (xdsopl-ldpc-pabr/layered_decoder.hh:23-133, algorithms.hh:206-277), bit-exact, like ldpc_kernel.hip, whose schedule (ldpc_plan.h) and
 // arithmetic (packed int16 "Q8" with the int8 saturation rules) it shares.  What differs is the mapping onto the machine:
-//   * ldpc_kernel.hip gives a lane a whole row (up to 30 links) and a workgroup two frames: 12 waves per compute unit, each with a
-//     ~300-instruction stream per layer between two barriers -- the decoder waits half of its resident cycles (profiles/r04_ldpc_pmc.txt).
-//   * here thread t of a 768-thread workgroup holds half h = t & 1 of row j = t >> 1 (ldpc_split_plan.h: HS = (max_deg + 2) / 2 link slots
-//     per half, shared links and the chain / walk / level machinery in half 0, the parity bits in half 1).  The halves join their
-//     (min0, min1, sign) with one DPP quad_perm step -- min and xor are associative, algorithms.hh:242-255 stays exact.  One frame per
-//     workgroup = 64.8 KB of posteriors in LDS, TWO workgroups per compute unit = 24 waves, each with half the stream; the two frames of a
-//     compute unit are no longer in lockstep, so one frame's serial sections (chain walks, deep layers) run beside the other's wide ones.
-//   * no address arithmetic in a layer: every slot's LDS byte offset, parity bits included, comes from the per-thread address table,
-//     fetched a layer ahead together with the 8-byte message record and the row word.
+//   * ldpc_kernel.hip gives a lane a whole row and a workgroup two frames in lockstep: 12 waves per compute unit.
+//   * here thread t of a 768-thread workgroup holds one half of a row (ldpc_split_plan.h), the halves join their (min0, min1, sign) with one
+//     DPP quad_perm step.  One frame per workgroup = 64.8 KB of posteriors in LDS, TWO workgroups per compute unit = 24 waves; the two
+//     frames of a compute unit are not in lockstep, so one frame's narrow phases run beside the other's wide ones.
+//   * what a decoder of this shape is bound by is its VALU CYCLE count (profiles/r05_valu_rates.txt): packed 16-bit, VOP3-only, SDWA and DPP
+//     instructions issue at half the rate of plain 32-bit VOP2 ones, and with 24 waves per compute unit the layer time follows the sum.  So:
+//     no address arithmetic (every slot's LDS byte offset comes from a per-thread table, unpacked by one and / shift each), no exec masking
+//     in the row update (idle lanes work on scratch bytes), the odd slot of a row half is a constant neutral link (posterior +127, message
+//     0: magnitude 126 never displaces a real minimum, sign +), plain 32-bit operations wherever both halves of a register hold the same
+//     value, and ONE code path for every layer without a deep dependency chain: a layer with shared bits is run level by level as packed
+//     conflict-free row updates (ldpc_split_plan.h).
 // Roofline: algorithmic bytes per frame = iters*4*edges + N + K/8 against HBM 8 TB/s is the NOMINAL figure: the state is
-// on-chip (LDS + Infinity Cache), what bounds the kernel is the latency of a layer's barrier-separated phases.
+// on-chip (LDS + Infinity Cache); DESIGN.md section 5 prices the kernel against its VALU cycles as well.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "ldpc_lane_common.h"
@@ -22,7 +24,7 @@
 namespace s2 {
 
 #ifndef LDPC_SPLIT_EXP
-#define LDPC_SPLIT_EXP 0          // development switch for TIMING experiments (results wrong): 1 = every layer runs as a conflict-free one, 2 = no table / record traffic in the layer loop, 4 = no layer barrier, 8 = no output phase
+#define LDPC_SPLIT_EXP 0          // development switch for TIMING experiments (results wrong): 2 = no table / record traffic in the layer loop, 4 = no layer barrier, 8 = no output phase
 #endif
 #ifndef LDPC_SPLIT_WPE
 #define LDPC_SPLIT_WPE 6          // waves per SIMD the register allocation aims at (6 = 80 VGPRs: two workgroups per compute unit; 8 = 64: room for a 128-register front-end wave beside them)
@@ -31,10 +33,14 @@ namespace s2 {
 template <int MAXDEG>
 struct SplitShape {
     static constexpr int NL = MAXDEG + 2, HS = NL / 2, NP = (HS + 1) / 2;
-    static constexpr int NPW = NP <= 1 ? 1 : NP <= 2 ? 2 : NP <= 4 ? 4 : 8;
+    static constexpr int NPW = (HS / 2 + 1) <= 1 ? 1 : (HS / 2 + 1) <= 2 ? 2 : (HS / 2 + 1) <= 4 ? 4 : 8;
     static constexpr int REC = HS <= 4 ? 1 : HS <= 8 ? 2 : 4;
+    static constexpr int RI_WORD = HS / 2, RI_SHIFT = (HS & 1) ? 16 : 0;     // where the row word sits (ldpc_split_plan.h)
     static_assert((NL & 1) == 0, "the half-row decoder takes rows with an even number of links");
 };
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void lds_read_lo_i8(uint32_t a_lo, uint32_t& r_lo) {
     if (LDPC_EXP & 4) { r_lo = a_lo & 0xffu; return; }
@@ -50,13 +56,25 @@ __device__ __forceinline__ void lds_ready_n(int outstanding, uint32_t& r_lo, uin
 }
 #undef LDS_READY_CASE
 
-template <int NPW>
-__device__ __forceinline__ void words_load(uint32_t (&w)[NPW], const uint32_t* __restrict__ p) {
-    if constexpr (NPW == 1) { w[0] = p[0]; }
-    else if constexpr (NPW == 2) { const uint2 v = *reinterpret_cast<const uint2*>(p); w[0] = v.x; w[1] = v.y; }
+// Table / record traffic of the layer loop goes through buffer resources: (uniform base in the descriptor) + (uniform pseudo-layer offset in a scalar
+// register) + (the thread's 32-bit byte offset) -- left to itself the compiler builds a 64-bit address per lane and load (v_lshl_add_u64, a half-rate
+// instruction, and twice the address registers).  The loads stay visible to the compiler, which keeps vmcnt.
+template <int NW>
+__device__ __forceinline__ void bload(uint32_t (&w)[NW], __amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+    if constexpr (NW == 1) { w[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0); }
+    else if constexpr (NW == 2) { const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0); w[0] = v.x; w[1] = v.y; }
     else {
 #pragma unroll
-        for (int i = 0; i < NPW; i += 4) { const uint4 v = *reinterpret_cast<const uint4*>(p + i); w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w; }
+        for (int i = 0; i < NW; i += 4) { const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 4 * i, soff, 0); w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w; }
+    }
+}
+template <int NW>
+__device__ __forceinline__ void bstore(const uint32_t (&w)[NW], __amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+    if constexpr (NW == 1) { __builtin_amdgcn_raw_buffer_store_b32(w[0], rs, voff, soff, 0); }
+    else if constexpr (NW == 2) { const u32x2 v = {w[0], w[1]}; __builtin_amdgcn_raw_buffer_store_b64(v, rs, voff, soff, 0); }
+    else {
+#pragma unroll
+        for (int i = 0; i < NW; i += 4) { const u32x4 v = {w[i], w[i + 1], w[i + 2], w[i + 3]}; __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff + 4 * i, soff, 0); }
     }
 }
 
@@ -64,37 +82,31 @@ __device__ __forceinline__ void words_load(uint32_t (&w)[NPW], const uint32_t* _
 constexpr int DPP_SWAP_HALVES = 0xB1;    // quad_perm [1,0,3,2]: the other half of the row
 constexpr int DPP_FROM_HALF0 = 0xA0;     // quad_perm [0,0,2,2]: half 0's value in both lanes of a row
 
-// One sweep step for one layer.  KIND 0: no shared bits in the layer; 1: one shared pair resolved by the chain walk; 3: levels (at most 4 shared
-// links); 6: quad walk (ldpc_kernel.hip / ldpc_plan.h describe the kinds; the middle sections below are theirs, run by the half-0 lanes).
-template <int MAXDEG, int KIND>
-__device__ __forceinline__ void split_layer(const uint32_t lbase, int8_t* __restrict__ post, const uint32_t* __restrict__ ents, const uint32_t (&AD)[SplitShape<MAXDEG>::NPW],
-                                            const LdpcLayerDesc L, const uint32_t rowword, const int layer, const int t, const bool active,
-                                            const uint32_t (&rec_in)[SplitShape<MAXDEG>::REC], uint32_t (&rec_out)[SplitShape<MAXDEG>::REC],
-                                            uint32_t* __restrict__ cw, uint8_t* __restrict__ cres, const uint32_t* __restrict__ walk) {
+__device__ __forceinline__ s16x2 swap2(s16x2 a) { return __builtin_shufflevector(a, a, 1, 0); }     // (folds into the op_sel of the packed instruction that uses it)
+
+// ---- the row update, in two parts so that a chain layer can put its walk between them.  Everything is per thread = per row half.
+template <int MAXDEG>
+struct RowState {
+    using S = SplitShape<MAXDEG>;
+    s16x2 V[S::NP], G[S::NP];        // extrinsic inputs and their offset magnitudes, two slots per register ("Q8": the int8 value in the high byte of each half)
+    uint32_t addr[S::HS];            // LDS byte addresses of the slots' posteriors
+};
+
+// input phase: posteriors in, extrinsic values, the row's two smallest magnitudes and sign -- M0 / M1 / SXs come back with BOTH halves of the
+// word holding the whole row's value (a word with equal halves orders like its 16-bit value under 32-bit signed compares; SXs: sign in bits 15 and 31).
+// LATE: the first LATE slots, where flagged in `late`, are left out of the totals (layers with shared links: 2 for a chain layer, 4 otherwise)
+template <int MAXDEG, int LATE>
+__device__ __forceinline__ void row_input(RowState<MAXDEG>& R, const uint32_t (&AD)[SplitShape<MAXDEG>::NPW], const uint32_t (&rec_in)[SplitShape<MAXDEG>::REC],
+                                          const uint32_t late, const bool noprev_layer, const uint32_t noprev_t, const int t, int& M0, int& M1, int& SXs) {
     using S = SplitShape<MAXDEG>;
     constexpr int HS = S::HS, NP = S::NP, REC = S::REC;
-    constexpr bool CONF = KIND != 0;
-    constexpr int MAXC0 = KIND == 1 ? 2 : 4;
-    constexpr int MAXC = MAXC0 < HS ? MAXC0 : HS;
-    const int j = t >> 1;
-    const bool half1 = (t & 1) != 0;
-    const bool act0 = active && !half1;
-    s16x2 V[NP], G[NP];
-    uint32_t addr[HS];
-    const int nc = CONF ? (int)(L.depth_nc >> 16) : 0;
-    const uint32_t level = rowword & 0xffu, late = (rowword >> 8) & 0xfffu, early = rowword >> 20;
-    const bool noprev = (t == 1) && (layer == 0);         // row 0 of layer 0 has no previous parity bit (slot HS-1 of half 1)
-#define LINK_IN(k) ((int)V[(k) >> 1][(k) & 1] >> 8)
-#define LINK_MG(k) ((int)G[(k) >> 1][(k) & 1] >> 8)
-#define LINK_SET(k, v, m) do { V[(k) >> 1][(k) & 1] = (short)((v) << 8); G[(k) >> 1][(k) & 1] = (short)((m) << 8); } while (0)
-    // ---- input phase: every lane (idle lanes read the scratch byte and never store)
     uint32_t XR[NP], XH[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const uint32_t a_lo = lbase + (AD[p] & 0xffffu), a_hi = lbase + (AD[p] >> 16);
-        addr[2 * p] = a_lo;
-        if (2 * p + 1 < HS) { addr[2 * p + 1] = a_hi; lds_read_pair_i8(a_lo, a_hi, XR[p], XH[p]); }
-        else { lds_read_lo_i8(a_lo, XR[p]); XH[p] = 0; }
+        const uint32_t a_lo = AD[p] & 0xffffu, a_hi = AD[p] >> 16;          // (the posteriors start at LDS offset 0)
+        R.addr[2 * p] = a_lo;
+        if (2 * p + 1 < HS) { R.addr[2 * p + 1] = a_hi; lds_read_pair_i8(a_lo, a_hi, XR[p], XH[p]); }
+        else { lds_read_lo_i8(a_lo, XR[p]); XH[p] = 0x007f0000u; }          // the odd slot: a neutral link, posterior +127
     }
     s16x2 MIN0 = splat2(Q8_NONE), MIN1 = splat2(Q8_NONE);
     uint32_t SX = 0;
@@ -109,309 +121,348 @@ __device__ __forceinline__ void split_layer(const uint32_t lbase, int8_t* __rest
         const s16x2 av = pmax2(v, sat_sub2(splat2(0), v));
         // |v| - 1 clamped at 0 (ldpc_kernel.hip: no upper clamp needed, only the high byte is ever consumed)
         s16x2 g = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, av), (u16x2){256, 256}));
+        if (2 * p + 2 > HS - 1 && 2 * p <= HS - 1 && noprev_layer) {
+            // row 0 of layer 0 has no previous parity bit (the last slot of half 1): that thread's slot becomes the neutral link
+            const bool me = (uint32_t)t == noprev_t;
+            constexpr int hh = (HS - 1) & 1;
+            v[hh] = me ? (short)(127 << 8) : v[hh];
+            g[hh] = me ? (short)(126 << 8) : g[hh];
+        }
+        if constexpr (LATE > 0) {
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int k = 2 * p + hh;
-            if (k >= HS) { v[hh] = 0; g[hh] = (short)Q8_NONE; }
-            if (k == HS - 1 && noprev) { v[hh] = 0; g[hh] = (short)Q8_NONE; }
-            if constexpr (CONF) {
-                if (k < MAXC && k < nc && ((late >> k) & 1)) { v[hh] = 0; g[hh] = (short)Q8_NONE; }   // joins the totals at its level (half 1: no late links)
+            for (int hh = 0; hh < 2; ++hh) {
+                const int k = 2 * p + hh;
+                if (k < LATE && ((late >> k) & 1)) { v[hh] = (short)(127 << 8); g[hh] = (short)(126 << 8); }   // joins the totals in the middle section; until then: neutral
             }
         }
-        V[p] = v; G[p] = g;
+        R.V[p] = v; R.G[p] = g;
         if (p == 0) { MIN0 = g; }
         else if (p == 1) { MIN1 = pmax2(MIN0, g); MIN0 = pmin2(MIN0, g); }
         else { MIN1 = pmin2(MIN1, pmax2(MIN0, g)); MIN0 = pmin2(MIN0, g); }
         SX ^= bits2(v);
     }
-    // even / odd slots joined: both halves of every word then hold the lane's value ...
+    // even / odd slots joined (op_sel swaps the halves inside the packed instructions) ...
+    const int m0 = (int)bits2(pmin2(MIN0, swap2(MIN0)));
+    const int m1 = (int)bits2(pmin2(pmax2(MIN0, swap2(MIN0)), pmin2(MIN1, swap2(MIN1))));
+    const int sx = (int)(SX ^ __builtin_amdgcn_alignbit(SX, SX, 16));
+    // ... and the two halves of the row
+    const int o0 = QUAD_DPP(m0, DPP_SWAP_HALVES), o1 = QUAD_DPP(m1, DPP_SWAP_HALVES), os = QUAD_DPP(sx, DPP_SWAP_HALVES);
+    M1 = min(max(m0, o0), min(m1, o1));
+    M0 = min(m0, o0);
+    SXs = sx ^ os;
+}
+
+// output phase: new messages and posteriors of every slot from the row totals (both halves of M0 / M1 equal, sign of the row in bits 15 and 31 of SXs)
+// SKIP: the first SKIP slots, where flagged in `early`, were written ahead (layers with shared links)
+template <int MAXDEG, int SKIP>
+__device__ __forceinline__ void row_output(const RowState<MAXDEG>& R, const int M0, const int M1, const int SXs, const uint32_t early, uint32_t (&rec_out)[SplitShape<MAXDEG>::REC]) {
+    using S = SplitShape<MAXDEG>;
+    constexpr int HS = S::HS, NP = S::NP, REC = S::REC;
+    // the selected magnitude is limited to 32 once per row (the per-link clamp to [-32, 31] then only needs its upper side); plain 32-bit operations on words with equal halves
+    const uint32_t C32 = 0x20002000u;
+    const uint32_t MIN1C = (uint32_t)min(M1, (int)C32);
+    const uint32_t SUMC = (uint32_t)min(M0, (int)C32) + MIN1C;
+    const uint32_t SXB = (uint32_t)SXs;
+    s16x2 NM[NP + 1];
+    NM[NP] = splat2(0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        // other = (mag == min0) ? min1c : min0c, as min0c + min1c - min(mag, min1c): a magnitude is the row minimum, where min(mag, min1c) = min0c, or at
+        // least the second one, where it is min1c (algorithms.hh:250-256).  No borrow between the halves: a 32-bit subtraction
+        const s16x2 other = from_bits2(SUMC - bits2(pmin2(R.G[p], from_bits2(MIN1C))));
+        const s16x2 neg = from_bits2(SXB ^ bits2(R.V[p])) >> 15;                   // 0 or -1
+        s16x2 nm = pmin2(from_bits2(bits2(other) ^ bits2(neg)) - neg, q8(31));
+        // new posterior: 16-bit saturating add = int8 saturation; >> 8 brings the bytes to bits 7:0 / 23:16 for the stores
+        const uint32_t pn = bits2(sat_add2(R.V[p], nm)) >> 8;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int k = 2 * p + hh;
+            if (k >= HS) { nm[hh] = 0; continue; }
+            if (k < SKIP) {
+                if (!((early >> k) & 1)) { if (hh == 0) lds_write_lo_i8(R.addr[k], pn); else lds_write_hi_i8(R.addr[k], pn); }
+            } else {
+                if (hh == 0) lds_write_lo_i8(R.addr[k], pn); else lds_write_hi_i8(R.addr[k], pn);
+            }
+        }
+        NM[p] = nm;
+    }
+#pragma unroll
+    for (int w = 0; w < REC; ++w) {
+        if (2 * w < NP) rec_out[w] = __builtin_amdgcn_perm(bits2(NM[2 * w + 1 <= NP ? 2 * w + 1 : NP]), bits2(NM[2 * w]), 0x07050301u);
+        else rec_out[w] = 0;
+    }
+}
+
+#if defined(LDPC_PROF) && LDPC_PROF == 3
+// waypoints inside a chain layer (threads 0 and 384 of workgroup 0): prof[300 + 16 * (thread != 0) + i] = cycles since the previous waypoint
+#define SPLIT_MARK(i) do { if (KIND == 1 && g_prof_dev && blockIdx.x == 0 && (t == 0 || t == 384)) { const unsigned long long t_now = clock64(); g_prof_dev[300 + (t ? 16 : 0) + (i)] += t_now - t_mark; t_mark = t_now; } } while (0)
+#define SPLIT_MARK_DECL unsigned long long t_mark = clock64()
+__device__ unsigned long long* g_prof_dev = nullptr;
+#else
+#define SPLIT_MARK(i) do { } while (0)
+#define SPLIT_MARK_DECL do { } while (0)
+#endif
+#define LINK_IN(k) ((int)R.V[(k) >> 1][(k) & 1] >> 8)
+#define LINK_MG(k) ((int)R.G[(k) >> 1][(k) & 1] >> 8)
+#define LINK_SET(k, v, m) do { R.V[(k) >> 1][(k) & 1] = (short)((v) << 8); R.G[(k) >> 1][(k) & 1] = (short)((m) << 8); } while (0)
+
+// A layer with shared links (slots 0..nc-1 of half 0), rows in lane order (row j = t >> 1): ldpc_kernel.hip's three forms.  KIND 1: one shared pair (slots 0 = "E",
+// 1 = "L"), the dependency chains walked by a few lanes; 6: quad walk (at most 4 shared links, deep and narrow level structure: one wave walks the rows of levels
+// >= 2, four lanes per row); 3: a barrier per level (at most 4 shared links).  The row word -- level | late << 8 | early << 12, zero for half 1 and idle lanes, so
+// every condition below is false there -- rides in the table.
+#ifndef LDPC_SPLIT_CONFLICT_INLINE
+#define LDPC_SPLIT_CONFLICT_INLINE __forceinline__
+#endif
+template <int MAXDEG, int KIND>
+__device__ LDPC_SPLIT_CONFLICT_INLINE void conflict_layer(const uint32_t (&AD)[SplitShape<MAXDEG>::NPW], const uint32_t (&rec_in)[SplitShape<MAXDEG>::REC], uint32_t (&rec_out)[SplitShape<MAXDEG>::REC],
+                                               const LdpcSplitLayer L, const uint32_t* __restrict__ ents, const uint32_t* __restrict__ walk, const int t,
+                                               int8_t* __restrict__ post, uint32_t* __restrict__ cw, uint8_t* __restrict__ cres) {
+    using S = SplitShape<MAXDEG>;
+    constexpr int REC = S::REC;
+    constexpr int MAXC0 = KIND == 1 ? 2 : 4;
+    constexpr int MAXC = MAXC0 < S::HS ? MAXC0 : S::HS;
+    const uint32_t rw = (AD[S::RI_WORD] >> S::RI_SHIFT) & 0xffffu;
+    const uint32_t level = rw & 0xffu, late = (rw >> 8) & 15u, early = rw >> 12;
+    const int nc = (int)((L.kind_nw >> 16) & 15u);
+    const int j = t >> 1;
+    RowState<MAXDEG> R;
     int M0, M1, SXs;
-    {
-        const s16x2 R0 = from_bits2(__builtin_amdgcn_alignbit(bits2(MIN0), bits2(MIN0), 16));
-        const s16x2 R1 = from_bits2(__builtin_amdgcn_alignbit(bits2(MIN1), bits2(MIN1), 16));
-        M0 = (int)bits2(pmin2(MIN0, R0));
-        M1 = (int)bits2(pmin2(pmax2(MIN0, R0), pmin2(MIN1, R1)));
-        SXs = (int)(SX ^ __builtin_amdgcn_alignbit(SX, SX, 16));
-    }
-    // ... and the two halves of the row: a word with equal halves orders like its 16-bit value under the 32-bit signed compare
-    {
-        const int o0 = QUAD_DPP(M0, DPP_SWAP_HALVES), o1 = QUAD_DPP(M1, DPP_SWAP_HALVES), os = QUAD_DPP(SXs, DPP_SWAP_HALVES);
-        M1 = min(max(M0, o0), min(M1, o1));
-        M0 = min(M0, o0);
-        SXs ^= os;
-    }
-    s16x2 MIN1CB, SUMCB;
-    uint32_t SXB;
-    if constexpr (!CONF) {
-        MIN1CB = pmin2(from_bits2((uint32_t)M1), q8(32));
-        SUMCB = pmin2(from_bits2((uint32_t)M0), q8(32)) + MIN1CB;
-        SXB = (uint32_t)SXs;
-    } else {
-        int min0 = M0 >> 24, min1 = M1 >> 24, sx = SXs;                 // (sx: the sign of the row's product sits in bit 31)
-        const int chain_d = (int)(L.deg >> 16);
-        if constexpr (KIND == 1) {
-            // ---- chain walk (ldpc_kernel.hip: single shared pair, links 0 = E, 1 = L)
-            if (act0) {
-                if (level == 1u) {
+    SPLIT_MARK_DECL;
+    row_input<MAXDEG, MAXC>(R, AD, rec_in, late, (L.kind_nw >> 20) & 1u, 1u, t, M0, M1, SXs);
+    int min0 = M0 >> 24, min1 = M1 >> 24, sx = SXs;                 // (sx: the sign of the row's product sits in bit 31)
+    SPLIT_MARK(0);
+    if constexpr (KIND == 1) {
+        const int chain_d = (int)L.aux;
+        // rows of level 1 publish their early links; every row whose L link is late leaves the walk's record (ldpc_lane_common.h: chain_record)
+        if (level == 1u) {
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        if ((early >> k) & 1) {
-                            int nm = new_msg(LINK_IN(k), LINK_MG(k), min0, min1, sx);
-                            LDS_I8(addr[k]) = (int8_t)clamp8(LINK_IN(k) + nm);
-                        }
-                    }
-                }
-                if ((late >> 1) & 1) {
-                    const int qE = (late & 1u) ? 255 : ((LINK_MG(0) == min0) ? min1 : min0);
-                    const ChainRec r = chain_record(rec_byte<REC>(rec_in, 1), qE, LINK_IN(0), (sx ^ LINK_IN(0)) >> 31);
-                    reinterpret_cast<uint2*>(cw)[j] = make_uint2(r.lim, r.se);
+            for (int k = 0; k < 2; ++k) {
+                if ((early >> k) & 1) {
+                    int nm = new_msg(LINK_IN(k), LINK_MG(k), min0, min1, sx);
+                    LDS_I8(R.addr[k]) = (int8_t)clamp8(LINK_IN(k) + nm);
                 }
             }
-            lds_barrier();
-            if (t < chain_d) {
-                // lane c walks rows c + k*d (ldpc_kernel.hip)
-                __builtin_amdgcn_s_setprio(3);
-                const uint32_t eL = ents[1];
-                const int T = 359 / chain_d;
-                int x = post[link_addr(eL, t + chain_d)];
-                const uint2* c = reinterpret_cast<const uint2*>(cw) + t + chain_d;
-                uint8_t* pr = reinterpret_cast<uint8_t*>(cres) + t + chain_d;
-                uint2 ra = c[0], rb = c[chain_d];
+        }
+        if ((late >> 1) & 1) {
+            // (a late slot's V / G hold the neutral link until the join below: the totals above exclude it; the record of a row whose E link is late is never stepped through)
+            const int qE = (late & 1u) ? 255 : ((LINK_MG(0) == min0) ? min1 : min0);
+            const ChainRec r = chain_record(rec_byte<REC>(rec_in, 1), qE, LINK_IN(0), (sx ^ LINK_IN(0)) >> 31);
+            reinterpret_cast<uint2*>(cw)[j] = make_uint2(r.lim, r.se);
+        }
+        SPLIT_MARK(1);
+        lds_barrier();
+        SPLIT_MARK(2);
+        if (t < chain_d) {
+            // lane c walks rows c + k*d (ldpc_kernel.hip)
+            __builtin_amdgcn_s_setprio(3);
+            const uint32_t eL = ents[1];
+            const int T = 359 / chain_d;
+            int x = post[link_addr(eL, t + chain_d)];
+            const uint2* c = reinterpret_cast<const uint2*>(cw) + t + chain_d;
+            uint8_t* pr = reinterpret_cast<uint8_t*>(cres) + t + chain_d;
+            uint2 ra = c[0], rb = c[chain_d];
+            c += 2 * chain_d;
+            int k = 1;
+            for (; k + 2 <= T; k += 2) {
+                const uint2 na = c[0];
+                pr[0] = (uint8_t)x;
+                x = chain_step(x, ra.x, ra.y);
+                ra = na;
+                const uint2 nb = c[chain_d];
+                pr[chain_d] = (uint8_t)x;
+                x = chain_step(x, rb.x, rb.y);
+                rb = nb;
                 c += 2 * chain_d;
-                int k = 1;
-                for (; k + 2 <= T; k += 2) {
-                    const uint2 na = c[0];
-                    pr[0] = (uint8_t)x;
-                    x = chain_step(x, ra.x, ra.y);
-                    ra = na;
-                    const uint2 nb = c[chain_d];
-                    pr[chain_d] = (uint8_t)x;
-                    x = chain_step(x, rb.x, rb.y);
-                    rb = nb;
-                    c += 2 * chain_d;
-                    pr += 2 * chain_d;
-                }
-                if (k < T) {
-                    pr[0] = (uint8_t)x;
-                    x = chain_step(x, ra.x, ra.y);
-                    pr += chain_d;
-                }
-                if (t + T * chain_d < 360) pr[0] = (uint8_t)x;
-                __builtin_amdgcn_s_setprio(0);
+                pr += 2 * chain_d;
             }
-            lds_barrier();
-            if (act0) {
-                const int xL = (int)(int8_t)cres[j], xE = (int)LDS_I8(addr[0]);
-                if ((late >> 1) & 1) {
-                    int v = clamp8(xL - rec_byte<REC>(rec_in, 1));
-                    int m = mag_of(v);
-                    LINK_SET(1, v, m);
-                    ROW_ACCUM(v, m);
-                }
-                if (late & 1u) {
-                    int v = clamp8(xE - rec_byte<REC>(rec_in, 0));
-                    int m = mag_of(v);
-                    LINK_SET(0, v, m);
-                    ROW_ACCUM(v, m);
-                }
+            if (k < T) {
+                pr[0] = (uint8_t)x;
+                x = chain_step(x, ra.x, ra.y);
+                pr += chain_d;
             }
-        } else if constexpr (KIND == 6) {
-            // ---- quad walk (ldpc_kernel.hip, ldpc_plan.h): four lanes of wave 0 per row of levels >= 2
-            (void)chain_d;
-            constexpr int CWD = 2;
-            const uint32_t whd = walk[0];
-            const int wk_steps = (int)(whd & 0xffffu);
-            if (act0) {
-                if (level == 1u) {
+            if (t + T * chain_d < 360) pr[0] = (uint8_t)x;
+            __builtin_amdgcn_s_setprio(0);
+        }
+        SPLIT_MARK(3);
+        lds_barrier();
+        SPLIT_MARK(4);
+        if (late) {
+            const int xL = (int)(int8_t)cres[j], xE = (int)LDS_I8(R.addr[0]);
+            if ((late >> 1) & 1) {
+                int v = clamp8(xL - rec_byte<REC>(rec_in, 1));
+                int m = mag_of(v);
+                LINK_SET(1, v, m);
+                ROW_ACCUM(v, m);
+            }
+            if (late & 1u) {
+                int v = clamp8(xE - rec_byte<REC>(rec_in, 0));
+                int m = mag_of(v);
+                LINK_SET(0, v, m);
+                ROW_ACCUM(v, m);
+            }
+        }
+    } else if constexpr (KIND == 6) {
+        // ---- quad walk (ldpc_kernel.hip, ldpc_plan.h).  Rows of level 1 publish their early links; every other row of half 0 leaves a hand-off record in cw[]: {min0,
+        // min1, sign of the totals so far, late mask, early mask} and one byte per shared link (its old message if the link is late, else its input value)
+        constexpr int CWD = 2;
+        const uint32_t whd = walk[0];
+        const int wk_steps = (int)(whd & 0xffffu);
+        if (level == 1u) {
 #pragma unroll
-                    for (int k = 0; k < MAXC; ++k) {
-                        if (k < nc && ((early >> k) & 1)) {
-                            int nm = new_msg(LINK_IN(k), LINK_MG(k), min0, min1, sx);
-                            LDS_I8(addr[k]) = (int8_t)clamp8(LINK_IN(k) + nm);
-                        }
-                    }
-                } else {
-                    uint32_t lb = 0;
-#pragma unroll
-                    for (int k = 0; k < MAXC; ++k) {
-                        const int b = (k < nc && ((late >> k) & 1)) ? rec_byte<REC>(rec_in, k) : LINK_IN(k);
-                        lb |= ((uint32_t)b & 0xffu) << (8 * k);
-                    }
-                    const uint32_t hd = (uint32_t)min(min0, 127) | ((uint32_t)min(min1, 127) << 7) | (((uint32_t)sx >> 31) << 14) | ((late & 0xffu) << 15) | ((early & 0xffu) << 23);
-                    cw[CWD * j] = hd;
-                    cw[CWD * j + 1] = lb;
+            for (int k = 0; k < MAXC; ++k) {
+                if ((early >> k) & 1) {
+                    int nm = new_msg(LINK_IN(k), LINK_MG(k), min0, min1, sx);
+                    LDS_I8(R.addr[k]) = (int8_t)clamp8(LINK_IN(k) + nm);
                 }
             }
-            lds_barrier();
-            if (t < 64) {
-                __builtin_amdgcn_s_setprio(3);
-                const int k = t & 3, qd = t >> 2;
-                const uint32_t ek = ents[k < nc ? k : 0];
-                const int spk = (int)(ek & 0xffffu);
-                const uint32_t basek = lbase + 360u * (ek >> 16);
-                const uint32_t scratch = lds_offset(reinterpret_cast<const int8_t*>(cres)) + (uint32_t)t;
-                const uint32_t cwb = lds_offset(reinterpret_cast<const int8_t*>(cw));
-                const int nsteps = wk_steps;
-                const uint32_t* __restrict__ list = walk + 1 + qd;
-                auto step = [&](const uint32_t e) {
-                    const bool valid = e != 0xffffffffu && k < nc;
-                    const int row = valid ? (int)e : 0;
-                    const uint32_t ra = cwb + (uint32_t)(4 * CWD) * (uint32_t)row;
-                    const uint2 r = reinterpret_cast<const uint2*>(cw)[row];
-                    const uint32_t hd = r.x;
-                    const int b = (int)__builtin_amdgcn_sbfe((int)r.y, 8 * k, 8);
-                    int tt = row + spk;
-                    tt = (int)min((uint32_t)tt, (uint32_t)(tt - 360));
-                    const uint32_t a = basek + (uint32_t)tt;
-                    const int x = (int)LDS_I8(a);
-                    const bool lt = valid && ((hd >> (15 + k)) & 1u), er = valid && ((hd >> (23 + k)) & 1u);
-                    const int v = lt ? clamp8(x - b) : b;
-                    const int g = mag_of(v);
-                    int m0 = lt ? g : 255, m1 = 255, sg = lt ? v : 0;
+        } else if (level != 0u) {
+            uint32_t lb = 0;
+#pragma unroll
+            for (int k = 0; k < MAXC; ++k) {
+                const int b = ((late >> k) & 1) ? rec_byte<REC>(rec_in, k) : LINK_IN(k);
+                lb |= ((uint32_t)b & 0xffu) << (8 * k);
+            }
+            const uint32_t hd = (uint32_t)min(min0, 127) | ((uint32_t)min(min1, 127) << 7) | (((uint32_t)sx >> 31) << 14) | ((late & 0xffu) << 15) | ((early & 0xffu) << 23);
+            cw[CWD * j] = hd;
+            cw[CWD * j + 1] = lb;
+        }
+        lds_barrier();
+        if (t < 64) {
+            __builtin_amdgcn_s_setprio(3);
+            const int k = t & 3, qd = t >> 2;
+            const uint32_t ek = ents[k < nc ? k : 0];
+            const int spk = (int)(ek & 0xffffu);
+            const uint32_t basek = 360u * (ek >> 16);                       // (the posteriors start at LDS offset 0)
+            const uint32_t scratch = lds_offset(reinterpret_cast<const int8_t*>(cres)) + (uint32_t)t;
+            const uint32_t cwb = lds_offset(reinterpret_cast<const int8_t*>(cw));
+            const uint32_t* __restrict__ list = walk + 1 + qd;
+            auto step = [&](const uint32_t e) {
+                const bool valid = e != 0xffffffffu && k < nc;
+                const int row = valid ? (int)e : 0;
+                const uint32_t ra = cwb + (uint32_t)(4 * CWD) * (uint32_t)row;
+                const uint2 r = reinterpret_cast<const uint2*>(cw)[row];
+                const uint32_t hd = r.x;
+                const int b = (int)__builtin_amdgcn_sbfe((int)r.y, 8 * k, 8);
+                int tt = row + spk;
+                tt = (int)min((uint32_t)tt, (uint32_t)(tt - 360));
+                const uint32_t a = basek + (uint32_t)tt;
+                const int x = (int)LDS_I8(a);
+                const bool lt = valid && ((hd >> (15 + k)) & 1u), er = valid && ((hd >> (23 + k)) & 1u);
+                const int v = lt ? clamp8(x - b) : b;
+                const int g = mag_of(v);
+                int m0 = lt ? g : 255, m1 = 255, sg = lt ? v : 0;
 #define JOIN(ctrl) do { const int o0 = QUAD_DPP(m0, ctrl), o1 = QUAD_DPP(m1, ctrl); m1 = min(max(m0, o0), min(m1, o1)); m0 = min(m0, o0); sg ^= QUAD_DPP(sg, ctrl); } while (0)
-                    JOIN(0xB1);                                                              // quad_perm [1,0,3,2]
-                    JOIN(0x4E);                                                              // quad_perm [2,3,0,1]
+                JOIN(0xB1);                                                              // quad_perm [1,0,3,2]
+                JOIN(0x4E);                                                              // quad_perm [2,3,0,1]
 #undef JOIN
-                    const int q0 = (int)(hd & 0x7fu), q1 = (int)((hd >> 7) & 0x7fu);
-                    const int t1 = min(max(m0, q0), min(m1, q1)), t0 = min(m0, q0);
-                    const int ss = sg ^ (int)(hd << 17);                                     // bit 31 = sign of the row's totals
-                    const int nm = new_msg(v, g, t0, t1, ss);
-                    LDS_I8(er ? a : scratch) = (int8_t)clamp8(v + nm);
-                    LDS_I8(valid ? ra + 4u + (uint32_t)k : scratch) = (int8_t)v;
-                };
+                const int q0 = (int)(hd & 0x7fu), q1 = (int)((hd >> 7) & 0x7fu);
+                const int t1 = min(max(m0, q0), min(m1, q1)), t0 = min(m0, q0);
+                const int ss = sg ^ (int)(hd << 17);                                     // bit 31 = sign of the row's totals
+                const int nm = new_msg(v, g, t0, t1, ss);
+                LDS_I8(er ? a : scratch) = (int8_t)clamp8(v + nm);
+                LDS_I8(valid ? ra + 4u + (uint32_t)k : scratch) = (int8_t)v;
+            };
+            // (the step list is fetched two steps ahead, by hand: the compiler sinks such a fetch to its use and then waits for it)
 #define LIST_FETCH(r, p) asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory")
 #define LIST_READY(r) asm volatile("s_waitcnt vmcnt(1)" : "+v"(r) : : "memory")
-                uint32_t eA, eB;
-                const uint32_t* lp = list;
-                LIST_FETCH(eA, lp); LIST_FETCH(eB, lp + 16);
+            uint32_t eA, eB;
+            const uint32_t* lp = list;
+            LIST_FETCH(eA, lp); LIST_FETCH(eB, lp + 16);
+            lp += 32;
+            for (int i = 0; i < wk_steps; i += 2) {
+                LIST_READY(eA);
+                step(eA);
+                LIST_FETCH(eA, lp);
+                LIST_READY(eB);
+                if (i + 1 < wk_steps) step(eB);
+                LIST_FETCH(eB, lp + 16);
                 lp += 32;
-                for (int i = 0; i < nsteps; i += 2) {
-                    LIST_READY(eA);
-                    step(eA);
-                    LIST_FETCH(eA, lp);
-                    LIST_READY(eB);
-                    if (i + 1 < nsteps) step(eB);
-                    LIST_FETCH(eB, lp + 16);
-                    lp += 32;
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef LIST_FETCH
 #undef LIST_READY
-                __builtin_amdgcn_s_setprio(0);
-            }
-            lds_barrier();
-            if (act0 && level != 1u) {
-                const uint32_t lb = cw[CWD * j + 1];
+            __builtin_amdgcn_s_setprio(0);
+        }
+        lds_barrier();
+        if (level > 1u) {
+            const uint32_t lb = cw[CWD * j + 1];
 #pragma unroll
-                for (int k = 0; k < MAXC; ++k) {
-                    if (k < nc && ((late >> k) & 1)) {
-                        int v = (int)__builtin_amdgcn_sbfe((int)lb, 8 * k, 8);
-                        int m = mag_of(v);
-                        LINK_SET(k, v, m);
-                        ROW_ACCUM(v, m);
-                    }
+            for (int k = 0; k < MAXC; ++k) {
+                if ((late >> k) & 1) {
+                    int v = (int)__builtin_amdgcn_sbfe((int)lb, 8 * k, 8);
+                    int m = mag_of(v);
+                    LINK_SET(k, v, m);
+                    ROW_ACCUM(v, m);
                 }
             }
-        } else {
-            // ---- levels: a barrier per dependency level (ldpc_kernel.hip, KIND 3)
-            (void)chain_d;
-            const int depth = (int)(L.depth_nc & 0xffffu);
-            for (int lvl = 1; lvl <= depth; ++lvl) {
-                if (lvl > 1) lds_barrier();
-                if (act0 && level == (uint32_t)lvl) {
-                    __builtin_amdgcn_s_setprio(3);
-                    if (lvl > 1) {
-                        int xs[MAXC];
+        }
+    } else {
+        // ---- levels: a barrier per dependency level (ldpc_kernel.hip, KIND 3)
+        const int depth = (int)L.aux;
+        for (int lvl = 1; lvl <= depth; ++lvl) {
+            if (lvl > 1) lds_barrier();
+            if (level == (uint32_t)lvl) {
+                __builtin_amdgcn_s_setprio(3);
+                if (lvl > 1) {
+                    int xs[MAXC];
 #pragma unroll
-                        for (int k = 0; k < MAXC; ++k) xs[k] = (int)LDS_I8(addr[k]);
-#pragma unroll
-                        for (int k = 0; k < MAXC; ++k) {
-                            if (k < nc && ((late >> k) & 1)) {
-                                int v = clamp8(xs[k] - rec_byte<REC>(rec_in, k));
-                                int m = mag_of(v);
-                                LINK_SET(k, v, m);
-                                ROW_ACCUM(v, m);
-                            }
-                        }
-                    }
+                    for (int k = 0; k < MAXC; ++k) xs[k] = (int)LDS_I8(R.addr[k]);
 #pragma unroll
                     for (int k = 0; k < MAXC; ++k) {
-                        if (k < nc && ((early >> k) & 1)) {
-                            int nm = new_msg(LINK_IN(k), LINK_MG(k), min0, min1, sx);
-                            LDS_I8(addr[k]) = (int8_t)clamp8(LINK_IN(k) + nm);
+                        if ((late >> k) & 1) {
+                            int v = clamp8(xs[k] - rec_byte<REC>(rec_in, k));
+                            int m = mag_of(v);
+                            LINK_SET(k, v, m);
+                            ROW_ACCUM(v, m);
                         }
                     }
-                    __builtin_amdgcn_s_setprio(0);
                 }
+#pragma unroll
+                for (int k = 0; k < MAXC; ++k) {
+                    if ((early >> k) & 1) {
+                        int nm = new_msg(LINK_IN(k), LINK_MG(k), min0, min1, sx);
+                        LDS_I8(R.addr[k]) = (int8_t)clamp8(LINK_IN(k) + nm);
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
             }
         }
-        // the complete totals sit in half 0: hand them to half 1
-        min0 = QUAD_DPP(min0, DPP_FROM_HALF0);
-        min1 = QUAD_DPP(min1, DPP_FROM_HALF0);
-        sx = QUAD_DPP(sx, DPP_FROM_HALF0);
-        const int min0c = min(min0, 32), min1c = min(min1, 32);
-        MIN1CB = q8(min1c);
-        SUMCB = q8(min0c + min1c);
-        SXB = (uint32_t)(sx >> 31);
     }
-    // ---- output phase
-    if (LDPC_SPLIT_EXP & 8) { rec_out[0] = bits2(MIN1CB) ^ bits2(SUMCB) ^ SXB; return; }
-    if (active) {
-        s16x2 NM[NP + 1];
-        NM[NP] = splat2(0);
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            // other = (mag == min0) ? min1c : min0c, as min0c + min1c - min(mag, min1c): a magnitude is the row minimum, where min(mag, min1c) = min0c, or at
-            // least the second one, where it is min1c (algorithms.hh:250-256, the selected magnitude limited to 32 once per row)
-            const s16x2 other = SUMCB - pmin2(G[p], MIN1CB);
-            const s16x2 neg = from_bits2(SXB ^ bits2(V[p])) >> 15;                   // 0 or -1
-            s16x2 nm = pmin2(from_bits2(bits2(other) ^ bits2(neg)) - neg, q8(31));
-            // new posterior: 16-bit saturating add = int8 saturation; >> 8 brings the bytes to bits 7:0 / 23:16 for the stores
-            const s16x2 pn = from_bits2(bits2(sat_add2(V[p], nm)) >> 8);
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int k = 2 * p + hh;
-                if (k >= HS) { nm[hh] = 0; continue; }
-                bool wr = true;
-                if constexpr (CONF) {
-                    if (k < MAXC && k < nc) wr = !((early >> k) & 1);
-                }
-                if (wr) {
-                    if (hh == 0) lds_write_lo_i8(addr[k], bits2(pn)); else lds_write_hi_i8(addr[k], bits2(pn));
-                }
-            }
-            NM[p] = nm;
-        }
-#pragma unroll
-        for (int w = 0; w < REC; ++w) {
-            if (2 * w < NP) rec_out[w] = __builtin_amdgcn_perm(bits2(NM[2 * w + 1 <= NP ? 2 * w + 1 : NP]), bits2(NM[2 * w]), 0x07050301u);
-            else rec_out[w] = 0;
-        }
-        lds_pairs_wait();
-    }
+    SPLIT_MARK(5);
+    // the complete totals sit in half 0: hand them to half 1, both halves of a word equal again
+    min0 = QUAD_DPP(min0, DPP_FROM_HALF0);
+    min1 = QUAD_DPP(min1, DPP_FROM_HALF0);
+    sx = QUAD_DPP(sx, DPP_FROM_HALF0);
+    row_output<MAXDEG, MAXC>(R, (int)bits2(q8(min0)), (int)bits2(q8(min1)), sx >> 31, early, rec_out);
+    SPLIT_MARK(6);
+}
 #undef LINK_IN
 #undef LINK_MG
 #undef LINK_SET
-}
 
 template <int MAXDEG>
-__global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LDPC_SPLIT_WPE))) void ldpc_split_kernel(const LdpcLayerDesc* __restrict__ layers, const uint32_t* __restrict__ ents,
-                                                                                                                     const uint32_t* __restrict__ rows, const uint32_t* __restrict__ atab, LdpcKernelArgs A) {
+__global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LDPC_SPLIT_WPE))) void ldpc_split_kernel(const LdpcSplitLayer* __restrict__ layers, const uint32_t* __restrict__ ents,
+                                                                                                                     const uint32_t* __restrict__ atab, const uint32_t* __restrict__ rows, const int npl, LdpcKernelArgs A) {
     using S = SplitShape<MAXDEG>;
     constexpr int T = LDPC_SPLIT_T, REC = S::REC, NPW = S::NPW;
-    extern __shared__ __attribute__((aligned(16))) int8_t lds_all[];
+    extern __shared__ __attribute__((aligned(16))) int8_t lds_all[];     // (the kernel has no static LDS: the posteriors start at LDS offset 0, what the table's offsets count from)
     const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int N = A.N, K = A.K, R = A.R, q = A.q;
-    const int npad = (N + 16 + 15) & ~15;                 // posteriors + the scratch byte (ldpc_split_plan.h)
+    const int npad = (N + LDPC_SPLIT_SCRATCH + 15) & ~15;                // posteriors + the scratch bytes (ldpc_split_plan.h)
     int8_t* __restrict__ post = lds_all;
-    uint32_t* __restrict__ cw = reinterpret_cast<uint32_t*>(lds_all + npad);      // hand-off records of the chain walk / quad walk: 8 bytes per row
+    uint32_t* __restrict__ cw = reinterpret_cast<uint32_t*>(lds_all + npad);      // hand-off records of the chain walk: 8 bytes per row
     uint8_t* __restrict__ cres = reinterpret_cast<uint8_t*>(cw + 2 * 360);
     int* __restrict__ s_flag = reinterpret_cast<int*>(cres + 384);                // [12] + next frame
-    const uint32_t lbase = lds_offset(post);
-    uint32_t* __restrict__ msg = A.msg_ws + (size_t)blockIdx.x * (size_t)q * T * REC;
+    uint32_t* __restrict__ msg = A.msg_ws + (size_t)blockIdx.x * (size_t)A.pent_base;     // (pent_base: dwords of message workspace per workgroup)
     uint32_t* __restrict__ sgn = A.sgn_ws + (size_t)blockIdx.x * SGN_WS_DWORDS;
-    const bool row_ok = t < 720;
+    const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(atab), 0, npl * (T * NPW * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_msg = __builtin_amdgcn_make_buffer_rsrc(msg, 0, A.pent_base * 4, 0x00020000);
 
+#if defined(LDPC_PROF) && LDPC_PROF == 3
+    if (blockIdx.x == 0) g_prof_dev = A.prof;      // (threads 0 and 384 of workgroup 0 are the only readers)
+    __syncthreads();
+#endif
     int f = blockIdx.x;
     while (f < A.nframes) {
         {
@@ -423,12 +474,9 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                 post[K + 360 * i + jj] = src[K + c];
             }
             // the first sweep reads all-zero messages: this thread's records are cleared here, so that a sweep fetches them without asking which sweep it is
-            uint32_t z[REC];
-#pragma unroll
-            for (int w = 0; w < REC; ++w) z[w] = 0;
-            for (int l = 0; l < q; ++l) rec_store<REC>(z, msg + (uint32_t)l * (T * REC) + (uint32_t)t * REC);
+            for (uint32_t o = (uint32_t)t; o < (uint32_t)A.pent_base; o += T) msg[o] = 0;
         }
-        lds_barrier();
+        __syncthreads();
 
         int it = 0, ret = 0;
         while (true) {
@@ -448,48 +496,81 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                 if (!any) { ret = it; break; }
                 if (it == A.max_trials) { ret = -1; break; }
             }
-            // ---- one layered sweep (LDPCDecoder::update); records, addresses and row words travel one layer ahead, descriptors two.
-            // Every fetch is (uniform base of the layer) + (this thread's 32-bit offset): scalar base registers, no 64-bit address arithmetic per lane
+            // ---- one layered sweep (LDPCDecoder::update) = the plan's pseudo-layers in order.  A wave fetches its table entry and message record one pseudo-layer
+            // ahead -- if it has rows there; descriptors travel two ahead.
             uint32_t rec_next[REC], pw_next[NPW];
-            rec_load<REC>(rec_next, msg + (uint32_t)t * REC);
-            words_load<NPW>(pw_next, atab + (uint32_t)t * NPW);
-            LdpcLayerDesc Lnext = layers[0], Lnext2 = layers[q > 1 ? 1 : 0];
-            uint32_t rw_next = (rows + Lnext.row_off)[(uint32_t)t];
-            for (int layer = 0; layer < q; ++layer) {
+#pragma unroll
+            for (int w = 0; w < REC; ++w) rec_next[w] = 0;
+#pragma unroll
+            for (int w = 0; w < NPW; ++w) pw_next[w] = 0;
+            LdpcSplitLayer Lnext = layers[0], Lnext2 = layers[npl > 1 ? 1 : 0];
+            uint32_t soff_tab = 0;
+            if (wave < (int)((Lnext.kind_nw >> 8) & 0xffu) && !(LDPC_SPLIT_EXP & 2)) {
+                bload<NPW>(pw_next, rs_tab, (uint32_t)t * (NPW * 4), soff_tab);
+                bload<REC>(rec_next, rs_msg, (uint32_t)t * (REC * 4), Lnext.rec_off * 4u);
+            }
+#if defined(LDPC_PROF)
+            unsigned long long t_layer = clock64();       // development aid (-DLDPC_PROF builds): cycles of every pseudo-layer, thread 0 of workgroup 0 -> prof[128 + pl]; prof[127]: the rest of an iteration
+            if (A.prof && blockIdx.x == 0 && t == 0) { A.prof[127] += t_layer - A.prof[126]; }
+#endif
+            for (int pl = 0; pl < npl; ++pl) {
+                const LdpcSplitLayer L = Lnext;
+                Lnext = Lnext2;
+                Lnext2 = layers[pl + 2 < npl ? pl + 2 : npl - 1];
+                soff_tab += T * NPW * 4;
+                // (everything a layer derives from the thread index is derived HERE, from a copy the compiler cannot see through: hoisted out of the loops these values
+                // stay in registers across the whole kernel, and at 64 / 80 registers they are what gets spilled and reloaded inside the layers)
+                int tt = t;
+                asm volatile("" : "+v"(tt));
+                const uint32_t voff_rec = (uint32_t)tt * (REC * 4), voff_tab = (uint32_t)tt * (NPW * 4);
+                const bool mine = wave < (int)((L.kind_nw >> 8) & 0xffu);
+                const bool mine_next = pl + 1 < npl && wave < (int)((Lnext.kind_nw >> 8) & 0xffu);
                 uint32_t rec[REC], pw[NPW];
 #pragma unroll
                 for (int w = 0; w < REC; ++w) rec[w] = rec_next[w];
 #pragma unroll
                 for (int w = 0; w < NPW; ++w) pw[w] = pw_next[w];
-                const LdpcLayerDesc L = Lnext;
-                const uint32_t rw = rw_next;
-                uint32_t* __restrict__ rp = msg + (uint32_t)layer * (T * REC);
-                const int ln = layer + 1 < q ? layer + 1 : q - 1;       // (behind the last layer: the last layer's once more -- nobody reads them)
-                Lnext = Lnext2;
-                Lnext2 = layers[layer + 2 < q ? layer + 2 : q - 1];
-                if (!(LDPC_SPLIT_EXP & 2)) {
-                    words_load<NPW>(pw_next, atab + (uint32_t)ln * (T * NPW) + (uint32_t)t * NPW);
-                    rec_load<REC>(rec_next, msg + (uint32_t)ln * (T * REC) + (uint32_t)t * REC);
-                    rw_next = (rows + Lnext.row_off)[(uint32_t)t];
+                if (mine_next && !(LDPC_SPLIT_EXP & 2)) {
+                    bload<NPW>(pw_next, rs_tab, voff_tab, soff_tab);
+                    bload<REC>(rec_next, rs_msg, voff_rec, Lnext.rec_off * 4u);
                 }
-                uint32_t ro[REC];
+                if (mine) {
+                    uint32_t ro[REC];
+#ifdef LDPC_SPLIT_NARROW_PRIO
+                    const bool narrow = ((L.kind_nw >> 8) & 0xffu) <= LDPC_SPLIT_NARROW_PRIO;
+                    if (narrow) __builtin_amdgcn_s_setprio(3);
+#endif
+                    if ((L.kind_nw & 0xffu) == 0) {
+                        RowState<MAXDEG> RS;
+                        int M0, M1, SXs;
+                        row_input<MAXDEG, 0>(RS, pw, rec, 0u, (L.kind_nw >> 20) & 1u, L.aux, tt, M0, M1, SXs);
+                        if (LDPC_SPLIT_EXP & 8) { ro[0] = (uint32_t)(M0 ^ M1 ^ SXs); ro[REC - 1] = ro[0]; }
+                        else row_output<MAXDEG, 0>(RS, M0, M1, SXs, 0u, ro);
+                    } else if ((L.kind_nw & 0xffu) == 1) {
+                        conflict_layer<MAXDEG, 1>(pw, rec, ro, L, ents + L.ent_off, nullptr, tt, post, cw, cres);
+                    } else if ((L.kind_nw & 0xffu) == 6) {
+                        conflict_layer<MAXDEG, 6>(pw, rec, ro, L, ents + L.ent_off, rows + L.aux, tt, post, cw, cres);
+                    } else {
+                        conflict_layer<MAXDEG, 3>(pw, rec, ro, L, ents + L.ent_off, nullptr, tt, post, cw, cres);
+                    }
+                    // the next pseudo-layer's words are claimed HERE, before this one's record store is issued: the wait for them then sits where they have had a whole
+                    // pseudo-layer to arrive, and the top of the next pseudo-layer waits for nothing (ldpc_kernel.hip)
 #pragma unroll
-                for (int w = 0; w < REC; ++w) ro[w] = 0;
-                const uint32_t* le = ents + L.ent_off;
-                if ((LDPC_SPLIT_EXP & 1) || (L.depth_nc & 0xffffu) == 1) split_layer<MAXDEG, 0>(lbase, post, le, pw, L, rw, layer, t, row_ok, rec, ro, cw, cres, nullptr);
-                else if ((L.deg >> 16) == LDPC_WALK_MARK) split_layer<MAXDEG, 6>(lbase, post, le, pw, L, rw, layer, t, row_ok, rec, ro, cw, cres, rows + L.row_off + T);
-                else if ((L.deg >> 16) > 0) split_layer<MAXDEG, 1>(lbase, post, le, pw, L, rw, layer, t, row_ok, rec, ro, cw, cres, nullptr);
-                else split_layer<MAXDEG, 3>(lbase, post, le, pw, L, rw, layer, t, row_ok, rec, ro, cw, cres, nullptr);
-                // the prefetched words are claimed here, in uniform control flow and before this layer's record store is issued (ldpc_kernel.hip)
+                    for (int w = 0; w < REC; ++w) asm volatile("" : "+v"(rec_next[w]));
 #pragma unroll
-                for (int w = 0; w < REC; ++w) asm volatile("" : "+v"(rec_next[w]));
-#pragma unroll
-                for (int w = 0; w < NPW; ++w) asm volatile("" : "+v"(pw_next[w]));
-                asm volatile("" : "+v"(rw_next));
-                asm volatile("" : "+s"(Lnext2.ent_off), "+s"(Lnext2.deg), "+s"(Lnext2.depth_nc), "+s"(Lnext2.row_off));
-                if (LDPC_SPLIT_EXP & 2) { asm volatile("" :: "v"(ro[0]), "v"(ro[REC - 1])); }
-                else if (row_ok) rec_store<REC>(ro, rp + (uint32_t)t * REC);
+                    for (int w = 0; w < NPW; ++w) asm volatile("" : "+v"(pw_next[w]));
+                    if (LDPC_SPLIT_EXP & 2) asm volatile("" :: "v"(ro[0]), "v"(ro[REC - 1]));
+                    else bstore<REC>(ro, rs_msg, voff_rec, L.rec_off * 4u);
+                    lds_pairs_wait();
+#ifdef LDPC_SPLIT_NARROW_PRIO
+                    if (narrow) __builtin_amdgcn_s_setprio(0);
+#endif
+                }
+                asm volatile("" : "+s"(Lnext2.kind_nw), "+s"(Lnext2.aux), "+s"(Lnext2.rec_off), "+s"(Lnext2.ent_off));
                 if (!(LDPC_SPLIT_EXP & 4)) lds_barrier();
+#if defined(LDPC_PROF)
+                if (A.prof && blockIdx.x == 0 && t == 0) { const unsigned long long t_now = clock64(); A.prof[128 + pl] += t_now - t_layer; t_layer = t_now; A.prof[126] = t_now; }
+#endif
             }
             ++it;
         }
@@ -499,7 +580,7 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
         {
             // hard decisions of [0,K): 64 bits per wave step via ballot, MSB-first bytes (module_dvbs2_demod.cpp:357-360)
             uint8_t* __restrict__ hd = A.hard + (size_t)f * A.hard_stride;
-            const int lane = t & 63, wave = t >> 6;
+            const int lane = t & 63;
             for (int base = wave * 64; base < K; base += (T / 64) * 64) {
                 int idx = base + lane;
                 int neg = (idx < K) ? (post[idx] < 0) : 0;
@@ -527,12 +608,12 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
         } else {
             f += gridDim.x;
         }
-        lds_barrier();
+        __syncthreads();
     }
 }
 
-size_t ldpc_split_lds_bytes(int N) { return (size_t)((N + 16 + 15) & ~15) + 2 * 360 * 4 + 384 + 16 * 4; }
-size_t ldpc_split_msg_bytes_per_block(const LdpcDeviceCode& C) { return (size_t)C.q * LDPC_SPLIT_T * C.split_rec_dwords * sizeof(uint32_t); }
+size_t ldpc_split_lds_bytes(int N) { return (size_t)((N + LDPC_SPLIT_SCRATCH + 15) & ~15) + 2 * 360 * 4 + 384 + 16 * 4; }
+size_t ldpc_split_msg_bytes_per_block(const LdpcDeviceCode& C) { return (size_t)C.split_rec_total * sizeof(uint32_t); }
 
 template <int MAXDEG>
 static hipError_t launch_split(const LdpcDeviceCode& C, const LdpcKernelArgs& A, int grid, hipStream_t stream) {
@@ -540,7 +621,7 @@ static hipError_t launch_split(const LdpcDeviceCode& C, const LdpcKernelArgs& A,
     auto kern = ldpc_split_kernel<MAXDEG>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(LDPC_SPLIT_T), lds, stream, C.d_split_layers, C.d_ents, C.d_split_rows, C.d_split_atab, A);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(LDPC_SPLIT_T), lds, stream, C.d_split_layers, C.d_ents, C.d_split_atab, C.d_rows, C.split_npl, A);
     return hipGetLastError();
 }
 template <int MAXDEG>
@@ -559,6 +640,7 @@ static int occupancy_split(int N) {
         default: break;                                 \
     }
 
+extern unsigned long long* g_ldpc_prof;   // (ldpc_kernel.hip)
 bool ldpc_split_supported(int max_deg) { return max_deg == 12; }
 int ldpc_split_blocks_per_cu(int max_deg, int N) {
     LDPC_SPLIT_DISPATCH(occupancy_split, N)
@@ -575,9 +657,9 @@ hipError_t ldpc_split_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, 
         if (e != hipSuccess) return e;
     }
     A.llr = llr; A.hard = hard; A.post = post; A.trials = trials; A.msg_ws = msg_ws;
-    A.nframes = nframes; A.N = C.N; A.K = C.K; A.R = C.R; A.q = C.q; A.pent_base = C.pent_base; A.synd_base = C.synd_base;
+    A.nframes = nframes; A.N = C.N; A.K = C.K; A.R = C.R; A.q = C.q; A.pent_base = C.split_rec_total; A.synd_base = C.synd_base;
     A.max_trials = max_trials; A.force = force; A.hard_stride = hard_stride;
-    A.prof = nullptr;
+    A.prof = g_ldpc_prof;
     const int max_deg = C.max_deg;
     LDPC_SPLIT_DISPATCH(launch_split, C, A, grid, stream)
     return hipErrorInvalidValue;

@@ -1,90 +1,154 @@
 // Host-side tables of the HALF-ROW LDPC decoder (ldpc_split_kernel.hip): two lanes per parity-check row, one frame per workgroup.
 //
-// The reference sweeps rows in order (xdsopl-ldpc-pabr/layered_decoder.hh:46-74); which rows of a layer may run side by side, and which
-// links must be read late / written early, is the plan of ldpc_plan.h -- unchanged.  What changes is who holds a row: thread t of the
-// 768-thread workgroup owns HALF h = t & 1 of row j = t >> 1 of every layer.  A row has NL = max_deg + 2 links (table links, own parity
-// bit, previous parity bit); half 0 holds table links [0, HS), half 1 table links [HS, max_deg), then the own and the previous parity
-// bit, HS = ceil(NL / 2) slots each.  The plan puts a layer's shared ("conflict") links first, so they all sit in half 0 (codes whose
-// layers share more than HS links keep the lane-per-row decoder).  min / xor are associative and commutative, so joining the two halves'
-// (min0, min1, sign) with one cross-lane step leaves algorithms.hh:242-255 bit-exact.
+// The reference sweeps rows in order (xdsopl-ldpc-pabr/layered_decoder.hh:46-74); which rows of a layer may run side by side is the plan of
+// ldpc_plan.h (levels, late / early links, chain steps) -- unchanged.  What changes is who holds a row and how dependent rows are ordered:
+//   * thread t of the 768-thread workgroup owns HALF h = t & 1 of a row.  A row has NL = max_deg + 2 links (table links, own parity bit,
+//     previous parity bit); half 0 holds links [0, HS), half 1 links [HS, NL), HS = NL / 2 slots each (NL even; an odd HS leaves the second
+//     half of the last register pair to a constant neutral link, ldpc_split_kernel.hip).  min / xor are associative and commutative, so
+//     joining the two halves' (min0, min1, sign) with one cross-lane step leaves algorithms.hh:242-255 bit-exact.
+//   * a sweep is a list of PSEUDO-LAYERS, each ending in a workgroup barrier.  Everything a thread needs for one -- the LDS byte offsets of
+//     its slots, parity bits included, and its row word -- comes from a per-thread table entry, so which row a thread holds is free per
+//     pseudo-layer:
+//       kind 0 (row update): the first nw waves update one row per lane pair, the plain conflict-free update.  A conflict-free layer is one
+//           such pseudo-layer (rows in lane order).  A layer with shared bits becomes one pseudo-layer per dependency LEVEL (ldpc_plan.h),
+//           the level's rows packed into the first lanes: rows of equal level share no bit, rows of later levels see the earlier ones'
+//           writes across the barrier -- the reference's row order, with no special code at all (the per-link "late / early" machinery of
+//           ldpc_kernel.hip is not needed: a row is updated in one piece, when its predecessors are done).
+//       kinds 1 / 3 / 6 (chain walk / levels / quad walk): a layer with more levels than LDPC_SPLIT_PACK_MAX_DEPTH keeps ldpc_kernel.hip's forms:
+//           all rows at once in lane order, the shared links (they all sit in half 0) resolved in a middle section -- chains walked by a few lanes
+//           through per-row hand-off records (~85 cycles per chained row), four lanes per row of a deep narrow level structure, or a barrier per
+//           level.  A packed level costs a whole row update and a vector-memory round trip for its table entry (measured ~1 750 cycles,
+//           profiles/r05_ldpc_split_layers.txt), a walked one a few hundred: only shallow layers are worth packing.
+//   * idle lanes (beyond the packed rows; rows 360..383 of a full layer) point every slot at scratch bytes behind the posteriors: they run
+//     the same instructions and store to bytes nobody reads -- no exec masking in the row update.  The missing previous parity bit of row 0
+//     of layer 0 points there too; its pseudo-layer carries a flag and the thread index.
 //
-// Tables (all indexed by the thread, stride LDPC_SPLIT_T, so that every fetch is one coalesced vector load):
-//   atab  [q][768][NPW]  link addresses, two 16-bit LDS byte offsets per word: slot 2p | slot 2p+1 << 16.  Parity bits included (the kernel
-//                        does no address arithmetic at all).  Absent slots and the missing previous parity bit of row 0 of layer 0 point
-//                        at the scratch byte behind the posteriors (offset N): read, masked, written, never looked at.
-//   rows  per conflict layer [768] row words (half 0: level | late << 8 | early << 20 of its row; half 1 and idle lanes: 0), followed for
-//                        quad-walk layers by the step list of ldpc_plan.h
+// Tables: atab [pseudo-layer][768][NPW] words, two 16-bit LDS byte offsets per word (slot 2p | slot 2p+1 << 16), the row word of kind-1 / 3 / 6
+// layers (level | late << 8 | early << 12) in the 16 bits behind the last slot; message records [pseudo-layer][64 * nw][REC] per workgroup.
 #pragma once
 #include "ldpc_plan.h"
 
 namespace s2 {
 
 constexpr int LDPC_SPLIT_T = 768;              // threads per workgroup = 2 x 384 (rows 360..383 idle)
+constexpr int LDPC_SPLIT_SCRATCH = 64;         // scratch bytes behind the posteriors (one per lane of a wave)
+#ifndef LDPC_SPLIT_PACK_MAX_DEPTH
+#define LDPC_SPLIT_PACK_MAX_DEPTH 0            // layers with shared bits and up to this many levels are packed level by level; deeper ones keep the walks of ldpc_kernel.hip
+#endif
+
+struct LdpcSplitLayer {   // 16 bytes = one s_load_dwordx4
+    uint32_t kind_nw;     // bits 0..7 kind, 8..15 active waves, 16..19 nc = shared links of the layer (slots 0..nc-1 of half 0), bit 20: holds row 0 of layer 0 (no previous parity bit)
+    uint32_t aux;         // kind 0: the half-1 thread of row 0 of layer 0 (bit 20); kind 1: chain step d; kind 3: levels; kind 6: index of the walk list in LdpcPlan::rows
+    uint32_t rec_off;     // dword offset of the pseudo-layer's records inside a workgroup's message workspace
+    uint32_t ent_off;     // kind 1: index of the layer's link entries in LdpcPlan::ents (the walker reads link 1's)
+};
 
 struct LdpcSplitPlan {
     bool ok = false;
     int hs = 0;                        // slots per half
-    int npw = 0;                       // address words per thread and layer (power of two)
-    int rec_dwords = 0;                // message record per thread and layer, dwords (1 byte per slot)
-    std::vector<LdpcLayerDesc> layers; // the plan's descriptors with row_off pointing into rows below
+    int npw = 0;                       // table words per thread and pseudo-layer (power of two)
+    int rec_dwords = 0;                // message record per thread and pseudo-layer, dwords (1 byte per slot)
+    int rec_total = 0;                 // dwords of message workspace per workgroup
+    int packed_layers = 0, chain_layers = 0;
+    std::vector<LdpcSplitLayer> layers;
     std::vector<uint32_t> atab;
-    std::vector<uint32_t> rows;
+    std::vector<int> row_of;           // [pseudo-layer][768 / 2] original row of every lane pair (-1: idle) and
+    std::vector<int> layer_of;         // [pseudo-layer] original layer: what the CPU-side plan test checks against the reference order
 };
 
-// which codes the half-row decoder takes: regular, an even number of links per row (both halves then hold the same number of slots),
-// every layer's shared links inside half 0 and of a kind the kernel implements (free, chain, quad walk, levels over <= 4 links)
-inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P) {
+inline int ldpc_split_npw(int hs) {
+    const int words = hs / 2 + 1;      // the 16 bits behind the last slot hold the row word
+    return words <= 1 ? 1 : words <= 2 ? 2 : words <= 4 ? 4 : 8;
+}
+
+// which codes the half-row decoder takes: regular ones with an even number of links per row (both halves then hold the same number of slots)
+inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P, int pack_max_depth = LDPC_SPLIT_PACK_MAX_DEPTH) {
     LdpcSplitPlan S;
     const int NL = P.max_deg + 2;
-    if (P.min_deg != P.max_deg || (NL & 1)) return S;
-    S.hs = NL / 2;
-    const int pairs = (S.hs + 1) / 2;
-    S.npw = pairs <= 1 ? 1 : pairs <= 2 ? 2 : pairs <= 4 ? 4 : 8;
-    S.rec_dwords = S.hs <= 4 ? 1 : S.hs <= 8 ? 2 : 4;
-    if (S.hs > 16) return S;
+    if (P.min_deg != P.max_deg || (NL & 1) || NL / 2 > 16 || P.N + LDPC_SPLIT_SCRATCH > 65536) return S;
     for (const LdpcLayerDesc& L : P.layers) {
         const int nc = (int)(L.depth_nc >> 16), depth = (int)(L.depth_nc & 0xffffu);
-        if (depth > 1 && nc > 4) return S;
-        if (nc > S.hs) return S;
+        if (depth > pack_max_depth && (nc > 4 || nc > NL / 2)) return S;       // (the middle sections handle up to four shared links, all in half 0)
     }
-    const int q = P.q, K = P.K, N = P.N, T = LDPC_SPLIT_T;
-    const uint32_t dummy = (uint32_t)N;
-    S.atab.assign((size_t)q * T * S.npw, dummy | (dummy << 16));
-    S.layers = P.layers;
+    S.hs = NL / 2;
+    S.npw = ldpc_split_npw(S.hs);
+    S.rec_dwords = S.hs <= 4 ? 1 : S.hs <= 8 ? 2 : 4;
+    const int q = P.q, K = P.K, N = P.N, T = LDPC_SPLIT_T, hs = S.hs, npw = S.npw;
+    auto scratch = [&](int t) { return (uint32_t)(N + (t & (LDPC_SPLIT_SCRATCH - 1))); };
+    auto slot_addr = [&](int i, int j, int k) -> uint32_t {     // link k of row j of layer i; ~0: none
+        const LdpcLayerDesc& L = P.layers[i];
+        if (k < P.max_deg) {
+            const uint32_t e = P.ents[L.ent_off + k];
+            return 360u * (e >> 16) + ((uint32_t)j + (e & 0xffffu)) % 360u;
+        }
+        if (k == P.max_deg) return (uint32_t)(K + 360 * i + j);
+        if (i > 0) return (uint32_t)(K + 360 * (i - 1) + j);
+        if (j > 0) return (uint32_t)(K + 360 * (q - 1) + j - 1);
+        return ~0u;
+    };
+    // one pseudo-layer: rows[] = the original rows of lane pairs 0, 1, ...; info[] = their row words (kind 1)
+    auto emit = [&](int kind, int i, const std::vector<int>& rows, const std::vector<uint32_t>* info, uint32_t aux) {
+        LdpcSplitLayer D{};
+        const int nthreads = 2 * (int)rows.size();
+        const int nw = kind != 0 ? T / 64 : (nthreads + 63) / 64;
+        D.kind_nw = (uint32_t)kind | ((uint32_t)nw << 8) | ((kind != 0 ? (P.layers[i].depth_nc >> 16) : 0u) << 16);
+        D.aux = aux;
+        D.rec_off = (uint32_t)S.rec_total;
+        D.ent_off = P.layers[i].ent_off;
+        S.rec_total += nw * 64 * S.rec_dwords;
+        const size_t base = S.atab.size();
+        S.atab.resize(base + (size_t)T * npw, 0);
+        const size_t rbase = S.row_of.size();
+        S.row_of.resize(rbase + T / 2, -1);
+        for (int t = 0; t < T; ++t) {
+            uint32_t* w = &S.atab[base + (size_t)t * npw];
+            const int pr = t >> 1, h = t & 1;
+            const int j = pr < (int)rows.size() ? rows[pr] : -1;
+            for (int s = 0; s < hs; ++s) {
+                uint32_t a = scratch(t);
+                if (j >= 0) {
+                    a = slot_addr(i, j, h * hs + s);
+                    if (a == ~0u) { a = scratch(t); D.kind_nw |= 1u << 20; if (kind == 0) D.aux = (uint32_t)t; }
+                }
+                w[s >> 1] |= a << (16 * (s & 1));
+            }
+            if (j >= 0 && h == 0) {
+                S.row_of[rbase + pr] = j;
+                if (info) w[hs >> 1] |= ((*info)[pr] & 0xffffu) << (16 * (hs & 1));
+            }
+        }
+        S.layers.push_back(D);
+        S.layer_of.push_back(i);
+    };
     for (int i = 0; i < q; ++i) {
         const LdpcLayerDesc& L = P.layers[i];
-        for (int t = 0; t < T; ++t) {
-            const int j = t >> 1, h = t & 1;
-            uint32_t* w = &S.atab[((size_t)i * T + t) * S.npw];
-            if (j >= 360) continue;                       // idle lanes: the scratch byte
-            for (int s = 0; s < S.hs; ++s) {
-                uint32_t a = dummy;
-                const int k = h * S.hs + s;               // link number in the row's order: table links, own parity, previous parity
-                if (k < P.max_deg) {
-                    const uint32_t e = P.ents[L.ent_off + k];
-                    a = 360u * (e >> 16) + ((uint32_t)j + (e & 0xffffu)) % 360u;
-                } else if (k == P.max_deg) {
-                    a = (uint32_t)(K + 360 * i + j);
-                } else if (k == P.max_deg + 1) {
-                    if (i > 0) a = (uint32_t)(K + 360 * (i - 1) + j);
-                    else if (j > 0) a = (uint32_t)(K + 360 * (q - 1) + j - 1);
-                }
-                w[s >> 1] = (w[s >> 1] & ~(0xffffu << (16 * (s & 1)))) | (a << (16 * (s & 1)));
-            }
-        }
         const int depth = (int)(L.depth_nc & 0xffffu);
-        if (depth > 1) {
-            S.layers[i].row_off = (uint32_t)S.rows.size();
-            for (int t = 0; t < T; ++t) S.rows.push_back(((t & 1) == 0 && (t >> 1) < 360) ? P.rows[L.row_off + (t >> 1)] : 0u);
-            if ((L.deg >> 16) == LDPC_WALK_MARK) {
-                const uint32_t hd = P.rows[L.row_off + 360];
-                const size_t nwords = 1 + (size_t)((hd & 0xffffu) + 3) * 16;       // header, the steps and the three empty ones behind them
-                for (size_t n = 0; n < nwords; ++n) S.rows.push_back(P.rows[L.row_off + 360 + n]);
+        const uint32_t chain = L.deg >> 16;
+        std::vector<int> rows;
+        if (depth == 1) {
+            for (int j = 0; j < 360; ++j) rows.push_back(j);
+            emit(0, i, rows, nullptr, 0);
+        } else if (depth > pack_max_depth) {
+            std::vector<uint32_t> info;
+            for (int j = 0; j < 360; ++j) {
+                const uint32_t rw = P.rows[L.row_off + j];
+                rows.push_back(j);
+                info.push_back((rw & 0xffu) | (((rw >> 8) & 15u) << 8) | (((rw >> 20) & 15u) << 12));
             }
+            if (chain == LDPC_WALK_MARK) emit(6, i, rows, &info, L.row_off + 360);
+            else if (chain != 0) emit(1, i, rows, &info, chain);
+            else emit(3, i, rows, &info, (uint32_t)depth);
+            S.chain_layers++;
+        } else {
+            for (int lvl = 1; lvl <= depth; ++lvl) {
+                rows.clear();
+                for (int j = 0; j < 360; ++j)
+                    if ((int)(P.rows[L.row_off + j] & 0xffu) == lvl) rows.push_back(j);
+                emit(0, i, rows, nullptr, 0);
+            }
+            S.packed_layers++;
         }
     }
-    if (S.rows.empty()) S.rows.push_back(0);
-    while (S.rows.size() < (size_t)T) S.rows.push_back(0);     // (conflict-free layers fetch "their" row word from offset 0: a word nobody looks at)
     S.ok = true;
     return S;
 }
