@@ -65,16 +65,20 @@ int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
         if (!P.atab.empty() && (rc = upload(P.atab, &D.d_atab))) return fail(rc);
         D.blocks_per_cu = ldpc_blocks_per_cu(P.max_deg, D.irregular, P.N);
         if (P.N > 16200 && ldpc_split_supported(P.max_deg)) {
-            // normal frames of the codes the half-row decoder takes (ldpc_split_plan.h); DVBS2GPU_LDPC_SPLIT=0 keeps the lane-per-row decoder
-            // (development aid / the parity tests run both)
-            const LdpcSplitPlan SP = build_ldpc_split_plan(P);
+            // the half-row decoder (ldpc_split_plan.h / ldpc_split_kernel.hip) for the normal frames it takes: NOT the default -- alone it equals the lane-per-row
+            // decoder (338 vs 337 ms per 32 768 frames of rate 3/4 at the 64 registers that leave room for a front-end wave, 321 at 80), beside the front end of the
+            // pipelined mode it loses (370 vs 342 ms: its 24 waves per compute unit use the vector issue slots the front end otherwise gets for free).  DVBS2GPU_LDPC_SPLIT=1
+            // selects it (the parity tests run both decoders); DESIGN.md section 5 has the measurements.
             const char* e = getenv("DVBS2GPU_LDPC_SPLIT");
-            if (SP.ok && !(e && atoi(e) == 0)) {
-                if ((rc = upload(SP.layers, &D.d_split_layers))) return fail(rc);
-                if ((rc = upload(SP.atab, &D.d_split_atab))) return fail(rc);
-                D.split_npl = (int)SP.layers.size(); D.split_rec_total = SP.rec_total;
-                D.split_blocks_per_cu = ldpc_split_blocks_per_cu(P.max_deg, P.N);
-                D.use_split = true;
+            if (e && atoi(e) != 0) {
+                const LdpcSplitPlan SP = build_ldpc_split_plan(P);
+                if (SP.ok) {
+                    if ((rc = upload(SP.layers, &D.d_split_layers))) return fail(rc);
+                    if ((rc = upload(SP.atab, &D.d_split_atab))) return fail(rc);
+                    D.split_npl = (int)SP.layers.size(); D.split_rec_total = SP.rec_total;
+                    D.split_blocks_per_cu = ldpc_split_blocks_per_cu(P.max_deg, P.N);
+                    D.use_split = true;
+                }
             }
         }
         if (P.N <= 16200) {
@@ -466,12 +470,12 @@ int dvbs2gpu_ldpc_addr_table_dump(int rate, int shortframes, uint32_t* table, in
     return 0;
 }
 
-int dvbs2gpu_ldpc_split_plan_dump(int rate, int shortframes, int pack_max_depth, uint32_t* layers4, uint32_t* table, int32_t* row_of, int32_t* layer_of, int32_t* counts6) {
+int dvbs2gpu_ldpc_split_plan_dump(int rate, int shortframes, int pack_max_depth, int pass_max_depth, uint32_t* layers4, uint32_t* table, int32_t* row_of, int32_t* layer_of, int32_t* counts6) {
     FecParams f;
     if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
     if (!counts6) return DVBS2GPU_ERR_ARG;
     const LdpcPlan P = build_ldpc_plan(f.code_index);
-    const LdpcSplitPlan S = pack_max_depth < 0 ? build_ldpc_split_plan(P) : build_ldpc_split_plan(P, pack_max_depth);
+    const LdpcSplitPlan S = build_ldpc_split_plan(P, pack_max_depth < 0 ? LDPC_SPLIT_PACK_MAX_DEPTH : pack_max_depth, pass_max_depth < 0 ? LDPC_SPLIT_PASS_MAX_DEPTH : pass_max_depth);
     counts6[0] = S.ok ? (int32_t)S.layers.size() : 0; counts6[1] = S.npw; counts6[2] = S.hs; counts6[3] = S.rec_total; counts6[4] = (int32_t)S.atab.size(); counts6[5] = S.rec_dwords;
     if (!S.ok) return 0;
     if (layers4) memcpy(layers4, S.layers.data(), S.layers.size() * sizeof(LdpcSplitLayer));

@@ -29,6 +29,32 @@ struct LdpcKernelArgs {
     unsigned long long* prof;   // development aid (-DLDPC_PROF builds only): per-wave phase cycle sums of workgroup 0
 };
 
+// What a decoder kernel is told arrives in ONE structure, read from the kernel-argument segment through a pointer the compiler cannot see through, afresh in every section
+// of the kernel (frame load | syndrome check + sweep | output): kept in scalar registers for the whole kernel, the two dozen values only the frame load and the output need
+// are what the allocator spills -- into vector-register lanes, read back inside the layers (profiles/r05_ldpc_split_layers.txt).
+struct LdpcKernelParams {
+    LdpcKernelArgs A;
+    const void* layers;                   // LdpcLayerDesc[] (ldpc_kernel.hip) / LdpcSplitLayer[] (ldpc_split_kernel.hip)
+    const uint32_t* ents;
+    const uint32_t* rows;
+    const uint32_t* atab;
+    int npl;                              // pseudo-layers (ldpc_split_kernel.hip)
+};
+typedef const __attribute__((address_space(4))) LdpcKernelParams* LdpcKernelParamsPtr;
+__device__ __forceinline__ LdpcKernelParamsPtr ldpc_params() {
+    uint32_t off = 0;
+    asm volatile("" : "+s"(off));        // (zero -- but not to the compiler: what is read through the pointer can be neither hoisted nor merged with another section's reads)
+    return (LdpcKernelParamsPtr)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + off);
+}
+__device__ __forceinline__ LdpcKernelArgs ldpc_args(LdpcKernelParamsPtr P) {
+    LdpcKernelArgs A;
+    A.llr = P->A.llr; A.hard = P->A.hard; A.post = P->A.post; A.trials = P->A.trials; A.msg_ws = P->A.msg_ws;
+    A.nframes = P->A.nframes; A.N = P->A.N; A.K = P->A.K; A.R = P->A.R; A.q = P->A.q; A.pent_base = P->A.pent_base; A.synd_base = P->A.synd_base;
+    A.max_trials = P->A.max_trials; A.force = P->A.force; A.hard_stride = P->A.hard_stride;
+    A.sgn_ws = P->A.sgn_ws; A.work_ctr = P->A.work_ctr; A.prof = P->A.prof;
+    return A;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() would also drain vmcnt, i.e. wait
 // for the in-flight message-record prefetch and store of every layer (cdna guide, "Pipelining across barriers").
 __device__ __forceinline__ void lds_barrier() {

@@ -27,7 +27,7 @@ namespace s2 {
 #define LDPC_SPLIT_EXP 0          // development switch for TIMING experiments (results wrong): 2 = no table / record traffic in the layer loop, 4 = no layer barrier, 8 = no output phase
 #endif
 #ifndef LDPC_SPLIT_WPE
-#define LDPC_SPLIT_WPE 6          // waves per SIMD the register allocation aims at (6 = 80 VGPRs: two workgroups per compute unit; 8 = 64: room for a 128-register front-end wave beside them)
+#define LDPC_SPLIT_WPE 8          // waves per SIMD the register allocation aims at (6 = 80 VGPRs: two workgroups per compute unit; 8 = 64: room for a 128-register front-end wave beside them)
 #endif
 
 template <int MAXDEG>
@@ -94,7 +94,8 @@ struct RowState {
 
 // input phase: posteriors in, extrinsic values, the row's two smallest magnitudes and sign -- M0 / M1 / SXs come back with BOTH halves of the
 // word holding the whole row's value (a word with equal halves orders like its 16-bit value under 32-bit signed compares; SXs: sign in bits 15 and 31).
-// LATE: the first LATE slots, where flagged in `late`, are left out of the totals (layers with shared links: 2 for a chain layer, 4 otherwise)
+// LATE > 0: the first LATE slots, where flagged in `late`, are left out of the totals (levels / quad walk: 4).  LATE == -1: the whole first pair is left out of
+// the totals where `late` is not zero (chain walk) -- V / G keep the values read
 template <int MAXDEG, int LATE>
 __device__ __forceinline__ void row_input(RowState<MAXDEG>& R, const uint32_t (&AD)[SplitShape<MAXDEG>::NPW], const uint32_t (&rec_in)[SplitShape<MAXDEG>::REC],
                                           const uint32_t late, const bool noprev_layer, const uint32_t noprev_t, const int t, int& M0, int& M1, int& SXs) {
@@ -136,6 +137,9 @@ __device__ __forceinline__ void row_input(RowState<MAXDEG>& R, const uint32_t (&
             }
         }
         R.V[p] = v; R.G[p] = g;
+        if constexpr (LATE == -1) {
+            if (p == 0) { v = late ? splat2(127 << 8) : v; g = late ? splat2(126 << 8) : g; }      // (the neutral link)
+        }
         if (p == 0) { MIN0 = g; }
         else if (p == 1) { MIN1 = pmax2(MIN0, g); MIN0 = pmin2(MIN0, g); }
         else { MIN1 = pmin2(MIN1, pmax2(MIN0, g)); MIN0 = pmin2(MIN0, g); }
@@ -205,6 +209,107 @@ __device__ unsigned long long* g_prof_dev = nullptr;
 #define LINK_IN(k) ((int)R.V[(k) >> 1][(k) & 1] >> 8)
 #define LINK_MG(k) ((int)R.G[(k) >> 1][(k) & 1] >> 8)
 #define LINK_SET(k, v, m) do { R.V[(k) >> 1][(k) & 1] = (short)((v) << 8); R.G[(k) >> 1][(k) & 1] = (short)((m) << 8); } while (0)
+
+// A layer whose shared links are one pair (slots 0 = "E", 1 = "L" of half 0: row j's E bit is row (j + d)'s L bit) with a deep dependency chain: ldpc_kernel.hip's chain
+// walk, its arithmetic kept packed.  Rows in lane order (row j = t >> 1).  The row word -- level | late << 8 | early << 12 in half 0, the level alone in half 1, zero in
+// idle lanes -- rides in the table.
+//   phase A  every row: the conflict-free input phase; rows of level > 1 keep their first pair out of the totals.  Rows of level 1 (no late link) finish here: their
+//            output phase writes every slot, the early ones included, before the first barrier.  A row whose L link is late leaves the walk's record: what its E link
+//            gives back as a function of what its L link reads (ldpc_lane_common.h: chain_record) -- the totals without the pair are exactly what that needs.
+//   walk     lane c < d follows rows c + d, c + 2d, ...: the posterior one row's E link leaves is the next row's L input (cres[])
+//   phase C  rows of level > 1: the pair's late slots re-read (L from cres[], E from its bit: a row whose E link is late waits for an EARLIER row's L link), joined into
+//            the totals with packed operations, handed to half 1, then the output phase -- which leaves out the early slots: a later row's L link owns that bit's final value.
+template <int MAXDEG>
+__device__ __forceinline__ void chain_layer(const uint32_t (&AD)[SplitShape<MAXDEG>::NPW], const uint32_t (&rec_in)[SplitShape<MAXDEG>::REC], uint32_t (&rec_out)[SplitShape<MAXDEG>::REC],
+                                            const LdpcSplitLayer L, const uint32_t eL, const int t, int8_t* __restrict__ post, uint32_t* __restrict__ cw, uint8_t* __restrict__ cres) {
+    using S = SplitShape<MAXDEG>;
+    constexpr int REC = S::REC;
+    [[maybe_unused]] constexpr int KIND = 1;
+    const uint32_t rw = (AD[S::RI_WORD] >> S::RI_SHIFT) & 0xffffu;
+    const uint32_t level = rw & 0xffu, late = (rw >> 8) & 3u, early = (rw >> 12) & 3u;
+    const int chain_d = (int)L.aux;
+    const int j = t >> 1;
+    const bool half1 = (t & 1) != 0;
+    RowState<MAXDEG> R;
+    int M0, M1, SXs;
+    SPLIT_MARK_DECL;
+    row_input<MAXDEG, -1>(R, AD, rec_in, (level > 1u && !half1) ? 1u : 0u, (L.kind_nw >> 20) & 1u, 1u, t, M0, M1, SXs);
+    SPLIT_MARK(0);
+    if (level == 1u) row_output<MAXDEG, 0>(R, M0, M1, SXs, 0u, rec_out);
+    if ((late >> 1) & 1) {
+        // totals without the pair: min0 = the smallest magnitude among the row's other links (what the E link's new message takes), sign = their product
+        const ChainRec r = chain_record(rec_byte<REC>(rec_in, 1), (late & 1u) ? 255 : (M0 >> 24), (int)R.V[0][0] >> 8, SXs >> 31);
+        reinterpret_cast<uint2*>(cw)[j] = make_uint2(r.lim, r.se);
+    }
+    SPLIT_MARK(1);
+    lds_pairs_wait();
+    lds_barrier();
+    SPLIT_MARK(2);
+    if (t < chain_d) {
+        // lane c walks rows c + k*d (ldpc_kernel.hip)
+        __builtin_amdgcn_s_setprio(3);
+        const int T = 359 / chain_d;
+        int x = post[link_addr(eL, t + chain_d)];
+        const uint2* c = reinterpret_cast<const uint2*>(cw) + t + chain_d;
+        uint8_t* pr = reinterpret_cast<uint8_t*>(cres) + t + chain_d;
+        uint2 ra = c[0], rb = c[chain_d];
+        c += 2 * chain_d;
+        int k = 1;
+        for (; k + 2 <= T; k += 2) {
+            const uint2 na = c[0];
+            pr[0] = (uint8_t)x;
+            x = chain_step(x, ra.x, ra.y);
+            ra = na;
+            const uint2 nb = c[chain_d];
+            pr[chain_d] = (uint8_t)x;
+            x = chain_step(x, rb.x, rb.y);
+            rb = nb;
+            c += 2 * chain_d;
+            pr += 2 * chain_d;
+        }
+        if (k < T) {
+            pr[0] = (uint8_t)x;
+            x = chain_step(x, ra.x, ra.y);
+            pr += chain_d;
+        }
+        if (t + T * chain_d < 360) pr[0] = (uint8_t)x;
+        __builtin_amdgcn_s_setprio(0);
+    }
+    SPLIT_MARK(3);
+    lds_barrier();
+    SPLIT_MARK(4);
+    if (level > 1u) {
+        if (!half1) {
+            // the pair again, from what the walk (L) and the earlier rows (E) left; only the late halves replace what phase A read
+            uint32_t xr, xh;
+            lds_read_pair_i8(R.addr[0], lds_offset(reinterpret_cast<const int8_t*>(cres)) + (uint32_t)j, xr, xh);
+            lds_ready_n(0, xr, xh);
+            const s16x2 X = from_bits2(__builtin_amdgcn_perm(xh, xr, 0x060c000cu));
+            const s16x2 v = sat_sub2(X, rec_pair<REC>(rec_in, 0));
+            const s16x2 av = pmax2(v, sat_sub2(splat2(0), v));
+            const s16x2 g = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, av), (u16x2){256, 256}));
+            // bits 8 / 9 of the row word -> 0xffff in the low / high half (v_perm: selectors 9 / 11 = the sign of byte 3 of either source)
+            const uint32_t rws = AD[S::RI_WORD] << (31 - (S::RI_SHIFT + 9));            // bit 31 = late L, bit 30 = late E
+            const uint32_t LM = __builtin_amdgcn_perm(rws << 1, rws, 0x09090b0bu);
+            R.V[0] = from_bits2((bits2(v) & LM) | (bits2(R.V[0]) & ~LM));
+            R.G[0] = from_bits2((bits2(g) & LM) | (bits2(R.G[0]) & ~LM));
+            // the pair joins the totals: its smaller magnitude first, then the larger one (words with equal halves: 32-bit operations)
+            const int a = (int)bits2(pmin2(R.G[0], swap2(R.G[0]))), b = (int)bits2(pmax2(R.G[0], swap2(R.G[0])));
+            M1 = min(M1, max(M0, a));
+            M0 = min(M0, a);
+            M1 = min(M1, max(M0, b));
+            const uint32_t sv = bits2(R.V[0]);
+            SXs ^= (int)(sv ^ __builtin_amdgcn_alignbit(sv, sv, 16));
+        }
+        // the complete totals sit in half 0: hand them to half 1
+        M0 = QUAD_DPP(M0, DPP_FROM_HALF0);
+        M1 = QUAD_DPP(M1, DPP_FROM_HALF0);
+        SXs = QUAD_DPP(SXs, DPP_FROM_HALF0);
+        SPLIT_MARK(5);
+        row_output<MAXDEG, 2>(R, M0, M1, SXs, early, rec_out);
+    }
+    SPLIT_MARK(6);
+}
 
 // A layer with shared links (slots 0..nc-1 of half 0), rows in lane order (row j = t >> 1): ldpc_kernel.hip's three forms.  KIND 1: one shared pair (slots 0 = "E",
 // 1 = "L"), the dependency chains walked by a few lanes; 6: quad walk (at most 4 shared links, deep and narrow level structure: one wave walks the rows of levels
@@ -281,7 +386,11 @@ __device__ LDPC_SPLIT_CONFLICT_INLINE void conflict_layer(const uint32_t (&AD)[S
                 pr += chain_d;
             }
             if (t + T * chain_d < 360) pr[0] = (uint8_t)x;
+#ifdef LDPC_SPLIT_PRIO
+            __builtin_amdgcn_s_setprio(LDPC_SPLIT_PRIO);
+#else
             __builtin_amdgcn_s_setprio(0);
+#endif
         }
         SPLIT_MARK(3);
         lds_barrier();
@@ -441,45 +550,56 @@ __device__ LDPC_SPLIT_CONFLICT_INLINE void conflict_layer(const uint32_t (&AD)[S
 #undef LINK_SET
 
 template <int MAXDEG>
-__global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LDPC_SPLIT_WPE))) void ldpc_split_kernel(const LdpcSplitLayer* __restrict__ layers, const uint32_t* __restrict__ ents,
-                                                                                                                     const uint32_t* __restrict__ atab, const uint32_t* __restrict__ rows, const int npl, LdpcKernelArgs A) {
+__global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LDPC_SPLIT_WPE))) void ldpc_split_kernel(LdpcKernelParams read_through_ldpc_params) {
+    // (the arguments are read section by section through ldpc_params(), ldpc_lane_common.h)
     using S = SplitShape<MAXDEG>;
     constexpr int T = LDPC_SPLIT_T, REC = S::REC, NPW = S::NPW;
     extern __shared__ __attribute__((aligned(16))) int8_t lds_all[];     // (the kernel has no static LDS: the posteriors start at LDS offset 0, what the table's offsets count from)
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int N = A.N, K = A.K, R = A.R, q = A.q;
-    const int npad = (N + LDPC_SPLIT_SCRATCH + 15) & ~15;                // posteriors + the scratch bytes (ldpc_split_plan.h)
     int8_t* __restrict__ post = lds_all;
-    uint32_t* __restrict__ cw = reinterpret_cast<uint32_t*>(lds_all + npad);      // hand-off records of the chain walk: 8 bytes per row
-    uint8_t* __restrict__ cres = reinterpret_cast<uint8_t*>(cw + 2 * 360);
-    int* __restrict__ s_flag = reinterpret_cast<int*>(cres + 384);                // [12] + next frame
-    uint32_t* __restrict__ msg = A.msg_ws + (size_t)blockIdx.x * (size_t)A.pent_base;     // (pent_base: dwords of message workspace per workgroup)
-    uint32_t* __restrict__ sgn = A.sgn_ws + (size_t)blockIdx.x * SGN_WS_DWORDS;
-    const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(atab), 0, npl * (T * NPW * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_msg = __builtin_amdgcn_make_buffer_rsrc(msg, 0, A.pent_base * 4, 0x00020000);
+#ifdef LDPC_SPLIT_PRIO
+    __builtin_amdgcn_s_setprio(LDPC_SPLIT_PRIO);
+#endif
 
 #if defined(LDPC_PROF) && LDPC_PROF == 3
-    if (blockIdx.x == 0) g_prof_dev = A.prof;      // (threads 0 and 384 of workgroup 0 are the only readers)
+    if (blockIdx.x == 0) g_prof_dev = ldpc_params()->A.prof;      // (threads 0 and 384 of workgroup 0 are the only readers)
     __syncthreads();
 #endif
     int f = blockIdx.x;
-    while (f < A.nframes) {
+    while (f < ldpc_params()->A.nframes) {
         {
-            const int8_t* __restrict__ src = A.llr + (size_t)f * N;
+            const LdpcKernelParamsPtr P = ldpc_params();
+            const int N = P->A.N, K = P->A.K, R = P->A.R, q = P->A.q;
+            uint32_t* __restrict__ msg = P->A.msg_ws + (size_t)blockIdx.x * (size_t)P->A.pent_base;
+            const int8_t* __restrict__ src = P->A.llr + (size_t)f * N;
             for (int i = t; i < K / 8; i += T) reinterpret_cast<uint2*>(post)[i] = reinterpret_cast<const uint2*>(src)[i];
             // parity LLRs: pty[360*i + jj] = llr[K + q*jj + i]   (layered_decoder.hh:124-126)
             for (int c = t; c < R; c += T) {
                 int jj = c / q, i = c - jj * q;
                 post[K + 360 * i + jj] = src[K + c];
             }
-            // the first sweep reads all-zero messages: this thread's records are cleared here, so that a sweep fetches them without asking which sweep it is
-            for (uint32_t o = (uint32_t)t; o < (uint32_t)A.pent_base; o += T) msg[o] = 0;
+            // the first sweep reads all-zero messages: the records are cleared here, so that a sweep fetches them without asking which sweep it is
+            for (uint32_t o = (uint32_t)t; o < (uint32_t)P->A.pent_base; o += T) msg[o] = 0;
         }
         __syncthreads();
 
         int it = 0, ret = 0;
         while (true) {
+            const LdpcKernelParamsPtr P = ldpc_params();
+            const LdpcKernelArgs A = ldpc_args(P);      // (what of it the check and the sweep use)
+            const int N = A.N, q = A.q, npl = P->npl;
+            const LdpcSplitLayer* __restrict__ layers = static_cast<const LdpcSplitLayer*>(P->layers);
+            const uint32_t* __restrict__ ents = P->ents;
+            const uint32_t* __restrict__ rows = P->rows;
+            const int npad = (N + LDPC_SPLIT_SCRATCH + 15) & ~15;                // posteriors + the scratch bytes (ldpc_split_plan.h)
+            uint32_t* __restrict__ cw = reinterpret_cast<uint32_t*>(lds_all + npad);      // hand-off records of the chain walk: 8 bytes per row
+            uint8_t* __restrict__ cres = reinterpret_cast<uint8_t*>(cw + 2 * 360);
+            int* __restrict__ s_flag = reinterpret_cast<int*>(cres + 384);                // [12] + next frame
+            uint32_t* __restrict__ msg = A.msg_ws + (size_t)blockIdx.x * (size_t)A.pent_base;
+            uint32_t* __restrict__ sgn = A.sgn_ws + (size_t)blockIdx.x * SGN_WS_DWORDS;
+            const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(P->atab), 0, npl * (T * NPW * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_msg = __builtin_amdgcn_make_buffer_rsrc(msg, 0, A.pent_base * 4, 0x00020000);
             const bool check = !A.force || it == A.max_trials;
             if (check) {
                 const uint32_t zflag = sign_pack(post, N, reinterpret_cast<uint8_t*>(sgn), t, T);
@@ -491,6 +611,7 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                 int any = 0;
 #pragma unroll
                 for (int w = 0; w < T / 64; ++w) any |= s_flag[w];
+                any = __builtin_amdgcn_readfirstlane(any);
                 lds_barrier();                // (the flags are rewritten by the next check)
                 if (A.force) { ret = any ? -1 : A.max_trials; break; }
                 if (!any) { ret = it; break; }
@@ -546,8 +667,24 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                         row_input<MAXDEG, 0>(RS, pw, rec, 0u, (L.kind_nw >> 20) & 1u, L.aux, tt, M0, M1, SXs);
                         if (LDPC_SPLIT_EXP & 8) { ro[0] = (uint32_t)(M0 ^ M1 ^ SXs); ro[REC - 1] = ro[0]; }
                         else row_output<MAXDEG, 0>(RS, M0, M1, SXs, 0u, ro);
+                    } else if ((L.kind_nw & 0xffu) == 2) {
+                        // level passes (ldpc_split_plan.h): pass l = the conflict-free update of the rows of level l, the others' lanes masked off
+                        const uint32_t level = (pw[S::RI_WORD] >> S::RI_SHIFT) & 0xffu;
+                        const int depth = (int)L.aux;
+#pragma unroll
+                        for (int w = 0; w < REC; ++w) ro[w] = 0;
+                        for (int pass = 1; pass <= depth; ++pass) {
+                            if (level == (uint32_t)pass) {
+                                RowState<MAXDEG> RS;
+                                int M0, M1, SXs;
+                                row_input<MAXDEG, 0>(RS, pw, rec, 0u, (L.kind_nw >> 20) & 1u, 1u, tt, M0, M1, SXs);
+                                row_output<MAXDEG, 0>(RS, M0, M1, SXs, 0u, ro);
+                                lds_pairs_wait();
+                            }
+                            if (pass < depth) lds_barrier();
+                        }
                     } else if ((L.kind_nw & 0xffu) == 1) {
-                        conflict_layer<MAXDEG, 1>(pw, rec, ro, L, ents + L.ent_off, nullptr, tt, post, cw, cres);
+                        chain_layer<MAXDEG>(pw, rec, ro, L, ents[L.ent_off + 1], tt, post, cw, cres);
                     } else if ((L.kind_nw & 0xffu) == 6) {
                         conflict_layer<MAXDEG, 6>(pw, rec, ro, L, ents + L.ent_off, rows + L.aux, tt, post, cw, cres);
                     } else {
@@ -566,7 +703,6 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                     if (narrow) __builtin_amdgcn_s_setprio(0);
 #endif
                 }
-                asm volatile("" : "+s"(Lnext2.kind_nw), "+s"(Lnext2.aux), "+s"(Lnext2.rec_off), "+s"(Lnext2.ent_off));
                 if (!(LDPC_SPLIT_EXP & 4)) lds_barrier();
 #if defined(LDPC_PROF)
                 if (A.prof && blockIdx.x == 0 && t == 0) { const unsigned long long t_now = clock64(); A.prof[128 + pl] += t_now - t_layer; t_layer = t_now; A.prof[126] = t_now; }
@@ -576,8 +712,12 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
         }
 
         // ---- outputs
-        if (t == 0) A.trials[f] = ret;
         {
+            const LdpcKernelParamsPtr P = ldpc_params();
+            const LdpcKernelArgs A = ldpc_args(P);
+            const int N = A.N, K = A.K, R = A.R, q = A.q;
+            int* __restrict__ s_flag = reinterpret_cast<int*>(lds_all + ((N + LDPC_SPLIT_SCRATCH + 15) & ~15) + 2 * 360 * 4 + 384);
+            if (t == 0) A.trials[f] = ret;
             // hard decisions of [0,K): 64 bits per wave step via ballot, MSB-first bytes (module_dvbs2_demod.cpp:357-360)
             uint8_t* __restrict__ hd = A.hard + (size_t)f * A.hard_stride;
             const int lane = t & 63;
@@ -600,13 +740,13 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                     dst[K + c] = post[K + 360 * i + jj];
                 }
             }
-        }
-        if (A.work_ctr) {
-            if (t == 0) s_flag[12] = (int)(gridDim.x + atomicAdd(A.work_ctr, 1u));
-            lds_barrier();
-            f = s_flag[12];
-        } else {
-            f += gridDim.x;
+            if (A.work_ctr) {
+                if (t == 0) s_flag[12] = (int)(gridDim.x + atomicAdd(A.work_ctr, 1u));
+                lds_barrier();
+                f = __builtin_amdgcn_readfirstlane(s_flag[12]);
+            } else {
+                f += gridDim.x;
+            }
         }
         __syncthreads();
     }
@@ -621,7 +761,9 @@ static hipError_t launch_split(const LdpcDeviceCode& C, const LdpcKernelArgs& A,
     auto kern = ldpc_split_kernel<MAXDEG>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(LDPC_SPLIT_T), lds, stream, C.d_split_layers, C.d_ents, C.d_split_atab, C.d_rows, C.split_npl, A);
+    LdpcKernelParams P;
+    P.A = A; P.layers = C.d_split_layers; P.ents = C.d_ents; P.atab = C.d_split_atab; P.rows = C.d_rows; P.npl = C.split_npl;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(LDPC_SPLIT_T), lds, stream, P);
     return hipGetLastError();
 }
 template <int MAXDEG>

@@ -19,6 +19,9 @@
 //           through per-row hand-off records (~85 cycles per chained row), four lanes per row of a deep narrow level structure, or a barrier per
 //           level.  A packed level costs a whole row update and a vector-memory round trip for its table entry (measured ~1 750 cycles,
 //           profiles/r05_ldpc_split_layers.txt), a walked one a few hundred: only shallow layers are worth packing.
+//       kind 2 (level passes): rows in lane order; pass l updates the rows of level l (whole conflict-free updates under an exec mask), a barrier between
+//           passes.  For the chain layers, whose levels are runs of consecutive rows, a wave works in one or two passes: ~1.3 row updates per wave and no
+//           special arithmetic, against ~1.8 for the chain walk's publish / record / join.
 //   * idle lanes (beyond the packed rows; rows 360..383 of a full layer) point every slot at scratch bytes behind the posteriors: they run
 //     the same instructions and store to bytes nobody reads -- no exec masking in the row update.  The missing previous parity bit of row 0
 //     of layer 0 points there too; its pseudo-layer carries a flag and the thread index.
@@ -35,10 +38,13 @@ constexpr int LDPC_SPLIT_SCRATCH = 64;         // scratch bytes behind the poste
 #ifndef LDPC_SPLIT_PACK_MAX_DEPTH
 #define LDPC_SPLIT_PACK_MAX_DEPTH 0            // layers with shared bits and up to this many levels are packed level by level; deeper ones keep the walks of ldpc_kernel.hip
 #endif
+#ifndef LDPC_SPLIT_PASS_MAX_DEPTH
+#define LDPC_SPLIT_PASS_MAX_DEPTH 5            // chain layers up to this many levels run as level PASSES (kind 2): rows in lane order, one whole-row update per level under the lanes' level mask
+#endif                                         // (a chain layer's levels are runs of consecutive rows: a wave takes part in one pass, two where a run ends inside it)
 
 struct LdpcSplitLayer {   // 16 bytes = one s_load_dwordx4
     uint32_t kind_nw;     // bits 0..7 kind, 8..15 active waves, 16..19 nc = shared links of the layer (slots 0..nc-1 of half 0), bit 20: holds row 0 of layer 0 (no previous parity bit)
-    uint32_t aux;         // kind 0: the half-1 thread of row 0 of layer 0 (bit 20); kind 1: chain step d; kind 3: levels; kind 6: index of the walk list in LdpcPlan::rows
+    uint32_t aux;         // kind 0: the half-1 thread of row 0 of layer 0 (bit 20); kind 1: chain step d; kinds 2, 3: levels; kind 6: index of the walk list in LdpcPlan::rows
     uint32_t rec_off;     // dword offset of the pseudo-layer's records inside a workgroup's message workspace
     uint32_t ent_off;     // kind 1: index of the layer's link entries in LdpcPlan::ents (the walker reads link 1's)
 };
@@ -62,7 +68,7 @@ inline int ldpc_split_npw(int hs) {
 }
 
 // which codes the half-row decoder takes: regular ones with an even number of links per row (both halves then hold the same number of slots)
-inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P, int pack_max_depth = LDPC_SPLIT_PACK_MAX_DEPTH) {
+inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P, int pack_max_depth = LDPC_SPLIT_PACK_MAX_DEPTH, int pass_max_depth = LDPC_SPLIT_PASS_MAX_DEPTH) {
     LdpcSplitPlan S;
     const int NL = P.max_deg + 2;
     if (P.min_deg != P.max_deg || (NL & 1) || NL / 2 > 16 || P.N + LDPC_SPLIT_SCRATCH > 65536) return S;
@@ -112,10 +118,9 @@ inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P, int pack_max_depth
                 }
                 w[s >> 1] |= a << (16 * (s & 1));
             }
-            if (j >= 0 && h == 0) {
-                S.row_of[rbase + pr] = j;
-                if (info) w[hs >> 1] |= ((*info)[pr] & 0xffffu) << (16 * (hs & 1));
-            }
+            if (j >= 0 && h == 0) S.row_of[rbase + pr] = j;
+            // the row word: kinds 3 / 6 in half 0 only (half 1 and idle lanes: 0, every condition on it false); kind 1: half 1 gets the level; kind 2: the level, in both halves
+            if (j >= 0 && info && (h == 0 || kind <= 2)) w[hs >> 1] |= ((*info)[pr] & (kind == 2 || h == 1 ? 0xffu : 0xffffu)) << (16 * (hs & 1));
         }
         S.layers.push_back(D);
         S.layer_of.push_back(i);
@@ -136,6 +141,7 @@ inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P, int pack_max_depth
                 info.push_back((rw & 0xffu) | (((rw >> 8) & 15u) << 8) | (((rw >> 20) & 15u) << 12));
             }
             if (chain == LDPC_WALK_MARK) emit(6, i, rows, &info, L.row_off + 360);
+            else if (chain != 0 && depth <= pass_max_depth) emit(2, i, rows, &info, (uint32_t)depth);
             else if (chain != 0) emit(1, i, rows, &info, chain);
             else emit(3, i, rows, &info, (uint32_t)depth);
             S.chain_layers++;

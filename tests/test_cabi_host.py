@@ -309,3 +309,70 @@ def test_ldpc_address_table_holds_the_links_of_every_row(pkg, rate, short):
     want = pos[:, :deg].astype(np.int64).reshape(q, 360, deg)
     assert np.array_equal(np.sort(a, axis=-1), np.sort(want, axis=-1))
     assert np.all(tab[:, 360:, :] == 0) and np.all(tab[:, :, npi:] == 0)
+
+
+@pytest.mark.parametrize('rate,short', [(r, s) for r, s in orc.ALL_CODES if not s])
+@pytest.mark.parametrize('pack,passes', [(-1, -1), (3, 0), (0, 5), (64, 0)])
+def test_ldpc_split_plan_keeps_the_reference_row_order(pkg, rate, short, pack, passes):
+    """the half-row decoder's plan (csrc/ldpc_split_plan.h), for the shipped settings and for the packed / level-pass alternatives: every row of every layer appears
+    exactly once, its table entry names exactly the bits the reference's row touches (information bits, own and previous parity bit), and two rows of a layer that
+    share a bit run in the reference's order -- separated by a barrier (different pseudo-layers) unless the pseudo-layer resolves shared links itself (kinds 1, 3, 6,
+    whose row words are the lane-per-row plan's, checked above) or masks its lanes by level (kind 2)"""
+    sp = pkg.ldpc_split_plan(rate, short, pack, passes)
+    p = orc.fec_params(rate, short)
+    N, K = p['N'], p['K']
+    R = N - K
+    q = R // 360
+    lib_o = orc.lib()
+    lib_o.orc_ldpc_rows.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    cnl = lib_o.orc_ldpc_rows(rate, short, None, None)
+    if sp is None:
+        return      # (an odd number of links per row, or layers with more than four shared links and no packing asked for: the lane-per-row decoder keeps the code)
+    pos = np.zeros((R, cnl), np.uint16); cn = np.zeros(R, np.uint8)
+    lib_o.orc_ldpc_rows(rate, short, pos.ctypes.data, cn.ctypes.data)
+    hs = sp['hs']
+    assert 2 * hs == cnl + 2
+    seen = np.zeros((q, 360), int)
+    last_touch = {}            # bit -> (pseudo-layer, layer, row) of its latest toucher, in execution order
+    for pl in range(sp['npl']):
+        i = int(sp['layer'][pl]); kind = int(sp['kind'][pl])
+        tab = sp['table'][pl]
+        rows_here = []
+        for pr in range(384):
+            j = int(sp['row_of'][pl, pr])
+            if j < 0:
+                for h in (0, 1):       # idle lanes: scratch bytes only
+                    a = [(int(tab[2 * pr + h, s >> 1]) >> (16 * (s & 1))) & 0xffff for s in range(hs)]
+                    assert all(N <= x < N + 64 for x in a)
+                continue
+            assert pr < 32 * int(sp['nw'][pl])
+            seen[i, j] += 1
+            addrs = []
+            for h in (0, 1):
+                addrs += [(int(tab[2 * pr + h, s >> 1]) >> (16 * (s & 1))) & 0xffff for s in range(hs)]
+            want = [int(x) for x in pos[360 * i + j, :cn[360 * i + j]]] + [K + 360 * i + j]
+            if i > 0: want.append(K + 360 * (i - 1) + j)
+            elif j > 0: want.append(K + 360 * (q - 1) + j - 1)
+            got = [a for a in addrs if a < N]
+            assert sorted(got) == sorted(want), (pl, i, j)
+            assert len(got) == len(addrs) or (i == 0 and j == 0 and sp['noprev'][pl])
+            rows_here.append((j, got))
+        lvl = None
+        if kind == 2:
+            lvl = {int(sp['row_of'][pl, pr]): (int(tab[2 * pr, hs >> 1]) >> (16 * (hs & 1))) & 0xff for pr in range(384) if sp['row_of'][pl, pr] >= 0}
+        within = {}
+        for j, bits in rows_here:
+            for b in bits:
+                if b in last_touch:
+                    pi, pj = last_touch[b]
+                    assert (pi, pj) < (i, j), (b, pi, pj, i, j)                      # the reference's order across pseudo-layers (a barrier lies between)
+                within.setdefault(b, []).append(j)
+        for b, js in within.items():
+            if len(js) > 1:                                                          # rows of ONE pseudo-layer share a bit: only where it orders shared links itself
+                assert kind in (1, 2, 3, 6), (pl, i, js)
+                if kind == 2:
+                    js = sorted(js)
+                    assert all(lvl[a] < lvl[c] for a, c in zip(js, js[1:]))
+        for j, bits in rows_here:
+            for b in bits: last_touch[b] = (i, j)
+    assert (seen == 1).all()

@@ -1,0 +1,63 @@
+"""The half-row LDPC decoder (csrc/ldpc_split_kernel.hip: two lanes per row, one frame per workgroup) is selected with DVBS2GPU_LDPC_SPLIT=1 for the normal
+frames it takes (rate 3/4); here it is FORCED on a fresh engine: posteriors, trial counts and hard decisions must equal the oracle's -- early exit, iteration
+limit, forced iterations, erasures, saturating garbage -- and many frames must flow through the persistent grid's work counter."""
+import os
+
+import numpy as np
+import pytest
+import orc
+from test_gpu_fec import MARGINAL_SNR, make_llrs, oracle_ldpc
+
+pytestmark = pytest.mark.gpu
+CODES = [(6, 0)]
+
+
+@pytest.fixture(scope='module')
+def split_engine(pkg):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    old = os.environ.get('DVBS2GPU_LDPC_SPLIT')
+    os.environ['DVBS2GPU_LDPC_SPLIT'] = '1'      # read when an engine first builds a code's plan
+    eng = pkg.Engine(0)
+    yield eng
+    eng.close()
+    if old is None:
+        os.environ.pop('DVBS2GPU_LDPC_SPLIT', None)
+    else:
+        os.environ['DVBS2GPU_LDPC_SPLIT'] = old
+
+
+@pytest.mark.parametrize('rate,short', CODES)
+def test_half_row_decoder_bit_exact(split_engine, pkg, rate, short):
+    import torch
+    assert pkg.ldpc_split_plan(rate, short) is not None
+    rng = np.random.default_rng(300 + rate)
+    m = MARGINAL_SNR[rate]
+    snrs = [m + 3.0, m + 0.6, m + 0.3, m, -8.0]
+    p, llr, _ = make_llrs(rate, short, 8, rng, snrs)
+    llr[0, ::7] = 0
+    llr[5] = rng.integers(-128, 128, size=p['N']).astype(np.int8)        # saturating garbage
+    for force, mt in ((0, 12), (1, 9), (0, 0), (0, 1)):
+        want_post, want_trials = oracle_ldpc(rate, short, llr, mt, force)
+        hard, trials, post = split_engine.ldpc_decode(torch.from_numpy(llr).cuda(), rate, bool(short), max_trials=mt, force=bool(force), want_post=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(trials.cpu().numpy(), want_trials), (force, mt)
+        assert np.array_equal(post.cpu().numpy(), want_post), (force, mt)
+        want_hard = np.packbits((want_post[:, :p['K']] < 0).astype(np.uint8), axis=1)
+        assert np.array_equal(hard.cpu().numpy(), want_hard), (force, mt)
+
+
+def test_half_row_decoder_many_frames(split_engine):
+    """more frames than resident workgroups: the work counter hands every frame to exactly one workgroup, every frame slot is reused with clean records"""
+    import torch
+    rate, short = 6, 0
+    rng = np.random.default_rng(19)
+    p, llr4, _ = make_llrs(rate, short, 4, rng, [MARGINAL_SNR[rate] + 0.5, -8.0])
+    reps = 300
+    llr = np.tile(llr4, (reps, 1))
+    want_post, want_trials = oracle_ldpc(rate, short, llr4, 5)
+    hard, trials, post = split_engine.ldpc_decode(torch.from_numpy(llr).cuda(), rate, False, max_trials=5, want_post=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(trials.cpu().numpy(), np.tile(want_trials, reps))
+    assert np.array_equal(post.cpu().numpy().reshape(reps, 4, -1), np.broadcast_to(want_post, (reps,) + want_post.shape))
