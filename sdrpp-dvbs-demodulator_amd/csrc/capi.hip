@@ -349,6 +349,8 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
     if (ctx->d_vcm_mods) (void)hipFree(ctx->d_vcm_mods);
     if (ctx->d_vcm_cons) (void)hipFree(ctx->d_vcm_cons);
     for (auto& w : ctx->ws_vcm) w.release();
+    for (auto& w : ctx->ws_mix) w.release();
+    for (auto& row : ctx->ev_mix) for (hipEvent_t& e : row) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (ctx->ev_ws) (void)hipEventDestroy(ctx->ev_ws);
     for (auto& sp : ctx->timers.pending) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (auto e : ctx->timers.pool) (void)hipEventDestroy(e);

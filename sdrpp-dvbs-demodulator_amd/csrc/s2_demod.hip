@@ -285,6 +285,7 @@ struct dvbs2gpu_demod {
     long long sym_base = 0;                  // symbols that have left the FIFO since the last reset
     int tap_sym_off = 0, tap_sym_cnt = 0, tap_fifo = 0;
     const cf32* tap_pll = nullptr;           // into ctx workspace, valid until the next call on this context
+    int tap_pll_stride = 0;                  // elements between the frames behind tap_pll (0: one frame behind the other; mixed batches keep every stream's frames in slots of the batch's longest PLFRAME)
     const int8_t* tap_llr = nullptr;
     std::vector<int> frame_len;              // ACM/VCM: PLFRAME length of each frame of the last call (CCM: empty = mp.plframe)
     long long tap_pll_count = -1, tap_llr_count = -1;   // ACM/VCM: element counts of the taps (frames differ in size)
@@ -679,6 +680,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         for (int i = 0; i < n; ++i) {
             int cnt = first[i + 1] - first[i];
             dm[i]->tap_pll = d_pll + (size_t)(staged ? (size_t)i * maxf : first[i]) * raw;
+            dm[i]->tap_pll_stride = 0;
             dm[i]->tap_llr = d_llr + (size_t)first[i] * N;
             int bytes = cnt * kb;
             if (bytes > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
@@ -886,7 +888,7 @@ int process_vcm_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const
         maxf = std::max(maxf, d->fifo_cap / VCM_DUMMY_PLFRAME + 2);
         if (!pipelined) d->stats.clear();
         d->frame_ptrs.clear(); d->frame_pos.clear(); d->frame_len.clear();
-        d->tap_pll = nullptr; d->tap_llr = nullptr; d->tap_pll_count = 0; d->tap_llr_count = 0;
+        d->tap_pll = nullptr; d->tap_llr = nullptr; d->tap_pll_count = 0; d->tap_llr_count = 0; d->tap_pll_stride = 0;
     }
     if ((rc = W[0].ensure(sizeof(S2StreamWork) * n + sizeof(int) * (n + 1) + sizeof(int) * 8 * n + sizeof(float) * n + 64))) return rc;
     S2StreamWork* d_work = (S2StreamWork*)W[0].p;
@@ -1193,15 +1195,18 @@ int process_mixed(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     std::map<std::tuple<int, int, int>, int> part_of;
     std::vector<int> first(n + 1, 0), fslot, frame_off, cur(n, 0), stream_bytes(n, 0);
     std::vector<S2FrameStats> hstats;
+    // (every capacity is checked before any handle's state is touched: a refused call leaves all receivers where they were)
+    for (int i = 0; i < n; ++i) {
+        if (cnts[4 * i + 2] > dm[i]->fifo_cap) { last_error() = "symbol FIFO overflow"; return DVBS2GPU_ERR_CAPACITY; }
+        if (cnts[4 * i] * (dm[i]->mp.fec.kbch / 8) > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
+    }
     for (int i = 0; i < n; ++i) {
         dvbs2gpu_demod* d = dm[i];
         const int nfi = cnts[4 * i], kb = d->mp.fec.kbch / 8;
         d->tap_sym_off = d->fifo_fill; d->tap_sym_cnt = cnts[4 * i + 3]; d->tap_fifo = d->fifo_cur;
         d->fifo_fill = cnts[4 * i + 2];
-        if (d->fifo_fill > d->fifo_cap) { last_error() = "symbol FIFO overflow"; return DVBS2GPU_ERR_CAPACITY; }
         cur[i] = cnts[4 * i + 1];
         first[i] = (int)fslot.size();
-        if (nfi * kb > out_cap) { last_error() = "output buffer too small"; return DVBS2GPU_ERR_CAPACITY; }
         const int force = d->cfg.force_ldpc_iters > 0, mt = force ? d->cfg.force_ldpc_iters : d->cfg.max_ldpc_trials;
         const auto key = std::make_tuple(d->mp.fec.code_index, mt, force);
         auto it = part_of.find(key);
@@ -1219,6 +1224,7 @@ int process_mixed(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         }
         stream_bytes[i] = nfi * kb;
         d->tap_pll = d_pll + (size_t)i * maxf * raw_max;
+        d->tap_pll_stride = raw_max;
         d->tap_llr = nullptr;
     }
     first[n] = (int)fslot.size();
@@ -1391,8 +1397,13 @@ int dvbs2gpu_demod_create(dvbs2gpu_ctx* ctx, const dvbs2gpu_demod_cfg* cfg, int 
 
 void dvbs2gpu_demod_destroy(dvbs2gpu_demod* d) {
     if (!d) return;
+    CallGuard guard(d->ctx);
     (void)hipSetDevice(d->ctx->device);
     (void)hipDeviceSynchronize();
+    // a pipelined FEC job still in flight names its streams by handle: this one leaves the lists, so that a handle created later at the same address is not taken
+    // for it (its frames are dropped at the collecting call, like those of any stream that has left the batch)
+    for (void* pj : d->ctx->pending_fec)
+        if (pj) for (auto& h : ((PendingFec*)pj)->dm) if (h == d) h = nullptr;
     (void)hipFree(d->d_state); if (d->d_in) (void)hipFree(d->d_in); (void)hipFree(d->d_fe);
     (void)hipFree(d->d_fifo[0]); (void)hipFree(d->d_fifo[1]); if (d->d_out) (void)hipFree(d->d_out);
     if (d->d_spec) (void)hipFree(d->d_spec);
@@ -1729,7 +1740,14 @@ int dvbs2gpu_demod_get_tap(dvbs2gpu_demod* d, int which, void* h_dst, int cap) {
                 return n;
             }
             int n = nf * raw;
-            if (h_dst && n && d->tap_pll) HIP_TRY(hipMemcpy(h_dst, d->tap_pll, sizeof(cf32) * std::min(n, cap), hipMemcpyDeviceToHost));
+            if (h_dst && n && d->tap_pll) {
+                if (d->tap_pll_stride > raw) {       // frames in slots wider than this stream's PLFRAME (mixed batches): frame by frame
+                    const int whole = std::min(nf, cap / raw);
+                    if (whole) HIP_TRY(hipMemcpy2D(h_dst, sizeof(cf32) * raw, d->tap_pll, sizeof(cf32) * d->tap_pll_stride, sizeof(cf32) * raw, whole, hipMemcpyDeviceToHost));
+                } else {
+                    HIP_TRY(hipMemcpy(h_dst, d->tap_pll, sizeof(cf32) * std::min(n, cap), hipMemcpyDeviceToHost));
+                }
+            }
             return n;
         }
         case 3: {

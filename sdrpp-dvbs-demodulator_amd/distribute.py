@@ -120,7 +120,7 @@ class Distributor:
         # verdict on the widths is COLLECTIVE (the smallest width of a rank that has rows travels as a negated maximum): every rank raises, or
         # none -- a rank that raised alone would leave the others waiting in the gathers below
         big = 1 << 40
-        nmax = torch.tensor([len(local_ids), width, -(width if len(local_ids) else big)], dtype=torch.int64, device=self.device)
+        nmax = torch.tensor([len(local_ids), width if len(local_ids) else 0, -(width if len(local_ids) else big)], dtype=torch.int64, device=self.device)      # (only ranks with rows vote on the width)
         self.dist.all_reduce(nmax, op=self.dist.ReduceOp.MAX)
         nmax, wmax, wmin = int(nmax[0].item()), int(nmax[1].item()), -int(nmax[2].item())
         if wmin != big and wmin != wmax:

@@ -352,20 +352,28 @@ def test_mixed_batch_of_all_four_constellations_with_and_without_pilots(engine):
     ref = []
     for s, (modcod, short, pilots) in enumerate(specs):
         d = engine.demod(engine.default_cfg(modcod, bool(short), bool(pilots)), max_samples=iqs[s].size)
-        ref.append([(np.concatenate([np.asarray(x).reshape(-1) for x in [d.process(parts(iqs[s], c))]] or [np.zeros(0, np.uint8)]),
-                     [(x.ldpc_trials, x.bch_corrections, x.detected_modcod, x.detected_pilots) for x in d.stats()]) for c in range(calls)])
+        r = []
+        for c in range(calls):
+            out = np.concatenate([np.asarray(x).reshape(-1) for x in [d.process(parts(iqs[s], c))]] or [np.zeros(0, np.uint8)])
+            r.append((out, [(x.ldpc_trials, x.bch_corrections, x.detected_modcod, x.detected_pilots) for x in d.stats()], d.tap(2).copy(), d.tap(3).copy()))
+        ref.append(r)
         d.close()
     dms = [engine.demod(engine.default_cfg(m, bool(sh), bool(p)), max_samples=iqs[s].size) for s, (m, sh, p) in enumerate(specs)]
     cap = max(d.info['kbch'] // 8 for d in dms) * 8
     tout = [torch.zeros(cap, dtype=torch.uint8, device='cuda') for _ in specs]
-    total = 0
+    total = multi = 0
     for c in range(calls):
         nb = engine.process_batch(dms, [torch.from_numpy(parts(iqs[s], c)).cuda() for s in range(len(specs))], tout)
         for s, d in enumerate(dms):
             assert np.array_equal(tout[s][:nb[s]].cpu().numpy(), ref[s][c][0]), (c, s, specs[s])
             assert [(x.ldpc_trials, x.bch_corrections, x.detected_modcod, x.detected_pilots) for x in d.stats()] == ref[s][c][1], (c, s, specs[s])
+            # the constellation / LLR taps of a stream of a mixed batch: every frame of the call, not just the first (the batch keeps the streams' frames in slots
+            # of its LONGEST PLFRAME)
+            assert same_bits(d.tap(2), ref[s][c][2]), (c, s, specs[s])
+            assert np.array_equal(d.tap(3), ref[s][c][3]), (c, s, specs[s])
             total += nb[s]
-    assert total > 40000
+            multi += len(ref[s][c][1]) > 1
+    assert total > 40000 and multi >= 4        # (calls with several frames per stream did occur)
     for d in dms:
         d.close()
 
@@ -871,6 +879,40 @@ def test_pipelined_batch_whose_streams_come_and_go(engine, pkg):
             else:
                 assert pipe[c][s][0].size == 0 and pipe[c][s][1] == [], (c, s)      # joined in this call: nothing pending
     assert all(v[0].size == 0 for v in pipe[0].values()) and frames >= 8
+
+
+def test_pipelined_handle_destroyed_and_recreated_between_two_calls(engine, pkg):
+    """throughput mode: a stream is closed while the FEC job of its last call is still pending, and a new handle is created right away (the allocator likes to hand
+    out the same address).  The new stream joins with NOTHING pending -- it must not inherit the closed stream's frames, byte count or statistics --, the streams
+    that stay get theirs"""
+    import torch
+    S, calls = 3, 4
+    iqs = [orc.transmit(11, 0, 0, nframes=calls, seed=900 + s, esn0_db=12.0, cfo=1e-3, timing=0.25, phase0=0.3)[0] for s in range(S + calls)]
+    kb = pkg.modcod_info(11, False, False)['kbch'] // 8
+    chunk = iqs[0].size // calls
+    cfg = engine.default_cfg(11, False, False)
+    demods = [engine.demod(cfg, max_samples=chunk) for _ in range(S)]
+    tout = [torch.zeros(4 * kb, dtype=torch.uint8, device='cuda') for _ in range(S)]
+    src = list(range(S)); fed = [0] * S
+    engine.set_pipelined(True)
+    try:
+        got_frames = 0
+        for c in range(calls):
+            tin = [torch.from_numpy(iqs[src[k]][fed[k] * chunk:(fed[k] + 1) * chunk]).cuda() for k in range(S)]
+            nb = engine.process_batch(demods, tin, tout)
+            for k in range(S): fed[k] += 1
+            if c >= 1:
+                assert nb[S - 1] == 0 and demods[S - 1].stats() == [], (c, nb)       # the handle created after the previous call: nothing pending
+                got_frames += sum(nb[:S - 1])
+            # the last stream leaves with its job in flight; its successor takes its place (and, usually, its address)
+            demods[S - 1].close()
+            demods[S - 1] = engine.demod(cfg, max_samples=chunk)
+            src[S - 1] = S + c; fed[S - 1] = 0
+        assert got_frames >= 2 * kb
+    finally:
+        engine.set_pipelined(False)
+        for d in demods:
+            d.close()
 
 
 @pytest.mark.parametrize('modcod,short,pilots,esn0,flags', [(14, 1, 1, 12.0, dict(pilot_aided=1)), (27, 1, 1, 18.0, dict(pilot_aided=1, soft_plsc=1)),
