@@ -292,7 +292,8 @@ def cpu_baseline(block_iq, budget_s=12.0):
     nsym, tfe = run_threads(fe, budget_s * 0.4)
     fe_sym_per_s = nsym / tfe
     t_per_sym = 1.0 / fe_sym_per_s + 1.0 / (fec_frames_per_s * sym_per_frame)
-    out = dict(value=round(1e-6 / t_per_sym, 4), unit='Msymbols/s', cores=ncpu, kind=kind, cpu_model=model, physical_cores=phys, logical_cpus=ncpu,
+    # kind: what the FEC leg ran (the ~97 % of the CPU time); the front-end leg is always the oracle restatement (SDR++ / VOLK are not available: unbuildable here)
+    out = dict(value=round(1e-6 / t_per_sym, 4), unit='Msymbols/s', cores=ncpu, kind=kind, kind_fec=kind, kind_frontend='port', cpu_model=model, physical_cores=phys, logical_cpus=ncpu,
                compiler_flags=flags or 'oracle: g++ -std=c++17 -O3 -ffp-contract=off',
                sample='%d threads (one per logical CPU): FEC leg %d frames in %.1f s (%s LDPC 50 it + repack + BCH + descramble, persistent decoder '
                       'objects = %.3f Msym/s), front-end leg %d symbols in %.1f s (oracle AGC..demap = %.3f Msym/s); per-symbol times added'

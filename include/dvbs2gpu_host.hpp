@@ -104,12 +104,14 @@ public:
             detected_modcod = s.detected_modcod; detected_shortframes = s.detected_shortframes != 0; detected_pilots = s.detected_pilots != 0;
             pl_sync_best_match = s.pl_sync_best_match; ldpc_trials = (float)s.ldpc_trials; bch_corrections = (float)s.bch_corrections;
         }
-        if (d_handler) {
+        if (d_handler && k > 0) {
+            // module_dvbs2_demod.cpp:337: the handler is called once per PL frame, with that frame's header + payload (+ pilot) symbols behind the PLL
             const int ns = dvbs2gpu_demod_get_tap(h, 2, nullptr, 0);
-            if (ns > 0) {
+            if (ns > 0 && ns % k == 0) {
                 tap.resize((size_t)ns);
                 dvbs2gpu_demod_get_tap(h, 2, tap.data(), ns);
-                d_handler(tap.data(), ns, d_ctx);
+                const int per = ns / k;
+                for (int f = 0; f < k; ++f) d_handler(tap.data() + (size_t)f * per, per, d_ctx);
             }
         }
         return n;

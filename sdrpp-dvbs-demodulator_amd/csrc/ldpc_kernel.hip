@@ -17,9 +17,12 @@
 //   * arithmetic: packed int16 ("Q8", two links per VALU instruction) with the int8 saturation rules of the reference's
 //     SIMD lanes; the syndrome check before an iteration works on bit-packed sign vectors (quasi-cyclic: a layer's 360
 //     syndromes are XORs of cyclic shifts of 360-bit groups).
-// Roofline: algorithmic bytes per frame = iters*4*edges + N + K/8 against HBM 8 TB/s is the NOMINAL figure; real
-// HBM traffic is ~N + K/8 per frame because the state is on-chip -- the kernel is bound by VALU issue and by the latency of
-// its serial sections (profiles/).
+// Roofline: algorithmic bytes per frame = iters*4*edges + N + K/8 against HBM 8 TB/s is the NOMINAL figure; the
+// state is on-chip (LDS + Infinity Cache: 26 MB of fabric traffic per frame, 0.58 x the algorithmic bytes).  What the kernel
+// spends is VECTOR-ALU time: its packed 16-bit / VOP3 / SDWA / DPP instructions issue at half the rate of plain 32-bit ones
+// (4.3 against 2.3 cycles per wave instruction and SIMD, profiles/r05_valu_rates.txt): 1.53e10 of them per 4096 frames x 50
+// iterations keep the SIMDs busy for 57 % of the launch; the rest is the latency of a layer's barrier-separated phases with
+// twelve waves per compute unit.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "ldpc_lane_common.h"
@@ -60,7 +63,7 @@ namespace s2 {
 #ifndef LDPC_ADDR_TABLE
 #define LDPC_ADDR_TABLE 1   // regular codes of degree 2, 8 and 12 (ldpc_plan.h: ldpc_atab_degree): the LDS addresses of a row's links come from a per-code table [layer][row][pair] (two 16-bit
                             // addresses per word, fetched a layer ahead like the message record) instead of four packed VALU operations per pair:
-                            // the kernel is bound by VALU issue (60 % alone, more with the front end beside it), vector memory instructions are free there
+                            // four half-rate vector instructions per pair (17 SIMD cycles) against 4 bytes per lane through the 64 B/clk vector-memory path (measured per kernel below)
 #endif
 // (measured per kernel, 4096 frames x 50 iterations: degree 12 (3/4) 44.1 -> 42.5 ms, degree 8 (2/3) 42.1 -> 39.6, degree 2 (1/4) 38.0 -> 36.1; the
 // kernels of degree 3, 4, 5 and 9 -- many short layers: the fetch a layer ahead no longer hides behind the layer -- LOSE 8-23 % and keep the arithmetic)
