@@ -299,3 +299,54 @@ def test_dvbs_segment_receiver_returns_one_continuous_bit_stream(pkg, engine, ra
     errs = int(np.count_nonzero((got[skip:skip + n] ^ inv) != ref[off:off + n]))
     assert errs <= 8, (errs, n, off, inv)                # one bit stream: a slip anywhere would make half of the rest differ
     assert n >= ref.size - off - 3 * 8192, (n, ref.size, off)
+
+
+def test_dvbs_bank_of_4096_carriers_equals_the_oracle_on_sampled_streams(engine, pkg):
+    """the receiver bank at the bench's size (4096 carriers: four-streams-per-wave FLL, time-sliced front end, every stage kernel co-resident with the others'
+    slices): sixteen sampled carriers go through the CPU restatement of DVBSDemod::process' receive side (module_dvbs_demod.cpp:78-117: QPSK_ALT front end,
+    slicer, self-locking Viterbi) with the same inputs, call by call -- decoded bits, symbols and loop state of those carriers must be the oracle's, bit for bit"""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    S, D, calls, chunk = 4096, 8, 3, 16384
+    base = [od.dvbs_iq(r % 5, chunk * calls // 2, seed=80 + r, esn0_db=11.0, cfo=(r - 3) * 4e-4, timing=0.11 * r, phase0=0.3 * r)[0] for r in range(D)]
+    n = base[0].size
+    d_base = [torch.from_numpy(b).cuda() for b in base]
+    shift = lambda s: 2 * ((s // D) * 977 % (n // 2))
+    iq = torch.empty((S, n), dtype=torch.complex64, device='cuda')
+    for s in range(S):
+        iq[s] = torch.roll(d_base[s % D], shift(s))
+    bank = pkg.DvbsDemodBank(engine, S, max_samples=chunk)
+    tout = [torch.zeros(4 * 8192 + chunk, dtype=torch.uint8, device='cuda') for _ in range(S)]
+    sample = [0, 1, 7, 8, 9, 255, 256, 1000, 2047, 2048, 2049, 3000, 3333, 4000, 4094, 4095]
+
+    def oracle_stream(s):
+        x = np.roll(base[s % D], shift(s))
+        rx = od.OracleQpskAlt()
+        o = od.L()
+        sl = od.VP(o.orc_dvbs_slicer_create())
+        vit = od.OracleViterbi()
+        out = []
+        for c in range(calls):
+            sy = np.ascontiguousarray(rx.process(x[c * chunk:(c + 1) * chunk]))
+            soft = np.zeros(2 * sy.size + 8192, np.int8)
+            k = o.orc_dvbs_slicer_process(sl, sy.size, od.P(sy), od.P(soft))
+            bits = []
+            if k:
+                eb, en, es = vit.work(soft[:k].reshape(-1, 8192))
+                bits = [eb[b, :en[b]] for b in range(len(en))]
+            out.append((np.concatenate(bits) if bits else np.zeros(0, np.uint8), sy, rx.state().copy()))
+        return out
+
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        want = dict(zip(sample, ex.map(oracle_stream, sample)))
+    nbits = 0
+    for c in range(calls):
+        nb = bank.process_batch([iq[s, c * chunk:(c + 1) * chunk] for s in range(S)], tout)
+        for s in sample:
+            bits, sy, st = want[s][c]
+            assert np.array_equal(bank.symbols(s).view(np.uint32), sy.view(np.uint32)), ('symbols', c, s)
+            assert np.array_equal(bank.loop_state(s).view(np.uint32), st.view(np.uint32)), ('loop state', c, s)
+            assert nb[s] == bits.size and np.array_equal(tout[s][:nb[s]].cpu().numpy(), bits), ('decoded bits', c, s)
+            nbits += bits.size
+    assert nbits > 16 * 8192
+    bank.close()

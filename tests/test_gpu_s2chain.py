@@ -468,6 +468,44 @@ def test_pipelined_full_load_every_stream_bit_exact(engine, pkg):
         assert bool(((out_s == out_p) | ~valid).all()), k
         assert chk_p['delivered'] >= S * F - S // 8 and chk_p['equal'] >= 0.95 * chk_p['delivered'] and chk_p['out_of_order'] == 0, chk_p
 
+    # ORACLE spot check under that load: sixteen of the 2048 streams go through the CPU restatement of DVBS2Demod::process (module_dvbs2_demod.cpp:216-372) with
+    # the same inputs, call by call; what the pipelined engine delivered for them -- while the decoder and the whole bank's front end shared the compute units --
+    # must be the oracle's BBFRAMEs byte for byte (front end incl. loop state across 15 calls, demapper, 50 forced LDPC iterations, BCH, descrambler)
+    from concurrent.futures import ThreadPoolExecutor
+    sample = [0, 1, 63, 64, 65, 127, 128, 500, 777, 1000, 1023, 1024, 1535, 2000, 2046, 2047]
+    ref_run = B.S2Run(engine, pkg, torch.device('cuda', 0), B.MODCOD, B.SHORT, B.PILOTS, 14.0, S, F, 16, seed=5)      # (the same inputs: seeded)
+    blocks = {s: ref_run.iq[s].cpu().numpy() for s in sample}
+    kb, N = ref_run.kb, ref_run.info['ldpc_n']
+    ref_run.close()
+    rate = pkg.modcod_info(B.MODCOD, bool(B.SHORT), bool(B.PILOTS))['rate']
+    assert rate == B.RATE
+
+    def oracle_stream(s):
+        rx = orc.OracleRx(orc.default_cfg(B.MODCOD, B.SHORT, B.PILOTS, force_ldpc_iters=-1))      # (-1: the front end alone; the FEC of the compared calls follows below)
+        kept = []
+        for c in range(calls):
+            rx.process(blocks[s])
+            if c >= calls - 3:
+                llr = rx.tap(3).reshape(-1, N)
+                frames = np.zeros((len(llr), kb), np.uint8)
+                for f in range(len(llr)):
+                    corr = np.zeros(1, np.int32)
+                    x = llr[f].copy()
+                    orc.lib().orc_fec_decode_frame(rate, B.SHORT, x, B.ITERS, 1, frames[f], corr)
+                kept.append(frames)
+        return kept
+
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        want = dict(zip(sample, ex.map(oracle_stream, sample)))
+    compared = 0
+    for k in range(3):
+        nb_p, out_p, _ = pipe[k + 1]
+        for s in sample:
+            got = out_p[s][:int(nb_p[s])].cpu().numpy().reshape(-1, kb)
+            assert got.shape == want[s][k].shape and np.array_equal(got, want[s][k]), ('oracle vs pipelined engine under full load', k, s)
+            compared += len(got)
+    assert compared >= 3 * len(sample) * (F - 1)
+
 
 def test_every_qpsk_and_8psk_modcod_in_one_mixed_batch(engine, pkg):
     """MODCODs 1..17 with normal and short frames (9/10 has no short frame) as 32 streams of ONE batch: every LDPC code of both
