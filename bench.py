@@ -596,9 +596,15 @@ def mixed64(eng, pkg, dev, dd, steps, warmup, nt=64, sub=64, F=1):
     dt_ranks = dd.all_over_ranks(t_steps_done - t0)
     # egress check: every unit's frames are transmitted frames of ITS transponder (input order restored by the gather)
     bad = delivered = 0
+    digest = None
     if dd.rank == dd.egress:
+        import hashlib
         host = g_out.cpu().numpy()
         cnt = g_cnt.cpu().numpy()
+        h = hashlib.sha256()
+        for u in range(n_units):          # what the egress rank holds after the last step, in transponder order: equal for every number of ranks
+            h.update(np.int32(cnt[u]).tobytes()); h.update(host[u, :cnt[u]].tobytes())
+        digest = h.hexdigest()
         all_sent = {}
         for t in range(nt):
             e = table[t]
@@ -627,7 +633,7 @@ def mixed64(eng, pkg, dev, dd, steps, warmup, nt=64, sub=64, F=1):
            'ms_per_step_rank_max_min': [round(max(dt_ranks) / steps * 1e3, 2), round(min(dt_ranks) / steps * 1e3, 2)],
            'modcods_per_rank': [sorted({table[i]['modcod'] for i in a}) for a in assign],
            'collectives': 'broadcast of table + configuration from rank 0; per step a gather of BBFRAMEs + byte counts to the egress rank 0 (in the timed region)',
-           'frames_at_egress_last_step': delivered, 'frames_not_transmitted_ones': bad}
+           'frames_at_egress_last_step': delivered, 'frames_not_transmitted_ones': bad, 'egress_sha256': digest}
     return res
 
 

@@ -66,3 +66,28 @@ def test_bench_gpus_2_starts_two_ranks_by_itself():
     line = lines[0]
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0
     assert line['config']['frames_delivered_checked'] > 0
+
+
+@pytest.mark.gpu
+def test_config4_sharded_over_two_ranks_delivers_what_one_rank_delivers():
+    """BASELINE config 4 (independent transponders, main.cpp:588,595) on the real engine with TWO ranks: table + configuration broadcast from rank 0, the MODCOD-grouped
+    weighted assignment, every rank's receivers, the per-step gather of BBFRAMEs + byte counts to the egress rank -- and what the egress rank holds, in transponder
+    order, must be byte for byte what ONE rank delivers for the same table (both ranks share the box's one device; gloo carries the collectives)"""
+    def run(gpus):
+        env = dict(os.environ, DVBS2GPU_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', 'mixed64', '--gpus', str(gpus), '--mixed-sub', '2', '--mixed-frames', '1',
+                            '--steps', '2', '--warmup', '1'], env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith('{')]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return lines[0]
+    two, one = run(2), run(1)
+    m2, m1 = two['mixed64'], one['mixed64']
+    assert two['n_gpus'] == 2 and m2['n_gpus'] == 2 and m2['scaling'] == 'strong'
+    assert len(m2['transponders_per_rank']) == 2 and min(m2['transponders_per_rank']) > 0 and sum(m2['transponders_per_rank']) == 64
+    # (frames that are not transmitted ones: carriers whose loops had not settled or slipped at these Es/N0 -- the same ones whatever the number of ranks)
+    assert m2['frames_not_transmitted_ones'] == m1['frames_not_transmitted_ones'] <= m1['frames_at_egress_last_step'] // 16
+    assert m2['frames_at_egress_last_step'] == m1['frames_at_egress_last_step'] >= 100
+    assert m2['egress_sha256'] == m1['egress_sha256'] and m2['egress_sha256']
