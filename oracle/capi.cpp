@@ -145,6 +145,13 @@ int orc_s2rx_tap(void* h, int which, void* dst) {
     return -1;
 }
 float orc_s2rx_nco_freq(void* h) { return ((S2Rx*)h)->nco_freq(); }
+// tools/pll_tile_study.py: passes-per-tile histogram of the parallel-in-time form of the payload PLL (34 bins) + tiles whose fixed point differed from the serial loop
+void orc_s2rx_pll_study(void* h, int tile, long long* hist34, long long* mismatch) {
+    S2Rx* r = (S2Rx*)h;
+    if (hist34) for (int i = 0; i < 34; ++i) hist34[i] = r->study_hist[i];
+    if (mismatch) *mismatch = r->study_mismatch;
+    r->study_tile = tile;
+}
 float orc_s2rx_agc_gain(void* h) { return ((S2Rx*)h)->agc_gain_now(); }   // (tools/sensitivity.py: level at the AGC output = gain x input rms)
 
 // stage-level entry points on a receiver object (state carried inside it)

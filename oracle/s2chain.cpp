@@ -502,7 +502,9 @@ void S2Rx::pll(const cf* in, cf* out, const FrameCtx& fc) {   // dvbs2_pll.cpp:3
         }
         acc = cf{0, 0};
     };
+    Pcl pcl90;
     for (int i = 0; i < total; i++) {
+        if (i == 90) pcl90 = pll_pcl;
         cf tmp_val = cmul(in[i], phasor(-pll_pcl.phase));
         float error = 0;
         bool block_end = false;
@@ -534,6 +536,46 @@ void S2Rx::pll(const cf* in, cf* out, const FrameCtx& fc) {   // dvbs2_pll.cpp:3
         }
         pll_pcl.advance(error);
         if (block_end) snap();
+    }
+    if (study_tile > 0 && !(mp.pilots && mp.pilot_blocks > 0) && !cfg.pilot_aided) {
+        const Pcl end = pll_pcl;
+        pll_tile_study(in, fc, pcl90);
+        pll_pcl = end;
+    }
+}
+
+// The payload loop (dvbs2_pll.cpp:81: freq += beta e, clamp, phase += freq + alpha e, wrap) in tiles: what a symbol contributes, e[k], depends on the loop
+// phase at that symbol only (rotation, LUT cell).  Per tile: evaluate e[k] for ALL symbols from guessed phases (pass 1: the phase at the tile's start advanced by
+// the frequency alone), replay the recurrence over the tile with those e[k] in the reference's order, evaluate again from the replayed phases ... until a replay
+// reproduces the phases its errors were evaluated at.  By induction over k that fixed point IS the serial result (phase[0] is exact; exact phase[k] gives exact
+// e[k], hence exact phase[k + 1]).  This routine counts the evaluation passes per tile and checks the fixed point against the serial loop.
+void S2Rx::pll_tile_study(const cf* in, const FrameCtx& fc, Pcl p0) {
+    const Constellation& constel = *fc.constel;
+    const int total = fc.mp.plframe, T = study_tile;
+    Pcl truth = p0;
+    std::vector<float> ph(T + 1), ph2(T + 1), e(T);
+    for (int base = 90; base < total; base += T) {
+        const int n = std::min(T, total - base);
+        // serial truth over the tile
+        Pcl st = truth;
+        for (int k = 0; k < n; ++k) { float err = 0; constel.soft_lut(cmul(in[base + k], phasor(-st.phase)), nullptr, &err); st.advance(err); }
+        // fixed point
+        Pcl g = truth;
+        for (int k = 0; k < n; ++k) { ph[k] = g.phase; g.advance(0.f); }
+        int passes = 0;
+        Pcl r;
+        for (;;) {
+            ++passes;
+            for (int k = 0; k < n; ++k) { float err = 0; constel.soft_lut(cmul(in[base + k], phasor(-ph[k])), nullptr, &err); e[k] = err; }
+            r = truth;
+            bool same = true;
+            for (int k = 0; k < n; ++k) { ph2[k] = r.phase; same &= (ph2[k] == ph[k]); r.advance(e[k]); }
+            if (same || passes >= 33) break;
+            std::swap(ph, ph2);
+        }
+        study_hist[passes < 33 ? passes : 33]++;
+        if (r.phase != st.phase || r.freq != st.freq) study_mismatch++;
+        truth = st;
     }
 }
 

@@ -114,6 +114,11 @@ public:
     std::vector<cf> dbg_symbols;        // 1-sps symbols entering PL sync
     std::vector<cf> dbg_frames;         // aligned raw PL frames
     std::vector<cf> dbg_pll;            // PLL output per frame (header un-rotated + descrambled payload)
+    // study of a parallel-in-time form of the payload PLL (tools/pll_tile_study.py): tile size (0 = off) and the histogram of evaluation
+    // passes per tile the fixed-point scheme would need (index = passes, last = more); every tile's result is checked against the serial loop
+    int study_tile = 0;
+    long long study_hist[34] = {};
+    long long study_mismatch = 0;
     std::vector<int8_t> dbg_llr;        // deinterleaved LLRs per frame
     std::vector<FrameStats> dbg_stats;
     float nco_freq() const { return nco_freq_; }
@@ -156,6 +161,7 @@ public:
     void rrc_filter(int n, const cf* in, cf* out);
     float coarse_fed(const cf* frame) const { return coarse_fed(frame, ccm); }
     void pll(const cf* frame, cf* out) { pll(frame, out, ccm); }
+    void pll_tile_study(const cf* in, const FrameCtx& fc, Pcl pcl_at_payload_start);
     void plhdr(const cf* frame, cf* out, int* modcod, int* sh, int* pil) { plhdr(frame, out, modcod, sh, pil, ccm.mp.plframe); }
     void to_soft(const cf* pllout, int8_t* llr) const { to_soft(pllout, llr, ccm); }
     float coarse_fed(const cf* frame, const FrameCtx& fc) const;
