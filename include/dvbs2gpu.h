@@ -42,6 +42,10 @@ const char* dvbs2gpu_last_error(void);
 /* Create a context on HIP device `device`.  Fails with DVBS2GPU_ERR_NODEVICE when no GPU is present. */
 int dvbs2gpu_create(int device, dvbs2gpu_ctx** out);
 void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx);
+/* Development / test options of a context (which of several bit-identical flows runs, time slicing, side streams ...; DESIGN.md section 11 lists them).  The same
+ * pairs can be given as DVBS2GPU_OPTIONS="name=value,name=value" in the environment when the context is created -- the one variable the library reads.  Options that
+ * choose a decoder plan (ldpc_wave, ldpc_split) must be set before the first frame of the code is decoded.  The reference has no counterpart (its behaviour is the default). */
+int dvbs2gpu_set_option(dvbs2gpu_ctx* ctx, const char* name, int value);
 
 /* Static parameter queries (no GPU needed).  Mirrors get_dvbs2_cfg (modcod_to_cfg.cpp:5-140),
  * BBFrameBCH::BBFrameBCH (bbframe_bch.cpp:39-161) and the PLFRAME size of dvbs2_pl_sync.cpp:14-31. */

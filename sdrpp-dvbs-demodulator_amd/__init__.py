@@ -67,6 +67,7 @@ PROTOTYPES = {
     'dvbs2gpu_destroy': (None, [_vp]),
     'dvbs2gpu_modcod_info_get': (_i, [_i, _i, _i, C.POINTER(ModcodInfo)]),
     'dvbs2gpu_fec_info_get': (_i, [_i, _i, C.POINTER(ModcodInfo)]),
+    'dvbs2gpu_set_option': (_i, [_vp, C.c_char_p, _i]),
     'dvbs2gpu_ldpc_plan_dump': (_i, [_i, _i, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
     'dvbs2gpu_ldpc_plan_info': (_i, [_vp, _i, _i, C.POINTER(C.c_int32)]),
     'dvbs2gpu_ldpc_wave_plan_dump': (_i, [_i, _i, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
@@ -207,7 +208,8 @@ def _ptr(t):
 class Engine:
     """One engine context on one GPU.  All tensor arguments are torch CUDA tensors on that GPU."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, options=None):
+        """options: development / test options of the context, {name: int} (dvbs2gpu_set_option)"""
         import torch
         self.torch = torch
         self.lib = load_library()
@@ -217,6 +219,11 @@ class Engine:
         h = C.c_void_p()
         self._check(self.lib.dvbs2gpu_create(int(device), C.byref(h)))
         self.h = h
+        for name, value in (options or {}).items():
+            self.set_option(name, value)
+
+    def set_option(self, name, value):
+        self._check(self.lib.dvbs2gpu_set_option(self.h, str(name).encode(), int(value)))
 
     def close(self):
         if getattr(self, 'h', None):

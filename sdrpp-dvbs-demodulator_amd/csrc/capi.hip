@@ -41,6 +41,31 @@ static int stage_enter(dvbs2gpu_ctx* ctx, hipStream_t st) {
     return ws_acquire(ctx, st);
 }
 
+// the development / test options of a context: one table for the environment variable and the entry point
+int apply_option(dvbs2gpu_ctx* c, const char* name, int v) {
+    const std::string n(name);
+    auto in = [v](int lo, int hi) { return v >= lo && v <= hi; };
+    if (n == "ldpc_wave") { if (!in(-1, 1)) return -1; c->ldpc_wave = v; }
+    else if (n == "ldpc_split") { if (!in(0, 1)) return -1; c->ldpc_split = v; }
+    else if (n == "gardner_form") { if (!(v == 0 || v == 1 || v == 2 || v == 4)) return -1; c->gardner_form = v; }
+    else if (n == "gardner_cand_skew") { c->gardner_cand_skew = v; }
+    else if (n == "fe_slices") { if (!in(0, s2::S2_FE_MAX_SLICES)) return -1; c->fe_slices = v; }
+    else if (n == "stage_pipeline") { if (!in(0, 2)) return -1; c->stage_pipeline = v; }
+    else if (n == "stage_post_stream") { if (!in(0, 2)) return -1; c->stage_post_stream = v; }
+    else if (n == "stage_loops") { if (!in(0, s2::S2_FE_MAX_SLICES)) return -1; c->stage_pipeline_launches = v; }
+    else if (n == "stage_min_duty") { if (!in(-1, 8)) return -1; c->stage_pipeline_min_duty = v; }
+    else if (n == "loops_ahead") { if (!in(0, 1)) return -1; c->loops_ahead = v; }
+    else if (n == "mixed_groups") { if (!in(0, 1)) return -1; c->mixed_groups = v; }
+    else if (n == "mix_fec_streams") { if (!in(1, 8)) return -1; c->mix_fec_streams = v; }
+    else if (n == "g_prio_duty") { if (!in(-1, 8)) return -1; if (v < 0) c->g_prio_auto = true; else { c->g_prio_duty = v; c->g_prio_auto = false; } }
+    else if (n == "dvbs_fe_slices") { if (!in(1, s2::DVBS_FE_MAX_SLICES)) return -1; c->dvbs_fe_slices = v; }
+    else if (n == "dvbs_bank_min") { if (v < 1) return -1; c->dvbs_bank_min = v; }
+    else if (n == "dvbs_agc_stream") { if (!in(0, 1)) return -1; c->dvbs_agc_stream = v != 0; }
+    else if (n == "host_timing") { if (!in(0, 1)) return -1; c->host_timing = v; }
+    else return -1;
+    return 0;
+}
+
 // every device table of one code (hipFree(nullptr) is a no-op)
 void free_ldpc_code(LdpcDeviceCode& D) {
     (void)hipFree(D.d_layers); (void)hipFree(D.d_ents); (void)hipFree(D.d_rows); (void)hipFree(D.d_atab);
@@ -67,10 +92,9 @@ int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
         if (P.N > 16200 && ldpc_split_supported(P.max_deg)) {
             // the half-row decoder (ldpc_split_plan.h / ldpc_split_kernel.hip) for the normal frames it takes: NOT the default -- alone it equals the lane-per-row
             // decoder (338 vs 337 ms per 32 768 frames of rate 3/4 at the 64 registers that leave room for a front-end wave, 321 at 80), beside the front end of the
-            // pipelined mode it loses (370 vs 342 ms: its 24 waves per compute unit use the vector issue slots the front end otherwise gets for free).  DVBS2GPU_LDPC_SPLIT=1
+            // pipelined mode it loses (370 vs 342 ms: its 24 waves per compute unit use the vector issue slots the front end otherwise gets for free).  the context option ldpc_split = 1
             // selects it (the parity tests run both decoders); DESIGN.md section 5 has the measurements.
-            const char* e = getenv("DVBS2GPU_LDPC_SPLIT");
-            if (e && atoi(e) != 0) {
+            if (ctx->ldpc_split) {
                 const LdpcSplitPlan SP = build_ldpc_split_plan(P);
                 if (SP.ok) {
                     if ((rc = upload(SP.layers, &D.d_split_layers))) return fail(rc);
@@ -83,14 +107,13 @@ int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
         }
         if (P.N <= 16200) {
             // short frames also get the wave-per-frame plan; which decoder serves the code: ldpc_wave_default() (measured per code),
-            // DVBS2GPU_LDPC_WAVE=0|1 in the environment forces one (development aid / the parity tests run both)
+            // the context option ldpc_wave = 0 | 1 forces one (development aid / the parity tests run both)
             const LdpcWavePlan W = build_ldpc_wave_plan(P);
             D.wave_lw = W.lw; D.wave_nsteps = W.nsteps; D.wave_nl_min = W.nl_min; D.wave_absent_base = W.absent_base;
             if ((rc = upload(W.lanec, &D.d_wave_lanec))) return fail(rc);
             if ((rc = upload(W.steps, &D.d_wave_steps))) return fail(rc);
             if ((rc = upload(W.layer_end, &D.d_wave_layer_end))) return fail(rc);
-            const char* e = getenv("DVBS2GPU_LDPC_WAVE");
-            D.use_wave = e ? atoi(e) != 0 : ldpc_wave_default(code_index);
+            D.use_wave = ctx->ldpc_wave >= 0 ? ctx->ldpc_wave != 0 : ldpc_wave_default(code_index);
         }
         it = ctx->ldpc.emplace(code_index, D).first;
     }
@@ -314,18 +337,33 @@ int dvbs2gpu_create(int device, dvbs2gpu_ctx** out) {
     dvbs2gpu_ctx* c = new dvbs2gpu_ctx();
     c->device = device;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char* v = getenv("DVBS2GPU_G_PRIO_DUTY")) { int k = atoi(v); if (k >= 0 && k <= 8) { c->g_prio_duty = k; c->g_prio_auto = false; } }
-    if (const char* v = getenv("DVBS2GPU_DVBS_BANK_MIN")) { int k = atoi(v); if (k >= 1) c->dvbs_bank_min = k; }
-    if (const char* v = getenv("DVBS2GPU_DVBS_AGC_STREAM")) c->dvbs_agc_stream = atoi(v) != 0;
-    if (const char* v = getenv("DVBS2GPU_DVBS_FE_SLICES")) { int k = atoi(v); if (k >= 1 && k <= s2::DVBS_FE_MAX_SLICES) c->dvbs_fe_slices = k; }
-    if (const char* v = getenv("DVBS2GPU_STAGE_PIPELINE")) c->stage_pipeline = atoi(v);
-    if (const char* v = getenv("DVBS2GPU_STAGE_POST_STREAM")) c->stage_post_stream = atoi(v);   // (2: in the pipelined mode too)
-    if (const char* v = getenv("DVBS2GPU_STAGE_LOOPS")) c->stage_pipeline_launches = atoi(v);
-    if (const char* v = getenv("DVBS2GPU_STAGE_MIN_DUTY")) c->stage_pipeline_min_duty = atoi(v);
-    if (const char* v = getenv("DVBS2GPU_FE_SLICES")) { int k = atoi(v); if (k >= 1 && k <= s2::S2_FE_MAX_SLICES) c->fe_slices = k; }   // (A/B switch)
+    // development / test options: DVBS2GPU_OPTIONS="name=value,name=value" in the environment -- the ONE variable the library reads -- or dvbs2gpu_set_option()
+    if (const char* v = getenv("DVBS2GPU_OPTIONS")) {
+        std::string all(v);
+        size_t pos = 0;
+        while (pos < all.size()) {
+            size_t end = all.find(',', pos);
+            if (end == std::string::npos) end = all.size();
+            const std::string item = all.substr(pos, end - pos);
+            const size_t eq = item.find('=');
+            if (eq == std::string::npos || s2::apply_option(c, item.substr(0, eq).c_str(), atoi(item.c_str() + eq + 1)) != 0) {
+                g_err = "DVBS2GPU_OPTIONS: unknown option or value out of range: " + item;
+                delete c;
+                return DVBS2GPU_ERR_ARG;
+            }
+            pos = end + 1;
+        }
+    }
     hipError_t ee = hipEventCreateWithFlags(&c->ev_ws, hipEventDisableTiming);
     if (ee != hipSuccess) { delete c; return fail_hip(ee, "hipEventCreate"); }
     *out = c;
+    return DVBS2GPU_OK;
+}
+
+int dvbs2gpu_set_option(dvbs2gpu_ctx* ctx, const char* name, int value) {
+    if (!ctx || !name) return DVBS2GPU_ERR_ARG;
+    CallGuard guard(ctx);
+    if (s2::apply_option(ctx, name, value) != 0) { g_err = std::string("unknown option or value out of range: ") + name; return DVBS2GPU_ERR_ARG; }
     return DVBS2GPU_OK;
 }
 

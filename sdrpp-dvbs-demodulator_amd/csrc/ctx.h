@@ -153,20 +153,29 @@ struct dvbs2gpu_ctx {
     // time-sliced front end (s2_rx_kernels.hip, s2_frontend_launch): per main stream one auxiliary stream + the slice events
     struct FeAux { hipStream_t aux = nullptr, aux2 = nullptr; hipEvent_t ev[s2::S2_FE_MAX_SLICES + 1] = {}, ev2[s2::S2_FE_MAX_SLICES + 1] = {}; hipStream_t dvbs_aux[4] = {}; hipEvent_t dvbs_ev[4][s2::DVBS_FE_MAX_SLICES + 1] = {}; };   // (dvbs_*: the DVB-S receiver's stage streams: AGC, FLL, RRC, soft FIFO + Viterbi)
     std::map<hipStream_t, FeAux> fe_aux;
-    int stage_pipeline_launches = 0;          // DVBS2GPU_STAGE_LOOPS: frame-loop launches per call (0 = chosen per call, s2_demod.hip)
-    int stage_pipeline_min_duty = 2;          // DVBS2GPU_STAGE_MIN_DUTY: pipelined mode uses the stage pipeline only above this balancer setting (-1: always).
+    // development / test options (dvbs2gpu_set_option, or DVBS2GPU_OPTIONS="name=value,..." in the environment when the context is created)
+    int loops_ahead = 1;                      // 0: frame loops only behind the PL sync (small banks)
+    int mixed_groups = 0;                     // 1: small mixed batches through the per-group flow instead of process_mixed
+    int mix_fec_streams = 4;                  // side streams for the FEC jobs of process_mixed (1..8)
+    int gardner_form = 0;                     // 1 / 2 / 4: one form of the timing recovery (0: chosen by bank size and balance)
+    int gardner_cand_skew = 0;                // tests only: skews the candidate form's arm prediction so that it leaves its tables
+    int ldpc_wave = -1;                       // short frames: 0 / 1 = lane-per-row / wave-per-frame decoder (-1: per code)
+    int ldpc_split = 0;                       // 1: the half-row decoder for the normal frames it takes (ldpc_split_kernel.hip)
+    int host_timing = 0;                      // 1: print where the host spends a batch call
+    int stage_pipeline_launches = 0;          // option stage_loops: frame-loop launches per call (0 = chosen per call, s2_demod.hip)
+    int stage_pipeline_min_duty = 2;          // option stage_min_duty: pipelined mode uses the stage pipeline only above this balancer setting (-1: always).
                                               // 2: with the frame loops at the decoder's base priority the two streams of a headline step are 6 ms apart, a stray
                                               // verdict of the balancer must not tip the step into the other flow (which costs it 3 %)
-    int stage_post_stream = 1;                // DVBS2GPU_STAGE_POST_STREAM: synchronous mode runs the post stages on a stream of their own (0: on the AGC's)
+    int stage_post_stream = 1;                // option stage_post_stream: synchronous mode runs the post stages on a stream of their own (0: on the AGC's)
     unsigned stage_calls = 0;
-    int stage_pipeline = 1;                   // DVBS2GPU_STAGE_PIPELINE: RRC, PL-sync walk and frame loops of a CCM call behind every timing-recovery slice (0: after the last one, frames pooled by the host first)
-    int fe_slices = 0;                        // DVBS2GPU_FE_SLICES (0 = by mode: 4 pipelined, 8 synchronous; 1 = both stages back to back on the caller's stream)
+    int stage_pipeline = 1;                   // option stage_pipeline: RRC, PL-sync walk and frame loops of a CCM call behind every timing-recovery slice (0: after the last one, frames pooled by the host first)
+    int fe_slices = 0;                        // option fe_slices (0 = by mode: 4 pipelined, 8 synchronous; 1 = both stages back to back on the caller's stream)
     // balance of the two streams of the pipelined mode (s2_demod.hip): share of the timing loop's tiles that run one priority level up
     int g_prio_duty = 0, g_prio_trend = 0;
-    bool g_prio_auto = true;                  // DVBS2GPU_G_PRIO_DUTY fixes the value
-    int dvbs_bank_min = 2048;                 // DVBS2GPU_DVBS_BANK_MIN: carriers from which a bank uses the four-streams-per-wave FLL (measured crossover with the written-out wave-per-stream loop: 2048 carriers 74.2 vs 74.8 ms, 1024: 46.2 vs 54.8, 4096: 128.8 vs 111.4; tests: 1)
-    int dvbs_agc_stream = 1;                  // DVBS2GPU_DVBS_AGC_STREAM: the AGC slices of a bank below dvbs_bank_min carriers on a third auxiliary stream (0: on the Viterbi stream)
-    int dvbs_fe_slices = 24;                 // DVBS2GPU_DVBS_FE_SLICES: time slices of a DVB-S call (dvbs_demod.hip)
+    bool g_prio_auto = true;                  // option g_prio_duty fixes the value
+    int dvbs_bank_min = 2048;                 // option dvbs_bank_min: carriers from which a bank uses the four-streams-per-wave FLL (measured crossover with the written-out wave-per-stream loop: 2048 carriers 74.2 vs 74.8 ms, 1024: 46.2 vs 54.8, 4096: 128.8 vs 111.4; tests: 1)
+    int dvbs_agc_stream = 1;                  // option dvbs_agc_stream: the AGC slices of a bank below dvbs_bank_min carriers on a third auxiliary stream (0: on the Viterbi stream)
+    int dvbs_fe_slices = 24;                 // option dvbs_fe_slices: time slices of a DVB-S call (dvbs_demod.hip)
     // DVB-S front end (dvbs_demod.hip)
     float* d_fd_bank = nullptr;               // COMPLEX_FD interpolator bank, 256 x 256
     std::map<int, s2::cf32*> bandedge;        // FLL band-edge taps [2][ntaps] by ntaps*100000 + round(alpha*1000)*10 + sps
@@ -183,6 +192,7 @@ int ws_acquire(dvbs2gpu_ctx* ctx, hipStream_t st);   // before enqueuing work th
 int ws_release(dvbs2gpu_ctx* ctx, hipStream_t st);   // after it
 int ws_quiesce(dvbs2gpu_ctx* ctx);                   // host-side wait for the last asynchronous user (synchronous entry points)
 bool fec_jobs_pending(dvbs2gpu_ctx* ctx);
+int apply_option(dvbs2gpu_ctx* ctx, const char* name, int value);   // 0, or -1: unknown name / value out of range
 int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out);
 int get_bch(dvbs2gpu_ctx* ctx, int m, int t, BchDeviceCode** out);
 int get_prbs(dvbs2gpu_ctx* ctx);

@@ -21,7 +21,7 @@ constexpr uint16_t LDPC_WAVE_NOROW = 0xffffu;
 #define LDPC_WAVE_LDS_RESERVE_KB 28
 #endif
 constexpr int LDPC_WAVE_LDS_RESERVE = LDPC_WAVE_LDS_RESERVE_KB * 1024;   // LDS per CU left to the front-end kernels that run beside the decoder in the pipelined mode
-// which codes (index into QC_CODES) go to the wave-per-frame decoder unless DVBS2GPU_LDPC_WAVE says otherwise (per-code timings: DESIGN.md)
+// which codes (index into QC_CODES) go to the wave-per-frame decoder unless the context option ldpc_wave says otherwise (per-code timings: DESIGN.md)
 // MI355X, 16384 frames x 50 forced iterations, lane-per-row vs wave-per-frame: 3/5 short 141 vs 119 ms, 4/5 short 65 vs 61, 5/6 short 155 vs 60,
 // 8/9 short 106 vs 48; the other six short codes (few links per row, few levels) stay with the lane-per-row decoder (1/4: 53 vs 305 ms)
 inline bool ldpc_wave_default(int code_index) { return code_index == 15 || code_index == 18 || code_index == 19 || code_index == 20; }

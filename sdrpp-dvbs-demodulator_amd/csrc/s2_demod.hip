@@ -310,6 +310,7 @@ int demod_configure(dvbs2gpu_demod* d) {
     }
     S2LoopCoefs& co = d->co;
     co.g_prio_duty = 0; co.g_lane_form = 0;       // (scheduling hints: set per call by the pipelined mode's balancer)
+    co.g_form = 0; co.g_cand_skew = 0;            // (context options, set per call)
     co.agc_rate = c.agc_rate;
     co.g_alpha = c.clock_mu_gain; co.g_beta = c.clock_omega_gain;
     co.g_min_freq = (float)(1.0 * (1.0 - c.omega_rel_limit)); co.g_max_freq = (float)(1.0 * (1.0 + c.omega_rel_limit));
@@ -458,6 +459,7 @@ static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work,
     S2LoopCoefs cc = co;
     cc.g_prio_duty = ctx->pipeline_fec ? ctx->g_prio_duty : 0;
     cc.g_lane_form = 0;
+    cc.g_form = ctx->gardner_form; cc.g_cand_skew = ctx->gardner_cand_skew;
     dvbs2gpu_ctx::FeAux* fa = nullptr;
     if (nsub > 1) {
         std::lock_guard<std::mutex> l(ctx->mtx);
@@ -482,7 +484,7 @@ static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work,
 
 struct HostMarks {
     bool on; std::chrono::steady_clock::time_point t0; std::string line;
-    HostMarks() : on(getenv("DVBS2GPU_HOST_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    explicit HostMarks(bool on_) : on(on_), t0(std::chrono::steady_clock::now()) {}
     void mark(const char* what) {
         if (!on) return;
         char b[64];
@@ -495,7 +497,7 @@ struct HostMarks {
 int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts,
                   uint8_t* const* d_out, int out_cap, int* out_bytes, hipStream_t st, bool pipelined, int slot, const int* pre_nsym, bool own_ws, bool deliver_now,
                   const BatchMap* bm = nullptr) {
-    HostMarks hm;
+    HostMarks hm(ctx->host_timing != 0);
     const auto t_entry = std::chrono::steady_clock::now();
     dvbs2gpu_demod* d0 = dm[0];
     Workspace* const W = own_ws ? ctx->ws_grp[slot] : ctx->ws_rx;      // per-call scratch: the group's own set when groups run side by side
@@ -512,8 +514,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     // ---- 1,2: front end + RRC
     // small banks (a workgroup per stream in the frame loops): the loops run behind EVERY slice and ahead of the PL sync (s2_frame_loops_kernel);
     // the window they are ahead in keeps its PLL output in a buffer of the stream's own (one PLFRAME of the longest kind)
-    static const bool loops_ahead_on = [] { const char* e = getenv("DVBS2GPU_LOOPS_AHEAD"); return !e || atoi(e) != 0; }();
-    const bool loops_ahead = loops_ahead_on && n <= S2_SMALL_BANK && !d0->cfg.pilot_aided && ctx->stage_pipeline_launches <= 0;     // (S2_SMALL_BANK = FL_SMALL_BANK of the kernels)
+    const bool loops_ahead = ctx->loops_ahead != 0 && n <= S2_SMALL_BANK && !d0->cfg.pilot_aided && ctx->stage_pipeline_launches <= 0;     // (S2_SMALL_BANK = FL_SMALL_BANK of the kernels)
     std::vector<S2StreamWork> work(n);
     int max_count = 0;
     for (int i = 0; i < n; ++i) {
@@ -1109,9 +1110,8 @@ int process_vcm_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const
 // behind a shared front-end pass.  Here the whole call is ONE stage pipeline: AGC / timing recovery / RRC are MODCOD-independent anyway, and the
 // PL-sync walk, the frame loops (ahead of the PL sync, as for a small bank of one configuration) and the demapper take what they otherwise get as
 // kernel arguments from a per-stream table (S2StreamCfgDev).  The FEC stays one job per LDPC code -- a handful of decoder workgroups each, a few
-// milliseconds of latency: they run side by side on up to MIX_FEC_STREAMS side streams -- and the BBFRAMEs go out through the per-frame
+// milliseconds of latency: they run side by side on up to four side streams (context option mix_fec_streams) -- and the BBFRAMEs go out through the per-frame
 // destination table of the ACM/VCM jobs.  No host thread per group; the streams: the caller's, the front end's two auxiliary ones, the side streams.
-constexpr int MIX_FEC_STREAMS = 4;
 int process_mixed(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf32* const* d_iq, const int* counts, uint8_t* const* d_out,
                   int out_cap, int* out_bytes, hipStream_t st, bool pipelined, const BatchMap* bm) {
     dvbs2gpu_demod* d0 = dm[0];
@@ -1120,8 +1120,7 @@ int process_mixed(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     if ((rc = get_rx_tables(ctx))) return rc;
     float* d_taps;
     if ((rc = get_rrc(ctx, d0->cfg.rrc_taps, d0->cfg.rrc_alpha, d0->cfg.samplerate / d0->cfg.symbolrate, &d_taps))) return rc;
-    static const bool loops_ahead_on = [] { const char* e = getenv("DVBS2GPU_LOOPS_AHEAD"); return !e || atoi(e) != 0; }();
-    const bool loops_ahead = loops_ahead_on && !d0->cfg.pilot_aided && ctx->stage_pipeline_launches <= 0;
+    const bool loops_ahead = ctx->loops_ahead != 0 && !d0->cfg.pilot_aided && ctx->stage_pipeline_launches <= 0;
     std::vector<S2StreamWork> work(n);
     std::vector<S2StreamCfgDev> cfgs(n);
     int max_count = 0, maxf = 0, raw_max = 0, raw_min = 1 << 30, max_slots = 0;
@@ -1266,8 +1265,7 @@ int process_mixed(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         J.frame_tr.assign(nf, -1); J.frame_co.assign(nf, -1);
         J.d_trials = (const int32_t*)ws_gt.p; J.n_results = to;
         J.d_dst = (uint8_t**)((char*)ws_gt.p + res_bytes + idx_bytes);
-        static const int side_max = [] { const char* e = getenv("DVBS2GPU_MIX_FEC_STREAMS"); const int k = e ? atoi(e) : MIX_FEC_STREAMS; return k < 1 ? 1 : (k > 8 ? 8 : k); }();
-        const int nside = std::min<int>((int)parts.size(), side_max);
+        const int nside = std::min<int>((int)parts.size(), std::min(8, std::max(1, ctx->mix_fec_streams)));
         size_t off_idx = 0;
         for (size_t pi = 0; pi < parts.size(); ++pi) {
             const PartH& P = parts[pi];
@@ -1546,7 +1544,7 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
     // a small mixed batch with one front-end and loop configuration: ONE stage pipeline for all MODCODs (process_mixed); DVBS2GPU_MIXED_GROUPS=1
     // keeps round 3's flow (a host thread and a HIP stream per configuration group behind a shared front-end pass), which bigger mixed batches use
     if (groups.size() > 1 && n <= S2_SMALL_BANK && ctx->stage_pipeline == 1) {
-        static const bool by_groups = getenv("DVBS2GPU_MIXED_GROUPS") != nullptr;
+        const bool by_groups = ctx->mixed_groups != 0;
         bool one = !by_groups;
         for (int i = 1; one && i < n; ++i) {
             const S2LoopCoefs &x = demods[0]->co, &y = demods[i]->co;

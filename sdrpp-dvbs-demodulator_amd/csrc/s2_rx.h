@@ -53,6 +53,7 @@ struct S2LoopCoefs {
     float fll_bw;
     int rrc_taps;
     int soft_plsc, pilot_aided;      // extensions (include/dvbs2gpu.h), 0 = the reference's behaviour
+    int g_form, g_cand_skew;         // scheduling / tests only: a forced form of the timing recovery (0: by bank size and balance), the candidate form's skew (context options)
     int g_lane_form;                 // scheduling only: a big bank's timing recovery runs in the lane-per-stream form (set by the balancer of s2_demod.hip, with hysteresis)
     int g_prio_duty;                 // scheduling only: of every 8 tiles of the timing loop, this many run one wave-priority level up (s2_demod.hip balances the two streams of the pipelined mode with it)
 };

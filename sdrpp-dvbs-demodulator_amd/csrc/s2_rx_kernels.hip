@@ -751,226 +751,8 @@ __global__ __launch_bounds__(128) void s2_gardner2_kernel(const S2StreamWork* __
     }
 }
 
-// ---- timing recovery, third form: LANE = STREAM ---------------------------------------------------------------------------
-// With the LDPC decoder of the previous call on the same SIMDs a step is bound by the instructions ALL resident waves issue, not by the
-// length of one chain -- and in the 8-lanes-per-stream forms above every wave instruction serves 8 streams.  Here a lane owns a stream
-// outright (64 streams per wave, like agc_pc_kernel): the resolver wave reads its stream's window from a small per-stream LDS ring
-// (nine samples per symbol: the on-symbol output's window and, one sample on, its follower's), interpolates the three arms of the
-// on-symbol output and the one arm of the follower in packed fp32 (re and im in one instruction, the reference's accumulation order)
-// and stores the values itself; a second wave feeds the ring (FastAGC scaling + FreqShift rotation of the next 8 samples per stream).
-// ~135 vector instructions per symbol for 64 streams instead of ~230 for 8: the timing recovery all but vanishes from the step's issue
-// budget, and one stream's chain is shorter as well.  Periods, pairing of the two outputs of a symbol and the single steps at the end
-// of a slice as in s2_gardner2_kernel.
-#ifndef GB_T_N
-#define GB_T_N 4
-#endif
-#ifndef GB_PRIO
-#define GB_PRIO 2
-#endif
-constexpr int GB_T = GB_T_N;                 // samples per stream and period
-static_assert(64 % GB_T == 0, "the feeder's lane = (stream, sample) layout needs a period that divides 64");
-// ring slots per stream: period t is resolved (reaching back 2 deferred positions + the 7 of the delay line) while t+1 is fed -- and not a
-// slot more: LDS is what decides whether this workgroup finds room beside a resident two-frame LDPC workgroup (136 KB; LDS is handed out
-// in contiguous pieces, tools/ubench/lds_fit.hip: whatever small workgroups were resident when the decoder's were placed leave holes of
-// their own size, and a kernel whose workgroup fits nowhere waits for the decoder to END).  Slot = buffer index mod GB_RING, kept as a
-// running counter per lane (no power of two needed).
-constexpr int GB_RING = 2 * GB_T + 9;
-constexpr int GB_PITCH = (GB_RING + 7) | 1;  // + mirror of the first 7 slots (a window never wraps); odd: the 8-byte accesses of 32 lanes hit 64 different banks
-__device__ __forceinline__ int gb_wrap(int slot) { return (int)min((unsigned)slot, (unsigned)(slot - GB_RING)); }   // slot in [0, 2 * GB_RING)
-
-// SPB = streams per workgroup: 64 (a full wave), or 16 -- lanes 16..63 of the resolver idle, but a bank of 4096 streams then is 256 workgroups, one per
-// compute unit, and a workgroup's ring is 4.6 KB instead of 16.9
-template <int SPB>
-__global__ __launch_bounds__(128) void s2_gardner_bank_kernel(const S2StreamWork* __restrict__ work, int nstreams, S2LoopCoefs co,
-                                                             const float* __restrict__ bank_g, int sub, int nsub) {
-    __shared__ __attribute__((aligned(16))) float bank[GARDNER_PHASES * GARDNER_TAPS];
-    __shared__ __attribute__((aligned(8))) f32x2 ring[SPB * GB_PITCH];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int s = blockIdx.x * SPB + lane;
-    const bool act = lane < SPB && s < nstreams;
-    for (int i = threadIdx.x; i < GARDNER_PHASES * GARDNER_TAPS; i += 128) bank[i] = bank_g[i];
-    const S2StreamWork w = work[act ? s : 0];
-    int lo, hi;
-    fe_sub_range(act ? w.count : 0, sub, nsub, lo, hi);
-    const int n = hi - lo;
-    S2StreamState* st = w.st;
-    f32x2* row = &ring[(lane % SPB) * GB_PITCH];
-    if (wave == 0 && lane < SPB)
-        for (int k = 0; k < GARDNER_TAPS - 1; ++k) {     // the delay line = buffer indices 0..6 = slots 0..6 (and their mirror)
-            const cf32 h = st->g_hist[k];
-            row[k] = f32x2{h.re, h.im}; row[GB_RING + k] = f32x2{h.re, h.im};
-        }
-    int nmax = n;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
-    const int ntiles = (nmax + GB_T - 1) / GB_T;
-    __syncthreads();
-
-    if (wave == 1) {
-        // ================= feeder: the samples of period t+1 go into the ring while period t is resolved.  Lane = (stream % SPI, sample):
-        // one load instruction fetches the period's samples (contiguous bytes) of SPI streams; all loads of a period are issued
-        // back to back a period ahead (unconditional, clamped indices: a load behind a branch is waited for on the spot)
-        constexpr int SPI = 64 / GB_T;                  // streams per load instruction
-        static_assert(SPB % SPI == 0, "a load instruction serves whole groups of streams");
-        constexpr int NQ = SPB / SPI;                   // load instructions per array and period
-        const int sub_s = lane / GB_T, smp = lane % GB_T;
-        // the pointers and sample counts of this lane's NQ streams, fetched once from the lanes that own them (a stream without samples
-        // in this slice may come with a null input pointer: the clamped loads then read the tap table)
-        const cf32* my_in = n > 0 ? w.in + lo : reinterpret_cast<const cf32*>(bank_g);
-        const cf32* my_gp = n > 0 ? w.fe_out + fe_scratch_offset(w.count) + lo : reinterpret_cast<const cf32*>(bank_g);
-        const cf32* q_in[NQ];
-        const cf32* q_gp[NQ];
-        int q_n[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int sj = SPI * q + sub_s;
-            q_in[q] = (const cf32*)__shfl((unsigned long long)my_in, sj);
-            q_gp[q] = (const cf32*)__shfl((unsigned long long)my_gp, sj);
-            q_n[q] = __shfl(n, sj);
-        }
-        cf32 px[NQ], pg[NQ];
-        auto issue = [&](int t) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int idx = min(t * GB_T + smp, max(q_n[q] - 1, 0));
-                px[q] = ldg(q_in[q] + idx); pg[q] = ldg(q_gp[q] + idx);
-            }
-        };
-        int slot_t = GARDNER_TAPS - 1 + smp;            // slot of this lane's sample of period t (buffer index = sample index + 7)
-        auto commit = [&](int t) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int sj = SPI * q + sub_s, idx = t * GB_T + smp;
-                if (idx < q_n[q]) {
-                    const cf32 z = cmul(cscale(px[q], pg[q].re), phasor_fast(-pg[q].im));   // FastAGC scaling, FreqShift rotation
-                    f32x2* rr = &ring[sj * GB_PITCH + slot_t];
-                    rr[0] = f32x2{z.re, z.im};
-                    if (slot_t < 7) rr[GB_RING] = f32x2{z.re, z.im};
-                }
-            }
-            slot_t = gb_wrap(slot_t + GB_T);
-        };
-        __builtin_amdgcn_s_setprio(GB_PRIO);
-        slot_t = gb_wrap(slot_t);
-        if (ntiles > 0) { issue(0); commit(0); }
-        if (ntiles > 1) issue(1);
-        lds_only_barrier();
-        for (int t = 0; t < ntiles; ++t) {
-            if (t + 1 < ntiles) commit(t + 1);
-            if (t + 2 < ntiles) issue(t + 2);
-            lds_only_barrier();
-        }
-        return;
-    }
-
-    // ================= resolver
-    PclDev pcl{co.g_alpha, co.g_beta, st->g_phase, st->g_freq, co.g_min_freq, co.g_max_freq};
-    int offset = st->g_offset, spsctr = st->g_spsctr, outCount = sub ? st->n_fe_out : 0;   // (later slices append to the call's output)
-    int slot = offset % GB_RING;                          // slot of buffer index `offset`, moved along with it
-    cf32* outp = w.fe_out;
-    // re and im of one arm: acc += x[k] * t[k] in tap order, every operation rounded (gardner.cpp / SDR++ polyphase dot product)
-    auto dot_arm = [&](const f32x2* x, const float* t) {
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(t), t1 = *reinterpret_cast<const f32x4*>(t + 4);
-        f32x2 acc = f32x2{0.f, 0.f};
-        acc += x[0] * t0.x; acc += x[1] * t0.y; acc += x[2] * t0.z; acc += x[3] * t0.w;
-        acc += x[4] * t1.x; acc += x[5] * t1.y; acc += x[6] * t1.z; acc += x[7] * t1.w;
-        return acc;
-    };
-    auto arm_of = [&]() {
-        const int phase = (int)floorf(pcl.phase * 128.0f);
-        return phase < 0 ? 0 : (phase > 127 ? 127 : phase);
-    };
-    auto put = [&](f32x2 v) {
-        *as_global(reinterpret_cast<f32x2*>(outp + outCount)) = v;
-        ++outCount;
-    };
-    auto finish = [&](float error) {
-        pcl.advance(error);
-        const float delta = floorf(pcl.phase);
-        const int o1 = (int)((float)offset + delta);
-        slot = gb_wrap(slot + (o1 - offset));             // (a step moves 0, 1 or 2 samples on)
-        offset = o1;
-        pcl.phase -= delta;
-    };
-    // on-symbol output from the window x[0..7]: arms phase-1 / phase / phase+1, error, advance (gardner.cpp:100-140)
-    auto err_step = [&](const f32x2* x) {
-        const int phase = arm_of();
-        const int base_arm = min(max(phase - 1, 0), GARDNER_PHASES - 3);       // three consecutive arms that hold what the phase needs
-        const float* t = &bank[base_arm * 8];
-        const f32x2 a = dot_arm(x, t), b = dot_arm(x, t + 8), c = dot_arm(x, t + 16);
-        f32x2 xo = b, d = (c - a) * 0.5f;
-        if (__any(phase == 0 || phase == GARDNER_PHASES - 1)) {                // one-sided at the ends of the bank (rare)
-            if (phase == 0) { xo = a; d = b - a; }
-            if (phase == GARDNER_PHASES - 1) { xo = c; d = c - b; }
-        }
-        put(xo);
-        const float error = -(((xo.x > 0 ? 1.0f : -1.0f) * d.x) + ((xo.y > 0 ? 1.0f : -1.0f) * d.y));
-        finish(clamp_med3(error, -1.0f, 1.0f));
-    };
-    // the other output of the symbol: error 0 (gardner.cpp:132-134)
-    auto off_step = [&](const f32x2* x) {
-        put(dot_arm(x, &bank[arm_of() * 8]));
-        finish(0.0f);
-    };
-    lds_only_barrier();                       // period 0 is in the ring
-    __builtin_amdgcn_s_setprio(GB_PRIO);      // 64 waves in all: they keep their latency against the decoder's waves (like agc_pc_kernel)
-    for (int t = 0; t < ntiles; ++t) {
-        const int base = t * GB_T;
-        const int lim = min(base + GB_T, n);              // outputs with offset < lim have their whole window in
-        const bool last = base + GB_T >= n;               // this stream's last period of the slice
-        // single steps: a slice that starts between the two outputs of a symbol, and (below) the last positions of a slice
-        if (__any(spsctr == 1 && offset < lim)) {
-            if (spsctr == 1 && offset < lim) {
-                f32x2 x[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) x[k] = row[slot + k];
-                off_step(x);
-                spsctr = 0;
-            }
-        }
-        // whole symbols: the follower lies at most two samples on (|freq - 1| <= 0.05, |alpha * error| << 1), so it is in as well
-        for (int guard = 0; guard < 2 * GB_T && __any(spsctr == 0 && offset < lim - 2); ++guard) {     // (bounded: a poisoned loop state -- NaN input -- must not hang the GPU)
-            if (spsctr == 0 && offset < lim - 2) {
-                f32x2 x[9];
-                const f32x2* xr = row + slot;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) x[k] = xr[k];
-                x[8] = row[gb_wrap(slot + 8)];            // (the mirror holds 7 slots: the ninth sample by its own slot)
-                const int o0 = offset;
-                err_step(x);
-                if (__all(offset == o0 + 1)) {
-                    off_step(x + 1);                      // (nearly always: the follower's window is the same registers, one sample on)
-                } else {
-                    f32x2 y[8];
-                    const f32x2* yr = row + slot;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) y[k] = yr[k];
-                    off_step(y);
-                }
-            }
-        }
-        if (__any(last && offset < n)) {
-            for (int guard = 0; guard < 8 && __any(last && offset < n); ++guard) {
-                if (last && offset < n) {
-                    f32x2 x[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) x[k] = row[slot + k];
-                    if (spsctr == 0) err_step(x); else off_step(x);
-                    spsctr ^= 1;
-                }
-            }
-        }
-        lds_only_barrier();
-    }
-    __builtin_amdgcn_s_setprio(0);
-    if (act) {
-        const int sn = n % GB_RING;
-        for (int k = 0; k < GARDNER_TAPS - 1; ++k) { const f32x2 h = row[gb_wrap(sn + k)]; st->g_hist[k] = cf32{h.x, h.y}; }
-        st->g_phase = pcl.phase; st->g_freq = pcl.freq; st->g_offset = offset - n; st->g_spsctr = spsctr;
-        st->n_fe_out = outCount;
-        st->n_fe_slice[sub & (S2_FE_MAX_SLICES - 1)] = outCount;
-    }
-}
+// (a third form -- lane = stream, 16 or 64 streams per workgroup: 102 instead of 185 ms of timing recovery per headline step, but the co-resident decoder 342 -> 366 ms and
+// no pipelined configuration where it beat the resolver + producer form -- was built in round 4 and deleted in round 5: profiles/r04_gardner_forms_ab.txt)
 
 // ---- timing recovery, fourth form: CANDIDATE TABLES for small banks -------------------------------------------------------
 // A small bank is bound by the length of ONE stream's chain, and ~100 of the ~135 instructions per symbol of the forms above are the
@@ -986,6 +768,9 @@ __global__ __launch_bounds__(128) void s2_gardner_bank_kernel(const S2StreamWork
 // + wave 2 (arms 4..7; output values).  Periods, single steps at the ends of a slice and the state hand-over as in the other forms.
 #ifndef S2_GCAND_ASM
 #define S2_GCAND_ASM 1    // the resolver's symbol loop of s2_gardner_cand_kernel written out (A/B switch)
+#endif
+#ifndef GB_PRIO
+#define GB_PRIO 2        // wave priority of the resolver (the value the deleted lane-per-stream form was tuned with)
 #endif
 constexpr int GC_T = 16;                      // samples per stream and period
 constexpr int GC_CS = 4;                      // streams per workgroup (64 = GC_CS * GC_T: one staged sample per lane of wave 1)
@@ -3419,22 +3204,17 @@ static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, c
 hipError_t s2_post_stages_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const S2PostStages& p, int c, int nsub, hipStream_t s) {
     return post_stages_launch(d_work, nstreams, coefs, p, c, nsub, s);
 }
-// Four forms of the timing recovery, all bit-identical (tests/test_gpu_gardner_forms.py runs every one): 1 = one wave, 8 lanes per stream
-// (s2_gardner_kernel); 2 = resolver + producer waves, 8 lanes per stream (s2_gardner2_kernel); 3 = lane per stream (s2_gardner_bank_kernel:
-// the fewest instructions in all); 4 = candidate tables (s2_gardner_cand_kernel: the shortest chain per stream -- what a small bank
-// needs: one stream 3.68 -> 2.5 ms per 21 690-sample slice against form 2; 64 streams x 1 frame 18.6 -> 16.7 ms per call, 256 x 4 frames
-// 50.3 -> 47.2).  Who wins where (round 4, MI355X, ms per step, front end | decoder in the step | step):
-//   4096 streams x 8 frames 8PSK 3/4 (decoder critical):  form 1  185 | 342 | 363     form 2  147 | 345 | 363     form 3  102 | 366 | 386
-//   4096 streams x 8 frames QPSK 1/2 (front end critical): form 1  283 | 337 | 465     form 2  297 | 356 | 410     form 3  146 | 365 | 396
-//   1024 streams x 4 frames 8PSK 3/4:                      form 1   71 |  48 |  76     form 2   60 |  49 |  65     form 3   65 |  51 |  71
-//    384 streams x 4 frames:                               form 1   65 |  19 |  67     form 2   52 |  18 |  54     form 3   58 |  19 |  60     form 4  51 | 19 | 53
-// Form 3 runs with 16 streams per workgroup (256 workgroups for 4096 streams: one per compute unit; DVBS2GPU_GARDNER_BANK_SPB=64: a full wave of
-// streams, 64 workgroups): alone it halves the timing recovery of a big bank, but it costs the co-resident decoder 20-25 ms per step and in every
-// pipelined configuration measured form 2 ends up at least as fast (the plugin's mode: form 1 202 | form 2 174 | form 3 181 | form 4 171 ms per step;
-// QPSK 1/2: 206 | 202 | 206): it is selectable (DVBS2GPU_GARDNER_FORM=3) and tested, not chosen by default.  A round-4 attempt to choose between the forms
-// by measured call times was taken out again: it spent its probes inside the very steps it was meant to speed up.  Default: form 4 up to
-// S2_GARDNER_CAND_MAX streams; form 2 below S2_GARDNER_BANK_MIN streams and wherever the pipelined mode's balancer has found the front end critical
-// (duty >= 2); form 1 for big banks beside a decoder that is.  DVBS2GPU_GARDNER_FORM=1|2|3|4 in the environment forces one.
+// Three forms of the timing recovery, all bit-identical (tests/test_gpu_gardner_forms.py runs every one): 1 = one wave, 8 lanes per stream
+// (s2_gardner_kernel); 2 = resolver + producer waves, 8 lanes per stream (s2_gardner2_kernel); 4 = candidate tables (s2_gardner_cand_kernel: the
+// shortest chain per stream -- what a small bank needs: one stream 3.68 -> 2.5 ms per 21 690-sample slice against form 2; 64 streams x 1 frame
+// 18.6 -> 16.7 ms per call, 256 x 4 frames 50.3 -> 47.2).  (Form 3, lane = stream, is gone: see above.)  Who wins where (round 4, MI355X, ms per
+// step, front end | decoder in the step | step):
+//   4096 streams x 8 frames 8PSK 3/4 (decoder critical):  form 1  185 | 342 | 363     form 2  147 | 345 | 363
+//   4096 streams x 8 frames QPSK 1/2 (front end critical): form 1  283 | 337 | 465     form 2  297 | 356 | 410
+//   1024 streams x 4 frames 8PSK 3/4:                      form 1   71 |  48 |  76     form 2   60 |  49 |  65
+//    384 streams x 4 frames:                               form 1   65 |  19 |  67     form 2   52 |  18 |  54     form 4  51 | 19 | 53
+// Default: form 4 up to S2_GARDNER_CAND_MAX streams; form 2 below S2_GARDNER_BANK_MIN streams and wherever the pipelined mode's balancer has found the front
+// end critical (duty >= 2); form 1 for big banks beside a decoder that is.  The context option gardner_form = 1 | 2 | 4 forces one.
 #ifndef S2_GARDNER_BANK_MIN
 #define S2_GARDNER_BANK_MIN 512
 #endif
@@ -3444,9 +3224,8 @@ hipError_t s2_post_stages_launch(const S2StreamWork* d_work, int nstreams, const
 #ifndef S2_GARDNER_CAND_MAX
 #define S2_GARDNER_CAND_MAX 256
 #endif
-static int gardner_form(int nstreams, int prio_duty, int lane_form) {
-    static const int forced = [] { const char* e = getenv("DVBS2GPU_GARDNER_FORM"); return e ? atoi(e) : 0; }();
-    if (forced >= 1 && forced <= 4) return forced;
+static int gardner_form(int nstreams, int prio_duty, int lane_form, int forced) {
+    if (forced == 1 || forced == 2 || forced == 4) return forced;      // (context option gardner_form: the parity tests run every form)
     if (nstreams <= S2_GARDNER_CAND_MAX) return 4;
     if (nstreams < S2_GARDNER_BANK_MIN) return 2;
     // a big bank beside the decoder of the previous call: the one-wave form disturbs the decoder least; once the balancer of the pipelined
@@ -3455,18 +3234,10 @@ static int gardner_form(int nstreams, int prio_duty, int lane_form) {
     return prio_duty < 2 ? 1 : 2;
 }
 static void gardner_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const float* d_bank, hipStream_t st, int c, int nsub) {
-    switch (gardner_form(nstreams, coefs.g_prio_duty, coefs.g_lane_form)) {
-        case 4: {
-            static const int skew = [] { const char* e = getenv("DVBS2GPU_GARDNER_CAND_SKEW"); return e ? atoi(e) : 0; }();     // (tests only)
-            hipLaunchKernelGGL(s2_gardner_cand_kernel, dim3((nstreams + GC_CS - 1) / GC_CS), dim3(192), 0, st, d_work, nstreams, coefs, d_bank, c, nsub, skew);
+    switch (gardner_form(nstreams, coefs.g_prio_duty, coefs.g_lane_form, coefs.g_form)) {
+        case 4:
+            hipLaunchKernelGGL(s2_gardner_cand_kernel, dim3((nstreams + GC_CS - 1) / GC_CS), dim3(192), 0, st, d_work, nstreams, coefs, d_bank, c, nsub, coefs.g_cand_skew);
             break;
-        }
-        case 3: {
-            static const int spb = [] { const char* e = getenv("DVBS2GPU_GARDNER_BANK_SPB"); return e ? atoi(e) : 16; }();
-            if (spb == 64) hipLaunchKernelGGL(s2_gardner_bank_kernel<64>, dim3((nstreams + 63) / 64), dim3(128), 0, st, d_work, nstreams, coefs, d_bank, c, nsub);
-            else hipLaunchKernelGGL(s2_gardner_bank_kernel<16>, dim3((nstreams + 15) / 16), dim3(128), 0, st, d_work, nstreams, coefs, d_bank, c, nsub);
-            break;
-        }
         case 2: hipLaunchKernelGGL(s2_gardner2_kernel, dim3((nstreams + G_SPW - 1) / G_SPW), dim3(128), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
         default: hipLaunchKernelGGL(s2_gardner_kernel, dim3((nstreams + G_SPW - 1) / G_SPW), dim3(64), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
     }

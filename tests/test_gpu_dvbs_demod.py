@@ -152,7 +152,7 @@ def test_dvbs_bank_batch_equals_single(engine, pkg):
 @pytest.mark.parametrize('slices', ['1', '3'])
 def test_dvbs_bank_kernels_equal_the_wave_per_stream_kernels(engine, pkg, slices):
     """a bank of more than 256 carriers runs the FLL with several streams per wave; forced here for 6 carriers of differing lengths
-    (DVBS2GPU_DVBS_BANK_MIN=1), in one time slice and in three: decoded bits, symbols and loop state must equal the wave-per-stream path's
+    (context option dvbs_bank_min = 1), in one time slice and in three: decoded bits, symbols and loop state must equal the wave-per-stream path's
     (which the tests above compare with the oracle), call by call"""
     import os
     import torch
@@ -160,17 +160,7 @@ def test_dvbs_bank_kernels_equal_the_wave_per_stream_kernels(engine, pkg, slices
     iqs = [od.dvbs_iq(r % 5, 12288, seed=60 + r, esn0_db=11.0, cfo=(r - 2) * 6e-4, timing=0.13 * r, phase0=0.2 * r)[0] for r in range(S)]
     counts = [[24576, 20001, 24576, 777, 16384, 9000], [1000, 24576, 63, 24576, 130, 24576], [24576, 4575, 24576, 24576, 8192, 15576]]
     single = [pkg.DvbsDemodBank(engine, 1, max_samples=24576) for _ in range(S)]
-    old = {k: os.environ.get(k) for k in ('DVBS2GPU_DVBS_BANK_MIN', 'DVBS2GPU_DVBS_FE_SLICES')}
-    try:
-        os.environ['DVBS2GPU_DVBS_BANK_MIN'] = '1'
-        os.environ['DVBS2GPU_DVBS_FE_SLICES'] = slices
-        e2 = pkg.Engine(0)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    e2 = pkg.Engine(0, options={'dvbs_bank_min': 1, 'dvbs_fe_slices': int(slices)})
     bank = pkg.DvbsDemodBank(e2, S, max_samples=24576)
     pos = [0] * S
     for rep in range(3):
@@ -193,7 +183,7 @@ def test_time_sliced_dvbs_front_end_changes_nothing(engine, pkg):
     """small banks run AGC / FLL + RRC / timing recovery / Costas + soft FIFO + Viterbi as time-sliced stages on three streams (every stage keeps
     its state in the stream record); 1 slice (what a GPU-filling bank uses), 3, 8, the maximum 32 and the default 24 must give the same symbols,
     loop state and decoded bits, call by call
-    (DVBS2GPU_DVBS_FE_SLICES is read when a context is created)"""
+    (context options dvbs_fe_slices, dvbs_agc_stream)"""
     import os
     iq, _ = od.dvbs_iq(2, 30000, seed=7, esn0_db=9.0, cfo=8e-4, timing=0.41, phase0=0.3)
     chunks = [4097, 12288, 900, 20000, iq.size - 4097 - 12288 - 900 - 20000]
@@ -211,27 +201,15 @@ def test_time_sliced_dvbs_front_end_changes_nothing(engine, pkg):
 
     ref = run(engine)
     assert sum(x.size for x in ref[1::3]) > 20000
-    names = ('DVBS2GPU_DVBS_FE_SLICES', 'DVBS2GPU_DVBS_AGC_STREAM')
-    old = {k: os.environ.get(k) for k in names}
-    try:
-        # (DVBS2GPU_DVBS_AGC_STREAM=0: the AGC slices on the Viterbi stream instead of a stream of their own)
-        for env in ({'DVBS2GPU_DVBS_FE_SLICES': '1'}, {'DVBS2GPU_DVBS_FE_SLICES': '3'}, {'DVBS2GPU_DVBS_FE_SLICES': '8'},
-                    {'DVBS2GPU_DVBS_FE_SLICES': '32'}, {'DVBS2GPU_DVBS_AGC_STREAM': '0'}, {'DVBS2GPU_DVBS_AGC_STREAM': '0', 'DVBS2GPU_DVBS_FE_SLICES': '5'}):
-            for k in names:
-                os.environ.pop(k, None)
-            os.environ.update(env)
-            e2 = pkg.Engine(0)
-            got = run(e2)
-            e2.close()
-            assert len(got) == len(ref)
-            for a, b in zip(ref, got):
-                assert np.array_equal(a, b), env
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    # (dvbs_agc_stream = 0: the AGC slices on the Viterbi stream instead of a stream of their own)
+    for opts in ({'dvbs_fe_slices': 1}, {'dvbs_fe_slices': 3}, {'dvbs_fe_slices': 8}, {'dvbs_fe_slices': 32}, {'dvbs_agc_stream': 0},
+                 {'dvbs_agc_stream': 0, 'dvbs_fe_slices': 5}):
+        e2 = pkg.Engine(0, options=opts)
+        got = run(e2)
+        e2.close()
+        assert len(got) == len(ref)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b), opts
 
 
 def test_dvbs_demod_error_codes(engine, pkg):

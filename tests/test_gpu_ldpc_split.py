@@ -1,4 +1,4 @@
-"""The half-row LDPC decoder (csrc/ldpc_split_kernel.hip: two lanes per row, one frame per workgroup) is selected with DVBS2GPU_LDPC_SPLIT=1 for the normal
+"""The half-row LDPC decoder (csrc/ldpc_split_kernel.hip: two lanes per row, one frame per workgroup) is selected with the context option ldpc_split = 1 for the normal
 frames it takes (rate 3/4); here it is FORCED on a fresh engine: posteriors, trial counts and hard decisions must equal the oracle's -- early exit, iteration
 limit, forced iterations, erasures, saturating garbage -- and many frames must flow through the persistent grid's work counter."""
 import os
@@ -17,15 +17,9 @@ def split_engine(pkg):
     import torch
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
-    old = os.environ.get('DVBS2GPU_LDPC_SPLIT')
-    os.environ['DVBS2GPU_LDPC_SPLIT'] = '1'      # read when an engine first builds a code's plan
-    eng = pkg.Engine(0)
+    eng = pkg.Engine(0, options={'ldpc_split': 1})      # (read when an engine first builds a code's plan)
     yield eng
     eng.close()
-    if old is None:
-        os.environ.pop('DVBS2GPU_LDPC_SPLIT', None)
-    else:
-        os.environ['DVBS2GPU_LDPC_SPLIT'] = old
 
 
 @pytest.mark.parametrize('rate,short', CODES)

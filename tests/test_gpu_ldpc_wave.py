@@ -17,15 +17,9 @@ def forced_engine(request, pkg):
     import torch
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
-    old = os.environ.get('DVBS2GPU_LDPC_WAVE')
-    os.environ['DVBS2GPU_LDPC_WAVE'] = str(request.param)      # read when an engine first builds a code's plan
-    eng = pkg.Engine(0)
+    eng = pkg.Engine(0, options={'ldpc_wave': request.param})      # (read when an engine first builds a code's plan)
     yield eng
     eng.close()
-    if old is None:
-        os.environ.pop('DVBS2GPU_LDPC_WAVE', None)
-    else:
-        os.environ['DVBS2GPU_LDPC_WAVE'] = old
 
 
 @pytest.mark.parametrize('rate,short', SHORT)

@@ -381,7 +381,7 @@ def test_mixed_batch_of_all_four_constellations_with_and_without_pilots(engine):
 def test_pipelined_mode_with_and_without_the_stage_pipeline(engine, pkg):
     """throughput mode: a call runs its RRC / PL sync / frame loops either behind the timing-recovery slices (stage pipeline) or after the
     last one, as the balancer sees fit -- so the flow may change from call to call.  Always, never and every other call
-    (DVBS2GPU_STAGE_PIPELINE=2) must deliver the same bytes and statistics, call by call"""
+    (context option stage_pipeline = 2) must deliver the same bytes and statistics, call by call"""
     import os, torch
     S, calls = 5, 6
     iqs = [orc.transmit(13, 0, 1, nframes=2 * calls, seed=940 + s, esn0_db=13.0, cfo=7e-4, timing=0.1 * s, phase0=0.2, lead_symbols=100 + 41 * s)[0] for s in range(S)]
@@ -408,23 +408,11 @@ def test_pipelined_mode_with_and_without_the_stage_pipeline(engine, pkg):
                 d.close()
         return outs
 
-    names = ('DVBS2GPU_STAGE_PIPELINE', 'DVBS2GPU_STAGE_MIN_DUTY')
-    old = {k: os.environ.get(k) for k in names}
     res = []
-    try:
-        for env in ({'DVBS2GPU_STAGE_PIPELINE': '0'}, {'DVBS2GPU_STAGE_MIN_DUTY': '-1'}, {'DVBS2GPU_STAGE_PIPELINE': '2'}):
-            for k in names:
-                os.environ.pop(k, None)
-            os.environ.update(env)
-            e2 = pkg.Engine(0)
-            res.append(run(e2))
-            e2.close()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    for opts in ({'stage_pipeline': 0}, {'stage_min_duty': -1}, {'stage_pipeline': 2}):
+        e2 = pkg.Engine(0, options=opts)
+        res.append(run(e2))
+        e2.close()
     assert sum(len(x) for c in res[0] for x in c[0]) >= S * (2 * calls - 4) * kb
     for other in res[1:]:
         for a, b in zip(res[0], other):
@@ -980,7 +968,7 @@ def test_soft_plsc_and_pilot_aided_modes_equal_oracle(engine, modcod, short, pil
 def test_time_sliced_front_end_changes_nothing(engine, pkg):
     """the AGC/NCO and timing-recovery stages keep their state in the stream record, so running a call's samples as 1, 4 (default) or 8
     time slices -- the AGC of slice c+1 beside the Gardner loop of slice c on an auxiliary stream -- must give the same bytes, call by call
-    (the DVBS2GPU_* switches are read when a context is created)"""
+    (context options, set on fresh engines)"""
     import os, torch
     modcod, S = 14, 6
     iqs = []
@@ -1007,28 +995,14 @@ def test_time_sliced_front_end_changes_nothing(engine, pkg):
     ref = run(engine)
     assert sum(x.size for x in ref[0] + ref[2] + ref[4]) > 0
     # ... and so do the later stages: with the stage pipeline (default) the RRC decimator, the PL-sync walk and the frame loops run behind
-    # every timing-recovery slice, frames in per-stream slots; without it (DVBS2GPU_STAGE_PIPELINE=0) after the last slice on frames the host
-    # pooled; DVBS2GPU_STAGE_LOOPS fixes how many of the slices are followed by a frame-loop launch; DVBS2GPU_STAGE_POST_STREAM=0 keeps
+    # every timing-recovery slice, frames in per-stream slots; without it (context option stage_pipeline = 0) after the last slice on frames the host
+    # pooled; stage_loops fixes how many of the slices are followed by a frame-loop launch; stage_post_stream = 0 keeps
     # them on the AGC's stream instead of a third one
-    names = ('DVBS2GPU_FE_SLICES', 'DVBS2GPU_STAGE_PIPELINE', 'DVBS2GPU_STAGE_LOOPS', 'DVBS2GPU_STAGE_POST_STREAM')
-    old = {k: os.environ.get(k) for k in names}
-    try:
-        for env in ({'DVBS2GPU_FE_SLICES': '1'}, {'DVBS2GPU_FE_SLICES': '8'}, {'DVBS2GPU_STAGE_PIPELINE': '0'},
-                    {'DVBS2GPU_STAGE_PIPELINE': '0', 'DVBS2GPU_FE_SLICES': '1'}, {'DVBS2GPU_STAGE_LOOPS': '4'},
-                    {'DVBS2GPU_STAGE_LOOPS': '3', 'DVBS2GPU_FE_SLICES': '8'}, {'DVBS2GPU_STAGE_LOOPS': '1'},
-                    {'DVBS2GPU_STAGE_POST_STREAM': '0', 'DVBS2GPU_FE_SLICES': '4'}, {'DVBS2GPU_FE_SLICES': '4'}):
-            for k in names:
-                os.environ.pop(k, None)
-            os.environ.update(env)
-            e2 = pkg.Engine(0)
-            got = run(e2)
-            e2.close()
-            for a, b in zip(ref, got):
-                for x, y in zip(a, b):
-                    assert np.array_equal(x, y), env
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    for opts in ({'fe_slices': 1}, {'fe_slices': 8}, {'stage_pipeline': 0}, {'stage_pipeline': 0, 'fe_slices': 1}, {'stage_loops': 4},
+                 {'stage_loops': 3, 'fe_slices': 8}, {'stage_loops': 1}, {'stage_post_stream': 0, 'fe_slices': 4}, {'fe_slices': 4}):
+        e2 = pkg.Engine(0, options=opts)
+        got = run(e2)
+        e2.close()
+        for a, b in zip(ref, got):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), opts
