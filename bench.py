@@ -323,10 +323,8 @@ def secondary_s2(eng, pkg, dev, name, modcod, rate, short, pilots, esn0_db, S, F
 
     def barrier():
         torch.cuda.synchronize()
-    # 8 untimed steps first: the pipelined mode's balancer (wave-priority share of the timing loop, stage pipeline on / off) is per engine and
-    # moves one notch per two consistent calls -- started from where the headline configuration left it, a front-end-bound configuration
-    # otherwise spends part of its 8 timed steps in the wrong flow now and then (1 970 instead of 2 660 Msym/s for config 2).  (An engine of
-    # its own per configuration is no way out: its streams would share the few hardware queues with the first engine's.)
+    # 8 untimed steps first: the pipelined mode's balancer (wave-priority share of the timing loop, stage pipeline on / off) starts from zero for every new
+    # configuration (s2_demod.hip) and moves one notch per two consistent calls: a front-end-bound configuration needs these steps to reach ITS setting
     dt, stages, acc = time_steps(run, steps, 8, barrier, True)
     k = ldpc_alone(eng, run.info, rate, short, S * F, dev)
     bpf = ITERS * 4 * run.info['ldpc_edges'] + run.info['ldpc_n'] + run.info['kbch'] // 8

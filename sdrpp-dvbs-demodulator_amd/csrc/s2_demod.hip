@@ -803,6 +803,11 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         // loop should yield more) or was the job long done (the front end is: it should yield less)?  One step of the priority duty per two
         // consistent calls; single-group batches only (the groups of a mixed batch share one front-end pass).
         if (ctx->g_prio_auto && !own_ws && !pre_nsym) {
+            // (the balance belongs to a configuration: what one batch settled at says nothing about the next one's -- a front-end-bound configuration that inherited the
+            //  headline's setting spent part of its steps in the wrong flow)
+            const long long sig = ((long long)n << 32) ^ ((long long)d0->cfg.modcod << 20) ^ ((long long)d0->cfg.shortframes << 19) ^ ((long long)d0->cfg.pilots << 18) ^
+                                  ((long long)(d0->cfg.force_ldpc_iters & 0xff) << 8) ^ (long long)(d0->cfg.max_ldpc_trials & 0xff);
+            if (sig != ctx->g_prio_sig) { ctx->g_prio_sig = sig; ctx->g_prio_duty = 0; ctx->g_prio_trend = 0; }
             const auto t_d1 = std::chrono::steady_clock::now();
             const double wait_ms = std::chrono::duration<double, std::milli>(t_d1 - t_d0).count();
             const double call_ms = std::chrono::duration<double, std::milli>(t_d1 - t_entry).count();
