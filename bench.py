@@ -63,7 +63,7 @@ def ldpc_source_hash():
     """identifies the decoder build a set of PMC figures belongs to (tools/collect_profiles.py stores it with them)"""
     import hashlib
     h = hashlib.sha256()
-    for n in ('ldpc_kernel.hip', 'ldpc_plan.h', 'ldpc_dev_common.h'):
+    for n in ('ldpc_kernel.hip', 'ldpc_split_kernel.hip', 'ldpc_split_plan.h', 'ldpc_lane_common.h', 'ldpc_plan.h', 'ldpc_dev_common.h'):
         h.update(open(os.path.join(ROOT, 'sdrpp-dvbs-demodulator_amd', 'csrc', n), 'rb').read())
     return h.hexdigest()[:16]
 
@@ -747,6 +747,8 @@ def main():
     k = ldpc_alone(eng, info, RATE, SHORT, nfr, dev)
     bytes_per_frame = ITERS * 4 * info['ldpc_edges'] + info['ldpc_n'] + info['kbch'] // 8
     plan = eng.ldpc_plan_info(RATE, bool(SHORT))
+    form = eng.ldpc_decoder_form(RATE, bool(SHORT))
+    plan['decoder'] = ('lane per row, two frames per workgroup', 'wave per frame', 'half a row per lane, one frame per workgroup')[form]
     # the decoder's launches as they ran INSIDE the timed steps (hipEvent pairs on the FEC stream, dvbs2gpu_get_stage_times)
     l_ms, l_n, l_frames = stages['ldpc']
     in_step_ms = l_ms / max(l_n, 1)
@@ -786,8 +788,8 @@ def main():
                        'check': 'every delivered frame of every stream, last timed step + pipeline flush, on the device (hash + full byte compare)',
                        'fec_pipelined_across_steps': pipelined},
             'roofline': {'bound': 'hbm',
-                         'bound_note': 'NOMINAL: algorithmic bytes against the 8 TB/s HBM peak, as the contract asks for a byte / integer path -- what actually bounds the kernel is the latency of the barrier-separated phases of a layer (per-wave instruction streams, LDS round trips, serial sections; see wave_cycles_fraction): the state is on-chip',
-                         'kernel': 'ldpc_decode_kernel<%d,%d,%s>' % (plan['max_deg'], plan['rec_dwords'], 'true' if plan.get('irregular') else 'false'),
+                         'bound_note': 'NOMINAL: algorithmic bytes against the 8 TB/s HBM peak, as the contract asks for a byte / integer path -- the state is on-chip and what bounds the kernel is vector issue -- its instructions are packed 16-bit / DPP / byte-permute forms, which a SIMD issues at HALF rate (valu_note) -- plus the serial sections of the layers with shared bits (profiles/r05_ldpc_split_layers.txt)',
+                         'kernel': ('ldpc_split_kernel<%d>' % plan['max_deg']) if form == 2 else 'ldpc_decode_kernel<%d,%d,%s>' % (plan['max_deg'], plan['rec_dwords'], 'true' if plan.get('irregular') else 'false'),
                          'achieved': round(achieved if achieved else achieved_alone, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round((achieved if achieved else achieved_alone) / HBM_PEAK_GBS, 4),
                          'timing': 'average over the %d decoder launches inside the timed steps (hipEvent pairs on the FEC stream; the front end of the next step shares the CUs)' % l_n,

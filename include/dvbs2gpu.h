@@ -80,9 +80,15 @@ int dvbs2gpu_ldpc_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, con
                                int max_trials, int force, uint8_t* d_hard, int8_t* d_post, int32_t* d_trials, void* stream);
 
 /* Introspection of the decoder plan of one code (for DESIGN.md / bench reporting):
- * out8 = {layers q, max row degree, message record dwords, sum of layer depths, resident workgroups per CU,
+ * out8 = {layers q, max row degree, message record dwords, sum of layer depths, resident workgroups per CU (both of the
+ *         decoder that serves the code),
  *         CUs, Tanner edges, layers with intra-layer shared bits}. */
 int dvbs2gpu_ldpc_plan_info(dvbs2gpu_ctx* ctx, int rate, int shortframes, int32_t* out8);
+
+/* Which of the three LDPC decoder kernels serves the code under the context's options (bench / profile reporting):
+ * 0 lane per row (ldpc_kernel.hip), 1 wave per frame (short frames, ldpc_wave_kernel.hip), 2 half a row per lane
+ * (ldpc_split_kernel.hip).  All three restate layered_decoder.hh:46-74 and are bit-exact with each other. */
+int dvbs2gpu_ldpc_decoder_form(dvbs2gpu_ctx* ctx, int rate, int shortframes);
 
 /* Host-only dump of the decoder plan (no GPU needed; used by the CPU test-suite to check the intra-layer
  * ordering against the reference's sequential row order).  Call with NULL arrays to get the counts:

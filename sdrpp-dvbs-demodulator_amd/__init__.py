@@ -70,6 +70,7 @@ PROTOTYPES = {
     'dvbs2gpu_set_option': (_i, [_vp, C.c_char_p, _i]),
     'dvbs2gpu_ldpc_plan_dump': (_i, [_i, _i, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
     'dvbs2gpu_ldpc_plan_info': (_i, [_vp, _i, _i, C.POINTER(C.c_int32)]),
+    'dvbs2gpu_ldpc_decoder_form': (_i, [_vp, _i, _i]),
     'dvbs2gpu_ldpc_wave_plan_dump': (_i, [_i, _i, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
     'dvbs2gpu_ldpc_addr_table_dump': (_i, [_i, _i, _vp, C.POINTER(C.c_int32)]),
     'dvbs2gpu_ldpc_split_plan_dump': (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
@@ -249,6 +250,13 @@ class Engine:
         self._check(self.lib.dvbs2gpu_ldpc_plan_info(self.h, int(rate), int(bool(shortframes)), out))
         keys = ['layers', 'max_deg', 'rec_dwords', 'sum_depth', 'blocks_per_cu', 'cus', 'edges', 'conflict_layers']
         return dict(zip(keys, list(out)))
+
+    def ldpc_decoder_form(self, rate, shortframes=False):
+        """0 lane per row, 1 wave per frame, 2 half a row per lane: the kernel that serves the code under this engine's options"""
+        r = self.lib.dvbs2gpu_ldpc_decoder_form(self.h, int(rate), int(bool(shortframes)))
+        if r < 0:
+            self._check(r)
+        return r
 
     def ldpc_split_plan(self, rate, shortframes=False):
         return ldpc_split_plan(rate, shortframes)

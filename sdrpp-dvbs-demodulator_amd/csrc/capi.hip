@@ -90,19 +90,16 @@ int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
         if (!P.atab.empty() && (rc = upload(P.atab, &D.d_atab))) return fail(rc);
         D.blocks_per_cu = ldpc_blocks_per_cu(P.max_deg, D.irregular, P.N);
         if (P.N > 16200 && ldpc_split_supported(P.max_deg)) {
-            // the half-row decoder (ldpc_split_plan.h / ldpc_split_kernel.hip) for the normal frames it takes: NOT the default -- alone it equals the lane-per-row
-            // decoder (338 vs 337 ms per 32 768 frames of rate 3/4 at the 64 registers that leave room for a front-end wave, 321 at 80), beside the front end of the
-            // pipelined mode it loses (370 vs 342 ms: its 24 waves per compute unit use the vector issue slots the front end otherwise gets for free).  the context option ldpc_split = 1
-            // selects it (the parity tests run both decoders); DESIGN.md section 5 has the measurements.
-            if (ctx->ldpc_split) {
-                const LdpcSplitPlan SP = build_ldpc_split_plan(P);
-                if (SP.ok) {
-                    if ((rc = upload(SP.layers, &D.d_split_layers))) return fail(rc);
-                    if ((rc = upload(SP.atab, &D.d_split_atab))) return fail(rc);
-                    D.split_npl = (int)SP.layers.size(); D.split_rec_total = SP.rec_total;
-                    D.split_blocks_per_cu = ldpc_split_blocks_per_cu(P.max_deg, P.N);
-                    D.use_split = true;
-                }
+            // the half-row decoder (ldpc_split_plan.h / ldpc_split_kernel.hip) for the normal frames it takes, and for them the default: 32 768 frames of rate 3/4 x 50 iterations
+            // in 308 ms against the lane-per-row decoder's 336, the pipelined step 335 against 348 ms (r05).  The context option ldpc_split = 0 selects the
+            // lane-per-row decoder (the parity tests run both).
+            const LdpcSplitPlan SP = build_ldpc_split_plan(P);
+            if (SP.ok) {
+                if ((rc = upload(SP.layers, &D.d_split_layers))) return fail(rc);
+                if ((rc = upload(SP.atab, &D.d_split_atab))) return fail(rc);
+                D.split_npl = (int)SP.layers.size(); D.split_rec_total = SP.rec_total;
+                D.split_blocks_per_cu = ldpc_split_blocks_per_cu(P.max_deg, P.N);
+                D.use_split = true;
             }
         }
         if (P.N <= 16200) {
@@ -249,7 +246,7 @@ static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, 
                                         (unsigned int*)((char*)W.msg.p + need), (uint32_t*)((char*)W.msg.p + need + 256)));
         return 0;
     }
-    if (C->use_split) {
+    if (C->use_split && ctx->ldpc_split) {
         // half-row decoder: one frame per workgroup, frames beyond the first wave of workgroups claimed through the work counter
         int grid = ctx->num_cus * C->split_blocks_per_cu;
         if (grid > nframes) grid = nframes;
@@ -543,7 +540,19 @@ int dvbs2gpu_ldpc_plan_info(dvbs2gpu_ctx* ctx, int rate, int shortframes, int32_
     LdpcPlan P = build_ldpc_plan(f.code_index);
     out8[0] = C->q; out8[1] = C->max_deg; out8[2] = C->rec_dwords; out8[3] = P.sum_depth;
     out8[4] = C->blocks_per_cu; out8[5] = ctx->num_cus; out8[6] = C->edges; out8[7] = P.conflict_layers;
+    if (C->use_split && ctx->ldpc_split) { out8[2] = ldpc_split_plan_rec_dwords(P.max_deg); out8[4] = C->split_blocks_per_cu; }
     return 0;
+}
+
+int dvbs2gpu_ldpc_decoder_form(dvbs2gpu_ctx* ctx, int rate, int shortframes) {
+    if (!ctx) return DVBS2GPU_ERR_ARG;
+    FecParams f;
+    if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    LdpcDeviceCode* C;
+    int rc = get_ldpc(ctx, f.code_index, &C);
+    if (rc) return rc;
+    return C->use_wave ? 1 : (C->use_split && ctx->ldpc_split) ? 2 : 0;
 }
 
 int dvbs2gpu_ldpc_decode_batch(dvbs2gpu_ctx* ctx, int rate, int shortframes, const int8_t* d_llr, int nframes, int max_trials,

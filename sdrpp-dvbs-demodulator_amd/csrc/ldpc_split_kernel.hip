@@ -24,7 +24,7 @@
 namespace s2 {
 
 #ifndef LDPC_SPLIT_EXP
-#define LDPC_SPLIT_EXP 0          // development switch for TIMING experiments (results wrong): 2 = no table / record traffic in the layer loop, 4 = no layer barrier, 8 = no output phase
+#define LDPC_SPLIT_EXP 0          // development switch for TIMING experiments (results wrong): 2 = no table / record traffic in the layer loop (16 / 32 / 64: no table loads / record loads / record stores), 4 = no layer barrier, 8 = no output phase
 #endif
 #ifndef LDPC_SPLIT_WPE
 #define LDPC_SPLIT_WPE 8          // waves per SIMD the register allocation aims at (6 = 80 VGPRs: two workgroups per compute unit; 8 = 64: room for a 128-register front-end wave beside them)
@@ -315,12 +315,28 @@ __device__ __forceinline__ void chain_layer(const uint32_t (&AD)[SplitShape<MAXD
 // 1 = "L"), the dependency chains walked by a few lanes; 6: quad walk (at most 4 shared links, deep and narrow level structure: one wave walks the rows of levels
 // >= 2, four lanes per row); 3: a barrier per level (at most 4 shared links).  The row word -- level | late << 8 | early << 12, zero for half 1 and idle lanes, so
 // every condition below is false there -- rides in the table.
+#ifndef LDPC_SPLIT_FIX
+#define LDPC_SPLIT_FIX 7
+#endif
+#if LDPC_SPLIT_FIX & 1
+typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;
+typedef const __attribute__((address_space(4))) LdpcSplitLayer* const_layer_ptr;
+#else
+typedef const uint32_t* const_u32_ptr;
+typedef const LdpcSplitLayer* const_layer_ptr;
+#endif
+
+__device__ __forceinline__ LdpcSplitLayer layer_at(const_layer_ptr layers, int i) {      // (field by field: a struct in the constant address space has no copy constructor on the host pass)
+    LdpcSplitLayer L;
+    L.kind_nw = layers[i].kind_nw; L.aux = layers[i].aux; L.rec_off = layers[i].rec_off; L.ent_off = layers[i].ent_off;
+    return L;
+}
 #ifndef LDPC_SPLIT_CONFLICT_INLINE
 #define LDPC_SPLIT_CONFLICT_INLINE __forceinline__
 #endif
 template <int MAXDEG, int KIND>
 __device__ LDPC_SPLIT_CONFLICT_INLINE void conflict_layer(const uint32_t (&AD)[SplitShape<MAXDEG>::NPW], const uint32_t (&rec_in)[SplitShape<MAXDEG>::REC], uint32_t (&rec_out)[SplitShape<MAXDEG>::REC],
-                                               const LdpcSplitLayer L, const uint32_t* __restrict__ ents, const uint32_t* __restrict__ walk, const int t,
+                                               const LdpcSplitLayer L, const_u32_ptr ents, const_u32_ptr walk, const int t,
                                                int8_t* __restrict__ post, uint32_t* __restrict__ cw, uint8_t* __restrict__ cres) {
     using S = SplitShape<MAXDEG>;
     constexpr int REC = S::REC;
@@ -444,7 +460,7 @@ __device__ LDPC_SPLIT_CONFLICT_INLINE void conflict_layer(const uint32_t (&AD)[S
             const uint32_t basek = 360u * (ek >> 16);                       // (the posteriors start at LDS offset 0)
             const uint32_t scratch = lds_offset(reinterpret_cast<const int8_t*>(cres)) + (uint32_t)t;
             const uint32_t cwb = lds_offset(reinterpret_cast<const int8_t*>(cw));
-            const uint32_t* __restrict__ list = walk + 1 + qd;
+            const const_u32_ptr list = walk + 1 + qd;
             auto step = [&](const uint32_t e) {
                 const bool valid = e != 0xffffffffu && k < nc;
                 const int row = valid ? (int)e : 0;
@@ -475,7 +491,7 @@ __device__ LDPC_SPLIT_CONFLICT_INLINE void conflict_layer(const uint32_t (&AD)[S
 #define LIST_FETCH(r, p) asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory")
 #define LIST_READY(r) asm volatile("s_waitcnt vmcnt(1)" : "+v"(r) : : "memory")
             uint32_t eA, eB;
-            const uint32_t* lp = list;
+            const_u32_ptr lp = list;
             LIST_FETCH(eA, lp); LIST_FETCH(eB, lp + 16);
             lp += 32;
             for (int i = 0; i < wk_steps; i += 2) {
@@ -573,6 +589,8 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
             const int N = P->A.N, K = P->A.K, R = P->A.R, q = P->A.q;
             uint32_t* __restrict__ msg = P->A.msg_ws + (size_t)blockIdx.x * (size_t)P->A.pent_base;
             const int8_t* __restrict__ src = P->A.llr + (size_t)f * N;
+            int t = threadIdx.x;                  // (an opaque copy, as in the sweep: the strided indices of these loops, hoisted out of the frame loop, would stay live through every layer)
+            asm volatile("" : "+v"(t));
             for (int i = t; i < K / 8; i += T) reinterpret_cast<uint2*>(post)[i] = reinterpret_cast<const uint2*>(src)[i];
             // parity LLRs: pty[360*i + jj] = llr[K + q*jj + i]   (layered_decoder.hh:124-126)
             for (int c = t; c < R; c += T) {
@@ -589,9 +607,11 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
             const LdpcKernelParamsPtr P = ldpc_params();
             const LdpcKernelArgs A = ldpc_args(P);      // (what of it the check and the sweep use)
             const int N = A.N, q = A.q, npl = P->npl;
-            const LdpcSplitLayer* __restrict__ layers = static_cast<const LdpcSplitLayer*>(P->layers);
-            const uint32_t* __restrict__ ents = P->ents;
-            const uint32_t* __restrict__ rows = P->rows;
+            // (the plan's tables through CONSTANT-address-space pointers: a uniform read is then a scalar load.  Through a plain pointer the compiler -- which sees the kernel
+            // store to global memory -- issues a vector load, and the vmcnt(0) in front of its first use also waits for the table words just requested for the next pseudo-layer)
+            const const_layer_ptr layers = (const_layer_ptr)P->layers;
+            const const_u32_ptr ents = (const_u32_ptr)P->ents;
+            const const_u32_ptr rows = (const_u32_ptr)P->rows;
             const int npad = (N + LDPC_SPLIT_SCRATCH + 15) & ~15;                // posteriors + the scratch bytes (ldpc_split_plan.h)
             uint32_t* __restrict__ cw = reinterpret_cast<uint32_t*>(lds_all + npad);      // hand-off records of the chain walk: 8 bytes per row
             uint8_t* __restrict__ cres = reinterpret_cast<uint8_t*>(cw + 2 * 360);
@@ -604,7 +624,7 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
             if (check) {
                 const uint32_t zflag = sign_pack(post, N, reinterpret_cast<uint8_t*>(sgn), t, T);
                 __syncthreads();              // the sign bytes went to global memory: full barrier (drains vmcnt)
-                const bool bad = zflag != 0 || syndromes_bad<MAXDEG>(q, A.synd_base, ents, sgn, t, T);
+                const bool bad = zflag != 0 || syndromes_bad<MAXDEG>(q, A.synd_base, P->ents, sgn, t, T);
                 const unsigned long long b = __ballot(bad);
                 if ((t & 63) == 0) s_flag[t >> 6] = (b != 0);
                 lds_barrier();
@@ -624,11 +644,19 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
             for (int w = 0; w < REC; ++w) rec_next[w] = 0;
 #pragma unroll
             for (int w = 0; w < NPW; ++w) pw_next[w] = 0;
-            LdpcSplitLayer Lnext = layers[0], Lnext2 = layers[npl > 1 ? 1 : 0];
+            LdpcSplitLayer Lnext = layer_at(layers, 0), Lnext2 = layer_at(layers, npl > 1 ? 1 : 0);
             uint32_t soff_tab = 0;
             if (wave < (int)((Lnext.kind_nw >> 8) & 0xffu) && !(LDPC_SPLIT_EXP & 2)) {
                 bload<NPW>(pw_next, rs_tab, (uint32_t)t * (NPW * 4), soff_tab);
                 bload<REC>(rec_next, rs_msg, (uint32_t)t * (REC * 4), Lnext.rec_off * 4u);
+            }
+            // (claimed before the loop: a load still in flight on the loop's entry edge makes the compiler open EVERY pseudo-layer with vmcnt(0) -- which, coming round the
+            // back edge, waits for the previous pseudo-layer's record store)
+            if (LDPC_SPLIT_FIX & 4) {
+#pragma unroll
+                for (int w = 0; w < REC; ++w) asm volatile("" : "+v"(rec_next[w]));
+#pragma unroll
+                for (int w = 0; w < NPW; ++w) asm volatile("" : "+v"(pw_next[w]));
             }
 #if defined(LDPC_PROF)
             unsigned long long t_layer = clock64();       // development aid (-DLDPC_PROF builds): cycles of every pseudo-layer, thread 0 of workgroup 0 -> prof[128 + pl]; prof[127]: the rest of an iteration
@@ -637,7 +665,7 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
             for (int pl = 0; pl < npl; ++pl) {
                 const LdpcSplitLayer L = Lnext;
                 Lnext = Lnext2;
-                Lnext2 = layers[pl + 2 < npl ? pl + 2 : npl - 1];
+                Lnext2 = layer_at(layers, pl + 2 < npl ? pl + 2 : npl - 1);
                 soff_tab += T * NPW * 4;
                 // (everything a layer derives from the thread index is derived HERE, from a copy the compiler cannot see through: hoisted out of the loops these values
                 // stay in registers across the whole kernel, and at 64 / 80 registers they are what gets spilled and reloaded inside the layers)
@@ -652,8 +680,8 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
 #pragma unroll
                 for (int w = 0; w < NPW; ++w) pw[w] = pw_next[w];
                 if (mine_next && !(LDPC_SPLIT_EXP & 2)) {
-                    bload<NPW>(pw_next, rs_tab, voff_tab, soff_tab);
-                    bload<REC>(rec_next, rs_msg, voff_rec, Lnext.rec_off * 4u);
+                    if (!(LDPC_SPLIT_EXP & 16) || pl < 1) bload<NPW>(pw_next, rs_tab, voff_tab, soff_tab);
+                    if (!(LDPC_SPLIT_EXP & 32)) bload<REC>(rec_next, rs_msg, voff_rec, Lnext.rec_off * 4u);
                 }
                 if (mine) {
                     uint32_t ro[REC];
@@ -688,7 +716,7 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                     } else if ((L.kind_nw & 0xffu) == 6) {
                         conflict_layer<MAXDEG, 6>(pw, rec, ro, L, ents + L.ent_off, rows + L.aux, tt, post, cw, cres);
                     } else {
-                        conflict_layer<MAXDEG, 3>(pw, rec, ro, L, ents + L.ent_off, nullptr, tt, post, cw, cres);
+                        conflict_layer<MAXDEG, 3>(pw, rec, ro, L, ents + L.ent_off, ents, tt, post, cw, cres);
                     }
                     // the next pseudo-layer's words are claimed HERE, before this one's record store is issued: the wait for them then sits where they have had a whole
                     // pseudo-layer to arrive, and the top of the next pseudo-layer waits for nothing (ldpc_kernel.hip)
@@ -696,12 +724,19 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                     for (int w = 0; w < REC; ++w) asm volatile("" : "+v"(rec_next[w]));
 #pragma unroll
                     for (int w = 0; w < NPW; ++w) asm volatile("" : "+v"(pw_next[w]));
-                    if (LDPC_SPLIT_EXP & 2) asm volatile("" :: "v"(ro[0]), "v"(ro[REC - 1]));
+                    if (LDPC_SPLIT_EXP & (2 | 64)) asm volatile("" :: "v"(ro[0]), "v"(ro[REC - 1]));
                     else bstore<REC>(ro, rs_msg, voff_rec, L.rec_off * 4u);
                     lds_pairs_wait();
 #ifdef LDPC_SPLIT_NARROW_PRIO
                     if (narrow) __builtin_amdgcn_s_setprio(0);
 #endif
+                } else if (LDPC_SPLIT_FIX & 2) {
+                    // (a wave without rows here claims too: where the two paths meet the compiler then knows the words have arrived on both, and the wait it would
+                    // otherwise place there -- vmcnt(0), one counter for loads and stores -- no longer holds the waves WITH rows until their record store is acknowledged)
+#pragma unroll
+                    for (int w = 0; w < REC; ++w) asm volatile("" : "+v"(rec_next[w]));
+#pragma unroll
+                    for (int w = 0; w < NPW; ++w) asm volatile("" : "+v"(pw_next[w]));
                 }
                 if (!(LDPC_SPLIT_EXP & 4)) lds_barrier();
 #if defined(LDPC_PROF)
@@ -717,6 +752,8 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
             const LdpcKernelArgs A = ldpc_args(P);
             const int N = A.N, K = A.K, R = A.R, q = A.q;
             int* __restrict__ s_flag = reinterpret_cast<int*>(lds_all + ((N + LDPC_SPLIT_SCRATCH + 15) & ~15) + 2 * 360 * 4 + 384);
+            int t = threadIdx.x;
+            asm volatile("" : "+v"(t));
             if (t == 0) A.trials[f] = ret;
             // hard decisions of [0,K): 64 bits per wave step via ballot, MSB-first bytes (module_dvbs2_demod.cpp:357-360)
             uint8_t* __restrict__ hd = A.hard + (size_t)f * A.hard_stride;

@@ -67,6 +67,8 @@ inline int ldpc_split_npw(int hs) {
     return words <= 1 ? 1 : words <= 2 ? 2 : words <= 4 ? 4 : 8;
 }
 
+inline int ldpc_split_plan_rec_dwords(int max_deg) { const int hs = (max_deg + 2) / 2; return hs <= 4 ? 1 : hs <= 8 ? 2 : 4; }
+
 // which codes the half-row decoder takes: regular ones with an even number of links per row (both halves then hold the same number of slots)
 inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P, int pack_max_depth = LDPC_SPLIT_PACK_MAX_DEPTH, int pass_max_depth = LDPC_SPLIT_PASS_MAX_DEPTH) {
     LdpcSplitPlan S;
@@ -78,7 +80,7 @@ inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P, int pack_max_depth
     }
     S.hs = NL / 2;
     S.npw = ldpc_split_npw(S.hs);
-    S.rec_dwords = S.hs <= 4 ? 1 : S.hs <= 8 ? 2 : 4;
+    S.rec_dwords = ldpc_split_plan_rec_dwords(P.max_deg);
     const int q = P.q, K = P.K, N = P.N, T = LDPC_SPLIT_T, hs = S.hs, npw = S.npw;
     auto scratch = [&](int t) { return (uint32_t)(N + (t & (LDPC_SPLIT_SCRATCH - 1))); };
     auto slot_addr = [&](int i, int j, int k) -> uint32_t {     // link k of row j of layer i; ~0: none

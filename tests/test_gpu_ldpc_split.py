@@ -1,6 +1,7 @@
-"""The half-row LDPC decoder (csrc/ldpc_split_kernel.hip: two lanes per row, one frame per workgroup) is selected with the context option ldpc_split = 1 for the normal
-frames it takes (rate 3/4); here it is FORCED on a fresh engine: posteriors, trial counts and hard decisions must equal the oracle's -- early exit, iteration
-limit, forced iterations, erasures, saturating garbage -- and many frames must flow through the persistent grid's work counter."""
+"""The half-row LDPC decoder (csrc/ldpc_split_kernel.hip: two lanes per row, one frame per workgroup) serves the normal frames it takes (rate 3/4) by default; the
+context option ldpc_split = 0 hands them back to the lane-per-row decoder (csrc/ldpc_kernel.hip).  BOTH are run here on engines of their own: posteriors, trial
+counts and hard decisions must equal the oracle's -- early exit, iteration limit, forced iterations, erasures, saturating garbage -- and many frames must flow
+through the persistent grid's work counter."""
 import os
 
 import numpy as np
@@ -12,12 +13,13 @@ pytestmark = pytest.mark.gpu
 CODES = [(6, 0)]
 
 
-@pytest.fixture(scope='module')
-def split_engine(pkg):
+@pytest.fixture(scope='module', params=[1, 0], ids=['half_row', 'lane_per_row'])
+def split_engine(pkg, request):
     import torch
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
-    eng = pkg.Engine(0, options={'ldpc_split': 1})      # (read when an engine first builds a code's plan)
+    eng = pkg.Engine(0, options={'ldpc_split': request.param})
+    assert eng.ldpc_decoder_form(6, False) == (2 if request.param else 0)
     yield eng
     eng.close()
 

@@ -15,7 +15,7 @@ rd = lambda n: open(os.path.join(F, n)).read()
 open(os.path.join(P, tag + '_bench.json'), 'w').write(rd('bench.json'))
 open(os.path.join(P, tag + '_bench_kernel_stats.csv'), 'w').write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary (tools/profile_run.sh)\n' + rd('kt.csv'))
 open(os.path.join(P, tag + '_bench_timeline.txt'), 'w').write('# start_ms end_ms duration_ms queue kernel -- dispatches >= 2 ms of the same run (tools/timeline.py); q=3: FEC stream, q=2: front-end stream\n' + rd('timeline.txt'))
-rows = [l.rstrip() for p in ('p1', 'p2', 'p3', 'p4') if os.path.exists(os.path.join(F, p + '.csv')) for l in open(os.path.join(F, p + '.csv')) if 'ldpc_decode_kernel' in l]
+rows = [l.rstrip() for p in ('p1', 'p2', 'p3', 'p4') if os.path.exists(os.path.join(F, p + '.csv')) for l in open(os.path.join(F, p + '.csv')) if 'ldpc_decode_kernel' in l or 'ldpc_split_kernel' in l]
 get = lambda c: ([float(l.split(',')[-1]) for l in rows if '"' + c + '"' in l] or [float('nan')])[0]
 dur_ns = [float(l.split(',')[-4]) for l in rows if 'FETCH' not in l and 'SQ_' not in l and 'WRITE' not in l]   # (name,calls,total,AVERAGE,min,max,percentage)
 ms = sum(dur_ns) / len(dur_ns) / 1e6
@@ -27,7 +27,7 @@ fetch, write, valu = get('FETCH_SIZE'), get('WRITE_SIZE'), get('SQ_INSTS_VALU')
 traffic = (2 * fetch + write) * 1024
 cus, simds, clk = 256, 4, 2.4e9
 t = {
-    'kernel': 'ldpc_decode_kernel<12,4,false>',
+    'kernel': 'ldpc_split_kernel<12>' if any('ldpc_split_kernel' in l for l in rows) else 'ldpc_decode_kernel<12,4,false>',
     'kernel_source_sha16': ldpc_source_hash(),     # bench.py flags these figures as stale when the decoder sources have changed since
     'launch': {'rate': '3/4 normal', 'frames': frames, 'iterations': iters, 'forced': True, 'kernel_ms': round(ms, 3)},
     'source': 'profiles/%s_ldpc_pmc.txt (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc SQ_* in separate passes, tools/pmc_ldpc.py); gfx950: FETCH_SIZE tallies '
@@ -44,9 +44,9 @@ t = {
     # where a wave's resident cycles go (SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES, both in quad-cycles; fourth PMC pass)
     'wave_cycles_fraction': {k: round(get(c) / get('SQ_WAVE_CYCLES'), 4) for k, c in (('valu', 'SQ_ACTIVE_INST_VALU'), ('scalar', 'SQ_ACTIVE_INST_SCA'),
                              ('lds', 'SQ_ACTIVE_INST_LDS'), ('misc', 'SQ_ACTIVE_INST_MISC'), ('waiting_for_lds', 'SQ_WAIT_INST_LDS'))},
-    'reading': 'a wave executes an instruction in ~30 % of its resident cycles and a SIMD issues a vector instruction in ~15 % of its cycles: the decoder is bound by the '
-               'latency of its barrier-separated phases (per-wave instruction streams, LDS round trips at the phase boundaries, serial sections), not by memory and not '
-               'by vector throughput (DESIGN.md section 5; round 4 experiments: profiles/r04_ubench_notes.txt)',
+    'reading': 'valu_per_simd_cycle x 4.3 = the share of the launch the vector ALUs are busy: the decoder\'s instructions are packed 16-bit / DPP / byte-permute forms, which '
+               'a SIMD issues every 4.3 cycles (plain 32-bit VOP2: 2.3; profiles/r05_valu_rates.txt) -- rounds 1-4 read the same counter against a full-rate issue model and '
+               'called the kernel latency-bound.  The rest is the serial sections of the layers with shared bits (profiles/r05_ldpc_split_layers.txt; DESIGN.md section 5)',
 }
 json.dump(t, open(os.path.join(P, tag + '_ldpc_traffic.json'), 'w'), indent=2)
 wrows = [l.rstrip() for p in ('w1', 'w2', 'w3') if os.path.exists(os.path.join(F, p + '.csv')) for l in open(os.path.join(F, p + '.csv')) if 'ldpc_wave_kernel' in l]
