@@ -19,9 +19,9 @@
 //           through per-row hand-off records (~85 cycles per chained row), four lanes per row of a deep narrow level structure, or a barrier per
 //           level.  A packed level costs a whole row update and a vector-memory round trip for its table entry (measured ~1 750 cycles,
 //           profiles/r05_ldpc_split_layers.txt), a walked one a few hundred: only shallow layers are worth packing.
-//       kind 2 (level passes): rows in lane order; pass l updates the rows of level l (whole conflict-free updates under an exec mask), a barrier between
-//           passes.  For the chain layers, whose levels are runs of consecutive rows, a wave works in one or two passes: ~1.3 row updates per wave and no
-//           special arithmetic, against ~1.8 for the chain walk's publish / record / join.
+//       kind 2 (level passes; NOT in the shipped plan, context option ldpc_split_passes): rows in lane order; pass l updates the rows of level l (whole conflict-free
+//           updates under an exec mask), a barrier between passes.  Measured (r05, rate 3/4, 4096 frames x 50 iterations): every chain layer walked 39.6 ms, the chain
+//           layers of up to 5 levels as passes 41.9 ms -- a barrier-separated pass costs ~1 000 cycles whatever it does, a walked row ~135.
 //   * idle lanes (beyond the packed rows; rows 360..383 of a full layer) point every slot at scratch bytes behind the posteriors: they run
 //     the same instructions and store to bytes nobody reads -- no exec masking in the row update.  The missing previous parity bit of row 0
 //     of layer 0 points there too; its pseudo-layer carries a flag and the thread index.
@@ -39,7 +39,7 @@ constexpr int LDPC_SPLIT_SCRATCH = 64;         // scratch bytes behind the poste
 #define LDPC_SPLIT_PACK_MAX_DEPTH 0            // layers with shared bits and up to this many levels are packed level by level; deeper ones keep the walks of ldpc_kernel.hip
 #endif
 #ifndef LDPC_SPLIT_PASS_MAX_DEPTH
-#define LDPC_SPLIT_PASS_MAX_DEPTH 5            // chain layers up to this many levels run as level PASSES (kind 2): rows in lane order, one whole-row update per level under the lanes' level mask
+#define LDPC_SPLIT_PASS_MAX_DEPTH 0            // chain layers up to this many levels run as level PASSES (kind 2) instead of the chain walk: rows in lane order, one whole-row update per level under the lanes' level mask
 #endif                                         // (a chain layer's levels are runs of consecutive rows: a wave takes part in one pass, two where a run ends inside it)
 
 struct LdpcSplitLayer {   // 16 bytes = one s_load_dwordx4

@@ -13,13 +13,15 @@ pytestmark = pytest.mark.gpu
 CODES = [(6, 0)]
 
 
-@pytest.fixture(scope='module', params=[1, 0], ids=['half_row', 'lane_per_row'])
+# (the plan's alternatives -- layers with shared bits packed level by level, chain layers as level passes -- are the shipped kernel's other paths: run them too)
+@pytest.fixture(scope='module', params=[{'ldpc_split': 1}, {'ldpc_split': 0}, {'ldpc_split': 1, 'ldpc_split_passes': 5}, {'ldpc_split': 1, 'ldpc_split_pack': 4}],
+                ids=['half_row', 'lane_per_row', 'half_row_level_passes', 'half_row_packed_levels'])
 def split_engine(pkg, request):
     import torch
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
-    eng = pkg.Engine(0, options={'ldpc_split': request.param})
-    assert eng.ldpc_decoder_form(6, False) == (2 if request.param else 0)
+    eng = pkg.Engine(0, options=request.param)
+    assert eng.ldpc_decoder_form(6, False) == (2 if request.param['ldpc_split'] else 0)
     yield eng
     eng.close()
 
