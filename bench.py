@@ -34,9 +34,10 @@ import time
 import numpy as np
 
 # Mixed batches drive up to nine HIP streams side by side, HIP maps them onto GPU_MAX_HW_QUEUES hardware queues (default 4; 64 mixed transponders: 74 ... 85 ms per call on
-# 4 queues, 48 on 6, 44 on 8).  The library asks for 8 when it is loaded (csrc/capi.hip) -- but this process imports torch first, whose HIP runtime has read its
-# environment by then: so here, and in any host that initialises HIP before it loads the plugin, the variable is set up front.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# 4 queues, 48 on 6, 44 on 8; the DVB-S line late in a full run, with the S2 engine's streams still alive: 1 570 Msym/s on 8 queues, 2 230-2 350 on 12).  The library asks for
+# 12 when it is loaded (csrc/capi.hip) -- but this process imports torch first, whose HIP runtime has read its environment by then: so here, and in any host that
+# initialises HIP before it loads the plugin, the variable is set up front.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '12')
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))

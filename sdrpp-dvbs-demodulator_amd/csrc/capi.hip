@@ -310,10 +310,10 @@ static int bch_run(dvbs2gpu_ctx* ctx, const FecParams& f, uint8_t* d_frames, int
 // ---------------------------------------------------------------------------------------------------
 // Mixed batches drive up to nine HIP streams side by side (the caller's, the front end's, the FEC jobs' side streams); HIP maps its streams onto GPU_MAX_HW_QUEUES
 // hardware queues (default 4), and streams that share a queue run one behind the other (64 mixed transponders: 74 ... 85 ms per call on 4 queues, 48 on 6, 44 on 8).
-// The runtime reads the variable when it initialises, i.e. at the first HIP call of the process: the library asks for 8 queues when it is LOADED -- a plugin is loaded
+// The runtime reads the variable when it initialises, i.e. at the first HIP call of the process: the library asks for 12 queues (an S2 batch and a DVB-S bank of one process side by side keep eleven streams busy) when it is LOADED -- a plugin is loaded
 // before its host touches the GPU -- unless the host's environment already says otherwise.  Loaded into a process that has initialised HIP it changes nothing
 // (results are the same on any number of queues).
-__attribute__((constructor)) static void dvbs2gpu_on_load() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+__attribute__((constructor)) static void dvbs2gpu_on_load() { setenv("GPU_MAX_HW_QUEUES", "12", 0); }
 
 extern "C" {
 
