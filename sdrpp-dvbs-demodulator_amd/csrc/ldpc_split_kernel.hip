@@ -26,6 +26,9 @@ namespace s2 {
 #ifndef LDPC_SPLIT_EXP
 #define LDPC_SPLIT_EXP 0          // development switch for TIMING experiments (results wrong): 2 = no table / record traffic in the layer loop (16 / 32 / 64: no table loads / record loads / record stores), 4 = no layer barrier, 8 = no output phase
 #endif
+#ifndef LDPC_SPLIT_SKIP
+#define LDPC_SPLIT_SKIP 0           // development switch for counter experiments (results wrong): bit k set = the pseudo-layers of kind k do nothing
+#endif
 #ifndef LDPC_SPLIT_WPE
 #define LDPC_SPLIT_WPE 8          // waves per SIMD the register allocation aims at (6 = 80 VGPRs: two workgroups per compute unit; 8 = 64: room for a 128-register front-end wave beside them)
 #endif
@@ -689,7 +692,10 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                     const bool narrow = ((L.kind_nw >> 8) & 0xffu) <= LDPC_SPLIT_NARROW_PRIO;
                     if (narrow) __builtin_amdgcn_s_setprio(3);
 #endif
-                    if ((L.kind_nw & 0xffu) == 0) {
+                    if (LDPC_SPLIT_SKIP && ((LDPC_SPLIT_SKIP >> (L.kind_nw & 0xffu)) & 1)) {      // (timing / counter experiments: the layers of these kinds do nothing)
+#pragma unroll
+                        for (int w = 0; w < REC; ++w) ro[w] = 0;
+                    } else if ((L.kind_nw & 0xffu) == 0) {
                         RowState<MAXDEG> RS;
                         int M0, M1, SXs;
                         row_input<MAXDEG, 0>(RS, pw, rec, 0u, (L.kind_nw >> 20) & 1u, L.aux, tt, M0, M1, SXs);
@@ -720,10 +726,16 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                     }
                     // the next pseudo-layer's words are claimed HERE, before this one's record store is issued: the wait for them then sits where they have had a whole
                     // pseudo-layer to arrive, and the top of the next pseudo-layer waits for nothing (ldpc_kernel.hip)
+#if defined(LDPC_PROF) && LDPC_PROF == 4
+                    const unsigned long long t_claim = clock64();        // (how long the claim waits: prof[200 + pl])
+#endif
 #pragma unroll
                     for (int w = 0; w < REC; ++w) asm volatile("" : "+v"(rec_next[w]));
 #pragma unroll
                     for (int w = 0; w < NPW; ++w) asm volatile("" : "+v"(pw_next[w]));
+#if defined(LDPC_PROF) && LDPC_PROF == 4
+                    if (A.prof && blockIdx.x == 0 && (t == 0 || t == 384)) A.prof[200 + pl + (t ? 50 : 0)] += clock64() - t_claim;
+#endif
                     if (LDPC_SPLIT_EXP & (2 | 64)) asm volatile("" :: "v"(ro[0]), "v"(ro[REC - 1]));
                     else bstore<REC>(ro, rs_msg, voff_rec, L.rec_off * 4u);
                     lds_pairs_wait();

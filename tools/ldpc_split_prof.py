@@ -41,3 +41,8 @@ if full[300:332].any():        # -DLDPC_PROF=3 build: waypoints inside the chain
     for who, wn in ((0, 'thread 0  '), (1, 'thread 384')):
         v = full[300 + 16 * who: 300 + 16 * who + 7] / iters / nfr / nchain
         print('chain layers, %s: ' % wn + '  '.join('%s=%.0f' % (names[i], v[i]) for i in range(7)) + '   sum=%.0f per layer' % v.sum())
+
+if full[200:300].any():        # -DLDPC_PROF=4 build: cycles the claim of the next pseudo-layer's words waits, per pseudo-layer
+    for who, off in (('thread 0  ', 200), ('thread 384', 250)):
+        v = full[off:off + len(sp['kind'])] / iters / nfr
+        print('claim wait, %s: total %.0f cycles per iteration; per pseudo-layer: %s' % (who, v.sum(), ' '.join('%.0f' % x for x in v)))
