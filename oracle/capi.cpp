@@ -152,6 +152,7 @@ void orc_s2rx_pll_study(void* h, int tile, long long* hist34, long long* mismatc
     if (mismatch) *mismatch = r->study_mismatch;
     r->study_tile = tile;
 }
+void orc_s2rx_pll_study2(void* h, long long* out3) { S2Rx* r = (S2Rx*)h; out3[0] = r->study_steps; out3[1] = r->study_syms; out3[2] = r->study_evals; }
 float orc_s2rx_agc_gain(void* h) { return ((S2Rx*)h)->agc_gain_now(); }   // (tools/sensitivity.py: level at the AGC output = gain x input rms)
 
 // stage-level entry points on a receiver object (state carried inside it)

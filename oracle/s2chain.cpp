@@ -575,6 +575,31 @@ void S2Rx::pll_tile_study(const cf* in, const FrameCtx& fc, Pcl p0) {
         }
         study_hist[passes < 33 ? passes : 33]++;
         if (r.phase != st.phase || r.freq != st.freq) study_mismatch++;
+        {
+            // the form the engine runs (s2_rx_kernels.hip, S2_PLL_TILES): guessed phases = start + k * freq; a pass evaluates every symbol's table cell, the replay restarts at
+            // the first symbol whose cell changed (everything before it stands), done when no cell changes
+            std::vector<int> cell(n, -1);
+            std::vector<float> pk(n + 1), fk(n + 1);
+            for (int k = 0; k < n; ++k) { pk[k] = truth.phase + (float)k * truth.freq; fk[k] = truth.freq; }
+            Pcl q = truth;
+            for (;;) {
+                ++study_evals;
+                int c = -1;
+                for (int k = 0; k < n; ++k) {
+                    float err = 0;
+                    const cf rv = cmul(in[base + k], phasor(-pk[k]));
+                    const int cl = Constellation::lut_index(rv.re) * 256 + Constellation::lut_index(rv.im);
+                    constel.soft_lut(rv, nullptr, &err);
+                    if (cl != cell[k]) { cell[k] = cl; e[k] = err; if (c < 0) c = k; }
+                }
+                if (c < 0) break;
+                q = truth;
+                if (c > 0) { q.phase = pk[c]; q.freq = fk[c]; }
+                for (int k = c; k < n; ++k) { pk[k] = q.phase; fk[k] = q.freq; q.advance(e[k]); ++study_steps; }
+            }
+            study_syms += n;
+            if (q.phase != st.phase || q.freq != st.freq) study_mismatch++;
+        }
         truth = st;
     }
 }

@@ -119,6 +119,7 @@ public:
     int study_tile = 0;
     long long study_hist[34] = {};
     long long study_mismatch = 0;
+    long long study_steps = 0, study_syms = 0, study_evals = 0;   // the same tiles with the replay restarted at the first symbol whose table cell changed: replay steps, symbols, evaluation passes
     std::vector<int8_t> dbg_llr;        // deinterleaved LLRs per frame
     std::vector<FrameStats> dbg_stats;
     float nco_freq() const { return nco_freq_; }

@@ -1308,6 +1308,9 @@ __device__ __attribute__((noinline)) float soft_phase_err_group(lds_cf32* __rest
 #ifndef FL_LPS_N
 #define FL_LPS_N 8
 #endif
+#ifndef S2_PLL_TILES
+#define S2_PLL_TILES 1   // one stream per workgroup: a payload tile of the PLL as a fixed point of (parallel phase-error evaluation, serial replay) instead of the serial loop (A/B switch)
+#endif
 #ifndef S2_PLL_ASM
 #define S2_PLL_ASM 1     // the PLL's payload-tile loop of s2_frame_loops_kernel written out (A/B switch)
 #endif
@@ -1471,7 +1474,111 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             // the loop) is left to the lanes that copy the tile out.  Everything else goes through the general loop below.
             const bool plain = base >= 90 && !(next_pilot >= 0 && next_pilot < base + m && next_pilot + 36 > base);
             if (plain) {
-                if (C.bits != 5) {
+                if (S2_PLL_TILES && C.bits != 5 && spw == 1) {
+                    // ONE STREAM PER WORKGROUP: THE TILE AS A FIXED POINT (oracle: S2Rx::pll_tile_study; profiles/r05_pll_tile_study.txt).  What a symbol contributes to the
+                    // loop, e[k], depends on the loop phase at that symbol only (rotation, table cell); the recurrence proper (dvbs2_pll.cpp:81) is a dozen instructions.  So: lane k
+                    // evaluates e[k] from a guessed phase (first the phase at the tile's start advanced by the frequency alone) -- all symbols of the tile side by side, one table
+                    // round trip for the lot -- then every lane replays the recurrence over the tile with those e[k] in the reference's order (uniform values: the errors come out
+                    // of the lanes through v_readlane, lane k keeps the phase of step k), the lanes evaluate again at the replayed phases ... until no symbol's table cell changes.
+                    // By induction over k that fixed point IS the serial result: phase[0] is exact; an exact phase[k] gives the exact e[k], hence the exact phase[k + 1].  A replay
+                    // starts at the first symbol whose cell changed (everything before it stands).  Same functions as the serial form below: bit-identical.
+                    const cf32* tl0 = &tiles[0][0];
+                    cf32* ot0 = &tiles[0][FL_TILE];
+                    const bool mine_k = lane < m;
+                    const cf32 sym = mine_k ? tl0[lane] : cf32{0.f, 0.f};
+                    // (the loop state of lane 0: the lane groups without a stream are restored to their frame's start after every frame and would replay from there)
+                    const float ph0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pll.phase)));
+                    const float fq0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pll.freq)));
+                    float myph = ph0 + (float)lane * fq0, myfq = fq0, mye = 0.f;
+                    int mycell = -1;
+                    cf32 tmp_val{0.f, 0.f};
+                    PclDev r = pll;
+                    for (;;) {
+                        bool changed = false;
+                        if (mine_k) {
+                            tmp_val = cmul(sym, phasor_fast(-myph));
+                            const int cell = lut_cell(tmp_val.re, tmp_val.im);
+                            changed = cell != mycell;
+                            mycell = cell;
+                        }
+                        const unsigned long long chg = __ballot(changed);
+                        if (chg == 0) break;                                       // every error reproduced: the phases are the serial loop's
+                        if (changed) mye = as_global(lut_err_v)[mycell];
+                        const int c = __ffsll((long long)chg) - 1;                 // the first symbol whose error changed: the replay starts there
+                        if (c > 0) {
+                            r.phase = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myph), c));
+                            r.freq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myfq), c));
+                        } else { r.phase = ph0; r.freq = fq0; }
+#if S2_PLL_ASM
+                        {
+                            // the replay written out (a lone wave's time is its instruction count, tools/ubench/lone_wave.hip): per symbol the error out of lane k (v_readlane), lane k
+                            // keeps the state the step starts from, PhaseControlLoop::advance and one wrap into [-pi, pi] -- the same operations in the same order as the serial loop's
+                            // tail below (multiplication and addition apart: no fused multiply-add); 11 vector instructions, four steps per trip of the loop (a taken branch costs ~28 cycles)
+                            uint32_t kq = (uint32_t)__builtin_amdgcn_readfirstlane(c), mq = (uint32_t)__builtin_amdgcn_readfirstlane(m);
+                            const float minf_q = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pll.minFreq)));
+                            float alpha_v = pll.alpha, beta_v = pll.beta, maxf_v = pll.maxFreq;
+                            asm volatile("" : "+v"(alpha_v), "+v"(beta_v), "+v"(maxf_v));
+#define S2_REPLAY_STEP(W, B)                                                    \
+                                "v_readlane_b32 s60, %[mye], %[k]\n\t"            \
+                                "v_cmp_eq_u32 vcc, %[k], %[lane]\n\t"             \
+                                "v_cndmask_b32 %[myph], %[myph], %[ph], vcc\n\t"  \
+                                "v_cndmask_b32 %[myfq], %[myfq], %[fr], vcc\n\t"  \
+                                "v_mul_f32 v124, s60, %[beta]\n\t"                \
+                                "v_add_f32 %[fr], %[fr], v124\n\t"                \
+                                "v_med3_f32 %[fr], %[fr], %[minf], %[maxf]\n\t"   \
+                                "v_mul_f32 v124, s60, %[alpha]\n\t"               \
+                                "v_add_f32 v124, %[fr], v124\n\t"                 \
+                                "v_add_f32 %[ph], %[ph], v124\n\t"                \
+                                "v_cmp_gt_f32 vcc, |%[ph]|, s71\n\t"              \
+                                "s_cbranch_vccnz " W "f\n\t"                      \
+                                B ":\n\t"                                         \
+                                "s_add_u32 %[k], %[k], 1\n\t"                     \
+                                "s_cmp_lt_u32 %[k], %[m]\n\t"
+                            // (the wrap into [-pi, pi] out of line: |phase| <= pi is the rule, and a branch not taken is nearly free)
+#define S2_REPLAY_WRAP(W, B)                                                    \
+                                W ":\n\t"                                         \
+                                "v_add_f32 v124, s74, %[ph]\n\t"                  \
+                                "v_cmp_lt_f32 vcc, s71, %[ph]\n\t"                \
+                                "v_cndmask_b32 %[ph], %[ph], v124, vcc\n\t"       \
+                                "v_add_f32 v124, s73, %[ph]\n\t"                  \
+                                "v_cmp_gt_f32 vcc, s72, %[ph]\n\t"                \
+                                "v_cndmask_b32 %[ph], %[ph], v124, vcc\n\t"       \
+                                "s_branch " B "b\n\t"
+                            asm volatile(
+                                "s_mov_b32 s71, 0x40490fdb\n\t"          // pi
+                                "s_mov_b32 s72, 0xc0490fdb\n\t"          // -pi
+                                "s_mov_b32 s73, 0x40c90fdb\n\t"          // 2 pi
+                                "s_mov_b32 s74, 0xc0c90fdb\n\t"          // -2 pi
+                                "s_cmp_lt_u32 %[k], %[m]\n\t"
+                                "s_cbranch_scc0 2f\n\t"
+                                "1:\n\t"
+                                S2_REPLAY_STEP("11", "21") "s_cbranch_scc0 2f\n\t"
+                                S2_REPLAY_STEP("12", "22") "s_cbranch_scc0 2f\n\t"
+                                S2_REPLAY_STEP("13", "23") "s_cbranch_scc0 2f\n\t"
+                                S2_REPLAY_STEP("14", "24") "s_cbranch_scc1 1b\n\t"
+                                "s_branch 2f\n\t"
+                                S2_REPLAY_WRAP("11", "21") S2_REPLAY_WRAP("12", "22") S2_REPLAY_WRAP("13", "23") S2_REPLAY_WRAP("14", "24")
+                                "2:"
+                                : [ph] "+v"(r.phase), [fr] "+v"(r.freq), [myph] "+v"(myph), [myfq] "+v"(myfq), [k] "+s"(kq)
+                                : [mye] "v"(mye), [lane] "v"(lane), [alpha] "v"(alpha_v), [beta] "v"(beta_v), [minf] "s"(minf_q), [maxf] "v"(maxf_v), [m] "s"(mq)
+                                : "v124", "s60", "s71", "s72", "s73", "s74", "vcc", "scc");
+#undef S2_REPLAY_WRAP
+#undef S2_REPLAY_STEP
+                        }
+#else
+                        for (int kk = c; kk < m; ++kk) {
+                            const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mye), kk));
+                            const bool me = lane == kk;
+                            myph = me ? r.phase : myph;
+                            myfq = me ? r.freq : myfq;
+                            r.advance(e);
+                            r.wrap_pi_once();
+                        }
+#endif
+                    }
+                    if (mine_k) ot0[lane] = tmp_val;
+                    pll.phase = r.phase; pll.freq = r.freq;
+                } else if (C.bits != 5) {
 #if S2_PLL_ASM
                     // THE SHORT LOOP WRITTEN OUT (a small bank's frame loops are one wave per CU: its time is its instruction count + the table's round trip;
                     // tools/ubench/lone_wave.hip).  Per symbol, as in the C++ form below: tmp = tl[k] * phasor(-phase) (dvbs2m::sincosf_det; two packed

@@ -15,7 +15,9 @@ iq, bb, _ = orc.transmit(modcod, short, pilots, nframes=frames, seed=77, esn0_db
 L = orc._bind_chain()
 L.orc_s2rx_pll_study.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
 L.orc_s2rx_pll_study.restype = None
-for tile in (16, 32, 64, 128):
+L.orc_s2rx_pll_study2.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+L.orc_s2rx_pll_study2.restype = None
+for tile in (16, 32, 46, 64, 128):
     rx = orc.OracleRx(orc.default_cfg(modcod, short, pilots, force_ldpc_iters=-1))
     L.orc_s2rx_pll_study(rx.h, tile, None, None)
     rx.process(iq)
@@ -29,3 +31,7 @@ for tile in (16, 32, 64, 128):
     print('tile %3d: %6d tiles, fixed point != serial loop in %d, passes per tile: mean %.2f, histogram %s%s' % (tile, n, mis.value, mean,
           ' '.join('%d:%.1f%%' % (i, 100 * h[i] / n) for i in range(34) if h[i]), ''))
     print('          modelled cycles per symbol: %.0f (the serial loop: ~590)' % (mean * per_pass / tile))
+    o3 = (C.c_longlong * 3)()
+    L.orc_s2rx_pll_study2(rx.h, o3)
+    steps, syms, evals = list(o3)
+    print('          the form the engine runs (replay restarted at the first symbol whose table cell changed): %.2f evaluation passes per tile, %.2f replay steps per symbol' % (evals / max(n, 1), steps / max(syms, 1)))
