@@ -625,10 +625,22 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
             const __amdgpu_buffer_rsrc_t rs_msg = __builtin_amdgcn_make_buffer_rsrc(msg, 0, A.pent_base * 4, 0x00020000);
             const bool check = !A.force || it == A.max_trials;
             if (check) {
+#if defined(LDPC_PROF) && LDPC_PROF == 5
+                const unsigned long long tc0 = clock64();        // (where a check's time goes: prof[400..403], thread 0 of workgroup 0)
+#endif
                 const uint32_t zflag = sign_pack(post, N, reinterpret_cast<uint8_t*>(sgn), t, T);
+#if defined(LDPC_PROF) && LDPC_PROF == 5
+                const unsigned long long tc1 = clock64();
+#endif
                 __syncthreads();              // the sign bytes went to global memory: full barrier (drains vmcnt)
+#if defined(LDPC_PROF) && LDPC_PROF == 5
+                const unsigned long long tc2 = clock64();
+#endif
                 const bool bad = zflag != 0 || syndromes_bad<MAXDEG>(q, A.synd_base, P->ents, sgn, t, T);
                 const unsigned long long b = __ballot(bad);
+#if defined(LDPC_PROF) && LDPC_PROF == 5
+                const unsigned long long tc3 = clock64();
+#endif
                 if ((t & 63) == 0) s_flag[t >> 6] = (b != 0);
                 lds_barrier();
                 int any = 0;
@@ -636,6 +648,9 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                 for (int w = 0; w < T / 64; ++w) any |= s_flag[w];
                 any = __builtin_amdgcn_readfirstlane(any);
                 lds_barrier();                // (the flags are rewritten by the next check)
+#if defined(LDPC_PROF) && LDPC_PROF == 5
+                if (A.prof && blockIdx.x == 0 && t == 0) { const unsigned long long tc4 = clock64(); A.prof[400] += tc1 - tc0; A.prof[401] += tc2 - tc1; A.prof[402] += tc3 - tc2; A.prof[403] += tc4 - tc3; A.prof[404] += 1; }
+#endif
                 if (A.force) { ret = any ? -1 : A.max_trials; break; }
                 if (!any) { ret = it; break; }
                 if (it == A.max_trials) { ret = -1; break; }
