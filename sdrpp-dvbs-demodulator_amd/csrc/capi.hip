@@ -58,6 +58,7 @@ int apply_option(dvbs2gpu_ctx* c, const char* name, int v) {
     else if (n == "stage_min_duty") { if (!in(-1, 8)) return -1; c->stage_pipeline_min_duty = v; }
     else if (n == "loops_ahead") { if (!in(0, 1)) return -1; c->loops_ahead = v; }
     else if (n == "mixed_groups") { if (!in(0, 1)) return -1; c->mixed_groups = v; }
+    else if (n == "fec_part") { if (!in(-1, 1)) return -1; c->fec_part = v; c->fec_part_on = v == 1; c->fec_part_trend = 0; }
     else if (n == "mix_fec_streams") { if (!in(1, 8)) return -1; c->mix_fec_streams = v; }
     else if (n == "g_prio_duty") { if (!in(-1, 8)) return -1; if (v < 0) c->g_prio_auto = true; else { c->g_prio_duty = v; c->g_prio_auto = false; } }
     else if (n == "dvbs_fe_slices") { if (!in(1, s2::DVBS_FE_MAX_SLICES)) return -1; c->dvbs_fe_slices = v; }
@@ -409,9 +410,11 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
     }
     if (ctx->fe_stream) (void)hipStreamDestroy(ctx->fe_stream);
     if (ctx->fec_stream) (void)hipStreamDestroy(ctx->fec_stream);
+    if (ctx->fec_part_stream) (void)hipStreamDestroy(ctx->fec_part_stream);
     if (ctx->ev_llr) (void)hipEventDestroy(ctx->ev_llr);
     for (int g = 0; g < dvbs2gpu_ctx::MAX_PIPE_GROUPS; ++g) {
         for (int k = 0; k < 2; ++k) if (ctx->ev_fec[g][k]) (void)hipEventDestroy(ctx->ev_fec[g][k]);
+        for (int k = 0; k < 2; ++k) if (ctx->ev_fec_t0[g][k]) (void)hipEventDestroy(ctx->ev_fec_t0[g][k]);
         if (ctx->ev_llr_grp[g]) (void)hipEventDestroy(ctx->ev_llr_grp[g]);
         if (ctx->grp_stream[g]) (void)hipStreamDestroy(ctx->grp_stream[g]);
         ctx->fws_grp[g].release();

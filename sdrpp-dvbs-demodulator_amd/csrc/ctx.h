@@ -12,6 +12,7 @@
 #include "ldpc_plan.h"
 #include "ldpc_wave_plan.h"
 #include "ldpc_split_plan.h"
+#include <chrono>
 #include "kernels.h"
 #include "s2_rx.h"
 
@@ -142,6 +143,17 @@ struct dvbs2gpu_ctx {
     s2::Workspace ws_fecbuf[MAX_PIPE_GROUPS][2][3];       // per parity: LLRs | BBFRAMEs | frame refs + first[] + trials + corrections
     int fec_parity[MAX_PIPE_GROUPS] = {};
     hipEvent_t ev_fec[MAX_PIPE_GROUPS][2] = {};   // end of a group's FEC job, per job parity (the next job is enqueued before the previous one is delivered)
+    hipEvent_t ev_fec_t0[MAX_PIPE_GROUPS][2] = {};   // ... and its start (timing events: the job's duration feeds the rule below)
+    // THE PLUGIN'S MODE BY SPACE (s2_demod.hip, process_group): a second FEC stream confined to FEC_PART_CUS compute units.  A single-configuration batch whose decoder job is long
+    // done when the next call's front end is through AND would still fit into a call period on that many units gets its jobs there: the front end, which is that batch's critical
+    // path, then shares fewer units with decoder workgroups.  Jobs on the two streams never overlap (they share the FEC workspaces): fec_last_done / fec_last_stream.
+    hipStream_t fec_part_stream = nullptr;
+    hipEvent_t fec_last_done = nullptr;
+    hipStream_t fec_last_stream = nullptr;
+    int fec_part = -1;                        // option fec_part: -1 by the rule, 0 never, 1 every big job of a single-configuration batch
+    bool fec_part_on = false;
+    int fec_part_trend = 0;
+    std::chrono::steady_clock::time_point fec_last_entry{};
     // several groups of one pipelined batch run their MODCOD-dependent stages side by side (one host thread and HIP stream each)
     s2::Workspace ws_grp[MAX_PIPE_GROUPS][8];
     hipStream_t grp_stream[MAX_PIPE_GROUPS] = {};

@@ -361,8 +361,31 @@ struct PendingFec {
     uint8_t** d_dst = nullptr;          // [nf] device table of the frames' destinations, filled by the delivery
     size_t n_results = 0;               // int32 words in d_trials (ACM/VCM)
     hipEvent_t done = nullptr;          // recorded on the FEC stream behind the job
+    hipEvent_t t0 = nullptr;            // ... and in front of it (big CCM jobs: the job's duration, for the partition rule)
+    bool on_part = false;               // the job ran on the partition stream
     std::vector<hipEvent_t> done_more;  // (a job whose parts ran on several streams: one event per stream)
 };
+
+
+// FEC jobs of one context share its FEC workspaces: whichever FEC stream a job goes onto, it starts behind the job before it
+#ifndef FEC_PART_CUS_N
+#define FEC_PART_CUS_N 128
+#endif
+constexpr int FEC_PART_CUS = FEC_PART_CUS_N;
+static int fec_stream_enter(dvbs2gpu_ctx* ctx, hipStream_t sf) {
+    if (ctx->fec_last_done && ctx->fec_last_stream && ctx->fec_last_stream != sf) HIP_TRY(hipStreamWaitEvent(sf, ctx->fec_last_done, 0));
+    return 0;
+}
+static void fec_stream_leave(dvbs2gpu_ctx* ctx, hipStream_t sf, hipEvent_t done) { ctx->fec_last_done = done; ctx->fec_last_stream = sf; }
+static int fec_part_stream(dvbs2gpu_ctx* ctx, hipStream_t* out) {
+    if (!ctx->fec_part_stream) {
+        uint32_t mask[8] = {};
+        for (int i = 0; i < FEC_PART_CUS && i < ctx->num_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+        HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->fec_part_stream, 8, mask));
+    }
+    *out = ctx->fec_part_stream;
+    return 0;
+}
 
 // the streams of the whole batch a pipelined call works on: a job is collected into the buffers of whichever of ITS streams are part of this batch
 // -- in any order, in any configuration group; frames of a stream that has left are dropped (collect them with a zero-count call before it leaves)
@@ -770,17 +793,27 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             if ((rc = fec_run(ctx, mp.fec, (const int8_t*)ctx->ws_fecbuf[slot][par][0].p, nf, mt, force, (uint8_t*)ctx->ws_fecbuf[slot][par][1].p, j_trials, j_corr, st,
                               &ctx->fws_grp[slot])))
                 return rc;
-            if (!ctx->ev_fec[slot][par]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fec[slot][par], hipEventDisableTiming));
+            if (!ctx->ev_fec[slot][par]) HIP_TRY(hipEventCreate(&ctx->ev_fec[slot][par]));
             HIP_TRY(hipEventRecord(ctx->ev_fec[slot][par], st));
             job->done = ctx->ev_fec[slot][par];
         } else {
             std::lock_guard<std::mutex> fl(ctx->fec_mtx);
+            // (a single-configuration batch whose decoder has room to spare: onto the partition stream, ctx.h)
+            if (ctx->fec_part_on && !own_ws && !pre_nsym) {
+                if ((rc = fec_part_stream(ctx, &sf))) return rc;
+                job->on_part = true;
+            }
+            if ((rc = fec_stream_enter(ctx, sf))) return rc;
             HIP_TRY(hipStreamWaitEvent(sf, ev_llr, 0));
+            if (!ctx->ev_fec_t0[slot][par]) HIP_TRY(hipEventCreate(&ctx->ev_fec_t0[slot][par]));
+            HIP_TRY(hipEventRecord(ctx->ev_fec_t0[slot][par], sf));
             if ((rc = fec_run(ctx, mp.fec, (const int8_t*)ctx->ws_fecbuf[slot][par][0].p, nf, mt, force, (uint8_t*)ctx->ws_fecbuf[slot][par][1].p, j_trials, j_corr, sf)))
                 return rc;
-            if (!ctx->ev_fec[slot][par]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fec[slot][par], hipEventDisableTiming));
+            if (!ctx->ev_fec[slot][par]) HIP_TRY(hipEventCreate(&ctx->ev_fec[slot][par]));
             HIP_TRY(hipEventRecord(ctx->ev_fec[slot][par], sf));
             job->done = ctx->ev_fec[slot][par];
+            job->t0 = ctx->ev_fec_t0[slot][par];
+            fec_stream_leave(ctx, sf, job->done);
         }
         ctx->fec_parity[slot] ^= 1;
         hm.mark("fec_enqueued");
@@ -807,7 +840,8 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             //  headline's setting spent part of its steps in the wrong flow)
             const long long sig = ((long long)n << 32) ^ ((long long)d0->cfg.modcod << 20) ^ ((long long)d0->cfg.shortframes << 19) ^ ((long long)d0->cfg.pilots << 18) ^
                                   ((long long)(d0->cfg.force_ldpc_iters & 0xff) << 8) ^ (long long)(d0->cfg.max_ldpc_trials & 0xff);
-            if (sig != ctx->g_prio_sig) { ctx->g_prio_sig = sig; ctx->g_prio_duty = 0; ctx->g_prio_trend = 0; }
+            const bool sig_changed = sig != ctx->g_prio_sig;
+            if (sig_changed) { ctx->g_prio_sig = sig; ctx->g_prio_duty = 0; ctx->g_prio_trend = 0; }
             const auto t_d1 = std::chrono::steady_clock::now();
             const double wait_ms = std::chrono::duration<double, std::milli>(t_d1 - t_d0).count();
             const double call_ms = std::chrono::duration<double, std::milli>(t_d1 - t_entry).count();
@@ -818,7 +852,21 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             } else {
                 ctx->g_prio_trend = verdict;
             }
-            if (hm.on) { char b[96]; snprintf(b, sizeof(b), " wait=%.2f call=%.1f duty=%d", wait_ms, call_ms, ctx->g_prio_duty); hm.line += b; }
+            // the partition rule (ctx.h): the job just delivered -- how long did it run, and how far apart do this batch's calls come?
+            float job_ms = 0.f;
+            const double period_ms = std::chrono::duration<double, std::milli>(t_entry - ctx->fec_last_entry).count();
+            ctx->fec_last_entry = t_entry;
+            if (ctx->fec_part < 0 && prev->t0 && prev->done && hipEventElapsedTime(&job_ms, prev->t0, prev->done) == hipSuccess && period_ms > 0.0 && period_ms < 5000.0) {
+                if (sig_changed) { ctx->fec_part_on = false; ctx->fec_part_trend = 0; }
+                const double scale = prev->on_part ? 1.0 : 256.0 / FEC_PART_CUS;
+                const bool fits = job_was_done && job_ms * scale * 1.15 < period_ms;
+                const int want = fits ? +1 : -1;
+                if ((want > 0) != ctx->fec_part_on) {
+                    if (ctx->fec_part_trend == want) { ctx->fec_part_on = want > 0; ctx->fec_part_trend = 0; }
+                    else ctx->fec_part_trend = want;
+                } else ctx->fec_part_trend = 0;
+            }
+            if (hm.on) { char b[128]; snprintf(b, sizeof(b), " wait=%.2f call=%.1f duty=%d job=%.1f period=%.1f part=%d", wait_ms, call_ms, ctx->g_prio_duty, job_ms, period_ms, (int)ctx->fec_part_on); hm.line += b; }
         }
     }
     if (started) {
@@ -1034,11 +1082,13 @@ int process_vcm_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const
             HIP_TRY(hipEventRecord(ctx->ev_llr, st));
             {
                 std::lock_guard<std::mutex> fl(ctx->fec_mtx);
+                if ((rc = fec_stream_enter(ctx, sf))) return rc;
                 HIP_TRY(hipStreamWaitEvent(sf, ctx->ev_llr, 0));
                 for (const Run& r : runs)
                     if ((rc = fec_run(ctx, r.f, r.llr, r.cnt, mt, force, r.bb, r.tr, r.tr + r.cnt, sf))) return rc;
-                if (!ctx->ev_fec[slot][par]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fec[slot][par], hipEventDisableTiming));
+                if (!ctx->ev_fec[slot][par]) HIP_TRY(hipEventCreate(&ctx->ev_fec[slot][par]));
                 HIP_TRY(hipEventRecord(ctx->ev_fec[slot][par], sf));
+                fec_stream_leave(ctx, sf, ctx->ev_fec[slot][par]);
             }
             ctx->fec_parity[slot] ^= 1;
             HIP_TRY(hipMemcpyAsync(hstats.data(), d_stats, sizeof(S2FrameStats) * nf, hipMemcpyDeviceToHost, st));
@@ -1471,6 +1521,7 @@ int dvbs2gpu_set_pipelined(dvbs2gpu_ctx* ctx, int on) {
     if (!on && ctx->fec_stream) {
         // frames of the last pipelined call that nobody collected are dropped (collect them with a zero-count call first)
         HIP_TRY(hipStreamSynchronize(ctx->fec_stream));
+        if (ctx->fec_part_stream) HIP_TRY(hipStreamSynchronize(ctx->fec_part_stream));
         for (hipStream_t sg : ctx->grp_stream) if (sg) HIP_TRY(hipStreamSynchronize(sg));      // (small jobs of mixed batches run on their group's stream)
         for (auto& pj : ctx->pending_fec) { delete (PendingFec*)pj; pj = nullptr; }
     }

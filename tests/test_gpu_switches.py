@@ -15,6 +15,8 @@ CASES = [
     (dict(DVBS2GPU_OPTIONS='mixed_groups=1'), 'mixed'),
     # ... and the one-launch-per-stage flow with its FEC jobs in line on ONE side stream
     (dict(DVBS2GPU_OPTIONS='mix_fec_streams=1'), 'mixed'),
+    # the throughput mode's big FEC jobs on the partition stream (a subset of the compute units; by default a rule decides per batch), jobs of other flows on the plain FEC stream behind them
+    (dict(DVBS2GPU_OPTIONS='fec_part=1'), 'pipelined'),
 ]
 
 
