@@ -324,9 +324,10 @@ def secondary_s2(eng, pkg, dev, name, modcod, rate, short, pilots, esn0_db, S, F
 
     def barrier():
         torch.cuda.synchronize()
-    # 8 untimed steps first: the pipelined mode's balancer (wave-priority share of the timing loop, stage pipeline on / off) starts from zero for every new
-    # configuration (s2_demod.hip) and moves one notch per two consistent calls: a front-end-bound configuration needs these steps to reach ITS setting
-    dt, stages, acc = time_steps(run, steps, 8, barrier, True)
+    # untimed steps first: the pipelined mode's balancer (wave-priority share of the timing loop, stage pipeline on / off; the FEC partition stream) starts from zero for every new
+    # configuration (s2_demod.hip) and moves one notch per two consistent calls: a front-end-bound configuration needs these steps to reach ITS setting -- 8 where the decoder
+    # is the critical path (the setting stays near zero), 20 in the plugin's mode (seven notches + the partition rule: 16 calls; a receiver runs for hours)
+    dt, stages, acc = time_steps(run, steps, 8 if force else 20, barrier, True)
     k = ldpc_alone(eng, run.info, rate, short, S * F, dev)
     bpf = ITERS * 4 * run.info['ldpc_edges'] + run.info['ldpc_n'] + run.info['kbch'] // 8
     if not force:
