@@ -1326,6 +1326,110 @@ constexpr int FL_TILE = 46;          // PLL symbols staged per round (>= 36: the
                                      // one kernel per configuration group, and with two 11.7 KB workgroups per CU plus a stray third the
                                      // decoder workgroup of that CU could not start before the frame loops had finished (pipelined mode)
 
+// A PAYLOAD TILE OF THE PLL AS A FIXED POINT (one stream per wave; s2_frame_loops_kernel with one stream per workgroup, s2_vcm_loops_kernel).
+// THE TILE AS A FIXED POINT (oracle: S2Rx::pll_tile_study; profiles/r05_pll_tile_study.txt).  What a symbol contributes to the
+// loop, e[k], depends on the loop phase at that symbol only (rotation, table cell); the recurrence proper (dvbs2_pll.cpp:81) is a dozen instructions.  So: lane k
+// evaluates e[k] from a guessed phase (first the phase at the tile's start advanced by the frequency alone) -- all symbols of the tile side by side, one table
+// round trip for the lot -- then every lane replays the recurrence over the tile with those e[k] in the reference's order (uniform values: the errors come out
+// of the lanes through v_readlane, lane k keeps the phase of step k), the lanes evaluate again at the replayed phases ... until no symbol's table cell changes.
+// By induction over k that fixed point IS the serial result: phase[0] is exact; an exact phase[k] gives the exact e[k], hence the exact phase[k + 1].  A replay
+// starts at the first symbol whose cell changed (everything before it stands).  Same functions as the serial form below: bit-identical.
+// `sym` = lane k's symbol (k < m), `lut` the constellation's phase-error table; returns lane k's rotated symbol (what the serial loop stores as tmp_val), the loop state in `pll` advanced by m symbols.
+__device__ __forceinline__ cf32 pll_payload_tile(const cf32 sym, const bool mine_k, const int lane, const int m, PclDev& pll, const float* lut_err_v) {
+    // (the loop state of lane 0: the lane groups without a stream are restored to their frame's start after every frame and would replay from there)
+    const float ph0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pll.phase)));
+    const float fq0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pll.freq)));
+    float myph = ph0 + (float)lane * fq0, myfq = fq0, mye = 0.f;
+    int mycell = -1;
+    cf32 tmp_val{0.f, 0.f};
+    PclDev r = pll;
+    for (;;) {
+        bool changed = false;
+        if (mine_k) {
+            tmp_val = cmul(sym, phasor_fast(-myph));
+            const int cell = lut_cell(tmp_val.re, tmp_val.im);
+            changed = cell != mycell;
+            mycell = cell;
+        }
+        const unsigned long long chg = __ballot(changed);
+        if (chg == 0) break;                                       // every error reproduced: the phases are the serial loop's
+        if (changed) mye = as_global(lut_err_v)[mycell];
+        const int c = __ffsll((long long)chg) - 1;                 // the first symbol whose error changed: the replay starts there
+        if (c > 0) {
+            r.phase = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myph), c));
+            r.freq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myfq), c));
+        } else { r.phase = ph0; r.freq = fq0; }
+#if S2_PLL_ASM
+        {
+            // the replay written out (a lone wave's time is its instruction count, tools/ubench/lone_wave.hip): per symbol the error out of lane k (v_readlane), lane k
+            // keeps the state the step starts from, PhaseControlLoop::advance and one wrap into [-pi, pi] -- the same operations in the same order as the serial loop's
+            // tail below (multiplication and addition apart: no fused multiply-add); 11 vector instructions, four steps per trip of the loop (a taken branch costs ~28 cycles)
+            uint32_t kq = (uint32_t)__builtin_amdgcn_readfirstlane(c), mq = (uint32_t)__builtin_amdgcn_readfirstlane(m);
+            const float minf_q = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pll.minFreq)));
+            float alpha_v = pll.alpha, beta_v = pll.beta, maxf_v = pll.maxFreq;
+            asm volatile("" : "+v"(alpha_v), "+v"(beta_v), "+v"(maxf_v));
+#define S2_REPLAY_STEP(W, B)                                                    \
+                "v_readlane_b32 s60, %[mye], %[k]\n\t"            \
+                "v_cmp_eq_u32 vcc, %[k], %[lane]\n\t"             \
+                "v_cndmask_b32 %[myph], %[myph], %[ph], vcc\n\t"  \
+                "v_cndmask_b32 %[myfq], %[myfq], %[fr], vcc\n\t"  \
+                "v_mul_f32 v124, s60, %[beta]\n\t"                \
+                "v_add_f32 %[fr], %[fr], v124\n\t"                \
+                "v_med3_f32 %[fr], %[fr], %[minf], %[maxf]\n\t"   \
+                "v_mul_f32 v124, s60, %[alpha]\n\t"               \
+                "v_add_f32 v124, %[fr], v124\n\t"                 \
+                "v_add_f32 %[ph], %[ph], v124\n\t"                \
+                "v_cmp_gt_f32 vcc, |%[ph]|, s71\n\t"              \
+                "s_cbranch_vccnz " W "f\n\t"                      \
+                B ":\n\t"                                         \
+                "s_add_u32 %[k], %[k], 1\n\t"                     \
+                "s_cmp_lt_u32 %[k], %[m]\n\t"
+            // (the wrap into [-pi, pi] out of line: |phase| <= pi is the rule, and a branch not taken is nearly free)
+#define S2_REPLAY_WRAP(W, B)                                                    \
+                W ":\n\t"                                         \
+                "v_add_f32 v124, s74, %[ph]\n\t"                  \
+                "v_cmp_lt_f32 vcc, s71, %[ph]\n\t"                \
+                "v_cndmask_b32 %[ph], %[ph], v124, vcc\n\t"       \
+                "v_add_f32 v124, s73, %[ph]\n\t"                  \
+                "v_cmp_gt_f32 vcc, s72, %[ph]\n\t"                \
+                "v_cndmask_b32 %[ph], %[ph], v124, vcc\n\t"       \
+                "s_branch " B "b\n\t"
+            asm volatile(
+                "s_mov_b32 s71, 0x40490fdb\n\t"          // pi
+                "s_mov_b32 s72, 0xc0490fdb\n\t"          // -pi
+                "s_mov_b32 s73, 0x40c90fdb\n\t"          // 2 pi
+                "s_mov_b32 s74, 0xc0c90fdb\n\t"          // -2 pi
+                "s_cmp_lt_u32 %[k], %[m]\n\t"
+                "s_cbranch_scc0 2f\n\t"
+                "1:\n\t"
+                S2_REPLAY_STEP("11", "21") "s_cbranch_scc0 2f\n\t"
+                S2_REPLAY_STEP("12", "22") "s_cbranch_scc0 2f\n\t"
+                S2_REPLAY_STEP("13", "23") "s_cbranch_scc0 2f\n\t"
+                S2_REPLAY_STEP("14", "24") "s_cbranch_scc1 1b\n\t"
+                "s_branch 2f\n\t"
+                S2_REPLAY_WRAP("11", "21") S2_REPLAY_WRAP("12", "22") S2_REPLAY_WRAP("13", "23") S2_REPLAY_WRAP("14", "24")
+                "2:"
+                : [ph] "+v"(r.phase), [fr] "+v"(r.freq), [myph] "+v"(myph), [myfq] "+v"(myfq), [k] "+s"(kq)
+                : [mye] "v"(mye), [lane] "v"(lane), [alpha] "v"(alpha_v), [beta] "v"(beta_v), [minf] "s"(minf_q), [maxf] "v"(maxf_v), [m] "s"(mq)
+                : "v124", "s60", "s71", "s72", "s73", "s74", "vcc", "scc");
+#undef S2_REPLAY_WRAP
+#undef S2_REPLAY_STEP
+        }
+#else
+        for (int kk = c; kk < m; ++kk) {
+            const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mye), kk));
+            const bool me = lane == kk;
+            myph = me ? r.phase : myph;
+            myfq = me ? r.freq : myfq;
+            r.advance(e);
+            r.wrap_pi_once();
+        }
+#endif
+    }
+    pll.phase = r.phase; pll.freq = r.freq;
+    return tmp_val;
+}
+
 // SPEC: with the loops ahead of the PL sync (below) compiled in -- small banks only: the plain instantiation has to stay within 128 registers
 // (it shares its SIMDs with three decoder waves in the pipelined mode), and the extra state costs it 14
 template <bool SPEC>
@@ -1475,109 +1579,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const bool plain = base >= 90 && !(next_pilot >= 0 && next_pilot < base + m && next_pilot + 36 > base);
             if (plain) {
                 if (S2_PLL_TILES && C.bits != 5 && spw == 1) {
-                    // ONE STREAM PER WORKGROUP: THE TILE AS A FIXED POINT (oracle: S2Rx::pll_tile_study; profiles/r05_pll_tile_study.txt).  What a symbol contributes to the
-                    // loop, e[k], depends on the loop phase at that symbol only (rotation, table cell); the recurrence proper (dvbs2_pll.cpp:81) is a dozen instructions.  So: lane k
-                    // evaluates e[k] from a guessed phase (first the phase at the tile's start advanced by the frequency alone) -- all symbols of the tile side by side, one table
-                    // round trip for the lot -- then every lane replays the recurrence over the tile with those e[k] in the reference's order (uniform values: the errors come out
-                    // of the lanes through v_readlane, lane k keeps the phase of step k), the lanes evaluate again at the replayed phases ... until no symbol's table cell changes.
-                    // By induction over k that fixed point IS the serial result: phase[0] is exact; an exact phase[k] gives the exact e[k], hence the exact phase[k + 1].  A replay
-                    // starts at the first symbol whose cell changed (everything before it stands).  Same functions as the serial form below: bit-identical.
-                    const cf32* tl0 = &tiles[0][0];
-                    cf32* ot0 = &tiles[0][FL_TILE];
+                    // one stream per workgroup: the tile as a fixed point over all 64 lanes (pll_payload_tile above)
                     const bool mine_k = lane < m;
-                    const cf32 sym = mine_k ? tl0[lane] : cf32{0.f, 0.f};
-                    // (the loop state of lane 0: the lane groups without a stream are restored to their frame's start after every frame and would replay from there)
-                    const float ph0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pll.phase)));
-                    const float fq0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pll.freq)));
-                    float myph = ph0 + (float)lane * fq0, myfq = fq0, mye = 0.f;
-                    int mycell = -1;
-                    cf32 tmp_val{0.f, 0.f};
-                    PclDev r = pll;
-                    for (;;) {
-                        bool changed = false;
-                        if (mine_k) {
-                            tmp_val = cmul(sym, phasor_fast(-myph));
-                            const int cell = lut_cell(tmp_val.re, tmp_val.im);
-                            changed = cell != mycell;
-                            mycell = cell;
-                        }
-                        const unsigned long long chg = __ballot(changed);
-                        if (chg == 0) break;                                       // every error reproduced: the phases are the serial loop's
-                        if (changed) mye = as_global(lut_err_v)[mycell];
-                        const int c = __ffsll((long long)chg) - 1;                 // the first symbol whose error changed: the replay starts there
-                        if (c > 0) {
-                            r.phase = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myph), c));
-                            r.freq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myfq), c));
-                        } else { r.phase = ph0; r.freq = fq0; }
-#if S2_PLL_ASM
-                        {
-                            // the replay written out (a lone wave's time is its instruction count, tools/ubench/lone_wave.hip): per symbol the error out of lane k (v_readlane), lane k
-                            // keeps the state the step starts from, PhaseControlLoop::advance and one wrap into [-pi, pi] -- the same operations in the same order as the serial loop's
-                            // tail below (multiplication and addition apart: no fused multiply-add); 11 vector instructions, four steps per trip of the loop (a taken branch costs ~28 cycles)
-                            uint32_t kq = (uint32_t)__builtin_amdgcn_readfirstlane(c), mq = (uint32_t)__builtin_amdgcn_readfirstlane(m);
-                            const float minf_q = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pll.minFreq)));
-                            float alpha_v = pll.alpha, beta_v = pll.beta, maxf_v = pll.maxFreq;
-                            asm volatile("" : "+v"(alpha_v), "+v"(beta_v), "+v"(maxf_v));
-#define S2_REPLAY_STEP(W, B)                                                    \
-                                "v_readlane_b32 s60, %[mye], %[k]\n\t"            \
-                                "v_cmp_eq_u32 vcc, %[k], %[lane]\n\t"             \
-                                "v_cndmask_b32 %[myph], %[myph], %[ph], vcc\n\t"  \
-                                "v_cndmask_b32 %[myfq], %[myfq], %[fr], vcc\n\t"  \
-                                "v_mul_f32 v124, s60, %[beta]\n\t"                \
-                                "v_add_f32 %[fr], %[fr], v124\n\t"                \
-                                "v_med3_f32 %[fr], %[fr], %[minf], %[maxf]\n\t"   \
-                                "v_mul_f32 v124, s60, %[alpha]\n\t"               \
-                                "v_add_f32 v124, %[fr], v124\n\t"                 \
-                                "v_add_f32 %[ph], %[ph], v124\n\t"                \
-                                "v_cmp_gt_f32 vcc, |%[ph]|, s71\n\t"              \
-                                "s_cbranch_vccnz " W "f\n\t"                      \
-                                B ":\n\t"                                         \
-                                "s_add_u32 %[k], %[k], 1\n\t"                     \
-                                "s_cmp_lt_u32 %[k], %[m]\n\t"
-                            // (the wrap into [-pi, pi] out of line: |phase| <= pi is the rule, and a branch not taken is nearly free)
-#define S2_REPLAY_WRAP(W, B)                                                    \
-                                W ":\n\t"                                         \
-                                "v_add_f32 v124, s74, %[ph]\n\t"                  \
-                                "v_cmp_lt_f32 vcc, s71, %[ph]\n\t"                \
-                                "v_cndmask_b32 %[ph], %[ph], v124, vcc\n\t"       \
-                                "v_add_f32 v124, s73, %[ph]\n\t"                  \
-                                "v_cmp_gt_f32 vcc, s72, %[ph]\n\t"                \
-                                "v_cndmask_b32 %[ph], %[ph], v124, vcc\n\t"       \
-                                "s_branch " B "b\n\t"
-                            asm volatile(
-                                "s_mov_b32 s71, 0x40490fdb\n\t"          // pi
-                                "s_mov_b32 s72, 0xc0490fdb\n\t"          // -pi
-                                "s_mov_b32 s73, 0x40c90fdb\n\t"          // 2 pi
-                                "s_mov_b32 s74, 0xc0c90fdb\n\t"          // -2 pi
-                                "s_cmp_lt_u32 %[k], %[m]\n\t"
-                                "s_cbranch_scc0 2f\n\t"
-                                "1:\n\t"
-                                S2_REPLAY_STEP("11", "21") "s_cbranch_scc0 2f\n\t"
-                                S2_REPLAY_STEP("12", "22") "s_cbranch_scc0 2f\n\t"
-                                S2_REPLAY_STEP("13", "23") "s_cbranch_scc0 2f\n\t"
-                                S2_REPLAY_STEP("14", "24") "s_cbranch_scc1 1b\n\t"
-                                "s_branch 2f\n\t"
-                                S2_REPLAY_WRAP("11", "21") S2_REPLAY_WRAP("12", "22") S2_REPLAY_WRAP("13", "23") S2_REPLAY_WRAP("14", "24")
-                                "2:"
-                                : [ph] "+v"(r.phase), [fr] "+v"(r.freq), [myph] "+v"(myph), [myfq] "+v"(myfq), [k] "+s"(kq)
-                                : [mye] "v"(mye), [lane] "v"(lane), [alpha] "v"(alpha_v), [beta] "v"(beta_v), [minf] "s"(minf_q), [maxf] "v"(maxf_v), [m] "s"(mq)
-                                : "v124", "s60", "s71", "s72", "s73", "s74", "vcc", "scc");
-#undef S2_REPLAY_WRAP
-#undef S2_REPLAY_STEP
-                        }
-#else
-                        for (int kk = c; kk < m; ++kk) {
-                            const float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mye), kk));
-                            const bool me = lane == kk;
-                            myph = me ? r.phase : myph;
-                            myfq = me ? r.freq : myfq;
-                            r.advance(e);
-                            r.wrap_pi_once();
-                        }
-#endif
-                    }
-                    if (mine_k) ot0[lane] = tmp_val;
-                    pll.phase = r.phase; pll.freq = r.freq;
+                    const cf32 tmp_val = pll_payload_tile(mine_k ? tiles[0][lane] : cf32{0.f, 0.f}, mine_k, lane, m, pll, lut_err_v);
+                    if (mine_k) tiles[0][FL_TILE + lane] = tmp_val;
                 } else if (C.bits != 5) {
 #if S2_PLL_ASM
                     // THE SHORT LOOP WRITTEN OUT (a small bank's frame loops are one wave per CU: its time is its instruction count + the table's round trip;
@@ -2297,6 +2302,14 @@ __global__ __launch_bounds__(64) void s2_vcm_loops_kernel(const S2StreamWork* __
                 rnt[lane] = base + lane >= 90 ? T.rn[base + lane - 90] : 0;
             }
             __syncthreads();
+            // a tile of payload symbols only (no header, no pilot symbol) of a LUT constellation: the fixed-point form (pll_payload_tile) -- the general loop below is
+            // ~100 instructions and a table round trip per symbol
+            const bool plain = S2_PLL_TILES && cbits != 5 && base >= 90 && !(next_pilot >= 0 && next_pilot < base + m && next_pilot + 36 > base);
+            if (plain) {
+                const bool mine_k = lane < m;
+                const cf32 tmp_val = pll_payload_tile(mine_k ? tile[lane] : cf32{0.f, 0.f}, mine_k, lane, m, pll, C->lut_err);
+                if (mine_k) otile[lane] = pl_descramble(tmp_val, rnt[lane]);
+            } else
             for (int k = 0; k < m; ++k) {
                 const int i = base + k;
                 cf32 tmp_val = cmul(tile[k], phasor(-pll.phase));

@@ -7,6 +7,9 @@ import __graft_entry__ as g
 import bench
 pkg = g.load_package()
 eng = pkg.Engine(0)
-for S, F in ((64, 1), (1, 4), (16, 4)):
+for S, F in (() if len(sys.argv) > 1 and sys.argv[1] == 'vcm' else ((64, 1), (1, 4), (16, 4))):
     r = bench.small_batch(eng, pkg, torch.device('cuda:0'), S, F)
     print(S, F, 'ms_per_call', r['ms_per_call'], 'per stream', r['msym_s_per_stream'], 'equal', r['frames_equal_to_transmitted'], '/', r['frames_delivered'], r['stage_ms_per_call'])
+if len(sys.argv) > 1 and sys.argv[1] == 'vcm':
+    r = bench.secondary_vcm(eng, pkg, torch.device("cuda:0"))
+    print('ACM/VCM', {k: r[k] for k in r if k in ('value', 'ms_per_call', 'msym_s_per_stream', 'frames_checked_last_call', 'frames_equal_to_transmitted')})
