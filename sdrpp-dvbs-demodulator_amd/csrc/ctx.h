@@ -185,6 +185,7 @@ struct dvbs2gpu_ctx {
     int fe_slices = 0;                        // option fe_slices (0 = by mode: 4 pipelined, 8 synchronous; 1 = both stages back to back on the caller's stream)
     // balance of the two streams of the pipelined mode (s2_demod.hip): share of the timing loop's tiles that run one priority level up
     int g_prio_duty = 0, g_prio_trend = 0;
+    int g_prio_hold = 0, g_prio_last_down = 0;      // the balancer's damper: calls during which no step down is tried / calls since the last step down (s2_demod.hip)
     long long g_prio_sig = -1;                // what the balance was found for (streams, MODCOD, frame kind, iteration setting of the batch): another configuration starts from 0 again
     bool g_prio_auto = true;                  // option g_prio_duty fixes the value
     int dvbs_bank_min = 2048;                 // option dvbs_bank_min: carriers from which a bank uses the four-streams-per-wave FLL (measured crossover with the written-out wave-per-stream loop: 2048 carriers 74.2 vs 74.8 ms, 1024: 46.2 vs 54.8, 4096: 128.8 vs 111.4; tests: 1)

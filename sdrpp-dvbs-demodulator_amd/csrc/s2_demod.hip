@@ -841,22 +841,37 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             const long long sig = ((long long)n << 32) ^ ((long long)d0->cfg.modcod << 20) ^ ((long long)d0->cfg.shortframes << 19) ^ ((long long)d0->cfg.pilots << 18) ^
                                   ((long long)(d0->cfg.force_ldpc_iters & 0xff) << 8) ^ (long long)(d0->cfg.max_ldpc_trials & 0xff);
             const bool sig_changed = sig != ctx->g_prio_sig;
-            if (sig_changed) { ctx->g_prio_sig = sig; ctx->g_prio_duty = 0; ctx->g_prio_trend = 0; }
+            // (a new configuration starts at share 2, where the decoder-bound ones settle -- from 0 the headline's first four calls ran 55 ms long each, the front end being their
+            //  critical path, and the plugin's mode needed 14 calls to its share of 7)
+            if (sig_changed) { ctx->g_prio_sig = sig; ctx->g_prio_duty = 2; ctx->g_prio_trend = 0; ctx->g_prio_hold = 0; ctx->g_prio_last_down = 0; }
             const auto t_d1 = std::chrono::steady_clock::now();
             const double wait_ms = std::chrono::duration<double, std::milli>(t_d1 - t_d0).count();
             const double call_ms = std::chrono::duration<double, std::milli>(t_d1 - t_entry).count();
-            const int verdict = job_was_done ? +1 : (wait_ms > 1.0 + 0.02 * call_ms ? -1 : 0);
-            if (verdict != 0 && verdict == ctx->g_prio_trend) {
-                ctx->g_prio_duty = std::min(7, std::max(0, ctx->g_prio_duty + verdict));
-                ctx->g_prio_trend = 0;
-            } else {
-                ctx->g_prio_trend = verdict;
-            }
-            // the partition rule (ctx.h): the job just delivered -- how long did it run, and how far apart do this batch's calls come?
+            // the job just delivered: how long did it run (timing events around it), and how far apart do this batch's calls come?
             float job_ms = 0.f;
             const double period_ms = std::chrono::duration<double, std::milli>(t_entry - ctx->fec_last_entry).count();
             ctx->fec_last_entry = t_entry;
-            if (ctx->fec_part < 0 && prev->t0 && prev->done && hipEventElapsedTime(&job_ms, prev->t0, prev->done) == hipSuccess && period_ms > 0.0 && period_ms < 5000.0) {
+            const bool timed = prev->t0 && prev->done && hipEventElapsedTime(&job_ms, prev->t0, prev->done) == hipSuccess && period_ms > 0.0 && period_ms < 5000.0;
+            const int verdict = job_was_done ? +1 : (wait_ms > 1.0 + 0.035 * call_ms ? -1 : 0);     // (3.5 %: the headline waits 2.2 % of its call at its best share, 2.9 % in the first calls of a run)
+            // a clear case moves the share at once: the job took less than 0.8 of the call (the front end is the critical path by a wide margin) / the call waited more
+            // than a twentieth of its time for the job; anything else needs two consistent calls
+            const bool clear = verdict > 0 ? (timed && job_ms < 0.8 * call_ms) : (verdict < 0 && wait_ms > 0.05 * call_ms);
+            // (no see-saw: a step down that the very next verdicts take back -- the lower share made the front end the critical path -- is not tried again for 64 calls;
+            //  the headline sat at share 2 with a wait right at the threshold and dipped to 1 every dozen calls, one 380 ms call each time)
+            if (ctx->g_prio_hold > 0) --ctx->g_prio_hold;
+            const bool held = verdict < 0 && ctx->g_prio_hold > 0;
+            if (verdict != 0 && !held && (clear || verdict == ctx->g_prio_trend)) {
+                const int before = ctx->g_prio_duty;
+                ctx->g_prio_duty = std::min(7, std::max(0, ctx->g_prio_duty + verdict));
+                if (verdict > 0 && ctx->g_prio_last_down > 0 && ctx->g_prio_duty != before) ctx->g_prio_hold = 64;     // (up again right behind a step down)
+                ctx->g_prio_last_down = (verdict < 0 && ctx->g_prio_duty != before) ? 4 : 0;
+                ctx->g_prio_trend = 0;
+            } else {
+                ctx->g_prio_trend = held ? 0 : verdict;
+                if (ctx->g_prio_last_down > 0) --ctx->g_prio_last_down;
+            }
+            // the partition rule (ctx.h)
+            if (ctx->fec_part < 0 && timed) {
                 if (sig_changed) { ctx->fec_part_on = false; ctx->fec_part_trend = 0; }
                 const double scale = prev->on_part ? 1.0 : 256.0 / FEC_PART_CUS;
                 const bool fits = job_was_done && job_ms * scale * 1.15 < period_ms;
