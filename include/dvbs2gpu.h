@@ -103,12 +103,12 @@ int dvbs2gpu_ldpc_plan_dump(int rate, int shortframes, uint32_t* layers4, uint32
  * counts2 = {words in the table, words per row}; table: [q][384][words per row], two 16-bit byte offsets per word. */
 int dvbs2gpu_ldpc_wave_plan_dump(int rate, int shortframes, uint32_t* lanec, uint16_t* steps, uint32_t* layer_end, int32_t* counts6);
 int dvbs2gpu_ldpc_addr_table_dump(int rate, int shortframes, uint32_t* table, int32_t* counts2);
-/* The half-row decoder's plan (csrc/ldpc_split_plan.h; codes it does not take: counts6[0] = 0).  pack_max_depth / pass_max_depth < 0: the built-in defaults.
+/* The half-row decoder's plan (csrc/ldpc_split_plan.h; codes it does not take: counts6[0] = 0).
  * counts6 = {pseudo-layers, table words per thread, slots per row half, message-workspace dwords per workgroup, words in the table, record dwords};
  * layers4: 4 uint32 per pseudo-layer {kind | waves << 8 | flags, chain step, record offset, first link entry}; table: [pseudo-layer][768][words]
  * (two 16-bit LDS byte offsets per word, the row word behind the last slot); row_of: [pseudo-layer][384] the row a lane pair updates (-1: idle);
  * layer_of: [pseudo-layer] its layer.  NULL arrays: counts only. */
-int dvbs2gpu_ldpc_split_plan_dump(int rate, int shortframes, int pack_max_depth, int pass_max_depth, uint32_t* layers4, uint32_t* table, int32_t* row_of, int32_t* layer_of, int32_t* counts6);
+int dvbs2gpu_ldpc_split_plan_dump(int rate, int shortframes, uint32_t* layers4, uint32_t* table, int32_t* row_of, int32_t* layer_of, int32_t* counts6);
 
 /* replaces BBFrameBCH::decode (bbframe_bch.cpp:380-405).  d_frames [nframes][K/8] corrected in place;
  * d_corrections [nframes] int32: #bits corrected, 0 clean, -1 uncorrectable (frame left untouched). */

@@ -70,8 +70,8 @@ public:
     DVBS2Demod(const DVBS2Demod&) = delete;
     DVBS2Demod& operator=(const DVBS2Demod&) = delete;
 
-    /* DVBS2Demod::init (module_dvbs2_demod.cpp:7-30) without the input stream; handler receives the PLL output of the last frame of a
-     * call (the constellation display, :337) and may be null */
+    /* DVBS2Demod::init (module_dvbs2_demod.cpp:7-30) without the input stream; handler is called once per PL frame a call completes, with that
+     * frame's symbols behind the PLL (the constellation display, :337), and may be null */
     void init(double symbolrate, double samplerate, float agc_rate, float rrc_alpha, int rrc_taps, float loop_bw, float fll_bw, double omegaGain,
               double muGain, void (*handler)(complex_t* data, int count, void* ctx), void* ctx, int modcod, bool shortframes, bool pilots,
               float sof_thresold, int max_ldpc_trials, double omegaRelLimit = 0.01, int device = 0) {
@@ -97,21 +97,25 @@ public:
     int process(int count, const complex_t* in, uint8_t* out) {
         const int n = dvbs2gpu_demod_process(need(), count, reinterpret_cast<const float*>(in), out, STREAM_BUFFER_SIZE);
         check(n);
-        dvbs2gpu_frame_stats st[64];
-        const int k = std::min(dvbs2gpu_demod_get_stats(h, st, 64), 64);
+        // every PL frame this call completed (a call of STREAM_BUFFER_SIZE samples of short frames holds more than a fixed-size array would)
+        const int k = dvbs2gpu_demod_get_stats(h, nullptr, 0);
         if (k > 0) {   // the public fields the plugin's menu polls (module_dvbs2_demod.h:82-87)
-            const dvbs2gpu_frame_stats& s = st[k - 1];
+            stats.resize((size_t)k);
+            dvbs2gpu_demod_get_stats(h, stats.data(), k);
+            const dvbs2gpu_frame_stats& s = stats[(size_t)k - 1];
             detected_modcod = s.detected_modcod; detected_shortframes = s.detected_shortframes != 0; detected_pilots = s.detected_pilots != 0;
             pl_sync_best_match = s.pl_sync_best_match; ldpc_trials = (float)s.ldpc_trials; bch_corrections = (float)s.bch_corrections;
         }
         if (d_handler && k > 0) {
-            // module_dvbs2_demod.cpp:337: the handler is called once per PL frame, with that frame's header + payload (+ pilot) symbols behind the PLL
+            // module_dvbs2_demod.cpp:337: the handler is called once per PL frame, with that frame's header + payload (+ pilot) symbols behind the PLL.
+            // A CCM block's frames all have the configured MODCOD's PLFRAME length (dvbs2gpu_modcod_info): tap 2 holds k of them back to back.
             const int ns = dvbs2gpu_demod_get_tap(h, 2, nullptr, 0);
-            if (ns > 0 && ns % k == 0) {
+            dvbs2gpu_modcod_info mi;
+            if (ns > 0 && dvbs2gpu_modcod_info_get(cfg.modcod, cfg.shortframes, cfg.pilots, &mi) == 0 && mi.plframe_symbols > 0 &&
+                (long long)mi.plframe_symbols * k == ns) {
                 tap.resize((size_t)ns);
                 dvbs2gpu_demod_get_tap(h, 2, tap.data(), ns);
-                const int per = ns / k;
-                for (int f = 0; f < k; ++f) d_handler(tap.data() + (size_t)f * per, per, d_ctx);
+                for (int f = 0; f < k; ++f) d_handler(tap.data() + (size_t)f * mi.plframe_symbols, mi.plframe_symbols, d_ctx);
             }
         }
         return n;
@@ -146,6 +150,7 @@ private:
     void (*d_handler)(complex_t*, int, void*) = nullptr;
     void* d_ctx = nullptr;
     std::vector<complex_t> tap;
+    std::vector<dvbs2gpu_frame_stats> stats;
 };
 
 struct BBHeader {   // bbframe_ts_parser.h:36-66

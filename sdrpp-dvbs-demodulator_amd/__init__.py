@@ -73,7 +73,7 @@ PROTOTYPES = {
     'dvbs2gpu_ldpc_decoder_form': (_i, [_vp, _i, _i]),
     'dvbs2gpu_ldpc_wave_plan_dump': (_i, [_i, _i, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
     'dvbs2gpu_ldpc_addr_table_dump': (_i, [_i, _i, _vp, C.POINTER(C.c_int32)]),
-    'dvbs2gpu_ldpc_split_plan_dump': (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
+    'dvbs2gpu_ldpc_split_plan_dump': (_i, [_i, _i, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
     'dvbs2gpu_ldpc_decode_batch': (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'dvbs2gpu_bch_decode_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
     'dvbs2gpu_bb_descramble_batch': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
@@ -181,12 +181,12 @@ def fec_info(rate, shortframes=False):
     return info.as_dict()
 
 
-def ldpc_split_plan(rate, shortframes=False, pack_max_depth=-1, pass_max_depth=-1):
+def ldpc_split_plan(rate, shortframes=False):
     """Host-only: the half-row LDPC decoder's plan (csrc/ldpc_split_plan.h) as numpy arrays; None for codes that decoder does not take."""
     import numpy as np
     lib = load_library()
     cnt = (C.c_int32 * 6)()
-    rc = lib.dvbs2gpu_ldpc_split_plan_dump(int(rate), int(bool(shortframes)), int(pack_max_depth), int(pass_max_depth), None, None, None, None, cnt)
+    rc = lib.dvbs2gpu_ldpc_split_plan_dump(int(rate), int(bool(shortframes)), None, None, None, None, cnt)
     if rc != 0:
         raise Dvbs2GpuError(rc, lib.dvbs2gpu_last_error().decode())
     npl, npw, hs, rec_total, nwords, rec_dw = list(cnt)
@@ -194,7 +194,7 @@ def ldpc_split_plan(rate, shortframes=False, pack_max_depth=-1, pass_max_depth=-
         return None
     layers = np.zeros((npl, 4), np.uint32); table = np.zeros(nwords, np.uint32)
     row_of = np.zeros((npl, 384), np.int32); layer_of = np.zeros(npl, np.int32)
-    rc = lib.dvbs2gpu_ldpc_split_plan_dump(int(rate), int(bool(shortframes)), int(pack_max_depth), int(pass_max_depth), layers.ctypes.data, table.ctypes.data, row_of.ctypes.data, layer_of.ctypes.data, cnt)
+    rc = lib.dvbs2gpu_ldpc_split_plan_dump(int(rate), int(bool(shortframes)), layers.ctypes.data, table.ctypes.data, row_of.ctypes.data, layer_of.ctypes.data, cnt)
     if rc != 0:
         raise Dvbs2GpuError(rc, lib.dvbs2gpu_last_error().decode())
     return {'npl': npl, 'npw': npw, 'hs': hs, 'rec_total': rec_total, 'rec_dwords': rec_dw, 'kind': (layers[:, 0] & 0xff).astype(int), 'nw': ((layers[:, 0] >> 8) & 0xff).astype(int),

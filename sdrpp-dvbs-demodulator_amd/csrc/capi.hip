@@ -47,8 +47,6 @@ int apply_option(dvbs2gpu_ctx* c, const char* name, int v) {
     auto in = [v](int lo, int hi) { return v >= lo && v <= hi; };
     if (n == "ldpc_wave") { if (!in(-1, 1)) return -1; c->ldpc_wave = v; }
     else if (n == "ldpc_split") { if (!in(0, 1)) return -1; c->ldpc_split = v; }
-    else if (n == "ldpc_split_pack") { if (!in(0, 360)) return -1; c->ldpc_split_pack = v; }          // (both read when the context first builds a code's plan)
-    else if (n == "ldpc_split_passes") { if (!in(0, 360)) return -1; c->ldpc_split_passes = v; }
     else if (n == "gardner_form") { if (!(v == 0 || v == 1 || v == 2 || v == 4)) return -1; c->gardner_form = v; }
     else if (n == "gardner_cand_skew") { c->gardner_cand_skew = v; }
     else if (n == "fe_slices") { if (!in(0, s2::S2_FE_MAX_SLICES)) return -1; c->fe_slices = v; }
@@ -96,7 +94,7 @@ int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
             // the half-row decoder (ldpc_split_plan.h / ldpc_split_kernel.hip) for the normal frames it takes, and for them the default: 32 768 frames of rate 3/4 x 50 iterations
             // in 308 ms against the lane-per-row decoder's 336, the pipelined step 335 against 348 ms (r05).  The context option ldpc_split = 0 selects the
             // lane-per-row decoder (the parity tests run both).
-            const LdpcSplitPlan SP = build_ldpc_split_plan(P, ctx->ldpc_split_pack, ctx->ldpc_split_passes);
+            const LdpcSplitPlan SP = build_ldpc_split_plan(P);
             if (SP.ok) {
                 if ((rc = upload(SP.layers, &D.d_split_layers))) return fail(rc);
                 if ((rc = upload(SP.atab, &D.d_split_atab))) return fail(rc);
@@ -519,12 +517,12 @@ int dvbs2gpu_ldpc_addr_table_dump(int rate, int shortframes, uint32_t* table, in
     return 0;
 }
 
-int dvbs2gpu_ldpc_split_plan_dump(int rate, int shortframes, int pack_max_depth, int pass_max_depth, uint32_t* layers4, uint32_t* table, int32_t* row_of, int32_t* layer_of, int32_t* counts6) {
+int dvbs2gpu_ldpc_split_plan_dump(int rate, int shortframes, uint32_t* layers4, uint32_t* table, int32_t* row_of, int32_t* layer_of, int32_t* counts6) {
     FecParams f;
     if (!fec_params(rate, shortframes, &f)) { g_err = "unsupported code rate"; return DVBS2GPU_ERR_MODCOD; }
     if (!counts6) return DVBS2GPU_ERR_ARG;
     const LdpcPlan P = build_ldpc_plan(f.code_index);
-    const LdpcSplitPlan S = build_ldpc_split_plan(P, pack_max_depth < 0 ? LDPC_SPLIT_PACK_MAX_DEPTH : pack_max_depth, pass_max_depth < 0 ? LDPC_SPLIT_PASS_MAX_DEPTH : pass_max_depth);
+    const LdpcSplitPlan S = build_ldpc_split_plan(P);
     counts6[0] = S.ok ? (int32_t)S.layers.size() : 0; counts6[1] = S.npw; counts6[2] = S.hs; counts6[3] = S.rec_total; counts6[4] = (int32_t)S.atab.size(); counts6[5] = S.rec_dwords;
     if (!S.ok) return 0;
     if (layers4) memcpy(layers4, S.layers.data(), S.layers.size() * sizeof(LdpcSplitLayer));

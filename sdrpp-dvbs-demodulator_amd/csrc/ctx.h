@@ -173,7 +173,6 @@ struct dvbs2gpu_ctx {
     int gardner_cand_skew = 0;                // tests only: skews the candidate form's arm prediction so that it leaves its tables
     int ldpc_wave = -1;                       // short frames: 0 / 1 = lane-per-row / wave-per-frame decoder (-1: per code)
     int ldpc_split = 1;                       // 1: the half-row decoder for the normal frames it takes (ldpc_split_kernel.hip); 0: the lane-per-row decoder for every code
-    int ldpc_split_pack = LDPC_SPLIT_PACK_MAX_DEPTH, ldpc_split_passes = LDPC_SPLIT_PASS_MAX_DEPTH;      // its plan's alternatives (ldpc_split_plan.h): the parity tests run them
     int host_timing = 0;                      // 1: print where the host spends a batch call
     int stage_pipeline_launches = 0;          // option stage_loops: frame-loop launches per call (0 = chosen per call, s2_demod.hip)
     int stage_pipeline_min_duty = 2;          // option stage_min_duty: pipelined mode uses the stage pipeline only above this balancer setting (-1: always).

@@ -40,6 +40,7 @@ struct SplitShape {
     static constexpr int REC = HS <= 4 ? 1 : HS <= 8 ? 2 : 4;
     static constexpr int RI_WORD = HS / 2, RI_SHIFT = (HS & 1) ? 16 : 0;     // where the row word sits (ldpc_split_plan.h)
     static_assert((NL & 1) == 0, "the half-row decoder takes rows with an even number of links");
+    static_assert(HS / 2 + 1 <= NPW, "slots + row word must fit the thread's table entry (ldpc_split_plan.h)");
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -62,15 +63,19 @@ __device__ __forceinline__ void lds_ready_n(int outstanding, uint32_t& r_lo, uin
 // Table / record traffic of the layer loop goes through buffer resources: (uniform base in the descriptor) + (uniform pseudo-layer offset in a scalar
 // register) + (the thread's 32-bit byte offset) -- left to itself the compiler builds a 64-bit address per lane and load (v_lshl_add_u64, a half-rate
 // instruction, and twice the address registers).  The loads stay visible to the compiler, which keeps vmcnt.
+// (the words a thread fetches ahead live in ONE register tuple per fetch -- a vector value -- so that the empty asm statements that pin them in place keep them contiguous: as
+// separate 32-bit values the allocator scatters them and the fetch lands in a second tuple, copied over behind a wait)
+template <int NW> struct FetchWords { typedef uint32_t type __attribute__((ext_vector_type(NW))); };
+template <> struct FetchWords<1> { typedef uint32_t type; };
 template <int NW>
-__device__ __forceinline__ void bload(uint32_t (&w)[NW], __amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
-    if constexpr (NW == 1) { w[0] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0); }
-    else if constexpr (NW == 2) { const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0); w[0] = v.x; w[1] = v.y; }
-    else {
-#pragma unroll
-        for (int i = 0; i < NW; i += 4) { const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 4 * i, soff, 0); w[i] = v.x; w[i + 1] = v.y; w[i + 2] = v.z; w[i + 3] = v.w; }
-    }
+__device__ __forceinline__ typename FetchWords<NW>::type bload(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+    static_assert(NW == 1 || NW == 2 || NW == 4, "one buffer load per fetch");
+    if constexpr (NW == 1) return __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
+    else if constexpr (NW == 2) return __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    else return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
 }
+template <int NW>
+__device__ __forceinline__ uint32_t fetch_word(const typename FetchWords<NW>::type& v, int i) { if constexpr (NW == 1) return v; else return v[i]; }
 template <int NW>
 __device__ __forceinline__ void bstore(const uint32_t (&w)[NW], __amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
     if constexpr (NW == 1) { __builtin_amdgcn_raw_buffer_store_b32(w[0], rs, voff, soff, 0); }
@@ -93,6 +98,29 @@ struct RowState {
     using S = SplitShape<MAXDEG>;
     s16x2 V[S::NP], G[S::NP];        // extrinsic inputs and their offset magnitudes, two slots per register ("Q8": the int8 value in the high byte of each half)
     uint32_t addr[S::HS];            // LDS byte addresses of the slots' posteriors
+    s16x2 RP[S::NP];                 // the slots' old messages, Q8 pairs
+    uint32_t rw;                     // the row word (ldpc_split_plan.h)
+    // everything the thread's table entry and message record hold, taken apart at the TOP of a pseudo-layer: the words fetched ahead are dead from here on, and the fetch for the
+    // next pseudo-layer is issued into the very registers they arrived in -- the layer loop carries no copies of them (r05: 14 v_mov per wave and pseudo-layer)
+    __device__ __forceinline__ void unpack(const typename FetchWords<S::NPW>::type& AD, const typename FetchWords<S::REC>::type& rec) {
+#pragma unroll
+        for (int p = 0; p < S::NP; ++p) {
+            const uint32_t w = fetch_word<S::NPW>(AD, p);
+            addr[2 * p] = w & 0xffffu;                                       // (the posteriors start at LDS offset 0)
+            if (2 * p + 1 < S::HS) addr[2 * p + 1] = w >> 16;
+            RP[p] = rec_pair_dw(fetch_word<S::REC>(rec, (2 * p) >> 2), 2 * p);
+        }
+        rw = (fetch_word<S::NPW>(AD, S::RI_WORD) >> S::RI_SHIFT) & 0xffffu;
+    }
+    __device__ __forceinline__ void pin() {
+#pragma unroll
+        for (int k = 0; k < S::HS; ++k) asm volatile("" : "+v"(addr[k]));
+#pragma unroll
+        for (int p = 0; p < S::NP; ++p) { uint32_t b = bits2(RP[p]); asm volatile("" : "+v"(b)); RP[p] = from_bits2(b); }
+        asm volatile("" : "+v"(rw));
+    }
+    // old message of slot k as an int (kinds 1 / 3 / 6: the shared links are slots 0..3)
+    __device__ __forceinline__ int msg(int k) const { return (k & 1) ? (int)bits2(RP[k >> 1]) >> 24 : (int)__builtin_amdgcn_sbfe((int)bits2(RP[k >> 1]), 8, 8); }
 };
 
 // input phase: posteriors in, extrinsic values, the row's two smallest magnitudes and sign -- M0 / M1 / SXs come back with BOTH halves of the
@@ -100,17 +128,14 @@ struct RowState {
 // LATE > 0: the first LATE slots, where flagged in `late`, are left out of the totals (levels / quad walk: 4).  LATE == -1: the whole first pair is left out of
 // the totals where `late` is not zero (chain walk) -- V / G keep the values read
 template <int MAXDEG, int LATE>
-__device__ __forceinline__ void row_input(RowState<MAXDEG>& R, const uint32_t (&AD)[SplitShape<MAXDEG>::NPW], const uint32_t (&rec_in)[SplitShape<MAXDEG>::REC],
-                                          const uint32_t late, const bool noprev_layer, const uint32_t noprev_t, const int t, int& M0, int& M1, int& SXs) {
+__device__ __forceinline__ void row_input(RowState<MAXDEG>& R, const uint32_t late, const bool noprev_layer, const uint32_t noprev_t, const int t, int& M0, int& M1, int& SXs) {
     using S = SplitShape<MAXDEG>;
-    constexpr int HS = S::HS, NP = S::NP, REC = S::REC;
+    constexpr int HS = S::HS, NP = S::NP;
     uint32_t XR[NP], XH[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const uint32_t a_lo = AD[p] & 0xffffu, a_hi = AD[p] >> 16;          // (the posteriors start at LDS offset 0)
-        R.addr[2 * p] = a_lo;
-        if (2 * p + 1 < HS) { R.addr[2 * p + 1] = a_hi; lds_read_pair_i8(a_lo, a_hi, XR[p], XH[p]); }
-        else { lds_read_lo_i8(a_lo, XR[p]); XH[p] = 0x007f0000u; }          // the odd slot: a neutral link, posterior +127
+        if (2 * p + 1 < HS) lds_read_pair_i8(R.addr[2 * p], R.addr[2 * p + 1], XR[p], XH[p]);
+        else { lds_read_lo_i8(R.addr[2 * p], XR[p]); XH[p] = 0x007f0000u; }          // the odd slot: a neutral link, posterior +127
     }
     s16x2 MIN0 = splat2(Q8_NONE), MIN1 = splat2(Q8_NONE);
     uint32_t SX = 0;
@@ -121,7 +146,7 @@ __device__ __forceinline__ void row_input(RowState<MAXDEG>& R, const uint32_t (&
         lds_ready_n(HS - issued, XR[p], XH[p]);
         // byte of the low load -> bits 15:8, byte of the high load (it sits in bits 23:16) -> bits 31:24
         const s16x2 X = from_bits2(__builtin_amdgcn_perm(XH[p], XR[p], 0x060c000cu));
-        s16x2 v = sat_sub2(X, rec_pair<REC>(rec_in, 2 * p));                     // int8 saturation by the 16-bit clamp
+        s16x2 v = sat_sub2(X, R.RP[p]);                     // int8 saturation by the 16-bit clamp
         const s16x2 av = pmax2(v, sat_sub2(splat2(0), v));
         // |v| - 1 clamped at 0 (ldpc_kernel.hip: no upper clamp needed, only the high byte is ever consumed)
         s16x2 g = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, av), (u16x2){256, 256}));
@@ -223,25 +248,22 @@ __device__ unsigned long long* g_prof_dev = nullptr;
 //   phase C  rows of level > 1: the pair's late slots re-read (L from cres[], E from its bit: a row whose E link is late waits for an EARLIER row's L link), joined into
 //            the totals with packed operations, handed to half 1, then the output phase -- which leaves out the early slots: a later row's L link owns that bit's final value.
 template <int MAXDEG>
-__device__ __forceinline__ void chain_layer(const uint32_t (&AD)[SplitShape<MAXDEG>::NPW], const uint32_t (&rec_in)[SplitShape<MAXDEG>::REC], uint32_t (&rec_out)[SplitShape<MAXDEG>::REC],
+__device__ __forceinline__ void chain_layer(RowState<MAXDEG>& R, uint32_t (&rec_out)[SplitShape<MAXDEG>::REC],
                                             const LdpcSplitLayer L, const uint32_t eL, const int t, int8_t* __restrict__ post, uint32_t* __restrict__ cw, uint8_t* __restrict__ cres) {
-    using S = SplitShape<MAXDEG>;
-    constexpr int REC = S::REC;
     [[maybe_unused]] constexpr int KIND = 1;
-    const uint32_t rw = (AD[S::RI_WORD] >> S::RI_SHIFT) & 0xffffu;
+    const uint32_t rw = R.rw;
     const uint32_t level = rw & 0xffu, late = (rw >> 8) & 3u, early = (rw >> 12) & 3u;
     const int chain_d = (int)L.aux;
     const int j = t >> 1;
     const bool half1 = (t & 1) != 0;
-    RowState<MAXDEG> R;
     int M0, M1, SXs;
     SPLIT_MARK_DECL;
-    row_input<MAXDEG, -1>(R, AD, rec_in, (level > 1u && !half1) ? 1u : 0u, (L.kind_nw >> 20) & 1u, 1u, t, M0, M1, SXs);
+    row_input<MAXDEG, -1>(R, (level > 1u && !half1) ? 1u : 0u, (L.kind_nw >> 20) & 1u, 1u, t, M0, M1, SXs);
     SPLIT_MARK(0);
     if (level == 1u) row_output<MAXDEG, 0>(R, M0, M1, SXs, 0u, rec_out);
     if ((late >> 1) & 1) {
         // totals without the pair: min0 = the smallest magnitude among the row's other links (what the E link's new message takes), sign = their product
-        const ChainRec r = chain_record(rec_byte<REC>(rec_in, 1), (late & 1u) ? 255 : (M0 >> 24), (int)R.V[0][0] >> 8, SXs >> 31);
+        const ChainRec r = chain_record(R.msg(1), (late & 1u) ? 255 : (M0 >> 24), (int)R.V[0][0] >> 8, SXs >> 31);
         reinterpret_cast<uint2*>(cw)[j] = make_uint2(r.lim, r.se);
     }
     SPLIT_MARK(1);
@@ -288,11 +310,11 @@ __device__ __forceinline__ void chain_layer(const uint32_t (&AD)[SplitShape<MAXD
             lds_read_pair_i8(R.addr[0], lds_offset(reinterpret_cast<const int8_t*>(cres)) + (uint32_t)j, xr, xh);
             lds_ready_n(0, xr, xh);
             const s16x2 X = from_bits2(__builtin_amdgcn_perm(xh, xr, 0x060c000cu));
-            const s16x2 v = sat_sub2(X, rec_pair<REC>(rec_in, 0));
+            const s16x2 v = sat_sub2(X, R.RP[0]);
             const s16x2 av = pmax2(v, sat_sub2(splat2(0), v));
             const s16x2 g = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, av), (u16x2){256, 256}));
             // bits 8 / 9 of the row word -> 0xffff in the low / high half (v_perm: selectors 9 / 11 = the sign of byte 3 of either source)
-            const uint32_t rws = AD[S::RI_WORD] << (31 - (S::RI_SHIFT + 9));            // bit 31 = late L, bit 30 = late E
+            const uint32_t rws = rw << 22;            // bit 31 = late L (bit 9 of the row word), bit 30 = late E (bit 8)
             const uint32_t LM = __builtin_amdgcn_perm(rws << 1, rws, 0x09090b0bu);
             R.V[0] = from_bits2((bits2(v) & LM) | (bits2(R.V[0]) & ~LM));
             R.G[0] = from_bits2((bits2(g) & LM) | (bits2(R.G[0]) & ~LM));
@@ -338,98 +360,21 @@ __device__ __forceinline__ LdpcSplitLayer layer_at(const_layer_ptr layers, int i
 #define LDPC_SPLIT_CONFLICT_INLINE __forceinline__
 #endif
 template <int MAXDEG, int KIND>
-__device__ LDPC_SPLIT_CONFLICT_INLINE void conflict_layer(const uint32_t (&AD)[SplitShape<MAXDEG>::NPW], const uint32_t (&rec_in)[SplitShape<MAXDEG>::REC], uint32_t (&rec_out)[SplitShape<MAXDEG>::REC],
+__device__ LDPC_SPLIT_CONFLICT_INLINE void conflict_layer(RowState<MAXDEG>& R, uint32_t (&rec_out)[SplitShape<MAXDEG>::REC],
                                                const LdpcSplitLayer L, const_u32_ptr ents, const_u32_ptr walk, const int t,
                                                int8_t* __restrict__ post, uint32_t* __restrict__ cw, uint8_t* __restrict__ cres) {
     using S = SplitShape<MAXDEG>;
-    constexpr int REC = S::REC;
-    constexpr int MAXC0 = KIND == 1 ? 2 : 4;
-    constexpr int MAXC = MAXC0 < S::HS ? MAXC0 : S::HS;
-    const uint32_t rw = (AD[S::RI_WORD] >> S::RI_SHIFT) & 0xffffu;
+    constexpr int MAXC = 4 < S::HS ? 4 : S::HS;
+    const uint32_t rw = R.rw;
     const uint32_t level = rw & 0xffu, late = (rw >> 8) & 15u, early = rw >> 12;
     const int nc = (int)((L.kind_nw >> 16) & 15u);
     const int j = t >> 1;
-    RowState<MAXDEG> R;
     int M0, M1, SXs;
     SPLIT_MARK_DECL;
-    row_input<MAXDEG, MAXC>(R, AD, rec_in, late, (L.kind_nw >> 20) & 1u, 1u, t, M0, M1, SXs);
+    row_input<MAXDEG, MAXC>(R, late, (L.kind_nw >> 20) & 1u, 1u, t, M0, M1, SXs);
     int min0 = M0 >> 24, min1 = M1 >> 24, sx = SXs;                 // (sx: the sign of the row's product sits in bit 31)
     SPLIT_MARK(0);
-    if constexpr (KIND == 1) {
-        const int chain_d = (int)L.aux;
-        // rows of level 1 publish their early links; every row whose L link is late leaves the walk's record (ldpc_lane_common.h: chain_record)
-        if (level == 1u) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                if ((early >> k) & 1) {
-                    int nm = new_msg(LINK_IN(k), LINK_MG(k), min0, min1, sx);
-                    LDS_I8(R.addr[k]) = (int8_t)clamp8(LINK_IN(k) + nm);
-                }
-            }
-        }
-        if ((late >> 1) & 1) {
-            // (a late slot's V / G hold the neutral link until the join below: the totals above exclude it; the record of a row whose E link is late is never stepped through)
-            const int qE = (late & 1u) ? 255 : ((LINK_MG(0) == min0) ? min1 : min0);
-            const ChainRec r = chain_record(rec_byte<REC>(rec_in, 1), qE, LINK_IN(0), (sx ^ LINK_IN(0)) >> 31);
-            reinterpret_cast<uint2*>(cw)[j] = make_uint2(r.lim, r.se);
-        }
-        SPLIT_MARK(1);
-        lds_barrier();
-        SPLIT_MARK(2);
-        if (t < chain_d) {
-            // lane c walks rows c + k*d (ldpc_kernel.hip)
-            __builtin_amdgcn_s_setprio(3);
-            const uint32_t eL = ents[1];
-            const int T = 359 / chain_d;
-            int x = post[link_addr(eL, t + chain_d)];
-            const uint2* c = reinterpret_cast<const uint2*>(cw) + t + chain_d;
-            uint8_t* pr = reinterpret_cast<uint8_t*>(cres) + t + chain_d;
-            uint2 ra = c[0], rb = c[chain_d];
-            c += 2 * chain_d;
-            int k = 1;
-            for (; k + 2 <= T; k += 2) {
-                const uint2 na = c[0];
-                pr[0] = (uint8_t)x;
-                x = chain_step(x, ra.x, ra.y);
-                ra = na;
-                const uint2 nb = c[chain_d];
-                pr[chain_d] = (uint8_t)x;
-                x = chain_step(x, rb.x, rb.y);
-                rb = nb;
-                c += 2 * chain_d;
-                pr += 2 * chain_d;
-            }
-            if (k < T) {
-                pr[0] = (uint8_t)x;
-                x = chain_step(x, ra.x, ra.y);
-                pr += chain_d;
-            }
-            if (t + T * chain_d < 360) pr[0] = (uint8_t)x;
-#ifdef LDPC_SPLIT_PRIO
-            __builtin_amdgcn_s_setprio(LDPC_SPLIT_PRIO);
-#else
-            __builtin_amdgcn_s_setprio(0);
-#endif
-        }
-        SPLIT_MARK(3);
-        lds_barrier();
-        SPLIT_MARK(4);
-        if (late) {
-            const int xL = (int)(int8_t)cres[j], xE = (int)LDS_I8(R.addr[0]);
-            if ((late >> 1) & 1) {
-                int v = clamp8(xL - rec_byte<REC>(rec_in, 1));
-                int m = mag_of(v);
-                LINK_SET(1, v, m);
-                ROW_ACCUM(v, m);
-            }
-            if (late & 1u) {
-                int v = clamp8(xE - rec_byte<REC>(rec_in, 0));
-                int m = mag_of(v);
-                LINK_SET(0, v, m);
-                ROW_ACCUM(v, m);
-            }
-        }
-    } else if constexpr (KIND == 6) {
+    if constexpr (KIND == 6) {
         // ---- quad walk (ldpc_kernel.hip, ldpc_plan.h).  Rows of level 1 publish their early links; every other row of half 0 leaves a hand-off record in cw[]: {min0,
         // min1, sign of the totals so far, late mask, early mask} and one byte per shared link (its old message if the link is late, else its input value)
         constexpr int CWD = 2;
@@ -447,7 +392,7 @@ __device__ LDPC_SPLIT_CONFLICT_INLINE void conflict_layer(const uint32_t (&AD)[S
             uint32_t lb = 0;
 #pragma unroll
             for (int k = 0; k < MAXC; ++k) {
-                const int b = ((late >> k) & 1) ? rec_byte<REC>(rec_in, k) : LINK_IN(k);
+                const int b = ((late >> k) & 1) ? R.msg(k) : LINK_IN(k);
                 lb |= ((uint32_t)b & 0xffu) << (8 * k);
             }
             const uint32_t hd = (uint32_t)min(min0, 127) | ((uint32_t)min(min1, 127) << 7) | (((uint32_t)sx >> 31) << 14) | ((late & 0xffu) << 15) | ((early & 0xffu) << 23);
@@ -538,7 +483,7 @@ __device__ LDPC_SPLIT_CONFLICT_INLINE void conflict_layer(const uint32_t (&AD)[S
 #pragma unroll
                     for (int k = 0; k < MAXC; ++k) {
                         if ((late >> k) & 1) {
-                            int v = clamp8(xs[k] - rec_byte<REC>(rec_in, k));
+                            int v = clamp8(xs[k] - R.msg(k));
                             int m = mag_of(v);
                             LINK_SET(k, v, m);
                             ROW_ACCUM(v, m);
@@ -655,27 +600,18 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                 if (!any) { ret = it; break; }
                 if (it == A.max_trials) { ret = -1; break; }
             }
-            // ---- one layered sweep (LDPCDecoder::update) = the plan's pseudo-layers in order.  A wave fetches its table entry and message record one pseudo-layer
-            // ahead -- if it has rows there; descriptors travel two ahead.
-            uint32_t rec_next[REC], pw_next[NPW];
-#pragma unroll
-            for (int w = 0; w < REC; ++w) rec_next[w] = 0;
-#pragma unroll
-            for (int w = 0; w < NPW; ++w) pw_next[w] = 0;
+            // ---- one layered sweep (LDPCDecoder::update) = the plan's pseudo-layers in order, every wave in every one of them (ldpc_split_plan.h).  A thread's table entry and
+            // message record are fetched one pseudo-layer ahead, descriptors travel two ahead.  The words fetched ahead are taken apart (RowState::unpack) at the top of their
+            // pseudo-layer and the fetch for the one after it goes into the registers they arrived in: no copies ride round the loop.
+            typename FetchWords<REC>::type rec_n;
+            typename FetchWords<NPW>::type pw_n;
             LdpcSplitLayer Lnext = layer_at(layers, 0), Lnext2 = layer_at(layers, npl > 1 ? 1 : 0);
             uint32_t soff_tab = 0;
-            if (wave < (int)((Lnext.kind_nw >> 8) & 0xffu) && !(LDPC_SPLIT_EXP & 2)) {
-                bload<NPW>(pw_next, rs_tab, (uint32_t)t * (NPW * 4), soff_tab);
-                bload<REC>(rec_next, rs_msg, (uint32_t)t * (REC * 4), Lnext.rec_off * 4u);
-            }
+            pw_n = bload<NPW>(rs_tab, (uint32_t)t * (NPW * 4), soff_tab);
+            rec_n = bload<REC>(rs_msg, (uint32_t)t * (REC * 4), Lnext.rec_off * 4u);
             // (claimed before the loop: a load still in flight on the loop's entry edge makes the compiler open EVERY pseudo-layer with vmcnt(0) -- which, coming round the
             // back edge, waits for the previous pseudo-layer's record store)
-            if (LDPC_SPLIT_FIX & 4) {
-#pragma unroll
-                for (int w = 0; w < REC; ++w) asm volatile("" : "+v"(rec_next[w]));
-#pragma unroll
-                for (int w = 0; w < NPW; ++w) asm volatile("" : "+v"(pw_next[w]));
-            }
+            asm volatile("" : "+v"(rec_n), "+v"(pw_n));
 #if defined(LDPC_PROF)
             unsigned long long t_layer = clock64();       // development aid (-DLDPC_PROF builds): cycles of every pseudo-layer, thread 0 of workgroup 0 -> prof[128 + pl]; prof[127]: the rest of an iteration
             if (A.prof && blockIdx.x == 0 && t == 0) { A.prof[127] += t_layer - A.prof[126]; }
@@ -690,81 +626,44 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                 int tt = t;
                 asm volatile("" : "+v"(tt));
                 const uint32_t voff_rec = (uint32_t)tt * (REC * 4), voff_tab = (uint32_t)tt * (NPW * 4);
-                const bool mine = wave < (int)((L.kind_nw >> 8) & 0xffu);
-                const bool mine_next = pl + 1 < npl && wave < (int)((Lnext.kind_nw >> 8) & 0xffu);
-                uint32_t rec[REC], pw[NPW];
-#pragma unroll
-                for (int w = 0; w < REC; ++w) rec[w] = rec_next[w];
-#pragma unroll
-                for (int w = 0; w < NPW; ++w) pw[w] = pw_next[w];
-                if (mine_next && !(LDPC_SPLIT_EXP & 2)) {
-                    if (!(LDPC_SPLIT_EXP & 16) || pl < 1) bload<NPW>(pw_next, rs_tab, voff_tab, soff_tab);
-                    if (!(LDPC_SPLIT_EXP & 32)) bload<REC>(rec_next, rs_msg, voff_rec, Lnext.rec_off * 4u);
+                RowState<MAXDEG> RS;
+                RS.unpack(pw_n, rec_n);
+                // (the fetched words end HERE as far as the compiler can tell -- every value taken from them exists, and the registers are free for the fetch below: without
+                // this the scheduler issues the fetch first, into a second register set, and copies it over at the bottom of the loop)
+                RS.pin();
+                asm volatile("" : "+v"(pw_n), "+v"(rec_n));
+                if (pl + 1 < npl && !(LDPC_SPLIT_EXP & 2)) {
+                    if (!(LDPC_SPLIT_EXP & 16)) pw_n = bload<NPW>(rs_tab, voff_tab, soff_tab);
+                    if (!(LDPC_SPLIT_EXP & 32)) rec_n = bload<REC>(rs_msg, voff_rec, Lnext.rec_off * 4u);
                 }
-                if (mine) {
-                    uint32_t ro[REC];
-#ifdef LDPC_SPLIT_NARROW_PRIO
-                    const bool narrow = ((L.kind_nw >> 8) & 0xffu) <= LDPC_SPLIT_NARROW_PRIO;
-                    if (narrow) __builtin_amdgcn_s_setprio(3);
-#endif
-                    if (LDPC_SPLIT_SKIP && ((LDPC_SPLIT_SKIP >> (L.kind_nw & 0xffu)) & 1)) {      // (timing / counter experiments: the layers of these kinds do nothing)
+                uint32_t ro[REC];
+                if (LDPC_SPLIT_SKIP && ((LDPC_SPLIT_SKIP >> (L.kind_nw & 0xffu)) & 1)) {      // (timing / counter experiments: the layers of these kinds do nothing)
 #pragma unroll
-                        for (int w = 0; w < REC; ++w) ro[w] = 0;
-                    } else if ((L.kind_nw & 0xffu) == 0) {
-                        RowState<MAXDEG> RS;
-                        int M0, M1, SXs;
-                        row_input<MAXDEG, 0>(RS, pw, rec, 0u, (L.kind_nw >> 20) & 1u, L.aux, tt, M0, M1, SXs);
-                        if (LDPC_SPLIT_EXP & 8) { ro[0] = (uint32_t)(M0 ^ M1 ^ SXs); ro[REC - 1] = ro[0]; }
-                        else row_output<MAXDEG, 0>(RS, M0, M1, SXs, 0u, ro);
-                    } else if ((L.kind_nw & 0xffu) == 2) {
-                        // level passes (ldpc_split_plan.h): pass l = the conflict-free update of the rows of level l, the others' lanes masked off
-                        const uint32_t level = (pw[S::RI_WORD] >> S::RI_SHIFT) & 0xffu;
-                        const int depth = (int)L.aux;
-#pragma unroll
-                        for (int w = 0; w < REC; ++w) ro[w] = 0;
-                        for (int pass = 1; pass <= depth; ++pass) {
-                            if (level == (uint32_t)pass) {
-                                RowState<MAXDEG> RS;
-                                int M0, M1, SXs;
-                                row_input<MAXDEG, 0>(RS, pw, rec, 0u, (L.kind_nw >> 20) & 1u, 1u, tt, M0, M1, SXs);
-                                row_output<MAXDEG, 0>(RS, M0, M1, SXs, 0u, ro);
-                                lds_pairs_wait();
-                            }
-                            if (pass < depth) lds_barrier();
-                        }
-                    } else if ((L.kind_nw & 0xffu) == 1) {
-                        chain_layer<MAXDEG>(pw, rec, ro, L, ents[L.ent_off + 1], tt, post, cw, cres);
-                    } else if ((L.kind_nw & 0xffu) == 6) {
-                        conflict_layer<MAXDEG, 6>(pw, rec, ro, L, ents + L.ent_off, rows + L.aux, tt, post, cw, cres);
-                    } else {
-                        conflict_layer<MAXDEG, 3>(pw, rec, ro, L, ents + L.ent_off, ents, tt, post, cw, cres);
-                    }
-                    // the next pseudo-layer's words are claimed HERE, before this one's record store is issued: the wait for them then sits where they have had a whole
-                    // pseudo-layer to arrive, and the top of the next pseudo-layer waits for nothing (ldpc_kernel.hip)
-#if defined(LDPC_PROF) && LDPC_PROF == 4
-                    const unsigned long long t_claim = clock64();        // (how long the claim waits: prof[200 + pl])
-#endif
-#pragma unroll
-                    for (int w = 0; w < REC; ++w) asm volatile("" : "+v"(rec_next[w]));
-#pragma unroll
-                    for (int w = 0; w < NPW; ++w) asm volatile("" : "+v"(pw_next[w]));
-#if defined(LDPC_PROF) && LDPC_PROF == 4
-                    if (A.prof && blockIdx.x == 0 && (t == 0 || t == 384)) A.prof[200 + pl + (t ? 50 : 0)] += clock64() - t_claim;
-#endif
-                    if (LDPC_SPLIT_EXP & (2 | 64)) asm volatile("" :: "v"(ro[0]), "v"(ro[REC - 1]));
-                    else bstore<REC>(ro, rs_msg, voff_rec, L.rec_off * 4u);
-                    lds_pairs_wait();
-#ifdef LDPC_SPLIT_NARROW_PRIO
-                    if (narrow) __builtin_amdgcn_s_setprio(0);
-#endif
-                } else if (LDPC_SPLIT_FIX & 2) {
-                    // (a wave without rows here claims too: where the two paths meet the compiler then knows the words have arrived on both, and the wait it would
-                    // otherwise place there -- vmcnt(0), one counter for loads and stores -- no longer holds the waves WITH rows until their record store is acknowledged)
-#pragma unroll
-                    for (int w = 0; w < REC; ++w) asm volatile("" : "+v"(rec_next[w]));
-#pragma unroll
-                    for (int w = 0; w < NPW; ++w) asm volatile("" : "+v"(pw_next[w]));
+                    for (int w = 0; w < REC; ++w) ro[w] = RS.rw;
+                } else if ((L.kind_nw & 0xffu) == 0) {
+                    int M0, M1, SXs;
+                    row_input<MAXDEG, 0>(RS, 0u, (L.kind_nw >> 20) & 1u, L.aux, tt, M0, M1, SXs);
+                    if (LDPC_SPLIT_EXP & 8) { ro[0] = (uint32_t)(M0 ^ M1 ^ SXs); ro[REC - 1] = ro[0]; }
+                    else row_output<MAXDEG, 0>(RS, M0, M1, SXs, 0u, ro);
+                } else if ((L.kind_nw & 0xffu) == 1) {
+                    chain_layer<MAXDEG>(RS, ro, L, ents[L.ent_off + 1], tt, post, cw, cres);
+                } else if ((L.kind_nw & 0xffu) == 6) {
+                    conflict_layer<MAXDEG, 6>(RS, ro, L, ents + L.ent_off, rows + L.aux, tt, post, cw, cres);
+                } else {
+                    conflict_layer<MAXDEG, 3>(RS, ro, L, ents + L.ent_off, ents, tt, post, cw, cres);
                 }
+                // the next pseudo-layer's words are claimed HERE, before this one's record store is issued: the wait for them then sits where they have had a whole
+                // pseudo-layer to arrive, and the top of the next pseudo-layer waits for nothing (ldpc_kernel.hip)
+#if defined(LDPC_PROF) && LDPC_PROF == 4
+                const unsigned long long t_claim = clock64();        // (how long the claim waits: prof[200 + pl])
+#endif
+                asm volatile("" : "+v"(rec_n), "+v"(pw_n));
+#if defined(LDPC_PROF) && LDPC_PROF == 4
+                if (A.prof && blockIdx.x == 0 && (t == 0 || t == 384)) A.prof[200 + pl + (t ? 50 : 0)] += clock64() - t_claim;
+#endif
+                if (LDPC_SPLIT_EXP & (2 | 64)) asm volatile("" :: "v"(ro[0]), "v"(ro[REC - 1]));
+                else bstore<REC>(ro, rs_msg, voff_rec, L.rec_off * 4u);
+                lds_pairs_wait();
                 if (!(LDPC_SPLIT_EXP & 4)) lds_barrier();
 #if defined(LDPC_PROF)
                 if (A.prof && blockIdx.x == 0 && t == 0) { const unsigned long long t_now = clock64(); A.prof[128 + pl] += t_now - t_layer; t_layer = t_now; A.prof[126] = t_now; }

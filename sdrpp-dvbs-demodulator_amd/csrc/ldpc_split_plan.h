@@ -6,22 +6,16 @@
 //     previous parity bit); half 0 holds links [0, HS), half 1 links [HS, NL), HS = NL / 2 slots each (NL even; an odd HS leaves the second
 //     half of the last register pair to a constant neutral link, ldpc_split_kernel.hip).  min / xor are associative and commutative, so
 //     joining the two halves' (min0, min1, sign) with one cross-lane step leaves algorithms.hh:242-255 bit-exact.
-//   * a sweep is a list of PSEUDO-LAYERS, each ending in a workgroup barrier.  Everything a thread needs for one -- the LDS byte offsets of
-//     its slots, parity bits included, and its row word -- comes from a per-thread table entry, so which row a thread holds is free per
-//     pseudo-layer:
-//       kind 0 (row update): the first nw waves update one row per lane pair, the plain conflict-free update.  A conflict-free layer is one
-//           such pseudo-layer (rows in lane order).  A layer with shared bits becomes one pseudo-layer per dependency LEVEL (ldpc_plan.h),
-//           the level's rows packed into the first lanes: rows of equal level share no bit, rows of later levels see the earlier ones'
-//           writes across the barrier -- the reference's row order, with no special code at all (the per-link "late / early" machinery of
-//           ldpc_kernel.hip is not needed: a row is updated in one piece, when its predecessors are done).
-//       kinds 1 / 3 / 6 (chain walk / levels / quad walk): a layer with more levels than LDPC_SPLIT_PACK_MAX_DEPTH keeps ldpc_kernel.hip's forms:
-//           all rows at once in lane order, the shared links (they all sit in half 0) resolved in a middle section -- chains walked by a few lanes
-//           through per-row hand-off records (~85 cycles per chained row), four lanes per row of a deep narrow level structure, or a barrier per
-//           level.  A packed level costs a whole row update and a vector-memory round trip for its table entry (measured ~1 750 cycles,
-//           profiles/r05_ldpc_split_layers.txt), a walked one a few hundred: only shallow layers are worth packing.
-//       kind 2 (level passes; NOT in the shipped plan, context option ldpc_split_passes): rows in lane order; pass l updates the rows of level l (whole conflict-free
-//           updates under an exec mask), a barrier between passes.  Measured (r05, rate 3/4, 4096 frames x 50 iterations): every chain layer walked 39.6 ms, the chain
-//           layers of up to 5 levels as passes 41.9 ms -- a barrier-separated pass costs ~1 000 cycles whatever it does, a walked row ~135.
+//   * a sweep is a list of PSEUDO-LAYERS, each ending in a workgroup barrier, one per layer of the code, all twelve waves at work in every one of them.  Everything a
+//     thread needs for one -- the LDS byte offsets of its slots, parity bits included, and its row word -- comes from a per-thread table entry:
+//       kind 0 (row update): a conflict-free layer, one row per lane pair, rows in lane order.
+//       kinds 1 / 3 / 6 (chain walk / levels / quad walk): a layer with shared bits keeps ldpc_kernel.hip's forms: all rows at once in lane order, the shared links
+//           (they all sit in half 0) resolved in a middle section -- chains walked by a few lanes through per-row hand-off records (~135 cycles per chained row), four
+//           lanes per row of a deep narrow level structure, or a barrier per level.
+//     Round 5 also carried two alternatives for the layers with shared bits -- one packed conflict-free pseudo-layer per dependency level, and level PASSES under the lanes'
+//     level mask -- as context options; both measured slower at every depth (rate 3/4, 4096 frames x 50 iterations: every chain layer walked 39.6 ms, chain layers of up to
+//     5 levels as passes 41.9, layers of up to 3 levels packed 42.5: a barrier-separated pass costs ~1 000 cycles whatever it does, a packed level ~1 750, a walked row
+//     ~135; profiles/r05_ldpc_split_layers.txt) and are gone: with every wave in every pseudo-layer the layer loop needs no per-wave bookkeeping.
 //   * idle lanes (beyond the packed rows; rows 360..383 of a full layer) point every slot at scratch bytes behind the posteriors: they run
 //     the same instructions and store to bytes nobody reads -- no exec masking in the row update.  The missing previous parity bit of row 0
 //     of layer 0 points there too; its pseudo-layer carries a flag and the thread index.
@@ -35,16 +29,10 @@ namespace s2 {
 
 constexpr int LDPC_SPLIT_T = 768;              // threads per workgroup = 2 x 384 (rows 360..383 idle)
 constexpr int LDPC_SPLIT_SCRATCH = 64;         // scratch bytes behind the posteriors (one per lane of a wave)
-#ifndef LDPC_SPLIT_PACK_MAX_DEPTH
-#define LDPC_SPLIT_PACK_MAX_DEPTH 0            // layers with shared bits and up to this many levels are packed level by level; deeper ones keep the walks of ldpc_kernel.hip
-#endif
-#ifndef LDPC_SPLIT_PASS_MAX_DEPTH
-#define LDPC_SPLIT_PASS_MAX_DEPTH 0            // chain layers up to this many levels run as level PASSES (kind 2) instead of the chain walk: rows in lane order, one whole-row update per level under the lanes' level mask
-#endif                                         // (a chain layer's levels are runs of consecutive rows: a wave takes part in one pass, two where a run ends inside it)
 
 struct LdpcSplitLayer {   // 16 bytes = one s_load_dwordx4
-    uint32_t kind_nw;     // bits 0..7 kind, 8..15 active waves, 16..19 nc = shared links of the layer (slots 0..nc-1 of half 0), bit 20: holds row 0 of layer 0 (no previous parity bit)
-    uint32_t aux;         // kind 0: the half-1 thread of row 0 of layer 0 (bit 20); kind 1: chain step d; kinds 2, 3: levels; kind 6: index of the walk list in LdpcPlan::rows
+    uint32_t kind_nw;     // bits 0..7 kind, 8..15 waves (always 12), 16..19 nc = shared links of the layer (slots 0..nc-1 of half 0), bit 20: holds row 0 of layer 0 (no previous parity bit)
+    uint32_t aux;         // kind 0: the half-1 thread of row 0 of layer 0 (bit 20); kind 1: chain step d; kind 3: levels; kind 6: index of the walk list in LdpcPlan::rows
     uint32_t rec_off;     // dword offset of the pseudo-layer's records inside a workgroup's message workspace
     uint32_t ent_off;     // kind 1: index of the layer's link entries in LdpcPlan::ents (the walker reads link 1's)
 };
@@ -55,7 +43,7 @@ struct LdpcSplitPlan {
     int npw = 0;                       // table words per thread and pseudo-layer (power of two)
     int rec_dwords = 0;                // message record per thread and pseudo-layer, dwords (1 byte per slot)
     int rec_total = 0;                 // dwords of message workspace per workgroup
-    int packed_layers = 0, chain_layers = 0;
+    int chain_layers = 0;
     std::vector<LdpcSplitLayer> layers;
     std::vector<uint32_t> atab;
     std::vector<int> row_of;           // [pseudo-layer][768 / 2] original row of every lane pair (-1: idle) and
@@ -70,13 +58,13 @@ inline int ldpc_split_npw(int hs) {
 inline int ldpc_split_plan_rec_dwords(int max_deg) { const int hs = (max_deg + 2) / 2; return hs <= 4 ? 1 : hs <= 8 ? 2 : 4; }
 
 // which codes the half-row decoder takes: regular ones with an even number of links per row (both halves then hold the same number of slots)
-inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P, int pack_max_depth = LDPC_SPLIT_PACK_MAX_DEPTH, int pass_max_depth = LDPC_SPLIT_PASS_MAX_DEPTH) {
+inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P) {
     LdpcSplitPlan S;
     const int NL = P.max_deg + 2;
-    if (P.min_deg != P.max_deg || (NL & 1) || NL / 2 > 16 || P.N + LDPC_SPLIT_SCRATCH > 65536) return S;
+    if (P.min_deg != P.max_deg || (NL & 1) || NL / 2 > 14 || P.N + LDPC_SPLIT_SCRATCH > 65536) return S;     // (NL / 2 slots + the row word in at most 8 table words)
     for (const LdpcLayerDesc& L : P.layers) {
         const int nc = (int)(L.depth_nc >> 16), depth = (int)(L.depth_nc & 0xffffu);
-        if (depth > pack_max_depth && (nc > 4 || nc > NL / 2)) return S;       // (the middle sections handle up to four shared links, all in half 0)
+        if (depth > 1 && (nc > 4 || nc > NL / 2)) return S;       // (the middle sections handle up to four shared links, all in half 0)
     }
     S.hs = NL / 2;
     S.npw = ldpc_split_npw(S.hs);
@@ -97,8 +85,7 @@ inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P, int pack_max_depth
     // one pseudo-layer: rows[] = the original rows of lane pairs 0, 1, ...; info[] = their row words (kind 1)
     auto emit = [&](int kind, int i, const std::vector<int>& rows, const std::vector<uint32_t>* info, uint32_t aux) {
         LdpcSplitLayer D{};
-        const int nthreads = 2 * (int)rows.size();
-        const int nw = kind != 0 ? T / 64 : (nthreads + 63) / 64;
+        const int nw = T / 64;
         D.kind_nw = (uint32_t)kind | ((uint32_t)nw << 8) | ((kind != 0 ? (P.layers[i].depth_nc >> 16) : 0u) << 16);
         D.aux = aux;
         D.rec_off = (uint32_t)S.rec_total;
@@ -121,8 +108,8 @@ inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P, int pack_max_depth
                 w[s >> 1] |= a << (16 * (s & 1));
             }
             if (j >= 0 && h == 0) S.row_of[rbase + pr] = j;
-            // the row word: kinds 3 / 6 in half 0 only (half 1 and idle lanes: 0, every condition on it false); kind 1: half 1 gets the level; kind 2: the level, in both halves
-            if (j >= 0 && info && (h == 0 || kind <= 2)) w[hs >> 1] |= ((*info)[pr] & (kind == 2 || h == 1 ? 0xffu : 0xffffu)) << (16 * (hs & 1));
+            // the row word: kinds 3 / 6 in half 0 only (half 1 and idle lanes: 0, every condition on it false); kind 1: half 1 gets the level
+            if (j >= 0 && info && (h == 0 || kind == 1)) w[hs >> 1] |= ((*info)[pr] & (h == 1 ? 0xffu : 0xffffu)) << (16 * (hs & 1));
         }
         S.layers.push_back(D);
         S.layer_of.push_back(i);
@@ -135,7 +122,7 @@ inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P, int pack_max_depth
         if (depth == 1) {
             for (int j = 0; j < 360; ++j) rows.push_back(j);
             emit(0, i, rows, nullptr, 0);
-        } else if (depth > pack_max_depth) {
+        } else {
             std::vector<uint32_t> info;
             for (int j = 0; j < 360; ++j) {
                 const uint32_t rw = P.rows[L.row_off + j];
@@ -143,18 +130,9 @@ inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P, int pack_max_depth
                 info.push_back((rw & 0xffu) | (((rw >> 8) & 15u) << 8) | (((rw >> 20) & 15u) << 12));
             }
             if (chain == LDPC_WALK_MARK) emit(6, i, rows, &info, L.row_off + 360);
-            else if (chain != 0 && depth <= pass_max_depth) emit(2, i, rows, &info, (uint32_t)depth);
             else if (chain != 0) emit(1, i, rows, &info, chain);
             else emit(3, i, rows, &info, (uint32_t)depth);
             S.chain_layers++;
-        } else {
-            for (int lvl = 1; lvl <= depth; ++lvl) {
-                rows.clear();
-                for (int j = 0; j < 360; ++j)
-                    if ((int)(P.rows[L.row_off + j] & 0xffu) == lvl) rows.push_back(j);
-                emit(0, i, rows, nullptr, 0);
-            }
-            S.packed_layers++;
         }
     }
     S.ok = true;

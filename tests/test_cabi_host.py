@@ -312,13 +312,12 @@ def test_ldpc_address_table_holds_the_links_of_every_row(pkg, rate, short):
 
 
 @pytest.mark.parametrize('rate,short', [(r, s) for r, s in orc.ALL_CODES if not s])
-@pytest.mark.parametrize('pack,passes', [(-1, -1), (3, 0), (0, 5), (64, 0)])
-def test_ldpc_split_plan_keeps_the_reference_row_order(pkg, rate, short, pack, passes):
-    """the half-row decoder's plan (csrc/ldpc_split_plan.h), for the shipped settings and for the packed / level-pass alternatives: every row of every layer appears
+def test_ldpc_split_plan_keeps_the_reference_row_order(pkg, rate, short):
+    """the half-row decoder's plan (csrc/ldpc_split_plan.h): every row of every layer appears
     exactly once, its table entry names exactly the bits the reference's row touches (information bits, own and previous parity bit), and two rows of a layer that
     share a bit run in the reference's order -- separated by a barrier (different pseudo-layers) unless the pseudo-layer resolves shared links itself (kinds 1, 3, 6,
-    whose row words are the lane-per-row plan's, checked above) or masks its lanes by level (kind 2)"""
-    sp = pkg.ldpc_split_plan(rate, short, pack, passes)
+    whose row words are the lane-per-row plan's, checked above); every pseudo-layer runs all twelve waves"""
+    sp = pkg.ldpc_split_plan(rate, short)
     p = orc.fec_params(rate, short)
     N, K = p['N'], p['K']
     R = N - K
@@ -345,7 +344,7 @@ def test_ldpc_split_plan_keeps_the_reference_row_order(pkg, rate, short, pack, p
                     a = [(int(tab[2 * pr + h, s >> 1]) >> (16 * (s & 1))) & 0xffff for s in range(hs)]
                     assert all(N <= x < N + 64 for x in a)
                 continue
-            assert pr < 32 * int(sp['nw'][pl])
+            assert int(sp['nw'][pl]) == 12
             seen[i, j] += 1
             addrs = []
             for h in (0, 1):
@@ -357,9 +356,6 @@ def test_ldpc_split_plan_keeps_the_reference_row_order(pkg, rate, short, pack, p
             assert sorted(got) == sorted(want), (pl, i, j)
             assert len(got) == len(addrs) or (i == 0 and j == 0 and sp['noprev'][pl])
             rows_here.append((j, got))
-        lvl = None
-        if kind == 2:
-            lvl = {int(sp['row_of'][pl, pr]): (int(tab[2 * pr, hs >> 1]) >> (16 * (hs & 1))) & 0xff for pr in range(384) if sp['row_of'][pl, pr] >= 0}
         within = {}
         for j, bits in rows_here:
             for b in bits:
@@ -369,10 +365,7 @@ def test_ldpc_split_plan_keeps_the_reference_row_order(pkg, rate, short, pack, p
                 within.setdefault(b, []).append(j)
         for b, js in within.items():
             if len(js) > 1:                                                          # rows of ONE pseudo-layer share a bit: only where it orders shared links itself
-                assert kind in (1, 2, 3, 6), (pl, i, js)
-                if kind == 2:
-                    js = sorted(js)
-                    assert all(lvl[a] < lvl[c] for a, c in zip(js, js[1:]))
+                assert kind in (1, 3, 6), (pl, i, js)
         for j, bits in rows_here:
             for b in bits: last_touch[b] = (i, j)
     assert (seen == 1).all()

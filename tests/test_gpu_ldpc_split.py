@@ -13,9 +13,7 @@ pytestmark = pytest.mark.gpu
 CODES = [(6, 0)]
 
 
-# (the plan's alternatives -- layers with shared bits packed level by level, chain layers as level passes -- are the shipped kernel's other paths: run them too)
-@pytest.fixture(scope='module', params=[{'ldpc_split': 1}, {'ldpc_split': 0}, {'ldpc_split': 1, 'ldpc_split_passes': 5}, {'ldpc_split': 1, 'ldpc_split_pack': 4}],
-                ids=['half_row', 'lane_per_row', 'half_row_level_passes', 'half_row_packed_levels'])
+@pytest.fixture(scope='module', params=[{'ldpc_split': 1}, {'ldpc_split': 0}], ids=['half_row', 'lane_per_row'])
 def split_engine(pkg, request):
     import torch
     if not torch.cuda.is_available():
