@@ -38,6 +38,10 @@ typedef struct dvbs2gpu_ctx dvbs2gpu_ctx;   /* one per device / host thread; own
 
 const char* dvbs2gpu_version(void);
 const char* dvbs2gpu_last_error(void);
+/* Optional, for hosts that want the engine's HIP streams on hardware queues of their own: sets GPU_MAX_HW_QUEUES=12 in the process environment unless the
+ * variable is already there.  The HIP runtime reads it at the process's first HIP call, so call this BEFORE that call and before starting threads (setenv is
+ * not thread-safe); loading the library changes nothing by itself.  Returns 1 = set, 0 = already present.  No reference counterpart. */
+int dvbs2gpu_preinit(void);
 
 /* Create a context on HIP device `device`.  Fails with DVBS2GPU_ERR_NODEVICE when no GPU is present. */
 int dvbs2gpu_create(int device, dvbs2gpu_ctx** out);

@@ -2,6 +2,8 @@
 // Host-side only logic here; kernels live in *_kernel.hip.  No CPU fallback: without a HIP device
 // dvbs2gpu_create fails with DVBS2GPU_ERR_NODEVICE.
 #include "ctx.h"
+#include <climits>
+#include <cstdlib>
 
 using namespace s2;
 namespace s2 { extern unsigned long long* g_ldpc_prof; }
@@ -41,12 +43,26 @@ static int stage_enter(dvbs2gpu_ctx* ctx, hipStream_t st) {
     return ws_acquire(ctx, st);
 }
 
+void free_ldpc_code(LdpcDeviceCode& D);
+static int drop_ldpc_cache(dvbs2gpu_ctx* c) {
+    if (fec_jobs_pending(c)) { last_error() = "option changes the decoder plan while pipelined FEC jobs are in flight"; return -1; }
+    if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+    std::lock_guard<std::mutex> l(c->mtx);
+    for (auto& kv : c->ldpc) free_ldpc_code(kv.second);
+    c->ldpc.clear();
+    return 0;
+}
 // the development / test options of a context: one table for the environment variable and the entry point
 int apply_option(dvbs2gpu_ctx* c, const char* name, int v) {
     const std::string n(name);
     auto in = [v](int lo, int hi) { return v >= lo && v <= hi; };
-    if (n == "ldpc_wave") { if (!in(-1, 1)) return -1; c->ldpc_wave = v; }
-    else if (n == "ldpc_split") { if (!in(0, 1)) return -1; c->ldpc_split = v; }
+    if (n == "ldpc_wave") {
+        // (which decoder serves a short code is fixed when the context first builds the code's tables: a change afterwards drops those tables -- refused while FEC jobs use them)
+        if (!in(-1, 1)) return -1;
+        if (v != c->ldpc_wave && !c->ldpc.empty()) { if (drop_ldpc_cache(c) != 0) return -1; }
+        c->ldpc_wave = v;
+    }
+    else if (n == "ldpc_split") { if (!in(0, 1)) return -1; c->ldpc_split = v; }       // (read at every launch)
     else if (n == "gardner_form") { if (!(v == 0 || v == 1 || v == 2 || v == 4)) return -1; c->gardner_form = v; }
     else if (n == "gardner_cand_skew") { c->gardner_cand_skew = v; }
     else if (n == "fe_slices") { if (!in(0, s2::S2_FE_MAX_SLICES)) return -1; c->fe_slices = v; }
@@ -307,16 +323,18 @@ static int bch_run(dvbs2gpu_ctx* ctx, const FecParams& f, uint8_t* d_frames, int
 }  // namespace s2
 
 // ---------------------------------------------------------------------------------------------------
-// Mixed batches drive up to nine HIP streams side by side (the caller's, the front end's, the FEC jobs' side streams); HIP maps its streams onto GPU_MAX_HW_QUEUES
-// hardware queues (default 4), and streams that share a queue run one behind the other (64 mixed transponders: 74 ... 85 ms per call on 4 queues, 48 on 6, 44 on 8).
-// The runtime reads the variable when it initialises, i.e. at the first HIP call of the process: the library asks for 12 queues (an S2 batch and a DVB-S bank of one process side by side keep eleven streams busy) when it is LOADED -- a plugin is loaded
-// before its host touches the GPU -- unless the host's environment already says otherwise.  Loaded into a process that has initialised HIP it changes nothing
-// (results are the same on any number of queues).
-__attribute__((constructor)) static void dvbs2gpu_on_load() { setenv("GPU_MAX_HW_QUEUES", "12", 0); }
-
+// The engine drives several HIP streams side by side (the caller's, the front end's, the FEC jobs'); HIP maps its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and
+// streams that share a queue run one behind the other.  The runtime reads the variable when it initialises, i.e. at the first HIP call of the process.  The library does NOT touch the
+// process environment on its own (round 5 did, from a load-time constructor: not thread-safe against a running host, and order-dependent): a host that wants more queues calls
+// dvbs2gpu_preinit() before its first HIP call and before it starts threads, or exports the variable itself.  Results are the same on any number of queues.
 extern "C" {
 
 const char* dvbs2gpu_version(void) { return "dvbs2gpu 0.1 (gfx950)"; }
+int dvbs2gpu_preinit(void) {
+    // 0: the variable was already there (left alone); 1: set.  Only meaningful before the process's first HIP call.
+    if (getenv("GPU_MAX_HW_QUEUES")) return 0;
+    return setenv("GPU_MAX_HW_QUEUES", "12", 0) == 0 ? 1 : DVBS2GPU_ERR_ARG;
+}
 const char* dvbs2gpu_last_error(void) { return g_err.c_str(); }
 
 int dvbs2gpu_create(int device, dvbs2gpu_ctx** out) {
@@ -344,7 +362,10 @@ int dvbs2gpu_create(int device, dvbs2gpu_ctx** out) {
             if (end == std::string::npos) end = all.size();
             const std::string item = all.substr(pos, end - pos);
             const size_t eq = item.find('=');
-            if (eq == std::string::npos || s2::apply_option(c, item.substr(0, eq).c_str(), atoi(item.c_str() + eq + 1)) != 0) {
+            char* endp = nullptr;
+            const long val = eq == std::string::npos ? 0 : strtol(item.c_str() + eq + 1, &endp, 10);
+            const bool numeric = eq != std::string::npos && endp != item.c_str() + eq + 1 && *endp == '\0' && val >= INT_MIN && val <= INT_MAX;
+            if (!numeric || s2::apply_option(c, item.substr(0, eq).c_str(), (int)val) != 0) {
                 g_err = "DVBS2GPU_OPTIONS: unknown option or value out of range: " + item;
                 delete c;
                 return DVBS2GPU_ERR_ARG;

@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstddef>
+#include <type_traits>
 #include "ldpc_plan.h"
 #include "kernels.h"
 #include "ldpc_dev_common.h"
@@ -40,6 +42,10 @@ struct LdpcKernelParams {
     const uint32_t* atab;
     int npl;                              // pseudo-layers (ldpc_split_kernel.hip)
 };
+// ldpc_params() reads the structure at offset 0 of the kernel-argument segment: a kernel that uses it takes ONE by-value LdpcKernelParams as its first and only parameter
+// (ldpc_split_kernel), and the launch arguments start with the LdpcKernelArgs member
+static_assert(offsetof(LdpcKernelParams, A) == 0, "ldpc_params(): the launch arguments sit at the start of the kernel-argument segment");
+static_assert(std::is_trivially_copyable<LdpcKernelParams>::value, "passed by value in the kernel-argument segment");
 typedef const __attribute__((address_space(4))) LdpcKernelParams* LdpcKernelParamsPtr;
 __device__ __forceinline__ LdpcKernelParamsPtr ldpc_params() {
     uint32_t off = 0;

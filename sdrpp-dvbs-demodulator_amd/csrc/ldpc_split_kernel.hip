@@ -127,8 +127,10 @@ struct RowState {
 // word holding the whole row's value (a word with equal halves orders like its 16-bit value under 32-bit signed compares; SXs: sign in bits 15 and 31).
 // LATE > 0: the first LATE slots, where flagged in `late`, are left out of the totals (levels / quad walk: 4).  LATE == -1: the whole first pair is left out of
 // the totals where `late` is not zero (chain walk) -- V / G keep the values read
-template <int MAXDEG, int LATE>
-__device__ __forceinline__ void row_input(RowState<MAXDEG>& R, const uint32_t late, const bool noprev_layer, const uint32_t noprev_t, const int t, int& M0, int& M1, int& SXs) {
+// NOPREV: the pseudo-layer holds row 0 of layer 0, which has no previous parity bit (kind 7: a conflict-free layer; the plan refuses codes whose layer 0 has shared bits) --
+// a kind of its own, so that the other 44 layers of a sweep do not carry the test (r05: 7 vector instructions per wave and layer)
+template <int MAXDEG, int LATE, int NOPREV = 0>     // NOPREV 2: asked at run time (A/B builds, -DLDPC_SPLIT_NOPREV_RT)
+__device__ __forceinline__ void row_input(RowState<MAXDEG>& R, const uint32_t late, const uint32_t noprev_t, const int t, int& M0, int& M1, int& SXs, const bool noprev_rt = false) {
     using S = SplitShape<MAXDEG>;
     constexpr int HS = S::HS, NP = S::NP;
     uint32_t XR[NP], XH[NP];
@@ -150,7 +152,7 @@ __device__ __forceinline__ void row_input(RowState<MAXDEG>& R, const uint32_t la
         const s16x2 av = pmax2(v, sat_sub2(splat2(0), v));
         // |v| - 1 clamped at 0 (ldpc_kernel.hip: no upper clamp needed, only the high byte is ever consumed)
         s16x2 g = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, av), (u16x2){256, 256}));
-        if (2 * p + 2 > HS - 1 && 2 * p <= HS - 1 && noprev_layer) {
+        if ((NOPREV == 1 || (NOPREV == 2 && noprev_rt)) && 2 * p + 2 > HS - 1 && 2 * p <= HS - 1) {
             // row 0 of layer 0 has no previous parity bit (the last slot of half 1): that thread's slot becomes the neutral link
             const bool me = (uint32_t)t == noprev_t;
             constexpr int hh = (HS - 1) & 1;
@@ -238,6 +240,31 @@ __device__ unsigned long long* g_prof_dev = nullptr;
 #define LINK_MG(k) ((int)R.G[(k) >> 1][(k) & 1] >> 8)
 #define LINK_SET(k, v, m) do { R.V[(k) >> 1][(k) & 1] = (short)((v) << 8); R.G[(k) >> 1][(k) & 1] = (short)((m) << 8); } while (0)
 
+// The chain walk's hand-off (ldpc_lane_common.h: chain_record / chain_step), in the form the WALKER is cheapest in.  A/B of round 6: a record that took 8 instead of 29
+// vector instructions per wave to build (17 chain layers x 12 waves per sweep) but cost the walker one instruction more per row made the kernel 1.2 % SLOWER -- the walk is the
+// workgroup's serial section (349 rows per sweep), a row costs its instruction count at one instruction per ~5 cycles (lone wave), and nothing else of the workgroup runs
+// meanwhile.  So: everything a row needs sits in ONE 8-byte record the walker reads with one load two rows ahead -- lim = the four clamp limits as bytes (SDWA operands),
+// se = E'' (16 bits) | sneg (byte 2: 0 / -1) | byte 3 = the posterior the row's L link reads, WRITTEN BY THE WALKER into the record it has just consumed (one running
+// pointer serves load and store) -- and the sign is applied as (t ^ sneg) + E'', E'' = E' - sneg: 4 clamps + add + xor + add + clamp = 8 vector instructions per row where the
+// multiply-add form took 9 and two field extractions; four records in flight, no copies.
+__device__ __forceinline__ uint2 chain_record_x(const int m, const int qE, const int vE, const int sneg /* 0 or -1 */) {
+    const int sig = 1 | sneg;
+    const int c31 = min(qE, 31), c32 = min(qE, 32);
+    const int CA = (sneg ? c32 : c31) + 1, CB = (sneg ? c31 : c32) + 1;
+    const uint32_t lim = ((uint32_t)(m + 1) & 0xffu) | (((uint32_t)(m + CA) & 0xffu) << 8) | (((uint32_t)(m - CB) & 0xffu) << 16) | ((uint32_t)(m - 1) << 24);
+    const uint32_t se = ((uint32_t)(vE - 2 * sig * m - sneg) & 0xffffu) | (((uint32_t)sneg & 0xffu) << 16);
+    return make_uint2(lim, se);
+}
+__device__ __forceinline__ int chain_step_x(const int x, const u32x2 r) {
+    const int q1 = min(max(x, (int)(int8_t)r.x), (int)(int8_t)(r.x >> 8));
+    const int q2 = min(max(x, (int)(int8_t)(r.x >> 16)), (int)r.x >> 24);
+    int tx = (q1 + q2) ^ (int)(int8_t)(r.y >> 16);
+    asm volatile("" : "+v"(tx));              // (left to itself the compiler fuses xor and add into a VOP3 v_xad_u32, which cannot take the SDWA byte / word operands: two extractions more)
+    return clamp8(tx + (int)(short)r.y);
+}
+typedef __attribute__((address_space(3))) u32x2 lds_u2;
+#define LDS_U2(a) (*(const lds_u2*)(uintptr_t)(a))
+
 // A layer whose shared links are one pair (slots 0 = "E", 1 = "L" of half 0: row j's E bit is row (j + d)'s L bit) with a deep dependency chain: ldpc_kernel.hip's chain
 // walk, its arithmetic kept packed.  Rows in lane order (row j = t >> 1).  The row word -- level | late << 8 | early << 12 in half 0, the level alone in half 1, zero in
 // idle lanes -- rides in the table.
@@ -253,51 +280,50 @@ __device__ __forceinline__ void chain_layer(RowState<MAXDEG>& R, uint32_t (&rec_
     [[maybe_unused]] constexpr int KIND = 1;
     const uint32_t rw = R.rw;
     const uint32_t level = rw & 0xffu, late = (rw >> 8) & 3u, early = (rw >> 12) & 3u;
-    const int chain_d = (int)L.aux;
+    const int chain_d = (int)(L.aux & 0xffffu);
     const int j = t >> 1;
     const bool half1 = (t & 1) != 0;
     int M0, M1, SXs;
     SPLIT_MARK_DECL;
-    row_input<MAXDEG, -1>(R, (level > 1u && !half1) ? 1u : 0u, (L.kind_nw >> 20) & 1u, 1u, t, M0, M1, SXs);
+    row_input<MAXDEG, -1>(R, (level > 1u && !half1) ? 1u : 0u, 1u, t, M0, M1, SXs);
     SPLIT_MARK(0);
     if (level == 1u) row_output<MAXDEG, 0>(R, M0, M1, SXs, 0u, rec_out);
     if ((late >> 1) & 1) {
         // totals without the pair: min0 = the smallest magnitude among the row's other links (what the E link's new message takes), sign = their product
-        const ChainRec r = chain_record(R.msg(1), (late & 1u) ? 255 : (M0 >> 24), (int)R.V[0][0] >> 8, SXs >> 31);
-        reinterpret_cast<uint2*>(cw)[j] = make_uint2(r.lim, r.se);
+        reinterpret_cast<uint2*>(cw)[j] = chain_record_x(R.msg(1), (late & 1u) ? 255 : (M0 >> 24), (int)R.V[0][0] >> 8, SXs >> 31);
     }
     SPLIT_MARK(1);
     lds_pairs_wait();
     lds_barrier();
     SPLIT_MARK(2);
+    uint32_t cwb = lds_offset(reinterpret_cast<const int8_t*>(cw));
+    asm volatile("" : "+s"(cwb));             // (an LDS address with the dynamic-LDS symbol still in it is re-added at every use)
     if (t < chain_d) {
-        // lane c walks rows c + k*d (ldpc_kernel.hip)
+        // lane c walks rows c + k d, k = 1 .. T - 1, and leaves row T its input
         __builtin_amdgcn_s_setprio(3);
-        const int T = 359 / chain_d;
+        const int T = (int)(L.aux >> 16);                 // 359 / d, from the plan (a division here sits in the workgroup's serial section)
         int x = post[link_addr(eL, t + chain_d)];
-        const uint2* c = reinterpret_cast<const uint2*>(cw) + t + chain_d;
-        uint8_t* pr = reinterpret_cast<uint8_t*>(cres) + t + chain_d;
-        uint2 ra = c[0], rb = c[chain_d];
-        c += 2 * chain_d;
+        const uint32_t step = 8u * (uint32_t)chain_d, step4 = 4u * step;
+        uint32_t p0 = cwb + 8u * (uint32_t)(t + chain_d), p1 = p0 + step, p2 = p1 + step, p3 = p2 + step;
+        u32x2 r0 = LDS_U2(p0), r1 = LDS_U2(p1), r2 = LDS_U2(p2), r3 = LDS_U2(p3);       // (reads past row 359 land in LDS the workgroup owns and are never used)
         int k = 1;
-        for (; k + 2 <= T; k += 2) {
-            const uint2 na = c[0];
-            pr[0] = (uint8_t)x;
-            x = chain_step(x, ra.x, ra.y);
-            ra = na;
-            const uint2 nb = c[chain_d];
-            pr[chain_d] = (uint8_t)x;
-            x = chain_step(x, rb.x, rb.y);
-            rb = nb;
-            c += 2 * chain_d;
-            pr += 2 * chain_d;
+        // (the asm statement orders the row's store, its arithmetic and the refill of its record register: the compiler otherwise hoists the refill and keeps a second set of pointers)
+#define WALK_ROW(p, r) do { LDS_I8((p) + 7u) = (int8_t)x; x = chain_step_x(x, r); asm volatile("" : "+v"(p), "+v"(x) : : "memory"); } while (0)
+        for (; k + 4 <= T; k += 4) {
+            WALK_ROW(p0, r0); p0 += step4; r0 = LDS_U2(p0);
+            WALK_ROW(p1, r1); p1 += step4; r1 = LDS_U2(p1);
+            WALK_ROW(p2, r2); p2 += step4; r2 = LDS_U2(p2);
+            WALK_ROW(p3, r3); p3 += step4; r3 = LDS_U2(p3);
         }
         if (k < T) {
-            pr[0] = (uint8_t)x;
-            x = chain_step(x, ra.x, ra.y);
-            pr += chain_d;
+            WALK_ROW(p0, r0); ++k;
+            if (k < T) {
+                WALK_ROW(p1, r1); ++k;
+                if (k < T) { WALK_ROW(p2, r2); ++k; }
+            }
         }
-        if (t + T * chain_d < 360) pr[0] = (uint8_t)x;
+#undef WALK_ROW
+        if (t + T * chain_d < 360) LDS_I8(cwb + 8u * (uint32_t)(t + T * chain_d) + 7u) = (int8_t)x;
         __builtin_amdgcn_s_setprio(0);
     }
     SPLIT_MARK(3);
@@ -307,7 +333,7 @@ __device__ __forceinline__ void chain_layer(RowState<MAXDEG>& R, uint32_t (&rec_
         if (!half1) {
             // the pair again, from what the walk (L) and the earlier rows (E) left; only the late halves replace what phase A read
             uint32_t xr, xh;
-            lds_read_pair_i8(R.addr[0], lds_offset(reinterpret_cast<const int8_t*>(cres)) + (uint32_t)j, xr, xh);
+            lds_read_pair_i8(R.addr[0], cwb + 8u * (uint32_t)j + 7u, xr, xh);        // (E from its bit, L from the byte the walker left in the row's record)
             lds_ready_n(0, xr, xh);
             const s16x2 X = from_bits2(__builtin_amdgcn_perm(xh, xr, 0x060c000cu));
             const s16x2 v = sat_sub2(X, R.RP[0]);
@@ -371,7 +397,7 @@ __device__ LDPC_SPLIT_CONFLICT_INLINE void conflict_layer(RowState<MAXDEG>& R, u
     const int j = t >> 1;
     int M0, M1, SXs;
     SPLIT_MARK_DECL;
-    row_input<MAXDEG, MAXC>(R, late, (L.kind_nw >> 20) & 1u, 1u, t, M0, M1, SXs);
+    row_input<MAXDEG, MAXC>(R, late, 1u, t, M0, M1, SXs);
     int min0 = M0 >> 24, min1 = M1 >> 24, sx = SXs;                 // (sx: the sign of the row's product sits in bit 31)
     SPLIT_MARK(0);
     if constexpr (KIND == 6) {
@@ -515,7 +541,8 @@ __device__ LDPC_SPLIT_CONFLICT_INLINE void conflict_layer(RowState<MAXDEG>& R, u
 
 template <int MAXDEG>
 __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LDPC_SPLIT_WPE))) void ldpc_split_kernel(LdpcKernelParams read_through_ldpc_params) {
-    // (the arguments are read section by section through ldpc_params(), ldpc_lane_common.h)
+    // (the arguments are read section by section through ldpc_params(), ldpc_lane_common.h: this by-value structure must stay the kernel's FIRST AND ONLY parameter --
+    // ldpc_params() reads it at offset 0 of the kernel-argument segment)
     using S = SplitShape<MAXDEG>;
     constexpr int T = LDPC_SPLIT_T, REC = S::REC, NPW = S::NPW;
     extern __shared__ __attribute__((aligned(16))) int8_t lds_all[];     // (the kernel has no static LDS: the posteriors start at LDS offset 0, what the table's offsets count from)
@@ -640,11 +667,21 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                 if (LDPC_SPLIT_SKIP && ((LDPC_SPLIT_SKIP >> (L.kind_nw & 0xffu)) & 1)) {      // (timing / counter experiments: the layers of these kinds do nothing)
 #pragma unroll
                     for (int w = 0; w < REC; ++w) ro[w] = RS.rw;
+#ifdef LDPC_SPLIT_NOPREV_RT
+                } else if ((L.kind_nw & 0xffu) == 0 || (L.kind_nw & 0xffu) == 7) {
+                    int M0, M1, SXs;
+                    row_input<MAXDEG, 0, 2>(RS, 0u, L.aux, tt, M0, M1, SXs, (L.kind_nw >> 20) & 1u);
+                    row_output<MAXDEG, 0>(RS, M0, M1, SXs, 0u, ro);
+#endif
                 } else if ((L.kind_nw & 0xffu) == 0) {
                     int M0, M1, SXs;
-                    row_input<MAXDEG, 0>(RS, 0u, (L.kind_nw >> 20) & 1u, L.aux, tt, M0, M1, SXs);
+                    row_input<MAXDEG, 0>(RS, 0u, 0u, tt, M0, M1, SXs);
                     if (LDPC_SPLIT_EXP & 8) { ro[0] = (uint32_t)(M0 ^ M1 ^ SXs); ro[REC - 1] = ro[0]; }
                     else row_output<MAXDEG, 0>(RS, M0, M1, SXs, 0u, ro);
+                } else if ((L.kind_nw & 0xffu) == 7) {
+                    int M0, M1, SXs;
+                    row_input<MAXDEG, 0, 1>(RS, 0u, L.aux, tt, M0, M1, SXs);
+                    row_output<MAXDEG, 0>(RS, M0, M1, SXs, 0u, ro);
                 } else if ((L.kind_nw & 0xffu) == 1) {
                     chain_layer<MAXDEG>(RS, ro, L, ents[L.ent_off + 1], tt, post, cw, cres);
                 } else if ((L.kind_nw & 0xffu) == 6) {

@@ -8,7 +8,7 @@
 //     joining the two halves' (min0, min1, sign) with one cross-lane step leaves algorithms.hh:242-255 bit-exact.
 //   * a sweep is a list of PSEUDO-LAYERS, each ending in a workgroup barrier, one per layer of the code, all twelve waves at work in every one of them.  Everything a
 //     thread needs for one -- the LDS byte offsets of its slots, parity bits included, and its row word -- comes from a per-thread table entry:
-//       kind 0 (row update): a conflict-free layer, one row per lane pair, rows in lane order.
+//       kind 0 (row update): a conflict-free layer, one row per lane pair, rows in lane order; kind 7: the same for layer 0, whose row 0 has no previous parity bit.
 //       kinds 1 / 3 / 6 (chain walk / levels / quad walk): a layer with shared bits keeps ldpc_kernel.hip's forms: all rows at once in lane order, the shared links
 //           (they all sit in half 0) resolved in a middle section -- chains walked by a few lanes through per-row hand-off records (~135 cycles per chained row), four
 //           lanes per row of a deep narrow level structure, or a barrier per level.
@@ -32,7 +32,7 @@ constexpr int LDPC_SPLIT_SCRATCH = 64;         // scratch bytes behind the poste
 
 struct LdpcSplitLayer {   // 16 bytes = one s_load_dwordx4
     uint32_t kind_nw;     // bits 0..7 kind, 8..15 waves (always 12), 16..19 nc = shared links of the layer (slots 0..nc-1 of half 0), bit 20: holds row 0 of layer 0 (no previous parity bit)
-    uint32_t aux;         // kind 0: the half-1 thread of row 0 of layer 0 (bit 20); kind 1: chain step d; kind 3: levels; kind 6: index of the walk list in LdpcPlan::rows
+    uint32_t aux;         // kind 7: the half-1 thread of row 0 of layer 0 (bit 20); kind 1: chain step d | (359 / d) << 16; kind 3: levels; kind 6: index of the walk list in LdpcPlan::rows
     uint32_t rec_off;     // dword offset of the pseudo-layer's records inside a workgroup's message workspace
     uint32_t ent_off;     // kind 1: index of the layer's link entries in LdpcPlan::ents (the walker reads link 1's)
 };
@@ -82,6 +82,7 @@ inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P) {
         if (j > 0) return (uint32_t)(K + 360 * (q - 1) + j - 1);
         return ~0u;
     };
+    bool bad_noprev = false;      // layer 0 (it holds the row without a previous parity bit) must be conflict-free: only kind 7 handles the missing link
     // one pseudo-layer: rows[] = the original rows of lane pairs 0, 1, ...; info[] = their row words (kind 1)
     auto emit = [&](int kind, int i, const std::vector<int>& rows, const std::vector<uint32_t>* info, uint32_t aux) {
         LdpcSplitLayer D{};
@@ -103,7 +104,7 @@ inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P) {
                 uint32_t a = scratch(t);
                 if (j >= 0) {
                     a = slot_addr(i, j, h * hs + s);
-                    if (a == ~0u) { a = scratch(t); D.kind_nw |= 1u << 20; if (kind == 0) D.aux = (uint32_t)t; }
+                    if (a == ~0u) { a = scratch(t); D.kind_nw |= 1u << 20; if (kind == 0) { D.aux = (uint32_t)t; D.kind_nw = (D.kind_nw & ~0xffu) | 7u; } else bad_noprev = true; }
                 }
                 w[s >> 1] |= a << (16 * (s & 1));
             }
@@ -130,12 +131,12 @@ inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P) {
                 info.push_back((rw & 0xffu) | (((rw >> 8) & 15u) << 8) | (((rw >> 20) & 15u) << 12));
             }
             if (chain == LDPC_WALK_MARK) emit(6, i, rows, &info, L.row_off + 360);
-            else if (chain != 0) emit(1, i, rows, &info, chain);
+            else if (chain != 0) emit(1, i, rows, &info, chain | ((359u / chain) << 16));
             else emit(3, i, rows, &info, (uint32_t)depth);
             S.chain_layers++;
         }
     }
-    S.ok = true;
+    S.ok = !bad_noprev;
     return S;
 }
 

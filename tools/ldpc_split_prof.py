@@ -26,7 +26,7 @@ print('pseudo-layers %d, frames per workgroup ~%d, cycles per iteration: %.0f (+
 cur = -1; line = ''
 tot = {}
 for i, c in enumerate(per):
-    k = 'free' if sp['kind'][i] == 0 and sp['nw'][i] == 12 and (i + 1 == len(per) or sp['layer'][i + 1] != sp['layer'][i]) and (i == 0 or sp['layer'][i - 1] != sp['layer'][i]) else ('walk%d' % sp['kind'][i] if sp['kind'][i] else 'packed')
+    k = 'free' if sp['kind'][i] in (0, 7) and sp['nw'][i] == 12 and (i + 1 == len(per) or sp['layer'][i + 1] != sp['layer'][i]) and (i == 0 or sp['layer'][i - 1] != sp['layer'][i]) else ('walk%d' % sp['kind'][i] if sp['kind'][i] else 'packed')
     tot.setdefault(k, [0, 0.0]); tot[k][0] += 1; tot[k][1] += c
     if sp['layer'][i] != cur:
         if line: print(line)
