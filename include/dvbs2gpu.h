@@ -50,6 +50,17 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx);
  * pairs can be given as DVBS2GPU_OPTIONS="name=value,name=value" in the environment when the context is created -- the one variable the library reads.  Options that
  * choose a decoder plan (ldpc_wave, ldpc_split) must be set before the first frame of the code is decoded.  The reference has no counterpart (its behaviour is the default). */
 int dvbs2gpu_set_option(dvbs2gpu_ctx* ctx, const char* name, int value);
+/* Read-only introspection (no reference counterpart; bench.py records the run-time balancer's final state and the launches a drop-in call costs with it).
+ * Names: "kernel_launches" (kernel launches of the whole library in this process so far), "g_prio_duty" / "g_prio_auto" / "g_prio_hold" (the pipelined mode's priority
+ * share of the timing loop, whether it is balanced at run time, calls the balancer still rests), "stage_pipeline_on" (the last CCM batch ran its post stages behind
+ * every front-end slice), "fec_part_on" / "fec_part" (big decoder jobs on the 128-unit partition stream; the option's setting), "pipelined", "num_cus". */
+int dvbs2gpu_get_state(dvbs2gpu_ctx* ctx, const char* name, long long* value);
+/* Test / bench aid: the pipelined CCM decoder job that configuration group `slot` (0 for a single-configuration batch) DELIVERED last -- what the decoder read and what it
+ * wrote, still in place until the group starts another job of the same parity (two calls later).  out10 = {device pointer of the LLRs [nf][N] int8, device pointer of the
+ * BBFRAMEs [nf][kb], nf frames, n streams, N, kb bytes per BBFRAME, code rate index, short frames, max_trials, forced}; h_first[n + 1]: first pooled frame of every stream
+ * of the job; h_handles[n]: the streams' dvbs2gpu_demod handles (as the call that started the job listed them).  bench.py decodes sampled LLR frames with the CPU oracle
+ * and compares them with the BBFRAMEs the engine delivered.  No reference counterpart. */
+int dvbs2gpu_debug_last_fec_job(dvbs2gpu_ctx* ctx, int slot, long long* out10, int32_t* h_first, const void** h_handles, int cap);
 
 /* Static parameter queries (no GPU needed).  Mirrors get_dvbs2_cfg (modcod_to_cfg.cpp:5-140),
  * BBFrameBCH::BBFrameBCH (bbframe_bch.cpp:39-161) and the PLFRAME size of dvbs2_pl_sync.cpp:14-31. */
@@ -273,6 +284,40 @@ int dvbs2gpu_demod_get_frame_positions(dvbs2gpu_demod* d, int64_t* h_out, int ca
  * 1 = aligned raw PLFRAMEs, 2 = PLL output, (complex64, count in complex samples); 3 = LLRs (int8).
  * Returns the element count; copies at most cap elements when h_dst != NULL. */
 int dvbs2gpu_demod_get_tap(dvbs2gpu_demod* d, int which, void* h_dst, int cap);
+
+/* ------------------------------------------------------------------ fleet: the transponders of one host over several GPUs
+ * The reference runs one independent DVBS2Demod instance per transponder (src/main.cpp:588,595: every plugin instance owns its demodulator and worker thread); nothing is
+ * exchanged inside a frame or between streams.  A FLEET is what a C++ plugin host with several GPUs calls: `n` members -- one engine context + one worker thread per entry
+ * of devices[] (a HIP device index may appear more than once: "logical devices", how the tests run a 4-member fleet on a 1-GPU box) -- and a transponder table placed on them
+ * by dvbs2gpu_fleet_plan's rule: whole MODCOD groups by longest-processing-time first (every member's LDPC batches stay homogeneous) when no member ends up more than
+ * `tolerance` above the average load, else the MODCOD-sorted list cut into n pieces of near-equal weight -- the rule of the multi-process harness
+ * (sdrpp-dvbs-demodulator_amd/distribute.py: assign_transponders; tests/test_cabi_host.py holds the two against each other).  No device talks to another.
+ *   dvbs2gpu_fleet_plan           the placement alone (no GPU): member_of[i] for nt transponders of given MODCOD and weight over `world` members.
+ *   dvbs2gpu_fleet_assign         places `table` (a demodulator configuration, a weight -- <= 0: edges x iterations + 40 x PLFRAME symbols -- and the largest call in samples per
+ *                                 transponder), creates every transponder's demodulator on its member (an earlier table's are destroyed), out_cap = bytes of the largest
+ *                                 delivery of one transponder and call; member_of (optional) receives the placement.
+ *   dvbs2gpu_fleet_process_batch  one call for ALL transponders: h_iq[i] / counts[i] HOST samples of transponder i (2 sps, interleaved floats), h_out[i] HOST buffers of out_cap
+ *                                 bytes, out_bytes[i] the bytes delivered -- EGRESS IN TABLE ORDER whichever member decoded them.  The members copy, run
+ *                                 dvbs2gpu_demod_process_batch and copy back side by side on their worker threads; the call returns when all are through; the first member
+ *                                 error is the return code (dvbs2gpu_last_error() names the device), every member is waited for either way.
+ *   dvbs2gpu_fleet_set_pipelined  the throughput mode of dvbs2gpu_set_pipelined on every member (frames one call late; a call with all counts 0 collects the last ones).
+ *   dvbs2gpu_fleet_get_stats      dvbs2gpu_demod_get_stats of transponder i.      dvbs2gpu_fleet_reset: DVBS2Demod::reset of every transponder. */
+typedef struct dvbs2gpu_fleet dvbs2gpu_fleet;
+typedef struct dvbs2gpu_fleet_entry {
+    dvbs2gpu_demod_cfg cfg;
+    double weight;
+    int32_t max_samples;
+    int32_t reserved;
+} dvbs2gpu_fleet_entry;
+int dvbs2gpu_fleet_plan(const int32_t* modcods, const double* weights, int nt, int world, double tolerance, int32_t* member_of);
+int dvbs2gpu_fleet_create(const int* devices, int n, dvbs2gpu_fleet** out);
+void dvbs2gpu_fleet_destroy(dvbs2gpu_fleet* f);
+int dvbs2gpu_fleet_size(const dvbs2gpu_fleet* f);
+int dvbs2gpu_fleet_assign(dvbs2gpu_fleet* f, const dvbs2gpu_fleet_entry* table, int nt, int out_cap, double tolerance, int32_t* member_of);
+int dvbs2gpu_fleet_set_pipelined(dvbs2gpu_fleet* f, int on);
+int dvbs2gpu_fleet_reset(dvbs2gpu_fleet* f);
+int dvbs2gpu_fleet_process_batch(dvbs2gpu_fleet* f, const float* const* h_iq, const int* counts, uint8_t* const* h_out, int out_cap, int* out_bytes);
+int dvbs2gpu_fleet_get_stats(dvbs2gpu_fleet* f, int transponder, dvbs2gpu_frame_stats* h_out, int cap);
 
 /* ------------------------------------------------------------------ segment receiver: ONE fast transponder
  * A stream's loops are serial recurrences (one stream: 0.69 Msym/s on MI355X), so a single 27.5 Msym/s transponder cannot be

@@ -68,6 +68,9 @@ PROTOTYPES = {
     'dvbs2gpu_modcod_info_get': (_i, [_i, _i, _i, C.POINTER(ModcodInfo)]),
     'dvbs2gpu_fec_info_get': (_i, [_i, _i, C.POINTER(ModcodInfo)]),
     'dvbs2gpu_set_option': (_i, [_vp, C.c_char_p, _i]),
+    'dvbs2gpu_preinit': (_i, []),
+    'dvbs2gpu_get_state': (_i, [_vp, C.c_char_p, C.POINTER(C.c_longlong)]),
+    'dvbs2gpu_debug_last_fec_job': (_i, [_vp, _i, C.POINTER(C.c_longlong), C.POINTER(C.c_int32), C.POINTER(_vp), _i]),
     'dvbs2gpu_ldpc_plan_dump': (_i, [_i, _i, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
     'dvbs2gpu_ldpc_plan_info': (_i, [_vp, _i, _i, C.POINTER(C.c_int32)]),
     'dvbs2gpu_ldpc_decoder_form': (_i, [_vp, _i, _i]),
@@ -225,6 +228,25 @@ class Engine:
 
     def set_option(self, name, value):
         self._check(self.lib.dvbs2gpu_set_option(self.h, str(name).encode(), int(value)))
+
+    def get_state(self, name):
+        """read-only introspection (dvbs2gpu_get_state): 'kernel_launches', 'g_prio_duty', 'stage_pipeline_on', 'fec_part_on', ..."""
+        v = C.c_longlong()
+        self._check(self.lib.dvbs2gpu_get_state(self.h, str(name).encode(), C.byref(v)))
+        return int(v.value)
+
+    def last_fec_job(self, slot=0):
+        """the pipelined CCM decoder job group `slot` delivered last (dvbs2gpu_debug_last_fec_job): dict with the device pointers of its LLRs / BBFRAMEs, the
+        frame count, N, kb, the code, and `first` (first pooled frame of every stream of the job) + `handles` (the streams' demod handles)"""
+        import numpy as np
+        o = (C.c_longlong * 10)()
+        self._check(self.lib.dvbs2gpu_debug_last_fec_job(self.h, int(slot), o, None, None, 0))
+        n = int(o[3])
+        first = (C.c_int32 * (n + 1))()
+        hs = (_vp * max(n, 1))()
+        self._check(self.lib.dvbs2gpu_debug_last_fec_job(self.h, int(slot), o, first, hs, n + 1))
+        return dict(d_llr=int(o[0]), d_bb=int(o[1]), nf=int(o[2]), n=n, N=int(o[4]), kb=int(o[5]), rate=int(o[6]), short=int(o[7]), max_trials=int(o[8]), force=int(o[9]),
+                    first=np.array(first[:n + 1], dtype=np.int64), handles=[hs[i] for i in range(n)])
 
     def close(self):
         if getattr(self, 'h', None):

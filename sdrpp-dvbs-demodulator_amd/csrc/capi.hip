@@ -9,6 +9,7 @@ using namespace s2;
 namespace s2 { extern unsigned long long* g_ldpc_prof; }
 
 namespace s2 {
+std::atomic<long long> g_kernel_launches{0};
 static thread_local std::string g_err;
 std::string& last_error() { return g_err; }
 int fail_hip(hipError_t e, const char* what) {
@@ -383,6 +384,34 @@ int dvbs2gpu_set_option(dvbs2gpu_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return DVBS2GPU_ERR_ARG;
     CallGuard guard(ctx);
     if (s2::apply_option(ctx, name, value) != 0) { g_err = std::string("unknown option or value out of range: ") + name; return DVBS2GPU_ERR_ARG; }
+    return DVBS2GPU_OK;
+}
+
+int dvbs2gpu_get_state(dvbs2gpu_ctx* ctx, const char* name, long long* value) {
+    if (!ctx || !name || !value) return DVBS2GPU_ERR_ARG;
+    CallGuard guard(ctx);
+    const std::string n(name);
+    if (n == "kernel_launches") *value = s2::g_kernel_launches.load(std::memory_order_relaxed);
+    else if (n == "g_prio_duty") *value = ctx->g_prio_duty;
+    else if (n == "g_prio_auto") *value = ctx->g_prio_auto ? 1 : 0;
+    else if (n == "g_prio_hold") *value = ctx->g_prio_hold;
+    else if (n == "stage_pipeline_on") *value = ctx->last_call_staged ? 1 : 0;
+    else if (n == "fec_part_on") *value = ctx->fec_part_on ? 1 : 0;
+    else if (n == "fec_part") *value = ctx->fec_part;
+    else if (n == "pipelined") *value = ctx->pipeline_fec;
+    else if (n == "num_cus") *value = ctx->num_cus;
+    else { g_err = std::string("unknown state name: ") + name; return DVBS2GPU_ERR_ARG; }
+    return DVBS2GPU_OK;
+}
+
+int dvbs2gpu_debug_last_fec_job(dvbs2gpu_ctx* ctx, int slot, long long* out10, int32_t* h_first, const void** h_handles, int cap) {
+    if (!ctx || !out10 || slot < 0 || slot >= dvbs2gpu_ctx::MAX_PIPE_GROUPS) return DVBS2GPU_ERR_ARG;
+    CallGuard guard(ctx);
+    const dvbs2gpu_ctx::LastFecJob& lj = ctx->last_fec[slot];
+    out10[0] = (long long)(uintptr_t)lj.d_llr; out10[1] = (long long)(uintptr_t)lj.d_bb; out10[2] = lj.nf; out10[3] = lj.n; out10[4] = lj.N; out10[5] = lj.kb;
+    out10[6] = lj.rate; out10[7] = lj.shortframe; out10[8] = lj.max_trials; out10[9] = lj.force;
+    for (int i = 0; h_first && i <= lj.n && i < cap && i < (int)lj.first.size(); ++i) h_first[i] = lj.first[i];
+    for (int i = 0; h_handles && i < lj.n && i < cap; ++i) h_handles[i] = lj.dm[i];
     return DVBS2GPU_OK;
 }
 

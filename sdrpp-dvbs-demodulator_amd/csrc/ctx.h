@@ -142,6 +142,11 @@ struct dvbs2gpu_ctx {
     void* pending_fec[MAX_PIPE_GROUPS] = {};              // s2::PendingFec*
     s2::Workspace ws_fecbuf[MAX_PIPE_GROUPS][2][3];       // per parity: LLRs | BBFRAMEs | frame refs + first[] + trials + corrections
     int fec_parity[MAX_PIPE_GROUPS] = {};
+    // what the bench's self-check reads back (dvbs2gpu_debug_last_fec_job): the pipelined CCM job a slot delivered last -- its LLR and BBFRAME buffers stay untouched until the
+    // slot's next job of the same parity is started
+    struct LastFecJob { const int8_t* d_llr = nullptr; const uint8_t* d_bb = nullptr; int nf = 0, n = 0, N = 0, kb = 0, rate = -1, shortframe = 0, max_trials = 0, force = 0; std::vector<int> first; std::vector<const void*> dm; };
+    LastFecJob last_fec[MAX_PIPE_GROUPS];
+    bool last_call_staged = false;            // the last CCM batch ran its post stages behind every front-end slice (the stage pipeline)
     hipEvent_t ev_fec[MAX_PIPE_GROUPS][2] = {};   // end of a group's FEC job, per job parity (the next job is enqueued before the previous one is delivered)
     hipEvent_t ev_fec_t0[MAX_PIPE_GROUPS][2] = {};   // ... and its start (timing events: the job's duration feeds the rule below)
     // THE PLUGIN'S MODE BY SPACE (s2_demod.hip, process_group): a second FEC stream confined to FEC_PART_CUS compute units.  A single-configuration batch whose decoder job is long

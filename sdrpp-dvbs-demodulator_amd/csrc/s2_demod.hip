@@ -349,6 +349,8 @@ struct PendingFec {
     const S2FrameRef* d_frames = nullptr;
     const int* d_first = nullptr;
     const uint8_t* d_bb = nullptr;
+    const int8_t* d_llr = nullptr;      // (CCM jobs: what the decoder read; kept for dvbs2gpu_debug_last_fec_job)
+    int N = 0, rate = -1, shortframe = 0, max_trials = 0, force = 0, slot = -1;
     const int32_t* d_trials = nullptr;  // CCM: [nf]; ACM/VCM: per part trials[cnt] ++ corrections[cnt] at part.to
     const int32_t* d_corr = nullptr;
     // ACM/VCM
@@ -377,14 +379,22 @@ static int fec_stream_enter(dvbs2gpu_ctx* ctx, hipStream_t sf) {
     return 0;
 }
 static void fec_stream_leave(dvbs2gpu_ctx* ctx, hipStream_t sf, hipEvent_t done) { ctx->fec_last_done = done; ctx->fec_last_stream = sf; }
-static int fec_part_stream(dvbs2gpu_ctx* ctx, hipStream_t* out) {
+// (hipExtStreamCreateWithCUMask has no flags argument: the stream it makes is a default-flag, BLOCKING stream -- work a host enqueues on the legacy null stream serialises with
+// the decoder jobs on it; INTEGRATION.md tells hosts to use explicit non-blocking streams beside the engine.  A driver that refuses the mask must not take the call down -- the
+// front end has advanced the streams' state by now: the rule is switched off for the context and the job goes onto the ordinary FEC stream.)
+static bool fec_part_stream(dvbs2gpu_ctx* ctx, hipStream_t* out) {
     if (!ctx->fec_part_stream) {
         uint32_t mask[8] = {};
         for (int i = 0; i < FEC_PART_CUS && i < ctx->num_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
-        HIP_TRY(hipExtStreamCreateWithCUMask(&ctx->fec_part_stream, 8, mask));
+        if (hipExtStreamCreateWithCUMask(&ctx->fec_part_stream, 8, mask) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->fec_part_stream = nullptr;
+            ctx->fec_part = 0; ctx->fec_part_on = false; ctx->fec_part_trend = 0;
+            return false;
+        }
     }
     *out = ctx->fec_part_stream;
-    return 0;
+    return true;
 }
 
 // the streams of the whole batch a pipelined call works on: a job is collected into the buffers of whichever of ITS streams are part of this batch
@@ -398,6 +408,12 @@ struct BatchMap {
 
 // results of a finished (or finishing) job -> the callers' output buffers and the per-frame stats of its streams.  `wo`: a scratch workspace of the caller's
 static int deliver_job(dvbs2gpu_ctx* ctx, PendingFec* job, hipStream_t st, Workspace& wo, const BatchMap& bm) {
+    if (!job->vcm && job->slot >= 0 && job->d_llr) {       // (bench.py's decoder self-check reads the job's buffers back through dvbs2gpu_debug_last_fec_job)
+        dvbs2gpu_ctx::LastFecJob& lj = ctx->last_fec[job->slot];
+        lj.d_llr = job->d_llr; lj.d_bb = job->d_bb; lj.nf = job->nf; lj.n = job->n; lj.N = job->N; lj.kb = job->kb;
+        lj.rate = job->rate; lj.shortframe = job->shortframe; lj.max_trials = job->max_trials; lj.force = job->force;
+        lj.first = job->first; lj.dm.assign(job->dm.begin(), job->dm.end());
+    }
     if (job->done) HIP_TRY(hipStreamWaitEvent(st, job->done, 0));
     for (hipEvent_t e : job->done_more) HIP_TRY(hipStreamWaitEvent(st, e, 0));
     int rc2;
@@ -574,6 +590,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     // (a small bank is a set of latency chains whatever the mode: always staged)
     const bool staged = !pre_nsym && (ctx->stage_pipeline == 2 ? (ctx->stage_calls++ & 1) != 0 :
         ctx->stage_pipeline && (n <= S2_SMALL_BANK || !(pipelined && ctx->g_prio_auto && ctx->g_prio_duty <= ctx->stage_pipeline_min_duty)));
+    ctx->last_call_staged = staged;
     Workspace& ws_pll = W[3];
     Workspace& ws_slot = W[7];
     std::vector<S2FrameStats> slot_stats;
@@ -784,6 +801,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         job->d_trials = j_trials; job->d_corr = j_corr;
         const int force = d0->cfg.force_ldpc_iters > 0;
         const int mt = force ? d0->cfg.force_ldpc_iters : d0->cfg.max_ldpc_trials;
+        job->d_llr = (const int8_t*)ctx->ws_fecbuf[slot][par][0].p; job->N = N; job->rate = mp.rate; job->shortframe = mp.shortframe; job->max_trials = mt; job->force = force; job->slot = slot;
         // A group's job that cannot fill the device (fewer decoder workgroups than half the CUs: the groups of a 64-transponder batch -- a
         // handful of workgroups and 4-6 ms of decoder LATENCY each) runs beside the other groups' jobs: on the GROUP's stream, behind its
         // demapper, with the group's own FEC workspaces (the group's next call enqueues its stages a whole front-end pass later, so nothing
@@ -800,8 +818,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             std::lock_guard<std::mutex> fl(ctx->fec_mtx);
             // (a single-configuration batch whose decoder has room to spare: onto the partition stream, ctx.h)
             if (ctx->fec_part_on && !own_ws && !pre_nsym) {
-                if ((rc = fec_part_stream(ctx, &sf))) return rc;
-                job->on_part = true;
+                job->on_part = fec_part_stream(ctx, &sf);
             }
             if ((rc = fec_stream_enter(ctx, sf))) return rc;
             HIP_TRY(hipStreamWaitEvent(sf, ev_llr, 0));

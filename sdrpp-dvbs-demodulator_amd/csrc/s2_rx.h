@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "launch_count.h"
 
 namespace s2 {
 
