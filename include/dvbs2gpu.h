@@ -45,6 +45,8 @@ int dvbs2gpu_preinit(void);
 
 /* Create a context on HIP device `device`.  Fails with DVBS2GPU_ERR_NODEVICE when no GPU is present. */
 int dvbs2gpu_create(int device, dvbs2gpu_ctx** out);
+/* HIP devices visible to the process (0: none -- there is no CPU fallback); what a multi-GPU host sizes its fleet with */
+int dvbs2gpu_device_count(void);
 void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx);
 /* Development / test options of a context (which of several bit-identical flows runs, time slicing, side streams ...; DESIGN.md section 11 lists them).  The same
  * pairs can be given as DVBS2GPU_OPTIONS="name=value,name=value" in the environment when the context is created -- the one variable the library reads.  Options that

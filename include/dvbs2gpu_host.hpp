@@ -291,5 +291,46 @@ private:
 };
 
 }   // namespace dvbs
+
+/* The transponders of one host over several GPUs (dvbs2gpu_fleet_*, include/dvbs2gpu.h): the reference runs one independent DVBS2Demod per transponder
+ * (src/main.cpp:588,595); a Fleet places a table of them on its members -- one engine context + worker thread per device -- by the MODCOD-grouped
+ * longest-processing-time rule and returns every call's BBFRAMEs in table order.  Every failing call throws std::runtime_error, as above. */
+class Fleet {
+public:
+    explicit Fleet(const std::vector<int>& devices) { check(dvbs2gpu_fleet_create(devices.data(), (int)devices.size(), &f)); }
+    ~Fleet() { dvbs2gpu_fleet_destroy(f); }
+    Fleet(const Fleet&) = delete;
+    Fleet& operator=(const Fleet&) = delete;
+
+    /* one table entry per transponder: DVBS2Demod::init's parameters as the plugin sets them (main.cpp:64-73,134-140), cfg.modcod etc. per transponder */
+    static dvbs2gpu_fleet_entry entry(int modcod, bool shortframes, bool pilots, int max_samples, int max_ldpc_trials = 16, int force_ldpc_iters = 0, double weight = 0.0) {
+        dvbs2gpu_fleet_entry e{};
+        dvbs2gpu_demod_default_cfg(modcod, shortframes, pilots, &e.cfg);
+        e.cfg.max_ldpc_trials = max_ldpc_trials; e.cfg.force_ldpc_iters = force_ldpc_iters;
+        e.weight = weight; e.max_samples = max_samples;
+        return e;
+    }
+    /* places the table; returns the member of every transponder */
+    std::vector<int> assign(const std::vector<dvbs2gpu_fleet_entry>& table, int out_cap, double tolerance = 0.25) {
+        std::vector<int32_t> m(table.size());
+        check(dvbs2gpu_fleet_assign(f, table.data(), (int)table.size(), out_cap, tolerance, m.data()));
+        nt = (int)table.size(); cap = out_cap;
+        return std::vector<int>(m.begin(), m.end());
+    }
+    void setPipelined(bool on) { check(dvbs2gpu_fleet_set_pipelined(f, on ? 1 : 0)); }
+    void reset() { check(dvbs2gpu_fleet_reset(f)); }
+    /* one call for all transponders, in table order: in[i] / count[i] samples of transponder i, out[i] receives its BBFRAMEs (capacity: assign's out_cap); returns the byte counts */
+    std::vector<int> process(const std::vector<const complex_t*>& in, const std::vector<int>& count, const std::vector<uint8_t*>& out) {
+        if ((int)in.size() != nt || (int)count.size() != nt || (int)out.size() != nt) throw std::runtime_error("dvbs2gpu: Fleet::process needs one entry per transponder");
+        std::vector<int> nb((size_t)nt, 0);
+        check(dvbs2gpu_fleet_process_batch(f, reinterpret_cast<const float* const*>(in.data()), count.data(), out.data(), cap, nb.data()));
+        return nb;
+    }
+    int size() const { return dvbs2gpu_fleet_size(f); }
+
+private:
+    dvbs2gpu_fleet* f = nullptr;
+    int nt = 0, cap = 0;
+};
 }   // namespace dvbs2gpu_host
 #endif

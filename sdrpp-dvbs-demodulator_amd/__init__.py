@@ -69,6 +69,16 @@ PROTOTYPES = {
     'dvbs2gpu_fec_info_get': (_i, [_i, _i, C.POINTER(ModcodInfo)]),
     'dvbs2gpu_set_option': (_i, [_vp, C.c_char_p, _i]),
     'dvbs2gpu_preinit': (_i, []),
+    'dvbs2gpu_device_count': (_i, []),
+    'dvbs2gpu_fleet_plan': (_i, [C.POINTER(C.c_int32), C.POINTER(C.c_double), _i, _i, C.c_double, C.POINTER(C.c_int32)]),
+    'dvbs2gpu_fleet_create': (_i, [C.POINTER(_i), _i, C.POINTER(_vp)]),
+    'dvbs2gpu_fleet_destroy': (None, [_vp]),
+    'dvbs2gpu_fleet_size': (_i, [_vp]),
+    'dvbs2gpu_fleet_assign': (_i, [_vp, _vp, _i, _i, C.c_double, C.POINTER(C.c_int32)]),
+    'dvbs2gpu_fleet_set_pipelined': (_i, [_vp, _i]),
+    'dvbs2gpu_fleet_reset': (_i, [_vp]),
+    'dvbs2gpu_fleet_process_batch': (_i, [_vp, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), _i, C.POINTER(_i)]),
+    'dvbs2gpu_fleet_get_stats': (_i, [_vp, _i, C.POINTER(FrameStats), _i]),
     'dvbs2gpu_get_state': (_i, [_vp, C.c_char_p, C.POINTER(C.c_longlong)]),
     'dvbs2gpu_debug_last_fec_job': (_i, [_vp, _i, C.POINTER(C.c_longlong), C.POINTER(C.c_int32), C.POINTER(_vp), _i]),
     'dvbs2gpu_ldpc_plan_dump': (_i, [_i, _i, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
@@ -203,6 +213,81 @@ def ldpc_split_plan(rate, shortframes=False):
     return {'npl': npl, 'npw': npw, 'hs': hs, 'rec_total': rec_total, 'rec_dwords': rec_dw, 'kind': (layers[:, 0] & 0xff).astype(int), 'nw': ((layers[:, 0] >> 8) & 0xff).astype(int),
             'nc': ((layers[:, 0] >> 16) & 15).astype(int), 'noprev': ((layers[:, 0] >> 20) & 1).astype(int), 'aux': layers[:, 1].astype(int), 'rec_off': layers[:, 2].astype(int),
             'ent_off': layers[:, 3].astype(int), 'table': table.reshape(npl, 768, npw), 'row_of': row_of, 'layer': layer_of}
+
+
+class FleetEntry(C.Structure):
+    """dvbs2gpu_fleet_entry"""
+    _fields_ = [('cfg', DemodCfg), ('weight', C.c_double), ('max_samples', C.c_int32), ('reserved', C.c_int32)]
+
+
+def fleet_plan(modcods, weights, world, tolerance=0.25):
+    """Host-only: the fleet's placement rule (dvbs2gpu_fleet_plan) -> member index of every transponder"""
+    lib = load_library()
+    n = len(modcods)
+    m = (C.c_int32 * max(n, 1))(*[int(x) for x in modcods])
+    w = (C.c_double * max(n, 1))(*[float(x) for x in weights])
+    out = (C.c_int32 * max(n, 1))()
+    rc = lib.dvbs2gpu_fleet_plan(m, w, n, int(world), float(tolerance), out)
+    if rc != 0:
+        raise Dvbs2GpuError(rc, lib.dvbs2gpu_last_error().decode())
+    return [int(out[i]) for i in range(n)]
+
+
+class Fleet:
+    """dvbs2gpu_fleet_*: a transponder table over several (logical) devices behind the C ABI; host buffers in, BBFRAMEs out in table order"""
+
+    def __init__(self, devices):
+        self.lib = load_library()
+        h = _vp()
+        d = (_i * len(devices))(*[int(x) for x in devices])
+        rc = self.lib.dvbs2gpu_fleet_create(d, len(devices), C.byref(h))
+        if rc != 0:
+            raise Dvbs2GpuError(rc, self.lib.dvbs2gpu_last_error().decode())
+        self.h, self.nt, self.cap = h, 0, 0
+
+    def _check(self, rc):
+        if rc < 0:
+            raise Dvbs2GpuError(rc, self.lib.dvbs2gpu_last_error().decode())
+        return rc
+
+    def assign(self, cfgs, max_samples, out_cap, weights=None, tolerance=0.25):
+        """cfgs: one DemodCfg per transponder -> member index of every transponder"""
+        n = len(cfgs)
+        tab = (FleetEntry * max(n, 1))()
+        for i, c in enumerate(cfgs):
+            tab[i].cfg = c
+            tab[i].weight = float(weights[i]) if weights is not None else 0.0
+            tab[i].max_samples = int(max_samples)
+        out = (C.c_int32 * max(n, 1))()
+        self._check(self.lib.dvbs2gpu_fleet_assign(self.h, C.cast(tab, _vp), n, int(out_cap), float(tolerance), out))
+        self.nt, self.cap = n, int(out_cap)
+        return [int(out[i]) for i in range(n)]
+
+    def set_pipelined(self, on):
+        self._check(self.lib.dvbs2gpu_fleet_set_pipelined(self.h, int(bool(on))))
+
+    def process(self, iqs):
+        """iqs: one numpy complex64 array per transponder (may be empty) -> list of numpy uint8 arrays (BBFRAME bytes, table order)"""
+        import numpy as np
+        iqs = [np.ascontiguousarray(x, np.complex64) for x in iqs]
+        outs = [np.zeros(self.cap, np.uint8) for _ in range(self.nt)]
+        pin = (_vp * self.nt)(*[x.ctypes.data for x in iqs])
+        cnt = (_i * self.nt)(*[int(x.size) for x in iqs])
+        pout = (_vp * self.nt)(*[o.ctypes.data for o in outs])
+        nb = (_i * self.nt)()
+        self._check(self.lib.dvbs2gpu_fleet_process_batch(self.h, pin, cnt, pout, self.cap, nb))
+        return [outs[i][:nb[i]] for i in range(self.nt)]
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.dvbs2gpu_fleet_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _ptr(t):

@@ -338,6 +338,11 @@ int dvbs2gpu_preinit(void) {
 }
 const char* dvbs2gpu_last_error(void) { return g_err.c_str(); }
 
+int dvbs2gpu_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
+}
+
 int dvbs2gpu_create(int device, dvbs2gpu_ctx** out) {
     if (!out) return DVBS2GPU_ERR_ARG;
     *out = nullptr;

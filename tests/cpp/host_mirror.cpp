@@ -5,6 +5,9 @@
 //   host_mirror dvbs <iq.cf32> <out.ts> <chunk>                                DVBSDemod::process per chunk       -> TS packets
 //   host_mirror s2x2 <iqA> <outA> <modcodA> <shortA> <pilotsA> <iqB> <outB> <modcodB> <shortB> <pilotsB> <chunk>
 //                    two DVBS2Demod blocks on two worker threads at once (two plugin instances share the engine context)
+//   host_mirror fleet <table.txt> <egress.bin> <members> <chunk> <pipelined> <forced_iters>
+//                    dvbs2gpu_host::Fleet: the table's transponders ("modcod short pilots iq-file" per line) over `members` logical devices (device = member index
+//                    modulo the box's device count), fed `chunk` samples per transponder and call; egress.bin = per call, per transponder in TABLE order: int32 bytes + BBFRAMEs
 // Prints one status line per mode; exit code 0 = ran, 2 = usage, 3 = exception (e.g. no GPU: there is no CPU fallback).
 #include <dvbs2gpu_host.hpp>
 
@@ -85,6 +88,57 @@ int main(int argc, char** argv) {
             ta.join(); tb.join();
             if (!jobs[0].err.empty() || !jobs[1].err.empty()) throw std::runtime_error(jobs[0].err + " " + jobs[1].err);
             std::printf("s2x2 bytesA=%ld bytesB=%ld\n", jobs[0].total, jobs[1].total);
+        } else if (mode == "fleet" && argc == 8) {
+            const int members = atoi(argv[4]), chunk = atoi(argv[5]), pipelined = atoi(argv[6]), forced = atoi(argv[7]);
+            const int ndev = dvbs2gpu_device_count();
+            if (ndev < 1) throw std::runtime_error("no HIP device visible (this engine has no CPU fallback)");
+            std::vector<int> devices;
+            for (int i = 0; i < members; ++i) devices.push_back(i % ndev);
+            std::vector<dvbs2gpu_fleet_entry> table;
+            std::vector<std::vector<char>> sig;
+            {
+                std::string text(in.begin(), in.end());
+                size_t pos = 0;
+                while (pos < text.size()) {
+                    size_t end = text.find('\n', pos);
+                    if (end == std::string::npos) end = text.size();
+                    const std::string ln = text.substr(pos, end - pos);
+                    pos = end + 1;
+                    int m, sh, pil; char path[1024];
+                    if (std::sscanf(ln.c_str(), "%d %d %d %1023s", &m, &sh, &pil, path) != 4) continue;
+                    table.push_back(Fleet::entry(m, sh != 0, pil != 0, chunk, 16, forced));
+                    sig.push_back(slurp(path));
+                }
+            }
+            const int nt = (int)table.size();
+            const int cap = 1 << 20;
+            Fleet fleet(devices);
+            const std::vector<int> where = fleet.assign(table, cap);
+            fleet.setPipelined(pipelined != 0);
+            std::vector<std::vector<uint8_t>> obufs((size_t)nt, std::vector<uint8_t>((size_t)cap));
+            std::vector<uint8_t*> outs;
+            for (auto& b : obufs) outs.push_back(b.data());
+            long longest = 0;
+            for (auto& s : sig) longest = std::max<long>(longest, (long)(s.size() / sizeof(complex_t)));
+            long total = 0, calls = 0;
+            for (long a = 0; a < longest + (pipelined ? chunk : 0); a += chunk, ++calls) {       // (pipelined: one more call with all counts 0 collects the last frames)
+                std::vector<const complex_t*> ins((size_t)nt);
+                std::vector<int> cnt((size_t)nt);
+                for (int t = 0; t < nt; ++t) {
+                    const long n = (long)(sig[(size_t)t].size() / sizeof(complex_t));
+                    ins[(size_t)t] = reinterpret_cast<const complex_t*>(sig[(size_t)t].data()) + std::min(a, n);
+                    cnt[(size_t)t] = (int)std::max<long>(0, std::min<long>(chunk, n - a));
+                }
+                const std::vector<int> nb = fleet.process(ins, cnt, outs);
+                for (int t = 0; t < nt; ++t) {
+                    const int32_t b = nb[(size_t)t];
+                    out.write(reinterpret_cast<const char*>(&b), sizeof b);
+                    out.write(reinterpret_cast<const char*>(obufs[(size_t)t].data()), b);
+                    total += b;
+                }
+            }
+            std::printf("fleet members=%d devices=%d transponders=%d calls=%ld bytes=%ld placement=", fleet.size(), ndev, nt, calls, total);
+            for (int t = 0; t < nt; ++t) std::printf("%d%s", where[(size_t)t], t + 1 < nt ? "," : "\n");
         } else if (mode == "bbts" && argc == 6) {
             const int kbch = atoi(argv[4]), per_call = atoi(argv[5]);
             dvbs2::BBFrameTSParser parser;

@@ -159,3 +159,25 @@ def test_assignment_helpers(pkg):
     out, cnt = dd.gather_units([2, 0], torch.tensor([[5, 6], [7, 8]], dtype=torch.uint8), torch.tensor([2, 1], dtype=torch.int32), 3)
     assert out.tolist() == [[7, 8], [0, 0], [5, 6]] and cnt.tolist() == [1, 0, 2]
     assert dd.broadcast_object({'a': 1}) == {'a': 1}
+
+
+def test_fleet_plan_behind_the_c_abi_places_like_the_python_harness(pkg):
+    """dvbs2gpu_fleet_plan (csrc/fleet.hip: what a C++ host with several GPUs gets) against distribute.assign_transponders on random tables: same placement,
+    transponder by transponder -- MODCOD groups on one member where the balance allows, the contiguous cut otherwise, degenerate tables included"""
+    import importlib
+    import random
+    D = importlib.import_module(pkg.__name__ + '.distribute')
+    rnd = random.Random(5)
+    cases = [([], 3), ([14], 4), ([4] * 7, 3), ([4, 6] * 8, 8)]
+    for _ in range(300):
+        n = rnd.randint(1, 80)
+        pool = rnd.sample([4, 6, 7, 11, 12, 13, 14, 15, 18, 20, 23, 27], rnd.randint(1, 8))
+        cases.append(([rnd.choice(pool) for _ in range(n)], rnd.randint(1, 9)))
+    for mods, world in cases:
+        heavy = rnd.random() < 0.3
+        table = [dict(modcod=m, weight=(1000.0 * m + (rnd.choice([0.0, 17.5, 300.0]) if heavy else 0.0))) for m in mods]
+        for tol in (0.25, 0.05, 1.0):
+            want = D.assign_transponders(table, world, tol)
+            got = pkg.fleet_plan([t['modcod'] for t in table], [t['weight'] for t in table], world, tol)
+            back = [sorted(i for i, r in enumerate(got) if r == k) for k in range(max(world, 1))]
+            assert back == [sorted(x) for x in want], (mods, world, tol)
