@@ -125,8 +125,8 @@ struct RowState {
 
 // input phase: posteriors in, extrinsic values, the row's two smallest magnitudes and sign -- M0 / M1 / SXs come back with BOTH halves of the
 // word holding the whole row's value (a word with equal halves orders like its 16-bit value under 32-bit signed compares; SXs: sign in bits 15 and 31).
-// LATE > 0: the first LATE slots, where flagged in `late`, are left out of the totals (levels / quad walk: 4).  LATE == -1: the whole first pair is left out of
-// the totals where `late` is not zero (chain walk) -- V / G keep the values read
+// LATE < 0: the whole first -LATE pairs are left out of
+// the totals where `late` is not zero (chain walk: 1, level walk: 2) -- V / G keep the values read
 // NOPREV: the pseudo-layer holds row 0 of layer 0, which has no previous parity bit (kind 7: a conflict-free layer; the plan refuses codes whose layer 0 has shared bits) --
 // a kind of its own, so that the other 44 layers of a sweep do not carry the test (r05: 7 vector instructions per wave and layer)
 template <int MAXDEG, int LATE, int NOPREV = 0>     // NOPREV 2: asked at run time (A/B builds, -DLDPC_SPLIT_NOPREV_RT)
@@ -159,16 +159,9 @@ __device__ __forceinline__ void row_input(RowState<MAXDEG>& R, const uint32_t la
             v[hh] = me ? (short)(127 << 8) : v[hh];
             g[hh] = me ? (short)(126 << 8) : g[hh];
         }
-        if constexpr (LATE > 0) {
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int k = 2 * p + hh;
-                if (k < LATE && ((late >> k) & 1)) { v[hh] = (short)(127 << 8); g[hh] = (short)(126 << 8); }   // joins the totals in the middle section; until then: neutral
-            }
-        }
         R.V[p] = v; R.G[p] = g;
-        if constexpr (LATE == -1) {
-            if (p == 0) { v = late ? splat2(127 << 8) : v; g = late ? splat2(126 << 8) : g; }      // (the neutral link)
+        if constexpr (LATE < 0) {
+            if (p < -LATE) { v = late ? splat2(127 << 8) : v; g = late ? splat2(126 << 8) : g; }      // (the neutral link)
         }
         if (p == 0) { MIN0 = g; }
         else if (p == 1) { MIN1 = pmax2(MIN0, g); MIN0 = pmin2(MIN0, g); }
@@ -382,158 +375,113 @@ __device__ __forceinline__ LdpcSplitLayer layer_at(const_layer_ptr layers, int i
     L.kind_nw = layers[i].kind_nw; L.aux = layers[i].aux; L.rec_off = layers[i].rec_off; L.ent_off = layers[i].ent_off;
     return L;
 }
-#ifndef LDPC_SPLIT_CONFLICT_INLINE
-#define LDPC_SPLIT_CONFLICT_INLINE __forceinline__
-#endif
-template <int MAXDEG, int KIND>
-__device__ LDPC_SPLIT_CONFLICT_INLINE void conflict_layer(RowState<MAXDEG>& R, uint32_t (&rec_out)[SplitShape<MAXDEG>::REC],
-                                               const LdpcSplitLayer L, const_u32_ptr ents, const_u32_ptr walk, const int t,
-                                               int8_t* __restrict__ post, uint32_t* __restrict__ cw, uint8_t* __restrict__ cres) {
-    using S = SplitShape<MAXDEG>;
-    constexpr int MAXC = 4 < S::HS ? 4 : S::HS;
-    const uint32_t rw = R.rw;
-    const uint32_t level = rw & 0xffu, late = (rw >> 8) & 15u, early = rw >> 12;
-    const int nc = (int)((L.kind_nw >> 16) & 15u);
+// A layer whose shared links are two pairs or a triple (slots 0..3 of half 0 cover them), levels = runs of W <= 64 consecutive rows (ldpc_split_plan.h; rate 3/4:
+// layers 3, 5, 42 with 6, 12 and 33 levels): the LEVEL WALK.  Round 5 ran these as a workgroup barrier per level (~1 050 cycles per level) or as ldpc_kernel.hip's quad
+// walk (four lanes per row, 640 cycles per step); together 21 % of a sweep for 3 of its 45 layers.  Here ONE wave walks the levels in order, lane = row of the level, and
+// treats the four slots UNIFORMLY -- no late / early flags anywhere:
+//   phase A  every row: the input phase; rows of level > 1 keep their first two pairs (slots 0..3) out of the totals and leave a record {the four slots' old messages,
+//            min0 | sign of the other ten links}.  Rows of level 1 (no predecessor in the layer) finish here, early slots included.
+//   walk     wave 0, step k = level k + 1, lane i = row W k + i: the four slots' posteriors as they stand NOW (a slot nobody has touched in this layer still holds what
+//            phase A read: recomputing its input gives the same value), inputs, magnitudes, for every slot the minimum over the other three and the record's min0,
+//            new messages, new posteriors -- packed, two slots per instruction -- written back at once: the next level reads them (the LDS pipeline is in order; a row's
+//            later toucher simply overwrites).  The four inputs go back into the record for phase C.
+//   phase C  rows of level > 1: the four inputs from the record join the totals (as the chain layer's pair does), then the output phase, which leaves slots 0..3 of half 0
+//            to the walker's stores.
+// Bit-exact by construction: every value is the reference's for the row order (layered_decoder.hh:46-74) -- a row reads a shared bit after exactly the rows before it.
+template <int MAXDEG>
+__device__ __forceinline__ void level_layer(RowState<MAXDEG>& R, uint32_t (&rec_out)[SplitShape<MAXDEG>::REC], const LdpcSplitLayer L, const_u32_ptr ents, const int t,
+                                            uint32_t* __restrict__ cw) {
+    static_assert(SplitShape<MAXDEG>::HS >= 4, "the level walk covers slots 0..3 of half 0");
+    const uint32_t level = R.rw & 0xffu;               // (both halves carry it; idle lanes: 0)
     const int j = t >> 1;
+    const bool half1 = (t & 1) != 0;
+    const int W = (int)(L.aux & 0xffffu), depth = (int)(L.aux >> 16);
     int M0, M1, SXs;
-    SPLIT_MARK_DECL;
-    row_input<MAXDEG, MAXC>(R, late, 1u, t, M0, M1, SXs);
-    int min0 = M0 >> 24, min1 = M1 >> 24, sx = SXs;                 // (sx: the sign of the row's product sits in bit 31)
-    SPLIT_MARK(0);
-    if constexpr (KIND == 6) {
-        // ---- quad walk (ldpc_kernel.hip, ldpc_plan.h).  Rows of level 1 publish their early links; every other row of half 0 leaves a hand-off record in cw[]: {min0,
-        // min1, sign of the totals so far, late mask, early mask} and one byte per shared link (its old message if the link is late, else its input value)
-        constexpr int CWD = 2;
-        const uint32_t whd = walk[0];
-        const int wk_steps = (int)(whd & 0xffffu);
-        if (level == 1u) {
-#pragma unroll
-            for (int k = 0; k < MAXC; ++k) {
-                if ((early >> k) & 1) {
-                    int nm = new_msg(LINK_IN(k), LINK_MG(k), min0, min1, sx);
-                    LDS_I8(R.addr[k]) = (int8_t)clamp8(LINK_IN(k) + nm);
-                }
-            }
-        } else if (level != 0u) {
-            uint32_t lb = 0;
-#pragma unroll
-            for (int k = 0; k < MAXC; ++k) {
-                const int b = ((late >> k) & 1) ? R.msg(k) : LINK_IN(k);
-                lb |= ((uint32_t)b & 0xffu) << (8 * k);
-            }
-            const uint32_t hd = (uint32_t)min(min0, 127) | ((uint32_t)min(min1, 127) << 7) | (((uint32_t)sx >> 31) << 14) | ((late & 0xffu) << 15) | ((early & 0xffu) << 23);
-            cw[CWD * j] = hd;
-            cw[CWD * j + 1] = lb;
-        }
-        lds_barrier();
-        if (t < 64) {
-            __builtin_amdgcn_s_setprio(3);
-            const int k = t & 3, qd = t >> 2;
-            const uint32_t ek = ents[k < nc ? k : 0];
-            const int spk = (int)(ek & 0xffffu);
-            const uint32_t basek = 360u * (ek >> 16);                       // (the posteriors start at LDS offset 0)
-            const uint32_t scratch = lds_offset(reinterpret_cast<const int8_t*>(cres)) + (uint32_t)t;
-            const uint32_t cwb = lds_offset(reinterpret_cast<const int8_t*>(cw));
-            const const_u32_ptr list = walk + 1 + qd;
-            auto step = [&](const uint32_t e) {
-                const bool valid = e != 0xffffffffu && k < nc;
-                const int row = valid ? (int)e : 0;
-                const uint32_t ra = cwb + (uint32_t)(4 * CWD) * (uint32_t)row;
-                const uint2 r = reinterpret_cast<const uint2*>(cw)[row];
-                const uint32_t hd = r.x;
-                const int b = (int)__builtin_amdgcn_sbfe((int)r.y, 8 * k, 8);
-                int tt = row + spk;
-                tt = (int)min((uint32_t)tt, (uint32_t)(tt - 360));
-                const uint32_t a = basek + (uint32_t)tt;
-                const int x = (int)LDS_I8(a);
-                const bool lt = valid && ((hd >> (15 + k)) & 1u), er = valid && ((hd >> (23 + k)) & 1u);
-                const int v = lt ? clamp8(x - b) : b;
-                const int g = mag_of(v);
-                int m0 = lt ? g : 255, m1 = 255, sg = lt ? v : 0;
-#define JOIN(ctrl) do { const int o0 = QUAD_DPP(m0, ctrl), o1 = QUAD_DPP(m1, ctrl); m1 = min(max(m0, o0), min(m1, o1)); m0 = min(m0, o0); sg ^= QUAD_DPP(sg, ctrl); } while (0)
-                JOIN(0xB1);                                                              // quad_perm [1,0,3,2]
-                JOIN(0x4E);                                                              // quad_perm [2,3,0,1]
-#undef JOIN
-                const int q0 = (int)(hd & 0x7fu), q1 = (int)((hd >> 7) & 0x7fu);
-                const int t1 = min(max(m0, q0), min(m1, q1)), t0 = min(m0, q0);
-                const int ss = sg ^ (int)(hd << 17);                                     // bit 31 = sign of the row's totals
-                const int nm = new_msg(v, g, t0, t1, ss);
-                LDS_I8(er ? a : scratch) = (int8_t)clamp8(v + nm);
-                LDS_I8(valid ? ra + 4u + (uint32_t)k : scratch) = (int8_t)v;
-            };
-            // (the step list is fetched two steps ahead, by hand: the compiler sinks such a fetch to its use and then waits for it)
-#define LIST_FETCH(r, p) asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory")
-#define LIST_READY(r) asm volatile("s_waitcnt vmcnt(1)" : "+v"(r) : : "memory")
-            uint32_t eA, eB;
-            const_u32_ptr lp = list;
-            LIST_FETCH(eA, lp); LIST_FETCH(eB, lp + 16);
-            lp += 32;
-            for (int i = 0; i < wk_steps; i += 2) {
-                LIST_READY(eA);
-                step(eA);
-                LIST_FETCH(eA, lp);
-                LIST_READY(eB);
-                if (i + 1 < wk_steps) step(eB);
-                LIST_FETCH(eB, lp + 16);
-                lp += 32;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#undef LIST_FETCH
-#undef LIST_READY
-            __builtin_amdgcn_s_setprio(0);
-        }
-        lds_barrier();
-        if (level > 1u) {
-            const uint32_t lb = cw[CWD * j + 1];
-#pragma unroll
-            for (int k = 0; k < MAXC; ++k) {
-                if ((late >> k) & 1) {
-                    int v = (int)__builtin_amdgcn_sbfe((int)lb, 8 * k, 8);
-                    int m = mag_of(v);
-                    LINK_SET(k, v, m);
-                    ROW_ACCUM(v, m);
-                }
-            }
-        }
-    } else {
-        // ---- levels: a barrier per dependency level (ldpc_kernel.hip, KIND 3)
-        const int depth = (int)L.aux;
-        for (int lvl = 1; lvl <= depth; ++lvl) {
-            if (lvl > 1) lds_barrier();
-            if (level == (uint32_t)lvl) {
-                __builtin_amdgcn_s_setprio(3);
-                if (lvl > 1) {
-                    int xs[MAXC];
-#pragma unroll
-                    for (int k = 0; k < MAXC; ++k) xs[k] = (int)LDS_I8(R.addr[k]);
-#pragma unroll
-                    for (int k = 0; k < MAXC; ++k) {
-                        if ((late >> k) & 1) {
-                            int v = clamp8(xs[k] - R.msg(k));
-                            int m = mag_of(v);
-                            LINK_SET(k, v, m);
-                            ROW_ACCUM(v, m);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < MAXC; ++k) {
-                    if ((early >> k) & 1) {
-                        int nm = new_msg(LINK_IN(k), LINK_MG(k), min0, min1, sx);
-                        LDS_I8(R.addr[k]) = (int8_t)clamp8(LINK_IN(k) + nm);
-                    }
-                }
-                __builtin_amdgcn_s_setprio(0);
-            }
-        }
+    row_input<MAXDEG, -2>(R, (level > 1u && !half1) ? 1u : 0u, 1u, t, M0, M1, SXs);
+    if (level == 1u) row_output<MAXDEG, 0>(R, M0, M1, SXs, 0u, rec_out);
+    if (level > 1u && !half1) {
+        // {m0 m1 m2 m3} | {min0 of the other links (byte 0), their sign product in bits 15 and 31}
+        const uint32_t mb = __builtin_amdgcn_perm(bits2(R.RP[1]), bits2(R.RP[0]), 0x07050301u);
+        reinterpret_cast<uint2*>(cw)[j] = make_uint2(mb, ((uint32_t)M0 >> 24) | ((uint32_t)SXs & 0x80008000u));
     }
-    SPLIT_MARK(5);
-    // the complete totals sit in half 0: hand them to half 1, both halves of a word equal again
-    min0 = QUAD_DPP(min0, DPP_FROM_HALF0);
-    min1 = QUAD_DPP(min1, DPP_FROM_HALF0);
-    sx = QUAD_DPP(sx, DPP_FROM_HALF0);
-    row_output<MAXDEG, MAXC>(R, (int)bits2(q8(min0)), (int)bits2(q8(min1)), sx >> 31, early, rec_out);
-    SPLIT_MARK(6);
+    lds_pairs_wait();
+    lds_barrier();
+    uint32_t cwb = lds_offset(reinterpret_cast<const int8_t*>(cw));
+    asm volatile("" : "+s"(cwb));
+    if (t < 64) {
+        __builtin_amdgcn_s_setprio(3);
+        // slot k of row r: byte 360 group_k + (r + sp_k) mod 360 (ldpc_plan.h link entries; slots 0..3 of half 0 are table links 0..3)
+        uint32_t tt[4], base[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t e = ents[k];
+            base[k] = 360u * (e >> 16);
+            tt[k] = (uint32_t)t + (e & 0xffffu);             // row of step 0 (level 1) = lane; advanced by W per step below
+            tt[k] = min(tt[k], tt[k] - 360u);
+        }
+        int row = t;
+        u32x2 rec = LDS_U2(cwb + 8u * (uint32_t)min(t + W, 359));
+        for (int k = 1; k < depth; ++k) {
+            row += W;
+            uint32_t a[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { tt[q] += (uint32_t)W; tt[q] = min(tt[q], tt[q] - 360u); a[q] = base[q] + tt[q]; }
+            const u32x2 r = rec;
+            rec = LDS_U2(cwb + 8u * (uint32_t)min(row + W, 359));          // the next level's record (written in phase A: no dependence on this step)
+            if (t < W && row < 360) {
+                uint32_t xr0, xh0, xr1, xh1;
+                lds_read_pair_i8(a[0], a[1], xr0, xh0);
+                lds_read_pair_i8(a[2], a[3], xr1, xh1);
+                const s16x2 RM0 = rec_pair_dw(r.x, 0), RM1 = rec_pair_dw(r.x, 2);
+                const s16x2 Q0 = from_bits2(__builtin_amdgcn_perm(0u, r.y, 0x000c000cu));          // min0 of the other links in both halves (Q8)
+                lds_ready_n(0, xr0, xh0);
+                asm volatile("" : "+v"(xr1), "+v"(xh1));
+                const s16x2 V0 = sat_sub2(from_bits2(__builtin_amdgcn_perm(xh0, xr0, 0x060c000cu)), RM0);
+                const s16x2 V1 = sat_sub2(from_bits2(__builtin_amdgcn_perm(xh1, xr1, 0x060c000cu)), RM1);
+                const s16x2 G0 = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, pmax2(V0, sat_sub2(splat2(0), V0))), (u16x2){256, 256}));
+                const s16x2 G1 = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, pmax2(V1, sat_sub2(splat2(0), V1))), (u16x2){256, 256}));
+                // for every slot the smallest magnitude among the row's OTHER links: the other slot of its pair, both slots of the other pair, min0 of the rest; limited to 32
+                const s16x2 P0 = pmin2(G0, swap2(G0)), P1 = pmin2(G1, swap2(G1));
+                const s16x2 C32 = splat2(32 << 8);
+                const s16x2 O0 = pmin2(pmin2(swap2(G0), P1), pmin2(Q0, C32)), O1 = pmin2(pmin2(swap2(G1), P0), pmin2(Q0, C32));
+                // sign of the row: the record's product times the four slots' (bits 15 and 31 after the fold)
+                uint32_t sx = bits2(V0) ^ bits2(V1);
+                sx ^= __builtin_amdgcn_alignbit(sx, sx, 16);
+                sx ^= r.y;
+                const s16x2 N0 = from_bits2(sx ^ bits2(V0)) >> 15, N1 = from_bits2(sx ^ bits2(V1)) >> 15;
+                const s16x2 NM0 = pmin2(from_bits2(bits2(O0) ^ bits2(N0)) - N0, q8(31)), NM1 = pmin2(from_bits2(bits2(O1) ^ bits2(N1)) - N1, q8(31));
+                const uint32_t pn0 = bits2(sat_add2(V0, NM0)) >> 8, pn1 = bits2(sat_add2(V1, NM1)) >> 8;
+                lds_write_lo_i8(a[0], pn0); lds_write_hi_i8(a[1], pn0);
+                lds_write_lo_i8(a[2], pn1); lds_write_hi_i8(a[3], pn1);
+                // the four inputs, for the row's phase C
+                *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)(cwb + 8u * (uint32_t)row) = __builtin_amdgcn_perm(bits2(V1), bits2(V0), 0x07050301u);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+    lds_pairs_wait();
+    lds_barrier();
+    if (level > 1u) {
+        if (!half1) {
+            const uint32_t vb = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(cwb + 8u * (uint32_t)j);
+            R.V[0] = rec_pair_dw(vb, 0); R.V[1] = rec_pair_dw(vb, 2);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                R.G[p] = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, pmax2(R.V[p], sat_sub2(splat2(0), R.V[p]))), (u16x2){256, 256}));
+                // the pair joins the totals: its smaller magnitude first, then the larger one (words with equal halves: 32-bit operations)
+                const int a = (int)bits2(pmin2(R.G[p], swap2(R.G[p]))), b = (int)bits2(pmax2(R.G[p], swap2(R.G[p])));
+                M1 = min(M1, max(M0, a));
+                M0 = min(M0, a);
+                M1 = min(M1, max(M0, b));
+            }
+            const uint32_t sv = bits2(R.V[0]) ^ bits2(R.V[1]);
+            SXs ^= (int)(sv ^ __builtin_amdgcn_alignbit(sv, sv, 16));
+        }
+        M0 = QUAD_DPP(M0, DPP_FROM_HALF0);
+        M1 = QUAD_DPP(M1, DPP_FROM_HALF0);
+        SXs = QUAD_DPP(SXs, DPP_FROM_HALF0);
+        row_output<MAXDEG, 4>(R, M0, M1, SXs, half1 ? 0u : 15u, rec_out);          // (slots 0..3 of half 0: the walker has written them)
+    }
 }
 #undef LINK_IN
 #undef LINK_MG
@@ -586,7 +534,6 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
             // store to global memory -- issues a vector load, and the vmcnt(0) in front of its first use also waits for the table words just requested for the next pseudo-layer)
             const const_layer_ptr layers = (const_layer_ptr)P->layers;
             const const_u32_ptr ents = (const_u32_ptr)P->ents;
-            const const_u32_ptr rows = (const_u32_ptr)P->rows;
             const int npad = (N + LDPC_SPLIT_SCRATCH + 15) & ~15;                // posteriors + the scratch bytes (ldpc_split_plan.h)
             uint32_t* __restrict__ cw = reinterpret_cast<uint32_t*>(lds_all + npad);      // hand-off records of the chain walk: 8 bytes per row
             uint8_t* __restrict__ cres = reinterpret_cast<uint8_t*>(cw + 2 * 360);
@@ -684,10 +631,8 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                     row_output<MAXDEG, 0>(RS, M0, M1, SXs, 0u, ro);
                 } else if ((L.kind_nw & 0xffu) == 1) {
                     chain_layer<MAXDEG>(RS, ro, L, ents[L.ent_off + 1], tt, post, cw, cres);
-                } else if ((L.kind_nw & 0xffu) == 6) {
-                    conflict_layer<MAXDEG, 6>(RS, ro, L, ents + L.ent_off, rows + L.aux, tt, post, cw, cres);
                 } else {
-                    conflict_layer<MAXDEG, 3>(RS, ro, L, ents + L.ent_off, ents, tt, post, cw, cres);
+                    level_layer<MAXDEG>(RS, ro, L, ents + L.ent_off, tt, cw);
                 }
                 // the next pseudo-layer's words are claimed HERE, before this one's record store is issued: the wait for them then sits where they have had a whole
                 // pseudo-layer to arrive, and the top of the next pseudo-layer waits for nothing (ldpc_kernel.hip)

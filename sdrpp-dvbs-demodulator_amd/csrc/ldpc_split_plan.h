@@ -9,9 +9,10 @@
 //   * a sweep is a list of PSEUDO-LAYERS, each ending in a workgroup barrier, one per layer of the code, all twelve waves at work in every one of them.  Everything a
 //     thread needs for one -- the LDS byte offsets of its slots, parity bits included, and its row word -- comes from a per-thread table entry:
 //       kind 0 (row update): a conflict-free layer, one row per lane pair, rows in lane order; kind 7: the same for layer 0, whose row 0 has no previous parity bit.
-//       kinds 1 / 3 / 6 (chain walk / levels / quad walk): a layer with shared bits keeps ldpc_kernel.hip's forms: all rows at once in lane order, the shared links
-//           (they all sit in half 0) resolved in a middle section -- chains walked by a few lanes through per-row hand-off records (~135 cycles per chained row), four
-//           lanes per row of a deep narrow level structure, or a barrier per level.
+//       kinds 1 / 5 (chain walk / level walk): a layer with shared bits: all rows at once in lane order, the shared links (they all sit in half 0) resolved in a middle
+//           section by ONE wave -- a single shared pair: chains walked by d lanes through per-row hand-off records (ldpc_kernel.hip's chain walk); two pairs or a triple:
+//           the levels walked in order, lane = row of the level (ldpc_split_kernel.hip: level_layer; round 5 ran these as ldpc_kernel.hip's barrier-per-level and
+//           quad-walk forms, kinds 3 / 6).
 //     Round 5 also carried two alternatives for the layers with shared bits -- one packed conflict-free pseudo-layer per dependency level, and level PASSES under the lanes'
 //     level mask -- as context options; both measured slower at every depth (rate 3/4, 4096 frames x 50 iterations: every chain layer walked 39.6 ms, chain layers of up to
 //     5 levels as passes 41.9, layers of up to 3 levels packed 42.5: a barrier-separated pass costs ~1 000 cycles whatever it does, a packed level ~1 750, a walked row
@@ -32,7 +33,7 @@ constexpr int LDPC_SPLIT_SCRATCH = 64;         // scratch bytes behind the poste
 
 struct LdpcSplitLayer {   // 16 bytes = one s_load_dwordx4
     uint32_t kind_nw;     // bits 0..7 kind, 8..15 waves (always 12), 16..19 nc = shared links of the layer (slots 0..nc-1 of half 0), bit 20: holds row 0 of layer 0 (no previous parity bit)
-    uint32_t aux;         // kind 7: the half-1 thread of row 0 of layer 0 (bit 20); kind 1: chain step d | (359 / d) << 16; kind 3: levels; kind 6: index of the walk list in LdpcPlan::rows
+    uint32_t aux;         // kind 7: the half-1 thread of row 0 of layer 0 (bit 20); kind 1: chain step d | (359 / d) << 16; kind 5: rows per level W | levels << 16
     uint32_t rec_off;     // dword offset of the pseudo-layer's records inside a workgroup's message workspace
     uint32_t ent_off;     // kind 1: index of the layer's link entries in LdpcPlan::ents (the walker reads link 1's)
 };
@@ -109,8 +110,8 @@ inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P) {
                 w[s >> 1] |= a << (16 * (s & 1));
             }
             if (j >= 0 && h == 0) S.row_of[rbase + pr] = j;
-            // the row word: kinds 3 / 6 in half 0 only (half 1 and idle lanes: 0, every condition on it false); kind 1: half 1 gets the level
-            if (j >= 0 && info && (h == 0 || kind == 1)) w[hs >> 1] |= ((*info)[pr] & (h == 1 ? 0xffu : 0xffffu)) << (16 * (hs & 1));
+            // the row word (idle lanes: 0, every condition on it false); half 1 gets the level alone
+            if (j >= 0 && info && (h == 0 || kind == 1 || kind == 5)) w[hs >> 1] |= ((*info)[pr] & (h == 1 ? 0xffu : 0xffffu)) << (16 * (hs & 1));
         }
         S.layers.push_back(D);
         S.layer_of.push_back(i);
@@ -130,9 +131,16 @@ inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P) {
                 rows.push_back(j);
                 info.push_back((rw & 0xffu) | (((rw >> 8) & 15u) << 8) | (((rw >> 20) & 15u) << 12));
             }
-            if (chain == LDPC_WALK_MARK) emit(6, i, rows, &info, L.row_off + 360);
-            else if (chain != 0) emit(1, i, rows, &info, chain | ((359u / chain) << 16));
-            else emit(3, i, rows, &info, (uint32_t)depth);
+            if (chain != 0 && chain != LDPC_WALK_MARK) emit(1, i, rows, &info, chain | ((359u / chain) << 16));
+            else {
+                // the level walk: levels must be runs of W <= 64 consecutive rows (level of row j = j / W + 1)
+                int W = 0;
+                while (W < 360 && (info[W] & 0xffu) == 1u) ++W;
+                bool runs = W >= 1 && W <= 64;
+                for (int j = 0; runs && j < 360; ++j) runs = (int)(info[j] & 0xffu) == j / W + 1;
+                if (!runs) return LdpcSplitPlan();
+                emit(5, i, rows, &info, (uint32_t)W | ((uint32_t)depth << 16));
+            }
             S.chain_layers++;
         }
     }

@@ -315,7 +315,7 @@ def test_ldpc_address_table_holds_the_links_of_every_row(pkg, rate, short):
 def test_ldpc_split_plan_keeps_the_reference_row_order(pkg, rate, short):
     """the half-row decoder's plan (csrc/ldpc_split_plan.h): every row of every layer appears
     exactly once, its table entry names exactly the bits the reference's row touches (information bits, own and previous parity bit), and two rows of a layer that
-    share a bit run in the reference's order -- separated by a barrier (different pseudo-layers) unless the pseudo-layer resolves shared links itself (kinds 1, 3, 6,
+    share a bit run in the reference's order -- separated by a barrier (different pseudo-layers) unless the pseudo-layer resolves shared links itself (kinds 1, 5,
     whose row words are the lane-per-row plan's, checked above); every pseudo-layer runs all twelve waves"""
     sp = pkg.ldpc_split_plan(rate, short)
     p = orc.fec_params(rate, short)
@@ -365,7 +365,7 @@ def test_ldpc_split_plan_keeps_the_reference_row_order(pkg, rate, short):
                 within.setdefault(b, []).append(j)
         for b, js in within.items():
             if len(js) > 1:                                                          # rows of ONE pseudo-layer share a bit: only where it orders shared links itself
-                assert kind in (1, 3, 6), (pl, i, js)
+                assert kind in (1, 5), (pl, i, js)
         for j, bits in rows_here:
             for b in bits: last_touch[b] = (i, j)
     assert (seen == 1).all()
