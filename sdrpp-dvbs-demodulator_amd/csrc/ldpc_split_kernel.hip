@@ -45,6 +45,7 @@ struct SplitShape {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+constexpr int LDPC_SPLIT_CW_DWORDS = 4 * 360;        // the hand-off record area behind the posteriors: 16 bytes per row
 
 __device__ __forceinline__ void lds_read_lo_i8(uint32_t a_lo, uint32_t& r_lo) {
     if (LDPC_EXP & 4) { r_lo = a_lo & 0xffu; return; }
@@ -269,7 +270,7 @@ typedef __attribute__((address_space(3))) u32x2 lds_u2;
 //            the totals with packed operations, handed to half 1, then the output phase -- which leaves out the early slots: a later row's L link owns that bit's final value.
 template <int MAXDEG>
 __device__ __forceinline__ void chain_layer(RowState<MAXDEG>& R, uint32_t (&rec_out)[SplitShape<MAXDEG>::REC],
-                                            const LdpcSplitLayer L, const uint32_t eL, const int t, int8_t* __restrict__ post, uint32_t* __restrict__ cw, uint8_t* __restrict__ cres) {
+                                            const LdpcSplitLayer L, const uint32_t eL, const int t, int8_t* __restrict__ post, uint32_t* __restrict__ cw) {
     [[maybe_unused]] constexpr int KIND = 1;
     const uint32_t rw = R.rw;
     const uint32_t level = rw & 0xffu, late = (rw >> 8) & 3u, early = (rw >> 12) & 3u;
@@ -400,9 +401,11 @@ __device__ __forceinline__ void level_layer(RowState<MAXDEG>& R, uint32_t (&rec_
     row_input<MAXDEG, -2>(R, (level > 1u && !half1) ? 1u : 0u, 1u, t, M0, M1, SXs);
     if (level == 1u) row_output<MAXDEG, 0>(R, M0, M1, SXs, 0u, rec_out);
     if (level > 1u && !half1) {
-        // {m0 m1 m2 m3} | {min0 of the other links (byte 0), their sign product in bits 15 and 31}
+        // {m0 m1 m2 m3} | {min(min0 of the other links, 32) in both halves (Q8), their sign product in bits 15 and 31} | the four slots' LDS addresses: the walker, whose every
+        // instruction is serial time of the workgroup (~10 cycles each beside the other workgroup's waves), only takes them apart
         const uint32_t mb = __builtin_amdgcn_perm(bits2(R.RP[1]), bits2(R.RP[0]), 0x07050301u);
-        reinterpret_cast<uint2*>(cw)[j] = make_uint2(mb, ((uint32_t)M0 >> 24) | ((uint32_t)SXs & 0x80008000u));
+        const uint32_t qs = (uint32_t)min(M0, 0x20002000) | ((uint32_t)SXs & 0x80008000u);
+        *reinterpret_cast<u32x4*>(cw + 4 * j) = u32x4{mb, qs, R.addr[0] | (R.addr[1] << 16), R.addr[2] | (R.addr[3] << 16)};
     }
     lds_pairs_wait();
     lds_barrier();
@@ -410,52 +413,45 @@ __device__ __forceinline__ void level_layer(RowState<MAXDEG>& R, uint32_t (&rec_
     asm volatile("" : "+s"(cwb));
     if (t < 64) {
         __builtin_amdgcn_s_setprio(3);
-        // slot k of row r: byte 360 group_k + (r + sp_k) mod 360 (ldpc_plan.h link entries; slots 0..3 of half 0 are table links 0..3)
-        uint32_t tt[4], base[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t e = ents[k];
-            base[k] = 360u * (e >> 16);
-            tt[k] = (uint32_t)t + (e & 0xffffu);             // row of step 0 (level 1) = lane; advanced by W per step below
-            tt[k] = min(tt[k], tt[k] - 360u);
-        }
-        int row = t;
-        u32x2 rec = LDS_U2(cwb + 8u * (uint32_t)min(t + W, 359));
+        typedef __attribute__((address_space(3))) u32x4 lds_u4;
+        uint32_t pr = cwb + 16u * (uint32_t)(t + W);          // record of the lane's row of the level in hand; a level's last rows may lie past row 359: such a read lands
+        const uint32_t pstep = 16u * (uint32_t)W;             // in LDS the workgroup owns (or beyond, where it returns zeros) and its lane is masked
+        u32x4 rec = *(const lds_u4*)(uintptr_t)pr;
+        int row = t + W;
         for (int k = 1; k < depth; ++k) {
-            row += W;
-            uint32_t a[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { tt[q] += (uint32_t)W; tt[q] = min(tt[q], tt[q] - 360u); a[q] = base[q] + tt[q]; }
-            const u32x2 r = rec;
-            rec = LDS_U2(cwb + 8u * (uint32_t)min(row + W, 359));          // the next level's record (written in phase A: no dependence on this step)
+            const u32x4 r = rec;
+            const uint32_t prn = pr + pstep;
+            rec = *(const lds_u4*)(uintptr_t)prn;              // the next level's record (written in phase A: no dependence on this step)
             if (t < W && row < 360) {
+                const uint32_t a0 = r.z & 0xffffu, a1 = r.z >> 16, a2 = r.w & 0xffffu, a3 = r.w >> 16;
                 uint32_t xr0, xh0, xr1, xh1;
-                lds_read_pair_i8(a[0], a[1], xr0, xh0);
-                lds_read_pair_i8(a[2], a[3], xr1, xh1);
+                lds_read_pair_i8(a0, a1, xr0, xh0);
+                lds_read_pair_i8(a2, a3, xr1, xh1);
                 const s16x2 RM0 = rec_pair_dw(r.x, 0), RM1 = rec_pair_dw(r.x, 2);
-                const s16x2 Q0 = from_bits2(__builtin_amdgcn_perm(0u, r.y, 0x000c000cu));          // min0 of the other links in both halves (Q8)
+                const s16x2 Q0 = from_bits2(r.y & 0x7fff7fffu);          // min(min0 of the other links, 32) in both halves (Q8)
                 lds_ready_n(0, xr0, xh0);
                 asm volatile("" : "+v"(xr1), "+v"(xh1));
                 const s16x2 V0 = sat_sub2(from_bits2(__builtin_amdgcn_perm(xh0, xr0, 0x060c000cu)), RM0);
                 const s16x2 V1 = sat_sub2(from_bits2(__builtin_amdgcn_perm(xh1, xr1, 0x060c000cu)), RM1);
                 const s16x2 G0 = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, pmax2(V0, sat_sub2(splat2(0), V0))), (u16x2){256, 256}));
                 const s16x2 G1 = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, pmax2(V1, sat_sub2(splat2(0), V1))), (u16x2){256, 256}));
-                // for every slot the smallest magnitude among the row's OTHER links: the other slot of its pair, both slots of the other pair, min0 of the rest; limited to 32
+                // for every slot the smallest magnitude among the row's OTHER links: the other slot of its pair, both slots of the other pair, min0 of the rest (limited to 32)
                 const s16x2 P0 = pmin2(G0, swap2(G0)), P1 = pmin2(G1, swap2(G1));
-                const s16x2 C32 = splat2(32 << 8);
-                const s16x2 O0 = pmin2(pmin2(swap2(G0), P1), pmin2(Q0, C32)), O1 = pmin2(pmin2(swap2(G1), P0), pmin2(Q0, C32));
-                // sign of the row: the record's product times the four slots' (bits 15 and 31 after the fold)
+                const s16x2 O0 = pmin2(pmin2(swap2(G0), P1), Q0), O1 = pmin2(pmin2(swap2(G1), P0), Q0);
+                // sign of the row: the record's product times the four slots' (bits 15 and 31 after the fold; the record word's other bits ride along unused)
                 uint32_t sx = bits2(V0) ^ bits2(V1);
                 sx ^= __builtin_amdgcn_alignbit(sx, sx, 16);
                 sx ^= r.y;
                 const s16x2 N0 = from_bits2(sx ^ bits2(V0)) >> 15, N1 = from_bits2(sx ^ bits2(V1)) >> 15;
                 const s16x2 NM0 = pmin2(from_bits2(bits2(O0) ^ bits2(N0)) - N0, q8(31)), NM1 = pmin2(from_bits2(bits2(O1) ^ bits2(N1)) - N1, q8(31));
                 const uint32_t pn0 = bits2(sat_add2(V0, NM0)) >> 8, pn1 = bits2(sat_add2(V1, NM1)) >> 8;
-                lds_write_lo_i8(a[0], pn0); lds_write_hi_i8(a[1], pn0);
-                lds_write_lo_i8(a[2], pn1); lds_write_hi_i8(a[3], pn1);
+                lds_write_lo_i8(a0, pn0); lds_write_hi_i8(a1, pn0);
+                lds_write_lo_i8(a2, pn1); lds_write_hi_i8(a3, pn1);
                 // the four inputs, for the row's phase C
-                *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)(cwb + 8u * (uint32_t)row) = __builtin_amdgcn_perm(bits2(V1), bits2(V0), 0x07050301u);
+                *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)pr = __builtin_amdgcn_perm(bits2(V1), bits2(V0), 0x07050301u);
             }
+            pr = prn;
+            row += W;
         }
         __builtin_amdgcn_s_setprio(0);
     }
@@ -463,7 +459,7 @@ __device__ __forceinline__ void level_layer(RowState<MAXDEG>& R, uint32_t (&rec_
     lds_barrier();
     if (level > 1u) {
         if (!half1) {
-            const uint32_t vb = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(cwb + 8u * (uint32_t)j);
+            const uint32_t vb = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(cwb + 16u * (uint32_t)j);
             R.V[0] = rec_pair_dw(vb, 0); R.V[1] = rec_pair_dw(vb, 2);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
@@ -535,9 +531,8 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
             const const_layer_ptr layers = (const_layer_ptr)P->layers;
             const const_u32_ptr ents = (const_u32_ptr)P->ents;
             const int npad = (N + LDPC_SPLIT_SCRATCH + 15) & ~15;                // posteriors + the scratch bytes (ldpc_split_plan.h)
-            uint32_t* __restrict__ cw = reinterpret_cast<uint32_t*>(lds_all + npad);      // hand-off records of the chain walk: 8 bytes per row
-            uint8_t* __restrict__ cres = reinterpret_cast<uint8_t*>(cw + 2 * 360);
-            int* __restrict__ s_flag = reinterpret_cast<int*>(cres + 384);                // [12] + next frame
+            uint32_t* __restrict__ cw = reinterpret_cast<uint32_t*>(lds_all + npad);      // hand-off records: 8 bytes per row (chain walk) / 16 (level walk)
+            int* __restrict__ s_flag = reinterpret_cast<int*>(cw + LDPC_SPLIT_CW_DWORDS);                // [12] + next frame
             uint32_t* __restrict__ msg = A.msg_ws + (size_t)blockIdx.x * (size_t)A.pent_base;
             uint32_t* __restrict__ sgn = A.sgn_ws + (size_t)blockIdx.x * SGN_WS_DWORDS;
             const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(P->atab), 0, npl * (T * NPW * 4), 0x00020000);
@@ -630,7 +625,7 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                     row_input<MAXDEG, 0, 1>(RS, 0u, L.aux, tt, M0, M1, SXs);
                     row_output<MAXDEG, 0>(RS, M0, M1, SXs, 0u, ro);
                 } else if ((L.kind_nw & 0xffu) == 1) {
-                    chain_layer<MAXDEG>(RS, ro, L, ents[L.ent_off + 1], tt, post, cw, cres);
+                    chain_layer<MAXDEG>(RS, ro, L, ents[L.ent_off + 1], tt, post, cw);
                 } else {
                     level_layer<MAXDEG>(RS, ro, L, ents + L.ent_off, tt, cw);
                 }
@@ -659,7 +654,7 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
             const LdpcKernelParamsPtr P = ldpc_params();
             const LdpcKernelArgs A = ldpc_args(P);
             const int N = A.N, K = A.K, R = A.R, q = A.q;
-            int* __restrict__ s_flag = reinterpret_cast<int*>(lds_all + ((N + LDPC_SPLIT_SCRATCH + 15) & ~15) + 2 * 360 * 4 + 384);
+            int* __restrict__ s_flag = reinterpret_cast<int*>(lds_all + ((N + LDPC_SPLIT_SCRATCH + 15) & ~15) + LDPC_SPLIT_CW_DWORDS * 4);
             int t = threadIdx.x;
             asm volatile("" : "+v"(t));
             if (t == 0) A.trials[f] = ret;
@@ -697,7 +692,7 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
     }
 }
 
-size_t ldpc_split_lds_bytes(int N) { return (size_t)((N + LDPC_SPLIT_SCRATCH + 15) & ~15) + 2 * 360 * 4 + 384 + 16 * 4; }
+size_t ldpc_split_lds_bytes(int N) { return (size_t)((N + LDPC_SPLIT_SCRATCH + 15) & ~15) + LDPC_SPLIT_CW_DWORDS * 4 + 16 * 4; }
 size_t ldpc_split_msg_bytes_per_block(const LdpcDeviceCode& C) { return (size_t)C.split_rec_total * sizeof(uint32_t); }
 
 template <int MAXDEG>
