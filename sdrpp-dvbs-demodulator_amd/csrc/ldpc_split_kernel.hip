@@ -411,9 +411,45 @@ __device__ __forceinline__ void level_layer(RowState<MAXDEG>& R, uint32_t (&rec_
     lds_barrier();
     uint32_t cwb = lds_offset(reinterpret_cast<const int8_t*>(cw));
     asm volatile("" : "+s"(cwb));
-    if (t < 64) {
+    typedef __attribute__((address_space(3))) u32x4 lds_u4;
+    if (t < 64 && W <= 16) {
+        // narrow levels (rate 3/4: layer 42, 33 levels of 11 rows -- two thirds of a sweep's level steps): FOUR LANES PER ROW, lane = slot, plain 32-bit arithmetic, the
+        // slots meet through quad permutes -- 29 instructions per level where the lane-per-row form below takes 58 (a walker instruction is ~10 cycles of serial time)
         __builtin_amdgcn_s_setprio(3);
-        typedef __attribute__((address_space(3))) u32x4 lds_u4;
+        const int k = t & 3, i = t >> 2;
+        uint32_t pr = cwb + 16u * (uint32_t)(i + W);
+        const uint32_t pstep = 16u * (uint32_t)W;
+        const uint32_t asel = k == 0 ? 0x0c0c0100u : k == 1 ? 0x0c0c0302u : k == 2 ? 0x0c0c0504u : 0x0c0c0706u;        // the slot's 16-bit address out of {a01, a23}
+        u32x4 rec = *(const lds_u4*)(uintptr_t)pr;
+        int row = i + W;
+        for (int lv = 1; lv < depth; ++lv) {
+            const u32x4 r = rec;
+            const uint32_t prn = pr + pstep;
+            rec = *(const lds_u4*)(uintptr_t)prn;
+            if (i < W && row < 360) {
+                const uint32_t a = __builtin_amdgcn_perm(r.w, r.z, asel);
+                const int x = (int)LDS_I8(a);
+                const int m = (int)__builtin_amdgcn_sbfe((int)r.x, 8 * k, 8);
+                const int q0 = (int)((r.y >> 8) & 0x3fu);                      // min(min0 of the other links, 32)
+                const int v = clamp8(x - m);
+                const int g = mag_of(v);
+                // the smallest magnitude among the row's other links: the three other slots (quad rotations) and the rest
+                int o = min(q0, (int)__builtin_amdgcn_update_dpp(0, g, 0x39, 0xf, 0xf, true));          // quad_perm [1,2,3,0]
+                o = min(o, (int)__builtin_amdgcn_update_dpp(0, g, 0x4E, 0xf, 0xf, true));                // quad_perm [2,3,0,1]
+                o = min(o, (int)__builtin_amdgcn_update_dpp(0, g, 0x93, 0xf, 0xf, true));                // quad_perm [3,0,1,2]
+                int sx = v ^ (int)__builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);               // quad_perm [1,0,3,2]
+                sx ^= (int)__builtin_amdgcn_update_dpp(0, sx, 0x4E, 0xf, 0xf, true);
+                const int neg = (sx ^ (int)r.y ^ v) >> 31;
+                const int nm = med3i((o ^ neg) - neg, -32, 31);
+                LDS_I8(a) = (int8_t)clamp8(v + nm);
+                LDS_I8(pr + (uint32_t)k) = (int8_t)v;                          // the slot's input, for the row's phase C
+            }
+            pr = prn;
+            row += W;
+        }
+        __builtin_amdgcn_s_setprio(0);
+    } else if (t < 64) {
+        __builtin_amdgcn_s_setprio(3);
         uint32_t pr = cwb + 16u * (uint32_t)(t + W);          // record of the lane's row of the level in hand; a level's last rows may lie past row 359: such a read lands
         const uint32_t pstep = 16u * (uint32_t)W;             // in LDS the workgroup owns (or beyond, where it returns zeros) and its lane is masked
         u32x4 rec = *(const lds_u4*)(uintptr_t)pr;
