@@ -18,6 +18,7 @@
 // on-chip (LDS + Infinity Cache); DESIGN.md section 5 prices the kernel against its VALU cycles as well.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include "ldpc_lane_common.h"
 #include "ldpc_split_plan.h"
 
@@ -45,7 +46,13 @@ struct SplitShape {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-constexpr int LDPC_SPLIT_CW_DWORDS = 4 * 360;        // the hand-off record area behind the posteriors: 16 bytes per row
+// LDS of a workgroup = posteriors (N bytes) + LDPC_SPLIT_SCRATCH bytes (idle lanes' scratch during a sweep; the syndrome check's flags and the next frame's index outside of
+// one: the two uses never overlap in time) + the hand-off records: 8 bytes per row (chain walk), 12 per row of level > 1 (level walk).  THE TOTAL MUST STAY WITHIN 54 LDS
+// ALLOCATION GRANULES of 1 280 bytes (69 120 bytes for N = 64 800): two decoder workgroups then leave 20 of a compute unit's 128 granules, room for TWO workgroups of the
+// front end's timing recovery (s2_gardner2_kernel: 9 granules each).  Round 6 measured it the hard way: at 56 granules (16-byte records) only ONE fitted, the timing
+// recovery beside the decoder ran in two rounds, and the pipelined step took 333.6 instead of 310.0 ms.
+constexpr int LDPC_SPLIT_LDS_BUDGET = 54 * 1280;
+constexpr int LDPC_SPLIT_REC5 = 12;                                   // bytes per level-walk record
 
 __device__ __forceinline__ void lds_read_lo_i8(uint32_t a_lo, uint32_t& r_lo) {
     if (LDPC_EXP & 4) { r_lo = a_lo & 0xffu; return; }
@@ -258,6 +265,9 @@ __device__ __forceinline__ int chain_step_x(const int x, const u32x2 r) {
 }
 typedef __attribute__((address_space(3))) u32x2 lds_u2;
 #define LDS_U2(a) (*(const lds_u2*)(uintptr_t)(a))
+typedef u32x2 __attribute__((aligned(4))) u32x2_a4;
+typedef __attribute__((address_space(3))) u32x2_a4 lds_u2_a4;
+#define LDS_U2_A4(a) (*(const lds_u2_a4*)(uintptr_t)(a))          // (records at a 12-byte stride: two dwords, dword-aligned)
 
 // A layer whose shared links are one pair (slots 0 = "E", 1 = "L" of half 0: row j's E bit is row (j + d)'s L bit) with a deep dependency chain: ldpc_kernel.hip's chain
 // walk, its arithmetic kept packed.  Rows in lane order (row j = t >> 1).  The row word -- level | late << 8 | early << 12 in half 0, the level alone in half 1, zero in
@@ -403,34 +413,40 @@ __device__ __forceinline__ void level_layer(RowState<MAXDEG>& R, uint32_t (&rec_
     if (level > 1u && !half1) {
         // {m0 m1 m2 m3} | {min(min0 of the other links, 32) in both halves (Q8), their sign product in bits 15 and 31} | the four slots' LDS addresses: the walker, whose every
         // instruction is serial time of the workgroup (~10 cycles each beside the other workgroup's waves), only takes them apart
-        const uint32_t mb = __builtin_amdgcn_perm(bits2(R.RP[1]), bits2(R.RP[0]), 0x07050301u);
-        const uint32_t qs = (uint32_t)min(M0, 0x20002000) | ((uint32_t)SXs & 0x80008000u);
-        *reinterpret_cast<u32x4*>(cw + 4 * j) = u32x4{mb, qs, R.addr[0] | (R.addr[1] << 16), R.addr[2] | (R.addr[3] << 16)};
+        // 12 bytes, rows of level > 1 only (index row - W): {the four old messages as 6-bit fields | min(min0 of the other links, 32) << 24 | their sign product in bit 31}, a0 | a1 << 16, a2 | a3 << 16
+        const uint32_t r0 = bits2(R.RP[0]), r1 = bits2(R.RP[1]);
+        const uint32_t mf = ((r0 >> 8) & 0x3fu) | ((r0 >> 18) & 0xfc0u) | ((r1 << 4) & 0x3f000u) | ((r1 >> 6) & 0xfc0000u);
+        const uint32_t d0 = mf | ((uint32_t)min(M0 >> 24, 32) << 24) | ((uint32_t)SXs & 0x80000000u);
+        uint32_t* rp = cw + 3 * (j - W);          // (12-byte stride: dword accesses)
+        rp[0] = d0; rp[1] = R.addr[0] | (R.addr[1] << 16); rp[2] = R.addr[2] | (R.addr[3] << 16);
     }
     lds_pairs_wait();
     lds_barrier();
     uint32_t cwb = lds_offset(reinterpret_cast<const int8_t*>(cw));
     asm volatile("" : "+s"(cwb));
-    typedef __attribute__((address_space(3))) u32x4 lds_u4;
     if (t < 64 && W <= 16) {
         // narrow levels (rate 3/4: layer 42, 33 levels of 11 rows -- two thirds of a sweep's level steps): FOUR LANES PER ROW, lane = slot, plain 32-bit arithmetic, the
         // slots meet through quad permutes -- 29 instructions per level where the lane-per-row form below takes 58 (a walker instruction is ~10 cycles of serial time)
         __builtin_amdgcn_s_setprio(3);
         const int k = t & 3, i = t >> 2;
-        uint32_t pr = cwb + 16u * (uint32_t)(i + W);
-        const uint32_t pstep = 16u * (uint32_t)W;
+        uint32_t pr = cwb + (uint32_t)LDPC_SPLIT_REC5 * (uint32_t)i;          // (records start at row W)
+        const uint32_t pstep = (uint32_t)LDPC_SPLIT_REC5 * (uint32_t)W;
         const uint32_t asel = k == 0 ? 0x0c0c0100u : k == 1 ? 0x0c0c0302u : k == 2 ? 0x0c0c0504u : 0x0c0c0706u;        // the slot's 16-bit address out of {a01, a23}
-        u32x4 rec = *(const lds_u4*)(uintptr_t)pr;
+        typedef __attribute__((address_space(3))) uint32_t lds_u1;
+        u32x2 rec = LDS_U2_A4(pr);
+        uint32_t rec2 = *(const lds_u1*)(uintptr_t)(pr + 8u);
         int row = i + W;
         for (int lv = 1; lv < depth; ++lv) {
-            const u32x4 r = rec;
+            const u32x2 r = rec;
+            const uint32_t r2 = rec2;
             const uint32_t prn = pr + pstep;
-            rec = *(const lds_u4*)(uintptr_t)prn;
+            rec = LDS_U2_A4(prn);
+            rec2 = *(const lds_u1*)(uintptr_t)(prn + 8u);
             if (i < W && row < 360) {
-                const uint32_t a = __builtin_amdgcn_perm(r.w, r.z, asel);
+                const uint32_t a = __builtin_amdgcn_perm(r2, r.y, asel);
                 const int x = (int)LDS_I8(a);
-                const int m = (int)__builtin_amdgcn_sbfe((int)r.x, 8 * k, 8);
-                const int q0 = (int)((r.y >> 8) & 0x3fu);                      // min(min0 of the other links, 32)
+                const int m = (int)__builtin_amdgcn_sbfe((int)r.x, 6 * k, 6);
+                const int q0 = (int)((r.x >> 24) & 0x3fu);                     // min(min0 of the other links, 32)
                 const int v = clamp8(x - m);
                 const int g = mag_of(v);
                 // the smallest magnitude among the row's other links: the three other slots (quad rotations) and the rest
@@ -439,10 +455,10 @@ __device__ __forceinline__ void level_layer(RowState<MAXDEG>& R, uint32_t (&rec_
                 o = min(o, (int)__builtin_amdgcn_update_dpp(0, g, 0x93, 0xf, 0xf, true));                // quad_perm [3,0,1,2]
                 int sx = v ^ (int)__builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);               // quad_perm [1,0,3,2]
                 sx ^= (int)__builtin_amdgcn_update_dpp(0, sx, 0x4E, 0xf, 0xf, true);
-                const int neg = (sx ^ (int)r.y ^ v) >> 31;
+                const int neg = (sx ^ (int)r.x ^ v) >> 31;
                 const int nm = med3i((o ^ neg) - neg, -32, 31);
                 LDS_I8(a) = (int8_t)clamp8(v + nm);
-                LDS_I8(pr + (uint32_t)k) = (int8_t)v;                          // the slot's input, for the row's phase C
+                LDS_I8(pr + (uint32_t)k) = (int8_t)v;                          // the slot's input, for the row's phase C (the four lanes of a row fill the record's first word)
             }
             pr = prn;
             row += W;
@@ -450,21 +466,28 @@ __device__ __forceinline__ void level_layer(RowState<MAXDEG>& R, uint32_t (&rec_
         __builtin_amdgcn_s_setprio(0);
     } else if (t < 64) {
         __builtin_amdgcn_s_setprio(3);
-        uint32_t pr = cwb + 16u * (uint32_t)(t + W);          // record of the lane's row of the level in hand; a level's last rows may lie past row 359: such a read lands
-        const uint32_t pstep = 16u * (uint32_t)W;             // in LDS the workgroup owns (or beyond, where it returns zeros) and its lane is masked
-        u32x4 rec = *(const lds_u4*)(uintptr_t)pr;
+        typedef __attribute__((address_space(3))) uint32_t lds_u1;
+        uint32_t pr = cwb + (uint32_t)LDPC_SPLIT_REC5 * (uint32_t)t;          // record of the lane's row of the level in hand (records start at row W); a level's last rows may lie
+        const uint32_t pstep = (uint32_t)LDPC_SPLIT_REC5 * (uint32_t)W;       // past row 359: such a read lands in LDS the workgroup owns (or beyond: zeros) and its lane is masked
+        u32x2 rec = LDS_U2_A4(pr);
+        uint32_t rec2 = *(const lds_u1*)(uintptr_t)(pr + 8u);
         int row = t + W;
         for (int k = 1; k < depth; ++k) {
-            const u32x4 r = rec;
+            const u32x2 r = rec;
+            const uint32_t r2 = rec2;
             const uint32_t prn = pr + pstep;
-            rec = *(const lds_u4*)(uintptr_t)prn;              // the next level's record (written in phase A: no dependence on this step)
+            rec = LDS_U2_A4(prn);                                  // the next level's record (written in phase A: no dependence on this step)
+            rec2 = *(const lds_u1*)(uintptr_t)(prn + 8u);
             if (t < W && row < 360) {
-                const uint32_t a0 = r.z & 0xffffu, a1 = r.z >> 16, a2 = r.w & 0xffffu, a3 = r.w >> 16;
+                const uint32_t a0 = r.y & 0xffffu, a1 = r.y >> 16, a2 = r2 & 0xffffu, a3 = r2 >> 16;
                 uint32_t xr0, xh0, xr1, xh1;
                 lds_read_pair_i8(a0, a1, xr0, xh0);
                 lds_read_pair_i8(a2, a3, xr1, xh1);
-                const s16x2 RM0 = rec_pair_dw(r.x, 0), RM1 = rec_pair_dw(r.x, 2);
-                const s16x2 Q0 = from_bits2(r.y & 0x7fff7fffu);          // min(min0 of the other links, 32) in both halves (Q8)
+                // the record's 6-bit fields -> Q8 pairs (byte 0 of either extract into the high bytes of the two halves)
+                const s16x2 RM0 = from_bits2(__builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_sbfe((int)r.x, 6, 6), (uint32_t)__builtin_amdgcn_sbfe((int)r.x, 0, 6), 0x040c000cu));
+                const s16x2 RM1 = from_bits2(__builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_sbfe((int)r.x, 18, 6), (uint32_t)__builtin_amdgcn_sbfe((int)r.x, 12, 6), 0x040c000cu));
+                const s16x2 Q0 = from_bits2(((r.x >> 24) & 0x3fu) * 0x01000100u);          // min(min0 of the other links, 32) in both halves (Q8)
+                const uint32_t s0w = (uint32_t)((int)r.x >> 31) & 0x80008000u;              // their sign product in bits 15 and 31
                 lds_ready_n(0, xr0, xh0);
                 asm volatile("" : "+v"(xr1), "+v"(xh1));
                 const s16x2 V0 = sat_sub2(from_bits2(__builtin_amdgcn_perm(xh0, xr0, 0x060c000cu)), RM0);
@@ -477,7 +500,7 @@ __device__ __forceinline__ void level_layer(RowState<MAXDEG>& R, uint32_t (&rec_
                 // sign of the row: the record's product times the four slots' (bits 15 and 31 after the fold; the record word's other bits ride along unused)
                 uint32_t sx = bits2(V0) ^ bits2(V1);
                 sx ^= __builtin_amdgcn_alignbit(sx, sx, 16);
-                sx ^= r.y;
+                sx ^= s0w;
                 const s16x2 N0 = from_bits2(sx ^ bits2(V0)) >> 15, N1 = from_bits2(sx ^ bits2(V1)) >> 15;
                 const s16x2 NM0 = pmin2(from_bits2(bits2(O0) ^ bits2(N0)) - N0, q8(31)), NM1 = pmin2(from_bits2(bits2(O1) ^ bits2(N1)) - N1, q8(31));
                 const uint32_t pn0 = bits2(sat_add2(V0, NM0)) >> 8, pn1 = bits2(sat_add2(V1, NM1)) >> 8;
@@ -495,7 +518,7 @@ __device__ __forceinline__ void level_layer(RowState<MAXDEG>& R, uint32_t (&rec_
     lds_barrier();
     if (level > 1u) {
         if (!half1) {
-            const uint32_t vb = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(cwb + 16u * (uint32_t)j);
+            const uint32_t vb = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(cwb + (uint32_t)LDPC_SPLIT_REC5 * (uint32_t)(j - W));
             R.V[0] = rec_pair_dw(vb, 0); R.V[1] = rec_pair_dw(vb, 2);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
@@ -568,7 +591,7 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
             const const_u32_ptr ents = (const_u32_ptr)P->ents;
             const int npad = (N + LDPC_SPLIT_SCRATCH + 15) & ~15;                // posteriors + the scratch bytes (ldpc_split_plan.h)
             uint32_t* __restrict__ cw = reinterpret_cast<uint32_t*>(lds_all + npad);      // hand-off records: 8 bytes per row (chain walk) / 16 (level walk)
-            int* __restrict__ s_flag = reinterpret_cast<int*>(cw + LDPC_SPLIT_CW_DWORDS);                // [12] + next frame
+            int* __restrict__ s_flag = reinterpret_cast<int*>(lds_all + N);                // [12] + next frame, in the sweep's scratch bytes (LDPC_SPLIT_SCRATCH = 64)
             uint32_t* __restrict__ msg = A.msg_ws + (size_t)blockIdx.x * (size_t)A.pent_base;
             uint32_t* __restrict__ sgn = A.sgn_ws + (size_t)blockIdx.x * SGN_WS_DWORDS;
             const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(P->atab), 0, npl * (T * NPW * 4), 0x00020000);
@@ -690,7 +713,7 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
             const LdpcKernelParamsPtr P = ldpc_params();
             const LdpcKernelArgs A = ldpc_args(P);
             const int N = A.N, K = A.K, R = A.R, q = A.q;
-            int* __restrict__ s_flag = reinterpret_cast<int*>(lds_all + ((N + LDPC_SPLIT_SCRATCH + 15) & ~15) + LDPC_SPLIT_CW_DWORDS * 4);
+            int* __restrict__ s_flag = reinterpret_cast<int*>(lds_all + N);
             int t = threadIdx.x;
             asm volatile("" : "+v"(t));
             if (t == 0) A.trials[f] = ret;
@@ -728,7 +751,11 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
     }
 }
 
-size_t ldpc_split_lds_bytes(int N) { return (size_t)((N + LDPC_SPLIT_SCRATCH + 15) & ~15) + LDPC_SPLIT_CW_DWORDS * 4 + 16 * 4; }
+// posteriors + scratch, then the records: up to the granule budget for the normal frames (the plan keeps the records within it: ldpc_split_plan.h), 8 bytes x 360 rows at least
+size_t ldpc_split_lds_bytes(int N) {
+    const size_t npad = (size_t)((N + LDPC_SPLIT_SCRATCH + 15) & ~15);
+    return std::max(npad + 8 * 360, (size_t)LDPC_SPLIT_LDS_BUDGET);
+}
 size_t ldpc_split_msg_bytes_per_block(const LdpcDeviceCode& C) { return (size_t)C.split_rec_total * sizeof(uint32_t); }
 
 template <int MAXDEG>

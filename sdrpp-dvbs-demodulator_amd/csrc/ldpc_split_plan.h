@@ -139,6 +139,8 @@ inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P) {
                 bool runs = W >= 1 && W <= 64;
                 for (int j = 0; runs && j < 360; ++j) runs = (int)(info[j] & 0xffu) == j / W + 1;
                 if (!runs) return LdpcSplitPlan();
+                // (the level walk's records -- 12 bytes per row of level > 1 -- must fit between the posteriors and the 54-granule LDS budget of ldpc_split_kernel.hip)
+                if (((P.N + LDPC_SPLIT_SCRATCH + 15) & ~15) + 12 * (360 - W) > 54 * 1280) return LdpcSplitPlan();
                 emit(5, i, rows, &info, (uint32_t)W | ((uint32_t)depth << 16));
             }
             S.chain_layers++;

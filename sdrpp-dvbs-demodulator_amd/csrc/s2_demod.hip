@@ -485,6 +485,14 @@ static int deliver_job(dvbs2gpu_ctx* ctx, PendingFec* job, hipStream_t st, Works
 
 // development aid: DVBS2GPU_HOST_TIMING=1 prints where the HOST spends a call (ms since entry at each mark)
 // AGC/NCO + timing recovery of a batch, time-sliced over the caller's stream and its auxiliary stream (ctx.h FeAux, created on first use)
+// Stream priorities (option stream_prio, default 0 = all streams alike): 1 = the front end's streams at the device's highest queue priority, the FEC stream at its lowest
+static hipError_t create_stream(dvbs2gpu_ctx* ctx, hipStream_t* out, int want) {
+    if (ctx->stream_prio) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) return hipStreamCreateWithPriority(out, hipStreamNonBlocking, want > 0 ? hi : lo);
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
 static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work, int n, const S2LoopCoefs& co, hipStream_t st, const S2PostStages* post = nullptr,
                                   bool own_post_stream = false, int* nsub_out = nullptr) {
     // (measured: beside the decoder of the previous call 4, alone 8; a small bank is a latency chain in either mode: the shorter pipeline fill wins)
@@ -504,7 +512,7 @@ static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work,
         std::lock_guard<std::mutex> l(ctx->mtx);
         fa = &ctx->fe_aux[st];
         if (!fa->aux) {
-            hipError_t e = hipStreamCreateWithFlags(&fa->aux, hipStreamNonBlocking);
+            hipError_t e = create_stream(ctx, &fa->aux, +1);
             if (e != hipSuccess) return e;
             for (int i = 0; i <= S2_FE_MAX_SLICES; ++i) {
                 if ((e = hipEventCreateWithFlags(&fa->ev[i], hipEventDisableTiming)) != hipSuccess) return e;
@@ -514,7 +522,7 @@ static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work,
     }
     if (fa && post && own_post_stream && !fa->aux2) {
         std::lock_guard<std::mutex> l(ctx->mtx);
-        hipError_t e = hipStreamCreateWithFlags(&fa->aux2, hipStreamNonBlocking);
+        hipError_t e = create_stream(ctx, &fa->aux2, +1);
         if (e != hipSuccess) return e;
     }
     return s2_frontend_launch(d_work, n, cc, ctx->d_gardner_bank, st, fa ? fa->aux : nullptr, fa ? fa->ev : nullptr, nsub, post, fa ? fa->ev2 : nullptr,
@@ -879,7 +887,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             const bool held = verdict < 0 && ctx->g_prio_hold > 0;
             if (verdict != 0 && !held && (clear || verdict == ctx->g_prio_trend)) {
                 const int before = ctx->g_prio_duty;
-                ctx->g_prio_duty = std::min(7, std::max(0, ctx->g_prio_duty + verdict));
+                ctx->g_prio_duty = std::min(ctx->g_prio_cap, std::max(0, ctx->g_prio_duty + verdict));
                 if (verdict > 0 && ctx->g_prio_last_down > 0 && ctx->g_prio_duty != before) ctx->g_prio_hold = 64;     // (up again right behind a step down)
                 ctx->g_prio_last_down = (verdict < 0 && ctx->g_prio_duty != before) ? 4 : 0;
                 ctx->g_prio_trend = 0;
@@ -1546,8 +1554,8 @@ int dvbs2gpu_set_pipelined(dvbs2gpu_ctx* ctx, int on) {
     CallGuard guard(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     if (on) {      // (the FEC stream may exist already: synchronous mixed batches use it too)
-        if (!ctx->fe_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->fe_stream, hipStreamNonBlocking));
-        if (!ctx->fec_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->fec_stream, hipStreamNonBlocking));
+        if (!ctx->fe_stream) HIP_TRY(create_stream(ctx, &ctx->fe_stream, +1));
+        if (!ctx->fec_stream) HIP_TRY(create_stream(ctx, &ctx->fec_stream, -1));
         if (!ctx->ev_llr) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_llr, hipEventDisableTiming));
     }
     if (!on && ctx->fec_stream) {
