@@ -37,7 +37,8 @@ import numpy as np
 # 4 queues, 48 on 6, 44 on 8; the DVB-S line late in a full run, with the S2 engine's streams still alive: 1 570 Msym/s on 8 queues, 2 230-2 350 on 12).  The library asks for
 # 12 when it is loaded (csrc/capi.hip) -- but this process imports torch first, whose HIP runtime has read its environment by then: so here, and in any host that
 # initialises HIP before it loads the plugin, the variable is set up front.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '12')
+if not os.environ.get('DVBS2GPU_BENCH_DEFAULT_QUEUES'):          # (development aid: leave the runtime's default of 4 hardware queues)
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '12')
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))

@@ -36,11 +36,14 @@ namespace s2 {
 
 template <int MAXDEG>
 struct SplitShape {
-    static constexpr int NL = MAXDEG + 2, HS = NL / 2, NP = (HS + 1) / 2;
+    // a row has NL = MAXDEG + 2 links; half 0 holds the first HS = ceil(NL / 2), half 1 the rest.  ODD: half 1 has one link less -- its last slot (HS - 1) is a constant
+    // neutral link in those lanes (posterior +127, message 0: magnitude 126 never displaces a real minimum, sign +), its table address a scratch byte
+    static constexpr int NL = MAXDEG + 2, HS = (NL + 1) / 2, NP = (HS + 1) / 2;
+    static constexpr bool ODD = (NL & 1) != 0;
+    static constexpr int PREV_SLOT = ODD ? HS - 2 : HS - 1;      // the previous parity bit's slot in half 1 (the row's last link)
     static constexpr int NPW = (HS / 2 + 1) <= 1 ? 1 : (HS / 2 + 1) <= 2 ? 2 : (HS / 2 + 1) <= 4 ? 4 : 8;
     static constexpr int REC = HS <= 4 ? 1 : HS <= 8 ? 2 : 4;
     static constexpr int RI_WORD = HS / 2, RI_SHIFT = (HS & 1) ? 16 : 0;     // where the row word sits (ldpc_split_plan.h)
-    static_assert((NL & 1) == 0, "the half-row decoder takes rows with an even number of links");
     static_assert(HS / 2 + 1 <= NPW, "slots + row word must fit the thread's table entry (ldpc_split_plan.h)");
 };
 
@@ -160,9 +163,16 @@ __device__ __forceinline__ void row_input(RowState<MAXDEG>& R, const uint32_t la
         const s16x2 av = pmax2(v, sat_sub2(splat2(0), v));
         // |v| - 1 clamped at 0 (ldpc_kernel.hip: no upper clamp needed, only the high byte is ever consumed)
         s16x2 g = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, av), (u16x2){256, 256}));
-        if ((NOPREV == 1 || (NOPREV == 2 && noprev_rt)) && 2 * p + 2 > HS - 1 && 2 * p <= HS - 1) {
-            // row 0 of layer 0 has no previous parity bit (the last slot of half 1): that thread's slot becomes the neutral link
+        if ((NOPREV == 1 || (NOPREV == 2 && noprev_rt)) && (S::PREV_SLOT >> 1) == p) {
+            // row 0 of layer 0 has no previous parity bit (the last link of half 1): that thread's slot becomes the neutral link
             const bool me = (uint32_t)t == noprev_t;
+            constexpr int hh = S::PREV_SLOT & 1;
+            v[hh] = me ? (short)(127 << 8) : v[hh];
+            g[hh] = me ? (short)(126 << 8) : g[hh];
+        }
+        if (S::ODD && ((HS - 1) >> 1) == p) {
+            // an odd number of links per row: half 1's last slot is the neutral link (whatever its scratch byte and record byte hold)
+            const bool me = (t & 1) != 0;
             constexpr int hh = (HS - 1) & 1;
             v[hh] = me ? (short)(127 << 8) : v[hh];
             g[hh] = me ? (short)(126 << 8) : g[hh];
@@ -781,12 +791,14 @@ static int occupancy_split(int N) {
 
 #define LDPC_SPLIT_DISPATCH(FN, ...)                    \
     switch (max_deg) {                                  \
+        case 5: return FN<5>(__VA_ARGS__);              \
+        case 9: return FN<9>(__VA_ARGS__);              \
         case 12: return FN<12>(__VA_ARGS__);            \
         default: break;                                 \
     }
 
 extern unsigned long long* g_ldpc_prof;   // (ldpc_kernel.hip)
-bool ldpc_split_supported(int max_deg) { return max_deg == 12; }
+bool ldpc_split_supported(int max_deg) { return max_deg == 5 || max_deg == 9 || max_deg == 12; }
 int ldpc_split_blocks_per_cu(int max_deg, int N) {
     LDPC_SPLIT_DISPATCH(occupancy_split, N)
     return 1;

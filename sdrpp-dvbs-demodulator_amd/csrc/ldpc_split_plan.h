@@ -3,7 +3,7 @@
 // The reference sweeps rows in order (xdsopl-ldpc-pabr/layered_decoder.hh:46-74); which rows of a layer may run side by side is the plan of
 // ldpc_plan.h (levels, late / early links, chain steps) -- unchanged.  What changes is who holds a row and how dependent rows are ordered:
 //   * thread t of the 768-thread workgroup owns HALF h = t & 1 of a row.  A row has NL = max_deg + 2 links (table links, own parity bit,
-//     previous parity bit); half 0 holds links [0, HS), half 1 links [HS, NL), HS = NL / 2 slots each (NL even; an odd HS leaves the second
+//     previous parity bit); half 0 holds links [0, HS), half 1 links [HS, NL), HS = ceil(NL / 2) slots each (an odd NL: half 1 has a link less and its last slot is a constant neutral link; an odd HS leaves the second
 //     half of the last register pair to a constant neutral link, ldpc_split_kernel.hip).  min / xor are associative and commutative, so
 //     joining the two halves' (min0, min1, sign) with one cross-lane step leaves algorithms.hh:242-255 bit-exact.
 //   * a sweep is a list of PSEUDO-LAYERS, each ending in a workgroup barrier, one per layer of the code, all twelve waves at work in every one of them.  Everything a
@@ -56,18 +56,18 @@ inline int ldpc_split_npw(int hs) {
     return words <= 1 ? 1 : words <= 2 ? 2 : words <= 4 ? 4 : 8;
 }
 
-inline int ldpc_split_plan_rec_dwords(int max_deg) { const int hs = (max_deg + 2) / 2; return hs <= 4 ? 1 : hs <= 8 ? 2 : 4; }
+inline int ldpc_split_plan_rec_dwords(int max_deg) { const int hs = (max_deg + 3) / 2; return hs <= 4 ? 1 : hs <= 8 ? 2 : 4; }
 
 // which codes the half-row decoder takes: regular ones with an even number of links per row (both halves then hold the same number of slots)
 inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P) {
     LdpcSplitPlan S;
     const int NL = P.max_deg + 2;
-    if (P.min_deg != P.max_deg || (NL & 1) || NL / 2 > 14 || P.N + LDPC_SPLIT_SCRATCH > 65536) return S;     // (NL / 2 slots + the row word in at most 8 table words)
+    if (P.min_deg != P.max_deg || (NL + 1) / 2 > 14 || P.N + LDPC_SPLIT_SCRATCH > 65536) return S;     // (ceil(NL / 2) slots + the row word in at most 8 table words)
     for (const LdpcLayerDesc& L : P.layers) {
         const int nc = (int)(L.depth_nc >> 16), depth = (int)(L.depth_nc & 0xffffu);
-        if (depth > 1 && (nc > 4 || nc > NL / 2)) return S;       // (the middle sections handle up to four shared links, all in half 0)
+        if (depth > 1 && (nc > 4 || nc > (NL + 1) / 2)) return S;       // (the middle sections handle up to four shared links, all in half 0)
     }
-    S.hs = NL / 2;
+    S.hs = (NL + 1) / 2;              // (an odd NL: half 1's last slot is a neutral link, its address a scratch byte)
     S.npw = ldpc_split_npw(S.hs);
     S.rec_dwords = ldpc_split_plan_rec_dwords(P.max_deg);
     const int q = P.q, K = P.K, N = P.N, T = LDPC_SPLIT_T, hs = S.hs, npw = S.npw;
@@ -103,7 +103,7 @@ inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P) {
             const int j = pr < (int)rows.size() ? rows[pr] : -1;
             for (int s = 0; s < hs; ++s) {
                 uint32_t a = scratch(t);
-                if (j >= 0) {
+                if (j >= 0 && h * hs + s < NL) {
                     a = slot_addr(i, j, h * hs + s);
                     if (a == ~0u) { a = scratch(t); D.kind_nw |= 1u << 20; if (kind == 0) { D.aux = (uint32_t)t; D.kind_nw = (D.kind_nw & ~0xffu) | 7u; } else bad_noprev = true; }
                 }

@@ -1,4 +1,4 @@
-"""The half-row LDPC decoder (csrc/ldpc_split_kernel.hip: two lanes per row, one frame per workgroup) serves the normal frames it takes (rate 3/4) by default; the
+"""The half-row LDPC decoder (csrc/ldpc_split_kernel.hip: two lanes per row, one frame per workgroup) serves the normal frames it takes (rates 1/2, 3/5, 3/4) by default; the
 context option ldpc_split = 0 hands them back to the lane-per-row decoder (csrc/ldpc_kernel.hip).  BOTH are run here on engines of their own: posteriors, trial
 counts and hard decisions must equal the oracle's -- early exit, iteration limit, forced iterations, erasures, saturating garbage -- and many frames must flow
 through the persistent grid's work counter."""
@@ -10,7 +10,7 @@ import orc
 from test_gpu_fec import MARGINAL_SNR, make_llrs, oracle_ldpc
 
 pytestmark = pytest.mark.gpu
-CODES = [(6, 0)]
+CODES = [(6, 0), (3, 0), (4, 0)]          # rate 3/4 (14 links per row), 1/2 (7: half 1 carries a neutral slot), 3/5 (11; level-walk layers of 10 .. 46 rows)
 
 
 @pytest.fixture(scope='module', params=[{'ldpc_split': 1}, {'ldpc_split': 0}], ids=['half_row', 'lane_per_row'])
@@ -19,7 +19,8 @@ def split_engine(pkg, request):
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     eng = pkg.Engine(0, options=request.param)
-    assert eng.ldpc_decoder_form(6, False) == (2 if request.param['ldpc_split'] else 0)
+    for r in (6, 3, 4):
+        assert eng.ldpc_decoder_form(r, False) == (2 if request.param['ldpc_split'] else 0)
     yield eng
     eng.close()
 
