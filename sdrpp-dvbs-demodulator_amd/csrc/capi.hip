@@ -76,7 +76,6 @@ int apply_option(dvbs2gpu_ctx* c, const char* name, int v) {
     else if (n == "fec_part") { if (!in(-1, 1)) return -1; c->fec_part = v; c->fec_part_on = v == 1; c->fec_part_trend = 0; }
     else if (n == "mix_fec_streams") { if (!in(1, 8)) return -1; c->mix_fec_streams = v; }
     else if (n == "g_prio_duty") { if (!in(-1, 8)) return -1; if (v < 0) c->g_prio_auto = true; else { c->g_prio_duty = v; c->g_prio_auto = false; } }
-    else if (n == "stream_prio") { if (!in(0, 1)) return -1; c->stream_prio = v; }
     else if (n == "g_prio_cap") { if (!in(0, 7)) return -1; c->g_prio_cap = v; }
     else if (n == "dvbs_fe_slices") { if (!in(1, s2::DVBS_FE_MAX_SLICES)) return -1; c->dvbs_fe_slices = v; }
     else if (n == "dvbs_bank_min") { if (v < 1) return -1; c->dvbs_bank_min = v; }

@@ -192,7 +192,6 @@ struct dvbs2gpu_ctx {
     int g_prio_hold = 0, g_prio_last_down = 0;      // the balancer's damper: calls during which no step down is tried / calls since the last step down (s2_demod.hip)
     long long g_prio_sig = -1;                // what the balance was found for (streams, MODCOD, frame kind, iteration setting of the batch): another configuration starts from 0 again
     bool g_prio_auto = true;                  // option g_prio_duty fixes the value
-    int stream_prio = 0;                      // option stream_prio: 1 = front-end streams at the highest, the FEC stream at the lowest queue priority (experiment)
     int g_prio_cap = 7;                       // option g_prio_cap: the highest share the balancer may reach (development aid)
     int dvbs_bank_min = 2048;                 // option dvbs_bank_min: carriers from which a bank uses the four-streams-per-wave FLL (measured crossover with the written-out wave-per-stream loop: 2048 carriers 74.2 vs 74.8 ms, 1024: 46.2 vs 54.8, 4096: 128.8 vs 111.4; tests: 1)
     int dvbs_agc_stream = 1;                  // option dvbs_agc_stream: the AGC slices of a bank below dvbs_bank_min carriers on a third auxiliary stream (0: on the Viterbi stream)

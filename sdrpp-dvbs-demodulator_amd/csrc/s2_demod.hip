@@ -485,14 +485,9 @@ static int deliver_job(dvbs2gpu_ctx* ctx, PendingFec* job, hipStream_t st, Works
 
 // development aid: DVBS2GPU_HOST_TIMING=1 prints where the HOST spends a call (ms since entry at each mark)
 // AGC/NCO + timing recovery of a batch, time-sliced over the caller's stream and its auxiliary stream (ctx.h FeAux, created on first use)
-// Stream priorities (option stream_prio, default 0 = all streams alike): 1 = the front end's streams at the device's highest queue priority, the FEC stream at its lowest
-static hipError_t create_stream(dvbs2gpu_ctx* ctx, hipStream_t* out, int want) {
-    if (ctx->stream_prio) {
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) return hipStreamCreateWithPriority(out, hipStreamNonBlocking, want > 0 ? hi : lo);
-    }
-    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
-}
+// (round 6 tried HIP stream priorities -- front-end streams at the device's highest queue priority, the FEC stream at its lowest, or only the post-stage streams high:
+//  302.8 / 303.2 / 304.0 ms per headline step, nothing: queue priority does not decide which resident kernel's workgroups get a compute unit's free wave slots)
+static hipError_t create_stream(dvbs2gpu_ctx*, hipStream_t* out, int) { return hipStreamCreateWithFlags(out, hipStreamNonBlocking); }
 static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work, int n, const S2LoopCoefs& co, hipStream_t st, const S2PostStages* post = nullptr,
                                   bool own_post_stream = false, int* nsub_out = nullptr) {
     // (measured: beside the decoder of the previous call 4, alone 8; a small bank is a latency chain in either mode: the shorter pipeline fill wins)
