@@ -76,6 +76,7 @@ int apply_option(dvbs2gpu_ctx* c, const char* name, int v) {
     else if (n == "fec_part") { if (!in(-1, 1)) return -1; c->fec_part = v; c->fec_part_on = v == 1; c->fec_part_trend = 0; }
     else if (n == "mix_fec_streams") { if (!in(1, 8)) return -1; c->mix_fec_streams = v; }
     else if (n == "g_prio_duty") { if (!in(-1, 8)) return -1; if (v < 0) c->g_prio_auto = true; else { c->g_prio_duty = v; c->g_prio_auto = false; } }
+    else if (n == "stage_loops_stream") { if (!in(0, 1)) return -1; c->stage_loops_stream = v; }
     else if (n == "g_prio_cap") { if (!in(0, 7)) return -1; c->g_prio_cap = v; }
     else if (n == "dvbs_fe_slices") { if (!in(1, s2::DVBS_FE_MAX_SLICES)) return -1; c->dvbs_fe_slices = v; }
     else if (n == "dvbs_bank_min") { if (v < 1) return -1; c->dvbs_bank_min = v; }
@@ -459,6 +460,8 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
         for (hipEvent_t e : kv.second.ev) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : kv.second.ev2) if (e) (void)hipEventDestroy(e);
         if (kv.second.aux2) (void)hipStreamDestroy(kv.second.aux2);
+        if (kv.second.aux3) (void)hipStreamDestroy(kv.second.aux3);
+        for (hipEvent_t e : kv.second.ev3) if (e) (void)hipEventDestroy(e);
         for (hipStream_t a : kv.second.dvbs_aux) if (a) (void)hipStreamDestroy(a);
         for (auto& row : kv.second.dvbs_ev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
     }

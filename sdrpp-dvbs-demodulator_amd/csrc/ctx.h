@@ -168,7 +168,7 @@ struct dvbs2gpu_ctx {
     // SIDE BY SIDE instead: on the group's own stream (grp_stream) with a set of FEC workspaces per group
     s2::FecWs fws_grp[MAX_PIPE_GROUPS];
     // time-sliced front end (s2_rx_kernels.hip, s2_frontend_launch): per main stream one auxiliary stream + the slice events
-    struct FeAux { hipStream_t aux = nullptr, aux2 = nullptr; hipEvent_t ev[s2::S2_FE_MAX_SLICES + 1] = {}, ev2[s2::S2_FE_MAX_SLICES + 1] = {}; hipStream_t dvbs_aux[4] = {}; hipEvent_t dvbs_ev[4][s2::DVBS_FE_MAX_SLICES + 1] = {}; };   // (dvbs_*: the DVB-S receiver's stage streams: AGC, FLL, RRC, soft FIFO + Viterbi)
+    struct FeAux { hipStream_t aux = nullptr, aux2 = nullptr, aux3 = nullptr; hipEvent_t ev[s2::S2_FE_MAX_SLICES + 1] = {}, ev2[s2::S2_FE_MAX_SLICES + 1] = {}, ev3[2 * (s2::S2_FE_MAX_SLICES + 1)] = {}; hipStream_t dvbs_aux[4] = {}; hipEvent_t dvbs_ev[4][s2::DVBS_FE_MAX_SLICES + 1] = {}; };   // (dvbs_*: the DVB-S receiver's stage streams: AGC, FLL, RRC, soft FIFO + Viterbi)
     std::map<hipStream_t, FeAux> fe_aux;
     // development / test options (dvbs2gpu_set_option, or DVBS2GPU_OPTIONS="name=value,..." in the environment when the context is created)
     int loops_ahead = 1;                      // 0: frame loops only behind the PL sync (small banks)
@@ -192,6 +192,7 @@ struct dvbs2gpu_ctx {
     int g_prio_hold = 0, g_prio_last_down = 0;      // the balancer's damper: calls during which no step down is tried / calls since the last step down (s2_demod.hip)
     long long g_prio_sig = -1;                // what the balance was found for (streams, MODCOD, frame kind, iteration setting of the batch): another configuration starts from 0 again
     bool g_prio_auto = true;                  // option g_prio_duty fixes the value
+    int stage_loops_stream = 1;               // option stage_loops_stream: big banks run the frame loops of a slice on a stream of their own, beside the next slice's RRC (0: all post stages of a slice on one stream)
     int g_prio_cap = 7;                       // option g_prio_cap: the highest share the balancer may reach (development aid)
     int dvbs_bank_min = 2048;                 // option dvbs_bank_min: carriers from which a bank uses the four-streams-per-wave FLL (measured crossover with the written-out wave-per-stream loop: 2048 carriers 74.2 vs 74.8 ms, 1024: 46.2 vs 54.8, 4096: 128.8 vs 111.4; tests: 1)
     int dvbs_agc_stream = 1;                  // option dvbs_agc_stream: the AGC slices of a bank below dvbs_bank_min carriers on a third auxiliary stream (0: on the Viterbi stream)

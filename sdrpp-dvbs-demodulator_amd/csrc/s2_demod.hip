@@ -520,8 +520,16 @@ static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work,
         hipError_t e = create_stream(ctx, &fa->aux2, +1);
         if (e != hipSuccess) return e;
     }
+    // (big banks: the frame loops on a third auxiliary stream, s2_frontend_launch)
+    const bool loops_own = fa && post && own_post_stream && ctx->stage_loops_stream && n > S2_SMALL_BANK && nsub > 1;
+    if (loops_own && !fa->aux3) {
+        std::lock_guard<std::mutex> l(ctx->mtx);
+        hipError_t e = create_stream(ctx, &fa->aux3, +1);
+        if (e != hipSuccess) return e;
+        for (hipEvent_t& ev : fa->ev3) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return e;
+    }
     return s2_frontend_launch(d_work, n, cc, ctx->d_gardner_bank, st, fa ? fa->aux : nullptr, fa ? fa->ev : nullptr, nsub, post, fa ? fa->ev2 : nullptr,
-                              fa && own_post_stream ? fa->aux2 : nullptr);
+                              fa && own_post_stream ? fa->aux2 : nullptr, loops_own ? fa->aux3 : nullptr, loops_own ? fa->ev3 : nullptr);
 }
 
 struct HostMarks {
@@ -1708,6 +1716,7 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
                 dvbs2gpu_ctx::FeAux& a = it->second;
                 if (a.aux) (void)hipStreamDestroy(a.aux);
                 if (a.aux2) (void)hipStreamDestroy(a.aux2);
+                if (a.aux3) (void)hipStreamDestroy(a.aux3);
                 for (hipEvent_t e : a.ev) if (e) (void)hipEventDestroy(e);
                 for (hipEvent_t e : a.ev2) if (e) (void)hipEventDestroy(e);
                 for (hipStream_t d : a.dvbs_aux) if (d) (void)hipStreamDestroy(d);

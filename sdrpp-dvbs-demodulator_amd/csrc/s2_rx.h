@@ -205,7 +205,8 @@ struct S2PostStages {
 };
 hipError_t s2_post_stages_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const S2PostStages& p, int c, int nsub, hipStream_t s);
 hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCoefs coefs, const float* d_bank, hipStream_t st, hipStream_t aux,
-                              hipEvent_t* ev, int nsub, const S2PostStages* post = nullptr, hipEvent_t* ev2 = nullptr, hipStream_t post_stream = nullptr);
+                              hipEvent_t* ev, int nsub, const S2PostStages* post = nullptr, hipEvent_t* ev2 = nullptr, hipStream_t post_stream = nullptr,
+                              hipStream_t loops_stream = nullptr, hipEvent_t* ev3 = nullptr);
 hipError_t s2_rrc_decim_launch(const S2StreamWork* d_work, int nstreams, int max_count, const float* d_taps, int ntaps, hipStream_t st);
 // per-stream frame loops: frames of stream s are d_frames[first[s] .. first[s+1])
 hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const S2FrameRef* d_frames, const int* d_first,

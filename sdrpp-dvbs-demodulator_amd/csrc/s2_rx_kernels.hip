@@ -3291,8 +3291,9 @@ hipError_t dvbs_soft_compact_launch(const DvbsStreamWork* d_work, int nstreams, 
 // walks the windows that are complete and runs the frame loops (FED, PLL, PLHDR: the call's other long latency chain) over the frames found
 // so far, while the timing loop works on the next slice.  No host in between: frames stay in per-stream slots (S2PostStages), the host reads
 // the frame tables once, after the last slice.  ev2: nsub + 1 more events (timing recovery of slice c done; the last: post stages done).
-static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const S2PostStages& p, int c, int nsub, hipStream_t s) {
-    {
+// which: 1 = RRC + decimation, 2 = PL-sync walk, 4 = frame loops (any combination; 7 = all of a slice on one stream)
+static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const S2PostStages& p, int c, int nsub, hipStream_t s, int which = 7) {
+    if (which & 1) {
         int gx = ((p.max_count / nsub) / 2 + 2 + 255) / 256;
         gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
         if (p.spans) p.spans->begin(1, s);
@@ -3300,10 +3301,12 @@ static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, c
         if (c == nsub - 1) hipLaunchKernelGGL(s2_rrc_state_kernel, dim3(nstreams), dim3(128), 0, s, d_work, p.ntaps);
         if (p.spans) p.spans->end(1, s);
     }
-    {
+    if (which & 2) {
         if (p.spans) p.spans->begin(2, s);
         hipLaunchKernelGGL(s2_ccm_walk_kernel, dim3(nstreams), dim3(256), 0, s, d_work, p.raw, p.maxf, p.d_found, p.d_counts, c, nsub, p.cfgs);
         if (p.spans) p.spans->end(2, s);
+    }
+    if (which & 4) {
         const int L = p.loops_launches < 1 ? 1 : (p.loops_launches > nsub ? nsub : p.loops_launches);
         if ((c + 1) * L / nsub > c * L / nsub) {
             if (p.spans) p.spans->begin(3, s);
@@ -3364,7 +3367,11 @@ static void gardner_launch(const S2StreamWork* d_work, int nstreams, const S2Loo
 }
 #define GARDNER_LAUNCH(c_, n_) gardner_launch(d_work, nstreams, coefs, d_bank, st, (c_), (n_))
 hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCoefs coefs, const float* d_bank, hipStream_t st, hipStream_t aux,
-                              hipEvent_t* ev, int nsub, const S2PostStages* post, hipEvent_t* ev2, hipStream_t post_stream) {
+                              hipEvent_t* ev, int nsub, const S2PostStages* post, hipEvent_t* ev2, hipStream_t post_stream, hipStream_t loops_stream, hipEvent_t* ev3) {
+    // loops_stream (+ ev3: 2 (nsub + 1) events): the frame loops of slice c on a stream of their own, beside the RRC of slice c + 1 -- a big bank's post stages are a pipeline
+    // of their own (plugin's mode, r06 timeline: RRC 3 + PL-sync walk 2 + frame loops 10 ms per slice behind 10 ms of timing recovery: the post stages, not the timing
+    // recovery, set the step).  The PL-sync walk of slice c + 1 still waits for the frame loops of slice c (they read its frame table); the RRC of slice c + 1 only appends
+    // symbols behind what slice c's frames hold.
     // post_stream: a stream of their own for the post stages (synchronous mode: the FEC stream's hardware queue is free) -- on `aux` the
     // frame loops queue behind the AGC slices, and for a few streams that queue is the longest (AGC 4 x 7 + loops 4 x 10 ms against 47 ms of
     // timing recovery per 4-frame call)
@@ -3396,10 +3403,23 @@ hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCo
             if ((e = hipEventRecord(ev2[c], st)) != hipSuccess) return e;
             if ((e = agc_upto(c + 2)) != hipSuccess) return e;              // (the AGC stays ahead of the timing loop: its next slices go in before this slice's post stages)
             if ((e = hipStreamWaitEvent(ps, ev2[c], 0)) != hipSuccess) return e;
-            if ((e = post_stages_launch(d_work, nstreams, coefs, *post, c, nsub, ps)) != hipSuccess) return e;
+            if (loops_stream && ev3) {
+                hipEvent_t* walked = ev3;                  // [c]: PL-sync walk of slice c done
+                hipEvent_t* looped = ev3 + nsub + 1;       // [c]: frame loops of slice c done
+                if ((e = post_stages_launch(d_work, nstreams, coefs, *post, c, nsub, ps, 1)) != hipSuccess) return e;
+                if (c > 0 && (e = hipStreamWaitEvent(ps, looped[c - 1], 0)) != hipSuccess) return e;
+                if ((e = post_stages_launch(d_work, nstreams, coefs, *post, c, nsub, ps, 2)) != hipSuccess) return e;
+                if ((e = hipEventRecord(walked[c], ps)) != hipSuccess) return e;
+                if ((e = hipStreamWaitEvent(loops_stream, walked[c], 0)) != hipSuccess) return e;
+                if ((e = post_stages_launch(d_work, nstreams, coefs, *post, c, nsub, loops_stream, 4)) != hipSuccess) return e;
+                if ((e = hipEventRecord(looped[c], loops_stream)) != hipSuccess) return e;
+            } else if ((e = post_stages_launch(d_work, nstreams, coefs, *post, c, nsub, ps)) != hipSuccess) return e;
         }
     }
     if (post) {
+        if (loops_stream && ev3) {
+            if ((e = hipStreamWaitEvent(ps, ev3[nsub + 1 + nsub - 1], 0)) != hipSuccess) return e;          // (the last slice's frame loops)
+        }
         if ((e = hipEventRecord(ev2[nsub], ps)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(st, ev2[nsub], 0)) != hipSuccess) return e;
     }
