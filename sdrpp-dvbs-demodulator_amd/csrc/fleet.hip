@@ -203,14 +203,22 @@ int dvbs2gpu_fleet_create(const int* devices, int n, dvbs2gpu_fleet** out) {
             }
             f->members.push_back(std::move(M));
         }
-        for (auto& M : f->members) M->th = std::thread(worker, M.get());
-        *out = f.release();
+        dvbs2gpu_fleet* raw = f.release();          // (from here on dvbs2gpu_fleet_destroy cleans up: it joins whatever threads have started)
+        try {
+            for (auto& M : raw->members) M->th = std::thread(worker, M.get());
+        } catch (const std::exception& e) {
+            dvbs2gpu_fleet_destroy(raw);
+            last_error() = std::string("fleet create: worker thread: ") + e.what();
+            return DVBS2GPU_ERR_ARG;
+        }
+        *out = raw;
     } catch (const std::exception& e) { last_error() = std::string("fleet create: ") + e.what(); return DVBS2GPU_ERR_ARG; }
     return DVBS2GPU_OK;
 }
 
 void dvbs2gpu_fleet_destroy(dvbs2gpu_fleet* f) {
     if (!f) return;
+    { std::lock_guard<std::mutex> guard(f->call_mtx); }          // (a call still running on another thread finishes first; destroying a fleet while calling into it is the host's bug)
     for (auto& M : f->members) {
         { std::lock_guard<std::mutex> l(M->m); M->quit = true; }
         M->cv.notify_all();

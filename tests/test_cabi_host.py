@@ -370,3 +370,16 @@ def test_ldpc_split_plan_keeps_the_reference_row_order(pkg, rate, short):
         for j, bits in rows_here:
             for b in bits: last_touch[b] = (i, j)
     assert (seen == 1).all()
+
+
+def test_fleet_without_a_gpu_fails_loudly(pkg):
+    """the fleet has no CPU fallback either: without a HIP device dvbs2gpu_fleet_create returns the no-device error (and dvbs2gpu_device_count says 0); the placement rule
+    alone (dvbs2gpu_fleet_plan) needs no device"""
+    import torch
+    assert pkg.fleet_plan([4, 4, 14, 14], [1.0, 1.0, 3.0, 3.0], 2, 1.0) in ([1, 1, 0, 0], [0, 0, 1, 1])
+    if torch.cuda.is_available():
+        pytest.skip('GPU present: the no-device path cannot be shown')
+    assert pkg.load_library().dvbs2gpu_device_count() == 0
+    with pytest.raises(pkg.Dvbs2GpuError) as e:
+        pkg.Fleet([0])
+    assert 'no CPU fallback' in str(e.value) or 'no HIP device' in str(e.value)
