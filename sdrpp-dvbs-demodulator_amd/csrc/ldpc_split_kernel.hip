@@ -474,6 +474,51 @@ __device__ __forceinline__ void level_layer(RowState<MAXDEG>& R, uint32_t (&rec_
             row += W;
         }
         __builtin_amdgcn_s_setprio(0);
+    } else if (t < 64 && W <= 32) {
+        // levels of 17 .. 32 rows (rate 3/4: layer 5, 12 levels of 31 rows): TWO LANES PER ROW, lane = one packed pair of slots; the pairs meet through one quad permute --
+        // 39 instructions per level where the lane-per-row form below takes 67
+        __builtin_amdgcn_s_setprio(3);
+        typedef __attribute__((address_space(3))) uint32_t lds_u1;
+        const int hp = t & 1, i = t >> 1;                       // the lane's pair of slots (0: slots 0, 1; 1: slots 2, 3), its row of the level
+        uint32_t pr = cwb + (uint32_t)LDPC_SPLIT_REC5 * (uint32_t)i;
+        const uint32_t pstep = (uint32_t)LDPC_SPLIT_REC5 * (uint32_t)W;
+        const uint32_t aoff = 4u + 4u * (uint32_t)hp;           // the pair's address word inside the record
+        const int f0 = 12 * hp;                                  // its two 6-bit message fields
+        uint32_t d0 = *(const lds_u1*)(uintptr_t)pr, aw = *(const lds_u1*)(uintptr_t)(pr + aoff);
+        int row = i + W;
+        for (int lv = 1; lv < depth; ++lv) {
+            const uint32_t r0 = d0, ra = aw;
+            const uint32_t prn = pr + pstep;
+            d0 = *(const lds_u1*)(uintptr_t)prn;
+            aw = *(const lds_u1*)(uintptr_t)(prn + aoff);
+            if (i < W && row < 360) {
+                const uint32_t a0 = ra & 0xffffu, a1 = ra >> 16;
+                uint32_t xr, xh;
+                lds_read_pair_i8(a0, a1, xr, xh);
+                const s16x2 RM = from_bits2(__builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_sbfe((int)r0, f0 + 6, 6), (uint32_t)__builtin_amdgcn_sbfe((int)r0, f0, 6), 0x040c000cu));
+                const s16x2 Q0 = from_bits2(((r0 >> 24) & 0x3fu) * 0x01000100u);
+                const uint32_t s0w = (uint32_t)((int)r0 >> 31) & 0x80008000u;
+                lds_ready_n(0, xr, xh);
+                const s16x2 V = sat_sub2(from_bits2(__builtin_amdgcn_perm(xh, xr, 0x060c000cu)), RM);
+                const s16x2 G = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, pmax2(V, sat_sub2(splat2(0), V))), (u16x2){256, 256}));
+                // for either slot the smallest magnitude among the row's other links: the other slot of the pair, the other pair's two (its lane's minimum), min0 of the rest
+                const s16x2 P = pmin2(G, swap2(G));
+                const s16x2 Po = from_bits2((uint32_t)QUAD_DPP(bits2(P), DPP_SWAP_HALVES));
+                const s16x2 O = pmin2(pmin2(swap2(G), Po), Q0);
+                uint32_t sx = bits2(V) ^ (uint32_t)QUAD_DPP(bits2(V), DPP_SWAP_HALVES);
+                sx ^= __builtin_amdgcn_alignbit(sx, sx, 16);
+                sx ^= s0w;
+                const s16x2 N = from_bits2(sx ^ bits2(V)) >> 15;
+                const s16x2 NM = pmin2(from_bits2(bits2(O) ^ bits2(N)) - N, q8(31));
+                const uint32_t pn = bits2(sat_add2(V, NM)) >> 8;
+                lds_write_lo_i8(a0, pn); lds_write_hi_i8(a1, pn);
+                // the pair's two inputs, for the row's phase C: bytes 2 hp, 2 hp + 1 of the record's first word
+                *(__attribute__((address_space(3))) uint16_t*)(uintptr_t)(pr + 2u * (uint32_t)hp) = (uint16_t)__builtin_amdgcn_perm(0u, bits2(V), 0x0c0c0301u);
+            }
+            pr = prn;
+            row += W;
+        }
+        __builtin_amdgcn_s_setprio(0);
     } else if (t < 64) {
         __builtin_amdgcn_s_setprio(3);
         typedef __attribute__((address_space(3))) uint32_t lds_u1;
