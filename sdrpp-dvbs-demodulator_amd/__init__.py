@@ -212,7 +212,7 @@ def ldpc_split_plan(rate, shortframes=False):
         raise Dvbs2GpuError(rc, lib.dvbs2gpu_last_error().decode())
     return {'npl': npl, 'npw': npw, 'hs': hs, 'rec_total': rec_total, 'rec_dwords': rec_dw, 'kind': (layers[:, 0] & 0xff).astype(int), 'nw': ((layers[:, 0] >> 8) & 0xff).astype(int),
             'nc': ((layers[:, 0] >> 16) & 15).astype(int), 'noprev': ((layers[:, 0] >> 20) & 1).astype(int), 'aux': layers[:, 1].astype(int), 'rec_off': layers[:, 2].astype(int),
-            'ent_off': layers[:, 3].astype(int), 'table': table.reshape(npl, 768, npw), 'row_of': row_of, 'layer': layer_of}
+            'ent_off': layers[:, 3].astype(int), 'table': table[:npl * 768 * npw].reshape(npl, 768, npw), 'words': table, 'row_of': row_of, 'layer': layer_of}
 
 
 class FleetEntry(C.Structure):

@@ -116,7 +116,10 @@ int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
             const LdpcSplitPlan SP = build_ldpc_split_plan(P);
             if (SP.ok) {
                 if ((rc = upload(SP.layers, &D.d_split_layers))) return fail(rc);
-                if ((rc = upload(SP.atab, &D.d_split_atab))) return fail(rc);
+                std::vector<uint32_t> tab(SP.atab);
+                tab.insert(tab.end(), SP.side.begin(), SP.side.end());
+                if ((rc = upload(tab, &D.d_split_atab))) return fail(rc);
+                D.split_tab_words = (int)tab.size();
                 D.split_npl = (int)SP.layers.size(); D.split_rec_total = SP.rec_total;
                 D.split_blocks_per_cu = ldpc_split_blocks_per_cu(P.max_deg, P.N);
                 D.use_split = true;
@@ -582,10 +585,10 @@ int dvbs2gpu_ldpc_split_plan_dump(int rate, int shortframes, uint32_t* layers4, 
     if (!counts6) return DVBS2GPU_ERR_ARG;
     const LdpcPlan P = build_ldpc_plan(f.code_index);
     const LdpcSplitPlan S = build_ldpc_split_plan(P);
-    counts6[0] = S.ok ? (int32_t)S.layers.size() : 0; counts6[1] = S.npw; counts6[2] = S.hs; counts6[3] = S.rec_total; counts6[4] = (int32_t)S.atab.size(); counts6[5] = S.rec_dwords;
+    counts6[0] = S.ok ? (int32_t)S.layers.size() : 0; counts6[1] = S.npw; counts6[2] = S.hs; counts6[3] = S.rec_total; counts6[4] = (int32_t)(S.atab.size() + S.side.size()); counts6[5] = S.rec_dwords;      // (table words: the pseudo-layers' tables, then the side entries of the kind-8 layers -- what the device holds)
     if (!S.ok) return 0;
     if (layers4) memcpy(layers4, S.layers.data(), S.layers.size() * sizeof(LdpcSplitLayer));
-    if (table) memcpy(table, S.atab.data(), S.atab.size() * sizeof(uint32_t));
+    if (table) { memcpy(table, S.atab.data(), S.atab.size() * sizeof(uint32_t)); if (!S.side.empty()) memcpy(table + S.atab.size(), S.side.data(), S.side.size() * sizeof(uint32_t)); }
     if (row_of) for (size_t i = 0; i < S.row_of.size(); ++i) row_of[i] = S.row_of[i];
     if (layer_of) for (size_t i = 0; i < S.layer_of.size(); ++i) layer_of[i] = S.layer_of[i];
     return 0;

@@ -26,7 +26,7 @@ struct LdpcDeviceCode {
     // half-row form (ldpc_split_plan.h / ldpc_split_kernel.hip): two lanes per row, one frame per workgroup
     struct LdpcSplitLayer* d_split_layers = nullptr;
     uint32_t* d_split_atab = nullptr;
-    int split_npl = 0, split_rec_total = 0, split_blocks_per_cu = 1;
+    int split_npl = 0, split_rec_total = 0, split_blocks_per_cu = 1, split_tab_words = 0;
     bool use_split = false;
 };
 

@@ -41,6 +41,7 @@ struct LdpcKernelParams {
     const uint32_t* rows;
     const uint32_t* atab;
     int npl;                              // pseudo-layers (ldpc_split_kernel.hip)
+    int tab_words;                        // words behind atab: the pseudo-layers' tables + the side entries of the kind-8 layers (ldpc_split_plan.h)
 };
 // ldpc_params() reads the structure at offset 0 of the kernel-argument segment: a kernel that uses it takes ONE by-value LdpcKernelParams as its first and only parameter
 // (ldpc_split_kernel), and the launch arguments start with the LdpcKernelArgs member

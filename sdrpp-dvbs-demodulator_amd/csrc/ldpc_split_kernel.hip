@@ -50,12 +50,10 @@ struct SplitShape {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // LDS of a workgroup = posteriors (N bytes) + LDPC_SPLIT_SCRATCH bytes (idle lanes' scratch during a sweep; the syndrome check's flags and the next frame's index outside of
-// one: the two uses never overlap in time) + the hand-off records: 8 bytes per row (chain walk), 12 per row of level > 1 (level walk).  THE TOTAL MUST STAY WITHIN 54 LDS
-// ALLOCATION GRANULES of 1 280 bytes (69 120 bytes for N = 64 800): two decoder workgroups then leave 20 of a compute unit's 128 granules, room for TWO workgroups of the
-// front end's timing recovery (s2_gardner2_kernel: 9 granules each).  Round 6 measured it the hard way: at 56 granules (16-byte records) only ONE fitted, the timing
-// recovery beside the decoder ran in two rounds, and the pipelined step took 333.6 instead of 310.0 ms.
-constexpr int LDPC_SPLIT_LDS_BUDGET = 54 * 1280;
-constexpr int LDPC_SPLIT_REC5 = 12;                                   // bytes per level-walk record
+// one: the two uses never overlap in time) + the hand-off area: 8 bytes per row (the chain walk's records; the speculative passes use 4 bytes per row of it + two flag words).
+// gfx950 hands LDS out in GRANULES of 1 280 bytes: 67 744 bytes for N = 64 800 = 53 of a compute unit's 128, two decoder workgroups leave 22 -- room for TWO workgroups of the
+// front end's timing recovery (s2_gardner2_kernel: 9 granules each) and a PL-sync walk.  Round 6 measured what a granule is worth: at 56 per decoder workgroup (16-byte level-walk
+// records, since gone) only ONE timing-recovery workgroup fitted, the timing recovery beside the decoder ran in two rounds, and the pipelined step took 333.6 instead of 310.0 ms.
 
 __device__ __forceinline__ void lds_read_lo_i8(uint32_t a_lo, uint32_t& r_lo) {
     if (LDPC_EXP & 4) { r_lo = a_lo & 0xffu; return; }
@@ -137,7 +135,7 @@ struct RowState {
 // input phase: posteriors in, extrinsic values, the row's two smallest magnitudes and sign -- M0 / M1 / SXs come back with BOTH halves of the
 // word holding the whole row's value (a word with equal halves orders like its 16-bit value under 32-bit signed compares; SXs: sign in bits 15 and 31).
 // LATE < 0: the whole first -LATE pairs are left out of
-// the totals where `late` is not zero (chain walk: 1, level walk: 2) -- V / G keep the values read
+// the totals where `late` is not zero (chain walk: 1, speculative passes: 2) -- V / G keep the values read
 // NOPREV: the pseudo-layer holds row 0 of layer 0, which has no previous parity bit (kind 7: a conflict-free layer; the plan refuses codes whose layer 0 has shared bits) --
 // a kind of its own, so that the other 44 layers of a sweep do not carry the test (r05: 7 vector instructions per wave and layer)
 template <int MAXDEG, int LATE, int NOPREV = 0>     // NOPREV 2: asked at run time (A/B builds, -DLDPC_SPLIT_NOPREV_RT)
@@ -396,190 +394,124 @@ __device__ __forceinline__ LdpcSplitLayer layer_at(const_layer_ptr layers, int i
     L.kind_nw = layers[i].kind_nw; L.aux = layers[i].aux; L.rec_off = layers[i].rec_off; L.ent_off = layers[i].ent_off;
     return L;
 }
-// A layer whose shared links are two pairs or a triple (slots 0..3 of half 0 cover them), levels = runs of W <= 64 consecutive rows (ldpc_split_plan.h; rate 3/4:
-// layers 3, 5, 42 with 6, 12 and 33 levels): the LEVEL WALK.  Round 5 ran these as a workgroup barrier per level (~1 050 cycles per level) or as ldpc_kernel.hip's quad
-// walk (four lanes per row, 640 cycles per step); together 21 % of a sweep for 3 of its 45 layers.  Here ONE wave walks the levels in order, lane = row of the level, and
-// treats the four slots UNIFORMLY -- no late / early flags anywhere:
-//   phase A  every row: the input phase; rows of level > 1 keep their first two pairs (slots 0..3) out of the totals and leave a record {the four slots' old messages,
-//            min0 | sign of the other ten links}.  Rows of level 1 (no predecessor in the layer) finish here, early slots included.
-//   walk     wave 0, step k = level k + 1, lane i = row W k + i: the four slots' posteriors as they stand NOW (a slot nobody has touched in this layer still holds what
-//            phase A read: recomputing its input gives the same value), inputs, magnitudes, for every slot the minimum over the other three and the record's min0,
-//            new messages, new posteriors -- packed, two slots per instruction -- written back at once: the next level reads them (the LDS pipeline is in order; a row's
-//            later toucher simply overwrites).  The four inputs go back into the record for phase C.
-//   phase C  rows of level > 1: the four inputs from the record join the totals (as the chain layer's pair does), then the output phase, which leaves slots 0..3 of half 0
-//            to the walker's stores.
-// Bit-exact by construction: every value is the reference's for the row order (layered_decoder.hh:46-74) -- a row reads a shared bit after exactly the rows before it.
+// A layer with shared links handled SPECULATIVELY (kind 8; rate 3/4: layers 3, 5, 42 -- two shared pairs / a triple, 6 / 12 / 33 dependency levels -- and layer 18, one pair
+// in two chains of 179 rows).  Rounds 5 / 6 walked such layers level by level with ONE wave (a barrier per level, a quad walk, the level walk: 7.8 / 11.5 / 18.4 / 21.8 k cycles
+// of a 192 k sweep, the other eleven waves waiting).  Here every row of level > 1 runs in ITS OWN lane, all at once, in PASSES:
+//   phase A  every row: the input phase; rows of level > 1 keep slots 0..3 out of the totals.  Rows of level 1 (no predecessor in the layer) finish here, shared slots included.
+//   passes   a row of level > 1 reads the posteriors of its four slots from their SOURCES -- the bit itself where nobody of level > 1 touches it before this row, else the
+//            output cell of the row that does (cw[row]: four bytes, one per slot; the plan's side entry names the cell) --, computes inputs, magnitudes, for every slot the
+//            minimum over the other three and the rest of the row, new messages, new posteriors, and writes its own cell.  After pass p the rows of level <= p + 2 hold their
+//            final values (induction over the levels), so depth - 1 passes always suffice; a pass in which NO row read anything new ends the layer earlier: the cells then
+//            are a fixed point of "every row computed from its predecessors' outputs", and by the same induction there is only one -- the reference's sequential result
+//            (layered_decoder.hh:46-74: a row reads a shared bit after exactly the rows before it).  What a row reads in its first pass is the bit as the previous layer
+//            left it -- on a frame that has converged that IS what its predecessor will write, and every layer ends after two passes; an early, noisy sweep takes a few more
+//            (a changed input reaches the next row's output only through the min, which mostly ignores it).  Reads race with the same pass's writes: a newer value is as good.
+//   phase C  rows of level > 1: the four inputs of the last pass join the totals, then the output phase; a slot a LATER row touches stays unwritten (that row owns the bit).
+// Bit-exact by construction; the time depends on the data (passes), the result does not.
+#ifndef LDPC_SPLIT_SPEC_STATS
+#define LDPC_SPLIT_SPEC_STATS 0      // development aid: prof[512 + 32 * (pseudo-layer % 11) + passes] counts the layers of workgroup 0 by passes taken (tools/ldpc_split_prof.py)
+#endif
 template <int MAXDEG>
-__device__ __forceinline__ void level_layer(RowState<MAXDEG>& R, uint32_t (&rec_out)[SplitShape<MAXDEG>::REC], const LdpcSplitLayer L, const_u32_ptr ents, const int t,
-                                            uint32_t* __restrict__ cw) {
-    static_assert(SplitShape<MAXDEG>::HS >= 4, "the level walk covers slots 0..3 of half 0");
+__device__ __forceinline__ void spec_layer(RowState<MAXDEG>& R, uint32_t (&rec_out)[SplitShape<MAXDEG>::REC], const LdpcSplitLayer L, const uint32_t* __restrict__ tab, const int t,
+                                           uint32_t* __restrict__ cw, [[maybe_unused]] unsigned long long* prof, [[maybe_unused]] const int pl) {
+    static_assert(SplitShape<MAXDEG>::HS >= 4, "the shared links are slots 0..3 of half 0");
+    typedef __attribute__((address_space(3))) uint32_t lds_u1;
     const uint32_t level = R.rw & 0xffu;               // (both halves carry it; idle lanes: 0)
     const int j = t >> 1;
     const bool half1 = (t & 1) != 0;
-    const int W = (int)(L.aux & 0xffffu), depth = (int)(L.aux >> 16);
-    int M0, M1, SXs;
-    row_input<MAXDEG, -2>(R, (level > 1u && !half1) ? 1u : 0u, 1u, t, M0, M1, SXs);
-    if (level == 1u) row_output<MAXDEG, 0>(R, M0, M1, SXs, 0u, rec_out);
-    if (level > 1u && !half1) {
-        // {m0 m1 m2 m3} | {min(min0 of the other links, 32) in both halves (Q8), their sign product in bits 15 and 31} | the four slots' LDS addresses: the walker, whose every
-        // instruction is serial time of the workgroup (~10 cycles each beside the other workgroup's waves), only takes them apart
-        // 12 bytes, rows of level > 1 only (index row - W): {the four old messages as 6-bit fields | min(min0 of the other links, 32) << 24 | their sign product in bit 31}, a0 | a1 << 16, a2 | a3 << 16
-        const uint32_t r0 = bits2(R.RP[0]), r1 = bits2(R.RP[1]);
-        const uint32_t mf = ((r0 >> 8) & 0x3fu) | ((r0 >> 18) & 0xfc0u) | ((r1 << 4) & 0x3f000u) | ((r1 >> 6) & 0xfc0000u);
-        const uint32_t d0 = mf | ((uint32_t)min(M0 >> 24, 32) << 24) | ((uint32_t)SXs & 0x80000000u);
-        uint32_t* rp = cw + 3 * (j - W);          // (12-byte stride: dword accesses)
-        rp[0] = d0; rp[1] = R.addr[0] | (R.addr[1] << 16); rp[2] = R.addr[2] | (R.addr[3] << 16);
+    const bool spec = level > 1u && !half1;
+    const int depth = (int)(L.aux >> 16);
+    // the row's side entry {f0 | f1 << 16, f2 | f3 << 16}: f & 0x7ff = distance from the row's own cell back to slot's source cell (0: the bit itself), bit 15: a later row touches the slot
+    // (fetched behind the compiler's back and claimed by hand behind the first pass: a load the compiler sees inside ONE kind's branch makes it open the claims of the layer
+    // loop -- every kind's -- with vmcnt(0), which also waits for the previous pseudo-layer's record store: +10 % on the whole kernel when tried)
+    u32x2 side;
+    {
+        const uint64_t sbase = (uint64_t)(uintptr_t)(tab + L.ent_off);
+        const uint32_t voff = (uint32_t)j * 8u;
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(side) : "v"(voff), "s"(sbase) : "memory");
     }
-    lds_pairs_wait();
-    lds_barrier();
+    int M0, M1, SXs;
+    row_input<MAXDEG, -2>(R, spec ? 1u : 0u, 1u, t, M0, M1, SXs);
+    if (level == 1u) row_output<MAXDEG, 0>(R, M0, M1, SXs, 0u, rec_out);
     uint32_t cwb = lds_offset(reinterpret_cast<const int8_t*>(cw));
     asm volatile("" : "+s"(cwb));
-    if (t < 64 && W <= 16) {
-        // narrow levels (rate 3/4: layer 42, 33 levels of 11 rows -- two thirds of a sweep's level steps): FOUR LANES PER ROW, lane = slot, plain 32-bit arithmetic, the
-        // slots meet through quad permutes -- 29 instructions per level where the lane-per-row form below takes 58 (a walker instruction is ~10 cycles of serial time)
-        __builtin_amdgcn_s_setprio(3);
-        const int k = t & 3, i = t >> 2;
-        uint32_t pr = cwb + (uint32_t)LDPC_SPLIT_REC5 * (uint32_t)i;          // (records start at row W)
-        const uint32_t pstep = (uint32_t)LDPC_SPLIT_REC5 * (uint32_t)W;
-        const uint32_t asel = k == 0 ? 0x0c0c0100u : k == 1 ? 0x0c0c0302u : k == 2 ? 0x0c0c0504u : 0x0c0c0706u;        // the slot's 16-bit address out of {a01, a23}
-        typedef __attribute__((address_space(3))) uint32_t lds_u1;
-        u32x2 rec = LDS_U2_A4(pr);
-        uint32_t rec2 = *(const lds_u1*)(uintptr_t)(pr + 8u);
-        int row = i + W;
-        for (int lv = 1; lv < depth; ++lv) {
-            const u32x2 r = rec;
-            const uint32_t r2 = rec2;
-            const uint32_t prn = pr + pstep;
-            rec = LDS_U2_A4(prn);
-            rec2 = *(const lds_u1*)(uintptr_t)(prn + 8u);
-            if (i < W && row < 360) {
-                const uint32_t a = __builtin_amdgcn_perm(r2, r.y, asel);
-                const int x = (int)LDS_I8(a);
-                const int m = (int)__builtin_amdgcn_sbfe((int)r.x, 6 * k, 6);
-                const int q0 = (int)((r.x >> 24) & 0x3fu);                     // min(min0 of the other links, 32)
-                const int v = clamp8(x - m);
-                const int g = mag_of(v);
-                // the smallest magnitude among the row's other links: the three other slots (quad rotations) and the rest
-                int o = min(q0, (int)__builtin_amdgcn_update_dpp(0, g, 0x39, 0xf, 0xf, true));          // quad_perm [1,2,3,0]
-                o = min(o, (int)__builtin_amdgcn_update_dpp(0, g, 0x4E, 0xf, 0xf, true));                // quad_perm [2,3,0,1]
-                o = min(o, (int)__builtin_amdgcn_update_dpp(0, g, 0x93, 0xf, 0xf, true));                // quad_perm [3,0,1,2]
-                int sx = v ^ (int)__builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);               // quad_perm [1,0,3,2]
-                sx ^= (int)__builtin_amdgcn_update_dpp(0, sx, 0x4E, 0xf, 0xf, true);
-                const int neg = (sx ^ (int)r.x ^ v) >> 31;
-                const int nm = med3i((o ^ neg) - neg, -32, 31);
-                LDS_I8(a) = (int8_t)clamp8(v + nm);
-                LDS_I8(pr + (uint32_t)k) = (int8_t)v;                          // the slot's input, for the row's phase C (the four lanes of a row fill the record's first word)
-            }
-            pr = prn;
-            row += W;
-        }
-        __builtin_amdgcn_s_setprio(0);
-    } else if (t < 64 && W <= 32) {
-        // levels of 17 .. 32 rows (rate 3/4: layer 5, 12 levels of 31 rows): TWO LANES PER ROW, lane = one packed pair of slots; the pairs meet through one quad permute --
-        // 39 instructions per level where the lane-per-row form below takes 67
-        __builtin_amdgcn_s_setprio(3);
-        typedef __attribute__((address_space(3))) uint32_t lds_u1;
-        const int hp = t & 1, i = t >> 1;                       // the lane's pair of slots (0: slots 0, 1; 1: slots 2, 3), its row of the level
-        uint32_t pr = cwb + (uint32_t)LDPC_SPLIT_REC5 * (uint32_t)i;
-        const uint32_t pstep = (uint32_t)LDPC_SPLIT_REC5 * (uint32_t)W;
-        const uint32_t aoff = 4u + 4u * (uint32_t)hp;           // the pair's address word inside the record
-        const int f0 = 12 * hp;                                  // its two 6-bit message fields
-        uint32_t d0 = *(const lds_u1*)(uintptr_t)pr, aw = *(const lds_u1*)(uintptr_t)(pr + aoff);
-        int row = i + W;
-        for (int lv = 1; lv < depth; ++lv) {
-            const uint32_t r0 = d0, ra = aw;
-            const uint32_t prn = pr + pstep;
-            d0 = *(const lds_u1*)(uintptr_t)prn;
-            aw = *(const lds_u1*)(uintptr_t)(prn + aoff);
-            if (i < W && row < 360) {
-                const uint32_t a0 = ra & 0xffffu, a1 = ra >> 16;
-                uint32_t xr, xh;
-                lds_read_pair_i8(a0, a1, xr, xh);
-                const s16x2 RM = from_bits2(__builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_sbfe((int)r0, f0 + 6, 6), (uint32_t)__builtin_amdgcn_sbfe((int)r0, f0, 6), 0x040c000cu));
-                const s16x2 Q0 = from_bits2(((r0 >> 24) & 0x3fu) * 0x01000100u);
-                const uint32_t s0w = (uint32_t)((int)r0 >> 31) & 0x80008000u;
-                lds_ready_n(0, xr, xh);
-                const s16x2 V = sat_sub2(from_bits2(__builtin_amdgcn_perm(xh, xr, 0x060c000cu)), RM);
-                const s16x2 G = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, pmax2(V, sat_sub2(splat2(0), V))), (u16x2){256, 256}));
-                // for either slot the smallest magnitude among the row's other links: the other slot of the pair, the other pair's two (its lane's minimum), min0 of the rest
-                const s16x2 P = pmin2(G, swap2(G));
-                const s16x2 Po = from_bits2((uint32_t)QUAD_DPP(bits2(P), DPP_SWAP_HALVES));
-                const s16x2 O = pmin2(pmin2(swap2(G), Po), Q0);
-                uint32_t sx = bits2(V) ^ (uint32_t)QUAD_DPP(bits2(V), DPP_SWAP_HALVES);
-                sx ^= __builtin_amdgcn_alignbit(sx, sx, 16);
-                sx ^= s0w;
-                const s16x2 N = from_bits2(sx ^ bits2(V)) >> 15;
-                const s16x2 NM = pmin2(from_bits2(bits2(O) ^ bits2(N)) - N, q8(31));
-                const uint32_t pn = bits2(sat_add2(V, NM)) >> 8;
-                lds_write_lo_i8(a0, pn); lds_write_hi_i8(a1, pn);
-                // the pair's two inputs, for the row's phase C: bytes 2 hp, 2 hp + 1 of the record's first word
-                *(__attribute__((address_space(3))) uint16_t*)(uintptr_t)(pr + 2u * (uint32_t)hp) = (uint16_t)__builtin_amdgcn_perm(0u, bits2(V), 0x0c0c0301u);
-            }
-            pr = prn;
-            row += W;
-        }
-        __builtin_amdgcn_s_setprio(0);
-    } else if (t < 64) {
-        __builtin_amdgcn_s_setprio(3);
-        typedef __attribute__((address_space(3))) uint32_t lds_u1;
-        uint32_t pr = cwb + (uint32_t)LDPC_SPLIT_REC5 * (uint32_t)t;          // record of the lane's row of the level in hand (records start at row W); a level's last rows may lie
-        const uint32_t pstep = (uint32_t)LDPC_SPLIT_REC5 * (uint32_t)W;       // past row 359: such a read lands in LDS the workgroup owns (or beyond: zeros) and its lane is masked
-        u32x2 rec = LDS_U2_A4(pr);
-        uint32_t rec2 = *(const lds_u1*)(uintptr_t)(pr + 8u);
-        int row = t + W;
-        for (int k = 1; k < depth; ++k) {
-            const u32x2 r = rec;
-            const uint32_t r2 = rec2;
-            const uint32_t prn = pr + pstep;
-            rec = LDS_U2_A4(prn);                                  // the next level's record (written in phase A: no dependence on this step)
-            rec2 = *(const lds_u1*)(uintptr_t)(prn + 8u);
-            if (t < W && row < 360) {
-                const uint32_t a0 = r.y & 0xffffu, a1 = r.y >> 16, a2 = r2 & 0xffffu, a3 = r2 >> 16;
+    const uint32_t flagb = cwb + 4u * 384u;            // two words behind the cells: flag[p & 1] = p + 1 where a row read something new in pass p
+    if (t == 0) { *(lds_u1*)(uintptr_t)flagb = 0u; *(lds_u1*)(uintptr_t)(flagb + 4u) = 0u; }
+    const uint32_t cell = cwb + 4u * (uint32_t)j;
+    // (the FIRST pass reads every slot from its bit -- the guess: what the previous layer left there; the later ones from the sources)
+    uint32_t cur[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) cur[s] = R.addr[s];
+    const s16x2 Q0 = from_bits2((uint32_t)min(M0 >> 24, 32) * 0x01000100u);      // min(min0 of the other links, 32) in both halves (Q8)
+    const uint32_t s0w = (uint32_t)(SXs >> 31) & 0x80008000u;                     // their sign product in bits 15 and 31
+    lds_pairs_wait();
+    lds_barrier();
+    s16x2 V0 = R.V[0], V1 = R.V[1];
+    uint32_t X0p = 0, X1p = 0;
+    int p = 0;
+    bool voted = false;                                 // the layer ended on a vote: its barrier already lies behind the last pass
+    const bool any_spec = __builtin_amdgcn_ballot_w64(spec) != 0;
+    for (;;) {
+        bool ch = false;
+        if (any_spec) {
+            if (spec) {
                 uint32_t xr0, xh0, xr1, xh1;
-                lds_read_pair_i8(a0, a1, xr0, xh0);
-                lds_read_pair_i8(a2, a3, xr1, xh1);
-                // the record's 6-bit fields -> Q8 pairs (byte 0 of either extract into the high bytes of the two halves)
-                const s16x2 RM0 = from_bits2(__builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_sbfe((int)r.x, 6, 6), (uint32_t)__builtin_amdgcn_sbfe((int)r.x, 0, 6), 0x040c000cu));
-                const s16x2 RM1 = from_bits2(__builtin_amdgcn_perm((uint32_t)__builtin_amdgcn_sbfe((int)r.x, 18, 6), (uint32_t)__builtin_amdgcn_sbfe((int)r.x, 12, 6), 0x040c000cu));
-                const s16x2 Q0 = from_bits2(((r.x >> 24) & 0x3fu) * 0x01000100u);          // min(min0 of the other links, 32) in both halves (Q8)
-                const uint32_t s0w = (uint32_t)((int)r.x >> 31) & 0x80008000u;              // their sign product in bits 15 and 31
+                lds_read_pair_i8(cur[0], cur[1], xr0, xh0);
+                lds_read_pair_i8(cur[2], cur[3], xr1, xh1);
                 lds_ready_n(0, xr0, xh0);
                 asm volatile("" : "+v"(xr1), "+v"(xh1));
-                const s16x2 V0 = sat_sub2(from_bits2(__builtin_amdgcn_perm(xh0, xr0, 0x060c000cu)), RM0);
-                const s16x2 V1 = sat_sub2(from_bits2(__builtin_amdgcn_perm(xh1, xr1, 0x060c000cu)), RM1);
+                const uint32_t X0 = __builtin_amdgcn_perm(xh0, xr0, 0x060c000cu), X1 = __builtin_amdgcn_perm(xh1, xr1, 0x060c000cu);
+                ch = ((X0 ^ X0p) | (X1 ^ X1p)) != 0;
+                X0p = X0; X1p = X1;
+                V0 = sat_sub2(from_bits2(X0), R.RP[0]);
+                V1 = sat_sub2(from_bits2(X1), R.RP[1]);
                 const s16x2 G0 = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, pmax2(V0, sat_sub2(splat2(0), V0))), (u16x2){256, 256}));
                 const s16x2 G1 = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, pmax2(V1, sat_sub2(splat2(0), V1))), (u16x2){256, 256}));
                 // for every slot the smallest magnitude among the row's OTHER links: the other slot of its pair, both slots of the other pair, min0 of the rest (limited to 32)
                 const s16x2 P0 = pmin2(G0, swap2(G0)), P1 = pmin2(G1, swap2(G1));
                 const s16x2 O0 = pmin2(pmin2(swap2(G0), P1), Q0), O1 = pmin2(pmin2(swap2(G1), P0), Q0);
-                // sign of the row: the record's product times the four slots' (bits 15 and 31 after the fold; the record word's other bits ride along unused)
+                // sign of the row: the rest's product times the four slots' (bits 15 and 31 after the fold)
                 uint32_t sx = bits2(V0) ^ bits2(V1);
                 sx ^= __builtin_amdgcn_alignbit(sx, sx, 16);
                 sx ^= s0w;
                 const s16x2 N0 = from_bits2(sx ^ bits2(V0)) >> 15, N1 = from_bits2(sx ^ bits2(V1)) >> 15;
                 const s16x2 NM0 = pmin2(from_bits2(bits2(O0) ^ bits2(N0)) - N0, q8(31)), NM1 = pmin2(from_bits2(bits2(O1) ^ bits2(N1)) - N1, q8(31));
-                const uint32_t pn0 = bits2(sat_add2(V0, NM0)) >> 8, pn1 = bits2(sat_add2(V1, NM1)) >> 8;
-                lds_write_lo_i8(a0, pn0); lds_write_hi_i8(a1, pn0);
-                lds_write_lo_i8(a2, pn1); lds_write_hi_i8(a3, pn1);
-                // the four inputs, for the row's phase C
-                *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)pr = __builtin_amdgcn_perm(bits2(V1), bits2(V0), 0x07050301u);
+                // the four new posteriors into the row's cell (byte s = slot s)
+                *(lds_u1*)(uintptr_t)cell = __builtin_amdgcn_perm(bits2(sat_add2(V1, NM1)), bits2(sat_add2(V0, NM0)), 0x07050301u);
             }
-            pr = prn;
-            row += W;
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (p == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(side) : : "memory");
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const uint32_t f = ((s < 2 ? side.x : side.y) >> (16 * (s & 1))) & 0x7ffu;
+                cur[s] = f ? cell - f : R.addr[s];
+            }
+        }
+        ++p;
+        if (p >= depth - 1) break;                      // (the rows of every level have had their final inputs: no vote)
+        // a row that read something new in this pass asks for another one (the first pass read guesses: no vote either)
+        if (p > 1 && __builtin_amdgcn_ballot_w64(ch) != 0 && (t & 63) == 0) *(lds_u1*)(uintptr_t)(flagb + 4u * (uint32_t)(p & 1)) = (uint32_t)p + 1u;
+        lds_pairs_wait();
+        lds_barrier();
+        if (p > 1) {
+            const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const lds_u1*)(uintptr_t)(flagb + 4u * (uint32_t)(p & 1)));
+            if (fl != (uint32_t)p + 1u) { voted = true; break; }
+        }
     }
-    lds_pairs_wait();
-    lds_barrier();
+#if LDPC_SPLIT_SPEC_STATS
+    if (prof && blockIdx.x == 0 && t == 0) prof[512 + 32 * (pl % 11) + (p < 31 ? p : 31)] += 1;
+#endif
+    // (phase C writes bits that rows of other waves read as sources in their last pass)
+    if (!voted) { lds_pairs_wait(); lds_barrier(); }
     if (level > 1u) {
         if (!half1) {
-            const uint32_t vb = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(cwb + (uint32_t)LDPC_SPLIT_REC5 * (uint32_t)(j - W));
-            R.V[0] = rec_pair_dw(vb, 0); R.V[1] = rec_pair_dw(vb, 2);
+            R.V[0] = V0; R.V[1] = V1;
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                R.G[p] = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, pmax2(R.V[p], sat_sub2(splat2(0), R.V[p]))), (u16x2){256, 256}));
+            for (int q = 0; q < 2; ++q) {
+                R.G[q] = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, pmax2(R.V[q], sat_sub2(splat2(0), R.V[q]))), (u16x2){256, 256}));
                 // the pair joins the totals: its smaller magnitude first, then the larger one (words with equal halves: 32-bit operations)
-                const int a = (int)bits2(pmin2(R.G[p], swap2(R.G[p]))), b = (int)bits2(pmax2(R.G[p], swap2(R.G[p])));
+                const int a = (int)bits2(pmin2(R.G[q], swap2(R.G[q]))), b = (int)bits2(pmax2(R.G[q], swap2(R.G[q])));
                 M1 = min(M1, max(M0, a));
                 M0 = min(M0, a);
                 M1 = min(M1, max(M0, b));
@@ -590,7 +522,8 @@ __device__ __forceinline__ void level_layer(RowState<MAXDEG>& R, uint32_t (&rec_
         M0 = QUAD_DPP(M0, DPP_FROM_HALF0);
         M1 = QUAD_DPP(M1, DPP_FROM_HALF0);
         SXs = QUAD_DPP(SXs, DPP_FROM_HALF0);
-        row_output<MAXDEG, 4>(R, M0, M1, SXs, half1 ? 0u : 15u, rec_out);          // (slots 0..3 of half 0: the walker has written them)
+        const uint32_t early = ((side.x >> 15) & 1u) | ((side.x >> 30) & 2u) | ((side.y >> 13) & 4u) | ((side.y >> 28) & 8u);
+        row_output<MAXDEG, 4>(R, M0, M1, SXs, half1 ? 0u : early, rec_out);          // (a slot a later row touches stays unwritten)
     }
 }
 #undef LINK_IN
@@ -645,11 +578,11 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
             const const_layer_ptr layers = (const_layer_ptr)P->layers;
             const const_u32_ptr ents = (const_u32_ptr)P->ents;
             const int npad = (N + LDPC_SPLIT_SCRATCH + 15) & ~15;                // posteriors + the scratch bytes (ldpc_split_plan.h)
-            uint32_t* __restrict__ cw = reinterpret_cast<uint32_t*>(lds_all + npad);      // hand-off records: 8 bytes per row (chain walk) / 16 (level walk)
+            uint32_t* __restrict__ cw = reinterpret_cast<uint32_t*>(lds_all + npad);      // hand-off area: 8 bytes per row (chain walk) / 4 bytes per row + 2 flag words (speculative passes)
             int* __restrict__ s_flag = reinterpret_cast<int*>(lds_all + N);                // [12] + next frame, in the sweep's scratch bytes (LDPC_SPLIT_SCRATCH = 64)
             uint32_t* __restrict__ msg = A.msg_ws + (size_t)blockIdx.x * (size_t)A.pent_base;
             uint32_t* __restrict__ sgn = A.sgn_ws + (size_t)blockIdx.x * SGN_WS_DWORDS;
-            const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(P->atab), 0, npl * (T * NPW * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(P->atab), 0, P->tab_words * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t rs_msg = __builtin_amdgcn_make_buffer_rsrc(msg, 0, A.pent_base * 4, 0x00020000);
             const bool check = !A.force || it == A.max_trials;
             if (check) {
@@ -741,7 +674,7 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                 } else if ((L.kind_nw & 0xffu) == 1) {
                     chain_layer<MAXDEG>(RS, ro, L, ents[L.ent_off + 1], tt, post, cw);
                 } else {
-                    level_layer<MAXDEG>(RS, ro, L, ents + L.ent_off, tt, cw);
+                    spec_layer<MAXDEG>(RS, ro, L, P->atab, tt, cw, A.prof, pl);
                 }
                 // the next pseudo-layer's words are claimed HERE, before this one's record store is issued: the wait for them then sits where they have had a whole
                 // pseudo-layer to arrive, and the top of the next pseudo-layer waits for nothing (ldpc_kernel.hip)
@@ -806,10 +739,10 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
     }
 }
 
-// posteriors + scratch, then the records: up to the granule budget for the normal frames (the plan keeps the records within it: ldpc_split_plan.h), 8 bytes x 360 rows at least
+// posteriors + scratch, then the hand-off area: 8 bytes x 360 rows (spec_layer's cells and flags end at 4 * 384 + 8 bytes of it)
 size_t ldpc_split_lds_bytes(int N) {
     const size_t npad = (size_t)((N + LDPC_SPLIT_SCRATCH + 15) & ~15);
-    return std::max(npad + 8 * 360, (size_t)LDPC_SPLIT_LDS_BUDGET);
+    return npad + 8 * 360;
 }
 size_t ldpc_split_msg_bytes_per_block(const LdpcDeviceCode& C) { return (size_t)C.split_rec_total * sizeof(uint32_t); }
 
@@ -820,7 +753,7 @@ static hipError_t launch_split(const LdpcDeviceCode& C, const LdpcKernelArgs& A,
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     LdpcKernelParams P;
-    P.A = A; P.layers = C.d_split_layers; P.ents = C.d_ents; P.atab = C.d_split_atab; P.rows = C.d_rows; P.npl = C.split_npl;
+    P.A = A; P.layers = C.d_split_layers; P.ents = C.d_ents; P.atab = C.d_split_atab; P.rows = C.d_rows; P.npl = C.split_npl; P.tab_words = C.split_tab_words;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(LDPC_SPLIT_T), lds, stream, P);
     return hipGetLastError();
 }

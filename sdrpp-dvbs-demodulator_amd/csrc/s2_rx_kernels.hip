@@ -129,6 +129,11 @@ __device__ __forceinline__ cf32 phasor_hw(float x) { return phasor(x); }
 #ifndef FL_PRIO
 #define FL_PRIO 2
 #endif
+#ifndef POST_PRIO
+#define POST_PRIO 1   // wave priority of the data-parallel post stages (RRC, PL-sync walk, demapper) beside the decoder.  Round 6: at 0 -- the decoder's own -- an RRC slice took 35-44 ms
+                      // beside the decoder (6 alone), a PL-sync walk 30 (5): they share the AGC's stream, so the AGC slices, and behind them the timing recovery, waited for them --
+                      // the front end was the step (299.7 ms; 285.4 at 1, 285.9 at 2: same call, tools/ab.sh)
+#endif
 #ifndef FE_PRIO
 #define FE_PRIO 2   // wave priority of the serial front-end loops (A/B switch; the decoder's parallel phases run at 0, its serial ones at 3)
 #endif
@@ -1129,6 +1134,7 @@ __global__ __launch_bounds__(192) void s2_gardner_cand_kernel(const S2StreamWork
 // sub / nsub: only the symbols whose windows the timing recovery's slice `sub` completed (the decimator phase and the delay line are
 // the call's: they change in s2_rrc_state_kernel, after the last slice); nsub == 1: the whole call
 __global__ __launch_bounds__(256) void s2_rrc_decim_kernel(const S2StreamWork* __restrict__ work, const float* __restrict__ taps_g, int ntaps, int sub, int nsub) {
+    if (POST_PRIO) __builtin_amdgcn_s_setprio(POST_PRIO);
     // a block = 256 consecutive kept symbols of one stream; their 2*256 + ntaps - 2 input samples go through LDS once (each is
     // used by up to (ntaps+1)/2 outputs: reading them from L2 per output cost 46 GB per step and competed with the LDPC messages).
     // The window lies DE-INTERLEAVED in LDS -- even samples in xe, odd ones in xo, re and im side by side: output t reads xe[t + k/2] / xo[t + k/2] for
@@ -1904,6 +1910,7 @@ template <bool MIXED>
 __global__ __launch_bounds__(256) void s2_demap_kernel(S2ConstelDev C_arg, int rate, int slots, int pilots, int plframe,
                                                        const cf32* __restrict__ pllout, int8_t* __restrict__ llr, int N, const int* __restrict__ slot,
                                                        const S2StreamCfgDev* __restrict__ cfgs, int maxf, int8_t* const* __restrict__ llr_of) {
+    if (POST_PRIO) __builtin_amdgcn_s_setprio(POST_PRIO);
     const int f = blockIdx.y;
     const cf32* __restrict__ fr = pllout + (size_t)(slot ? slot[f] : f) * plframe;      // (stage pipeline: the loops wrote frame f to its stream's slot)
     int8_t* __restrict__ out = llr + (size_t)f * N;
@@ -1985,6 +1992,7 @@ __global__ __launch_bounds__(256) void s2_ccm_walk_kernel(const S2StreamWork* __
     __shared__ cf32 d[256 + 96];
     __shared__ float r_val[256];
     __shared__ int r_idx[256];
+    if (POST_PRIO) __builtin_amdgcn_s_setprio(POST_PRIO);
     const int s = blockIdx.x, tid = threadIdx.x;
     if (cfgs) raw = cfgs[s].plframe;             // mixed batch: the PLFRAME length of THIS stream's MODCOD
     const S2StreamWork w = work[s];

@@ -315,8 +315,8 @@ def test_ldpc_address_table_holds_the_links_of_every_row(pkg, rate, short):
 def test_ldpc_split_plan_keeps_the_reference_row_order(pkg, rate, short):
     """the half-row decoder's plan (csrc/ldpc_split_plan.h): every row of every layer appears
     exactly once, its table entry names exactly the bits the reference's row touches (information bits, own and previous parity bit), and two rows of a layer that
-    share a bit run in the reference's order -- separated by a barrier (different pseudo-layers) unless the pseudo-layer resolves shared links itself (kinds 1, 5,
-    whose row words are the lane-per-row plan's, checked above); every pseudo-layer runs all twelve waves"""
+    share a bit run in the reference's order -- separated by a barrier (different pseudo-layers) unless the pseudo-layer resolves shared links itself (kinds 1, 8:
+    test_ldpc_split_plan_side_entries below); every pseudo-layer runs all twelve waves"""
     sp = pkg.ldpc_split_plan(rate, short)
     p = orc.fec_params(rate, short)
     N, K = p['N'], p['K']
@@ -366,10 +366,58 @@ def test_ldpc_split_plan_keeps_the_reference_row_order(pkg, rate, short):
                 within.setdefault(b, []).append(j)
         for b, js in within.items():
             if len(js) > 1:                                                          # rows of ONE pseudo-layer share a bit: only where it orders shared links itself
-                assert kind in (1, 5), (pl, i, js)
+                assert kind in (1, 8), (pl, i, js)
         for j, bits in rows_here:
             for b in bits: last_touch[b] = (i, j)
     assert (seen == 1).all()
+
+
+@pytest.mark.parametrize('rate', [6, 3, 4])
+def test_ldpc_split_plan_side_entries(pkg, rate):
+    """the speculative passes (kind 8, csrc/ldpc_split_kernel.hip: spec_layer) read a shared slot from the output cell of the row that touched the bit last before this
+    row -- in the reference's row order (layered_decoder.hh:46-74) -- or from the bit itself where that row has level 1 or does not exist; the plan's side entries must say
+    exactly that, a row's level must be one more than its deepest predecessor's, and only slots 0..3 of half 0 may be shared"""
+    sp = pkg.ldpc_split_plan(rate, False)
+    hs, N = sp['hs'], orc.fec_params(rate, False)['N']
+    seen8 = 0
+    for pl in range(sp['npl']):
+        if int(sp['kind'][pl]) != 8:
+            continue
+        seen8 += 1
+        tab = sp['table'][pl]
+        side = sp['words'][int(sp['ent_off'][pl]):int(sp['ent_off'][pl]) + 2 * 384].reshape(384, 2)
+        depth = int(sp['aux'][pl]) >> 16
+        last = {}; level = {}
+        succ_want = {}
+        for j in range(360):
+            assert int(sp['row_of'][pl, j]) == j
+            addrs = []
+            for h in (0, 1):
+                addrs += [(int(tab[2 * j + h, s >> 1]) >> (16 * (s & 1))) & 0xffff for s in range(hs)]
+            rw = [(int(tab[2 * j + h, hs >> 1]) >> (16 * (hs & 1))) & 0xffff for h in (0, 1)]
+            lvl = 1
+            for k, a in enumerate(addrs):
+                if a >= N:
+                    continue              # (a neutral slot's scratch byte)
+                f = (int(side[j, k >> 1]) >> (16 * (k & 1))) & 0x7ff if k < 4 else 0
+                if a in last:
+                    assert k < 4, (pl, j, k)
+                    pj, pk = last[a]
+                    succ_want[(pj, pk)] = True
+                    lvl = max(lvl, level[pj] + 1)
+                    assert f == (4 * (j - pj) - pk if level[pj] > 1 else 0), (pl, j, k)
+                else:
+                    assert f == 0, (pl, j, k)
+                last[a] = (j, k)
+            level[j] = lvl
+            assert rw[0] & 0xff == lvl and rw[1] & 0xff == lvl, (pl, j)
+        assert max(level.values()) == depth
+        for j in range(360):
+            for k in range(4):
+                bit = (int(side[j, k >> 1]) >> (16 * (k & 1) + 15)) & 1
+                assert bit == int(succ_want.get((j, k), False)), (pl, j, k)
+        assert not side[360:].any()
+    assert seen8 >= 1 or rate == 3          # (rate 1/2: its one layer with shared bits is a chain of 32 steps -- the chain walk's)
 
 
 def test_fleet_without_a_gpu_fails_loudly(pkg):

@@ -12,7 +12,14 @@ rate, short = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (6,
 iters = int(os.environ.get('ITERS', '20'))
 fi = pkg.fec_info(rate, short); pi = eng.ldpc_plan_info(rate, short)
 F = int(os.environ.get('FRAMES', '2048'))
-llr = torch.randint(-30, 31, (F, fi['ldpc_n']), dtype=torch.int8, device='cuda')
+if os.environ.get('SNR'):
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import orc
+    rng = np.random.default_rng(5)
+    base = np.stack([orc.bits_to_llr(orc.encode_frame(rate, short, 200 + k)[1], float(os.environ['SNR']), rng) for k in range(32)])
+    llr = torch.from_numpy(base).cuda().repeat((F + 31) // 32, 1)[:F].contiguous()
+else:
+    llr = torch.randint(-30, 31, (F, fi['ldpc_n']), dtype=torch.int8, device='cuda')
 buf = torch.zeros(1024, dtype=torch.int64, device='cuda')
 eng.lib.dvbs2gpu_debug_set_prof.argtypes = [C.c_void_p]
 eng.lib.dvbs2gpu_debug_set_prof(C.c_void_p(buf.data_ptr()))
@@ -46,3 +53,9 @@ if full[200:300].any():        # -DLDPC_PROF=4 build: cycles the claim of the ne
     for who, off in (('thread 0  ', 200), ('thread 384', 250)):
         v = full[off:off + len(sp['kind'])] / iters / nfr
         print('claim wait, %s: total %.0f cycles per iteration; per pseudo-layer: %s' % (who, v.sum(), ' '.join('%.0f' % x for x in v)))
+
+if full[512:896].any():        # -DLDPC_SPLIT_SPEC_STATS=1 build: passes per kind-8 layer (workgroup 0)
+    for i, k in enumerate(sp['kind']):
+        if k == 8:
+            h = full[512 + 32 * (i % 11): 512 + 32 * (i % 11) + 32]
+            print('layer %2d (depth %d): passes  ' % (i, sp['aux'][i] >> 16) + '  '.join('%d:%.1f%%' % (n, 100 * c / h.sum()) for n, c in enumerate(h) if c) + '   mean %.2f' % ((h * np.arange(32)).sum() / h.sum()))

@@ -13,7 +13,15 @@ for rate, short in codes:
     fi = pkg.fec_info(rate, short)
     pi = eng.ldpc_plan_info(rate, short)
     F = int(os.environ.get('FRAMES', str(pi['cus'] * pi['blocks_per_cu'] * 4)))
-    llr = torch.randint(-30, 31, (F, fi['ldpc_n']), dtype=torch.int8, device='cuda')
+    if os.environ.get('SNR'):
+        # decodable frames (SNR = Es/N0 in dB of a BPSK channel): 32 noisy codewords from the CPU encoder, repeated -- what the speculative passes of the half-row decoder
+        # (kind 8) are fast on; the default, uniform noise, never converges: their slow case
+        import orc
+        rng = np.random.default_rng(5)
+        base = np.stack([orc.bits_to_llr(orc.encode_frame(rate, short, 200 + k)[1], float(os.environ['SNR']), rng) for k in range(32)])
+        llr = torch.from_numpy(base).cuda().repeat((F + 31) // 32, 1)[:F].contiguous()
+    else:
+        llr = torch.randint(-30, 31, (F, fi['ldpc_n']), dtype=torch.int8, device='cuda')
     eng.ldpc_decode(llr, rate, bool(short), max_trials=2, force=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
