@@ -248,8 +248,23 @@ def decoder_self_check(run, nb, valid, good, n_spread=40, n_odd=24):
     with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
         res = list(ex.map(one, picks))
     n_odd_checked = sum(1 for (s_, k) in picks if not good[s_, k])
+    # the decoder ALONE on this very job's LLRs (frames that decode: the half-row decoder's speculative layers end after two passes, its chain layers skip their walk;
+    # `kernel_ms_alone` of the roofline object is taken on noise that never converges -- their slow case)
+    import torch
+    nf_job = int(job['nf'])
+    hard = torch.empty((nf_job, kb), dtype=torch.uint8, device=run.out[0].device)
+    tri = torch.empty((nf_job,), dtype=torch.int32, device=run.out[0].device)
+    alone_ms = None
+    if job['force']:
+        def go():
+            eng._check(eng.lib.dvbs2gpu_ldpc_decode_batch(eng.h, job['rate'], job['short'], C.c_void_p(job['d_llr']), nf_job, job['max_trials'], 1, hard.data_ptr(), None, tri.data_ptr(), eng._stream()))
+        go(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); go(); e1.record(); torch.cuda.synchronize()
+        alone_ms = round(e0.elapsed_time(e1), 3)
     return {'frames_checked': len(picks), 'frames_equal_to_oracle_fec': int(sum(res)), 'of_which_not_transmitted_frames': n_odd_checked,
             'streams_spanned': [min(p_[0] for p_ in picks), max(p_[0] for p_ in picks)],
+            'decoder_ms_alone_on_this_jobs_llrs': alone_ms, 'frames_of_the_job': nf_job,
             'how': 'LLRs of the last timed step read back from the decoder job\'s buffer, CPU oracle FEC (orc_fec_decode_frame, %d %s iterations), byte equality with the delivered BBFRAMEs'
                    % (job['max_trials'], 'forced' if job['force'] else 'max')}
 

@@ -30,6 +30,9 @@ namespace s2 {
 #ifndef LDPC_SPLIT_SKIP
 #define LDPC_SPLIT_SKIP 0           // development switch for counter experiments (results wrong): bit k set = the pseudo-layers of kind k do nothing
 #endif
+#ifndef LDPC_SPLIT_CHAIN_SPEC
+#define LDPC_SPLIT_CHAIN_SPEC 1    // chain layers try the plain row update where the previous chain layer changed no shared posterior (A/B switch)
+#endif
 #ifndef LDPC_SPLIT_WPE
 #define LDPC_SPLIT_WPE 8          // waves per SIMD the register allocation aims at (6 = 80 VGPRs: two workgroups per compute unit; 8 = 64: room for a 128-register front-end wave beside them)
 #endif
@@ -139,7 +142,8 @@ struct RowState {
 // NOPREV: the pseudo-layer holds row 0 of layer 0, which has no previous parity bit (kind 7: a conflict-free layer; the plan refuses codes whose layer 0 has shared bits) --
 // a kind of its own, so that the other 44 layers of a sweep do not carry the test (r05: 7 vector instructions per wave and layer)
 template <int MAXDEG, int LATE, int NOPREV = 0>     // NOPREV 2: asked at run time (A/B builds, -DLDPC_SPLIT_NOPREV_RT)
-__device__ __forceinline__ void row_input(RowState<MAXDEG>& R, const uint32_t late, const uint32_t noprev_t, const int t, int& M0, int& M1, int& SXs, const bool noprev_rt = false) {
+__device__ __forceinline__ void row_input(RowState<MAXDEG>& R, const uint32_t late, const uint32_t noprev_t, const int t, int& M0, int& M1, int& SXs, const bool noprev_rt = false,
+                                          uint32_t* x0 = nullptr /* the posteriors of slots 0 / 1 as read: bits 15:8 / 31:24 */) {
     using S = SplitShape<MAXDEG>;
     constexpr int HS = S::HS, NP = S::NP;
     uint32_t XR[NP], XH[NP];
@@ -157,6 +161,7 @@ __device__ __forceinline__ void row_input(RowState<MAXDEG>& R, const uint32_t la
         lds_ready_n(HS - issued, XR[p], XH[p]);
         // byte of the low load -> bits 15:8, byte of the high load (it sits in bits 23:16) -> bits 31:24
         const s16x2 X = from_bits2(__builtin_amdgcn_perm(XH[p], XR[p], 0x060c000cu));
+        if (p == 0 && x0) *x0 = bits2(X);
         s16x2 v = sat_sub2(X, R.RP[p]);                     // int8 saturation by the 16-bit clamp
         const s16x2 av = pmax2(v, sat_sub2(splat2(0), v));
         // |v| - 1 clamped at 0 (ldpc_kernel.hip: no upper clamp needed, only the high byte is ever consumed)
@@ -195,10 +200,38 @@ __device__ __forceinline__ void row_input(RowState<MAXDEG>& R, const uint32_t la
     SXs = sx ^ os;
 }
 
+// the totals again, from the values row_input left in the registers (a chain layer whose speculative attempt failed: now without the pair)
+template <int MAXDEG, int LATE>
+__device__ __forceinline__ void row_totals(const RowState<MAXDEG>& R, const uint32_t late, int& M0, int& M1, int& SXs) {
+    using S = SplitShape<MAXDEG>;
+    constexpr int NP = S::NP;
+    s16x2 MIN0 = splat2(Q8_NONE), MIN1 = splat2(Q8_NONE);
+    uint32_t SX = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        s16x2 v = R.V[p], g = R.G[p];
+        if constexpr (LATE < 0) {
+            if (p < -LATE) { v = late ? splat2(127 << 8) : v; g = late ? splat2(126 << 8) : g; }
+        }
+        if (p == 0) { MIN0 = g; }
+        else if (p == 1) { MIN1 = pmax2(MIN0, g); MIN0 = pmin2(MIN0, g); }
+        else { MIN1 = pmin2(MIN1, pmax2(MIN0, g)); MIN0 = pmin2(MIN0, g); }
+        SX ^= bits2(v);
+    }
+    const int m0 = (int)bits2(pmin2(MIN0, swap2(MIN0)));
+    const int m1 = (int)bits2(pmin2(pmax2(MIN0, swap2(MIN0)), pmin2(MIN1, swap2(MIN1))));
+    const int sx = (int)(SX ^ __builtin_amdgcn_alignbit(SX, SX, 16));
+    const int o0 = QUAD_DPP(m0, DPP_SWAP_HALVES), o1 = QUAD_DPP(m1, DPP_SWAP_HALVES), os = QUAD_DPP(sx, DPP_SWAP_HALVES);
+    M1 = min(max(m0, o0), min(m1, o1));
+    M0 = min(m0, o0);
+    SXs = sx ^ os;
+}
+
 // output phase: new messages and posteriors of every slot from the row totals (both halves of M0 / M1 equal, sign of the row in bits 15 and 31 of SXs)
 // SKIP: the first SKIP slots, where flagged in `early`, were written ahead (layers with shared links)
 template <int MAXDEG, int SKIP>
-__device__ __forceinline__ void row_output(const RowState<MAXDEG>& R, const int M0, const int M1, const int SXs, const uint32_t early, uint32_t (&rec_out)[SplitShape<MAXDEG>::REC]) {
+__device__ __forceinline__ void row_output(const RowState<MAXDEG>& R, const int M0, const int M1, const int SXs, const uint32_t early, uint32_t (&rec_out)[SplitShape<MAXDEG>::REC],
+                                           uint32_t* pn0 = nullptr /* the new posteriors of slots 0 / 1: bits 7:0 / 23:16 */) {
     using S = SplitShape<MAXDEG>;
     constexpr int HS = S::HS, NP = S::NP, REC = S::REC;
     // the selected magnitude is limited to 32 once per row (the per-link clamp to [-32, 31] then only needs its upper side); plain 32-bit operations on words with equal halves
@@ -217,6 +250,7 @@ __device__ __forceinline__ void row_output(const RowState<MAXDEG>& R, const int 
         s16x2 nm = pmin2(from_bits2(bits2(other) ^ bits2(neg)) - neg, q8(31));
         // new posterior: 16-bit saturating add = int8 saturation; >> 8 brings the bytes to bits 7:0 / 23:16 for the stores
         const uint32_t pn = bits2(sat_add2(R.V[p], nm)) >> 8;
+        if (p == 0 && pn0) *pn0 = pn;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int k = 2 * p + hh;
@@ -286,20 +320,54 @@ typedef __attribute__((address_space(3))) u32x2_a4 lds_u2_a4;
 //   walk     lane c < d follows rows c + d, c + 2d, ...: the posterior one row's E link leaves is the next row's L input (cres[])
 //   phase C  rows of level > 1: the pair's late slots re-read (L from cres[], E from its bit: a row whose E link is late waits for an EARLIER row's L link), joined into
 //            the totals with packed operations, handed to half 1, then the output phase -- which leaves out the early slots: a later row's L link owns that bit's final value.
+//   SPECULATION (round 6)  On a frame that has converged no row changes a posterior any more: what a row's late link reads from its bit at the start of the layer IS what
+//            the earlier row will leave there.  A chain layer that finds this -- every slot a later row reads ("early") got back the value it held -- tells the next chain
+//            layer (a flag word behind the records), and that one makes an ATTEMPT: the plain row update with every input taken from its bit, the pair's slots of the rows
+//            of level > 1 held back, the same check; one barrier; where the check held for every row of the workgroup the layer is done after the held-back stores (the
+//            guesses were the values the walk would have carried: induction along the chains) -- no records, no walk, no second output phase: 100 instead of 187 vector
+//            instructions per wave, two barriers instead of three.  Where it did not, the layer goes the long way from the totals on (phase A's stores of the rows of
+//            level 1 stand, everything else is computed again from the inputs in the registers) and the next chain layer does not try.
 template <int MAXDEG>
 __device__ __forceinline__ void chain_layer(RowState<MAXDEG>& R, uint32_t (&rec_out)[SplitShape<MAXDEG>::REC],
-                                            const LdpcSplitLayer L, const uint32_t eL, const int t, int8_t* __restrict__ post, uint32_t* __restrict__ cw) {
+                                            const LdpcSplitLayer L, const uint32_t eL, const int t, int8_t* __restrict__ post, uint32_t* __restrict__ cw,
+                                            const uint32_t flagb /* LDS address of the two verdict words */, const uint32_t cseq /* chain layers of this frame so far, this one included */) {
     [[maybe_unused]] constexpr int KIND = 1;
+    typedef __attribute__((address_space(3))) uint32_t lds_u1;
     const uint32_t rw = R.rw;
     const uint32_t level = rw & 0xffu, late = (rw >> 8) & 3u, early = (rw >> 12) & 3u;
     const int chain_d = (int)(L.aux & 0xffffu);
     const int j = t >> 1;
     const bool half1 = (t & 1) != 0;
+    const uint32_t emask = ((early & 1u) ? 0xffu : 0u) | ((early & 2u) ? 0xff0000u : 0u);      // the bytes of the pair's posteriors a later row reads
+    const uint32_t my_flag = flagb + 4u * (cseq & 1u);
+    // the previous chain layer's verdict: its word holds its number where some early slot changed (the words are cleared with the frame: the first chain layer does not try).
+    // (Tried: two consistent layers in a row before an attempt -- slower where frames converge slowly, no faster on noise; the word read behind the layer's barrier and
+    //  claimed at the top of the next pseudo-layer -- the bookkeeping in the layer loop cost more than the round trip here.)
+    const bool attempt = LDPC_SPLIT_CHAIN_SPEC && (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const lds_u1*)(uintptr_t)(flagb + 4u * ((cseq - 1u) & 1u))) != cseq - 1u;
     int M0, M1, SXs;
+    uint32_t x0, pn0 = 0;
     SPLIT_MARK_DECL;
-    row_input<MAXDEG, -1>(R, (level > 1u && !half1) ? 1u : 0u, 1u, t, M0, M1, SXs);
+    row_input<MAXDEG, -1>(R, (!attempt && level > 1u && !half1) ? 1u : 0u, 1u, t, M0, M1, SXs, false, &x0);
     SPLIT_MARK(0);
-    if (level == 1u) row_output<MAXDEG, 0>(R, M0, M1, SXs, 0u, rec_out);
+    if (attempt) {
+        row_output<MAXDEG, 2>(R, M0, M1, SXs, (level > 1u && !half1) ? 3u : 0u, rec_out, &pn0);
+        const bool bad = ((pn0 ^ (x0 >> 8)) & emask) != 0;
+        if (__builtin_amdgcn_ballot_w64(bad) != 0 && (t & 63) == 0) *(lds_u1*)(uintptr_t)my_flag = cseq;
+        lds_pairs_wait();
+        lds_barrier();
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*(const lds_u1*)(uintptr_t)my_flag) != cseq) {
+            // every guess was right: the held-back stores (a slot a later row touches stays that row's), and the layer is done
+            if (level > 1u && !half1) {
+                if (!(early & 1u)) lds_write_lo_i8(R.addr[0], pn0);
+                if (!(early & 2u)) lds_write_hi_i8(R.addr[1], pn0);
+            }
+            return;
+        }
+        // the long way: the totals again, without the pair where the row has late links (the rows of level 1 are done: their inputs were no guesses)
+        row_totals<MAXDEG, -1>(R, (level > 1u && !half1) ? 1u : 0u, M0, M1, SXs);
+    } else if (level == 1u) {
+        row_output<MAXDEG, 0>(R, M0, M1, SXs, 0u, rec_out, &pn0);
+    }
     if ((late >> 1) & 1) {
         // totals without the pair: min0 = the smallest magnitude among the row's other links (what the E link's new message takes), sign = their product
         reinterpret_cast<uint2*>(cw)[j] = chain_record_x(R.msg(1), (late & 1u) ? 255 : (M0 >> 24), (int)R.V[0][0] >> 8, SXs >> 31);
@@ -369,7 +437,12 @@ __device__ __forceinline__ void chain_layer(RowState<MAXDEG>& R, uint32_t (&rec_
         M1 = QUAD_DPP(M1, DPP_FROM_HALF0);
         SXs = QUAD_DPP(SXs, DPP_FROM_HALF0);
         SPLIT_MARK(5);
-        row_output<MAXDEG, 2>(R, M0, M1, SXs, early, rec_out);
+        row_output<MAXDEG, 2>(R, M0, M1, SXs, early, rec_out, &pn0);
+    }
+    // the verdict for the next chain layer: did any slot a later row reads change?  (after a failed attempt the word is set already)
+    if (LDPC_SPLIT_CHAIN_SPEC && !attempt) {
+        const bool bad = ((pn0 ^ (x0 >> 8)) & emask) != 0;
+        if (__builtin_amdgcn_ballot_w64(bad) != 0 && (t & 63) == 0) *(lds_u1*)(uintptr_t)my_flag = cseq;
     }
     SPLIT_MARK(6);
 }
@@ -565,10 +638,12 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
             }
             // the first sweep reads all-zero messages: the records are cleared here, so that a sweep fetches them without asking which sweep it is
             for (uint32_t o = (uint32_t)t; o < (uint32_t)P->A.pent_base; o += T) msg[o] = 0;
+            if (t < 2) reinterpret_cast<uint32_t*>(lds_all + ((N + LDPC_SPLIT_SCRATCH + 15) & ~15) + 8 * 360)[t] = 0;      // the chain layers' verdict words
         }
         __syncthreads();
 
         int it = 0, ret = 0;
+        uint32_t cseq = 0;                  // chain layers of this frame so far (chain_layer: the verdict words)
         while (true) {
             const LdpcKernelParamsPtr P = ldpc_params();
             const LdpcKernelArgs A = ldpc_args(P);      // (what of it the check and the sweep use)
@@ -580,6 +655,7 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
             const int npad = (N + LDPC_SPLIT_SCRATCH + 15) & ~15;                // posteriors + the scratch bytes (ldpc_split_plan.h)
             uint32_t* __restrict__ cw = reinterpret_cast<uint32_t*>(lds_all + npad);      // hand-off area: 8 bytes per row (chain walk) / 4 bytes per row + 2 flag words (speculative passes)
             int* __restrict__ s_flag = reinterpret_cast<int*>(lds_all + N);                // [12] + next frame, in the sweep's scratch bytes (LDPC_SPLIT_SCRATCH = 64)
+            const uint32_t cflagb = (uint32_t)npad + 8u * 360u;                            // LDS address of the chain layers' two verdict words (the posteriors start at 0)
             uint32_t* __restrict__ msg = A.msg_ws + (size_t)blockIdx.x * (size_t)A.pent_base;
             uint32_t* __restrict__ sgn = A.sgn_ws + (size_t)blockIdx.x * SGN_WS_DWORDS;
             const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(P->atab), 0, P->tab_words * 4, 0x00020000);
@@ -672,7 +748,8 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                     row_input<MAXDEG, 0, 1>(RS, 0u, L.aux, tt, M0, M1, SXs);
                     row_output<MAXDEG, 0>(RS, M0, M1, SXs, 0u, ro);
                 } else if ((L.kind_nw & 0xffu) == 1) {
-                    chain_layer<MAXDEG>(RS, ro, L, ents[L.ent_off + 1], tt, post, cw);
+                    ++cseq;
+                    chain_layer<MAXDEG>(RS, ro, L, ents[L.ent_off + 1], tt, post, cw, cflagb, cseq);
                 } else {
                     spec_layer<MAXDEG>(RS, ro, L, P->atab, tt, cw, A.prof, pl);
                 }
@@ -742,7 +819,7 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
 // posteriors + scratch, then the hand-off area: 8 bytes x 360 rows (spec_layer's cells and flags end at 4 * 384 + 8 bytes of it)
 size_t ldpc_split_lds_bytes(int N) {
     const size_t npad = (size_t)((N + LDPC_SPLIT_SCRATCH + 15) & ~15);
-    return npad + 8 * 360;
+    return npad + 8 * 360 + 16;                 // (+ the chain layers' two verdict words)
 }
 size_t ldpc_split_msg_bytes_per_block(const LdpcDeviceCode& C) { return (size_t)C.split_rec_total * sizeof(uint32_t); }
 

@@ -121,7 +121,8 @@ __device__ __forceinline__ cf32 phasor_hw(float x) { return phasor(x); }
 #define AGC_PRIO 2
 #endif
 #ifndef G_PRIO
-#define G_PRIO 0
+#define G_PRIO 1      // (round 6, with every front-end kernel above the decoder's parallel phases: the front end of the headline step is through in 129 ms instead of 256 and the
+                      //  step is the decoder again: 283.9 -> 274.2 ms; at 0 the timing recovery shared the decoder's level for (8 - share) of every 8 tiles)
 #endif
 #ifndef G_PRIO_DUTY
 #define G_PRIO_DUTY 0
@@ -130,7 +131,7 @@ __device__ __forceinline__ cf32 phasor_hw(float x) { return phasor(x); }
 #define FL_PRIO 2
 #endif
 #ifndef POST_PRIO
-#define POST_PRIO 1   // wave priority of the data-parallel post stages (RRC, PL-sync walk, demapper) beside the decoder.  Round 6: at 0 -- the decoder's own -- an RRC slice took 35-44 ms
+#define POST_PRIO 2   // wave priority of the data-parallel post stages (RRC, PL-sync walk, demapper) beside the decoder.  Round 6: at 0 -- the decoder's own -- an RRC slice took 35-44 ms
                       // beside the decoder (6 alone), a PL-sync walk 30 (5): they share the AGC's stream, so the AGC slices, and behind them the timing recovery, waited for them --
                       // the front end was the step (299.7 ms; 285.4 at 1, 285.9 at 2: same call, tools/ab.sh)
 #endif
