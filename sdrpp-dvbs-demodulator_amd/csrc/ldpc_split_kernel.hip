@@ -33,6 +33,12 @@ namespace s2 {
 #ifndef LDPC_SPLIT_CHAIN_SPEC
 #define LDPC_SPLIT_CHAIN_SPEC 1    // chain layers try the plain row update where the previous chain layer changed no shared posterior (A/B switch)
 #endif
+#ifndef LDPC_SPLIT_SPEC_ATTEMPT
+#define LDPC_SPLIT_SPEC_ATTEMPT 1  // the same attempt ahead of the speculative passes (A/B switch)
+#endif
+#ifndef LDPC_SPLIT_DBG
+#define LDPC_SPLIT_DBG 0
+#endif
 #ifndef LDPC_SPLIT_WPE
 #define LDPC_SPLIT_WPE 8          // waves per SIMD the register allocation aims at (6 = 80 VGPRs: two workgroups per compute unit; 8 = 64: room for a 128-register front-end wave beside them)
 #endif
@@ -143,7 +149,7 @@ struct RowState {
 // a kind of its own, so that the other 44 layers of a sweep do not carry the test (r05: 7 vector instructions per wave and layer)
 template <int MAXDEG, int LATE, int NOPREV = 0>     // NOPREV 2: asked at run time (A/B builds, -DLDPC_SPLIT_NOPREV_RT)
 __device__ __forceinline__ void row_input(RowState<MAXDEG>& R, const uint32_t late, const uint32_t noprev_t, const int t, int& M0, int& M1, int& SXs, const bool noprev_rt = false,
-                                          uint32_t* x0 = nullptr /* the posteriors of slots 0 / 1 as read: bits 15:8 / 31:24 */) {
+                                          uint32_t* x0 = nullptr /* [2]: the posteriors of slots 0 / 1 and 2 / 3 as read: bits 15:8 / 31:24 */, const int nx = 1) {
     using S = SplitShape<MAXDEG>;
     constexpr int HS = S::HS, NP = S::NP;
     uint32_t XR[NP], XH[NP];
@@ -161,7 +167,7 @@ __device__ __forceinline__ void row_input(RowState<MAXDEG>& R, const uint32_t la
         lds_ready_n(HS - issued, XR[p], XH[p]);
         // byte of the low load -> bits 15:8, byte of the high load (it sits in bits 23:16) -> bits 31:24
         const s16x2 X = from_bits2(__builtin_amdgcn_perm(XH[p], XR[p], 0x060c000cu));
-        if (p == 0 && x0) *x0 = bits2(X);
+        if (p < nx && x0) x0[p] = bits2(X);
         s16x2 v = sat_sub2(X, R.RP[p]);                     // int8 saturation by the 16-bit clamp
         const s16x2 av = pmax2(v, sat_sub2(splat2(0), v));
         // |v| - 1 clamped at 0 (ldpc_kernel.hip: no upper clamp needed, only the high byte is ever consumed)
@@ -231,7 +237,7 @@ __device__ __forceinline__ void row_totals(const RowState<MAXDEG>& R, const uint
 // SKIP: the first SKIP slots, where flagged in `early`, were written ahead (layers with shared links)
 template <int MAXDEG, int SKIP>
 __device__ __forceinline__ void row_output(const RowState<MAXDEG>& R, const int M0, const int M1, const int SXs, const uint32_t early, uint32_t (&rec_out)[SplitShape<MAXDEG>::REC],
-                                           uint32_t* pn0 = nullptr /* the new posteriors of slots 0 / 1: bits 7:0 / 23:16 */) {
+                                           uint32_t* pn0 = nullptr /* [2]: the new posteriors of slots 0 / 1 and 2 / 3: bits 7:0 / 23:16 */, const int npn = 1) {
     using S = SplitShape<MAXDEG>;
     constexpr int HS = S::HS, NP = S::NP, REC = S::REC;
     // the selected magnitude is limited to 32 once per row (the per-link clamp to [-32, 31] then only needs its upper side); plain 32-bit operations on words with equal halves
@@ -250,7 +256,7 @@ __device__ __forceinline__ void row_output(const RowState<MAXDEG>& R, const int 
         s16x2 nm = pmin2(from_bits2(bits2(other) ^ bits2(neg)) - neg, q8(31));
         // new posterior: 16-bit saturating add = int8 saturation; >> 8 brings the bytes to bits 7:0 / 23:16 for the stores
         const uint32_t pn = bits2(sat_add2(R.V[p], nm)) >> 8;
-        if (p == 0 && pn0) *pn0 = pn;
+        if (p < npn && pn0) pn0[p] = pn;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int k = 2 * p + hh;
@@ -486,7 +492,8 @@ __device__ __forceinline__ LdpcSplitLayer layer_at(const_layer_ptr layers, int i
 #endif
 template <int MAXDEG>
 __device__ __forceinline__ void spec_layer(RowState<MAXDEG>& R, uint32_t (&rec_out)[SplitShape<MAXDEG>::REC], const LdpcSplitLayer L, const uint32_t* __restrict__ tab, const int t,
-                                           uint32_t* __restrict__ cw, [[maybe_unused]] unsigned long long* prof, [[maybe_unused]] const int pl) {
+                                           uint32_t* __restrict__ cw, [[maybe_unused]] unsigned long long* prof, [[maybe_unused]] const int pl,
+                                           const uint32_t vflagb /* LDS address of the two verdict words */, const uint32_t cseq /* layers with shared bits of this frame so far, this one included */) {
     static_assert(SplitShape<MAXDEG>::HS >= 4, "the shared links are slots 0..3 of half 0");
     typedef __attribute__((address_space(3))) uint32_t lds_u1;
     const uint32_t level = R.rw & 0xffu;               // (both halves carry it; idle lanes: 0)
@@ -503,13 +510,55 @@ __device__ __forceinline__ void spec_layer(RowState<MAXDEG>& R, uint32_t (&rec_o
         const uint32_t voff = (uint32_t)j * 8u;
         asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(side) : "v"(voff), "s"(sbase) : "memory");
     }
-    int M0, M1, SXs;
-    row_input<MAXDEG, -2>(R, spec ? 1u : 0u, 1u, t, M0, M1, SXs);
-    if (level == 1u) row_output<MAXDEG, 0>(R, M0, M1, SXs, 0u, rec_out);
     uint32_t cwb = lds_offset(reinterpret_cast<const int8_t*>(cw));
     asm volatile("" : "+s"(cwb));
     const uint32_t flagb = cwb + 4u * 384u;            // two words behind the cells: flag[p & 1] = p + 1 where a row read something new in pass p
     if (t == 0) { *(lds_u1*)(uintptr_t)flagb = 0u; *(lds_u1*)(uintptr_t)(flagb + 4u) = 0u; }
+    // the verdict words the layers with shared bits hand on (chain_layer): where the layer before changed no posterior a later row reads, this one first tries the plain row
+    // update -- every input from its bit, slots 0..3 of the rows of level > 1 held back, one barrier, done if every such posterior got its value back -- and only else the passes
+    const uint32_t my_flag = vflagb + 4u * (cseq & 1u);
+    const bool attempt = LDPC_SPLIT_CHAIN_SPEC && LDPC_SPLIT_SPEC_ATTEMPT && (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const lds_u1*)(uintptr_t)(vflagb + 4u * ((cseq - 1u) & 1u))) != cseq - 1u;
+    // (a copy of the side entry of its own for the attempt: a value fetched behind the compiler's back must have ONE place where it is claimed -- with two, the compiler
+    //  moved the registers between them while the load was still on its way)
+    u32x2 side_a = {0u, 0u};
+    if (attempt) {
+        const uint64_t sbase = (uint64_t)(uintptr_t)(tab + L.ent_off);
+        const uint32_t voff = (uint32_t)j * 8u;
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(side_a) : "v"(voff), "s"(sbase) : "memory");
+    }
+    int M0, M1, SXs;
+    uint32_t xr[2], pn[2] = {0u, 0u};
+    row_input<MAXDEG, -2>(R, (!attempt && spec) ? 1u : 0u, 1u, t, M0, M1, SXs, false, xr, 2);
+    uint32_t em0 = 0, em1 = 0;                         // the bytes of slots 0..3 a later row reads (known once the side entry is in)
+#if LDPC_SPLIT_SPEC_STATS
+    if (prof && blockIdx.x == 0 && t == 0) { prof[900] += 1; prof[901] += attempt; prof[910 + (cseq < 40 ? cseq : 40)] += attempt; }
+#endif
+    if (attempt) {
+        if (!(LDPC_SPLIT_DBG & 2) || level == 1u) row_output<MAXDEG, 4>(R, M0, M1, SXs, spec ? 15u : 0u, rec_out, pn, 2);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(side_a) : : "memory");
+        em0 = (((side_a.x >> 15) & 1u) ? 0xffu : 0u) | (((side_a.x >> 31) & 1u) ? 0xff0000u : 0u);
+        em1 = (((side_a.y >> 15) & 1u) ? 0xffu : 0u) | (((side_a.y >> 31) & 1u) ? 0xff0000u : 0u);
+        const bool bad = (LDPC_SPLIT_DBG & 1) || (!half1 && ((((pn[0] ^ (xr[0] >> 8)) & em0) | ((pn[1] ^ (xr[1] >> 8)) & em1)) != 0));
+        if (__builtin_amdgcn_ballot_w64(bad) != 0 && (t & 63) == 0) *(lds_u1*)(uintptr_t)my_flag = cseq;
+        if (!(LDPC_SPLIT_DBG & 8)) { lds_pairs_wait();
+        lds_barrier(); }
+        if (!(LDPC_SPLIT_DBG & 8) && (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const lds_u1*)(uintptr_t)my_flag) != cseq) {
+#if LDPC_SPLIT_SPEC_STATS
+            if (prof && blockIdx.x == 0 && t == 0) prof[902] += 1;
+#endif
+            if (spec) {
+                if (!(em0 & 0xffu)) lds_write_lo_i8(R.addr[0], pn[0]);
+                if (!(em0 >> 16)) lds_write_hi_i8(R.addr[1], pn[0]);
+                if (!(em1 & 0xffu)) lds_write_lo_i8(R.addr[2], pn[1]);
+                if (!(em1 >> 16)) lds_write_hi_i8(R.addr[3], pn[1]);
+            }
+            return;
+        }
+        if (LDPC_SPLIT_DBG & 4) row_input<MAXDEG, -2>(R, spec ? 1u : 0u, 1u, t, M0, M1, SXs);
+        else row_totals<MAXDEG, -2>(R, spec ? 1u : 0u, M0, M1, SXs);          // the long way: the totals without slots 0..3 where the row has predecessors
+    } else {
+        if (level == 1u) row_output<MAXDEG, 0>(R, M0, M1, SXs, 0u, rec_out, pn, 2);
+    }
     const uint32_t cell = cwb + 4u * (uint32_t)j;
     // (the FIRST pass reads every slot from its bit -- the guess: what the previous layer left there; the later ones from the sources)
     uint32_t cur[4];
@@ -596,7 +645,14 @@ __device__ __forceinline__ void spec_layer(RowState<MAXDEG>& R, uint32_t (&rec_o
         M1 = QUAD_DPP(M1, DPP_FROM_HALF0);
         SXs = QUAD_DPP(SXs, DPP_FROM_HALF0);
         const uint32_t early = ((side.x >> 15) & 1u) | ((side.x >> 30) & 2u) | ((side.y >> 13) & 4u) | ((side.y >> 28) & 8u);
-        row_output<MAXDEG, 4>(R, M0, M1, SXs, half1 ? 0u : early, rec_out);          // (a slot a later row touches stays unwritten)
+        row_output<MAXDEG, 4>(R, M0, M1, SXs, half1 ? 0u : early, rec_out, pn, 2);          // (a slot a later row touches stays unwritten)
+    }
+    // the verdict for the next layer with shared bits (after a failed attempt the word is set already)
+    if (LDPC_SPLIT_CHAIN_SPEC && !attempt) {
+        em0 = (((side.x >> 15) & 1u) ? 0xffu : 0u) | (((side.x >> 31) & 1u) ? 0xff0000u : 0u);
+        em1 = (((side.y >> 15) & 1u) ? 0xffu : 0u) | (((side.y >> 31) & 1u) ? 0xff0000u : 0u);
+        const bool bad = !half1 && ((((pn[0] ^ (xr[0] >> 8)) & em0) | ((pn[1] ^ (xr[1] >> 8)) & em1)) != 0);
+        if (__builtin_amdgcn_ballot_w64(bad) != 0 && (t & 63) == 0) *(lds_u1*)(uintptr_t)my_flag = cseq;
     }
 }
 #undef LINK_IN
@@ -751,7 +807,8 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                     ++cseq;
                     chain_layer<MAXDEG>(RS, ro, L, ents[L.ent_off + 1], tt, post, cw, cflagb, cseq);
                 } else {
-                    spec_layer<MAXDEG>(RS, ro, L, P->atab, tt, cw, A.prof, pl);
+                    ++cseq;
+                    spec_layer<MAXDEG>(RS, ro, L, P->atab, tt, cw, A.prof, pl, cflagb, cseq);
                 }
                 // the next pseudo-layer's words are claimed HERE, before this one's record store is issued: the wait for them then sits where they have had a whole
                 // pseudo-layer to arrive, and the top of the next pseudo-layer waits for nothing (ldpc_kernel.hip)
