@@ -917,13 +917,18 @@ def main():
                        'setup_seconds_before_first_step': round(t_setup, 1),
                        'ranks_seen_by_backend': (dist.get_world_size() if dist is not None else 1), 'backend': (backend if dist is not None else 'none')},
             'roofline': {'bound': 'hbm',
-                         'bound_note': 'NOMINAL: algorithmic bytes against the 8 TB/s HBM peak, as the contract asks for a byte / integer path -- the state is on-chip and what bounds the kernel is vector issue -- its instructions are packed 16-bit / DPP / byte-permute forms, which a SIMD issues at HALF rate (valu_note) -- plus the serial sections of the layers with shared bits (profiles/r05_ldpc_split_layers.txt)',
+                         'bound_note': 'NOMINAL: algorithmic bytes against the 8 TB/s HBM peak, as the contract asks for a byte / integer path -- the state is on-chip and what bounds the kernel is vector issue -- its instructions are packed 16-bit / DPP / byte-permute forms, which a SIMD issues at HALF rate (valu_note) -- plus what the layers with shared bits cost beyond a plain row update (profiles/r06_ldpc_split_layers.txt); the layers with shared bits are SPECULATIVE since round 6: their time depends on how far the frame has converged (kernel_ms_alone: noise; kernel_ms_alone_on_the_steps_llrs: the step\'s own frames), their result does not',
                          'kernel': ('ldpc_split_kernel<%d>' % plan['max_deg']) if form == 2 else 'ldpc_decode_kernel<%d,%d,%s>' % (plan['max_deg'], plan['rec_dwords'], 'true' if plan.get('irregular') else 'false'),
                          'achieved': round(achieved if achieved else achieved_alone, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round((achieved if achieved else achieved_alone) / HBM_PEAK_GBS, 4),
                          'timing': 'average over the %d decoder launches inside the timed steps (hipEvent pairs on the FEC stream; the front end of the next step shares the CUs)' % l_n,
                          'kernel_ms_in_step': round(in_step_ms, 4), 'frames_per_launch': int(in_step_frames),
+                         # alone, on NOISE that never converges (the slow case of the half-row decoder's speculative layers: 4-8 passes, every chain walked) ...
                          'kernel_ms_alone': round(k['forced'], 4), 'achieved_alone': round(achieved_alone, 1), 'frac_alone': round(achieved_alone / HBM_PEAK_GBS, 4),
+                         # ... and alone on the very LLRs the last timed step decoded (frames that decode: two passes, no walks) -- the decoder's time depends on its data, its result does not
+                         'kernel_ms_alone_on_the_steps_llrs': (acc['decoder_self_check'] or {}).get('decoder_ms_alone_on_this_jobs_llrs'),
+                         'frac_alone_on_the_steps_llrs': (round(bytes_per_frame * (acc['decoder_self_check'] or {}).get('frames_of_the_job', 0) / ((acc['decoder_self_check'] or {}).get('decoder_ms_alone_on_this_jobs_llrs') * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                          if (acc['decoder_self_check'] or {}).get('decoder_ms_alone_on_this_jobs_llrs') else None),
                          'kernel_ms_alone_normal_mode_same_iterations': round(k['normal'], 4) if k['normal_all_ran'] else None,
                          'traffic': traffic, 'traffic_taken_from_this_build': traffic_current, 'traffic_unit': 'bytes per launch (fabric-side FETCH_SIZE x2 + WRITE_SIZE, per frame x frames of the launch)', 'traffic_source': traffic_note,
                          'valu_per_simd_cycle': issue, 'valu_note': 'wave64 VALU instructions per SIMD and clock over the launch (PMC).  They are packed 16-bit / VOP3 / SDWA / DPP forms almost throughout, which a SIMD issues every 4.3 cycles (plain 32-bit VOP2: 2.3; tools/ubench/valu_tput.hip, profiles/r05_valu_rates.txt): x 4 = the share of the launch the vector ALUs are busy',

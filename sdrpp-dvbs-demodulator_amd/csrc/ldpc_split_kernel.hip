@@ -39,6 +39,9 @@ namespace s2 {
 #ifndef LDPC_SPLIT_DBG
 #define LDPC_SPLIT_DBG 0
 #endif
+#ifndef LDPC_SPLIT_BASE_PRIO
+#define LDPC_SPLIT_BASE_PRIO 0     // wave priority of the decoder outside its chain walks (A/B switch)
+#endif
 #ifndef LDPC_SPLIT_WPE
 #define LDPC_SPLIT_WPE 8          // waves per SIMD the register allocation aims at (6 = 80 VGPRs: two workgroups per compute unit; 8 = 64: room for a 128-register front-end wave beside them)
 #endif
@@ -410,7 +413,7 @@ __device__ __forceinline__ void chain_layer(RowState<MAXDEG>& R, uint32_t (&rec_
         }
 #undef WALK_ROW
         if (t + T * chain_d < 360) LDS_I8(cwb + 8u * (uint32_t)(t + T * chain_d) + 7u) = (int8_t)x;
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(LDPC_SPLIT_BASE_PRIO);
     }
     SPLIT_MARK(3);
     lds_barrier();
@@ -669,9 +672,7 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     int8_t* __restrict__ post = lds_all;
-#ifdef LDPC_SPLIT_PRIO
-    __builtin_amdgcn_s_setprio(LDPC_SPLIT_PRIO);
-#endif
+    if (LDPC_SPLIT_BASE_PRIO) __builtin_amdgcn_s_setprio(LDPC_SPLIT_BASE_PRIO);
 
 #if defined(LDPC_PROF) && LDPC_PROF == 3
     if (blockIdx.x == 0) g_prof_dev = ldpc_params()->A.prof;      // (threads 0 and 384 of workgroup 0 are the only readers)

@@ -309,7 +309,7 @@ int demod_configure(dvbs2gpu_demod* d) {
         last_error() = "loop gains must be finite"; return DVBS2GPU_ERR_ARG;
     }
     S2LoopCoefs& co = d->co;
-    co.g_prio_duty = 0; co.g_lane_form = 0;       // (scheduling hints: set per call by the pipelined mode's balancer)
+    co.g_prio_duty = 0; co.g_lane_form = 0; co.post_prio = 0;       // (scheduling hints: set per call by the pipelined mode's balancer)
     co.g_form = 0; co.g_cand_skew = 0;            // (context options, set per call)
     co.agc_rate = c.agc_rate;
     co.g_alpha = c.clock_mu_gain; co.g_beta = c.clock_omega_gain;
@@ -487,6 +487,13 @@ static int deliver_job(dvbs2gpu_ctx* ctx, PendingFec* job, hipStream_t st, Works
 // AGC/NCO + timing recovery of a batch, time-sliced over the caller's stream and its auxiliary stream (ctx.h FeAux, created on first use)
 // (round 6 tried HIP stream priorities -- front-end streams at the device's highest queue priority, the FEC stream at its lowest, or only the post-stage streams high:
 //  302.8 / 303.2 / 304.0 ms per headline step, nothing: queue priority does not decide which resident kernel's workgroups get a compute unit's free wave slots)
+// The data-parallel post stages (RRC, PL-sync walk, demapper) above the decoder's wave priority: where the pipelined mode's balancer has found the FRONT END to be the critical
+// path (share >= 5: a decoder-bound configuration whose balancer strays to 4 in its first calls stays below).  At the decoder's own level they took 35-44 / 30 ms per slice beside it instead of 6 / 5, and the AGC slices -- same stream -- waited behind them (headline
+// 299.7 -> 285.4 ms per step); a decoder-bound configuration loses to them (config 5's stand-in: 106.7 -> 115.0 ms per step with them always up).
+#ifndef S2_POST_PRIO_MIN_DUTY
+#define S2_POST_PRIO_MIN_DUTY 5
+#endif
+static int post_prio_wanted(const dvbs2gpu_ctx* ctx) { return ctx->pipeline_fec && ctx->g_prio_duty >= S2_POST_PRIO_MIN_DUTY ? 1 : 0; }
 static hipError_t create_stream(dvbs2gpu_ctx*, hipStream_t* out, int) { return hipStreamCreateWithFlags(out, hipStreamNonBlocking); }
 static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work, int n, const S2LoopCoefs& co, hipStream_t st, const S2PostStages* post = nullptr,
                                   bool own_post_stream = false, int* nsub_out = nullptr) {
@@ -500,6 +507,7 @@ static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work,
     if (nsub_out) *nsub_out = nsub > 1 ? nsub : 1;
     S2LoopCoefs cc = co;
     cc.g_prio_duty = ctx->pipeline_fec ? ctx->g_prio_duty : 0;
+    cc.post_prio = post_prio_wanted(ctx);
     cc.g_lane_form = 0;
     cc.g_form = ctx->gardner_form; cc.g_cand_skew = ctx->gardner_cand_skew;
     dvbs2gpu_ctx::FeAux* fa = nullptr;
@@ -637,9 +645,9 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         if (!pre_nsym) {
             // (with pre_nsym the MODCOD-independent stages already ran for the whole batch: frontend_prepass)
             { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st)); }
-            { StageSpan sp(ctx->timers, ST_RRC, st); HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st)); }
+            { StageSpan sp(ctx->timers, ST_RRC, st); HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st, post_prio_wanted(ctx))); }
         }
-        { StageSpan sp(ctx->timers, ST_PLSYNC, st); HIP_TRY(s2_ccm_walk_launch(d_work, n, raw, maxf, d_found, d_counts, st)); }
+        { StageSpan sp(ctx->timers, ST_PLSYNC, st); HIP_TRY(s2_ccm_walk_launch(d_work, n, raw, maxf, d_found, d_counts, st, post_prio_wanted(ctx))); }
     }
     std::vector<S2VcmFound> found((size_t)n * maxf);
     std::vector<int> cnts(4 * n);
@@ -717,7 +725,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             HIP_TRY(s2_frame_loops_launch(d_work, n, d_frames, d_first, lc, ctx->pl, CT->dev, d0->pls_code, mp.slots, mp.pilots,
                                           mp.pilot_blocks, raw, d_pll, d_stats, st));
         }
-        { StageSpan sp(ctx->timers, ST_DEMAP, st); HIP_TRY(s2_demap_launch(CT->dev, mp.rate, mp.shortframe, mp.slots, mp.pilots, raw, d_pll, nf, d_llr, N, st, staged ? d_slot : nullptr)); }
+        { StageSpan sp(ctx->timers, ST_DEMAP, st); HIP_TRY(s2_demap_launch(CT->dev, mp.rate, mp.shortframe, mp.slots, mp.pilots, raw, d_pll, nf, d_llr, N, st, staged ? d_slot : nullptr, post_prio_wanted(ctx))); }
         const int force = d0->cfg.force_ldpc_iters > 0;
         const int mt = force ? d0->cfg.force_ldpc_iters : d0->cfg.max_ldpc_trials;
         // keep a copy of the demapper output for the tap before LDPC consumes it? LDPC does not modify d_llr.

@@ -56,6 +56,7 @@ struct S2LoopCoefs {
     int soft_plsc, pilot_aided;      // extensions (include/dvbs2gpu.h), 0 = the reference's behaviour
     int g_form, g_cand_skew;         // scheduling / tests only: a forced form of the timing recovery (0: by bank size and balance), the candidate form's skew (context options)
     int g_lane_form;                 // scheduling only: a big bank's timing recovery runs in the lane-per-stream form (set by the balancer of s2_demod.hip, with hysteresis)
+    int post_prio;                   // scheduling only: 1 = the data-parallel post stages (RRC, PL-sync walk, demapper) run above the decoder's wave priority (the balancer has found the front end critical)
     int g_prio_duty;                 // scheduling only: of every 8 tiles of the timing loop, this many run one wave-priority level up (s2_demod.hip balances the two streams of the pipelined mode with it)
 };
 
@@ -207,7 +208,7 @@ hipError_t s2_post_stages_launch(const S2StreamWork* d_work, int nstreams, const
 hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCoefs coefs, const float* d_bank, hipStream_t st, hipStream_t aux,
                               hipEvent_t* ev, int nsub, const S2PostStages* post = nullptr, hipEvent_t* ev2 = nullptr, hipStream_t post_stream = nullptr,
                               hipStream_t loops_stream = nullptr, hipEvent_t* ev3 = nullptr);
-hipError_t s2_rrc_decim_launch(const S2StreamWork* d_work, int nstreams, int max_count, const float* d_taps, int ntaps, hipStream_t st);
+hipError_t s2_rrc_decim_launch(const S2StreamWork* d_work, int nstreams, int max_count, const float* d_taps, int ntaps, hipStream_t st, int post_prio = 0);
 // per-stream frame loops: frames of stream s are d_frames[first[s] .. first[s+1])
 hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const S2FrameRef* d_frames, const int* d_first,
                                  S2LoopCoefs coefs, S2PlTablesDev tabs, S2ConstelDev con, int pls_code, int slots, int pilots,
@@ -220,7 +221,7 @@ hipError_t s2_scatter_out2_launch(uint8_t* const* d_outs, const S2FrameRef* d_fr
                                   const uint8_t* d_bb, hipStream_t st);
 hipError_t s2_fifo_compact_launch(const S2StreamWork* d_work, int nstreams, const int* d_cur_fill /*[2*nstreams]: cur, fill*/, hipStream_t st);
 // PL sync with its 2-state realign machine on the device: one workgroup per stream walks the stream's complete windows in order
-hipError_t s2_ccm_walk_launch(const S2StreamWork* d_work, int nstreams, int raw, int maxf, S2VcmFound* d_found, int* d_counts, hipStream_t st);
+hipError_t s2_ccm_walk_launch(const S2StreamWork* d_work, int nstreams, int raw, int maxf, S2VcmFound* d_found, int* d_counts, hipStream_t st, int post_prio = 0);
 // ACM/VCM path
 hipError_t s2_vcm_walk_launch(const S2StreamWork* d_work, int nstreams, S2PlTablesDev tabs, const S2VcmMod* d_mods, float sof_threshold, int maxf,
                               S2VcmFound* d_found, int* d_counts /*[nstreams][4]: frames, consumed, avail, new symbols*/, hipStream_t st);
@@ -234,7 +235,7 @@ hipError_t s2_vcm_scatter_launch(const int* d_idx, int count, int kb, const uint
 hipError_t s2_deinterleave_launch(int constel, int rate, int bits, int N, const int8_t* d_in, int nframes, int8_t* d_out, hipStream_t st);
 hipError_t math_eval_launch(int func, int n, const float* a, const float* b, float* o0, float* o1, hipStream_t st);
 hipError_t s2_demap_launch(S2ConstelDev con, int rate, int shortframe, int slots, int pilots, int plframe, const cf32* d_pllout,
-                           int nframes, int8_t* d_llr, int N, hipStream_t st, const int* d_slot = nullptr);   // d_slot: frame f's symbols lie in slot d_slot[f] of d_pllout
+                           int nframes, int8_t* d_llr, int N, hipStream_t st, const int* d_slot = nullptr, int post_prio = 0);   // d_slot: frame f's symbols lie in slot d_slot[f] of d_pllout
 // mixed batch: frame f belongs to stream d_slot[f] / maxf (its configuration: cfgs), its symbols lie in slot d_slot[f] (stride slot_stride), its LLRs go to d_llr_of[f]
 hipError_t s2_demap_mixed_launch(const S2StreamCfgDev* cfgs, int max_slots, int maxf, int slot_stride, const cf32* d_pllout, int nframes,
                                  int8_t* const* d_llr_of, hipStream_t st, const int* d_slot);

@@ -127,11 +127,17 @@ __device__ __forceinline__ cf32 phasor_hw(float x) { return phasor(x); }
 #ifndef G_PRIO_DUTY
 #define G_PRIO_DUTY 0
 #endif
+#ifndef G_PRIO_HI
+#define G_PRIO_HI (G_PRIO + 1)   // the timing recovery's priority for `share` of every 8 tiles ...
+#endif
+#ifndef G_PRIO_LO
+#define G_PRIO_LO G_PRIO         // ... and for the rest
+#endif
 #ifndef FL_PRIO
 #define FL_PRIO 2
 #endif
 #ifndef POST_PRIO
-#define POST_PRIO 2   // wave priority of the data-parallel post stages (RRC, PL-sync walk, demapper) beside the decoder.  Round 6: at 0 -- the decoder's own -- an RRC slice took 35-44 ms
+#define POST_PRIO 2   // wave priority of the data-parallel post stages (RRC, PL-sync walk, demapper) beside the decoder WHERE THE HOST ASKS FOR IT (S2LoopCoefs::post_prio: the balancer's share >= 5 = the front end is the critical path; a decoder-bound configuration -- config 5's stand-in -- loses 8 % to post stages above its decoder).  Round 6: at 0 -- the decoder's own -- an RRC slice took 35-44 ms
                       // beside the decoder (6 alone), a PL-sync walk 30 (5): they share the AGC's stream, so the AGC slices, and behind them the timing recovery, waited for them --
                       // the front end was the step (299.7 ms; 285.4 at 1, 285.9 at 2: same call, tools/ab.sh)
 #endif
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(64) void s2_gardner_kernel(const S2StreamWork* __re
         // co.g_prio_duty (+ the build's G_PRIO_DUTY) of every 8 tiles run one priority level up: the balance point between "this kernel yields to
         // the decoder" (the front end becomes the critical path) and "it does not" (the decoder does) lies between two priority levels, and
         // where it lies depends on the MODCOD -- the host moves it from call to call (s2_demod.hip)
-        if ((((unsigned)base / G_TILE) & 7u) < (unsigned)(co.g_prio_duty + G_PRIO_DUTY)) __builtin_amdgcn_s_setprio(G_PRIO + 1); else __builtin_amdgcn_s_setprio(G_PRIO);
+        if ((((unsigned)base / G_TILE) & 7u) < (unsigned)(co.g_prio_duty + G_PRIO_DUTY)) __builtin_amdgcn_s_setprio(G_PRIO_HI); else __builtin_amdgcn_s_setprio(G_PRIO_LO);
         commit(base);
         __syncthreads();
         issue(base + G_TILE);
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(128) void s2_gardner2_kernel(const S2StreamWork* __
     lds_only_barrier();                       // period 0 is staged
     __builtin_amdgcn_s_setprio(G_PRIO);       // latency-critical serial loop (see agc_pc_kernel)
     for (int t = 0; t < ntiles; ++t) {
-        if ((((unsigned)t * G2_TILE / G_TILE) & 7u) < (unsigned)(co.g_prio_duty + G_PRIO_DUTY)) __builtin_amdgcn_s_setprio(G_PRIO + 1); else __builtin_amdgcn_s_setprio(G_PRIO);
+        if ((((unsigned)t * G2_TILE / G_TILE) & 7u) < (unsigned)(co.g_prio_duty + G_PRIO_DUTY)) __builtin_amdgcn_s_setprio(G_PRIO_HI); else __builtin_amdgcn_s_setprio(G_PRIO_LO);
         const int base = t * G2_TILE;
         const int lim = min(base + G2_TILE, n);            // outputs with offset < lim have their window staged
         lp = &list[t & 1][g][0];
@@ -1135,7 +1141,9 @@ __global__ __launch_bounds__(192) void s2_gardner_cand_kernel(const S2StreamWork
 // sub / nsub: only the symbols whose windows the timing recovery's slice `sub` completed (the decimator phase and the delay line are
 // the call's: they change in s2_rrc_state_kernel, after the last slice); nsub == 1: the whole call
 __global__ __launch_bounds__(256) void s2_rrc_decim_kernel(const S2StreamWork* __restrict__ work, const float* __restrict__ taps_g, int ntaps, int sub, int nsub) {
-    if (POST_PRIO) __builtin_amdgcn_s_setprio(POST_PRIO);
+    // (bits 16.. of nsub: the wave priority the host asks for -- POST_PRIO where its balancer has found the front end critical, s2_demod.hip)
+    if (nsub >> 16) __builtin_amdgcn_s_setprio(POST_PRIO);
+    nsub &= 0xffff;
     // a block = 256 consecutive kept symbols of one stream; their 2*256 + ntaps - 2 input samples go through LDS once (each is
     // used by up to (ntaps+1)/2 outputs: reading them from L2 per output cost 46 GB per step and competed with the LDPC messages).
     // The window lies DE-INTERLEAVED in LDS -- even samples in xe, odd ones in xo, re and im side by side: output t reads xe[t + k/2] / xo[t + k/2] for
@@ -1911,7 +1919,7 @@ template <bool MIXED>
 __global__ __launch_bounds__(256) void s2_demap_kernel(S2ConstelDev C_arg, int rate, int slots, int pilots, int plframe,
                                                        const cf32* __restrict__ pllout, int8_t* __restrict__ llr, int N, const int* __restrict__ slot,
                                                        const S2StreamCfgDev* __restrict__ cfgs, int maxf, int8_t* const* __restrict__ llr_of) {
-    if (POST_PRIO) __builtin_amdgcn_s_setprio(POST_PRIO);
+    if (!MIXED && maxf) __builtin_amdgcn_s_setprio(POST_PRIO);     // (one configuration: `maxf` carries the host's request, see s2_rrc_decim_kernel)
     const int f = blockIdx.y;
     const cf32* __restrict__ fr = pllout + (size_t)(slot ? slot[f] : f) * plframe;      // (stage pipeline: the loops wrote frame f to its stream's slot)
     int8_t* __restrict__ out = llr + (size_t)f * N;
@@ -1993,7 +2001,8 @@ __global__ __launch_bounds__(256) void s2_ccm_walk_kernel(const S2StreamWork* __
     __shared__ cf32 d[256 + 96];
     __shared__ float r_val[256];
     __shared__ int r_idx[256];
-    if (POST_PRIO) __builtin_amdgcn_s_setprio(POST_PRIO);
+    if (nsub >> 16) __builtin_amdgcn_s_setprio(POST_PRIO);         // (see s2_rrc_decim_kernel)
+    nsub &= 0xffff;
     const int s = blockIdx.x, tid = threadIdx.x;
     if (cfgs) raw = cfgs[s].plframe;             // mixed batch: the PLFRAME length of THIS stream's MODCOD
     const S2StreamWork w = work[s];
@@ -3306,13 +3315,13 @@ static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, c
         int gx = ((p.max_count / nsub) / 2 + 2 + 255) / 256;
         gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
         if (p.spans) p.spans->begin(1, s);
-        hipLaunchKernelGGL(s2_rrc_decim_kernel, dim3(gx, nstreams), dim3(256), 0, s, d_work, p.d_taps, p.ntaps, c, nsub);
+        hipLaunchKernelGGL(s2_rrc_decim_kernel, dim3(gx, nstreams), dim3(256), 0, s, d_work, p.d_taps, p.ntaps, c, nsub | (coefs.post_prio << 16));
         if (c == nsub - 1) hipLaunchKernelGGL(s2_rrc_state_kernel, dim3(nstreams), dim3(128), 0, s, d_work, p.ntaps);
         if (p.spans) p.spans->end(1, s);
     }
     if (which & 2) {
         if (p.spans) p.spans->begin(2, s);
-        hipLaunchKernelGGL(s2_ccm_walk_kernel, dim3(nstreams), dim3(256), 0, s, d_work, p.raw, p.maxf, p.d_found, p.d_counts, c, nsub, p.cfgs);
+        hipLaunchKernelGGL(s2_ccm_walk_kernel, dim3(nstreams), dim3(256), 0, s, d_work, p.raw, p.maxf, p.d_found, p.d_counts, c, nsub | (coefs.post_prio << 16), p.cfgs);
         if (p.spans) p.spans->end(2, s);
     }
     if (which & 4) {
@@ -3434,11 +3443,11 @@ hipError_t s2_frontend_launch(const S2StreamWork* d_work, int nstreams, S2LoopCo
     }
     return hipGetLastError();
 }
-hipError_t s2_rrc_decim_launch(const S2StreamWork* d_work, int nstreams, int max_count, const float* d_taps, int ntaps, hipStream_t st) {
+hipError_t s2_rrc_decim_launch(const S2StreamWork* d_work, int nstreams, int max_count, const float* d_taps, int ntaps, hipStream_t st, int post_prio) {
     int gx = (max_count / 2 + 2 + 255) / 256;
     if (gx < 1) gx = 1;
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(s2_rrc_decim_kernel, dim3(gx, nstreams), dim3(256), 0, st, d_work, d_taps, ntaps, 0, 1);
+    hipLaunchKernelGGL(s2_rrc_decim_kernel, dim3(gx, nstreams), dim3(256), 0, st, d_work, d_taps, ntaps, 0, 1 | ((post_prio ? 1 : 0) << 16));
     hipLaunchKernelGGL(s2_rrc_state_kernel, dim3(nstreams), dim3(128), 0, st, d_work, ntaps);
     return hipGetLastError();
 }
@@ -3450,8 +3459,8 @@ hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const
                        tabs, con, pls_code, slots, pilots, pilot_blocks, plframe, d_pllout, d_stats, (const S2VcmFound*)nullptr, 0, spw, (const S2StreamCfgDev*)nullptr);
     return hipGetLastError();
 }
-hipError_t s2_ccm_walk_launch(const S2StreamWork* d_work, int nstreams, int raw, int maxf, S2VcmFound* d_found, int* d_counts, hipStream_t st) {
-    hipLaunchKernelGGL(s2_ccm_walk_kernel, dim3(nstreams), dim3(256), 0, st, d_work, raw, maxf, d_found, d_counts, 0, 1, (const S2StreamCfgDev*)nullptr);
+hipError_t s2_ccm_walk_launch(const S2StreamWork* d_work, int nstreams, int raw, int maxf, S2VcmFound* d_found, int* d_counts, hipStream_t st, int post_prio) {
+    hipLaunchKernelGGL(s2_ccm_walk_kernel, dim3(nstreams), dim3(256), 0, st, d_work, raw, maxf, d_found, d_counts, 0, 1 | ((post_prio ? 1 : 0) << 16), (const S2StreamCfgDev*)nullptr);
     return hipGetLastError();
 }
 hipError_t s2_vcm_walk_launch(const S2StreamWork* d_work, int nstreams, S2PlTablesDev tabs, const S2VcmMod* d_mods, float sof_threshold, int maxf,
@@ -3483,7 +3492,7 @@ hipError_t s2_deinterleave_launch(int constel, int rate, int bits, int N, const 
     return hipGetLastError();
 }
 hipError_t s2_demap_launch(S2ConstelDev con, int rate, int shortframe, int slots, int pilots, int plframe, const cf32* d_pllout,
-                           int nframes, int8_t* d_llr, int N, hipStream_t st, const int* d_slot) {
+                           int nframes, int8_t* d_llr, int N, hipStream_t st, const int* d_slot, int post_prio) {
     (void)shortframe;
     int gx = (slots * 90 + 255) / 256;
     // the wide form (four symbols per lane) wants 16-byte aligned symbols and word-aligned LLR columns: buffers of this library are, a caller's need
@@ -3493,7 +3502,7 @@ hipError_t s2_demap_launch(S2ConstelDev con, int rate, int shortframe, int slots
     if (!wide) con.lut_bits4 = nullptr;
     else gx = (slots * 90 / 4 + 255) / 256;
     hipLaunchKernelGGL(s2_demap_kernel<false>, dim3(gx, nframes), dim3(256), 0, st, con, rate, slots, pilots, plframe, d_pllout, d_llr, N, d_slot,
-                       (const S2StreamCfgDev*)nullptr, 0, (int8_t* const*)nullptr);
+                       (const S2StreamCfgDev*)nullptr, post_prio ? 1 : 0, (int8_t* const*)nullptr);
     return hipGetLastError();
 }
 hipError_t s2_demap_mixed_launch(const S2StreamCfgDev* cfgs, int max_slots, int maxf, int slot_stride, const cf32* d_pllout, int nframes,

@@ -22,7 +22,10 @@ ms = sum(dur_ns) / len(dur_ns) / 1e6
 frames, iters = 4096, 50
 head = ['# %s: PMC passes over ONE forced LDPC launch = the bench\'s dominant kernel (rate 3/4 normal, %d frames, %d iterations): tools/pmc_ldpc.py 6, FRAMES=%d ITERS=%d' % (tag, frames, iters, frames, iters),
         '# separate passes: --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_*  (rocprofv3, ROCm 7.2; values summed over XCDs; FETCH/WRITE_SIZE unit = KB)']
-open(os.path.join(P, tag + '_ldpc_pmc.txt'), 'w').write('\n'.join(head + rows) + '\n')
+rows5 = [l.rstrip() for l in (open(os.path.join(F, 'p5.csv')) if os.path.exists(os.path.join(F, 'p5.csv')) else []) if 'ldpc_split_kernel' in l]
+tail5 = (['# the issue counters again on DECODABLE frames (SNR=8 tools/pmc_ldpc.py 6: 32 noisy codewords repeated) -- the passes above decode uniform noise, which never converges:',
+          '# the layers with shared bits are speculative (round 6), their instruction count and time depend on the data'] + rows5) if rows5 else []
+open(os.path.join(P, tag + '_ldpc_pmc.txt'), 'w').write('\n'.join(head + rows + tail5) + '\n')
 fetch, write, valu = get('FETCH_SIZE'), get('WRITE_SIZE'), get('SQ_INSTS_VALU')
 traffic = (2 * fetch + write) * 1024
 cus, simds, clk = 256, 4, 2.4e9
@@ -36,6 +39,8 @@ t = {
     'fetch_size_kb': fetch, 'write_size_kb': write,
     'traffic_bytes_per_launch': traffic, 'traffic_bytes_per_frame': traffic / frames,
     'sq_insts_valu': valu,
+    'input': 'uniform noise (never converges: the slow case of the speculative layers)',
+    'on_decodable_frames': ({'kernel_ms': round([float(l.split(',')[-4]) for l in rows5 if 'SQ_' not in l][0] / 1e6, 3), 'sq_insts_valu': [float(l.split(',')[-1]) for l in rows5 if '"SQ_INSTS_VALU"' in l][0]} if rows5 else None),
     'valu_per_simd_cycle': round(valu / (cus * simds * ms * 1e-3 * clk), 4),
     'valu_per_simd_cycle_formula': 'SQ_INSTS_VALU / (256 CUs x 4 SIMDs x kernel time x 2.4 GHz); tools/ubench/valu_cu.hip: a wave issues one VALU instruction per 4.6 (4-byte '
                                    'encoding) / 5.6 (8-byte) cycles whatever else runs on its SIMD, and a SIMD sustains >= 0.88 per cycle with four such waves '
