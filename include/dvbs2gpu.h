@@ -122,8 +122,10 @@ int dvbs2gpu_ldpc_wave_plan_dump(int rate, int shortframes, uint32_t* lanec, uin
 int dvbs2gpu_ldpc_addr_table_dump(int rate, int shortframes, uint32_t* table, int32_t* counts2);
 /* The half-row decoder's plan (csrc/ldpc_split_plan.h; codes it does not take: counts6[0] = 0).
  * counts6 = {pseudo-layers, table words per thread, slots per row half, message-workspace dwords per workgroup, words in the table, record dwords};
- * layers4: 4 uint32 per pseudo-layer {kind | waves << 8 | flags, chain step, record offset, first link entry}; table: [pseudo-layer][768][words]
- * (two 16-bit LDS byte offsets per word, the row word behind the last slot); row_of: [pseudo-layer][384] the row a lane pair updates (-1: idle);
+ * layers4: 4 uint32 per pseudo-layer {kind | waves << 8 | flags, kind 1: chain step | steps << 16, kind 8: levels << 16, record offset, kind 1: first link entry, kind 8: word offset
+ * of the layer's side entries in `table`}; table: [pseudo-layer][768][words] (two 16-bit LDS byte offsets per word, the row word behind the last slot), then the side entries of the
+ * kind-8 layers [384 rows][2 words] (per shared slot: distance from the row's output cell back to the slot's source cell in bits 0..10, 0 = the bit itself; bit 15: a later row
+ * of the layer touches the slot) -- `words in the table` counts both; row_of: [pseudo-layer][384] the row a lane pair updates (-1: idle);
  * layer_of: [pseudo-layer] its layer.  NULL arrays: counts only. */
 int dvbs2gpu_ldpc_split_plan_dump(int rate, int shortframes, uint32_t* layers4, uint32_t* table, int32_t* row_of, int32_t* layer_of, int32_t* counts6);
 

@@ -64,6 +64,7 @@ int apply_option(dvbs2gpu_ctx* c, const char* name, int v) {
         c->ldpc_wave = v;
     }
     else if (n == "ldpc_split") { if (!in(0, 1)) return -1; c->ldpc_split = v; }       // (read at every launch)
+    else if (n == "ldpc_split_fail_attempts") { if (!in(0, 1)) return -1; c->ldpc_split_fail_attempts = v; }       // (tests: the fall-back path of the half-row decoder's speculative layers)
     else if (n == "gardner_form") { if (!(v == 0 || v == 1 || v == 2 || v == 4)) return -1; c->gardner_form = v; }
     else if (n == "gardner_cand_skew") { c->gardner_cand_skew = v; }
     else if (n == "fe_slices") { if (!in(0, s2::S2_FE_MAX_SLICES)) return -1; c->fe_slices = v; }
@@ -287,7 +288,7 @@ static int ldpc_run(dvbs2gpu_ctx* ctx, const FecParams& f, const int8_t* d_llr, 
         }
         if (nframes > 0)
             HIP_TRY(ldpc_split_decode_launch(*C, d_llr, nframes, max_trials, force, d_hard, hard_stride, d_post, d_trials, (uint32_t*)W.msg.p, grid, st,
-                                             (unsigned int*)((char*)W.msg.p + need), (uint32_t*)((char*)W.msg.p + need + 256)));
+                                             (unsigned int*)((char*)W.msg.p + need), (uint32_t*)((char*)W.msg.p + need + 256), ctx->ldpc_split_fail_attempts));
         return 0;
     }
     // workgroups hold 2 frame slots, or 1 for batches smaller than the device (ldpc_kernel.hip)

@@ -177,6 +177,7 @@ struct dvbs2gpu_ctx {
     int gardner_form = 0;                     // 1 / 2 / 4: one form of the timing recovery (0: chosen by bank size and balance)
     int gardner_cand_skew = 0;                // tests only: skews the candidate form's arm prediction so that it leaves its tables
     int ldpc_wave = -1;                       // short frames: 0 / 1 = lane-per-row / wave-per-frame decoder (-1: per code)
+    int ldpc_split_fail_attempts = 0;         // tests only: every attempt of the half-row decoder's layers with shared bits is made to fail (ldpc_split_kernel.hip: the long way must give the same bits)
     int ldpc_split = 1;                       // 1: the half-row decoder for the normal frames it takes (ldpc_split_kernel.hip); 0: the lane-per-row decoder for every code
     int host_timing = 0;                      // 1: print where the host spends a batch call
     int stage_pipeline_launches = 0;          // option stage_loops: frame-loop launches per call (0 = chosen per call, s2_demod.hip)

@@ -40,7 +40,7 @@ bool ldpc_split_supported(int max_deg);
 int ldpc_split_blocks_per_cu(int max_deg, int N);
 size_t ldpc_split_msg_bytes_per_block(const LdpcDeviceCode& C);
 hipError_t ldpc_split_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nframes, int max_trials, int force, uint8_t* hard, int hard_stride,
-                                    int8_t* post, int32_t* trials, uint32_t* msg_ws, int grid, hipStream_t stream, unsigned int* work_ctr, uint32_t* sgn_ws);
+                                    int8_t* post, int32_t* trials, uint32_t* msg_ws, int grid, hipStream_t stream, unsigned int* work_ctr, uint32_t* sgn_ws, int dbg = 0);
 size_t ldpc_wave_msg_bytes_per_frame(const LdpcDeviceCode& C);
 size_t ldpc_wave_lds_bytes(const LdpcDeviceCode& C);
 hipError_t ldpc_wave_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nframes, int max_trials, int force, uint8_t* hard, int hard_stride,

@@ -867,7 +867,7 @@ hipError_t ldpc_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nf
     }
     A.llr = llr; A.hard = hard; A.post = post; A.trials = trials; A.msg_ws = msg_ws;
     A.nframes = nframes; A.N = C.N; A.K = C.K; A.R = C.R; A.q = C.q; A.pent_base = C.pent_base; A.synd_base = C.synd_base;
-    A.max_trials = max_trials; A.force = force; A.hard_stride = hard_stride;
+    A.max_trials = max_trials; A.force = force; A.hard_stride = hard_stride; A.dbg = 0;
     A.prof = g_ldpc_prof;
     const int max_deg = C.max_deg, irregular = C.irregular;
     LDPC_DISPATCH(launch_ldpc, C, A, grid, fpb, stream)

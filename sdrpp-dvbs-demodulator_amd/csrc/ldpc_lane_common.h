@@ -25,6 +25,7 @@ struct LdpcKernelArgs {
     int synd_base;         // offset of the syndrome-check table inside ents[] (ldpc_plan.h)
     int max_trials, force;
     int hard_stride;
+    int dbg;                    // tests only (context option ldpc_split_fail_attempts): 1 = every attempt of the half-row decoder's layers with shared bits is made to fail (the fall-back path)
     uint32_t* sgn_ws;           // [gridDim.x * slots][SGN_WS_DWORDS]: bit-packed posterior signs for the syndrome check
     unsigned int* work_ctr;     // optional: frames beyond the first gridDim.x*2 are claimed dynamically (workgroups slowed by
                                 // co-resident kernels of the pipelined mode then simply take fewer frames)
@@ -57,7 +58,7 @@ __device__ __forceinline__ LdpcKernelArgs ldpc_args(LdpcKernelParamsPtr P) {
     LdpcKernelArgs A;
     A.llr = P->A.llr; A.hard = P->A.hard; A.post = P->A.post; A.trials = P->A.trials; A.msg_ws = P->A.msg_ws;
     A.nframes = P->A.nframes; A.N = P->A.N; A.K = P->A.K; A.R = P->A.R; A.q = P->A.q; A.pent_base = P->A.pent_base; A.synd_base = P->A.synd_base;
-    A.max_trials = P->A.max_trials; A.force = P->A.force; A.hard_stride = P->A.hard_stride;
+    A.max_trials = P->A.max_trials; A.force = P->A.force; A.hard_stride = P->A.hard_stride; A.dbg = P->A.dbg;
     A.sgn_ws = P->A.sgn_ws; A.work_ctr = P->A.work_ctr; A.prof = P->A.prof;
     return A;
 }

@@ -339,7 +339,8 @@ typedef __attribute__((address_space(3))) u32x2_a4 lds_u2_a4;
 template <int MAXDEG>
 __device__ __forceinline__ void chain_layer(RowState<MAXDEG>& R, uint32_t (&rec_out)[SplitShape<MAXDEG>::REC],
                                             const LdpcSplitLayer L, const uint32_t eL, const int t, int8_t* __restrict__ post, uint32_t* __restrict__ cw,
-                                            const uint32_t flagb /* LDS address of the two verdict words */, const uint32_t cseq /* chain layers of this frame so far, this one included */) {
+                                            const uint32_t flagb /* LDS address of the two verdict words */, const uint32_t cseq /* chain layers of this frame so far, this one included */,
+                                            const bool fail_attempts /* tests: every attempt is made to fail */) {
     [[maybe_unused]] constexpr int KIND = 1;
     typedef __attribute__((address_space(3))) uint32_t lds_u1;
     const uint32_t rw = R.rw;
@@ -360,7 +361,7 @@ __device__ __forceinline__ void chain_layer(RowState<MAXDEG>& R, uint32_t (&rec_
     SPLIT_MARK(0);
     if (attempt) {
         row_output<MAXDEG, 2>(R, M0, M1, SXs, (level > 1u && !half1) ? 3u : 0u, rec_out, &pn0);
-        const bool bad = ((pn0 ^ (x0 >> 8)) & emask) != 0;
+        const bool bad = fail_attempts || ((pn0 ^ (x0 >> 8)) & emask) != 0;
         if (__builtin_amdgcn_ballot_w64(bad) != 0 && (t & 63) == 0) *(lds_u1*)(uintptr_t)my_flag = cseq;
         lds_pairs_wait();
         lds_barrier();
@@ -496,7 +497,8 @@ __device__ __forceinline__ LdpcSplitLayer layer_at(const_layer_ptr layers, int i
 template <int MAXDEG>
 __device__ __forceinline__ void spec_layer(RowState<MAXDEG>& R, uint32_t (&rec_out)[SplitShape<MAXDEG>::REC], const LdpcSplitLayer L, const uint32_t* __restrict__ tab, const int t,
                                            uint32_t* __restrict__ cw, [[maybe_unused]] unsigned long long* prof, [[maybe_unused]] const int pl,
-                                           const uint32_t vflagb /* LDS address of the two verdict words */, const uint32_t cseq /* layers with shared bits of this frame so far, this one included */) {
+                                           const uint32_t vflagb /* LDS address of the two verdict words */, const uint32_t cseq /* layers with shared bits of this frame so far, this one included */,
+                                           const bool fail_attempts /* tests: every attempt is made to fail */) {
     static_assert(SplitShape<MAXDEG>::HS >= 4, "the shared links are slots 0..3 of half 0");
     typedef __attribute__((address_space(3))) uint32_t lds_u1;
     const uint32_t level = R.rw & 0xffu;               // (both halves carry it; idle lanes: 0)
@@ -541,7 +543,7 @@ __device__ __forceinline__ void spec_layer(RowState<MAXDEG>& R, uint32_t (&rec_o
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(side_a) : : "memory");
         em0 = (((side_a.x >> 15) & 1u) ? 0xffu : 0u) | (((side_a.x >> 31) & 1u) ? 0xff0000u : 0u);
         em1 = (((side_a.y >> 15) & 1u) ? 0xffu : 0u) | (((side_a.y >> 31) & 1u) ? 0xff0000u : 0u);
-        const bool bad = (LDPC_SPLIT_DBG & 1) || (!half1 && ((((pn[0] ^ (xr[0] >> 8)) & em0) | ((pn[1] ^ (xr[1] >> 8)) & em1)) != 0));
+        const bool bad = (LDPC_SPLIT_DBG & 1) || fail_attempts || (!half1 && ((((pn[0] ^ (xr[0] >> 8)) & em0) | ((pn[1] ^ (xr[1] >> 8)) & em1)) != 0));
         if (__builtin_amdgcn_ballot_w64(bad) != 0 && (t & 63) == 0) *(lds_u1*)(uintptr_t)my_flag = cseq;
         if (!(LDPC_SPLIT_DBG & 8)) { lds_pairs_wait();
         lds_barrier(); }
@@ -806,10 +808,10 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                     row_output<MAXDEG, 0>(RS, M0, M1, SXs, 0u, ro);
                 } else if ((L.kind_nw & 0xffu) == 1) {
                     ++cseq;
-                    chain_layer<MAXDEG>(RS, ro, L, ents[L.ent_off + 1], tt, post, cw, cflagb, cseq);
+                    chain_layer<MAXDEG>(RS, ro, L, ents[L.ent_off + 1], tt, post, cw, cflagb, cseq, A.dbg != 0);
                 } else {
                     ++cseq;
-                    spec_layer<MAXDEG>(RS, ro, L, P->atab, tt, cw, A.prof, pl, cflagb, cseq);
+                    spec_layer<MAXDEG>(RS, ro, L, P->atab, tt, cw, A.prof, pl, cflagb, cseq, A.dbg != 0);
                 }
                 // the next pseudo-layer's words are claimed HERE, before this one's record store is issued: the wait for them then sits where they have had a whole
                 // pseudo-layer to arrive, and the top of the next pseudo-layer waits for nothing (ldpc_kernel.hip)
@@ -918,7 +920,7 @@ int ldpc_split_blocks_per_cu(int max_deg, int N) {
 }
 
 hipError_t ldpc_split_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nframes, int max_trials, int force, uint8_t* hard, int hard_stride,
-                                    int8_t* post, int32_t* trials, uint32_t* msg_ws, int grid, hipStream_t stream, unsigned int* work_ctr, uint32_t* sgn_ws) {
+                                    int8_t* post, int32_t* trials, uint32_t* msg_ws, int grid, hipStream_t stream, unsigned int* work_ctr, uint32_t* sgn_ws, int dbg) {
     LdpcKernelArgs A;
     A.work_ctr = work_ctr;
     A.sgn_ws = sgn_ws;
@@ -928,7 +930,7 @@ hipError_t ldpc_split_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, 
     }
     A.llr = llr; A.hard = hard; A.post = post; A.trials = trials; A.msg_ws = msg_ws;
     A.nframes = nframes; A.N = C.N; A.K = C.K; A.R = C.R; A.q = C.q; A.pent_base = C.split_rec_total; A.synd_base = C.synd_base;
-    A.max_trials = max_trials; A.force = force; A.hard_stride = hard_stride;
+    A.max_trials = max_trials; A.force = force; A.hard_stride = hard_stride; A.dbg = dbg;
     A.prof = g_ldpc_prof;
     const int max_deg = C.max_deg;
     LDPC_SPLIT_DISPATCH(launch_split, C, A, grid, stream)

@@ -1,7 +1,9 @@
 """The half-row LDPC decoder (csrc/ldpc_split_kernel.hip: two lanes per row, one frame per workgroup) serves the normal frames it takes (rates 1/2, 3/5, 3/4) by default; the
 context option ldpc_split = 0 hands them back to the lane-per-row decoder (csrc/ldpc_kernel.hip).  BOTH are run here on engines of their own: posteriors, trial
 counts and hard decisions must equal the oracle's -- early exit, iteration limit, forced iterations, erasures, saturating garbage -- and many frames must flow
-through the persistent grid's work counter."""
+through the persistent grid's work counter.  The half-row decoder's layers with shared bits are speculative (an ATTEMPT at the plain row update where the layer before changed no
+shared posterior, else a chain walk / passes): a third engine runs it with every attempt made to fail (context option ldpc_split_fail_attempts), so the fall-back path is held
+to the same bits."""
 import os
 
 import numpy as np
@@ -13,7 +15,7 @@ pytestmark = pytest.mark.gpu
 CODES = [(6, 0), (3, 0), (4, 0)]          # rate 3/4 (14 links per row), 1/2 (7: half 1 carries a neutral slot), 3/5 (11; level-walk layers of 10 .. 46 rows)
 
 
-@pytest.fixture(scope='module', params=[{'ldpc_split': 1}, {'ldpc_split': 0}], ids=['half_row', 'lane_per_row'])
+@pytest.fixture(scope='module', params=[{'ldpc_split': 1}, {'ldpc_split': 0}, {'ldpc_split': 1, 'ldpc_split_fail_attempts': 1}], ids=['half_row', 'lane_per_row', 'half_row_attempts_fail'])
 def split_engine(pkg, request):
     import torch
     if not torch.cuda.is_available():
@@ -43,6 +45,12 @@ def test_half_row_decoder_bit_exact(split_engine, pkg, rate, short):
         assert np.array_equal(post.cpu().numpy(), want_post), (force, mt)
         want_hard = np.packbits((want_post[:, :p['K']] < 0).astype(np.uint8), axis=1)
         assert np.array_equal(hard.cpu().numpy(), want_hard), (force, mt)
+    # frames that have long converged (the attempts' home ground): 30 forced iterations at a comfortable level
+    p2, llr2, _ = make_llrs(rate, short, 4, rng, [m + 4.0, m + 6.0])
+    want_post, want_trials = oracle_ldpc(rate, short, llr2, 30, 1)
+    hard, trials, post = split_engine.ldpc_decode(torch.from_numpy(llr2).cuda(), rate, bool(short), max_trials=30, force=True, want_post=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(trials.cpu().numpy(), want_trials) and np.array_equal(post.cpu().numpy(), want_post)
 
 
 def test_half_row_decoder_many_frames(split_engine):
