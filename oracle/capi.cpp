@@ -152,6 +152,20 @@ void orc_s2rx_pll_study(void* h, int tile, long long* hist34, long long* mismatc
     if (mismatch) *mismatch = r->study_mismatch;
     r->study_tile = tile;
 }
+// tools/g1_tile_study.py: the same question for FastAGC and the timing recovery (S2Rx::agc_tile_study, gardner_tile_study).  set: tile sizes (0 = off); get (NULL to skip): agc66 =
+// passes-per-tile histogram, agc2 = {tiles whose fixed point differs from the serial loop, samples}; gd34 = evaluation passes per tile, gd5 = {mismatching tiles, symbols, evaluation
+// passes, replay steps, tiles}
+void orc_s2rx_g1_study(void* h, int agc_tile, int gardner_tile, long long* agc66, long long* agc2, long long* gd34, long long* gd5) {
+    S2Rx* r = (S2Rx*)h;
+    if (agc66) for (int i = 0; i < 66; ++i) agc66[i] = r->agc_hist[i];
+    if (agc2) { agc2[0] = r->agc_mismatch; agc2[1] = r->agc_samples; }
+    if (gd34) for (int i = 0; i < 34; ++i) gd34[i] = r->gd_hist[i];
+    if (gd5) { gd5[0] = r->gd_mismatch; gd5[1] = r->gd_syms; gd5[2] = r->gd_evals; gd5[3] = r->gd_replay_steps; gd5[4] = r->gd_tiles; }
+    r->agc_study_tile = agc_tile; r->gardner_study_tile = gardner_tile;
+    for (long long& x : r->agc_hist) x = 0;
+    for (long long& x : r->gd_hist) x = 0;
+    r->agc_mismatch = r->agc_samples = r->gd_mismatch = r->gd_syms = r->gd_evals = r->gd_replay_steps = r->gd_tiles = 0;
+}
 void orc_s2rx_pll_study2(void* h, long long* out3) { S2Rx* r = (S2Rx*)h; out3[0] = r->study_steps; out3[1] = r->study_syms; out3[2] = r->study_evals; }
 float orc_s2rx_agc_gain(void* h) { return ((S2Rx*)h)->agc_gain_now(); }   // (tools/sensitivity.py: level at the AGC output = gain x input rms)
 

@@ -320,7 +320,44 @@ void S2Rx::reset() {
     hdr_pcl.init(a, b, 0, -(float)M_PI, (float)M_PI, 0, -1.0f * (float)M_PI, 1.0f * (float)M_PI, true);
 }
 
+// ---- round 6: the fixed-point question for FastAGC (test infrastructure, like pll_tile_study; nothing of the product runs this).  Per tile: the gain BEFORE every sample is guessed
+// (first: the tile's starting gain everywhere), a[k] = |x[k] g[k]| is evaluated for all k at once, the recurrence g[k + 1] = min(g[k] + (1 - a[k]) rate, 10e6) is replayed in the
+// reference's order with those a[k], and that is repeated until no gain changes: g[0] is exact, an exact g[k] gives the exact a[k] and so the exact g[k + 1] -- the fixed point is the
+// serial loop's sequence.  Histogram: evaluation passes per tile (the last one only confirms).
+void S2Rx::agc_tile_study(int n, const cf* in) {
+    const int T = agc_study_tile;
+    float g = agc_gain;
+    std::vector<float> G(T + 1), Gn(T + 1), A(T);
+    for (int base = 0; base < n; base += T) {
+        const int m = std::min(T, n - base);
+        std::vector<float> truth(m + 1);
+        truth[0] = g;
+        for (int k = 0; k < m; ++k) {
+            float a = camp(cscale(in[base + k], truth[k]));
+            float gn = truth[k] + (1.0f - a) * cfg.agc_rate;
+            truth[k + 1] = gn > 10e6f ? 10e6f : gn;
+        }
+        for (int k = 0; k <= m; ++k) G[k] = g;
+        int passes = 0;
+        for (;;) {
+            for (int k = 0; k < m; ++k) A[k] = camp(cscale(in[base + k], G[k]));
+            Gn[0] = g;
+            for (int k = 0; k < m; ++k) { float gn = Gn[k] + (1.0f - A[k]) * cfg.agc_rate; Gn[k + 1] = gn > 10e6f ? 10e6f : gn; }
+            ++passes;
+            bool same = true;
+            for (int k = 0; k <= m; ++k) same = same && memcmp(&Gn[k], &G[k], 4) == 0;
+            if (same || passes > T + 2) break;
+            for (int k = 0; k <= m; ++k) G[k] = Gn[k];
+        }
+        agc_hist[passes < 65 ? passes : 65]++;
+        for (int k = 0; k <= m; ++k) if (memcmp(&Gn[k], &truth[k], 4) != 0) { agc_mismatch++; break; }
+        agc_samples += m;
+        g = truth[m];
+    }
+}
+
 void S2Rx::agc(int n, const cf* in, cf* out) {   // SDR++ loop::FastAGC<complex_t>: set point 1, max gain 10e6
+    if (agc_study_tile > 0) agc_tile_study(n, in);
     for (int i = 0; i < n; ++i) {
         out[i] = cscale(in[i], agc_gain);
         float a = camp(out[i]);
@@ -345,7 +382,76 @@ static inline cf dot8(const cf* x, const float* t) {
     return acc;
 }
 
+// ---- round 6: the fixed-point question for the timing recovery (test infrastructure).  What an on-symbol output contributes to the loop -- the error e -- depends on WHERE it is taken
+// only: the sample offset and the polyphase arm floor(128 phase), two integers.  Per tile of S symbols: the (offset, arm) of every on-symbol output is guessed (first: the loop run
+// forward from the tile's start with e = 0), the errors are evaluated for all symbols at once (three interpolants each), the loop is replayed in the reference's order with those
+// errors up to the first symbol whose (offset, arm) is not the guessed one; from there the guesses are renewed (the loop run on with e = 0) and the errors evaluated again.  A symbol
+// whose place is right has the right error, so the replay's state behind it is the serial loop's: the result is the serial sequence.  Counted: evaluation passes per tile, replay
+// steps per symbol.
+void S2Rx::gardner_tile_study(int n, const cf* in) {
+    const int S = gardner_study_tile;
+    std::vector<cf> buf(n + 8);
+    for (int i = 0; i < 7; ++i) buf[i] = g_hist[i];
+    memcpy(&buf[7], in, sizeof(cf) * n);
+    Pcl pcl = g_pcl;
+    int offset = g_offset, sps = g_spsctr;
+    auto arm_of = [](const Pcl& p) { int a = (int)floorf(p.phase * 128.0f); return a < 0 ? 0 : (a > 127 ? 127 : a); };
+    auto step = [&](Pcl& p, int& off, float error) {
+        if (error > 1.0f) error = 1.0f;
+        if (error < -1.0f) error = -1.0f;
+        p.advance(error);
+        float delta = floorf(p.phase);
+        off = (int)((float)off + delta);
+        p.phase -= delta;
+    };
+    auto error_at = [&](int off, int phase) -> float {
+        cf outVal = dot8(&buf[off], &bank[(size_t)phase * 8]);
+        cf dfdt;
+        if (phase == 0) dfdt = csub(dot8(&buf[off], &bank[(size_t)(phase + 1) * 8]), outVal);
+        else if (phase == 127) dfdt = csub(outVal, dot8(&buf[off], &bank[(size_t)(phase - 1) * 8]));
+        else dfdt = cscale(csub(dot8(&buf[off], &bank[(size_t)(phase + 1) * 8]), dot8(&buf[off], &bank[(size_t)(phase - 1) * 8])), 0.5f);
+        return -(((outVal.re > 0 ? 1.0f : -1.0f) * dfdt.re) + ((outVal.im > 0 ? 1.0f : -1.0f) * dfdt.im));
+    };
+    // a slice that starts between the two outputs of a symbol: the follower first (as the engine's kernels do)
+    if (sps == 1 && offset < n) { step(pcl, offset, 0.0f); sps = 0; }
+    while (offset < n - 4 * S - 8) {          // whole tiles only (the ends of a slice go through single steps in the engine as well)
+        // serial truth
+        Pcl tp = pcl; int toff = offset;
+        std::vector<int> t_off(S), t_arm(S);
+        for (int k = 0; k < S; ++k) {
+            t_off[k] = toff; t_arm[k] = arm_of(tp);
+            step(tp, toff, error_at(toff, t_arm[k]));
+            step(tp, toff, 0.0f);
+        }
+        // tile
+        std::vector<int> g_off(S), g_arm(S);
+        std::vector<float> e(S);
+        Pcl rp = pcl; int roff = offset;      // the replay's state: exact up to symbol `done`
+        int done = 0, evals = 0;
+        while (done < S) {
+            // guesses from `done` on: the loop run on with e = 0
+            Pcl gp = rp; int goff = roff;
+            for (int k = done; k < S; ++k) { g_off[k] = goff; g_arm[k] = arm_of(gp); step(gp, goff, 0.0f); step(gp, goff, 0.0f); }
+            for (int k = done; k < S; ++k) e[k] = error_at(g_off[k], g_arm[k]);          // (in parallel on the device)
+            ++evals;
+            // replay up to the first symbol that is somewhere else
+            for (; done < S; ++done) {
+                if (roff != g_off[done] || arm_of(rp) != g_arm[done]) break;
+                step(rp, roff, e[done]);
+                step(rp, roff, 0.0f);
+                gd_replay_steps++;
+            }
+            if (evals > S + 2) break;
+        }
+        gd_hist[evals < 33 ? evals : 33]++;
+        gd_evals += evals; gd_tiles++; gd_syms += S;
+        if (roff != toff || memcmp(&rp.phase, &tp.phase, 4) != 0 || memcmp(&rp.freq, &tp.freq, 4) != 0) gd_mismatch++;
+        pcl = tp; offset = toff;
+    }
+}
+
 int S2Rx::gardner(int n, const cf* in, cf* out) {   // gardner.cpp:89-152, omega 1, outSps 2
+    if (gardner_study_tile > 0) gardner_tile_study(n, in);
     std::vector<cf> buf(n + 8);
     for (int i = 0; i < 7; ++i) buf[i] = g_hist[i];
     memcpy(&buf[7], in, sizeof(cf) * n);

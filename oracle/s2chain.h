@@ -119,7 +119,15 @@ public:
     int study_tile = 0;
     long long study_hist[34] = {};
     long long study_mismatch = 0;
-    long long study_steps = 0, study_syms = 0, study_evals = 0;   // the same tiles with the replay restarted at the first symbol whose table cell changed: replay steps, symbols, evaluation passes
+    long long study_steps = 0, study_syms = 0, study_evals = 0;
+    // the same question for the other two serial chains of a stream (round 6, tools/g1_tile_study.py): FastAGC in tiles of agc_study_tile samples (gains guessed, |x g| evaluated in
+    // parallel, the recurrence g += (1 - a) rate replayed, repeated until no gain changes) and the timing recovery in tiles of gardner_study_tile symbols ((sample offset, polyphase
+    // arm) of every on-symbol output guessed, the three interpolants and the error evaluated in parallel, the loop replayed up to the first symbol that lands elsewhere)
+    int agc_study_tile = 0, gardner_study_tile = 0;
+    long long agc_hist[66] = {}, agc_mismatch = 0, agc_samples = 0;
+    long long gd_hist[34] = {}, gd_mismatch = 0, gd_syms = 0, gd_evals = 0, gd_replay_steps = 0, gd_tiles = 0;
+    void agc_tile_study(int n, const cf* in);
+    void gardner_tile_study(int n, const cf* in);   // the same tiles with the replay restarted at the first symbol whose table cell changed: replay steps, symbols, evaluation passes
     std::vector<int8_t> dbg_llr;        // deinterleaved LLRs per frame
     std::vector<FrameStats> dbg_stats;
     float nco_freq() const { return nco_freq_; }
