@@ -66,3 +66,32 @@ def test_half_row_decoder_many_frames(split_engine):
     torch.cuda.synchronize()
     assert np.array_equal(trials.cpu().numpy(), np.tile(want_trials, reps))
     assert np.array_equal(post.cpu().numpy().reshape(reps, 4, -1), np.broadcast_to(want_post, (reps,) + want_post.shape))
+
+
+@pytest.mark.parametrize('rate', [6, 4, 3])
+def test_half_row_decoder_soak_against_the_lane_per_row_decoder(pkg, rate):
+    """many frames over a spread of noise levels (frames that converge at once, slowly, never), normal and forced mode, several iteration limits: the half-row decoder -- attempts,
+    passes, walks, whatever each frame makes it take -- and the lane-per-row decoder must agree bit for bit (posteriors, trial counts, hard decisions); the lane-per-row decoder
+    is held to the oracle by the tests above and by test_gpu_fec.py"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    rng = np.random.default_rng(77 + rate)
+    m = MARGINAL_SNR[rate]
+    snrs = list(np.linspace(m - 1.0, m + 6.0, 24)) + [-8.0]
+    p, llr, _ = make_llrs(rate, 0, 200, rng, snrs)
+    llr[7] = rng.integers(-128, 128, size=p['N']).astype(np.int8)
+    llr[9, ::5] = 0
+    a = pkg.Engine(0, options={'ldpc_split': 1})
+    b = pkg.Engine(0, options={'ldpc_split': 0})
+    try:
+        x = torch.from_numpy(llr).cuda()
+        for force, mt in ((0, 25), (1, 40), (1, 3), (0, 6)):
+            ha, ta, pa = a.ldpc_decode(x, rate, False, max_trials=mt, force=bool(force), want_post=True)
+            hb, tb, pb = b.ldpc_decode(x, rate, False, max_trials=mt, force=bool(force), want_post=True)
+            torch.cuda.synchronize()
+            assert torch.equal(ta, tb), (force, mt)
+            assert torch.equal(pa, pb), (force, mt)
+            assert torch.equal(ha, hb), (force, mt)
+    finally:
+        a.close(); b.close()
