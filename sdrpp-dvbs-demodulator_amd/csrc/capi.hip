@@ -115,7 +115,7 @@ int get_ldpc(dvbs2gpu_ctx* ctx, int code_index, LdpcDeviceCode** out) {
             // in 308 ms against the lane-per-row decoder's 336, the pipelined step 335 against 348 ms (r05).  The context option ldpc_split = 0 selects the
             // lane-per-row decoder (the parity tests run both).
             const LdpcSplitPlan SP = build_ldpc_split_plan(P);
-            if (SP.ok) {
+            if (SP.ok && (!SP.noprev_shared || ldpc_split_noprev_shared(P.max_deg))) {
                 if ((rc = upload(SP.layers, &D.d_split_layers))) return fail(rc);
                 std::vector<uint32_t> tab(SP.atab);
                 tab.insert(tab.end(), SP.side.begin(), SP.side.end());

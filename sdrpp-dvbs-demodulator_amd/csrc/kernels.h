@@ -37,6 +37,7 @@ hipError_t ldpc_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nf
                               int fpb, hipStream_t stream, unsigned int* work_ctr, uint32_t* sgn_ws);
 size_t ldpc_sign_ws_bytes_per_slot();
 bool ldpc_split_supported(int max_deg);
+bool ldpc_split_noprev_shared(int max_deg);      // kernels whose layers with shared bits handle the row without a previous parity bit
 int ldpc_split_blocks_per_cu(int max_deg, int N);
 size_t ldpc_split_msg_bytes_per_block(const LdpcDeviceCode& C);
 hipError_t ldpc_split_decode_launch(const LdpcDeviceCode& C, const int8_t* llr, int nframes, int max_trials, int force, uint8_t* hard, int hard_stride,

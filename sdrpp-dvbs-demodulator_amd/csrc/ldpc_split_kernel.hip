@@ -56,6 +56,9 @@ struct SplitShape {
     static constexpr int NPW = (HS / 2 + 1) <= 1 ? 1 : (HS / 2 + 1) <= 2 ? 2 : (HS / 2 + 1) <= 4 ? 4 : 8;
     static constexpr int REC = HS <= 4 ? 1 : HS <= 8 ? 2 : 4;
     static constexpr int RI_WORD = HS / 2, RI_SHIFT = (HS & 1) ? 16 : 0;     // where the row word sits (ldpc_split_plan.h)
+    // codes whose LAYER 0 -- it holds row 0, the row without a previous parity bit -- has shared bits (rates 2/5 and 2/3 normal): their layers with shared bits ask the
+    // descriptor (bit 20) whether they hold that row; the other codes' instruction streams stay as they were (their layer 0 is conflict-free: kind 7)
+    static constexpr int NOPREV_SHARED = (MAXDEG == 4 || MAXDEG == 8) ? 2 : 0;
     static_assert(HS / 2 + 1 <= NPW, "slots + row word must fit the thread's table entry (ldpc_split_plan.h)");
 };
 
@@ -357,7 +360,7 @@ __device__ __forceinline__ void chain_layer(RowState<MAXDEG>& R, uint32_t (&rec_
     int M0, M1, SXs;
     uint32_t x0, pn0 = 0;
     SPLIT_MARK_DECL;
-    row_input<MAXDEG, -1>(R, (!attempt && level > 1u && !half1) ? 1u : 0u, 1u, t, M0, M1, SXs, false, &x0);
+    row_input<MAXDEG, -1, SplitShape<MAXDEG>::NOPREV_SHARED>(R, (!attempt && level > 1u && !half1) ? 1u : 0u, 1u /* rows in lane order: row 0's half 1 */, t, M0, M1, SXs, ((L.kind_nw >> 20) & 1u) != 0, &x0);
     SPLIT_MARK(0);
     if (attempt) {
         row_output<MAXDEG, 2>(R, M0, M1, SXs, (level > 1u && !half1) ? 3u : 0u, rec_out, &pn0);
@@ -533,7 +536,7 @@ __device__ __forceinline__ void spec_layer(RowState<MAXDEG>& R, uint32_t (&rec_o
     }
     int M0, M1, SXs;
     uint32_t xr[2], pn[2] = {0u, 0u};
-    row_input<MAXDEG, -2>(R, (!attempt && spec) ? 1u : 0u, 1u, t, M0, M1, SXs, false, xr, 2);
+    row_input<MAXDEG, -2, SplitShape<MAXDEG>::NOPREV_SHARED>(R, (!attempt && spec) ? 1u : 0u, 1u, t, M0, M1, SXs, ((L.kind_nw >> 20) & 1u) != 0, xr, 2);
     uint32_t em0 = 0, em1 = 0;                         // the bytes of slots 0..3 a later row reads (known once the side entry is in)
 #if LDPC_SPLIT_SPEC_STATS
     if (prof && blockIdx.x == 0 && t == 0) { prof[900] += 1; prof[901] += attempt; prof[910 + (cseq < 40 ? cseq : 40)] += attempt; }
@@ -559,7 +562,7 @@ __device__ __forceinline__ void spec_layer(RowState<MAXDEG>& R, uint32_t (&rec_o
             }
             return;
         }
-        if (LDPC_SPLIT_DBG & 4) row_input<MAXDEG, -2>(R, spec ? 1u : 0u, 1u, t, M0, M1, SXs);
+        if (LDPC_SPLIT_DBG & 4) row_input<MAXDEG, -2, SplitShape<MAXDEG>::NOPREV_SHARED>(R, spec ? 1u : 0u, 1u, t, M0, M1, SXs, ((L.kind_nw >> 20) & 1u) != 0);
         else row_totals<MAXDEG, -2>(R, spec ? 1u : 0u, M0, M1, SXs);          // the long way: the totals without slots 0..3 where the row has predecessors
     } else {
         if (level == 1u) row_output<MAXDEG, 0>(R, M0, M1, SXs, 0u, rec_out, pn, 2);
@@ -811,7 +814,8 @@ __global__ __launch_bounds__(LDPC_SPLIT_T) __attribute__((amdgpu_waves_per_eu(LD
                     chain_layer<MAXDEG>(RS, ro, L, ents[L.ent_off + 1], tt, post, cw, cflagb, cseq, A.dbg != 0);
                 } else {
                     ++cseq;
-                    spec_layer<MAXDEG>(RS, ro, L, P->atab, tt, cw, A.prof, pl, cflagb, cseq, A.dbg != 0);
+                    // (a half of fewer than four slots has no speculative layers: the plan refuses them, ldpc_split_plan.h)
+                    if constexpr (S::HS >= 4) spec_layer<MAXDEG>(RS, ro, L, P->atab, tt, cw, A.prof, pl, cflagb, cseq, A.dbg != 0);
                 }
                 // the next pseudo-layer's words are claimed HERE, before this one's record store is issued: the wait for them then sits where they have had a whole
                 // pseudo-layer to arrive, and the top of the next pseudo-layer waits for nothing (ldpc_kernel.hip)
@@ -906,14 +910,18 @@ static int occupancy_split(int N) {
 
 #define LDPC_SPLIT_DISPATCH(FN, ...)                    \
     switch (max_deg) {                                  \
+        case 2: return FN<2>(__VA_ARGS__);              \
+        case 4: return FN<4>(__VA_ARGS__);              \
         case 5: return FN<5>(__VA_ARGS__);              \
+        case 8: return FN<8>(__VA_ARGS__);              \
         case 9: return FN<9>(__VA_ARGS__);              \
         case 12: return FN<12>(__VA_ARGS__);            \
         default: break;                                 \
     }
 
 extern unsigned long long* g_ldpc_prof;   // (ldpc_kernel.hip)
-bool ldpc_split_supported(int max_deg) { return max_deg == 5 || max_deg == 9 || max_deg == 12; }
+bool ldpc_split_supported(int max_deg) { return max_deg == 2 || max_deg == 4 || max_deg == 5 || max_deg == 8 || max_deg == 9 || max_deg == 12; }
+bool ldpc_split_noprev_shared(int max_deg) { return max_deg == 4 || max_deg == 8; }      // SplitShape::NOPREV_SHARED
 int ldpc_split_blocks_per_cu(int max_deg, int N) {
     LDPC_SPLIT_DISPATCH(occupancy_split, N)
     return 1;

@@ -45,11 +45,13 @@ struct LdpcSplitLayer {   // 16 bytes = one s_load_dwordx4
 
 struct LdpcSplitPlan {
     bool ok = false;
+    const char* why = "";            // why the half-row decoder does not take the code (ok == false)
     int hs = 0;                        // slots per half
     int npw = 0;                       // table words per thread and pseudo-layer (power of two)
     int rec_dwords = 0;                // message record per thread and pseudo-layer, dwords (1 byte per slot)
     int rec_total = 0;                 // dwords of message workspace per workgroup
     int chain_layers = 0;
+    bool noprev_shared = false;        // layer 0 -- it holds the row without a previous parity bit -- has shared bits: only kernels built for that take the code (SplitShape::NOPREV_SHARED)
     std::vector<LdpcSplitLayer> layers;
     std::vector<uint32_t> atab;
     std::vector<uint32_t> side;        // side entries of the kind-8 layers, [layer][384 rows][2]: uploaded BEHIND atab (LdpcSplitLayer::ent_off counts from the start of atab)
@@ -68,10 +70,10 @@ inline int ldpc_split_plan_rec_dwords(int max_deg) { const int hs = (max_deg + 3
 inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P) {
     LdpcSplitPlan S;
     const int NL = P.max_deg + 2;
-    if (P.min_deg != P.max_deg || (NL + 1) / 2 > 14 || P.N + LDPC_SPLIT_SCRATCH > 65536) return S;     // (ceil(NL / 2) slots + the row word in at most 8 table words)
+    if (P.min_deg != P.max_deg || (NL + 1) / 2 > 14 || P.N + LDPC_SPLIT_SCRATCH > 65536) { S.why = "irregular row degree, more than 14 slots per half or more than 65 472 bits"; return S; }     // (ceil(NL / 2) slots + the row word in at most 8 table words)
     for (const LdpcLayerDesc& L : P.layers) {
         const int nc = (int)(L.depth_nc >> 16), depth = (int)(L.depth_nc & 0xffffu);
-        if (depth > 1 && (nc > 4 || nc > (NL + 1) / 2)) return S;       // (the middle sections handle up to four shared links, all in half 0)
+        if (depth > 1 && (nc > 4 || nc > (NL + 1) / 2)) { S.why = "a layer with more than four shared links"; return S; }      // (the middle sections handle up to four shared links, all in half 0)
     }
     S.hs = (NL + 1) / 2;              // (an odd NL: half 1's last slot is a neutral link, its address a scratch byte)
     S.npw = ldpc_split_npw(S.hs);
@@ -90,7 +92,7 @@ inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P) {
         return ~0u;
     };
     std::vector<std::pair<int, std::vector<uint32_t>>> side_of;      // (pseudo-layer, its side entries): appended behind the tables once every layer is emitted
-    bool bad_noprev = false;      // layer 0 (it holds the row without a previous parity bit) must be conflict-free: only kind 7 handles the missing link
+    bool bad_noprev = false;      // the row without a previous parity bit in a layer with shared bits: kinds 1 / 8 ask bit 20 of the descriptor in the kernels built for it (S.noprev_shared)
     // one pseudo-layer: rows[] = the original rows of lane pairs 0, 1, ...; info[] = their row words (kind 1)
     auto emit = [&](int kind, int i, const std::vector<int>& rows, const std::vector<uint32_t>* info, uint32_t aux) {
         LdpcSplitLayer D{};
@@ -155,7 +157,7 @@ inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P) {
                         if (a == ~0u) continue;
                         auto it = last.find(a);
                         if (it != last.end()) {
-                            if (k >= 4 || k >= hs) return LdpcSplitPlan();          // (a shared link outside slots 0..3 of half 0)
+                            if (k >= 4 || k >= hs) { LdpcSplitPlan F; F.why = "a shared link outside slots 0..3 of half 0"; return F; }          // (a shared link outside slots 0..3 of half 0)
                             pred[k] = it->second;
                             lvl[j] = std::max(lvl[j], lvl[it->second.first] + 1);
                             side[2 * it->second.first + (it->second.second >> 1)] |= 0x8000u << (16 * (it->second.second & 1));       // that row's slot has a successor
@@ -166,7 +168,7 @@ inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P) {
                     for (int k = 0; k < 4; ++k)
                         if (pred[k].first >= 0 && lvl[pred[k].first] > 1) side[2 * j + (k >> 1)] |= (uint32_t)(4 * (j - pred[k].first) - pred[k].second) << (16 * (k & 1));
                 }
-                if (depth8 > 255 || hs < 4) return LdpcSplitPlan();
+                if (depth8 > 255 || hs < 4) { LdpcSplitPlan F; F.why = "a speculative layer deeper than 255 levels or fewer than 4 slots per half"; return F; }
                 for (int j = 0; j < 360; ++j) info[j] = (uint32_t)lvl[j];
                 emit(8, i, rows, &info, (uint32_t)depth8 << 16);
                 side_of.push_back({(int)S.layers.size() - 1, side});
@@ -178,7 +180,8 @@ inline LdpcSplitPlan build_ldpc_split_plan(const LdpcPlan& P) {
         S.layers[so.first].ent_off = (uint32_t)(S.atab.size() + S.side.size());
         S.side.insert(S.side.end(), so.second.begin(), so.second.end());
     }
-    S.ok = !bad_noprev;
+    S.ok = true;
+    S.noprev_shared = bad_noprev;
     return S;
 }
 

@@ -372,7 +372,7 @@ def test_ldpc_split_plan_keeps_the_reference_row_order(pkg, rate, short):
     assert (seen == 1).all()
 
 
-@pytest.mark.parametrize('rate', [6, 3, 4])
+@pytest.mark.parametrize('rate', [6, 3, 4, 5])
 def test_ldpc_split_plan_side_entries(pkg, rate):
     """the speculative passes (kind 8, csrc/ldpc_split_kernel.hip: spec_layer) read a shared slot from the output cell of the row that touched the bit last before this
     row -- in the reference's row order (layered_decoder.hh:46-74) -- or from the bit itself where that row has level 1 or does not exist; the plan's side entries must say

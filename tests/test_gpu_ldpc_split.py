@@ -1,4 +1,4 @@
-"""The half-row LDPC decoder (csrc/ldpc_split_kernel.hip: two lanes per row, one frame per workgroup) serves the normal frames it takes (rates 1/2, 3/5, 3/4) by default; the
+"""The half-row LDPC decoder (csrc/ldpc_split_kernel.hip: two lanes per row, one frame per workgroup) serves the normal frames it takes (rates 1/4, 2/5, 1/2, 3/5, 2/3, 3/4) by default; the
 context option ldpc_split = 0 hands them back to the lane-per-row decoder (csrc/ldpc_kernel.hip).  BOTH are run here on engines of their own: posteriors, trial
 counts and hard decisions must equal the oracle's -- early exit, iteration limit, forced iterations, erasures, saturating garbage -- and many frames must flow
 through the persistent grid's work counter.  The half-row decoder's layers with shared bits are speculative (an ATTEMPT at the plain row update where the layer before changed no
@@ -12,7 +12,8 @@ import orc
 from test_gpu_fec import MARGINAL_SNR, make_llrs, oracle_ldpc
 
 pytestmark = pytest.mark.gpu
-CODES = [(6, 0), (3, 0), (4, 0)]          # rate 3/4 (14 links per row), 1/2 (7: half 1 carries a neutral slot), 3/5 (11; level-walk layers of 10 .. 46 rows)
+CODES = [(6, 0), (3, 0), (4, 0), (5, 0), (2, 0), (0, 0)]          # rate 3/4 (14 links per row), 1/2 (7: half 1 carries a neutral slot), 3/5 (11), 2/3 (10; LAYER 0 -- with the row that has no previous
+                                                                  # parity bit -- is one with two shared pairs, 90 levels: speculative passes), 2/5 (6; layer 0 a chain layer), 1/4 (4: two slots per half)
 
 
 @pytest.fixture(scope='module', params=[{'ldpc_split': 1}, {'ldpc_split': 0}, {'ldpc_split': 1, 'ldpc_split_fail_attempts': 1}], ids=['half_row', 'lane_per_row', 'half_row_attempts_fail'])
@@ -21,7 +22,7 @@ def split_engine(pkg, request):
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     eng = pkg.Engine(0, options=request.param)
-    for r in (6, 3, 4):
+    for r, _ in CODES:
         assert eng.ldpc_decoder_form(r, False) == (2 if request.param['ldpc_split'] else 0)
     yield eng
     eng.close()
@@ -68,7 +69,7 @@ def test_half_row_decoder_many_frames(split_engine):
     assert np.array_equal(post.cpu().numpy().reshape(reps, 4, -1), np.broadcast_to(want_post, (reps,) + want_post.shape))
 
 
-@pytest.mark.parametrize('rate', [6, 4, 3])
+@pytest.mark.parametrize('rate', [6, 4, 3, 5, 2, 0])
 def test_half_row_decoder_soak_against_the_lane_per_row_decoder(pkg, rate):
     """many frames over a spread of noise levels (frames that converge at once, slowly, never), normal and forced mode, several iteration limits: the half-row decoder -- attempts,
     passes, walks, whatever each frame makes it take -- and the lane-per-row decoder must agree bit for bit (posteriors, trial counts, hard decisions); the lane-per-row decoder
