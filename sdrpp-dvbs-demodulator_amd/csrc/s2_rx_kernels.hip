@@ -451,6 +451,10 @@ __global__ __launch_bounds__(64) void s2_gardner_kernel(const S2StreamWork* __re
 #ifndef G2_TILE_N
 #define G2_TILE_N 16
 #endif
+#ifndef G2_PAIRS_N
+#define G2_PAIRS_N 2      // resolver + producer pairs per workgroup (A/B switch: 1 = round 5's 128-thread workgroups)
+#endif
+constexpr int G2_PAIRS = G2_PAIRS_N;
 constexpr int G2_TILE = G2_TILE_N;            // samples per stream and period
 constexpr int G2_RING = 4 * G2_TILE;
 constexpr int G2_PITCH = G2_RING + 8 + 1;     // ring + mirror of its first 8 slots; odd pitch
@@ -463,20 +467,33 @@ __device__ __forceinline__ void lds_only_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-__global__ __launch_bounds__(128) void s2_gardner2_kernel(const S2StreamWork* __restrict__ work, int nstreams, S2LoopCoefs co,
+__global__ __launch_bounds__(64 * 2 * G2_PAIRS) void s2_gardner2_kernel(const S2StreamWork* __restrict__ work, int nstreams, S2LoopCoefs co,
                                                          const float* __restrict__ bank_g, int sub, int nsub) {
     __shared__ __attribute__((aligned(16))) float bank[GARDNER_PHASES * GARDNER_TAPS];
-    __shared__ float ring[G_SPW * 2 * G2_PITCH];        // [stream][re/im][slot]
-    __shared__ uint32_t list[2][G_SPW][G2_LIST];        // per period parity: slot << 7 | arm of every output, in output order
-    __shared__ int s_cnt[2][G_SPW], s_ostart[2][G_SPW];
-    __shared__ const cf32* s_in[G_SPW];
-    __shared__ const cf32* s_gp[G_SPW];
-    __shared__ cf32* s_out[G_SPW];
-    __shared__ int s_n[G_SPW];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 3, r = lane & 7, arm = r >> 1, c = r & 1;
-    const int s0 = blockIdx.x * G_SPW, s = s0 + g;
+    // G2_PAIRS resolver + producer pairs per workgroup, each with its own 8 streams, rings and lists; they share the tap bank and the period barriers.  Why two: the hardware
+    // spreads the FOUR waves of a 256-thread workgroup over the four SIMDs of its compute unit, one each; of the two waves of a 128-thread workgroup it says nothing -- two such
+    // workgroups per compute unit leave one SIMD with two of these waves and one with none in 5 of 8 compute units (tools/ubench/placement.hip), and a decoder workgroup beside
+    // them (three waves per SIMD, a barrier per layer) runs at the pace of its most loaded SIMD.
+    __shared__ float ring_all[G2_PAIRS][G_SPW * 2 * G2_PITCH];        // [stream][re/im][slot]
+    __shared__ uint32_t list_all[G2_PAIRS][2][G_SPW][G2_LIST];        // per period parity: slot << 7 | arm of every output, in output order
+    __shared__ int s_cnt_all[G2_PAIRS][2][G_SPW], s_ostart_all[G2_PAIRS][2][G_SPW];
+    __shared__ const cf32* s_in_all[G2_PAIRS][G_SPW];
+    __shared__ const cf32* s_gp_all[G2_PAIRS][G_SPW];
+    __shared__ cf32* s_out_all[G2_PAIRS][G_SPW];
+    __shared__ int s_n_all[G2_PAIRS][G_SPW];
+    const int wave_wg = threadIdx.x >> 6, pair = wave_wg >> 1, wave = wave_wg & 1;
+    const int lane = threadIdx.x & 63, g = lane >> 3, r = lane & 7, arm = r >> 1, c = r & 1;
+    float* const ring = ring_all[pair];
+    uint32_t (*const list)[G_SPW][G2_LIST] = list_all[pair];
+    int (*const s_cnt)[G_SPW] = s_cnt_all[pair];
+    int (*const s_ostart)[G_SPW] = s_ostart_all[pair];
+    const cf32** const s_in = s_in_all[pair];
+    const cf32** const s_gp = s_gp_all[pair];
+    cf32** const s_out = s_out_all[pair];
+    int* const s_n = s_n_all[pair];
+    const int s0 = (blockIdx.x * G2_PAIRS + pair) * G_SPW, s = s0 + g;
     const bool act = s < nstreams;
-    for (int i = threadIdx.x; i < GARDNER_PHASES * GARDNER_TAPS; i += 128) bank[i] = bank_g[i];
+    for (int i = threadIdx.x; i < GARDNER_PHASES * GARDNER_TAPS; i += 64 * 2 * G2_PAIRS) bank[i] = bank_g[i];
     S2StreamWork w = work[act ? s : 0];
     int lo, hi;
     fe_sub_range(act ? w.count : 0, sub, nsub, lo, hi);
@@ -489,6 +506,16 @@ __global__ __launch_bounds__(128) void s2_gardner2_kernel(const S2StreamWork* __
             for (int k = 0; k < GARDNER_TAPS - 1; ++k) { const float h = c ? st->g_hist[k].im : st->g_hist[k].re; row[k] = h; row[G2_RING + k] = h; }
     }
     int nmax = n;
+    if constexpr (G2_PAIRS > 1) {
+        // (the other pairs' streams: every wave of the workgroup runs the same number of periods -- the barriers are the workgroup's)
+#pragma unroll
+        for (int op = 1; op < G2_PAIRS; ++op) {
+            const int so = (blockIdx.x * G2_PAIRS + ((pair + op) % G2_PAIRS)) * G_SPW + g;
+            int lo2, hi2;
+            fe_sub_range(so < nstreams ? work[so].count : 0, sub, nsub, lo2, hi2);
+            nmax = max(nmax, hi2 - lo2);
+        }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
     const int ntiles = (nmax + G2_TILE - 1) / G2_TILE;
@@ -3379,7 +3406,7 @@ static void gardner_launch(const S2StreamWork* d_work, int nstreams, const S2Loo
         case 4:
             hipLaunchKernelGGL(s2_gardner_cand_kernel, dim3((nstreams + GC_CS - 1) / GC_CS), dim3(192), 0, st, d_work, nstreams, coefs, d_bank, c, nsub, coefs.g_cand_skew);
             break;
-        case 2: hipLaunchKernelGGL(s2_gardner2_kernel, dim3((nstreams + G_SPW - 1) / G_SPW), dim3(128), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
+        case 2: hipLaunchKernelGGL(s2_gardner2_kernel, dim3((nstreams + G2_PAIRS * G_SPW - 1) / (G2_PAIRS * G_SPW)), dim3(64 * 2 * G2_PAIRS), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
         default: hipLaunchKernelGGL(s2_gardner_kernel, dim3((nstreams + G_SPW - 1) / G_SPW), dim3(64), 0, st, d_work, nstreams, coefs, d_bank, c, nsub); break;
     }
 }
