@@ -451,6 +451,10 @@ __global__ __launch_bounds__(64) void s2_gardner_kernel(const S2StreamWork* __re
 #ifndef G2_TILE_N
 #define G2_TILE_N 16
 #endif
+#ifndef G2_PROD_PRIO
+#define G2_PROD_PRIO 1    // wave priority of the producer waves (A/B switch).  Round 6: at 0 -- the decoder's own level, one of seven waves of its SIMD -- the producer, not the resolver, paced a period beside the
+                          // decoder; headline (driver's command, same call) 258.6 / 259.7 ms per step at 0, 255.1 / 252.6 at 1, 254.2 / 252.8 at 2; plugin's mode 126.9 / 124.7 / 123.9
+#endif
 #ifndef G2_PAIRS_N
 #define G2_PAIRS_N 2      // resolver + producer pairs per workgroup (A/B switch: 1 = round 5's 128-thread workgroups)
 #endif
@@ -567,6 +571,7 @@ __global__ __launch_bounds__(64 * 2 * G2_PAIRS) void s2_gardner2_kernel(const S2
         if (ntiles > 0) { issue(0); commit(0); }
         if (ntiles > 1) issue(1);
         lds_only_barrier();
+        if (G2_PROD_PRIO) __builtin_amdgcn_s_setprio(G2_PROD_PRIO);
         for (int t = 0; t < ntiles; ++t) {
             if (!(G2_EXP & 2) && t + 1 < ntiles) commit(t + 1);
             if (t + 2 < ntiles) issue(t + 2);
@@ -1474,8 +1479,17 @@ __device__ __forceinline__ cf32 pll_payload_tile(const cf32 sym, const bool mine
 
 // SPEC: with the loops ahead of the PL sync (below) compiled in -- small banks only: the plain instantiation has to stay within 128 registers
 // (it shares its SIMDs with three decoder waves in the pipelined mode), and the extra state costs it 14
+#ifndef FL_WPB_MAX_N
+#define FL_WPB_MAX_N 1      // waves per workgroup of a big bank's frame loops (A/B switch).  Round 6, same call: 2 -> decoder in the step 247.8 -> 245.8 ms but frame loops 108-115 -> 123-132 and the step 264.4 -> 271.7: a two-wave workgroup needs two free 128-register places on one compute unit at once, and beside the decoder every SIMD has ONE
+#endif
+constexpr int FL_WPB_MAX = FL_WPB_MAX_N;
+// a bank of at least one single-wave workgroup per compute unit (256) goes out in workgroups of FL_WPB_MAX waves; smaller ones keep a workgroup -- a compute unit -- per wave
+static inline int frame_loops_wpb(int nstreams, int spw) { const int nb = (nstreams + spw - 1) / spw; return nb >= 256 ? FL_WPB_MAX : 1; }
+static inline int frame_loops_grid(int nstreams, int spw) { const int nb = (nstreams + spw - 1) / spw, w = frame_loops_wpb(nstreams, spw); return (nb + w - 1) / w; }
+// what __syncthreads() is in a single-wave workgroup (the compiler drops its s_barrier there): a wave's LDS writes before its LDS reads -- the waves of these workgroups share nothing
+#define FL_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 template <bool SPEC>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void s2_frame_loops_kernel(const S2StreamWork* __restrict__ work, int nstreams,
+__global__ __launch_bounds__(64 * FL_WPB_MAX) __attribute__((amdgpu_waves_per_eu(4, 4))) void s2_frame_loops_kernel(const S2StreamWork* __restrict__ work, int nstreams,
                                                             const S2FrameRef* __restrict__ frames, const int* __restrict__ first,
                                                             S2LoopCoefs co, S2PlTablesDev T, S2ConstelDev C, int pls_code, int slots,
                                                             int pilots, int pilot_blocks, int plframe, cf32* __restrict__ pllout,
@@ -1489,19 +1503,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // mixed batch: this workgroup's streams share the configuration of its first one (s2_demod.hip sees to that); `plframe` as passed is then the
     // stride of the PLL-output slots (the longest PLFRAME of the batch)
     const int slot_stride = plframe;
+    // WAVES of a workgroup are independent of one another (a big bank is launched with FL_WPB_MAX of them per workgroup for the sake of their PLACEMENT: the hardware spreads the
+    // waves of one workgroup over the SIMDs of its compute unit, single-wave workgroups land where they land -- tools/ubench/placement.hip); wave `wv` of workgroup b is what
+    // the single-wave workgroup b * waves + wv was: its own streams, its own tiles, no workgroup barrier anywhere (FL_SYNC orders a wave's own LDS traffic)
+    const int wv = threadIdx.x >> 6, vb = (int)blockIdx.x * ((int)blockDim.x >> 6) + wv;
+    if (vb * spw >= nstreams) return;
     if (cfgs) {
-        const S2StreamCfgDev* __restrict__ q = cfgs + min((int)blockIdx.x * spw, nstreams - 1);
+        const S2StreamCfgDev* __restrict__ q = cfgs + min(vb * spw, nstreams - 1);
         C = q->con; pls_code = q->pls_code; slots = q->slots; pilots = q->pilots; pilot_blocks = q->pilot_blocks; plframe = q->plframe;
     }
-    __shared__ cf32 tiles[FL_SPW][2 * FL_TILE]; // per stream: [input tile | output tile]
-    __shared__ uint8_t rnt[FL_TILE];
-    __shared__ cf32 s_pts[32];                 // constellation points for the 32APSK phase-error search (the other constellations use the LUT)
-    if (C.bits == 5 && threadIdx.x < 32) s_pts[threadIdx.x] = threadIdx.x < (unsigned)C.states ? C.pts_g[threadIdx.x] : cf32{0.f, 0.f};
-    const int lane = threadIdx.x, g = lane / FL_LPS, gl = lane % FL_LPS;
+    __shared__ cf32 tiles_all[FL_WPB_MAX][FL_SPW][2 * FL_TILE]; // per wave and stream: [input tile | output tile]
+    __shared__ uint8_t rnt_all[FL_WPB_MAX][FL_TILE];
+    __shared__ cf32 s_pts_all[FL_WPB_MAX][32];                 // constellation points for the 32APSK phase-error search (the other constellations use the LUT)
+    cf32 (*const tiles)[2 * FL_TILE] = tiles_all[wv];
+    uint8_t* const rnt = rnt_all[wv];
+    cf32* const s_pts = s_pts_all[wv];
+    const int lane = threadIdx.x & 63, g = lane / FL_LPS, gl = lane % FL_LPS;
+    if (C.bits == 5 && lane < 32) s_pts[lane] = lane < C.states ? C.pts_g[lane] : cf32{0.f, 0.f};
     cf32* const tl = &tiles[g][0];                      // input tile (also a 36-symbol pilot block for the FED; with the output tile: the 90 header symbols)
     cf32* const ot = &tiles[g][FL_TILE];                // output tile
     float* const fd = reinterpret_cast<float*>(ot);     // FED terms live in the (then unused) output tile
-    const int s0 = blockIdx.x * spw, s = s0 + g;
+    const int s0 = vb * spw, s = s0 + g;
     const bool act = g < spw && s < nstreams;
     const int sc = act ? s : s0;
     S2StreamState* st = work[sc].st;
@@ -1606,14 +1628,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         fetch(b0);
         for (int base = b0; base < b1; base += FL_TILE) {
             const int m = min(FL_TILE, plframe - base);
-            __syncthreads();
+            FL_SYNC();
 #pragma unroll
             for (int t = 0; t < NPF; ++t) {
                 const int i = gl + t * FL_LPS;
                 if (i < m) tl[i] = pf[t];
             }
             if (lane < m) rnt[lane] = (uint8_t)prn;
-            __syncthreads();
+            FL_SYNC();
             if (base + FL_TILE < b1) fetch(base + FL_TILE);
             // A tile of payload symbols only (no header, no pilot symbol: all but a handful of the frame's tiles) takes the short loop: rotate, phase
             // error, advance -- the Gold-sequence rotation of the OUTPUT (descrambling acts on the rotated symbol and feeds nothing back into
@@ -1808,7 +1830,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     pacc = cf32{0.f, 0.f};
                 }
             }
-            __syncthreads();
+            FL_SYNC();
             if (fact)
                 for (int i = gl; i < m; i += FL_LPS)
                     if (base + i >= 90) {
@@ -1818,7 +1840,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     }
         }
         if (fin) {
-        __syncthreads();
+        FL_SYNC();
         // ---- coarse frequency error detector (dvbs2_fed.h): terms in parallel, summed in the reference's order
         #pragma unroll 1
         for (int i = gl; i < 88; i += FL_LPS) {
@@ -1826,19 +1848,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             cf32 r0 = i < 26 ? T.sof[i] : plsc[i - 26];
             fd[i] = cmul(cmul(cmul(fr[i + 2], cconj(r2)), cconj(fr[i])), r0).im;
         }
-        __syncthreads();
+        FL_SYNC();
         float err = 0.f, symcnt = 90 - 2;
         for (int i = 0; i < 88; ++i) err += fd[i];
         if (pilots) {
             const cf32 p{0.707f, 0.707f};
             for (int b = 0; b < pilot_blocks; ++b) {
                 int start = pilot_start(b);
-                __syncthreads();
+                FL_SYNC();
                 for (int i = gl; i < 36; i += FL_LPS) tl[i] = pl_descramble(fr[start + i], T.rn[start - 90 + i]);
-                __syncthreads();
+                FL_SYNC();
                 for (int i = gl; i < 36; i += FL_LPS)
                     if (i >= 2) fd[i] = cmul(cmul(cmul(tl[i], cconj(p)), cconj(tl[i - 2])), p).im;
-                __syncthreads();
+                FL_SYNC();
                 for (int i = 2; i < 36; ++i) err += fd[i];
                 symcnt += 36 - 2;
             }
@@ -1850,12 +1872,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (nco_freq < -0.3f * PI_F) nco_freq = -0.3f * PI_F;
         // ---- PL header demod (dvbs2_plhdr_demod.cpp:33-67)
         // (the 90 header symbols are staged now, over the input + output tiles the PLL loop is through with)
-        __syncthreads();
+        FL_SYNC();
         #pragma unroll 1
         for (int i = gl; i < 90; i += FL_LPS) tl[i] = fr[i];
         unsigned long long plheader = 0;
         const cf32 rot{(float)0.70710678118654757, (float)-0.70710678118654746};   // (cos(-pi/4), sin(-pi/4)) in double, cast
-        __syncthreads();
+        FL_SYNC();
         for (int i = 0; i < 90; ++i) {
             cf32 tmp_val = cmul(tl[i], phasor_fast(-hdr.phase));
             float error = ((tmp_val.re > 0 ? 1.0f : -1.0f) * tmp_val.im) - ((tmp_val.im > 0 ? 1.0f : -1.0f) * tmp_val.re);
@@ -1884,7 +1906,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             for (int o = FL_LPS / 2; o > 0; o >>= 1) key = min(key, __shfl_xor(key, o));      // all-reduce inside the lane group
         } else {
             // soft ML decode over all 64 code bits (include/dvbs2gpu.h): metric_c = sum_p +-soft[p] in index order, highest wins, lowest c on ties
-            __syncthreads();
+            FL_SYNC();
             float bm = 0.f;
             int bc = 0x7fffffff;
             #pragma unroll 1
@@ -1912,7 +1934,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         }   // fin
         if (!fact) { pll = pll_in; hdr = hdr_in; nco_freq = nco_in; }
-        __syncthreads();
+        FL_SYNC();
     }
     if (act && gl == 0) {
         st->pll_phase = pll.phase; st->pll_freq = pll.freq;
@@ -1927,6 +1949,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
 }
 
+#undef FL_SYNC
 // ------------------------------------------------------------------------------------------------ demapper
 // where bit c (MSB first) of payload symbol j goes (s2_deinterleaver.cpp:72-136): QPSK swaps the pair (:80-84), the others are
 // column-row de-interleaved, 8PSK 3/5 with the columns reversed (:26-31)
@@ -3361,7 +3384,7 @@ static hipError_t post_stages_launch(const S2StreamWork* d_work, int nstreams, c
                                    (const int*)nullptr, coefs, p.tabs, p.con, p.pls_code, p.slots, p.pilots, p.pilot_blocks, p.raw, p.d_pllout, p.d_stats,
                                    (const S2VcmFound*)p.d_found, p.maxf, spw, p.cfgs);
             else
-            hipLaunchKernelGGL(s2_frame_loops_kernel<false>, dim3((nstreams + spw - 1) / spw), dim3(64), 0, s, d_work, nstreams, (const S2FrameRef*)nullptr,
+            hipLaunchKernelGGL(s2_frame_loops_kernel<false>, dim3(frame_loops_grid(nstreams, spw)), dim3(64 * frame_loops_wpb(nstreams, spw)), 0, s, d_work, nstreams, (const S2FrameRef*)nullptr,
                                (const int*)nullptr, coefs, p.tabs, p.con, p.pls_code, p.slots, p.pilots, p.pilot_blocks, p.raw, p.d_pllout, p.d_stats,
                                (const S2VcmFound*)p.d_found, p.maxf, spw, p.cfgs);
             if (p.spans) p.spans->end(3, s);
@@ -3482,7 +3505,7 @@ hipError_t s2_frame_loops_launch(const S2StreamWork* d_work, int nstreams, const
                                  S2LoopCoefs coefs, S2PlTablesDev tabs, S2ConstelDev con, int pls_code, int slots, int pilots,
                                  int pilot_blocks, int plframe, cf32* d_pllout, S2FrameStats* d_stats, hipStream_t st) {
     const int spw = frame_loops_spw(nstreams);
-    hipLaunchKernelGGL(s2_frame_loops_kernel<false>, dim3((nstreams + spw - 1) / spw), dim3(64), 0, st, d_work, nstreams, d_frames, d_first, coefs,
+    hipLaunchKernelGGL(s2_frame_loops_kernel<false>, dim3(frame_loops_grid(nstreams, spw)), dim3(64 * frame_loops_wpb(nstreams, spw)), 0, st, d_work, nstreams, d_frames, d_first, coefs,
                        tabs, con, pls_code, slots, pilots, pilot_blocks, plframe, d_pllout, d_stats, (const S2VcmFound*)nullptr, 0, spw, (const S2StreamCfgDev*)nullptr);
     return hipGetLastError();
 }

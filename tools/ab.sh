@@ -18,7 +18,7 @@ for V in "$@"; do
   elif [ "${MODE:-bench}" = ldpc ]; then
     echo "== $V"; (cd $R && DVBS2GPU_LIB=/tmp/libdvbs2gpu_variant.so python tools/ldpc_sweep.py ${RATES:-6,0})
   else
-    (cd $R && DVBS2GPU_LIB=/tmp/libdvbs2gpu_variant.so python bench.py --steps ${STEPS:-8} --warmup 1 --no-cpu-baseline --no-secondary ${BENCH_ARGS:-} 2>/dev/null | python -c "
+    (cd $R && DVBS2GPU_LIB=/tmp/libdvbs2gpu_variant.so python bench.py --steps ${STEPS:-8} --warmup ${WARMUP:-1} --no-cpu-baseline --no-secondary ${BENCH_ARGS:-} 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$V', d['value'], d['ms_per_step'], d['stage_ms_per_step'], 'ldpc alone', d['roofline']['kernel_ms_alone'])")
   fi
