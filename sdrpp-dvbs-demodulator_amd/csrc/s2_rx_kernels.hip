@@ -451,6 +451,9 @@ __global__ __launch_bounds__(64) void s2_gardner_kernel(const S2StreamWork* __re
 #ifndef G2_TILE_N
 #define G2_TILE_N 16
 #endif
+#ifndef G2_FORCE_VGPRS
+#define G2_FORCE_VGPRS 0
+#endif
 #ifndef G2_PROD_PRIO
 #define G2_PROD_PRIO 1    // wave priority of the producer waves (A/B switch).  Round 6: at 0 -- the decoder's own level, one of seven waves of its SIMD -- the producer, not the resolver, paced a period beside the
                           // decoder; headline (driver's command, same call) 258.6 / 259.7 ms per step at 0, 255.1 / 252.6 at 1, 254.2 / 252.8 at 2; plugin's mode 126.9 / 124.7 / 123.9
@@ -626,6 +629,9 @@ __global__ __launch_bounds__(64 * 2 * G2_PAIRS) void s2_gardner2_kernel(const S2
         offset = (int)((float)offset + delta);
         pcl.phase -= delta;
     };
+#if G2_FORCE_VGPRS
+    asm volatile("" ::: "v123");             // (A/B: the register count the kernel had while its written-out loop named v100..v123)
+#endif
     lds_only_barrier();                       // period 0 is staged
     __builtin_amdgcn_s_setprio(G_PRIO);       // latency-critical serial loop (see agc_pc_kernel)
     for (int t = 0; t < ntiles; ++t) {
@@ -672,87 +678,87 @@ __global__ __launch_bounds__(64 * 2 * G2_PAIRS) void s2_gardner2_kernel(const S2
                 "s_and_b64 vcc, vcc, s[86:87]\n\t"
                 "s_and_b64 exec, exec, vcc\n\t"
                 "s_cbranch_execz 4f\n\t"
-                "v_mul_f32 v100, s82, %[ph]\n\t"
-                "v_floor_f32 v100, v100\n\t"
-                "v_cvt_i32_f32 v100, v100\n\t"
-                "v_med3_i32 v100, v100, 0, s83\n\t"                                        // phase
-                "v_add_u32 v101, -1, v100\n\t"
-                "v_cmp_lt_u32 vcc, s84, v101\n\t"                                          // phase 0 or 127: the one-sided derivative, the general way
+                "v_mul_f32 v36, s82, %[ph]\n\t"
+                "v_floor_f32 v36, v36\n\t"
+                "v_cvt_i32_f32 v36, v36\n\t"
+                "v_med3_i32 v36, v36, 0, s83\n\t"                                        // phase
+                "v_add_u32 v37, -1, v36\n\t"
+                "v_cmp_lt_u32 vcc, s84, v37\n\t"                                          // phase 0 or 127: the one-sided derivative, the general way
                 "s_cbranch_vccnz 4f\n\t"
-                "v_add_u32 v101, v100, %[darm]\n\t"
-                "v_med3_i32 v101, v101, 0, s83\n\t"                                        // this lane's arm
-                "v_and_b32 v102, 63, %[off]\n\t"                                           // slot
-                "v_lshl_add_u32 v103, v102, 2, %[rowa]\n\t"
-                "v_lshl_add_u32 v101, v101, 5, %[banka]\n\t"
-                "ds_read_b128 v[104:107], v101\n\t"
-                "ds_read_b128 v[108:111], v101 offset:16\n\t"
-                "ds_read2_b32 v[112:113], v103 offset1:1\n\t"
-                "ds_read2_b32 v[114:115], v103 offset0:2 offset1:3\n\t"
-                "ds_read2_b32 v[116:117], v103 offset0:4 offset1:5\n\t"
-                "ds_read2_b32 v[118:119], v103 offset0:6 offset1:7\n\t"
-                "v_lshl_or_b32 v102, v102, 7, v100\n\t"
-                "ds_write_b32 %[lpa], v102\n\t"                                            // list: (slot, phase) of the on-symbol output
+                "v_add_u32 v37, v36, %[darm]\n\t"
+                "v_med3_i32 v37, v37, 0, s83\n\t"                                        // this lane's arm
+                "v_and_b32 v38, 63, %[off]\n\t"                                           // slot
+                "v_lshl_add_u32 v39, v38, 2, %[rowa]\n\t"
+                "v_lshl_add_u32 v37, v37, 5, %[banka]\n\t"
+                "ds_read_b128 v[40:43], v37\n\t"
+                "ds_read_b128 v[44:47], v37 offset:16\n\t"
+                "ds_read2_b32 v[48:49], v39 offset1:1\n\t"
+                "ds_read2_b32 v[50:51], v39 offset0:2 offset1:3\n\t"
+                "ds_read2_b32 v[52:53], v39 offset0:4 offset1:5\n\t"
+                "ds_read2_b32 v[54:55], v39 offset0:6 offset1:7\n\t"
+                "v_lshl_or_b32 v38, v38, 7, v36\n\t"
+                "ds_write_b32 %[lpa], v38\n\t"                                            // list: (slot, phase) of the on-symbol output
                 "s_waitcnt lgkmcnt(4)\n\t"
-                "v_mul_f32 v120, v112, v104\n\t"
-                "v_add_f32 v120, 0, v120\n\t"
-                "v_mul_f32 v121, v113, v105\n\t"
-                "v_add_f32 v120, v120, v121\n\t"
+                "v_mul_f32 v56, v48, v40\n\t"
+                "v_add_f32 v56, 0, v56\n\t"
+                "v_mul_f32 v57, v49, v41\n\t"
+                "v_add_f32 v56, v56, v57\n\t"
                 "s_waitcnt lgkmcnt(3)\n\t"
-                "v_mul_f32 v121, v114, v106\n\t"
-                "v_add_f32 v120, v120, v121\n\t"
-                "v_mul_f32 v121, v115, v107\n\t"
-                "v_add_f32 v120, v120, v121\n\t"
+                "v_mul_f32 v57, v50, v42\n\t"
+                "v_add_f32 v56, v56, v57\n\t"
+                "v_mul_f32 v57, v51, v43\n\t"
+                "v_add_f32 v56, v56, v57\n\t"
                 "s_waitcnt lgkmcnt(2)\n\t"
-                "v_mul_f32 v121, v116, v108\n\t"
-                "v_add_f32 v120, v120, v121\n\t"
-                "v_mul_f32 v121, v117, v109\n\t"
-                "v_add_f32 v120, v120, v121\n\t"
+                "v_mul_f32 v57, v52, v44\n\t"
+                "v_add_f32 v56, v56, v57\n\t"
+                "v_mul_f32 v57, v53, v45\n\t"
+                "v_add_f32 v56, v56, v57\n\t"
                 "s_waitcnt lgkmcnt(1)\n\t"
-                "v_mul_f32 v121, v118, v110\n\t"
-                "v_add_f32 v120, v120, v121\n\t"
-                "v_mul_f32 v121, v119, v111\n\t"
-                "v_add_f32 v120, v120, v121\n\t"                                           // acc = this lane's interpolant (arm x re / im)
-                "v_cvt_f32_i32 v122, %[off]\n\t"
+                "v_mul_f32 v57, v54, v46\n\t"
+                "v_add_f32 v56, v56, v57\n\t"
+                "v_mul_f32 v57, v55, v47\n\t"
+                "v_add_f32 v56, v56, v57\n\t"                                           // acc = this lane's interpolant (arm x re / im)
+                "v_cvt_f32_i32 v58, %[off]\n\t"
                 "s_nop 0\n\t"
-                "v_mov_b32_dpp v121, v120 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          // xm: the phase - 1 arm
-                "v_sub_f32_dpp v121, v120, v121 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"    // xp - xm
-                "v_mul_f32 v121, 0.5, v121\n\t"
-                "v_cmp_lt_f32 vcc, 0, v120\n\t"
-                "v_cndmask_b32_e64 v121, -v121, v121, vcc\n\t"                             // (xo > 0 ? 1 : -1) * d, valid in the lanes of arm 1
+                "v_mov_b32_dpp v57, v56 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          // xm: the phase - 1 arm
+                "v_sub_f32_dpp v57, v56, v57 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"    // xp - xm
+                "v_mul_f32 v57, 0.5, v57\n\t"
+                "v_cmp_lt_f32 vcc, 0, v56\n\t"
+                "v_cndmask_b32_e64 v57, -v57, v57, vcc\n\t"                             // (xo > 0 ? 1 : -1) * d, valid in the lanes of arm 1
                 "s_nop 1\n\t"
-                "v_add_f32_dpp v121, v121, v121 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   // re half + im half
+                "v_add_f32_dpp v57, v57, v57 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   // re half + im half
                 "s_nop 1\n\t"
-                "v_mov_b32_dpp v123, v121 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_mov_b32_dpp v59, v57 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                 "s_nop 1\n\t"
-                "v_mov_b32_dpp v121, v123 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                "v_cndmask_b32_e64 v121, v121, v123, %[lo4]\n\t"
-                "v_med3_f32 v121, -v121, -1.0, 1.0\n\t"                                    // error = clamp(-(e_re + e_im))
-                "v_mul_f32 v123, %[beta], v121\n\t"
-                "v_add_f32 %[fr], %[fr], v123\n\t"
+                "v_mov_b32_dpp v57, v59 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                "v_cndmask_b32_e64 v57, v57, v59, %[lo4]\n\t"
+                "v_med3_f32 v57, -v57, -1.0, 1.0\n\t"                                    // error = clamp(-(e_re + e_im))
+                "v_mul_f32 v59, %[beta], v57\n\t"
+                "v_add_f32 %[fr], %[fr], v59\n\t"
                 "v_med3_f32 %[fr], %[fr], %[minf], %[maxf]\n\t"
-                "v_mul_f32 v123, %[alpha], v121\n\t"
-                "v_add_f32 v123, %[fr], v123\n\t"
-                "v_add_f32 %[ph], %[ph], v123\n\t"
-                "v_floor_f32 v123, %[ph]\n\t"
-                "v_sub_f32 %[ph], %[ph], v123\n\t"
-                "v_add_f32 v122, v122, v123\n\t"
-                "v_cvt_i32_f32 %[off], v122\n\t"
+                "v_mul_f32 v59, %[alpha], v57\n\t"
+                "v_add_f32 v59, %[fr], v59\n\t"
+                "v_add_f32 %[ph], %[ph], v59\n\t"
+                "v_floor_f32 v59, %[ph]\n\t"
+                "v_sub_f32 %[ph], %[ph], v59\n\t"
+                "v_add_f32 v58, v58, v59\n\t"
+                "v_cvt_i32_f32 %[off], v58\n\t"
                 // the follower
-                "v_mul_f32 v100, s82, %[ph]\n\t"
-                "v_floor_f32 v100, v100\n\t"
-                "v_cvt_i32_f32 v100, v100\n\t"
-                "v_med3_i32 v100, v100, 0, s83\n\t"
-                "v_and_b32 v102, 63, %[off]\n\t"
-                "v_lshl_or_b32 v102, v102, 7, v100\n\t"
-                "ds_write_b32 %[lpa], v102 offset:4\n\t"
+                "v_mul_f32 v36, s82, %[ph]\n\t"
+                "v_floor_f32 v36, v36\n\t"
+                "v_cvt_i32_f32 v36, v36\n\t"
+                "v_med3_i32 v36, v36, 0, s83\n\t"
+                "v_and_b32 v38, 63, %[off]\n\t"
+                "v_lshl_or_b32 v38, v38, 7, v36\n\t"
+                "ds_write_b32 %[lpa], v38 offset:4\n\t"
                 "v_add_u32 %[lpa], 8, %[lpa]\n\t"
                 "v_med3_f32 %[fr], %[fr], %[minf], %[maxf]\n\t"
                 "v_add_f32 %[ph], %[ph], %[fr]\n\t"
-                "v_floor_f32 v123, %[ph]\n\t"
-                "v_cvt_f32_i32 v122, %[off]\n\t"
-                "v_sub_f32 %[ph], %[ph], v123\n\t"
-                "v_add_f32 v122, v122, v123\n\t"
-                "v_cvt_i32_f32 %[off], v122\n\t"
+                "v_floor_f32 v59, %[ph]\n\t"
+                "v_cvt_f32_i32 v58, %[off]\n\t"
+                "v_sub_f32 %[ph], %[ph], v59\n\t"
+                "v_add_f32 v58, v58, v59\n\t"
+                "v_cvt_i32_f32 %[off], v58\n\t"
                 "s_branch 1b\n\t"
                 "4:\n\t"
                 "s_mov_b64 exec, s[80:81]\n\t"
@@ -760,8 +766,8 @@ __global__ __launch_bounds__(64 * 2 * G2_PAIRS) void s2_gardner2_kernel(const S2
                 : [ph] "+v"(pcl.phase), [fr] "+v"(pcl.freq), [off] "+v"(offset), [lpa] "+v"(lpa)
                 : [lim3] "v"(lim3), [lpalim] "v"(lpa_lim), [darm] "v"(d_arm), [rowa] "v"(rowa), [banka] "v"(banka), [inmask] "s"(inmask),
                   [alpha] "s"(alpha_s), [beta] "s"(beta_s), [minf] "s"(minf_s), [maxf] "v"(maxf_v), [lo4] "s"(0x0F0F0F0F0F0F0F0Full)
-                : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117",
-                  "v118", "v119", "v120", "v121", "v122", "v123", "s80", "s81", "s82", "s83", "s84", "s86", "s87", "vcc", "scc", "memory");
+                : "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53",
+                  "v54", "v55", "v56", "v57", "v58", "v59", "s80", "s81", "s82", "s83", "s84", "s86", "s87", "vcc", "scc", "memory");
             cnt = (int)((lpa - lista) >> 2);
         }
 #endif
