@@ -451,6 +451,9 @@ __global__ __launch_bounds__(64) void s2_gardner_kernel(const S2StreamWork* __re
 #ifndef G2_TILE_N
 #define G2_TILE_N 16
 #endif
+#ifndef G2_EXTRA_VALU
+#define G2_EXTRA_VALU 0     // sensitivity experiment: dead vector instructions per producer wave and period (how much does the decoder beside it pay per front-end instruction?)
+#endif
 #ifndef G2_FORCE_VGPRS
 #define G2_FORCE_VGPRS 0
 #endif
@@ -579,6 +582,14 @@ __global__ __launch_bounds__(64 * 2 * G2_PAIRS) void s2_gardner2_kernel(const S2
             if (!(G2_EXP & 2) && t + 1 < ntiles) commit(t + 1);
             if (t + 2 < ntiles) issue(t + 2);
             if (!(G2_EXP & 1) && t >= 1) produce(t - 1);
+#if G2_EXTRA_VALU
+            {   // (sensitivity experiment: dead vector instructions per period)
+                float dead = (float)t;
+#pragma unroll 8
+                for (int i = 0; i < G2_EXTRA_VALU; ++i) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dead));
+                asm volatile("" :: "v"(dead));
+            }
+#endif
             lds_only_barrier();
         }
         if (!(G2_EXP & 1) && ntiles > 0) produce(ntiles - 1);
