@@ -3421,8 +3421,8 @@ hipError_t s2_post_stages_launch(const S2StreamWork* d_work, int nstreams, const
 //   4096 streams x 8 frames QPSK 1/2 (front end critical): form 1  283 | 337 | 465     form 2  297 | 356 | 410
 //   1024 streams x 4 frames 8PSK 3/4:                      form 1   71 |  48 |  76     form 2   60 |  49 |  65
 //    384 streams x 4 frames:                               form 1   65 |  19 |  67     form 2   52 |  18 |  54     form 4  51 | 19 | 53
-// Default: form 4 up to S2_GARDNER_CAND_MAX streams; form 2 below S2_GARDNER_BANK_MIN streams and wherever the pipelined mode's balancer has found the front
-// end critical (duty >= 2); form 1 for big banks beside a decoder that is.  The context option gardner_form = 1 | 2 | 4 forces one.
+// Default: form 4 up to S2_GARDNER_CAND_MAX streams; form 2 above (rounds 4-5: form 1 for big banks beside a decoder that is the critical path -- see gardner_form()).
+// The context option gardner_form = 1 | 2 | 4 forces one.
 #ifndef S2_GARDNER_BANK_MIN
 #define S2_GARDNER_BANK_MIN 512
 #endif
@@ -3438,8 +3438,10 @@ static int gardner_form(int nstreams, int prio_duty, int lane_form, int forced) 
     if (nstreams < S2_GARDNER_BANK_MIN) return 2;
     // a big bank beside the decoder of the previous call: the one-wave form disturbs the decoder least; once the balancer of the pipelined
     // mode (s2_demod.hip) has found the FRONT END to be the critical path (it raises the timing loop's priority share), the shorter forms win
-    (void)lane_form;
-    return prio_duty < 2 ? 1 : 2;
+    // (round 6: form 2's workgroups of four waves spread evenly over a compute unit's SIMDs and its waves take 60 registers -- it now disturbs the decoder less than the one-wave
+    //  form everywhere: mixed 64-entry batch, whose shared front-end pass has no balancer, 206 -> 195.5 ms per step; the headline's balancer ends at a share >= 2 anyway)
+    (void)lane_form; (void)prio_duty;
+    return 2;
 }
 static void gardner_launch(const S2StreamWork* d_work, int nstreams, const S2LoopCoefs& coefs, const float* d_bank, hipStream_t st, int c, int nsub) {
     switch (gardner_form(nstreams, coefs.g_prio_duty, coefs.g_lane_form, coefs.g_form)) {
