@@ -493,6 +493,9 @@ static int deliver_job(dvbs2gpu_ctx* ctx, PendingFec* job, hipStream_t st, Works
 #ifndef S2_POST_PRIO_MIN_DUTY
 #define S2_POST_PRIO_MIN_DUTY 5
 #endif
+#ifndef S2_PRIO_START_DUTY
+#define S2_PRIO_START_DUTY 3      // (third part of round 6, headline at --warmup 2 | 5: start 2 -> 274.8, 254.4 | 252.3; 3 -> 253.0, 252.8, 252.5 | 252.7, 252.6; 4 -> 254.8, 255.6 | 256.0: from 4 the first verdicts take it to 5, post stages up, and the dead band keeps it there)
+#endif
 static int post_prio_wanted(const dvbs2gpu_ctx* ctx) { return ctx->pipeline_fec && ctx->g_prio_duty >= S2_POST_PRIO_MIN_DUTY ? 1 : 0; }
 static hipError_t create_stream(dvbs2gpu_ctx*, hipStream_t* out, int) { return hipStreamCreateWithFlags(out, hipStreamNonBlocking); }
 static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work, int n, const S2LoopCoefs& co, hipStream_t st, const S2PostStages* post = nullptr,
@@ -877,9 +880,10 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             const long long sig = ((long long)n << 32) ^ ((long long)d0->cfg.modcod << 20) ^ ((long long)d0->cfg.shortframes << 19) ^ ((long long)d0->cfg.pilots << 18) ^
                                   ((long long)(d0->cfg.force_ldpc_iters & 0xff) << 8) ^ (long long)(d0->cfg.max_ldpc_trials & 0xff);
             const bool sig_changed = sig != ctx->g_prio_sig;
-            // (a new configuration starts at share 2, where the decoder-bound ones settle -- from 0 the headline's first four calls ran 55 ms long each, the front end being their
-            //  critical path, and the plugin's mode needed 14 calls to its share of 7)
-            if (sig_changed) { ctx->g_prio_sig = sig; ctx->g_prio_duty = 2; ctx->g_prio_trend = 0; ctx->g_prio_hold = 0; ctx->g_prio_last_down = 0; }
+            // (a new configuration starts at share S2_PRIO_START_DUTY -- from 0 the headline's first four calls ran 55 ms long each, the front end being their critical path, and the
+            //  plugin's mode needed 14 calls to its share of 7; rounds 5-6 started at 2, where the decoder-bound configurations settled then; since the timing recovery's producers
+            //  run above the decoder they settle at 4: headline 4, config 5's stand-in 4, config 2 5, plugin's mode 7)
+            if (sig_changed) { ctx->g_prio_sig = sig; ctx->g_prio_duty = std::min(ctx->g_prio_cap, S2_PRIO_START_DUTY); ctx->g_prio_trend = 0; ctx->g_prio_hold = 0; ctx->g_prio_last_down = 0; }
             const auto t_d1 = std::chrono::steady_clock::now();
             const double wait_ms = std::chrono::duration<double, std::milli>(t_d1 - t_d0).count();
             const double call_ms = std::chrono::duration<double, std::milli>(t_d1 - t_entry).count();
