@@ -120,7 +120,9 @@ int dvbs2gpu_ldpc_plan_dump(int rate, int shortframes, uint32_t* layers4, uint32
  * counts2 = {words in the table, words per row}; table: [q][384][words per row], two 16-bit byte offsets per word. */
 int dvbs2gpu_ldpc_wave_plan_dump(int rate, int shortframes, uint32_t* lanec, uint16_t* steps, uint32_t* layer_end, int32_t* counts6);
 int dvbs2gpu_ldpc_addr_table_dump(int rate, int shortframes, uint32_t* table, int32_t* counts2);
-/* The half-row decoder's plan (csrc/ldpc_split_plan.h; codes it does not take: counts6[0] = 0).
+/* The half-row decoder's plan (csrc/ldpc_split_plan.h; codes it does not take: counts6[0] = 0, return value 0, and dvbs2gpu_last_error() says why -- irregular rows, a layer
+ * with more than four shared links, ...).  A plan is listed for every code the PLAN takes; the decoder serves the normal frames of rates 1/4, 2/5, 1/2, 3/5, 2/3, 3/4
+ * (dvbs2gpu_ldpc_decoder_form).
  * counts6 = {pseudo-layers, table words per thread, slots per row half, message-workspace dwords per workgroup, words in the table, record dwords};
  * layers4: 4 uint32 per pseudo-layer {kind | waves << 8 | flags, kind 1: chain step | steps << 16, kind 8: levels << 16, record offset, kind 1: first link entry, kind 8: word offset
  * of the layer's side entries in `table`}; table: [pseudo-layer][768][words] (two 16-bit LDS byte offsets per word, the row word behind the last slot), then the side entries of the

@@ -587,7 +587,7 @@ int dvbs2gpu_ldpc_split_plan_dump(int rate, int shortframes, uint32_t* layers4, 
     const LdpcPlan P = build_ldpc_plan(f.code_index);
     const LdpcSplitPlan S = build_ldpc_split_plan(P);
     counts6[0] = S.ok ? (int32_t)S.layers.size() : 0; counts6[1] = S.npw; counts6[2] = S.hs; counts6[3] = S.rec_total; counts6[4] = (int32_t)(S.atab.size() + S.side.size()); counts6[5] = S.rec_dwords;      // (table words: the pseudo-layers' tables, then the side entries of the kind-8 layers -- what the device holds)
-    if (!S.ok) return 0;
+    if (!S.ok) { g_err = std::string("the half-row decoder does not take this code: ") + S.why; return 0; }      // (not an error: counts6[0] = 0; the reason through dvbs2gpu_last_error)
     if (layers4) memcpy(layers4, S.layers.data(), S.layers.size() * sizeof(LdpcSplitLayer));
     if (table) { memcpy(table, S.atab.data(), S.atab.size() * sizeof(uint32_t)); if (!S.side.empty()) memcpy(table + S.atab.size(), S.side.data(), S.side.size() * sizeof(uint32_t)); }
     if (row_of) for (size_t i = 0; i < S.row_of.size(); ++i) row_of[i] = S.row_of[i];
