@@ -749,7 +749,7 @@ def mixed64(eng, pkg, dev, dd, steps, warmup, nt=64, sub=64, F=1):
             % (nt * cfg['sub'], len(MIXED_MODCODS), nt, MIXED_MODCODS, cfg['sub']))
     res = {'config': what + ', normal frames, %d PLFRAME(s) per stream per step, 50 forced LDPC iterations' % cfg['frames'],
            'value': round(total_sym_per_step * steps / dt / 1e6, 1), 'unit': 'Msymbols/s', 'scaling': 'strong', 'n_gpus': dd.world,
-           'ms_per_step': round(dt / steps * 1e3, 2), 'transponders_per_rank': [len(a) for a in assign],
+           'ms_per_step': round(dt / steps * 1e3, 2), 'steps': steps, 'warmup': warmup, 'transponders_per_rank': [len(a) for a in assign],
            'load_per_rank_rel_to_average': [round(sum(table[i]['weight'] for i in a) * dd.world / sum(t['weight'] for t in table), 3) for a in assign],
            'ms_per_step_per_rank': [round(x / steps * 1e3, 2) for x in dt_ranks],
            'ms_per_step_rank_max_min': [round(max(dt_ranks) / steps * 1e3, 2), round(min(dt_ranks) / steps * 1e3, 2)],
@@ -969,7 +969,7 @@ def main():
     if not args.no_secondary:
         # BASELINE config 4 runs on every world size (strong scaling; at N = 1 it is the one-GPU number)
         try:
-            m64 = mixed64(eng, pkg, dev, dd, 10, 1, F=args.mixed_frames)
+            m64 = mixed64(eng, pkg, dev, dd, 20, 2, F=args.mixed_frames)
         except Exception as e:
             m64 = {'error': repr(e)}
         if rank == 0:
@@ -977,7 +977,7 @@ def main():
         # ... and BASELINE config 4 as it is named: 64 transponders, one stream each (4 PLFRAMEs per transponder and step)
         # (measured in either order: the GPU-sized variant loses 4 % behind this one, this one gains nothing in front)
         try:
-            m64l = mixed64(eng, pkg, dev, dd, 10, 1, sub=1, F=4)
+            m64l = mixed64(eng, pkg, dev, dd, 20, 2, sub=1, F=4)
         except Exception as e:
             m64l = {'error': repr(e)}
         if rank == 0:
