@@ -968,6 +968,11 @@ def main():
             line['secondary'] = sec
     if not args.no_secondary:
         # BASELINE config 4 runs on every world size (strong scaling; at N = 1 it is the one-GPU number)
+        # (an engine of their own for the mixed-batch lines when DVBS2GPU_BENCH_FRESH_ENGINE=1: development aid -- do the streams the earlier lines created cost these their hardware queues?)
+        if os.environ.get('DVBS2GPU_BENCH_FRESH_ENGINE') == '1':
+            eng.close()
+            torch.cuda.empty_cache()
+            eng = pkg.Engine(local_rank)
         try:
             m64 = mixed64(eng, pkg, dev, dd, 20, 2, F=args.mixed_frames)
         except Exception as e:
