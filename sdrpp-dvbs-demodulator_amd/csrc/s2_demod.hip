@@ -1564,11 +1564,41 @@ int dvbs2gpu_demod_set_params(dvbs2gpu_demod* d, int modcod, int shortframes, in
 
 int dvbs2gpu_demod_get_kbch(dvbs2gpu_demod* d) { return d ? d->mp.fec.kbch : DVBS2GPU_ERR_ARG; }
 
+// The runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues as they are created, and streams that share a queue take turns: a pipelined run's streams should not find the
+// queues half taken by streams an EARLIER run of another shape left behind (round 6: the 4096-carrier mixed batch 192 ms per step in an engine of its own, 205-214 ms behind the
+// bench's other lines -- and config 4 as named 36 or 61 ms depending on who came first).  So a pipelined run starts by giving the context's streams back; everything here is created
+// on demand again.  (Not at the END of a run: synchronous small calls are better off on the streams they inherit -- a wait between two streams of ONE hardware queue is cheap, and a
+// call of a few thousand samples is ~130 launches tied together by such waits: with fresh streams the drop-in call of 8192 samples took 3.4 instead of 2.4 ms.)
+static int release_streams(dvbs2gpu_ctx* ctx) {
+    HIP_TRY(hipDeviceSynchronize());
+    {
+        std::lock_guard<std::mutex> l(ctx->mtx);
+        for (auto& kv : ctx->fe_aux) {
+            dvbs2gpu_ctx::FeAux& a = kv.second;
+            if (a.aux) (void)hipStreamDestroy(a.aux);
+            if (a.aux2) (void)hipStreamDestroy(a.aux2);
+            if (a.aux3) (void)hipStreamDestroy(a.aux3);
+            for (hipEvent_t e : a.ev) if (e) (void)hipEventDestroy(e);
+            for (hipEvent_t e : a.ev2) if (e) (void)hipEventDestroy(e);
+            for (hipEvent_t e : a.ev3) if (e) (void)hipEventDestroy(e);
+            for (hipStream_t d : a.dvbs_aux) if (d) (void)hipStreamDestroy(d);
+            for (auto& row : a.dvbs_ev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
+        }
+        ctx->fe_aux.clear();
+    }
+    for (hipStream_t& sg : ctx->grp_stream) if (sg) { (void)hipStreamDestroy(sg); sg = nullptr; }
+    if (ctx->fec_part_stream) { (void)hipStreamDestroy(ctx->fec_part_stream); ctx->fec_part_stream = nullptr; }
+    if (ctx->fec_stream) { (void)hipStreamDestroy(ctx->fec_stream); ctx->fec_stream = nullptr; }
+    if (ctx->fe_stream) { (void)hipStreamDestroy(ctx->fe_stream); ctx->fe_stream = nullptr; }
+    ctx->fec_last_done = nullptr; ctx->fec_last_stream = nullptr;
+    return 0;
+}
 int dvbs2gpu_set_pipelined(dvbs2gpu_ctx* ctx, int on) {
     if (!ctx) return DVBS2GPU_ERR_ARG;
     CallGuard guard(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     if (on) {      // (the FEC stream may exist already: synchronous mixed batches use it too)
+        if (!ctx->pipeline_fec) { int rr = release_streams(ctx); if (rr) return rr; }
         if (!ctx->fe_stream) HIP_TRY(create_stream(ctx, &ctx->fe_stream, +1));
         if (!ctx->fec_stream) HIP_TRY(create_stream(ctx, &ctx->fec_stream, -1));
         if (!ctx->ev_llr) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_llr, hipEventDisableTiming));
@@ -1731,6 +1761,7 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
                 if (a.aux3) (void)hipStreamDestroy(a.aux3);
                 for (hipEvent_t e : a.ev) if (e) (void)hipEventDestroy(e);
                 for (hipEvent_t e : a.ev2) if (e) (void)hipEventDestroy(e);
+                for (hipEvent_t e : a.ev3) if (e) (void)hipEventDestroy(e);
                 for (hipStream_t d : a.dvbs_aux) if (d) (void)hipStreamDestroy(d);
                 for (auto& row : a.dvbs_ev) for (hipEvent_t e : row) if (e) (void)hipEventDestroy(e);
                 it = ctx->fe_aux.erase(it);
