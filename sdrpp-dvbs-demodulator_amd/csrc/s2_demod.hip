@@ -498,8 +498,11 @@ static int deliver_job(dvbs2gpu_ctx* ctx, PendingFec* job, hipStream_t st, Works
 #endif
 static int post_prio_wanted(const dvbs2gpu_ctx* ctx) { return ctx->pipeline_fec && ctx->g_prio_duty >= S2_POST_PRIO_MIN_DUTY ? 1 : 0; }
 static hipError_t create_stream(dvbs2gpu_ctx*, hipStream_t* out, int) { return hipStreamCreateWithFlags(out, hipStreamNonBlocking); }
+#ifndef S2_MIN_SLICE_SAMPLES
+#define S2_MIN_SLICE_SAMPLES 1024     // a time slice holds at least this many samples per stream (a call of a few thousand samples is not cut into 32 slices of 133 launches)
+#endif
 static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work, int n, const S2LoopCoefs& co, hipStream_t st, const S2PostStages* post = nullptr,
-                                  bool own_post_stream = false, int* nsub_out = nullptr) {
+                                  bool own_post_stream = false, int* nsub_out = nullptr, int max_count = 0 /* the longest input of the call, samples (0: not known) */) {
     // (measured: beside the decoder of the previous call 4, alone 8; a small bank is a latency chain in either mode: the shorter pipeline fill wins)
     // (banks up to 256 streams: 16 -- one 8PSK stream 32.4 -> 31.6 ms per 4-frame call, 64 x 1 frame 16.1 -> 15.7)
     // (a big bank in the throughput mode whose FRONT END the balancer has found critical -- priority share 4 or more -- is sliced like a synchronous call: plugin's mode 139.9 -> 137.4 ms,
@@ -507,6 +510,9 @@ static hipError_t frontend_sliced(dvbs2gpu_ctx* ctx, const S2StreamWork* d_work,
     const bool fe_critical = ctx->pipeline_fec && ctx->g_prio_auto && ctx->g_prio_duty >= 4;
     int nsub = ctx->fe_slices > 0 ? ctx->fe_slices : (n <= 8 ? 32 : (n <= 256 ? 16 : (ctx->pipeline_fec && !fe_critical ? 4 : 8)));    // (a handful of streams: 32 -- 28.7 -> 27.9 ms per 4-frame call)
     if (nsub > S2_FE_MAX_SLICES) nsub = S2_FE_MAX_SLICES;
+    // (SDR++-sized calls, third part of round 6: one stream, 8 192 samples per call, ms per call at 2 / 4 / 8 / 16 / 32 slices: 2.31 / 2.16 / 2.12 / 2.20 / 2.45; 32 768 samples:
+    //  7.03 / 5.50 / 5.17 / 4.87 -- about a thousand samples per slice and stream)
+    if (max_count > 0 && ctx->fe_slices <= 0) nsub = std::max(1, std::min(nsub, max_count / S2_MIN_SLICE_SAMPLES));
     if (nsub_out) *nsub_out = nsub > 1 ? nsub : 1;
     S2LoopCoefs cc = co;
     cc.g_prio_duty = ctx->pipeline_fec ? ctx->g_prio_duty : 0;
@@ -639,7 +645,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
             post.spec = 1;
             post.loops_launches = std::min(S2_FE_MAX_SLICES, std::max(launches, (max_count / 2) / std::max(sym_per_launch, 1)));
         }
-        { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st, &post, ctx->stage_post_stream == 2 || ((!pipelined || n <= S2_SMALL_BANK || (ctx->g_prio_auto && ctx->g_prio_duty >= 4)) && ctx->stage_post_stream))); }   // (a small bank is a set of latency chains in the throughput mode too: its post stages on the AGC's stream made one stream's 4-frame call 39.9 ms instead of 25;
+        { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st, &post, ctx->stage_post_stream == 2 || ((!pipelined || n <= S2_SMALL_BANK || (ctx->g_prio_auto && ctx->g_prio_duty >= 4)) && ctx->stage_post_stream), nullptr, max_count)); }   // (a small bank is a set of latency chains in the throughput mode too: its post stages on the AGC's stream made one stream's 4-frame call 39.9 ms instead of 25;
         //  a big bank whose FRONT END the balancer has found critical -- priority share 4 or more: the plugin's mode, QPSK -- likewise: AGC + RRC + walk + frame loops on one
         //  stream were 127 ms of launches per 140 ms step; beside a decoder that is the critical path the shared stream stays: headline 347 vs 361 ms per step)
         slot_stats.resize(nslot);
@@ -647,7 +653,7 @@ int process_group(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
     } else {
         if (!pre_nsym) {
             // (with pre_nsym the MODCOD-independent stages already ran for the whole batch: frontend_prepass)
-            { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st)); }
+            { StageSpan sp(ctx->timers, ST_FRONTEND, st); HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st, nullptr, false, nullptr, max_count)); }
             { StageSpan sp(ctx->timers, ST_RRC, st); HIP_TRY(s2_rrc_decim_launch(d_work, n, max_count + max_count / 32 + 8, d_taps, d0->cfg.rrc_taps, st, post_prio_wanted(ctx))); }
         }
         { StageSpan sp(ctx->timers, ST_PLSYNC, st); HIP_TRY(s2_ccm_walk_launch(d_work, n, raw, maxf, d_found, d_counts, st, post_prio_wanted(ctx))); }
@@ -1289,7 +1295,7 @@ int process_mixed(dvbs2gpu_ctx* ctx, dvbs2gpu_demod* const* dm, int n, const cf3
         StageSpan sp(ctx->timers, ST_FRONTEND, st);
         // (the post stages on a stream of their own in either mode: on the AGC's stream every slice's frame loops queue in front of the AGC slice the
         //  timing recovery waits for next -- 4.3 instead of 2.4 ms per slice)
-        HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st, &post, true));
+        HIP_TRY(frontend_sliced(ctx, d_work, n, d0->co, st, &post, true, nullptr, max_count));
     }
     std::vector<S2FrameStats> slot_stats(nslot);
     std::vector<S2VcmFound> found(nslot);
