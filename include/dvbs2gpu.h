@@ -265,7 +265,11 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
  * to collect them).  Streams of different configurations may share the batch (one FEC job per configuration group and call, at
  * most 16 groups); ACM/VCM streams too (one job per LDPC code present in the call, BBFRAMEs of differing size: per-frame sizes in
  * dvbs2gpu_frame_stats.bbframe_bytes).  A call with all counts 0 collects the last frames; switching the mode off drops
- * uncollected ones. */
+ * uncollected ones.
+ * INPUT AND OUTPUT BUFFERS: as in the synchronous mode, device work the host has put on the legacy null stream before the call -- the copies or kernels that fill d_iq --
+ * lies in front of the demodulator (the mode's own stream waits for it), and the buffers may be reused when the call returns; a host that fills them on a stream of
+ * its own synchronises that stream before the call.  The delivered BBFRAMEs are complete when the call returns.  Switching the mode ON synchronises the device and
+ * gives the context's internal streams back to the runtime (created again on demand). */
 int dvbs2gpu_set_pipelined(dvbs2gpu_ctx* ctx, int on);
 
 /* Stats of the frames completed by the last process call of this handle (the public fields the GUI polls,

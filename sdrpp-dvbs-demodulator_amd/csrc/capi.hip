@@ -473,6 +473,7 @@ void dvbs2gpu_destroy(dvbs2gpu_ctx* ctx) {
     if (ctx->fec_stream) (void)hipStreamDestroy(ctx->fec_stream);
     if (ctx->fec_part_stream) (void)hipStreamDestroy(ctx->fec_part_stream);
     if (ctx->ev_llr) (void)hipEventDestroy(ctx->ev_llr);
+    if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
     for (int g = 0; g < dvbs2gpu_ctx::MAX_PIPE_GROUPS; ++g) {
         for (int k = 0; k < 2; ++k) if (ctx->ev_fec[g][k]) (void)hipEventDestroy(ctx->ev_fec[g][k]);
         for (int k = 0; k < 2; ++k) if (ctx->ev_fec_t0[g][k]) (void)hipEventDestroy(ctx->ev_fec_t0[g][k]);

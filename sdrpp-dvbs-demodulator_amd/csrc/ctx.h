@@ -136,6 +136,7 @@ struct dvbs2gpu_ctx {
     int pipeline_fec = 0;
     hipStream_t fe_stream = nullptr, fec_stream = nullptr;
     hipEvent_t ev_llr = nullptr;
+    hipEvent_t ev_in = nullptr;               // throughput mode: the call's own stream starts behind what the host has put on the legacy null stream (its input buffers)
     // one slot per configuration group of the batch (groups are formed in order of first appearance, so a slot keeps its
     // streams from call to call): the job in flight, its buffers (double-buffered) and the event that marks its completion
     static constexpr int MAX_PIPE_GROUPS = 16;

@@ -1648,6 +1648,16 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
     for (int i = 0; i < n; ++i) any_vcm = any_vcm || demods[i]->cfg.acm_vcm != 0;
     if (pipe && (int)groups.size() > dvbs2gpu_ctx::MAX_PIPE_GROUPS) { last_error() = "pipelined mode handles at most 16 configuration groups per batch"; return DVBS2GPU_ERR_ARG; }
     hipStream_t st = pipe ? ctx->fe_stream : nullptr;
+    if (pipe) {
+        // The synchronous mode runs on the legacy null stream: whatever the host has put there before the call -- the kernels or copies that FILL its input buffers -- lies in
+        // front of the demodulator by itself.  The throughput mode's own stream is non-blocking: without this it READ INPUT THAT WAS STILL BEING WRITTEN whenever the host's
+        // producer had not finished (round 6, tools/stress_pipelined.py on fresh streams: a frame of a busy call came out with LDPC trials -1 and two BCH corrections where
+        // the synchronous run had 0 / 0; with streams that happened to share a hardware queue with the null stream it never showed).  Same contract in both modes now: inputs
+        // produced on the null stream are ordered; a host that fills them on a stream of its own synchronises that stream first.
+        if (!ctx->ev_in) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ctx->ev_in, nullptr));
+        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_in, 0));
+    }
     // pipelined: every job is collected through this map -- the streams of a batch may come and go and change places between calls
     BatchMap bmap;
     if (pipe) {

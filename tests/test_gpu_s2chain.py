@@ -306,6 +306,63 @@ def test_pipelined_batch_delivers_the_same_frames_one_call_later(engine, pkg):
     assert total >= S * (calls - 2) * kb
 
 
+def test_pipelined_call_waits_for_inputs_the_host_is_still_writing_on_the_null_stream(engine, pkg):
+    """throughput mode: the call runs on a non-blocking stream of its own, the host's producer of the input buffers (here torch: a long chain of kernels on the legacy
+    null stream, ending in the copy that fills the buffer the call is given) on the null stream -- the call must start behind it, as the synchronous mode does by running
+    on the null stream itself.  (Found by tools/stress_pipelined.py on fresh streams in round 6: frames of busy calls came out with LDPC trials -1 and BCH corrections
+    where the synchronous run had 0 / 0 -- the front end had read input that was still being written.)"""
+    import torch
+    S, calls = 4, 4
+    iqs = [orc.transmit(14, 1, 0, nframes=6 * calls, seed=7700 + s, esn0_db=22.0, cfo=2e-4, timing=0.1 * s, phase0=0.2)[0] for s in range(S)]
+    chunk = min(x.size for x in iqs) // calls
+    chunk -= chunk & 1
+    kb = pkg.modcod_info(14, True, False)['kbch'] // 8
+    cfg = engine.default_cfg(14, True, False)
+    dev = [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in iqs]
+    ballast = torch.zeros(64 << 20, dtype=torch.float32, device='cuda')
+    torch.cuda.synchronize()
+
+    def run(eng, pipelined):
+        demods = [eng.demod(cfg, max_samples=chunk) for _ in range(S)]
+        tout = [torch.zeros(16 * kb, dtype=torch.uint8, device='cuda') for _ in range(S)]
+        tin = [torch.zeros(chunk, dtype=torch.complex64, device='cuda') for _ in range(S)]
+        eng.set_pipelined(pipelined)
+        outs = []
+        try:
+            for c in range(calls + (1 if pipelined else 0)):
+                if c < calls:
+                    for _ in range(6):
+                        ballast.add_(1.0)                                   # ~1.5 ms of null-stream work in front of the copies ...
+                    for s in range(S):
+                        tin[s].zero_()                                      # ... which first wipe the buffers (a call that does not wait demodulates zeros / half a buffer)
+                        tin[s].copy_(dev[s][c * chunk:(c + 1) * chunk])
+                    nb = eng.process_batch(demods, tin, tout)               # (no synchronisation by the host in between)
+                else:
+                    nb = eng.process_batch(demods, [torch.empty(0, dtype=torch.complex64, device='cuda') for _ in range(S)], tout)
+                outs.append(([tout[s][:nb[s]].cpu().numpy().copy() for s in range(S)],
+                             [[(x.ldpc_trials, x.bch_corrections) for x in d.stats()] for d in demods]))
+        finally:
+            eng.set_pipelined(False)
+            for d in demods:
+                d.close()
+        return outs
+
+    sync = run(engine, False)
+    # (an engine of its own for the throughput mode: its streams are the first it creates -- streams that happen to share a hardware queue with the null stream hide the race)
+    fresh = pkg.Engine(0)
+    try:
+        pipe = run(fresh, True)
+    finally:
+        fresh.close()
+    frames = 0
+    for c in range(calls):
+        for s in range(S):
+            assert np.array_equal(pipe[c + 1][0][s], sync[c][0][s]), (c, s)
+            assert pipe[c + 1][1][s] == sync[c][1][s], (c, s)
+            frames += len(sync[c][1][s])
+    assert frames >= S * calls * 3
+
+
 def test_mixed_modcod_batch_matches_single(engine):
     """BASELINE config 4 shape: one process_batch call over transponders with DIFFERENT MODCODs (QPSK and 8PSK, normal and short
     frames): streams are grouped per configuration inside the call; every stream == its own single-stream handle"""

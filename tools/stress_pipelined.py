@@ -58,7 +58,9 @@ def run(pipelined):
                     n = int(rng_len[ci][s])
                     tin.append(dev_sig[s % len(dev_sig)][a:a + n].clone())
                     pos[s] += n
+            if os.environ.get('STRESS_INPUT_SYNC') == '1': torch.cuda.current_stream().synchronize()       # (the inputs -- torch's clones on the null stream -- complete before the call)
             nb = eng.process_batch([dms[s] for s in who], tin, [tout[s] for s in who])
+            if os.environ.get('STRESS_SYNC') == '1': torch.cuda.synchronize()       # (debugging: no FEC job of call k beside the front end of call k + 1)
             outs.append({s: (tout[s][:nb[k]].cpu().numpy().copy(), [(x.ldpc_trials, x.bch_corrections, x.detected_modcod, x.bbframe_bytes) for x in dms[s].stats()]) for k, s in enumerate(who)})
     finally:
         eng.set_pipelined(False)
@@ -69,15 +71,19 @@ def run(pipelined):
 
 # per (call, stream) sample counts, fixed for both runs: mostly whole chunks, sometimes short or empty calls
 rng_len = [[int(rng.choice([chunk, chunk, chunk, 20000, 2000, 0])) & ~1 for _ in range(S)] for _ in range(len(schedule) + 1)]
-sync = run(False)
-pipe = run(True)
+if os.environ.get('STRESS_PIPE_FIRST') == '1':      # (the pipelined run on the engine's FIRST streams: which hardware queues streams share depends on their creation order)
+    pipe = run(True)
+    sync = run(False)
+else:
+    sync = run(False)
+    pipe = run(True)
 full = schedule + [list(range(S))]
 bytes_ok = frames = dropped = 0
 for c in range(1, len(full)):
     for s in full[c]:
         if s in full[c - 1]:
             assert np.array_equal(pipe[c][s][0], sync[c - 1][s][0]), ('bytes', c, s, kinds[s])
-            assert pipe[c][s][1] == sync[c - 1][s][1], ('stats', c, s, kinds[s])
+            assert pipe[c][s][1] == sync[c - 1][s][1], ('stats', c, s, kinds[s], cfgs[s], 'pipelined', pipe[c][s][1], 'synchronous', sync[c - 1][s][1])
             bytes_ok += sync[c - 1][s][0].size; frames += len(sync[c - 1][s][1])
         else:
             assert pipe[c][s][0].size == 0 and pipe[c][s][1] == [], ('joined', c, s)
