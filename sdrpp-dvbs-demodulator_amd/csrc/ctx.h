@@ -156,7 +156,11 @@ struct dvbs2gpu_ctx {
     hipStream_t fec_part_stream = nullptr;
     hipEvent_t fec_last_done = nullptr;
     hipStream_t fec_last_stream = nullptr;
-    int fec_part = -1;                        // option fec_part: -1 by the rule, 0 never, 1 every big job of a single-configuration batch
+    // OFF BY DEFAULT since the third part of round 6: hipExtStreamCreateWithCUMask makes a BLOCKING stream, and every operation on the legacy null stream waits for the jobs on a
+    // blocking stream -- the host's own null-stream work did, and so does the event that orders a throughput-mode call behind the host's input producers
+    // (s2_demod.hip: ev_in): with the rule on, the front end of call k + 1 waited for the decoder job of call k (plugin's mode 118.7 -> 171.6 ms per step).  Without the rule
+    // the plugin's mode takes 122.5 ms (it bought 3 %); fec_part = -1 / 1 still select it for hosts that keep everything off the null stream and synchronise their inputs.
+    int fec_part = 0;                         // option fec_part: -1 by the rule, 0 never (default), 1 every big job of a single-configuration batch
     bool fec_part_on = false;
     int fec_part_trend = 0;
     std::chrono::steady_clock::time_point fec_last_entry{};
