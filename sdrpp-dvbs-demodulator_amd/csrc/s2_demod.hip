@@ -498,6 +498,9 @@ static int deliver_job(dvbs2gpu_ctx* ctx, PendingFec* job, hipStream_t st, Works
 #endif
 static int post_prio_wanted(const dvbs2gpu_ctx* ctx) { return ctx->pipeline_fec && ctx->g_prio_duty >= S2_POST_PRIO_MIN_DUTY ? 1 : 0; }
 static hipError_t create_stream(dvbs2gpu_ctx*, hipStream_t* out, int) { return hipStreamCreateWithFlags(out, hipStreamNonBlocking); }
+#ifndef S2_INPUT_EVENT
+#define S2_INPUT_EVENT 1      // (A/B switch, timing only: 0 = the throughput mode does not wait for the host's null-stream work -- the race of round 6)
+#endif
 #ifndef S2_MIN_SLICE_SAMPLES
 #define S2_MIN_SLICE_SAMPLES 1024     // a time slice holds at least this many samples per stream (a call of a few thousand samples is not cut into 32 slices of 133 launches)
 #endif
@@ -1648,7 +1651,7 @@ int dvbs2gpu_demod_process_batch(dvbs2gpu_demod* const* demods, int n, const flo
     for (int i = 0; i < n; ++i) any_vcm = any_vcm || demods[i]->cfg.acm_vcm != 0;
     if (pipe && (int)groups.size() > dvbs2gpu_ctx::MAX_PIPE_GROUPS) { last_error() = "pipelined mode handles at most 16 configuration groups per batch"; return DVBS2GPU_ERR_ARG; }
     hipStream_t st = pipe ? ctx->fe_stream : nullptr;
-    if (pipe) {
+    if (pipe && S2_INPUT_EVENT) {
         // The synchronous mode runs on the legacy null stream: whatever the host has put there before the call -- the kernels or copies that FILL its input buffers -- lies in
         // front of the demodulator by itself.  The throughput mode's own stream is non-blocking: without this it READ INPUT THAT WAS STILL BEING WRITTEN whenever the host's
         // producer had not finished (round 6, tools/stress_pipelined.py on fresh streams: a frame of a busy call came out with LDPC trials -1 and two BCH corrections where
